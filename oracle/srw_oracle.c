@@ -1,0 +1,637 @@
+/*
+ * srw_oracle.c — CPU restatement (plain C) of the reference's random-walk hot path.
+ * TEST INFRASTRUCTURE ONLY — see srw_oracle.h.  Parity pinned against the reference's own
+ * known-answer tests (tests/test_oracle_reference_vectors.py).
+ *
+ * Compile with -O2 -ffp-contract=off -fno-fast-math: the f64 accumulation order below IS the spec.
+ */
+#define _GNU_SOURCE
+#include "srw_oracle.h"
+
+#include <errno.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+/* ============================================================================================ */
+/* RNG                                                                                          */
+/* ============================================================================================ */
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+float orc_walk_uniform(uint32_t seed, uint32_t iter, uint32_t src, uint32_t step) {
+  uint32_t ctr[4] = {iter, src, step, 0u}, key[2] = {seed, 0u}, out[4];
+  orc_philox4x32_10(ctr, key, out);
+  return (float)(out[0] >> 8) * (1.0f / 16777216.0f); /* exact: 24-bit integer * 2^-24 */
+}
+
+void orc_java_random_floats(int64_t seed, int n, float *out) {
+  uint64_t s = ((uint64_t)seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1);
+  for (int i = 0; i < n; ++i) {
+    s = (s * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+    out[i] = (float)(uint32_t)(s >> 24) / (float)(1 << 24);
+  }
+}
+
+/* ============================================================================================ */
+/* Sampler — M/algorithm/RandomSample.scala                                                     */
+/* ============================================================================================ */
+
+/* RandomSample.sample, RandomSample.scala:12-25.
+ *   :14  sum = foldLeft(0.0)(w1 + w2)      left-to-right, Double accumulator, Float widened
+ *   :16  p = nextFloat()                   (the caller supplies r)
+ *   :18-22 acc += w / sum ; first acc >= p  (Float/Double -> f64 divide, f64 add, f64 compare)
+ *   :24  edges.head                         fallback */
+int64_t orc_sample_index(const float *w, int64_t n, float r) {
+  if (n <= 0) return -1;
+  double sum = 0.0;
+  for (int64_t k = 0; k < n; ++k) sum = sum + (double)w[k];
+  double p = (double)r;
+  double acc = 0.0;
+  for (int64_t k = 0; k < n; ++k) {
+    acc += (double)w[k] / sum;
+    if (acc >= p) return k;
+  }
+  return 0;
+}
+
+/* RandomSample.computeSecondOrderWeights, RandomSample.scala:27-44 — linear `exists`, f32 divides. */
+void orc_second_order_weights(float p, float q, int32_t prev_id, const int32_t *prev_ids, int64_t n_prev,
+                              const int32_t *curr_ids, const float *curr_w, int64_t n, float *out_w) {
+  for (int64_t k = 0; k < n; ++k) {
+    int32_t dst = curr_ids[k];
+    float w = curr_w[k];
+    float unnorm = w / q;                 /* :33 */
+    if (dst == prev_id) {
+      unnorm = w / p;                     /* :35 */
+    } else {
+      for (int64_t j = 0; j < n_prev; ++j) /* :37 prevNeighbors.exists(_._1 == dstId) */
+        if (prev_ids[j] == dst) { unnorm = w; break; }
+    }
+    out_w[k] = unnorm;
+  }
+}
+
+int64_t orc_second_order_sample_index(float p, float q, int32_t prev_id, const int32_t *prev_ids,
+                                      int64_t n_prev, const int32_t *curr_ids, const float *curr_w,
+                                      int64_t n, float r) {
+  if (n <= 0) return -1;
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)n);
+  orc_second_order_weights(p, q, prev_id, prev_ids, n_prev, curr_ids, curr_w, n, tmp);
+  int64_t k = orc_sample_index(tmp, n, r);
+  free(tmp);
+  return k;
+}
+
+/* ============================================================================================ */
+/* GraphMap — M/algorithm/GraphMap.scala                                                        */
+/* ============================================================================================ */
+
+typedef struct { int32_t key; int32_t val; uint8_t used; } imap_slot;
+typedef struct { imap_slot *s; int64_t cap, n; } imap;
+
+static void imap_init(imap *m) { m->cap = 64; m->n = 0; m->s = (imap_slot *)calloc((size_t)m->cap, sizeof(imap_slot)); }
+static void imap_free(imap *m) { free(m->s); m->s = NULL; m->cap = m->n = 0; }
+static uint64_t imap_hash(int32_t k) { uint64_t x = (uint32_t)k; x *= 0x9E3779B97F4A7C15ULL; return x >> 20; }
+static imap_slot *imap_find(const imap *m, int32_t k) {
+  uint64_t i = imap_hash(k) & (uint64_t)(m->cap - 1);
+  while (m->s[i].used) { if (m->s[i].key == k) return &m->s[i]; i = (i + 1) & (uint64_t)(m->cap - 1); }
+  return NULL;
+}
+static void imap_put(imap *m, int32_t k, int32_t v);
+static void imap_grow(imap *m) {
+  imap old = *m;
+  m->cap = old.cap * 2; m->n = 0; m->s = (imap_slot *)calloc((size_t)m->cap, sizeof(imap_slot));
+  for (int64_t i = 0; i < old.cap; ++i) if (old.s[i].used) imap_put(m, old.s[i].key, old.s[i].val);
+  free(old.s);
+}
+static void imap_put(imap *m, int32_t k, int32_t v) {
+  if ((m->n + 1) * 2 > m->cap) imap_grow(m);
+  uint64_t i = imap_hash(k) & (uint64_t)(m->cap - 1);
+  while (m->s[i].used) { if (m->s[i].key == k) { m->s[i].val = v; return; } i = (i + 1) & (uint64_t)(m->cap - 1); }
+  m->s[i].used = 1; m->s[i].key = k; m->s[i].val = v; m->n++;
+}
+
+struct orc_graphmap {
+  imap src_vertex_map;        /* srcVertexMap: id -> row index, -1 = no out-edges (GraphMap.scala:13) */
+  imap vertex_partition_map;  /* vertexPartitionMap (:21) */
+  int32_t *offsets, *lengths; /* :14-15 */
+  int64_t rows_cap;
+  int32_t *edge_ids; float *edge_w; /* edges (:16) */
+  int64_t edges_cap;
+  int32_t index_counter, offset_counter; /* :17-18 */
+};
+
+orc_graphmap *orc_graphmap_new(void) {
+  orc_graphmap *g = (orc_graphmap *)calloc(1, sizeof(*g));
+  imap_init(&g->src_vertex_map); imap_init(&g->vertex_partition_map);
+  return g;
+}
+void orc_graphmap_free(orc_graphmap *g) {
+  if (!g) return;
+  imap_free(&g->src_vertex_map); imap_free(&g->vertex_partition_map);
+  free(g->offsets); free(g->lengths); free(g->edge_ids); free(g->edge_w); free(g);
+}
+void orc_graphmap_reset(orc_graphmap *g) { /* GraphMap.reset :98-107 */
+  imap_free(&g->src_vertex_map); imap_free(&g->vertex_partition_map);
+  imap_init(&g->src_vertex_map); imap_init(&g->vertex_partition_map);
+  g->index_counter = 0; g->offset_counter = 0;
+}
+static void gm_update_indices(orc_graphmap *g, int32_t v, int64_t out_degree) { /* updateIndices :58-64 */
+  if (g->index_counter + 1 > g->rows_cap) {
+    g->rows_cap = g->rows_cap ? g->rows_cap * 2 : 64;
+    g->offsets = (int32_t *)realloc(g->offsets, sizeof(int32_t) * (size_t)g->rows_cap);
+    g->lengths = (int32_t *)realloc(g->lengths, sizeof(int32_t) * (size_t)g->rows_cap);
+  }
+  imap_put(&g->src_vertex_map, v, g->index_counter);
+  g->offsets[g->index_counter] = g->offset_counter;
+  g->lengths[g->index_counter] = (int32_t)out_degree;
+  g->index_counter++;
+}
+static void gm_push_edge(orc_graphmap *g, int32_t dst, float w) {
+  if (g->offset_counter + 1 > g->edges_cap) {
+    g->edges_cap = g->edges_cap ? g->edges_cap * 2 : 256;
+    g->edge_ids = (int32_t *)realloc(g->edge_ids, sizeof(int32_t) * (size_t)g->edges_cap);
+    g->edge_w = (float *)realloc(g->edge_w, sizeof(float) * (size_t)g->edges_cap);
+  }
+  g->edge_ids[g->offset_counter] = dst; g->edge_w[g->offset_counter] = w; g->offset_counter++;
+}
+void orc_graphmap_add_vertex_p(orc_graphmap *g, int32_t v, const int32_t *ids, const int32_t *pids,
+                               const float *w, int64_t n) {
+  if (imap_find(&g->src_vertex_map, v)) return;             /* case Some(value) => value (:37,:54) */
+  if (n > 0) {
+    gm_update_indices(g, v, n);
+    for (int64_t k = 0; k < n; ++k) {
+      gm_push_edge(g, ids[k], w[k]);
+      if (pids) imap_put(&g->vertex_partition_map, ids[k], pids[k]); /* :31 */
+    }
+  } else {
+    imap_put(&g->src_vertex_map, v, -1);                     /* addVertex(vId) :83-85 */
+  }
+}
+void orc_graphmap_add_vertex(orc_graphmap *g, int32_t v, const int32_t *ids, const float *w, int64_t n) {
+  orc_graphmap_add_vertex_p(g, v, ids, NULL, w, n);
+}
+int64_t orc_graphmap_num_vertices(const orc_graphmap *g) { return g->src_vertex_map.n; }
+int64_t orc_graphmap_num_edges(const orc_graphmap *g) { return g->offset_counter; }
+int64_t orc_graphmap_get_neighbors(const orc_graphmap *g, int32_t v, int32_t *ids, float *w, int64_t cap) {
+  imap_slot *s = imap_find(&g->src_vertex_map, v);
+  if (!s) return -1;            /* case None => null */
+  if (s->val == -1) return 0;   /* Array.empty */
+  int64_t off = g->offsets[s->val], len = g->lengths[s->val];
+  for (int64_t k = 0; k < len && k < cap; ++k) {
+    if (ids) ids[k] = g->edge_ids[off + k];
+    if (w) w[k] = g->edge_w[off + k];
+  }
+  return len;
+}
+int orc_graphmap_get_partition(const orc_graphmap *g, int32_t v, int32_t *pid) {
+  imap_slot *s = imap_find(&g->vertex_partition_map, v);
+  if (!s) return 0;
+  *pid = s->val; return 1;
+}
+
+/* ============================================================================================ */
+/* Edge-list parsing — UniformRandomWalk.scala:23-43, VCutRandomWalk.scala:19-41                */
+/* ============================================================================================ */
+
+static int java_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == 0x0B || c == '\f' || c == '\r'; }
+
+/* java.lang.Integer.parseInt on [s, s+n): 1 ok, 0 NumberFormatException */
+static int java_parse_int(const char *s, size_t n, int32_t *out) {
+  if (n == 0) return 0;
+  size_t i = 0; int neg = 0;
+  if (s[0] == '-' || s[0] == '+') { neg = (s[0] == '-'); i = 1; if (n == 1) return 0; }
+  int64_t v = 0;
+  for (; i < n; ++i) {
+    if (s[i] < '0' || s[i] > '9') return 0;
+    v = v * 10 + (s[i] - '0');
+    if (v > 2147483648LL) return 0;
+  }
+  if (neg) v = -v;
+  if (v > 2147483647LL || v < -2147483648LL) return 0;
+  *out = (int32_t)v; return 1;
+}
+
+/* java.lang.Float.parseFloat on [s, s+n) (already whitespace-free): 1 ok, 0 NumberFormatException.
+ * Grammar: [sign] (NaN | Infinity | HexFloat | Decimal) with optional f/F/d/D suffix; conversion is
+ * correctly rounded to binary32 (glibc strtof). */
+static int java_parse_float(const char *s, size_t n, float *out) {
+  char buf[128];
+  if (n == 0 || n >= sizeof(buf) - 1) return 0;
+  size_t i = 0;
+  int neg = 0;
+  if (s[i] == '+' || s[i] == '-') { neg = (s[i] == '-'); ++i; }
+  if (i >= n) return 0;
+  if (n - i == 3 && memcmp(s + i, "NaN", 3) == 0) { *out = NAN; return 1; }
+  if (n - i == 8 && memcmp(s + i, "Infinity", 8) == 0) { *out = neg ? -INFINITY : INFINITY; return 1; }
+  size_t end = n;
+  int hex = (n - i >= 2 && s[i] == '0' && (s[i + 1] == 'x' || s[i + 1] == 'X'));
+  if (end > i && (s[end - 1] == 'f' || s[end - 1] == 'F' || s[end - 1] == 'd' || s[end - 1] == 'D')) {
+    if (!hex) end--;            /* in a hex literal a trailing d/f before 'p' is a digit; after the */
+    else {                      /* exponent it is a suffix */
+      size_t pp = i; int seen_p = 0;
+      for (; pp < end; ++pp) if (s[pp] == 'p' || s[pp] == 'P') { seen_p = 1; break; }
+      if (seen_p) end--;
+    }
+  }
+  size_t j = i;
+  if (hex) {
+    j += 2; int digits = 0;
+    while (j < end && ((s[j] >= '0' && s[j] <= '9') || (s[j] >= 'a' && s[j] <= 'f') || (s[j] >= 'A' && s[j] <= 'F'))) { ++j; ++digits; }
+    if (j < end && s[j] == '.') { ++j; while (j < end && ((s[j] >= '0' && s[j] <= '9') || (s[j] >= 'a' && s[j] <= 'f') || (s[j] >= 'A' && s[j] <= 'F'))) { ++j; ++digits; } }
+    if (!digits) return 0;
+    if (j >= end || (s[j] != 'p' && s[j] != 'P')) return 0; /* binary exponent is mandatory in Java */
+    ++j; if (j < end && (s[j] == '+' || s[j] == '-')) ++j;
+    int ed = 0; while (j < end && s[j] >= '0' && s[j] <= '9') { ++j; ++ed; }
+    if (!ed || j != end) return 0;
+  } else {
+    int digits = 0;
+    while (j < end && s[j] >= '0' && s[j] <= '9') { ++j; ++digits; }
+    if (j < end && s[j] == '.') { ++j; while (j < end && s[j] >= '0' && s[j] <= '9') { ++j; ++digits; } }
+    if (!digits) return 0;
+    if (j < end && (s[j] == 'e' || s[j] == 'E')) {
+      ++j; if (j < end && (s[j] == '+' || s[j] == '-')) ++j;
+      int ed = 0; while (j < end && s[j] >= '0' && s[j] <= '9') { ++j; ++ed; }
+      if (!ed) return 0;
+    }
+    if (j != end) return 0;
+  }
+  memcpy(buf, s, end); buf[end] = 0;
+  char *ep = NULL;
+  float v = strtof(buf, &ep);
+  if (ep != buf + end) return 0;
+  *out = v; return 1;
+}
+
+typedef struct { int32_t *src, *dst, *pid; float *w; int64_t n, cap; } line_vec;
+static void lv_push(line_vec *v, int32_t s, int32_t d, float w, int32_t pid) {
+  if (v->n == v->cap) {
+    v->cap = v->cap ? v->cap * 2 : 1024;
+    v->src = (int32_t *)realloc(v->src, sizeof(int32_t) * (size_t)v->cap);
+    v->dst = (int32_t *)realloc(v->dst, sizeof(int32_t) * (size_t)v->cap);
+    v->pid = (int32_t *)realloc(v->pid, sizeof(int32_t) * (size_t)v->cap);
+    v->w = (float *)realloc(v->w, sizeof(float) * (size_t)v->cap);
+  }
+  v->src[v->n] = s; v->dst[v->n] = d; v->w[v->n] = w; v->pid[v->n] = pid; v->n++;
+}
+
+/* One text line -> (src, dst, weight, pId).  Returns 0 and fills err where the reference throws. */
+static int parse_line(const char *s, size_t n, int weighted, int partitioned, int64_t lineno,
+                      int32_t *src, int32_t *dst, float *w, int32_t *pid, char *err, size_t errlen) {
+  /* Java String.split("\\s+"): a separator at index 0 yields a leading "" token; trailing empty
+   * tokens are dropped. */
+  enum { MAXP = 64 };
+  const char *tok[MAXP]; size_t len[MAXP]; int np = 0;
+  size_t i = 0;
+  if (n == 0) { tok[0] = s; len[0] = 0; np = 1; }           /* "".split -> [""] */
+  else {
+    if (java_ws((unsigned char)s[0])) { tok[np] = s; len[np] = 0; np++; }
+    while (i < n) {
+      while (i < n && java_ws((unsigned char)s[i])) ++i;
+      if (i >= n) break;
+      size_t b = i;
+      while (i < n && !java_ws((unsigned char)s[i])) ++i;
+      if (np < MAXP) { tok[np] = s + b; len[np] = i - b; np++; }
+      else { tok[MAXP - 1] = s + b; len[MAXP - 1] = i - b; } /* keep "last" meaningful */
+    }
+    if (np == 1 && len[0] == 0) np = 0;                      /* all-whitespace line -> [] */
+  }
+  if (np < 2) { snprintf(err, errlen, "line %lld: fewer than two columns", (long long)lineno); return 0; }
+  /* weight: UniformRandomWalk.scala:29-32 / VCutRandomWalk.scala:29-32 */
+  *w = 1.0f;
+  int wcols = partitioned ? 3 : 2;
+  if (weighted && np > wcols) { float f; if (java_parse_float(tok[np - 1], len[np - 1], &f)) *w = f; }
+  /* pId: VCutRandomWalk.scala:23-26 (a missing/unparsable pId is Random.nextInt there; -1 here) */
+  *pid = -1;
+  if (partitioned && np > 2) { int32_t pv; if (java_parse_int(tok[2], len[2], &pv)) *pid = pv; }
+  /* ids: UniformRandomWalk.scala:34 */
+  if (!java_parse_int(tok[0], len[0], src) || !java_parse_int(tok[1], len[1], dst)) {
+    snprintf(err, errlen, "line %lld: NumberFormatException for vertex id", (long long)lineno); return 0;
+  }
+  return 1;
+}
+
+struct orc_graph {
+  int64_t n_lines; int32_t *l_src, *l_dst, *l_pid; float *l_w;
+  int32_t vmin, vmax; int64_t n_slots;
+  uint8_t *present; int64_t *off; /* n_slots + 1 */
+  int32_t *ids; float *w; int32_t *sorted_ids;
+  int64_t n_entries, n_vertices;
+};
+
+static int cmp_i32(const void *a, const void *b) { int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return (x > y) - (x < y); }
+
+/* Adjacency of v = concatenation, in line order, of every line's contribution to v
+ * (UniformRandomWalk.scala:35-41: flatMap then reduceByKey(_ ++ _); canonical order). */
+static orc_graph *graph_build(line_vec *lv, int directed) {
+  orc_graph *g = (orc_graph *)calloc(1, sizeof(*g));
+  g->n_lines = lv->n; g->l_src = lv->src; g->l_dst = lv->dst; g->l_pid = lv->pid; g->l_w = lv->w;
+  if (lv->n == 0) { g->vmin = 0; g->vmax = -1; g->n_slots = 0; g->off = (int64_t *)calloc(1, sizeof(int64_t)); return g; }
+  int32_t vmin = lv->src[0], vmax = lv->src[0];
+  for (int64_t i = 0; i < lv->n; ++i) {
+    if (lv->src[i] < vmin) vmin = lv->src[i]; if (lv->src[i] > vmax) vmax = lv->src[i];
+    if (lv->dst[i] < vmin) vmin = lv->dst[i]; if (lv->dst[i] > vmax) vmax = lv->dst[i];
+  }
+  g->vmin = vmin; g->vmax = vmax; g->n_slots = (int64_t)vmax - (int64_t)vmin + 1;
+  g->present = (uint8_t *)calloc((size_t)g->n_slots, 1);
+  g->off = (int64_t *)calloc((size_t)g->n_slots + 1, sizeof(int64_t));
+  for (int64_t i = 0; i < lv->n; ++i) {
+    int64_t s = (int64_t)lv->src[i] - vmin, d = (int64_t)lv->dst[i] - vmin;
+    g->present[s] = 1; g->present[d] = 1;
+    g->off[s + 1]++;
+    if (!directed) g->off[d + 1]++;
+  }
+  for (int64_t v = 0; v < g->n_slots; ++v) { g->off[v + 1] += g->off[v]; g->n_vertices += g->present[v]; }
+  g->n_entries = g->off[g->n_slots];
+  g->ids = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->n_entries ? g->n_entries : 1));
+  g->w = (float *)malloc(sizeof(float) * (size_t)(g->n_entries ? g->n_entries : 1));
+  int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)g->n_slots);
+  memcpy(cur, g->off, sizeof(int64_t) * (size_t)g->n_slots);
+  for (int64_t i = 0; i < lv->n; ++i) {
+    int64_t s = (int64_t)lv->src[i] - vmin, d = (int64_t)lv->dst[i] - vmin;
+    g->ids[cur[s]] = lv->dst[i]; g->w[cur[s]] = lv->w[i]; cur[s]++;          /* (src, [(dst, w)]) */
+    if (!directed) { g->ids[cur[d]] = lv->src[i]; g->w[cur[d]] = lv->w[i]; cur[d]++; } /* (dst, [(src, w)]) */
+  }
+  free(cur);
+  g->sorted_ids = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->n_entries ? g->n_entries : 1));
+  memcpy(g->sorted_ids, g->ids, sizeof(int32_t) * (size_t)g->n_entries);
+  for (int64_t v = 0; v < g->n_slots; ++v)
+    qsort(g->sorted_ids + g->off[v], (size_t)(g->off[v + 1] - g->off[v]), sizeof(int32_t), cmp_i32);
+  return g;
+}
+
+orc_graph *orc_graph_from_coo(const int32_t *src, const int32_t *dst, const float *w, int64_t n_lines, int directed) {
+  line_vec lv; memset(&lv, 0, sizeof(lv));
+  for (int64_t i = 0; i < n_lines; ++i) lv_push(&lv, src[i], dst[i], w ? w[i] : 1.0f, -1);
+  return graph_build(&lv, directed);
+}
+
+orc_graph *orc_graph_load_edgelist(const char *path, int directed, int weighted, int partitioned,
+                                   char *err, size_t errlen) {
+  char ebuf[256]; if (!err) { err = ebuf; errlen = sizeof(ebuf); }
+  err[0] = 0;
+  FILE *f = fopen(path, "rb");
+  if (!f) { snprintf(err, errlen, "cannot open %s: %s", path, strerror(errno)); return NULL; }
+  fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+  char *buf = (char *)malloc((size_t)sz + 1);
+  if (sz > 0 && fread(buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(buf); snprintf(err, errlen, "read error"); return NULL; }
+  fclose(f);
+  line_vec lv; memset(&lv, 0, sizeof(lv));
+  /* Hadoop LineRecordReader: a line ends at \n, \r\n or a lone \r; a final unterminated line counts. */
+  size_t pos = 0; int64_t lineno = 0;
+  while (pos < (size_t)sz) {
+    size_t b = pos;
+    while (pos < (size_t)sz && buf[pos] != '\n' && buf[pos] != '\r') ++pos;
+    size_t e = pos;
+    if (pos < (size_t)sz) { if (buf[pos] == '\r' && pos + 1 < (size_t)sz && buf[pos + 1] == '\n') pos += 2; else pos += 1; }
+    ++lineno;
+    int32_t s, d, pid; float w;
+    if (!parse_line(buf + b, e - b, weighted, partitioned, lineno, &s, &d, &w, &pid, err, errlen)) {
+      free(buf); free(lv.src); free(lv.dst); free(lv.pid); free(lv.w); return NULL;
+    }
+    lv_push(&lv, s, d, w, pid);
+  }
+  free(buf);
+  return graph_build(&lv, directed);
+}
+
+void orc_graph_free(orc_graph *g) {
+  if (!g) return;
+  free(g->l_src); free(g->l_dst); free(g->l_pid); free(g->l_w);
+  free(g->present); free(g->off); free(g->ids); free(g->w); free(g->sorted_ids); free(g);
+}
+int64_t orc_graph_num_vertices(const orc_graph *g) { return g->n_vertices; }
+int64_t orc_graph_num_entries(const orc_graph *g) { return g->n_entries; }
+int64_t orc_graph_num_lines(const orc_graph *g) { return g->n_lines; }
+void orc_graph_vertices(const orc_graph *g, int32_t *out) {
+  int64_t k = 0;
+  for (int64_t v = 0; v < g->n_slots; ++v) if (g->present[v]) out[k++] = (int32_t)(v + g->vmin);
+}
+static inline int64_t slot_of(const orc_graph *g, int32_t v) {
+  if (g->n_slots == 0 || v < g->vmin || v > g->vmax) return -1;
+  int64_t s = (int64_t)v - g->vmin;
+  return g->present[s] ? s : -1;
+}
+int64_t orc_graph_degree(const orc_graph *g, int32_t v) {
+  int64_t s = slot_of(g, v); if (s < 0) return -1; return g->off[s + 1] - g->off[s];
+}
+int64_t orc_graph_neighbors(const orc_graph *g, int32_t v, int32_t *ids, float *w, int64_t cap) {
+  int64_t s = slot_of(g, v); if (s < 0) return -1;
+  int64_t n = g->off[s + 1] - g->off[s];
+  for (int64_t k = 0; k < n && k < cap; ++k) { if (ids) ids[k] = g->ids[g->off[s] + k]; if (w) w[k] = g->w[g->off[s] + k]; }
+  return n;
+}
+void orc_graph_lines(const orc_graph *g, int32_t *src, int32_t *dst, float *w, int32_t *pid) {
+  for (int64_t i = 0; i < g->n_lines; ++i) {
+    if (src) src[i] = g->l_src[i]; if (dst) dst[i] = g->l_dst[i];
+    if (w) w[i] = g->l_w[i]; if (pid) pid[i] = g->l_pid[i];
+  }
+}
+
+/* ============================================================================================ */
+/* Walk — RandomWalk.scala:51-66 (first step), :95-139 (second-order loop)                      */
+/* ============================================================================================ */
+
+static inline float draw(const orc_walk_params *P, uint32_t iter, int32_t src, uint32_t step) {
+  return P->rng_mode == ORC_RNG_CONST ? P->const_r : orc_walk_uniform(P->seed, iter, (uint32_t)src, step);
+}
+
+static int sorted_contains(const int32_t *a, int64_t n, int32_t x) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { int64_t mid = lo + ((hi - lo) >> 1); if (a[mid] < x) lo = mid + 1; else hi = mid; }
+  return lo < n && a[lo] == x;
+}
+
+/* secondOrderSample on CSR rows.  faithful: literally computeSecondOrderWeights + sample on a
+ * scratch array (linear exists).  fast: same arithmetic, membership by binary search. */
+static int64_t second_order_pick(const orc_graph *g, const orc_walk_params *P, int32_t prev, int64_t ps,
+                                 int64_t cs, float r, float *scratch) {
+  const int32_t *cid = g->ids + g->off[cs]; const float *cw = g->w + g->off[cs];
+  int64_t n = g->off[cs + 1] - g->off[cs];
+  int64_t np = g->off[ps + 1] - g->off[ps];
+  if (P->faithful) {
+    orc_second_order_weights(P->p, P->q, prev, g->ids + g->off[ps], np, cid, cw, n, scratch);
+  } else {
+    const int32_t *sp = g->sorted_ids + g->off[ps];
+    for (int64_t k = 0; k < n; ++k) {
+      float w = cw[k], u = w / P->q;
+      if (cid[k] == prev) u = w / P->p; else if (sorted_contains(sp, np, cid[k])) u = w;
+      scratch[k] = u;
+    }
+  }
+  return orc_sample_index(scratch, n, r);
+}
+
+static int32_t walk_one(const orc_graph *g, const orc_walk_params *P, int32_t src, uint32_t iter,
+                        int32_t *path, float **scratch, int64_t *scratch_cap) {
+  int32_t L2 = P->walk_length + 2;
+  int32_t len = 0;
+  path[len++] = src;
+  int64_t cs = slot_of(g, src);
+  if (cs < 0) return len;
+  int64_t n = g->off[cs + 1] - g->off[cs];
+  if (n == 0) return len;                                       /* dead end, RandomWalk.scala:59-62 */
+  int64_t k = orc_sample_index(g->w + g->off[cs], n, draw(P, iter, src, 1)); /* :57 */
+  int32_t prev = src; int64_t ps = cs;
+  int32_t curr = g->ids[g->off[cs] + k];
+  path[len++] = curr;
+  while (len != L2) {                                           /* :103 */
+    cs = slot_of(g, curr);
+    n = g->off[cs + 1] - g->off[cs];
+    if (n == 0) break;                                          /* :115-120 */
+    if (n > *scratch_cap) { *scratch_cap = n * 2; *scratch = (float *)realloc(*scratch, sizeof(float) * (size_t)*scratch_cap); }
+    k = second_order_pick(g, P, prev, ps, cs, draw(P, iter, src, (uint32_t)len), *scratch); /* :112-113 */
+    prev = curr; ps = cs;
+    curr = g->ids[g->off[cs] + k];
+    path[len++] = curr;                                         /* :114 */
+  }
+  return len;
+}
+
+int32_t orc_seq_walk(const orc_graph *g, int32_t src, int32_t iter, const orc_walk_params *P, int32_t *out_path) {
+  /* T/UniformRandomWalkTest.scala:293-321 (doSecondOrderRandomWalk): first-order step, then
+   * walkLength second-order steps with getNeighbors(prev) re-read each time. */
+  orc_walk_params Q = *P; Q.faithful = 1;
+  float *scratch = NULL; int64_t cap = 0;
+  int32_t len = 0;
+  out_path[len++] = src;
+  int64_t n = orc_graph_degree(g, src);
+  if (n <= 0) return len;
+  {
+    int64_t s = slot_of(g, src);
+    int64_t k = orc_sample_index(g->w + g->off[s], n, draw(&Q, (uint32_t)iter, src, 1));
+    out_path[len++] = g->ids[g->off[s] + k];
+  }
+  for (int32_t t = 0; t < P->walk_length; ++t) {
+    int32_t curr = out_path[len - 1], prev = out_path[len - 2];
+    int64_t cs = slot_of(g, curr), ps = slot_of(g, prev);
+    int64_t cn = g->off[cs + 1] - g->off[cs];
+    if (cn <= 0) break;
+    if (cn > cap) { cap = cn * 2; scratch = (float *)realloc(scratch, sizeof(float) * (size_t)cap); }
+    int64_t k = second_order_pick(g, &Q, prev, ps, cs, draw(&Q, (uint32_t)iter, src, (uint32_t)len), scratch);
+    out_path[len++] = g->ids[g->off[cs] + k];
+  }
+  free(scratch);
+  return len;
+}
+
+typedef struct {
+  const orc_graph *g; const orc_walk_params *P; const int32_t *starts; int64_t n_starts;
+  int32_t *paths, *lens; int tid, nthreads; int64_t steps;
+} walk_job;
+
+static void *walk_thread(void *arg) {
+  walk_job *J = (walk_job *)arg;
+  const orc_walk_params *P = J->P;
+  int32_t L2 = P->walk_length + 2;
+  float *scratch = NULL; int64_t cap = 0; int64_t steps = 0;
+  int64_t total = (int64_t)P->num_walks * J->n_starts;
+  for (int64_t wi = J->tid; wi < total; wi += J->nthreads) {
+    int64_t it = wi / J->n_starts, vi = wi % J->n_starts;
+    int32_t *path = J->paths + wi * L2;
+    for (int32_t t = 0; t < L2; ++t) path[t] = -1;
+    int32_t len = walk_one(J->g, P, J->starts[vi], (uint32_t)(P->first_walk + it), path, &scratch, &cap);
+    J->lens[wi] = len; steps += len - 1;
+  }
+  free(scratch);
+  J->steps = steps;
+  return NULL;
+}
+
+int64_t orc_walk(const orc_graph *g, const orc_walk_params *P, const int32_t *sources, int64_t n_sources,
+                 int32_t *paths, int32_t *lens) {
+  int32_t *all = NULL;
+  if (!sources) {
+    n_sources = g->n_vertices;
+    all = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_sources ? n_sources : 1));
+    orc_graph_vertices(g, all); sources = all;
+  }
+  int nt = P->threads > 0 ? P->threads : 1;
+  if (nt > 256) nt = 256;
+  walk_job jobs[256]; pthread_t th[256];
+  for (int t = 0; t < nt; ++t) {
+    jobs[t] = (walk_job){g, P, sources, n_sources, paths, lens, t, nt, 0};
+    if (nt > 1) pthread_create(&th[t], NULL, walk_thread, &jobs[t]); else walk_thread(&jobs[t]);
+  }
+  int64_t steps = 0;
+  for (int t = 0; t < nt; ++t) { if (nt > 1) pthread_join(th[t], NULL); steps += jobs[t].steps; }
+  free(all);
+  return steps;
+}
+
+/* ============================================================================================ */
+/* Writer — RandomWalk.scala:234-241 (path.mkString("\t"), saveAsTextFile(output/path))         */
+/* ============================================================================================ */
+
+int orc_write_paths(const int32_t *paths, const int32_t *lens, int64_t n_walkers, int64_t stride,
+                    const char *output_dir, int n_parts) {
+  char dir[4096], fn[4200];
+  mkdir(output_dir, 0777);
+  snprintf(dir, sizeof(dir), "%s/path", output_dir);
+  if (mkdir(dir, 0777) != 0) return -1;   /* FileAlreadyExistsException in the reference */
+  if (n_parts < 1) n_parts = 1;
+  int64_t per = (n_walkers + n_parts - 1) / n_parts;
+  for (int part = 0; part < n_parts; ++part) {
+    snprintf(fn, sizeof(fn), "%s/part-%05d", dir, part);
+    FILE *f = fopen(fn, "wb"); if (!f) return -2;
+    int64_t b = part * per, e = b + per; if (e > n_walkers) e = n_walkers;
+    for (int64_t wI = b; wI < e; ++wI) {
+      for (int32_t t = 0; t < lens[wI]; ++t) fprintf(f, t ? "\t%d" : "%d", paths[wI * stride + t]);
+      fputc('\n', f);
+    }
+    fclose(f);
+  }
+  snprintf(fn, sizeof(fn), "%s/_SUCCESS", dir);
+  FILE *f = fopen(fn, "wb"); if (!f) return -2; fclose(f);
+  return 0;
+}
+
+/* ============================================================================================ */
+/* Synthetic RMAT (a,b,c,d) = (.57,.19,.19,.05) — build-defined, shared with the HIP generator  */
+/* ============================================================================================ */
+
+void orc_rmat_edges(int scale, uint32_t seed, int64_t first, int64_t count, int32_t *src, int32_t *dst) {
+  const uint32_t T1 = 2448131358u, T2 = 3264175144u, T3 = 4080218930u; /* floor(.57,.76,.95 * 2^32) */
+  for (int64_t i = 0; i < count; ++i) {
+    uint64_t e = (uint64_t)(first + i);
+    uint32_t s = 0, d = 0, out[4] = {0, 0, 0, 0};
+    for (int l = 0; l < scale; ++l) {
+      if ((l & 3) == 0) {
+        uint32_t ctr[4] = {(uint32_t)e, (uint32_t)(e >> 32), (uint32_t)(l >> 2), 0x524D4154u};
+        uint32_t key[2] = {seed, 1u};
+        orc_philox4x32_10(ctr, key, out);
+      }
+      uint32_t x = out[l & 3];
+      uint32_t rb = (x >= T2), cb = (x >= T1 && x < T2) || (x >= T3);
+      s = (s << 1) | rb; d = (d << 1) | cb;
+    }
+    src[i] = (int32_t)s; dst[i] = (int32_t)d;
+  }
+}
+
+float orc_rmat_weight(int32_t u, int32_t v, uint32_t seed) {
+  uint32_t a = (uint32_t)(u < v ? u : v), b = (uint32_t)(u < v ? v : u);
+  uint32_t x = b * 0x85EBCA77u;
+  uint32_t h = seed ^ (a * 0x9E3779B1u) ^ ((x << 13) | (x >> 19));
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return (float)(1u + (h & 15u));
+}

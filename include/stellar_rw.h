@@ -1,0 +1,185 @@
+/*
+ * stellar_rw.h — C ABI of libstellar_rw.so, the MI355X-native (gfx950) engine behind the
+ * `--cmd randomwalk` path of data61/stellar-random-walk.
+ *
+ * The reference has no FFI of its own (it is 100 % Scala on Spark); its seams for this path are the
+ * Scala-level interfaces cited next to each entry point below.  A JNI shim
+ * (Java_au_csiro_data61_randomwalk_algorithm_HipRandomWalk_*) binds exactly these functions — see
+ * INTEGRATION.md.  Paths: M/ = randomwalk/src/main/scala/au/csiro/data61/randomwalk/.
+ *
+ * Conventions: plain C, no exceptions cross the boundary; every function returns an srw status
+ * (0 = ok) and srw_last_error() gives the message.  The opaque handle owns all device memory; the
+ * caller owns every buffer it passes in.  A handle is single-threaded; distinct handles may be used
+ * from distinct threads.  There is NO CPU fallback: every compute entry point runs HIP kernels on the
+ * handle's device and fails with SRW_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef STELLAR_RW_H
+#define STELLAR_RW_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srw_handle srw_handle;
+
+enum {
+  SRW_OK = 0,
+  SRW_ERR_INVALID = 1, /* bad argument / bad state */
+  SRW_ERR_IO = 2,      /* file cannot be opened / written */
+  SRW_ERR_PARSE = 3,   /* an input line on which the reference job throws (NumberFormatException ...) */
+  SRW_ERR_HIP = 4,     /* HIP runtime error, or no usable GPU */
+  SRW_ERR_EXISTS = 5,  /* <output>/path already exists (FileAlreadyExistsException in the reference) */
+  SRW_ERR_NOMEM = 6
+};
+
+/* sampler selection */
+enum {
+  SRW_SAMPLER_REFERENCE = 0, /* Mode R: reference-exact linear-CDF inversion (bit-identical paths) */
+  SRW_SAMPLER_ALIAS = 1      /* Mode A: per-vertex alias tables + rejection (statistically identical) */
+};
+/* RNG selection.  The reference's only determinism hook is the injected nextFloat closure
+ * (M/algorithm/RandomSample.scala:5, M/algorithm/RandomWalk.scala:51-52,75-76). */
+enum {
+  SRW_RNG_CONST = 0,  /* nextFloat = () => const_r, as the reference's tests inject */
+  SRW_RNG_PHILOX = 1  /* Philox4x32-10, key (seed,0), ctr (walk iteration, source id, step index, 0),
+                         u = (x0 >> 8) * 2^-24 (same 24-bit lattice as java.util.Random.nextFloat) */
+};
+
+typedef struct {
+  int32_t device; /* HIP device ordinal */
+  int32_t rank;   /* vertex sharding: this handle stores the rows of vertices v with            */
+  int32_t world;  /*   nonNegativeMod(v, world) == rank (HashPartitioner, RandomWalk.scala:16); */
+                  /*   world = 1 keeps the whole graph (single-GPU and replicated modes)         */
+  int32_t flags;  /* reserved, 0 */
+} srw_config;
+
+/* Replaces: SparkContext + GraphMap singleton lifetime (M/Main.scala:21-23, M/algorithm/GraphMap.scala:11). */
+int32_t srw_create(const srw_config *cfg, srw_handle **out);
+void srw_destroy(srw_handle *h);
+/* Message of the last failure on h (h may be NULL for srw_create failures). */
+const char *srw_last_error(const srw_handle *h);
+/* Launch all kernels on this hipStream_t (default: the handle's own stream). */
+int32_t srw_set_stream(srw_handle *h, void *hip_stream);
+
+/* ---- graph load ---------------------------------------------------------------------------- */
+/* Replaces UniformRandomWalk.loadGraph (M/algorithm/UniformRandomWalk.scala:17-88) and, with
+ * partitioned != 0, VCutRandomWalk.loadGraph (M/algorithm/VCutRandomWalk.scala:13-98): parses the
+ * edge-list text with the reference's token rules, builds the adjacency in HBM as CSR with every
+ * neighbor list in input-line order, multi-edges and self-loops kept. */
+int32_t srw_load_edgelist(srw_handle *h, const char *path, int32_t directed, int32_t weighted,
+                          int32_t partitioned, int32_t rdd_partitions);
+/* Same construction from already-parsed lines in file order (host pointers).  w may be NULL (1.0f),
+ * pid may be NULL.  Replaces the flatMap/reduceByKey stage, UniformRandomWalk.scala:26-41. */
+int32_t srw_load_coo(srw_handle *h, const int32_t *src, const int32_t *dst, const float *w,
+                     const int32_t *pid, int64_t n_lines, int32_t directed);
+/* Complete adjacency rows, the GraphMap.addVertex surface (M/algorithm/GraphMap.scala:23-56,83-85):
+ * row i is vertex vids[i] with neighbors [offs[i], offs[i+1]); first occurrence of a vertex wins. */
+int32_t srw_load_adjacency(srw_handle *h, const int32_t *vids, const int64_t *offs, int64_t n_rows,
+                           const int32_t *ids, const float *w, const int32_t *pids);
+/* Synthetic RMAT (a,b,c,d)=(.57,.19,.19,.05) generated on the device straight into COO -> CSR
+ * (BASELINE.md §4).  Edge i is a pure function of (seed, i), so any rank can generate any slice. */
+int32_t srw_generate_rmat(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, int32_t weighted,
+                          int32_t directed);
+
+/* nVertices / nEdges as the reference prints them ("vertices: N", "edges: N",
+ * UniformRandomWalk.scala:69-72); int64 because the reference's Int counters overflow at C4. */
+int32_t srw_graph_stats(const srw_handle *h, int64_t *n_vertices, int64_t *n_entries);
+/* Present vertex ids, ascending (the walker seeds, UniformRandomWalk.scala:81-87). out[n_vertices]. */
+int32_t srw_graph_vertices(const srw_handle *h, int32_t *out);
+/* GraphMap.getNeighbors (M/algorithm/GraphMap.scala:109-120): *n = -1 for `null` (unknown vertex),
+ * 0 for a vertex without out-edges, else the list length; copies at most cap entries. */
+int32_t srw_graph_neighbors(const srw_handle *h, int32_t v, int32_t *ids, float *w, int64_t cap, int64_t *n);
+/* GraphMap.getPartition (:66-68): *pid = last partition id recorded for dst v, *known = 0 if none. */
+int32_t srw_graph_partition(const srw_handle *h, int32_t v, int32_t *pid, int32_t *known);
+
+/* ---- walk ---------------------------------------------------------------------------------- */
+typedef struct {
+  float p, q;          /* --p / --q already cast to float (RandomWalk.scala:112) */
+  int32_t walk_length; /* --walkLength: a full path has walk_length + 2 ids */
+  int32_t num_walks;   /* --numWalks walk iterations in this call */
+  int32_t first_walk;  /* index of the first walk iteration (Philox counter word 0) */
+  int32_t rng_mode;    /* SRW_RNG_* */
+  float const_r;
+  uint32_t seed;
+  int32_t sampler;     /* SRW_SAMPLER_* */
+  int32_t flags;       /* SRW_WALK_* */
+} srw_walk_params;
+enum {
+  SRW_WALK_FORCE_GENERAL = 1 /* use the general second-order kernel even when p == q == 1 (testing) */
+};
+
+typedef struct {
+  int64_t n_walkers;    /* num_walks * nVertices */
+  int64_t n_steps;      /* sum over paths of (len - 1): the metric's unit */
+  int64_t dead_ends;    /* "Zero Neighbors" accumulator, RandomWalk.scala:117 */
+  int64_t sum_deg_curr; /* general kernel: sum of deg(curr) over steps (algorithmic bytes) */
+  int64_t sum_deg_prev; /* general kernel: sum of deg(prev) over second-order steps with q != 1 */
+  int64_t ent_reads;    /* first-order kernel: CDF records read */
+  int64_t fallbacks;    /* steps that needed the exact sequential fallback */
+  double kernel_ms;     /* hipEvent time of the walk kernels of this call, on the handle's stream */
+  int32_t kernel_kind;  /* 1 = first-order guide-table kernel, 2 = general second-order kernel, 3 = alias */
+  int32_t reserved;
+} srw_walk_stats;
+
+/* Replaces RandomWalk.randomWalk (M/algorithm/RandomWalk.scala:75-176) incl. initFirstStep (:51-66):
+ * num_walks iterations, one walker per present vertex (ascending id), walker index =
+ * iteration * nVertices + rank(vertex).  Paths stay in HBM as int32 [n_walkers][walk_length + 2]
+ * (unused tail = -1) plus int32 lens[n_walkers]. */
+int32_t srw_walk(srw_handle *h, const srw_walk_params *params, srw_walk_stats *stats);
+/* Copy the last walk's paths / lens to host buffers (either may be NULL). */
+int32_t srw_fetch_paths(const srw_handle *h, int32_t *paths, int32_t *lens);
+/* Device pointers of the last walk's result (valid until the next srw_walk / destroy). */
+int32_t srw_device_paths(const srw_handle *h, void **d_paths, void **d_lens, int64_t *n_walkers, int32_t *stride);
+/* Replaces RandomWalk.save (M/algorithm/RandomWalk.scala:234-241) + Property.pathSuffix: writes
+ * <output_dir>/path/part-00000.. (TAB-joined ids, one '\n' per path) and _SUCCESS; canonical line
+ * order (walk iteration major, source id ascending).  write_crc != 0 adds Hadoop .crc side files. */
+int32_t srw_write_paths(const srw_handle *h, const char *output_dir, int32_t n_parts, int32_t write_crc);
+
+/* ---- vertex-sharded multi-GPU path (one handle per GPU, world > 1) -------------------------- */
+typedef struct { int32_t wid, src, prev, curr; } srw_walker; /* 16-byte record exchanged over xGMI */
+/* Seeds for this rank's vertices, replaces initWalkersToTheirPartitions / the walker seeds
+ * (UniformRandomWalk.scala:81-87).  d_out (device) must hold srw_shard_capacity records. */
+int32_t srw_shard_capacity(const srw_handle *h, int64_t *n_local_vertices, int64_t *n_global_vertices);
+int32_t srw_shard_seed(srw_handle *h, int32_t iter_in_call, void *d_out, int64_t *n_out, void *d_paths,
+                       int64_t stride); /* also writes path slot 0 of the seeded walkers into d_paths */
+/* One super-step (RandomWalk.scala:92-139 with exactly one step per walker): samples the next vertex
+ * of the n_in records in d_in (all at path slot `step`), writes it to d_paths[wid * stride + step],
+ * and emits the surviving walkers into d_out grouped by owner(next); counts_out[world] (host). */
+int32_t srw_shard_step(srw_handle *h, const srw_walk_params *params, int32_t iter, int32_t step,
+                       const void *d_in, int64_t n_in, void *d_out, int64_t *counts_out,
+                       void *d_paths, int64_t stride, srw_walk_stats *stats);
+
+/* ---- unit hooks (device arithmetic of RandomSample, for parity tests) ----------------------- */
+/* RandomSample.sample (M/algorithm/RandomSample.scala:12-25) on the GPU; *index = chosen position. */
+int32_t srw_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index);
+/* RandomSample.computeSecondOrderWeights (:27-44) on the GPU. */
+int32_t srw_second_order_weights(srw_handle *h, float p, float q, int32_t prev_id, const int32_t *prev_ids,
+                                 int64_t n_prev, const int32_t *curr_ids, const float *curr_w, int64_t n,
+                                 float *out_w);
+/* RandomSample.secondOrderSample (:55-62) on the GPU. */
+int32_t srw_second_order_sample(srw_handle *h, float p, float q, int32_t prev_id, const int32_t *prev_ids,
+                                int64_t n_prev, const int32_t *curr_ids, const float *curr_w, int64_t n,
+                                float r, int64_t *index);
+/* The walk RNG stream evaluated on the GPU: out[i] = u(seed, iter[i], src[i], step[i]). */
+int32_t srw_rng_uniform(srw_handle *h, uint32_t seed, const uint32_t *iter, const uint32_t *src,
+                        const uint32_t *step, int64_t n, float *out);
+
+/* ---- host-only helpers (no GPU needed) ------------------------------------------------------ */
+/* The edge-list tokenizer on its own: parses `path` into caller-visible arrays owned by the library
+ * (released by srw_free).  Used by the CLI and by tests of the parse rules. */
+int32_t srw_parse_edgelist(const char *path, int32_t weighted, int32_t partitioned, int32_t **src,
+                           int32_t **dst, float **w, int32_t **pid, int64_t *n_lines, char *err, size_t errlen);
+void srw_free(void *p);
+/* RandomWalk.save on host-resident paths (M/algorithm/RandomWalk.scala:234-241): same files as
+ * srw_write_paths, for callers that assembled several walk calls themselves. */
+int32_t srw_save_paths(const int32_t *paths, const int32_t *lens, int64_t n_walkers, int64_t stride,
+                       const char *output_dir, int32_t n_parts, int32_t write_crc);
+/* Library / build identification ("stellar_rw gfx950 <git describe>"). */
+const char *srw_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,327 @@
+"""stellar_random_walk_amd — Python binding (ctypes) of libstellar_rw.so, the MI355X-native engine behind the
+`--cmd randomwalk` path of data61/stellar-random-walk.
+
+This module is plumbing: every computation happens in hand-written HIP kernels behind the C ABI declared in
+include/stellar_rw.h.  There is no CPU fallback — importing works anywhere (so the symbols can be checked), but
+creating an Engine without a usable gfx950 device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libstellar_rw.so")
+CLI_PATH = os.path.join(_DIR, "stellar-rw")
+
+OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_HIP, ERR_EXISTS, ERR_NOMEM = range(7)
+SAMPLER_REFERENCE, SAMPLER_ALIAS = 0, 1
+RNG_CONST, RNG_PHILOX = 0, 1
+WALK_FORCE_GENERAL = 1
+
+
+class SrwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("srw error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("flags", C.c_int32)]
+
+
+class WalkParams(C.Structure):
+    _fields_ = [("p", C.c_float), ("q", C.c_float), ("walk_length", C.c_int32), ("num_walks", C.c_int32),
+                ("first_walk", C.c_int32), ("rng_mode", C.c_int32), ("const_r", C.c_float), ("seed", C.c_uint32),
+                ("sampler", C.c_int32), ("flags", C.c_int32)]
+
+
+class WalkStats(C.Structure):
+    _fields_ = [("n_walkers", C.c_int64), ("n_steps", C.c_int64), ("dead_ends", C.c_int64),
+                ("sum_deg_curr", C.c_int64), ("sum_deg_prev", C.c_int64), ("ent_reads", C.c_int64),
+                ("fallbacks", C.c_int64), ("kernel_ms", C.c_double), ("kernel_kind", C.c_int32),
+                ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/stellar_rw.h declares
+EXPORTS = [
+    "srw_create", "srw_destroy", "srw_last_error", "srw_set_stream", "srw_load_edgelist", "srw_load_coo",
+    "srw_load_adjacency", "srw_generate_rmat", "srw_graph_stats", "srw_graph_vertices", "srw_graph_neighbors",
+    "srw_graph_partition", "srw_walk", "srw_fetch_paths", "srw_device_paths", "srw_write_paths",
+    "srw_shard_capacity", "srw_shard_seed", "srw_shard_step", "srw_sample", "srw_second_order_weights",
+    "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_version",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libstellar_rw.so.  Fails loudly if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libstellar_rw.so is missing at %s — build it with `make -C %s/csrc` "
+                          "(there is no CPU fallback)" % (LIB_PATH, _DIR))
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, i64p, f32p, u32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float), \
+        C.POINTER(C.c_uint32)
+    L.srw_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.srw_destroy.argtypes = [vp]
+    L.srw_destroy.restype = None
+    L.srw_last_error.argtypes = [vp]
+    L.srw_last_error.restype = C.c_char_p
+    L.srw_set_stream.argtypes = [vp, vp]
+    L.srw_load_edgelist.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.srw_load_coo.argtypes = [vp, i32p, i32p, f32p, i32p, C.c_int64, C.c_int32]
+    L.srw_load_adjacency.argtypes = [vp, i32p, i64p, C.c_int64, i32p, f32p, i32p]
+    L.srw_generate_rmat.argtypes = [vp, C.c_int32, C.c_int64, C.c_uint32, C.c_int32, C.c_int32]
+    L.srw_graph_stats.argtypes = [vp, i64p, i64p]
+    L.srw_graph_vertices.argtypes = [vp, i32p]
+    L.srw_graph_neighbors.argtypes = [vp, C.c_int32, i32p, f32p, C.c_int64, i64p]
+    L.srw_graph_partition.argtypes = [vp, C.c_int32, i32p, i32p]
+    L.srw_walk.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(WalkStats)]
+    L.srw_fetch_paths.argtypes = [vp, i32p, i32p]
+    L.srw_device_paths.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i64p, i32p]
+    L.srw_write_paths.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
+    L.srw_shard_capacity.argtypes = [vp, i64p, i64p]
+    L.srw_shard_seed.argtypes = [vp, C.c_int32, vp, i64p, vp, C.c_int64]
+    L.srw_shard_step.argtypes = [vp, C.POINTER(WalkParams), C.c_int32, C.c_int32, vp, C.c_int64, vp, i64p, vp,
+                                 C.c_int64, C.POINTER(WalkStats)]
+    L.srw_sample.argtypes = [vp, f32p, C.c_int64, C.c_float, i64p]
+    L.srw_second_order_weights.argtypes = [vp, C.c_float, C.c_float, C.c_int32, i32p, C.c_int64, i32p, f32p,
+                                           C.c_int64, f32p]
+    L.srw_second_order_sample.argtypes = [vp, C.c_float, C.c_float, C.c_int32, i32p, C.c_int64, i32p, f32p,
+                                          C.c_int64, C.c_float, i64p]
+    L.srw_rng_uniform.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, C.c_int64, f32p]
+    L.srw_parse_edgelist.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(i32p), C.POINTER(i32p),
+                                     C.POINTER(f32p), C.POINTER(i32p), i64p, C.c_char_p, C.c_size_t]
+    L.srw_free.argtypes = [vp]
+    L.srw_free.restype = None
+    L.srw_save_paths.argtypes = [i32p, i32p, C.c_int64, C.c_int64, C.c_char_p, C.c_int32, C.c_int32]
+    L.srw_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _i32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def version():
+    return lib().srw_version().decode()
+
+
+def parse_edgelist(path, weighted=True, partitioned=False):
+    """Host-only: the edge-list tokenizer (UniformRandomWalk.scala:26-34 / VCutRandomWalk.scala:21-34 rules).
+    Returns (src, dst, w, pid) numpy arrays in file order; raises SrwError(ERR_PARSE) where the reference throws."""
+    L = lib()
+    s, d, p = (C.POINTER(C.c_int32)() for _ in range(3))
+    w = C.POINTER(C.c_float)()
+    n = C.c_int64(0)
+    err = C.create_string_buffer(512)
+    rc = L.srw_parse_edgelist(os.fsencode(path), int(weighted), int(partitioned), C.byref(s), C.byref(d), C.byref(w),
+                              C.byref(p), C.byref(n), err, 512)
+    if rc != OK:
+        raise SrwError(rc, err.value.decode())
+    k = n.value
+    out = tuple(np.ctypeslib.as_array(x, shape=(max(k, 1),))[:k].copy() for x in (s, d, w, p))
+    for x in (s, d, w, p):
+        L.srw_free(x)
+    return out
+
+
+def save_paths(paths, lens, output_dir, n_parts=1, write_crc=False):
+    paths = np.ascontiguousarray(paths, dtype=np.int32)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    rc = lib().srw_save_paths(_i32(paths), _i32(lens), len(lens), paths.shape[1] if paths.ndim == 2 else 0,
+                              os.fsencode(output_dir), n_parts, int(write_crc))
+    if rc != OK:
+        raise SrwError(rc, lib().srw_last_error(None).decode())
+
+
+class Engine:
+    """One handle = one GPU.  Mirrors the life of the reference's SparkContext + GraphMap + RandomWalk object."""
+
+    def __init__(self, device=0, rank=0, world=1):
+        self.h = C.c_void_p()
+        cfg = Config(device, rank, world, 0)
+        rc = lib().srw_create(C.byref(cfg), C.byref(self.h))
+        if rc != OK:
+            self.h = None
+            raise SrwError(rc, lib().srw_last_error(None).decode())
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().srw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise SrwError(rc, lib().srw_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._ck(lib().srw_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ---- graph ----
+    def load_edgelist(self, path, directed=False, weighted=True, partitioned=False, rdd_partitions=200):
+        self._ck(lib().srw_load_edgelist(self.h, os.fsencode(path), int(directed), int(weighted), int(partitioned),
+                                         rdd_partitions))
+        return self
+
+    def load_coo(self, src, dst, w=None, pid=None, directed=False):
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        dst = np.ascontiguousarray(dst, dtype=np.int32)
+        wp = pp = None
+        if w is not None:
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            wp = _f32(w)
+        if pid is not None:
+            pid = np.ascontiguousarray(pid, dtype=np.int32)
+            pp = _i32(pid)
+        self._ck(lib().srw_load_coo(self.h, _i32(src), _i32(dst), wp, pp, len(src), int(directed)))
+        return self
+
+    def load_adjacency(self, rows):
+        """rows: list of (vid, [(dst, w)] or [(dst, pid, w)]) — the GraphMap.addVertex surface."""
+        vids = np.ascontiguousarray([r[0] for r in rows], dtype=np.int32)
+        offs = np.zeros(len(rows) + 1, dtype=np.int64)
+        ids, ws, pids = [], [], []
+        has_pid = any(len(e) == 3 for _, nb in rows for e in nb)
+        for i, (_, nb) in enumerate(rows):
+            for e in nb:
+                ids.append(e[0])
+                ws.append(e[-1])
+                pids.append(e[1] if len(e) == 3 else -1)
+            offs[i + 1] = len(ids)
+        ids = np.ascontiguousarray(ids if ids else [0], dtype=np.int32)
+        ws = np.ascontiguousarray(ws if ws else [0], dtype=np.float32)
+        pids = np.ascontiguousarray(pids if pids else [0], dtype=np.int32)
+        self._ck(lib().srw_load_adjacency(self.h, _i32(vids), offs.ctypes.data_as(C.POINTER(C.c_int64)), len(rows),
+                                          _i32(ids), _f32(ws), _i32(pids) if has_pid else None))
+        return self
+
+    def generate_rmat(self, scale, n_edges=None, seed=42, weighted=False, directed=False):
+        if n_edges is None:
+            n_edges = 16 << scale
+        self._ck(lib().srw_generate_rmat(self.h, scale, n_edges, seed, int(weighted), int(directed)))
+        return self
+
+    def stats(self):
+        v, e = C.c_int64(0), C.c_int64(0)
+        self._ck(lib().srw_graph_stats(self.h, C.byref(v), C.byref(e)))
+        return v.value, e.value
+
+    @property
+    def num_vertices(self):
+        return self.stats()[0]
+
+    @property
+    def num_entries(self):
+        return self.stats()[1]
+
+    def shard_capacity(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._ck(lib().srw_shard_capacity(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def vertices(self):
+        n = self.shard_capacity()[0]
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        self._ck(lib().srw_graph_vertices(self.h, _i32(out)))
+        return out[:n]
+
+    def neighbors(self, v):
+        """GraphMap.getNeighbors: None for an unknown vertex, else (ids, w)."""
+        n = C.c_int64(0)
+        self._ck(lib().srw_graph_neighbors(self.h, v, None, None, 0, C.byref(n)))
+        if n.value < 0:
+            return None
+        ids = np.zeros(max(n.value, 1), dtype=np.int32)
+        w = np.zeros(max(n.value, 1), dtype=np.float32)
+        self._ck(lib().srw_graph_neighbors(self.h, v, _i32(ids), _f32(w), n.value, C.byref(n)))
+        return ids[:n.value], w[:n.value]
+
+    def partition(self, v):
+        pid, known = C.c_int32(0), C.c_int32(0)
+        self._ck(lib().srw_graph_partition(self.h, v, C.byref(pid), C.byref(known)))
+        return pid.value if known.value else None
+
+    # ---- walk ----
+    @staticmethod
+    def params(p=1.0, q=1.0, walk_length=80, num_walks=1, first_walk=0, rng="philox", const_r=0.0, seed=42,
+               sampler=SAMPLER_REFERENCE, force_general=False):
+        return WalkParams(np.float32(p), np.float32(q), walk_length, num_walks, first_walk,
+                          RNG_CONST if rng == "const" else RNG_PHILOX, np.float32(const_r), seed, sampler,
+                          WALK_FORCE_GENERAL if force_general else 0)
+
+    def walk(self, fetch=True, **kw):
+        """Runs srw_walk.  Returns (paths [nWalkers, L+2] int32 (-1 tail), lens, stats dict) or just stats."""
+        P = self.params(**kw)
+        st = WalkStats()
+        self._ck(lib().srw_walk(self.h, C.byref(P), C.byref(st)))
+        if not fetch:
+            return st.as_dict()
+        paths = np.empty((max(st.n_walkers, 1), P.walk_length + 2), dtype=np.int32)
+        lens = np.empty(max(st.n_walkers, 1), dtype=np.int32)
+        self._ck(lib().srw_fetch_paths(self.h, _i32(paths), _i32(lens)))
+        return paths[:st.n_walkers], lens[:st.n_walkers], st.as_dict()
+
+    def device_paths(self):
+        dp, dl, n, s = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.c_int32(0)
+        self._ck(lib().srw_device_paths(self.h, C.byref(dp), C.byref(dl), C.byref(n), C.byref(s)))
+        return dp.value, dl.value, n.value, s.value
+
+    def write_paths(self, output_dir, n_parts=1, write_crc=False):
+        self._ck(lib().srw_write_paths(self.h, os.fsencode(output_dir), n_parts, int(write_crc)))
+
+    # ---- unit hooks: RandomSample on the GPU ----
+    def sample(self, w, r):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        k = C.c_int64(0)
+        self._ck(lib().srw_sample(self.h, _f32(w), len(w), C.c_float(r), C.byref(k)))
+        return k.value
+
+    def second_order_weights(self, p, q, prev_id, prev_ids, curr_ids, curr_w):
+        prev_ids = np.ascontiguousarray(prev_ids, dtype=np.int32)
+        curr_ids = np.ascontiguousarray(curr_ids, dtype=np.int32)
+        curr_w = np.ascontiguousarray(curr_w, dtype=np.float32)
+        out = np.empty_like(curr_w)
+        self._ck(lib().srw_second_order_weights(self.h, C.c_float(p), C.c_float(q), prev_id, _i32(prev_ids),
+                                                len(prev_ids), _i32(curr_ids), _f32(curr_w), len(curr_ids), _f32(out)))
+        return out
+
+    def second_order_sample(self, p, q, prev_id, prev_ids, curr_ids, curr_w, r):
+        prev_ids = np.ascontiguousarray(prev_ids, dtype=np.int32)
+        curr_ids = np.ascontiguousarray(curr_ids, dtype=np.int32)
+        curr_w = np.ascontiguousarray(curr_w, dtype=np.float32)
+        k = C.c_int64(0)
+        self._ck(lib().srw_second_order_sample(self.h, C.c_float(p), C.c_float(q), prev_id, _i32(prev_ids),
+                                               len(prev_ids), _i32(curr_ids), _f32(curr_w), len(curr_ids),
+                                               C.c_float(r), C.byref(k)))
+        return k.value
+
+    def rng_uniform(self, seed, it, src, step):
+        it, src, step = (np.ascontiguousarray(x, dtype=np.uint32) for x in (it, src, step))
+        out = np.empty(len(it), dtype=np.float32)
+        u32p = C.POINTER(C.c_uint32)
+        self._ck(lib().srw_rng_uniform(self.h, seed, it.ctypes.data_as(u32p), src.ctypes.data_as(u32p),
+                                       step.ctypes.data_as(u32p), len(it), _f32(out)))
+        return out

@@ -1,0 +1,364 @@
+// api.cpp — the C ABI (include/stellar_rw.h).  Everything here is glue: argument checks, host<->device
+// staging, and translation of C++ exceptions into status codes + srw_last_error().
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+#include "engine.h"
+
+using namespace srw;
+
+namespace {
+std::mutex g_err_mu;
+std::string g_create_error;
+
+template <typename F>
+int32_t guarded(srw_handle *h, F &&f) {
+  try {
+    if (h) SRW_HIP(hipSetDevice(h->cfg.device));
+    f();
+    return SRW_OK;
+  } catch (const Error &e) {
+    if (h) h->last_error = e.what();
+    else { std::lock_guard<std::mutex> l(g_err_mu); g_create_error = e.what(); }
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    if (h) h->last_error = "host allocation failed";
+    return SRW_ERR_NOMEM;
+  } catch (const std::exception &e) {
+    if (h) h->last_error = e.what();
+    return SRW_ERR_INVALID;
+  }
+}
+
+void need(bool ok, const char *msg) { if (!ok) throw Error(SRW_ERR_INVALID, msg); }
+
+void load_lines(srw_handle *h, const int32_t *src, const int32_t *dst, const float *w, const int32_t *pid,
+                int64_t n, bool directed) {
+  need(n > 0, "empty edge list");
+  int32_t vmin = src[0], vmax = src[0];
+  for (int64_t i = 0; i < n; ++i) {
+    vmin = std::min(vmin, std::min(src[i], dst[i]));
+    vmax = std::max(vmax, std::max(src[i], dst[i]));
+  }
+  hipStream_t st = h->stream;
+  DevBuf<int32_t> d_src, d_dst; DevBuf<float> d_w;
+  d_src.alloc((size_t)n); d_dst.alloc((size_t)n);
+  SRW_HIP(hipMemcpyAsync(d_src.p, src, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemcpyAsync(d_dst.p, dst, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  if (w) { d_w.alloc((size_t)n); SRW_HIP(hipMemcpyAsync(d_w.p, w, (size_t)n * 4, hipMemcpyHostToDevice, st)); }
+  SRW_HIP(hipStreamSynchronize(st));
+  build_graph_from_device_lines(h, d_src.p, d_dst.p, w ? d_w.p : nullptr, n, directed, vmin, vmax);
+  // VCut: vertexPartitionMap.put(dst, pId) for every adjacency entry, last put wins (GraphMap.scala:28-32).
+  h->g.part_of.clear();
+  if (pid) {
+    h->g.part_of.assign((size_t)h->g.n_slots, -1);
+    for (int64_t i = 0; i < n; ++i) {
+      h->g.part_of[(size_t)((int64_t)dst[i] - vmin)] = pid[i];
+      if (!directed) h->g.part_of[(size_t)((int64_t)src[i] - vmin)] = pid[i];
+    }
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int32_t srw_create(const srw_config *cfg, srw_handle **out) {
+  if (!out) return SRW_ERR_INVALID;
+  *out = nullptr;
+  srw_handle *h = nullptr;
+  int32_t rc = guarded(nullptr, [&] {
+    srw_config c{};
+    if (cfg) c = *cfg;
+    if (c.world <= 0) { c.world = 1; c.rank = 0; }
+    need(c.rank >= 0 && c.rank < c.world, "rank must be in [0, world)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+      throw Error(SRW_ERR_HIP, std::string("no usable HIP device (this library has no CPU fallback): ") +
+                                   (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    need(c.device >= 0 && c.device < ndev, "device ordinal out of range");
+    SRW_HIP(hipSetDevice(c.device));
+    h = new srw_handle();
+    h->cfg = c;
+    SRW_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    SRW_HIP(hipEventCreate(&h->ev0));
+    SRW_HIP(hipEventCreate(&h->ev1));
+    h->counters.alloc(1);
+  });
+  if (rc != SRW_OK) { delete h; return rc; }
+  *out = h;
+  return SRW_OK;
+}
+
+void srw_destroy(srw_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char *srw_last_error(const srw_handle *h) {
+  if (h) return h->last_error.c_str();
+  std::lock_guard<std::mutex> l(g_err_mu);
+  return g_create_error.c_str();
+}
+
+int32_t srw_set_stream(srw_handle *h, void *hip_stream) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    if (h->own_stream && h->stream) { SRW_HIP(hipStreamSynchronize(h->stream)); SRW_HIP(hipStreamDestroy(h->stream)); }
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+  });
+}
+
+int32_t srw_load_edgelist(srw_handle *h, const char *path, int32_t directed, int32_t weighted, int32_t partitioned,
+                          int32_t rdd_partitions) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(path != nullptr, "path is null");
+    ParsedLines L;
+    parse_edgelist_file(path, weighted != 0, partitioned != 0, L);
+    if (L.src.empty()) throw Error(SRW_ERR_INVALID, "edge list has no lines");
+    if (partitioned) {
+      // a missing / unparsable pId is Random.nextInt(rddPartitions) in the reference (VCutRandomWalk.scala:24-25,
+      // unseeded); partition ids never change walk results, so a deterministic hash stands in.
+      int32_t np = rdd_partitions > 0 ? rdd_partitions : 1;
+      for (size_t i = 0; i < L.pid.size(); ++i)
+        if (L.pid[i] < 0) L.pid[i] = (int32_t)(((uint32_t)L.src[i] * 0x9E3779B1u ^ (uint32_t)L.dst[i] * 0x85EBCA77u) % (uint32_t)np);
+    }
+    load_lines(h, L.src.data(), L.dst.data(), L.w.data(), partitioned ? L.pid.data() : nullptr, (int64_t)L.src.size(),
+               directed != 0);
+  });
+}
+
+int32_t srw_load_coo(srw_handle *h, const int32_t *src, const int32_t *dst, const float *w, const int32_t *pid,
+                     int64_t n_lines, int32_t directed) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(src && dst, "src/dst are null");
+    load_lines(h, src, dst, w, pid, n_lines, directed != 0);
+  });
+}
+
+int32_t srw_load_adjacency(srw_handle *h, const int32_t *vids, const int64_t *offs, int64_t n_rows, const int32_t *ids,
+                           const float *w, const int32_t *pids) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(vids && offs && (ids || offs[n_rows] == 0), "null argument");
+    build_graph_from_host_rows(h, vids, offs, n_rows, ids, w);
+    h->g.part_of.clear();
+    if (pids) {
+      h->g.part_of.assign((size_t)h->g.n_slots, -1);
+      std::vector<char> seen((size_t)h->g.n_slots, 0);
+      for (int64_t i = 0; i < n_rows; ++i) {
+        size_t s = (size_t)((int64_t)vids[i] - h->g.vmin);
+        if (seen[s]) continue;   // a re-added vertex is ignored entirely (GraphMap.scala:37)
+        seen[s] = 1;
+        for (int64_t e = offs[i]; e < offs[i + 1]; ++e) h->g.part_of[(size_t)((int64_t)ids[e] - h->g.vmin)] = pids[e];
+      }
+    }
+  });
+}
+
+int32_t srw_generate_rmat(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, int32_t weighted, int32_t directed) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    DevBuf<int32_t> d_src, d_dst; DevBuf<float> d_w;
+    generate_rmat_lines(h, scale, n_edges, seed, weighted != 0, d_src, d_dst, d_w);
+    build_graph_from_device_lines(h, d_src.p, d_dst.p, weighted ? d_w.p : nullptr, n_edges, directed != 0, 0,
+                                  (int32_t)(((int64_t)1 << scale) - 1));
+    h->g.part_of.clear();
+  });
+}
+
+int32_t srw_graph_stats(const srw_handle *h, int64_t *n_vertices, int64_t *n_entries) {
+  if (!h || !h->g.loaded) return SRW_ERR_INVALID;
+  if (n_vertices) *n_vertices = h->g.n_vertices;
+  if (n_entries) *n_entries = h->g.n_entries_global;
+  return SRW_OK;
+}
+
+int32_t srw_graph_vertices(const srw_handle *ch, int32_t *out) {
+  srw_handle *h = const_cast<srw_handle *>(ch);
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(h->g.loaded && out, "no graph / null out");
+    SRW_HIP(hipMemcpy(out, h->g.verts.p, (size_t)h->g.n_local_vertices * 4, hipMemcpyDeviceToHost));
+  });
+}
+
+int32_t srw_graph_neighbors(const srw_handle *ch, int32_t v, int32_t *ids, float *w, int64_t cap, int64_t *n) {
+  srw_handle *h = const_cast<srw_handle *>(ch);
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(h->g.loaded && n, "no graph / null n");
+    const Graph &g = h->g;
+    int64_t s = (int64_t)v - g.vmin;
+    if (s < 0 || s >= g.n_slots) { *n = -1; return; }
+    Row r;
+    SRW_HIP(hipMemcpy(&r, g.rows.p + s, sizeof(Row), hipMemcpyDeviceToHost));
+    if (!(r.flags & ROW_PRESENT)) { *n = -1; return; }       // case None => null
+    *n = r.deg;
+    int64_t m = std::min<int64_t>(cap, r.deg);
+    if (m > 0 && (ids || w)) {
+      std::vector<Ent> tmp((size_t)m);
+      SRW_HIP(hipMemcpy(tmp.data(), g.ent.p + r.off, (size_t)m * sizeof(Ent), hipMemcpyDeviceToHost));
+      for (int64_t k = 0; k < m; ++k) { if (ids) ids[k] = tmp[k].id; if (w) w[k] = tmp[k].w; }
+    }
+  });
+}
+
+int32_t srw_graph_partition(const srw_handle *h, int32_t v, int32_t *pid, int32_t *known) {
+  if (!h || !h->g.loaded || !known) return SRW_ERR_INVALID;
+  *known = 0;
+  int64_t s = (int64_t)v - h->g.vmin;
+  if (h->g.part_of.empty() || s < 0 || s >= h->g.n_slots || h->g.part_of[(size_t)s] < 0) return SRW_OK;
+  if (pid) *pid = h->g.part_of[(size_t)s];
+  *known = 1;
+  return SRW_OK;
+}
+
+int32_t srw_walk(srw_handle *h, const srw_walk_params *params, srw_walk_stats *stats) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { need(params != nullptr, "params is null"); run_walk(h, *params, stats); });
+}
+
+int32_t srw_fetch_paths(const srw_handle *ch, int32_t *paths, int32_t *lens) {
+  srw_handle *h = const_cast<srw_handle *>(ch);
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(h->res.valid, "no walk result");
+    if (paths) SRW_HIP(hipMemcpy(paths, h->res.paths.p, (size_t)h->res.n_walkers * h->res.stride * 4, hipMemcpyDeviceToHost));
+    if (lens) SRW_HIP(hipMemcpy(lens, h->res.lens.p, (size_t)h->res.n_walkers * 4, hipMemcpyDeviceToHost));
+  });
+}
+
+int32_t srw_device_paths(const srw_handle *h, void **d_paths, void **d_lens, int64_t *n_walkers, int32_t *stride) {
+  if (!h || !h->res.valid) return SRW_ERR_INVALID;
+  if (d_paths) *d_paths = h->res.paths.p;
+  if (d_lens) *d_lens = h->res.lens.p;
+  if (n_walkers) *n_walkers = h->res.n_walkers;
+  if (stride) *stride = h->res.stride;
+  return SRW_OK;
+}
+
+int32_t srw_write_paths(const srw_handle *ch, const char *output_dir, int32_t n_parts, int32_t write_crc) {
+  srw_handle *h = const_cast<srw_handle *>(ch);
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(h->res.valid && output_dir, "no walk result / null output_dir");
+    std::vector<int32_t> paths((size_t)h->res.n_walkers * h->res.stride), lens((size_t)h->res.n_walkers);
+    SRW_HIP(hipMemcpy(paths.data(), h->res.paths.p, paths.size() * 4, hipMemcpyDeviceToHost));
+    SRW_HIP(hipMemcpy(lens.data(), h->res.lens.p, lens.size() * 4, hipMemcpyDeviceToHost));
+    write_path_files(paths.data(), lens.data(), h->res.n_walkers, h->res.stride, output_dir, n_parts, write_crc != 0);
+  });
+}
+
+int32_t srw_shard_capacity(const srw_handle *h, int64_t *n_local_vertices, int64_t *n_global_vertices) {
+  if (!h || !h->g.loaded) return SRW_ERR_INVALID;
+  if (n_local_vertices) *n_local_vertices = h->g.n_local_vertices;
+  if (n_global_vertices) *n_global_vertices = h->g.n_vertices;
+  return SRW_OK;
+}
+
+int32_t srw_shard_seed(srw_handle *h, int32_t iter_in_call, void *d_out, int64_t *n_out, void *d_paths, int64_t stride) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(d_out && n_out, "null argument");
+    run_shard_seed(h, iter_in_call, (Walker *)d_out, n_out, (int32_t *)d_paths, stride);
+  });
+}
+
+int32_t srw_shard_step(srw_handle *h, const srw_walk_params *params, int32_t iter, int32_t step, const void *d_in,
+                       int64_t n_in, void *d_out, int64_t *counts_out, void *d_paths, int64_t stride,
+                       srw_walk_stats *stats) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(params && counts_out && d_paths && (n_in == 0 || (d_in && d_out)), "null argument");
+    run_shard_step(h, *params, iter, step, (const Walker *)d_in, n_in, (Walker *)d_out, counts_out, (int32_t *)d_paths,
+                   stride, stats);
+  });
+}
+
+int32_t srw_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { need(w && index, "null argument"); hook_sample(h, w, n, r, index); });
+}
+
+int32_t srw_second_order_weights(srw_handle *h, float p, float q, int32_t prev_id, const int32_t *prev_ids, int64_t n_prev,
+                                 const int32_t *curr_ids, const float *curr_w, int64_t n, float *out_w) {
+  if (!h) return SRW_ERR_INVALID;
+  static const int32_t dummy = 0;
+  return guarded(h, [&] {
+    need(curr_ids && curr_w && out_w, "null argument");
+    hook_second_order(h, p, q, prev_id, prev_ids ? prev_ids : &dummy, prev_ids ? n_prev : 0, curr_ids, curr_w, n, 0.f,
+                      out_w, nullptr);
+  });
+}
+
+int32_t srw_second_order_sample(srw_handle *h, float p, float q, int32_t prev_id, const int32_t *prev_ids, int64_t n_prev,
+                                const int32_t *curr_ids, const float *curr_w, int64_t n, float r, int64_t *index) {
+  if (!h) return SRW_ERR_INVALID;
+  static const int32_t dummy = 0;
+  return guarded(h, [&] {
+    need(curr_ids && curr_w && index, "null argument");
+    hook_second_order(h, p, q, prev_id, prev_ids ? prev_ids : &dummy, prev_ids ? n_prev : 0, curr_ids, curr_w, n, r,
+                      nullptr, index);
+  });
+}
+
+int32_t srw_rng_uniform(srw_handle *h, uint32_t seed, const uint32_t *iter, const uint32_t *src, const uint32_t *step,
+                        int64_t n, float *out) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { need(iter && src && step && out, "null argument"); hook_rng(h, seed, iter, src, step, n, out); });
+}
+
+int32_t srw_parse_edgelist(const char *path, int32_t weighted, int32_t partitioned, int32_t **src, int32_t **dst, float **w,
+                           int32_t **pid, int64_t *n_lines, char *err, size_t errlen) {
+  if (!path || !n_lines) return SRW_ERR_INVALID;
+  try {
+    ParsedLines L;
+    parse_edgelist_file(path, weighted != 0, partitioned != 0, L);
+    size_t n = L.src.size();
+    auto dup = [n](const void *p, size_t el) { void *q = malloc(std::max<size_t>(n * el, 1)); memcpy(q, p, n * el); return q; };
+    if (src) *src = (int32_t *)dup(L.src.data(), 4);
+    if (dst) *dst = (int32_t *)dup(L.dst.data(), 4);
+    if (w) *w = (float *)dup(L.w.data(), 4);
+    if (pid) *pid = (int32_t *)dup(L.pid.data(), 4);
+    *n_lines = (int64_t)n;
+    return SRW_OK;
+  } catch (const Error &e) {
+    if (err && errlen) snprintf(err, errlen, "%s", e.what());
+    return e.code;
+  } catch (const std::exception &e) {
+    if (err && errlen) snprintf(err, errlen, "%s", e.what());
+    return SRW_ERR_INVALID;
+  }
+}
+
+void srw_free(void *p) { free(p); }
+
+int32_t srw_save_paths(const int32_t *paths, const int32_t *lens, int64_t n_walkers, int64_t stride, const char *output_dir,
+                       int32_t n_parts, int32_t write_crc) {
+  if (!paths || !lens || !output_dir || n_walkers < 0) return SRW_ERR_INVALID;
+  try {
+    write_path_files(paths, lens, n_walkers, stride, output_dir, n_parts, write_crc != 0);
+    return SRW_OK;
+  } catch (const Error &e) {
+    std::lock_guard<std::mutex> l(g_err_mu);
+    g_create_error = e.what();
+    return e.code;
+  } catch (const std::exception &) {
+    return SRW_ERR_IO;
+  }
+}
+
+const char *srw_version(void) { return "stellar_rw gfx950 r1"; }
+
+}  // extern "C"

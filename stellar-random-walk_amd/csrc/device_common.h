@@ -1,0 +1,86 @@
+// device_common.h — HBM data layout + device primitives shared by the gfx950 kernels.
+//
+// Layout:
+//   rows[slot]  16 B  {off:int64, deg:int32, flags:u32}   slot = vertex id - vmin, dense
+//   ent[e]       8 B  {id:int32, w:f32}                   adjacency in input-line order (CSR payload)
+//   sids[e]      4 B  u32 (id - vmin) sorted inside each row   (membership test of computeSecondOrderWeights)
+//   fo[e]       16 B  {cdf:f64, id:int32, guide:int32}    first-order exact CDF + guide table (p = q = 1)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace srw {
+
+struct alignas(16) Row {
+  int64_t off;
+  int32_t deg;
+  uint32_t flags;
+};
+enum : uint32_t { ROW_PRESENT = 1u, ROW_IRREGULAR = 2u };
+
+struct alignas(8) Ent {
+  int32_t id;
+  float w;
+};
+
+struct alignas(16) FoEnt {
+  double cdf;    // acc after adding this entry, computed exactly as RandomSample.sample does (:18-20)
+  int32_t id;
+  int32_t guide; // first k with cdf_k >= ceil(j * 2^24 / deg) * 2^-24, for bucket j = this position
+};
+
+struct alignas(16) Walker {
+  int32_t wid, src, prev, curr;
+};
+
+struct GraphView {
+  const Row *rows;
+  const Ent *ent;
+  const uint32_t *sids;
+  const FoEnt *fo;
+  int32_t vmin;
+  int64_t n_slots;
+};
+
+// Philox4x32-10 (Random123).  Same constants as oracle/srw_oracle.c:orc_philox4x32_10.
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// 24 random bits of the walk stream: ctr = (walk iteration, source id, step index, 0), key = (seed, 0).
+__host__ __device__ inline uint32_t walk_bits24(uint32_t seed, uint32_t iter, uint32_t src, uint32_t step) {
+  uint32_t o[4];
+  philox4x32_10(iter, src, step, 0u, seed, 0u, o);
+  return o[0] >> 8;
+}
+
+struct RngSpec {
+  int32_t mode;   // SRW_RNG_*
+  float const_r;
+  uint32_t seed;
+};
+
+__device__ inline float draw_uniform(const RngSpec &rng, uint32_t iter, uint32_t src, uint32_t step) {
+  if (rng.mode == 0) return rng.const_r;
+  return (float)walk_bits24(rng.seed, iter, src, step) * (1.0f / 16777216.0f);
+}
+
+__host__ __device__ inline int32_t owner_of(int32_t v, int32_t world) {
+  int32_t m = v % world;   // Utils.nonNegativeMod of HashPartitioner (RandomWalk.scala:16)
+  return m < 0 ? m + world : m;
+}
+
+}  // namespace srw

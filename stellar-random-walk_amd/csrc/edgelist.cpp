@@ -1,0 +1,211 @@
+// edgelist.cpp — host-side edge-list tokenizer with the reference's exact token rules.
+//
+// Replaces the per-line lambda of UniformRandomWalk.loadGraph (M/algorithm/UniformRandomWalk.scala:26-34)
+// and VCutRandomWalk.loadGraph (M/algorithm/VCutRandomWalk.scala:21-34):
+//   * records are Hadoop TextInputFormat lines: terminated by \n, \r\n or a lone \r; a final unterminated
+//     line counts; an empty line is a record (and makes the reference throw);
+//   * String.split("\\s+") — \s = [ \t\n\x0B\f\r]; a separator at index 0 yields a leading "" token,
+//     trailing empty tokens are dropped;
+//   * ids by Integer.parseInt (optional sign, decimal digits, int32 range) — failure kills the job;
+//   * weight = Float.parseFloat of the LAST column iff weighted && parts.length > 2 (> 3 when partitioned),
+//     Try(...).getOrElse(1.0f); pId = parts(2).toInt iff partitioned && parts.length > 2.
+// The file is split into byte ranges parsed by one std::thread each and concatenated in file order.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "engine.h"
+
+namespace srw {
+namespace {
+
+inline bool java_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == 0x0B || c == '\f' || c == '\r'; }
+
+bool parse_int_token(const char *s, size_t n, int32_t &out) {
+  if (n == 0) return false;
+  size_t i = 0;
+  bool neg = false;
+  if (s[0] == '-' || s[0] == '+') {
+    neg = s[0] == '-';
+    i = 1;
+    if (n == 1) return false;
+  }
+  int64_t v = 0;
+  for (; i < n; ++i) {
+    unsigned d = (unsigned)(s[i] - '0');
+    if (d > 9u) return false;
+    v = v * 10 + d;
+    if (v > 2147483648LL) return false;
+  }
+  if (neg) v = -v;
+  if (v > 2147483647LL) return false;
+  out = (int32_t)v;
+  return true;
+}
+
+inline bool is_hex_digit(char c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F'); }
+
+// java.lang.Float.parseFloat grammar (FloatingDecimal.readJavaFormatString); value by glibc strtof, which is
+// correctly rounded to binary32 like the JDK's.
+bool parse_float_token(const char *s, size_t n, float &out) {
+  char buf[160];
+  if (n == 0 || n >= sizeof(buf) - 1) return false;
+  size_t i = 0;
+  bool neg = false;
+  if (s[i] == '+' || s[i] == '-') { neg = s[i] == '-'; ++i; }
+  if (i >= n) return false;
+  if (n - i == 3 && !memcmp(s + i, "NaN", 3)) { out = NAN; return true; }
+  if (n - i == 8 && !memcmp(s + i, "Infinity", 8)) { out = neg ? -INFINITY : INFINITY; return true; }
+  size_t end = n;
+  const bool hex = n - i >= 2 && s[i] == '0' && (s[i + 1] == 'x' || s[i + 1] == 'X');
+  const char last = s[end - 1];
+  if (last == 'f' || last == 'F' || last == 'd' || last == 'D') {
+    if (!hex) --end;
+    else {
+      bool seen_p = false;
+      for (size_t t = i; t < end; ++t) seen_p |= (s[t] == 'p' || s[t] == 'P');
+      if (seen_p) --end;
+    }
+  }
+  size_t j = i;
+  int digits = 0;
+  if (hex) {
+    j += 2;
+    while (j < end && is_hex_digit(s[j])) { ++j; ++digits; }
+    if (j < end && s[j] == '.') { ++j; while (j < end && is_hex_digit(s[j])) { ++j; ++digits; } }
+    if (!digits || j >= end || (s[j] != 'p' && s[j] != 'P')) return false;
+    ++j;
+    if (j < end && (s[j] == '+' || s[j] == '-')) ++j;
+    int ed = 0;
+    while (j < end && s[j] >= '0' && s[j] <= '9') { ++j; ++ed; }
+    if (!ed || j != end) return false;
+  } else {
+    while (j < end && s[j] >= '0' && s[j] <= '9') { ++j; ++digits; }
+    if (j < end && s[j] == '.') { ++j; while (j < end && s[j] >= '0' && s[j] <= '9') { ++j; ++digits; } }
+    if (!digits) return false;
+    if (j < end && (s[j] == 'e' || s[j] == 'E')) {
+      ++j;
+      if (j < end && (s[j] == '+' || s[j] == '-')) ++j;
+      int ed = 0;
+      while (j < end && s[j] >= '0' && s[j] <= '9') { ++j; ++ed; }
+      if (!ed) return false;
+    }
+    if (j != end) return false;
+  }
+  memcpy(buf, s, end);
+  buf[end] = 0;
+  char *ep = nullptr;
+  float v = strtof(buf, &ep);
+  if (ep != buf + end) return false;
+  out = v;
+  return true;
+}
+
+struct Chunk {
+  std::vector<int32_t> src, dst, pid;
+  std::vector<float> w;
+  int64_t first_line = 0, n_lines = 0;
+  int64_t bad_line = -1;  // 1-based, relative to chunk start
+  std::string bad_msg;
+};
+
+// Parses the records that START in [b, e).  `data` spans the whole file.
+void parse_range(const char *data, size_t size, size_t b, size_t e, bool weighted, bool partitioned, Chunk &out) {
+  size_t pos = b;
+  // a range that begins right after the \r of a \r\n pair must not treat the \n as an empty record
+  if (pos > 0 && pos < size && data[pos] == '\n' && data[pos - 1] == '\r') ++pos;
+  const int wcols = partitioned ? 3 : 2;
+  while (pos < e && pos < size) {
+    size_t lb = pos;
+    while (pos < size && data[pos] != '\n' && data[pos] != '\r') ++pos;
+    size_t le = pos;
+    if (pos < size) pos += (data[pos] == '\r' && pos + 1 < size && data[pos + 1] == '\n') ? 2 : 1;
+    ++out.n_lines;
+    // tokenise
+    const char *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *tl = nullptr;
+    size_t l0 = 0, l1 = 0, l2 = 0, ll = 0;
+    int np = 0;
+    size_t i = lb;
+    if (le == lb) { np = 1; t0 = data + lb; l0 = 0; }           // "".split -> [""]
+    else {
+      if (java_ws((unsigned char)data[lb])) { np = 1; t0 = data + lb; l0 = 0; }  // leading "" token
+      while (i < le) {
+        while (i < le && java_ws((unsigned char)data[i])) ++i;
+        if (i >= le) break;
+        size_t tb = i;
+        while (i < le && !java_ws((unsigned char)data[i])) ++i;
+        const char *tp = data + tb; size_t tn = i - tb;
+        if (np == 0) { t0 = tp; l0 = tn; } else if (np == 1) { t1 = tp; l1 = tn; } else if (np == 2) { t2 = tp; l2 = tn; }
+        tl = tp; ll = tn;
+        ++np;
+      }
+      if (np == 1 && l0 == 0) np = 0;                             // all-whitespace line -> []
+    }
+    if (np < 2) { out.bad_line = out.n_lines; out.bad_msg = "fewer than two columns (ArrayIndexOutOfBounds / NumberFormatException in the reference)"; return; }
+    float w = 1.0f;
+    if (weighted && np > wcols) { float f; if (parse_float_token(tl, ll, f)) w = f; }
+    int32_t pid = -1;
+    if (partitioned && np > 2) { int32_t pv; if (parse_int_token(t2, l2, pv)) pid = pv; }
+    int32_t s, d;
+    if (!parse_int_token(t0, l0, s) || !parse_int_token(t1, l1, d)) {
+      out.bad_line = out.n_lines; out.bad_msg = "NumberFormatException for vertex id"; return;
+    }
+    out.src.push_back(s); out.dst.push_back(d); out.w.push_back(w); out.pid.push_back(pid);
+  }
+}
+
+}  // namespace
+
+void parse_edgelist_file(const char *path, bool weighted, bool partitioned, ParsedLines &out) {
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) throw Error(SRW_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); throw Error(SRW_ERR_IO, std::string("cannot stat ") + path); }
+  size_t size = (size_t)sb.st_size;
+  out = ParsedLines();
+  if (size == 0) { close(fd); return; }
+  const char *data = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (data == MAP_FAILED) throw Error(SRW_ERR_IO, std::string("cannot mmap ") + path);
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t nthreads = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, size / (1 << 20) + 1));
+  // split points: each range starts at a record start
+  std::vector<size_t> cut(nthreads + 1, size);
+  cut[0] = 0;
+  for (size_t t = 1; t < nthreads; ++t) {
+    size_t p = size / nthreads * t;
+    while (p < size && data[p - 1] != '\n' && data[p - 1] != '\r') ++p;
+    if (p < size && data[p] == '\n' && data[p - 1] == '\r') ++p;
+    cut[t] = std::max(p, cut[t - 1]);
+  }
+  std::vector<Chunk> chunks(nthreads);
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nthreads; ++t)
+    th.emplace_back([&, t] { parse_range(data, size, cut[t], cut[t + 1], weighted, partitioned, chunks[t]); });
+  for (auto &x : th) x.join();
+  munmap((void *)data, size);
+  int64_t lines_before = 0;
+  size_t total = 0;
+  for (auto &c : chunks) {
+    if (c.bad_line >= 0)
+      throw Error(SRW_ERR_PARSE, "line " + std::to_string(lines_before + c.bad_line) + ": " + c.bad_msg);
+    lines_before += c.n_lines;
+    total += c.src.size();
+  }
+  out.src.reserve(total); out.dst.reserve(total); out.w.reserve(total); out.pid.reserve(total);
+  for (auto &c : chunks) {
+    out.src.insert(out.src.end(), c.src.begin(), c.src.end());
+    out.dst.insert(out.dst.end(), c.dst.begin(), c.dst.end());
+    out.w.insert(out.w.end(), c.w.begin(), c.w.end());
+    out.pid.insert(out.pid.end(), c.pid.begin(), c.pid.end());
+  }
+}
+
+}  // namespace srw

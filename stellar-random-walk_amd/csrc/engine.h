@@ -1,0 +1,139 @@
+// engine.h — host-side state behind srw_handle and the internal interfaces between translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/stellar_rw.h"
+#include "device_common.h"
+
+namespace srw {
+
+struct Error : std::runtime_error {
+  int32_t code;
+  Error(int32_t c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define SRW_HIP(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      throw ::srw::Error(SRW_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+  } while (0)
+
+// RAII device buffer.
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e != hipSuccess)
+      throw Error(e == hipErrorOutOfMemory ? SRW_ERR_NOMEM : SRW_ERR_HIP,
+                  std::string("hipMalloc(") + std::to_string(count * sizeof(T)) + " B): " + hipGetErrorString(e));
+    n = count;
+  }
+  void ensure(size_t count) { if (count > n) alloc(count); }
+};
+
+struct Graph {
+  bool loaded = false;
+  int32_t vmin = 0, vmax = -1;
+  int64_t n_slots = 0;
+  int64_t n_lines = 0;
+  int64_t n_entries_global = 0;   // "edges: N" of the whole graph
+  int64_t n_entries = 0;          // entries stored on this handle (== global when world == 1)
+  int64_t n_vertices = 0;         // present vertices of the whole graph
+  int64_t n_local_vertices = 0;   // present vertices owned by this handle
+  DevBuf<Row> rows;               // [n_slots]
+  DevBuf<Ent> ent;                // [n_entries]
+  DevBuf<uint32_t> sids;          // [n_entries]
+  DevBuf<FoEnt> fo;               // [n_entries], built lazily
+  bool has_fo = false;
+  DevBuf<int32_t> verts;          // owned present vertices, ascending
+  DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
+  std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
+  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, has_fo ? fo.p : nullptr, vmin, n_slots}; }
+};
+
+struct WalkResult {
+  DevBuf<int32_t> paths, lens;
+  int64_t n_walkers = 0;
+  int32_t stride = 0;
+  bool valid = false;
+};
+
+struct DevCounters {  // device-side accumulators, one 64-bit word each
+  unsigned long long steps, dead_ends, sum_deg_curr, sum_deg_prev, ent_reads, fallbacks, owned_entries, pad;
+};
+
+}  // namespace srw
+
+struct srw_handle {
+  srw_config cfg{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string last_error;
+  srw::Graph g;
+  srw::WalkResult res;
+  srw::DevBuf<srw::DevCounters> counters;
+  srw::DevBuf<unsigned long long> shard_counts;  // [world] bucket counters / cursors for srw_shard_step
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace srw {
+
+// ---- edgelist.cpp (host) ----
+struct ParsedLines {
+  std::vector<int32_t> src, dst, pid;
+  std::vector<float> w;
+};
+void parse_edgelist_file(const char *path, bool weighted, bool partitioned, ParsedLines &out);
+
+// ---- writer.cpp (host) ----
+void write_path_files(const int32_t *paths, const int32_t *lens, int64_t n_walkers, int64_t stride,
+                      const char *output_dir, int n_parts, bool write_crc);
+
+// ---- graph_build.hip ----
+// Lines already on the device (d_src/d_dst/d_w; d_w may be null = 1.0f).  Builds rows/ent/sids/verts.
+void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
+                                   int64_t n_lines, bool directed, int32_t vmin, int32_t vmax);
+void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_t *offs, int64_t n_rows,
+                                const int32_t *ids, const float *w);
+void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,
+                         DevBuf<int32_t> &d_src, DevBuf<int32_t> &d_dst, DevBuf<float> &d_w);
+void build_first_order_tables(srw_handle *h);
+
+// ---- walk_kernels.hip ----
+void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats);
+void run_shard_seed(srw_handle *h, int32_t iter_in_call, Walker *d_out, int64_t *n_out, int32_t *d_paths,
+                    int64_t stride);
+void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32_t step, const Walker *d_in,
+                    int64_t n_in, Walker *d_out, int64_t *counts_out, int32_t *d_paths, int64_t stride,
+                    srw_walk_stats *stats);
+void hook_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index);
+void hook_second_order(srw_handle *h, float p, float q, int32_t prev_id, const int32_t *prev_ids, int64_t n_prev,
+                       const int32_t *curr_ids, const float *curr_w, int64_t n, float r, float *out_w,
+                       int64_t *index);
+void hook_rng(srw_handle *h, uint32_t seed, const uint32_t *iter, const uint32_t *src, const uint32_t *step,
+              int64_t n, float *out);
+
+}  // namespace srw

@@ -1,0 +1,310 @@
+// graph_build.hip — COO lines -> CSR in HBM, entirely on the device (gfx950).
+//
+// Replaces the adjacency assembly of the reference: flatMap + reduceByKey(_ ++ _) + partitionBy
+// (M/algorithm/UniformRandomWalk.scala:26-42, M/algorithm/VCutRandomWalk.scala:19-54) and the GraphMap
+// fill (M/algorithm/GraphMap.scala:23-64).  The neighbor list of v is the concatenation, in input-line
+// order, of every line's contribution to v, so the entry stream [(src_i -> dst_i), (dst_i -> src_i)]_i is
+// STABLY sorted by owning vertex (rocPRIM LSD radix sort is stable).  HBM-bound integer work: no MFMA.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <unordered_set>
+
+#include "engine.h"
+
+namespace srw {
+namespace {
+
+constexpr uint32_t KEY_SENTINEL = 0xFFFFFFFFu;
+constexpr int TPB = 256;
+
+inline int grid_for(int64_t n, int cap = 256 * 8 * 4) {
+  int64_t b = (n + TPB - 1) / TPB;
+  if (b < 1) b = 1;
+  return (int)std::min<int64_t>(b, cap);
+}
+
+__device__ inline uint64_t pack_ent(int32_t id, float w) {
+  return ((uint64_t)__float_as_uint(w) << 32) | (uint32_t)id;
+}
+
+// One line -> one (directed) or two (undirected) adjacency entries, in line order.
+__global__ void k_expand(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                         const float *__restrict__ w, int64_t n_lines, int directed, int32_t vmin, int32_t rank,
+                         int32_t world, uint32_t *__restrict__ keys, uint64_t *__restrict__ vals,
+                         uint32_t *__restrict__ present, unsigned long long *owned) {
+  unsigned long long cnt = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_lines; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t s = src[i], d = dst[i];
+    float ww = w ? w[i] : 1.0f;
+    uint32_t ks = (uint32_t)((int64_t)s - vmin), kd = (uint32_t)((int64_t)d - vmin);
+    present[ks] = 1u;
+    present[kd] = 1u;
+    bool os = world == 1 || owner_of(s, world) == rank;
+    if (directed) {
+      keys[i] = os ? ks : KEY_SENTINEL;
+      vals[i] = pack_ent(d, ww);
+      cnt += os;
+    } else {
+      bool od = world == 1 || owner_of(d, world) == rank;
+      keys[2 * i] = os ? ks : KEY_SENTINEL;
+      vals[2 * i] = pack_ent(d, ww);
+      keys[2 * i + 1] = od ? kd : KEY_SENTINEL;
+      vals[2 * i + 1] = pack_ent(s, ww);
+      cnt += (unsigned)os + (unsigned)od;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(owned, cnt);
+}
+
+__global__ void k_rows_init(Row *rows, const uint32_t *present, int64_t n_slots) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
+    Row r; r.off = 0; r.deg = 0; r.flags = present[v] ? ROW_PRESENT : 0u;
+    rows[v] = r;
+  }
+}
+__global__ void k_rows_start(const uint32_t *__restrict__ keys, int64_t n, Row *rows) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    if (e == 0 || keys[e] != keys[e - 1]) rows[keys[e]].off = e;
+}
+__global__ void k_rows_deg(const uint32_t *__restrict__ keys, int64_t n, Row *rows) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    if (e == n - 1 || keys[e + 1] != keys[e]) rows[keys[e]].deg = (int32_t)(e + 1 - rows[keys[e]].off);
+}
+
+__global__ void k_member_keys(const uint32_t *__restrict__ keys, const Ent *__restrict__ ent, int64_t n, int32_t vmin,
+                              uint64_t *__restrict__ out) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = ((uint64_t)keys[e] << 32) | (uint32_t)((int64_t)ent[e].id - vmin);
+}
+__global__ void k_low32(const uint64_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = (uint32_t)in[e];
+}
+
+__global__ void k_owned_flags(const uint32_t *__restrict__ present, int64_t n_slots, int32_t vmin, int32_t rank,
+                              int32_t world, uint32_t *__restrict__ out) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x)
+    out[v] = (present[v] && owner_of((int32_t)(v + vmin), world) == rank) ? 1u : 0u;
+}
+__global__ void k_scatter_verts(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ local_pos,
+                                const uint32_t *__restrict__ global_pos, int64_t n_slots, int32_t vmin,
+                                int32_t *__restrict__ verts, int32_t *__restrict__ vrank) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x)
+    if (flags[v]) {
+      verts[local_pos[v]] = (int32_t)(v + vmin);
+      vrank[local_pos[v]] = (int32_t)global_pos[v];
+    }
+}
+
+// RMAT edge i = f(seed, i): 4 levels per Philox call; quadrant thresholds floor({.57,.76,.95} * 2^32).
+// Same arithmetic as oracle/srw_oracle.c:orc_rmat_edges / orc_rmat_weight (build-defined synthetic input).
+__global__ void k_rmat(int32_t scale, uint32_t seed, int64_t n_edges, int weighted, int32_t *__restrict__ src,
+                       int32_t *__restrict__ dst, float *__restrict__ w) {
+  const uint32_t T1 = 2448131358u, T2 = 3264175144u, T3 = 4080218930u;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_edges; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t e = (uint64_t)i;
+    uint32_t s = 0, d = 0, o[4] = {0, 0, 0, 0};
+    for (int l = 0; l < scale; ++l) {
+      if ((l & 3) == 0) philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)(l >> 2), 0x524D4154u, seed, 1u, o);
+      uint32_t x = o[l & 3];
+      uint32_t rb = (x >= T2), cb = ((x >= T1 && x < T2) || (x >= T3)) ? 1u : 0u;
+      s = (s << 1) | rb;
+      d = (d << 1) | cb;
+    }
+    src[i] = (int32_t)s;
+    dst[i] = (int32_t)d;
+    if (weighted) {
+      uint32_t a = s < d ? s : d, b = s < d ? d : s;
+      uint32_t x = b * 0x85EBCA77u;
+      uint32_t hsh = seed ^ (a * 0x9E3779B1u) ^ ((x << 13) | (x >> 19));
+      hsh ^= hsh >> 16; hsh *= 0x85EBCA6Bu; hsh ^= hsh >> 13; hsh *= 0xC2B2AE35u; hsh ^= hsh >> 16;
+      w[i] = (float)(1u + (hsh & 15u));
+    }
+  }
+}
+
+int bits_for(uint64_t max_value) {
+  int b = 1;
+  while (b < 64 && (max_value >> b)) ++b;
+  return b;
+}
+
+// keys/vals: n_total unsorted entries; n_owned of them carry a real key.  present: [n_slots] flags.
+void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals, int64_t n_total, int64_t n_owned,
+                  DevBuf<uint32_t> &present, int32_t vmin, int32_t vmax, bool sharded) {
+  hipStream_t st = h->stream;
+  Graph &g = h->g;
+  g.vmin = vmin; g.vmax = vmax;
+  g.n_slots = (int64_t)vmax - (int64_t)vmin + 1;
+  g.n_entries = n_owned;
+  g.has_fo = false;
+  g.fo.release();
+
+  // 1. stable sort of the entry stream by owning vertex
+  DevBuf<uint32_t> keys2; DevBuf<uint64_t> vals2; DevBuf<char> temp;
+  keys2.alloc((size_t)n_total); vals2.alloc((size_t)n_total);
+  int key_bits = sharded ? 32 : bits_for((uint64_t)std::max<int64_t>(g.n_slots - 1, 1));
+  if (n_total > 0) {
+    size_t tb = 0;
+    SRW_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, vals.p, vals2.p, (size_t)n_total, 0u,
+                                      (unsigned)key_bits, st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::radix_sort_pairs((void *)temp.p, tb, keys.p, keys2.p, vals.p, vals2.p, (size_t)n_total, 0u,
+                                      (unsigned)key_bits, st));
+  }
+  SRW_HIP(hipStreamSynchronize(st));
+  keys.release(); vals.release(); temp.release();
+
+  // 2. payload: the sorted values ARE the {id, w} records
+  if (n_owned == n_total) {
+    g.ent.release();
+    g.ent.p = reinterpret_cast<Ent *>(vals2.p); g.ent.n = vals2.n;
+    vals2.p = nullptr; vals2.n = 0;
+  } else {
+    g.ent.alloc((size_t)n_owned);
+    if (n_owned) SRW_HIP(hipMemcpyAsync(g.ent.p, vals2.p, (size_t)n_owned * sizeof(Ent), hipMemcpyDeviceToDevice, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    vals2.release();
+  }
+
+  // 3. row table
+  g.rows.alloc((size_t)g.n_slots);
+  hipLaunchKernelGGL(k_rows_init, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, g.rows.p, present.p, g.n_slots);
+  if (n_owned) {
+    hipLaunchKernelGGL(k_rows_start, dim3(grid_for(n_owned)), dim3(TPB), 0, st, keys2.p, n_owned, g.rows.p);
+    hipLaunchKernelGGL(k_rows_deg, dim3(grid_for(n_owned)), dim3(TPB), 0, st, keys2.p, n_owned, g.rows.p);
+  }
+
+  // 4. per-row sorted ids (membership structure for computeSecondOrderWeights' `exists`)
+  g.sids.alloc((size_t)n_owned);
+  if (n_owned) {
+    DevBuf<uint64_t> mk, mk2;
+    mk.alloc((size_t)n_owned); mk2.alloc((size_t)n_owned);
+    hipLaunchKernelGGL(k_member_keys, dim3(grid_for(n_owned)), dim3(TPB), 0, st, keys2.p, g.ent.p, n_owned, vmin, mk.p);
+    int id_bits = bits_for((uint64_t)std::max<int64_t>(g.n_slots - 1, 1));
+    size_t tb = 0;
+    SRW_HIP(rocprim::radix_sort_keys(nullptr, tb, mk.p, mk2.p, (size_t)n_owned, 0u, (unsigned)(32 + id_bits), st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::radix_sort_keys((void *)temp.p, tb, mk.p, mk2.p, (size_t)n_owned, 0u, (unsigned)(32 + id_bits), st));
+    hipLaunchKernelGGL(k_low32, dim3(grid_for(n_owned)), dim3(TPB), 0, st, mk2.p, n_owned, g.sids.p);
+    SRW_HIP(hipStreamSynchronize(st));
+  }
+  keys2.release(); temp.release();
+
+  // 5. vertex list (walker seeds, ascending id) + global ranks
+  DevBuf<uint32_t> gpos, lflags, lpos;
+  gpos.alloc((size_t)g.n_slots);
+  size_t tb = 0;
+  SRW_HIP(rocprim::exclusive_scan(nullptr, tb, present.p, gpos.p, 0u, (size_t)g.n_slots, rocprim::plus<uint32_t>(), st));
+  temp.alloc(tb);
+  SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, present.p, gpos.p, 0u, (size_t)g.n_slots, rocprim::plus<uint32_t>(), st));
+  uint32_t last_pos = 0, last_flag = 0;
+  SRW_HIP(hipMemcpyAsync(&last_pos, gpos.p + (g.n_slots - 1), 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipMemcpyAsync(&last_flag, present.p + (g.n_slots - 1), 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  g.n_vertices = (int64_t)last_pos + last_flag;
+  const uint32_t *flags_p = present.p; const uint32_t *lpos_p = gpos.p;
+  g.n_local_vertices = g.n_vertices;
+  if (sharded) {
+    lflags.alloc((size_t)g.n_slots); lpos.alloc((size_t)g.n_slots);
+    hipLaunchKernelGGL(k_owned_flags, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, present.p, g.n_slots, vmin,
+                       h->cfg.rank, h->cfg.world, lflags.p);
+    SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, lflags.p, lpos.p, 0u, (size_t)g.n_slots, rocprim::plus<uint32_t>(), st));
+    SRW_HIP(hipMemcpyAsync(&last_pos, lpos.p + (g.n_slots - 1), 4, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipMemcpyAsync(&last_flag, lflags.p + (g.n_slots - 1), 4, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    g.n_local_vertices = (int64_t)last_pos + last_flag;
+    flags_p = lflags.p; lpos_p = lpos.p;
+  }
+  g.verts.alloc((size_t)g.n_local_vertices);
+  g.vrank.alloc((size_t)g.n_local_vertices);
+  hipLaunchKernelGGL(k_scatter_verts, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, flags_p, lpos_p, gpos.p, g.n_slots,
+                     vmin, g.verts.p, g.vrank.p);
+  SRW_HIP(hipStreamSynchronize(st));
+  SRW_HIP(hipGetLastError());
+  g.loaded = true;
+}
+
+}  // namespace
+
+void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
+                                   int64_t n_lines, bool directed, int32_t vmin, int32_t vmax) {
+  if (n_lines <= 0) throw Error(SRW_ERR_INVALID, "empty edge list");
+  int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
+  if (n_slots <= 0 || n_slots >= (int64_t)0xFFFFFFFEll) throw Error(SRW_ERR_INVALID, "vertex id range too large");
+  hipStream_t st = h->stream;
+  Graph &g = h->g;
+  g = Graph();
+  g.n_lines = n_lines;
+  int64_t n_total = directed ? n_lines : 2 * n_lines;
+  g.n_entries_global = n_total;
+  bool sharded = h->cfg.world > 1;
+
+  DevBuf<uint32_t> keys, present; DevBuf<uint64_t> vals;
+  keys.alloc((size_t)n_total); vals.alloc((size_t)n_total); present.alloc((size_t)n_slots);
+  SRW_HIP(hipMemsetAsync(present.p, 0, (size_t)n_slots * 4, st));
+  h->counters.ensure(1);
+  SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
+  hipLaunchKernelGGL(k_expand, dim3(grid_for(n_lines)), dim3(TPB), 0, st, d_src, d_dst, d_w, n_lines, directed ? 1 : 0,
+                     vmin, h->cfg.rank, h->cfg.world, keys.p, vals.p, present.p, &h->counters.p->owned_entries);
+  unsigned long long owned = 0;
+  SRW_HIP(hipMemcpyAsync(&owned, &h->counters.p->owned_entries, 8, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  finish_build(h, keys, vals, n_total, (int64_t)owned, present, vmin, vmax, sharded);
+}
+
+void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_t *offs, int64_t n_rows,
+                                const int32_t *ids, const float *w) {
+  if (n_rows <= 0) throw Error(SRW_ERR_INVALID, "no vertices");
+  if (h->cfg.world > 1) throw Error(SRW_ERR_INVALID, "srw_load_adjacency needs world == 1");
+  // GraphMap.addVertex: first occurrence of a vertex wins (GraphMap.scala:24-25,37).
+  int32_t vmin = vids[0], vmax = vids[0];
+  int64_t n_ent_in = offs[n_rows];
+  for (int64_t i = 0; i < n_rows; ++i) { vmin = std::min(vmin, vids[i]); vmax = std::max(vmax, vids[i]); }
+  for (int64_t e = 0; e < n_ent_in; ++e) { vmin = std::min(vmin, ids[e]); vmax = std::max(vmax, ids[e]); }
+  int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
+  if (n_slots >= (int64_t)0xFFFFFFFEll) throw Error(SRW_ERR_INVALID, "vertex id range too large");
+  std::vector<uint32_t> hkeys; std::vector<uint64_t> hvals; std::vector<uint32_t> hpresent((size_t)n_slots, 0u);
+  hkeys.reserve((size_t)n_ent_in); hvals.reserve((size_t)n_ent_in);
+  for (int64_t i = 0; i < n_rows; ++i) {
+    uint32_t k = (uint32_t)((int64_t)vids[i] - vmin);
+    if (hpresent[k]) continue;
+    hpresent[k] = 1u;
+    for (int64_t e = offs[i]; e < offs[i + 1]; ++e) {
+      float ww = w ? w[e] : 1.0f; uint32_t wb; memcpy(&wb, &ww, 4);
+      hkeys.push_back(k);
+      hvals.push_back(((uint64_t)wb << 32) | (uint32_t)ids[e]);
+    }
+  }
+  hipStream_t st = h->stream;
+  Graph &g = h->g;
+  g = Graph();
+  int64_t n_total = (int64_t)hkeys.size();
+  g.n_lines = n_rows; g.n_entries_global = n_total;
+  DevBuf<uint32_t> keys, present; DevBuf<uint64_t> vals;
+  keys.alloc((size_t)n_total); vals.alloc((size_t)n_total); present.alloc((size_t)n_slots);
+  if (n_total) {
+    SRW_HIP(hipMemcpyAsync(keys.p, hkeys.data(), (size_t)n_total * 4, hipMemcpyHostToDevice, st));
+    SRW_HIP(hipMemcpyAsync(vals.p, hvals.data(), (size_t)n_total * 8, hipMemcpyHostToDevice, st));
+  }
+  SRW_HIP(hipMemcpyAsync(present.p, hpresent.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  finish_build(h, keys, vals, n_total, n_total, present, vmin, vmax, false);
+}
+
+void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,
+                         DevBuf<int32_t> &d_src, DevBuf<int32_t> &d_dst, DevBuf<float> &d_w) {
+  if (scale < 1 || scale > 30) throw Error(SRW_ERR_INVALID, "rmat scale must be in [1, 30]");
+  if (n_edges <= 0) throw Error(SRW_ERR_INVALID, "rmat n_edges must be > 0");
+  d_src.alloc((size_t)n_edges); d_dst.alloc((size_t)n_edges);
+  if (weighted) d_w.alloc((size_t)n_edges);
+  hipLaunchKernelGGL(k_rmat, dim3(grid_for(n_edges)), dim3(TPB), 0, h->stream, scale, seed, n_edges, weighted ? 1 : 0,
+                     d_src.p, d_dst.p, weighted ? d_w.p : nullptr);
+  SRW_HIP(hipGetLastError());
+}
+
+}  // namespace srw

@@ -1,0 +1,130 @@
+// random_walk.cpp — see random_walk.h.
+#include "random_walk.h"
+
+#include <iostream>
+
+namespace randomwalk {
+namespace algorithm {
+namespace {
+void check(srw_handle *h, int32_t rc, const char *what) {
+  if (rc != SRW_OK) throw std::runtime_error(std::string(what) + ": " + srw_last_error(h));
+}
+}  // namespace
+
+int64_t GraphMap::getNumVertices() const { int64_t v = 0, e = 0; srw_graph_stats(h_, &v, &e); return v; }
+int64_t GraphMap::getNumEdges() const { int64_t v = 0, e = 0; srw_graph_stats(h_, &v, &e); return e; }
+bool GraphMap::getNeighbors(int32_t vid, std::vector<std::pair<int32_t, float>> &out) const {
+  int64_t n = 0;
+  check(h_, srw_graph_neighbors(h_, vid, nullptr, nullptr, 0, &n), "getNeighbors");
+  out.clear();
+  if (n < 0) return false;
+  std::vector<int32_t> ids((size_t)n); std::vector<float> w((size_t)n);
+  if (n) check(h_, srw_graph_neighbors(h_, vid, ids.data(), w.data(), n, &n), "getNeighbors");
+  for (int64_t k = 0; k < n; ++k) out.emplace_back(ids[(size_t)k], w[(size_t)k]);
+  return true;
+}
+bool GraphMap::getPartition(int32_t vid, int32_t &pid) const {
+  int32_t known = 0;
+  srw_graph_partition(h_, vid, &pid, &known);
+  return known != 0;
+}
+
+static void split(const std::vector<std::pair<int32_t, float>> &e, std::vector<int32_t> &ids, std::vector<float> &w) {
+  ids.resize(e.size()); w.resize(e.size());
+  for (size_t k = 0; k < e.size(); ++k) { ids[k] = e[k].first; w[k] = e[k].second; }
+}
+
+std::pair<int32_t, float> RandomSample::sample(const std::vector<std::pair<int32_t, float>> &edges) const {
+  std::vector<int32_t> ids; std::vector<float> w; split(edges, ids, w);
+  int64_t k = 0;
+  check(h_, srw_sample(h_, w.data(), (int64_t)w.size(), nextFloat_(), &k), "sample");
+  return edges.at((size_t)k);
+}
+std::vector<std::pair<int32_t, float>> RandomSample::computeSecondOrderWeights(
+    float p, float q, int32_t prevId, const std::vector<std::pair<int32_t, float>> &prevNeighbors,
+    const std::vector<std::pair<int32_t, float>> &currNeighbors) const {
+  std::vector<int32_t> pi, ci; std::vector<float> pw, cw; split(prevNeighbors, pi, pw); split(currNeighbors, ci, cw);
+  std::vector<float> out(cw.size());
+  static const int32_t none = 0;
+  check(h_, srw_second_order_weights(h_, p, q, prevId, pi.empty() ? &none : pi.data(), (int64_t)pi.size(), ci.data(),
+                                     cw.data(), (int64_t)cw.size(), out.data()), "computeSecondOrderWeights");
+  std::vector<std::pair<int32_t, float>> r;
+  for (size_t k = 0; k < ci.size(); ++k) r.emplace_back(ci[k], out[k]);
+  return r;
+}
+std::pair<int32_t, float> RandomSample::secondOrderSample(float p, float q, int32_t prevId,
+                                                           const std::vector<std::pair<int32_t, float>> &prevNeighbors,
+                                                           const std::vector<std::pair<int32_t, float>> &currNeighbors) const {
+  std::vector<int32_t> pi, ci; std::vector<float> pw, cw; split(prevNeighbors, pi, pw); split(currNeighbors, ci, cw);
+  int64_t k = 0;
+  static const int32_t none = 0;
+  check(h_, srw_second_order_sample(h_, p, q, prevId, pi.empty() ? &none : pi.data(), (int64_t)pi.size(), ci.data(),
+                                    cw.data(), (int64_t)cw.size(), nextFloat_(), &k), "secondOrderSample");
+  return {ci.at((size_t)k), cw.at((size_t)k)};   // sample returns the biased tuple's id; weight of the original edge kept for reference
+}
+
+RandomWalk::RandomWalk(const Params &config, std::ostream *log) : config_(config), log_(log) {
+  srw_config c{};
+  c.device = config.device; c.rank = 0; c.world = 1;
+  int32_t rc = srw_create(&c, &h_);
+  if (rc != SRW_OK) throw std::runtime_error(std::string("srw_create: ") + srw_last_error(nullptr));
+}
+RandomWalk::~RandomWalk() { srw_destroy(h_); }
+
+void RandomWalk::printGraphStats() {
+  check(h_, srw_graph_stats(h_, &nVertices, &nEdges), "graph stats");
+  if (log_) {
+    // UniformRandomWalk.scala:69-79 / VCutRandomWalk.scala:80-90.  One process = one "JVM": a single pair of totals.
+    *log_ << "edges: " << nEdges << "\n" << "vertices: " << nVertices << "\n"
+          << "E Partitions: " << nEdges << "\n" << "V Partitions: " << nVertices << "\n";
+  }
+}
+
+void UniformRandomWalk::loadGraph() {
+  check(h_, srw_load_edgelist(h_, config_.input.c_str(), config_.directed, config_.weighted, /*partitioned=*/0,
+                              config_.rddPartitions), "loadGraph");
+  printGraphStats();
+}
+void VCutRandomWalk::loadGraph() {
+  check(h_, srw_load_edgelist(h_, config_.input.c_str(), config_.directed, config_.weighted, config_.partitioned ? 1 : 0,
+                              config_.rddPartitions), "loadGraph");
+  printGraphStats();
+}
+
+Paths RandomWalk::walkImpl(bool useConst, float constR) {
+  Paths out;
+  out.stride = config_.walkLength + 2;
+  out.n = (int64_t)config_.numWalks * nVertices;
+  out.ids.resize((size_t)out.n * out.stride);
+  out.lens.resize((size_t)out.n);
+  for (int it = 0; it < config_.numWalks; ++it) {               // for (_ <- 0 until config.numWalks), :82
+    srw_walk_params P{};
+    P.p = (float)config_.p; P.q = (float)config_.q;             // .toFloat, :112
+    P.walk_length = config_.walkLength; P.num_walks = 1; P.first_walk = it;
+    P.rng_mode = useConst ? SRW_RNG_CONST : SRW_RNG_PHILOX; P.const_r = constR; P.seed = (uint32_t)config_.seed;
+    P.sampler = SRW_SAMPLER_REFERENCE;
+    srw_walk_stats st{};
+    check(h_, srw_walk(h_, &P, &st), "randomWalk");
+    check(h_, srw_fetch_paths(h_, out.ids.data() + (size_t)it * nVertices * out.stride,
+                              out.lens.data() + (size_t)it * nVertices), "fetch paths");
+    if (log_) {
+      *log_ << "Unfinished Walkers: 0\n";                       // :154 (one super-step per iteration on one GPU)
+      if (st.dead_ends) *log_ << "Wrong Transports: 0\n" << "Zero Neighbors: " << st.dead_ends << "\n";  // :155-160
+    }
+  }
+  return out;
+}
+Paths RandomWalk::randomWalk() { return walkImpl(config_.hasConstR, config_.constR); }
+Paths RandomWalk::randomWalk(float constR) { return walkImpl(true, constR); }
+
+void RandomWalk::save(const Paths &paths, int partitions, const std::string &output) const {
+  int32_t rc = srw_save_paths(paths.ids.data(), paths.lens.data(), paths.n, paths.stride, output.c_str(), partitions,
+                              config_.crc ? 1 : 0);
+  if (rc == SRW_ERR_EXISTS)
+    throw std::runtime_error("org.apache.hadoop.mapred.FileAlreadyExistsException: Output directory " + output + "/" +
+                             common::Property::pathSuffix + " already exists");
+  if (rc != SRW_OK) throw std::runtime_error("save failed");
+}
+
+}  // namespace algorithm
+}  // namespace randomwalk

@@ -1,0 +1,419 @@
+// walk_kernels.hip — the walk itself (gfx950).  Replaces RandomWalk.initFirstStep + the super-step loop of
+// RandomWalk.randomWalk (M/algorithm/RandomWalk.scala:51-66, 95-139).
+//
+//   k_walk_first_order   p == q == 1: one walker per LANE, all walk_length+1 steps in one launch, O(1)
+//                        exact sampling through the CDF+guide records (16 B, one sector per probe), paths
+//                        staged in LDS and flushed as 64-byte runs.  HBM-latency/sector bound gather.
+//   k_walk_general       any p, q: one walker per WAVE; the wave streams N(curr) coalesced (8 B/lane),
+//                        applies the node2vec bias with a binary search in the sorted N(prev), and evaluates
+//                        the reference's sequential f64 CDF exactly (sampling.h).
+//   k_shard_step         one super-step of the vertex-sharded multi-GPU path: same samplers, one step,
+//                        output records bucketed by owner(next) for the RCCL all-to-all.
+// No MFMA anywhere: integer/byte gather work bounded by HBM.
+#include <algorithm>
+#include <cstring>
+
+#include "engine.h"
+#include "sampling.h"
+
+namespace srw {
+namespace {
+
+constexpr int TPB = 256;
+constexpr int TILE = 16;  // path slots staged in LDS between flushes (64 B per walker per flush)
+
+__device__ inline const Row *row_of(const GraphView &g, int32_t v) {
+  int64_t s = (int64_t)v - g.vmin;
+  if (s < 0 || s >= g.n_slots) return nullptr;
+  return g.rows + s;
+}
+
+__device__ inline void flush_counters(DevCounters *ctr, unsigned long long steps, unsigned long long dead,
+                                      unsigned long long degc, unsigned long long degp, unsigned long long reads,
+                                      unsigned long long fb) {
+  steps = wave_sum_u64(steps); dead = wave_sum_u64(dead); degc = wave_sum_u64(degc);
+  degp = wave_sum_u64(degp); reads = wave_sum_u64(reads); fb = wave_sum_u64(fb);
+  if (lane_id() == 0) {
+    if (steps) atomicAdd(&ctr->steps, steps);
+    if (dead) atomicAdd(&ctr->dead_ends, dead);
+    if (degc) atomicAdd(&ctr->sum_deg_curr, degc);
+    if (degp) atomicAdd(&ctr->sum_deg_prev, degp);
+    if (reads) atomicAdd(&ctr->ent_reads, reads);
+    if (fb) atomicAdd(&ctr->fallbacks, fb);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_walk_first_order(GraphView g, const int32_t *__restrict__ verts,
+                                                          int64_t n_verts, int64_t n_walkers, int32_t L,
+                                                          int32_t first_walk, RngSpec rng,
+                                                          int32_t *__restrict__ paths, int32_t *__restrict__ lens,
+                                                          DevCounters *ctr) {
+  __shared__ int32_t tile[TPB / 64][64][TILE + 1];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const int64_t wi = blockIdx.x * (int64_t)TPB + threadIdx.x;
+  const int64_t wave_base = wi - lane;
+  const int64_t stride = (int64_t)L + 2;
+  bool alive = wi < n_walkers;
+  uint32_t iter = 0; int32_t src = 0;
+  if (alive) {
+    int64_t it = wi / n_verts, vi = wi - it * n_verts;
+    iter = (uint32_t)(first_walk + it);
+    src = verts[vi];
+  }
+  int32_t curr = src, len = 1;
+  unsigned long long reads = 0, dead = 0, fb = 0;
+  Bias nobias; nobias.second_order = false; nobias.need_member = false; nobias.p = nobias.q = 1.0f;
+  nobias.prev = 0; nobias.prev_sids = nullptr; nobias.prev_deg = 0; nobias.vmin = g.vmin;
+  tile[wv][lane][0] = src;
+  for (int32_t s = 1; s <= L + 1; ++s) {
+    const int c = s & (TILE - 1);
+    int32_t val = -1;
+    if (alive) {
+      const Row *rp = row_of(g, curr);
+      Row r; r.off = 0; r.deg = 0; r.flags = 0;
+      if (rp) r = *rp;
+      if (r.deg == 0) {
+        alive = false; if (s > 1) ++dead;                      // dead end, RandomWalk.scala:115-120 (acc2 counts the loop only)
+      } else {
+        float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
+        int32_t next;
+        if (r.flags & ROW_IRREGULAR) {
+          int32_t k = lane_pick_sequential(g.ent + r.off, r.deg, nobias, u);
+          next = g.ent[r.off + k].id; ++fb;
+        } else {
+          unsigned rd; fo_pick(g.fo + r.off, r.deg, u, next, rd); reads += rd;
+        }
+        val = next; curr = next; ++len;
+      }
+    }
+    tile[wv][lane][c] = val;
+    if (c == TILE - 1 || s == L + 1) {
+      const int ncols = c + 1;
+      const int64_t base_slot = s - c;
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        int row = rr * 4 + (lane >> 4), col = lane & 15;
+        int64_t w = wave_base + row;
+        if (col < ncols && w < n_walkers) paths[w * stride + base_slot + col] = tile[wv][row][col];
+      }
+      __syncthreads();
+    }
+  }
+  if (wi < n_walkers) lens[wi] = len;
+  flush_counters(ctr, (unsigned long long)(len - 1), dead, 0, 0, reads, fb);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline Bias make_bias(const GraphView &g, float p, float q, int32_t prev, bool second_order) {
+  Bias b;
+  b.p = p; b.q = q; b.prev = prev; b.second_order = second_order;
+  b.need_member = second_order && (q != 1.0f);
+  b.prev_sids = nullptr; b.prev_deg = 0; b.vmin = g.vmin;
+  if (b.need_member) {
+    const Row *pr = row_of(g, prev);
+    if (pr) { Row r = *pr; b.prev_sids = g.sids + r.off; b.prev_deg = r.deg; }
+  }
+  return b;
+}
+
+__global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t *__restrict__ verts,
+                                                      int64_t n_verts, int64_t n_walkers, int32_t L,
+                                                      int32_t first_walk, RngSpec rng, float p, float q,
+                                                      int32_t *__restrict__ paths, int32_t *__restrict__ lens,
+                                                      DevCounters *ctr) {
+  const int lane = lane_id();
+  const int64_t wi = (blockIdx.x * (int64_t)TPB + threadIdx.x) >> 6;  // one wave per walker
+  if (wi >= n_walkers) return;
+  const int64_t stride = (int64_t)L + 2;
+  int64_t it = wi / n_verts, vi = wi - it * n_verts;
+  const uint32_t iter = (uint32_t)(first_walk + it);
+  const int32_t src = verts[vi];
+  int32_t *path = paths + wi * stride;
+  if (lane == 0) path[0] = src;
+  int32_t prev = src, curr = src, len = 1;
+  unsigned long long degc = 0, degp = 0, fb = 0, dead = 0;
+  for (int32_t s = 1; s <= L + 1; ++s) {
+    const Row *rp = row_of(g, curr);
+    Row r; r.off = 0; r.deg = 0; r.flags = 0;
+    if (rp) r = *rp;
+    if (r.deg == 0) { dead = s > 1; break; }
+    Bias b = make_bias(g, p, q, prev, s > 1);
+    float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
+    unsigned f = 0;
+    int32_t k = wave_pick(g.ent + r.off, r.deg, b, u, f);
+    int32_t next = g.ent[r.off + k].id;
+    degc += (unsigned long long)r.deg; fb += f;
+    if (b.need_member) degp += (unsigned long long)b.prev_deg;
+    if (lane == 0) path[s] = next;
+    prev = curr; curr = next; ++len;
+  }
+  for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
+  if (lane == 0) {
+    lens[wi] = len;
+    atomicAdd(&ctr->steps, (unsigned long long)(len - 1));
+    if (dead) atomicAdd(&ctr->dead_ends, dead);
+    atomicAdd(&ctr->sum_deg_curr, degc);
+    if (degp) atomicAdd(&ctr->sum_deg_prev, degp);
+    if (fb) atomicAdd(&ctr->fallbacks, fb);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Vertex-sharded super-step.  mode 0: count survivors per destination owner; mode 1: emit them.
+// One wave per record keeps the sampler identical to k_walk_general (bit-identical paths for any world).
+__global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *__restrict__ in, int64_t n_in,
+                                                    int64_t n_verts_global, int32_t first_walk, int32_t step,
+                                                    RngSpec rng, float p, float q, int32_t world,
+                                                    Walker *__restrict__ out, unsigned long long *cursors,
+                                                    int32_t *__restrict__ paths, int64_t stride, DevCounters *ctr) {
+  const int lane = lane_id();
+  const int64_t ri = (blockIdx.x * (int64_t)TPB + threadIdx.x) >> 6;
+  if (ri >= n_in) return;
+  Walker wk = in[ri];
+  const Row *rp = row_of(g, wk.curr);
+  Row r; r.off = 0; r.deg = 0; r.flags = 0;
+  if (rp) r = *rp;
+  if (r.deg == 0) {
+    if (lane == 0 && step > 1) atomicAdd(&ctr->dead_ends, 1ull);
+    return;
+  }
+  const uint32_t iter = (uint32_t)(first_walk + (int64_t)wk.wid / n_verts_global);
+  Bias b = make_bias(g, p, q, wk.prev, step > 1);
+  float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
+  unsigned f = 0;
+  int32_t k = wave_pick(g.ent + r.off, r.deg, b, u, f);
+  int32_t next = g.ent[r.off + k].id;
+  if (lane == 0) {
+    paths[(int64_t)wk.wid * stride + step] = next;
+    int32_t o = owner_of(next, world);
+    unsigned long long pos = atomicAdd(&cursors[o], 1ull);
+    Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
+    out[pos] = nw;
+    atomicAdd(&ctr->steps, 1ull);
+    atomicAdd(&ctr->sum_deg_curr, (unsigned long long)r.deg);
+    if (b.need_member) atomicAdd(&ctr->sum_deg_prev, (unsigned long long)b.prev_deg);
+    if (f) atomicAdd(&ctr->fallbacks, 1ull);
+  }
+}
+
+// pre-pass of the super-step: where will each record go?  (needs the sampled vertex, so the step kernel runs
+// once into a scratch ordering and k_shard_bucket reorders — see run_shard_step)
+__global__ void k_shard_count(const Walker *__restrict__ recs, int64_t n, int32_t world, unsigned long long *counts) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&counts[owner_of(recs[i].curr, world)], 1ull);
+}
+__global__ void k_shard_bucket(const Walker *__restrict__ recs, int64_t n, int32_t world, unsigned long long *cursors,
+                               Walker *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    Walker w = recs[i];
+    unsigned long long pos = atomicAdd(&cursors[owner_of(w.curr, world)], 1ull);
+    out[pos] = w;
+  }
+}
+
+__global__ void k_shard_seed(const int32_t *__restrict__ verts, const int32_t *__restrict__ vrank, int64_t n_local,
+                             int64_t n_verts_global, int32_t iter_in_call, Walker *__restrict__ out,
+                             int32_t *__restrict__ paths, int64_t stride) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_local; i += (int64_t)gridDim.x * blockDim.x) {
+    Walker w;
+    w.wid = (int32_t)((int64_t)iter_in_call * n_verts_global + vrank[i]);
+    w.src = verts[i]; w.prev = verts[i]; w.curr = verts[i];
+    out[i] = w;
+    if (paths) paths[(int64_t)w.wid * stride] = w.src;
+  }
+}
+
+// ---- unit hooks ------------------------------------------------------------------------------------------
+__global__ void k_hook_pick(const Ent *row, int32_t deg, Bias b, float r, float *out_w, int64_t *index) {
+  const int lane = lane_id();
+  if (out_w)
+    for (int32_t k = lane; k < deg; k += 64) out_w[k] = biased_weight(b, row[k].id, row[k].w);
+  if (index) {
+    unsigned f = 0;
+    int32_t k = wave_pick(row, deg, b, r, f);
+    if (lane == 0) *index = k;
+  }
+}
+__global__ void k_hook_rng(uint32_t seed, const uint32_t *iter, const uint32_t *src, const uint32_t *step, int64_t n,
+                           float *out) {
+  RngSpec rng; rng.mode = 1; rng.const_r = 0.f; rng.seed = seed;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = draw_uniform(rng, iter[i], src[i], step[i]);
+}
+
+void read_counters(srw_handle *h, srw_walk_stats *stats) {
+  DevCounters c;
+  SRW_HIP(hipMemcpyAsync(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  SRW_HIP(hipStreamSynchronize(h->stream));
+  if (!stats) return;
+  stats->n_steps = (int64_t)c.steps; stats->dead_ends = (int64_t)c.dead_ends;
+  stats->sum_deg_curr = (int64_t)c.sum_deg_curr; stats->sum_deg_prev = (int64_t)c.sum_deg_prev;
+  stats->ent_reads = (int64_t)c.ent_reads; stats->fallbacks = (int64_t)c.fallbacks;
+}
+
+void check_params(const srw_walk_params &P) {
+  if (P.walk_length < 0) throw Error(SRW_ERR_INVALID, "walk_length must be >= 0");
+  if (P.num_walks < 1) throw Error(SRW_ERR_INVALID, "num_walks must be >= 1");
+  if (P.rng_mode != SRW_RNG_CONST && P.rng_mode != SRW_RNG_PHILOX) throw Error(SRW_ERR_INVALID, "bad rng_mode");
+  if (P.sampler != SRW_SAMPLER_REFERENCE)
+    throw Error(SRW_ERR_INVALID, "sampler: only SRW_SAMPLER_REFERENCE (Mode R) is built in this round");
+}
+
+}  // namespace
+
+void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
+  Graph &g = h->g;
+  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
+  if (h->cfg.world != 1) throw Error(SRW_ERR_INVALID, "srw_walk needs a whole-graph handle (world == 1); use srw_shard_*");
+  check_params(P);
+  hipStream_t st = h->stream;
+  const int64_t n_walkers = (int64_t)P.num_walks * g.n_vertices;
+  if (n_walkers >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "more than 2^31 walkers in one call: lower num_walks");
+  const int32_t stride = P.walk_length + 2;
+  const bool first_order = (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
+  if (first_order) build_first_order_tables(h);
+  h->res.valid = false;
+  h->res.paths.ensure((size_t)n_walkers * stride);
+  h->res.lens.ensure((size_t)n_walkers);
+  h->res.n_walkers = n_walkers; h->res.stride = stride;
+  h->counters.ensure(1);
+  SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
+  RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
+  GraphView gv = g.view();
+  SRW_HIP(hipEventRecord(h->ev0, st));
+  if (first_order) {
+    int64_t blocks = (n_walkers + TPB - 1) / TPB;
+    hipLaunchKernelGGL(k_walk_first_order, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices,
+                       n_walkers, P.walk_length, P.first_walk, rng, h->res.paths.p, h->res.lens.p, h->counters.p);
+  } else {
+    int64_t blocks = (n_walkers * 64 + TPB - 1) / TPB;
+    hipLaunchKernelGGL(k_walk_general, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
+                       P.walk_length, P.first_walk, rng, P.p, P.q, h->res.paths.p, h->res.lens.p, h->counters.p);
+  }
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipEventRecord(h->ev1, st));
+  srw_walk_stats local;
+  srw_walk_stats *s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  read_counters(h, s);
+  float ms = 0.f;
+  SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  s->kernel_ms = ms; s->n_walkers = n_walkers; s->kernel_kind = first_order ? 1 : 2;
+  h->res.valid = true;
+}
+
+void run_shard_seed(srw_handle *h, int32_t iter_in_call, Walker *d_out, int64_t *n_out, int32_t *d_paths,
+                    int64_t stride) {
+  Graph &g = h->g;
+  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
+  int64_t n = g.n_local_vertices;
+  if (n > 0) {
+    int blocks = (int)std::min<int64_t>((n + TPB - 1) / TPB, 8192);
+    hipLaunchKernelGGL(k_shard_seed, dim3(blocks), dim3(TPB), 0, h->stream, g.verts.p, g.vrank.p, n, g.n_vertices,
+                       iter_in_call, d_out, d_paths, stride);
+    SRW_HIP(hipGetLastError());
+  }
+  SRW_HIP(hipStreamSynchronize(h->stream));
+  *n_out = n;
+}
+
+void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32_t step, const Walker *d_in,
+                    int64_t n_in, Walker *d_out, int64_t *counts_out, int32_t *d_paths, int64_t stride,
+                    srw_walk_stats *stats) {
+  (void)iter;
+  Graph &g = h->g;
+  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
+  check_params(P);
+  const int32_t world = h->cfg.world;
+  hipStream_t st = h->stream;
+  h->counters.ensure(1);
+  h->shard_counts.ensure((size_t)world * 2);
+  SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
+  SRW_HIP(hipMemsetAsync(h->shard_counts.p, 0, sizeof(unsigned long long) * world * 2, st));
+  std::vector<unsigned long long> counts((size_t)world, 0ull);
+  srw_walk_stats local; srw_walk_stats *s = stats ? stats : &local; memset(s, 0, sizeof(*s));
+  if (n_in > 0) {
+    // pass A: sample into a scratch buffer (cursor 0 only => dense, arbitrary order)
+    DevBuf<Walker> scratch; scratch.alloc((size_t)n_in);
+    RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
+    int64_t blocks = (n_in * 64 + TPB - 1) / TPB;
+    SRW_HIP(hipEventRecord(h->ev0, st));
+    hipLaunchKernelGGL(k_shard_step, dim3((unsigned)blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, g.n_vertices,
+                       P.first_walk, step, rng, P.p, P.q, /*world=*/1, scratch.p, h->shard_counts.p + world, d_paths,
+                       stride, h->counters.p);
+    SRW_HIP(hipEventRecord(h->ev1, st));
+    unsigned long long survivors = 0;
+    SRW_HIP(hipMemcpyAsync(&survivors, h->shard_counts.p + world, 8, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    // pass B: bucket by owner(next): count -> exclusive offsets -> scatter
+    if (survivors) {
+      int gb = (int)std::min<int64_t>(((int64_t)survivors + TPB - 1) / TPB, 8192);
+      hipLaunchKernelGGL(k_shard_count, dim3(gb), dim3(TPB), 0, st, scratch.p, (int64_t)survivors, world, h->shard_counts.p);
+      SRW_HIP(hipMemcpyAsync(counts.data(), h->shard_counts.p, 8 * world, hipMemcpyDeviceToHost, st));
+      SRW_HIP(hipStreamSynchronize(st));
+      std::vector<unsigned long long> cur((size_t)world, 0ull);
+      unsigned long long acc = 0;
+      for (int r = 0; r < world; ++r) { cur[r] = acc; acc += counts[r]; }
+      SRW_HIP(hipMemcpyAsync(h->shard_counts.p, cur.data(), 8 * world, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_shard_bucket, dim3(gb), dim3(TPB), 0, st, scratch.p, (int64_t)survivors, world, h->shard_counts.p, d_out);
+      SRW_HIP(hipStreamSynchronize(st));
+    }
+    SRW_HIP(hipGetLastError());
+    float ms = 0.f; SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    s->kernel_ms = ms;
+  }
+  read_counters(h, s);
+  s->kernel_kind = 2; s->n_walkers = n_in;
+  for (int r = 0; r < world; ++r) counts_out[r] = (int64_t)counts[r];
+}
+
+void hook_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index) {
+  hook_second_order(h, 1.0f, 1.0f, 0, nullptr, 0, nullptr, w, n, r, nullptr, index);
+}
+
+void hook_second_order(srw_handle *h, float p, float q, int32_t prev_id, const int32_t *prev_ids, int64_t n_prev,
+                       const int32_t *curr_ids, const float *curr_w, int64_t n, float r, float *out_w,
+                       int64_t *index) {
+  if (n <= 0) { if (index) *index = -1; return; }
+  if (n > 0x7FFFFFFF || n_prev > 0x7FFFFFFF) throw Error(SRW_ERR_INVALID, "list too long");
+  hipStream_t st = h->stream;
+  std::vector<Ent> row((size_t)n);
+  int32_t vmin = prev_id;
+  for (int64_t k = 0; k < n; ++k) { row[k].id = curr_ids ? curr_ids[k] : (int32_t)k; row[k].w = curr_w[k]; vmin = std::min(vmin, row[k].id); }
+  for (int64_t k = 0; k < n_prev; ++k) vmin = std::min(vmin, prev_ids[k]);
+  std::vector<uint32_t> sp((size_t)n_prev);
+  for (int64_t k = 0; k < n_prev; ++k) sp[k] = (uint32_t)((int64_t)prev_ids[k] - vmin);
+  std::sort(sp.begin(), sp.end());
+  DevBuf<Ent> d_row; DevBuf<uint32_t> d_sp; DevBuf<float> d_w; DevBuf<int64_t> d_idx;
+  d_row.alloc((size_t)n); d_sp.alloc((size_t)n_prev); d_w.alloc((size_t)n); d_idx.alloc(1);
+  SRW_HIP(hipMemcpyAsync(d_row.p, row.data(), (size_t)n * sizeof(Ent), hipMemcpyHostToDevice, st));
+  if (n_prev) SRW_HIP(hipMemcpyAsync(d_sp.p, sp.data(), (size_t)n_prev * 4, hipMemcpyHostToDevice, st));
+  Bias b; b.p = p; b.q = q; b.prev = prev_id; b.second_order = (prev_ids != nullptr) || (p != 1.0f) || (q != 1.0f);
+  b.need_member = b.second_order && q != 1.0f; b.prev_sids = d_sp.p; b.prev_deg = (int32_t)n_prev; b.vmin = vmin;
+  hipLaunchKernelGGL(k_hook_pick, dim3(1), dim3(64), 0, st, d_row.p, (int32_t)n, b, r, out_w ? d_w.p : nullptr,
+                     index ? d_idx.p : nullptr);
+  SRW_HIP(hipGetLastError());
+  if (out_w) SRW_HIP(hipMemcpyAsync(out_w, d_w.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (index) SRW_HIP(hipMemcpyAsync(index, d_idx.p, 8, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+}
+
+void hook_rng(srw_handle *h, uint32_t seed, const uint32_t *iter, const uint32_t *src, const uint32_t *step,
+              int64_t n, float *out) {
+  if (n <= 0) return;
+  hipStream_t st = h->stream;
+  DevBuf<uint32_t> a, b, c; DevBuf<float> o;
+  a.alloc((size_t)n); b.alloc((size_t)n); c.alloc((size_t)n); o.alloc((size_t)n);
+  SRW_HIP(hipMemcpyAsync(a.p, iter, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemcpyAsync(b.p, src, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemcpyAsync(c.p, step, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_hook_rng, dim3(blocks), dim3(256), 0, st, seed, a.p, b.p, c.p, n, o.p);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipMemcpyAsync(out, o.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+}
+
+}  // namespace srw

@@ -1,0 +1,76 @@
+// wave_primitives.h — 64-lane wavefront building blocks for the exact (reference-bit-identical) sampler.
+//
+// The reference's RandomSample.sample (M/algorithm/RandomSample.scala:12-25) is two LEFT-TO-RIGHT f64
+// accumulations.  A parallel scan rounds differently in the last ulps and flips the chosen neighbor whenever
+// the 24-bit uniform lands on a CDF boundary (SURVEY §8c "rounding known-answers"), so:
+//   * the sum  S = foldLeft(0.0)(_ + w)  is taken in parallel ONLY when a certificate proves that every
+//     partial sum in ANY order is exactly representable (then order cannot matter);
+//   * the running CDF  acc += w / S  is evaluated as a wave-uniform sequential chain: the 64 quotients of a
+//     chunk are computed in parallel (the expensive part: loads, bias, membership, f64 divide), then added in
+//     lane order with v_readlane + v_add_f64 — the same additions, in the same order, as the reference.
+#pragma once
+#include "device_common.h"
+
+namespace srw {
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ inline double readlane_f64(double v, int lane) {
+  uint64_t b = (uint64_t)__double_as_longlong(v);
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+__device__ inline double wave_sum_f64(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline int wave_min_i32(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline int wave_max_i32(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Exactness certificate for a sum of f32 values widened to f64.
+// Every nonzero finite f32 x with unbiased exponent e is an integer multiple of 2^(max(e,-126)-23).  If all
+// addends are multiples of u = 2^ue_min and n * 2^(e_max+1) <= 2^53 * u, then every partial sum, in any
+// order, is a multiple of u of magnitude < 2^53 * u — exactly representable — so no addition ever rounds
+// and the result equals the reference's left-to-right sum bit for bit.
+struct SumCert {
+  int emin;  // min over nonzero addends of max(e, -126)
+  int emax;  // max over nonzero addends of max(e, -126)
+  bool bad;  // NaN / Inf seen
+  __device__ SumCert() : emin(1 << 20), emax(-(1 << 20)), bad(false) {}
+  __device__ inline void add(float x) {
+    uint32_t b = __float_as_uint(x);
+    int ex = (int)((b >> 23) & 0xFFu);
+    if (ex == 255) { bad = true; return; }
+    if ((b & 0x7FFFFFFFu) == 0u) return;
+    int e = ex ? ex - 127 : -126;
+    emin = min(emin, e);
+    emax = max(emax, e);
+  }
+};
+
+__device__ inline int ceil_log2_i64(int64_t n) {
+  int b = 0;
+  while (((int64_t)1 << b) < n) ++b;
+  return b;
+}
+
+// true when the sum of `n` addends described by the (wave-reduced) certificate is order-independent
+__device__ inline bool sum_is_exact(int emin, int emax, bool bad, int64_t n) {
+  if (bad) return false;
+  if (emax < emin) return true;  // all zeros
+  return ceil_log2_i64(n) + emax - emin <= 29;  // log2(n) + e_max + 1 <= 53 + (e_min - 23)
+}
+
+}  // namespace srw

@@ -1,0 +1,297 @@
+"""GPU parity tests: the HIP path (through the C ABI) must equal the CPU oracle BIT FOR BIT on the same inputs.
+
+Run on the MI355X box with `pytest -m gpu`.  Every comparison is exact (integer ids / lengths); the only
+floating-point outputs (biased weights, RNG uniforms) are compared bitwise as well.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import KARATE, TESTGRAPH
+from helpers import digest, pkg, random_multigraph, rmat_lines
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = pkg().Engine(device=0)
+    yield e
+    e.close()
+
+
+def both_walk(eng, g, **kw):
+    paths, lens, st = eng.walk(**kw)
+    okw = {k: v for k, v in kw.items() if k != "force_general"}
+    rp, rl, rs = g.walk(**okw)
+    return (paths, lens, st), (rp, rl, rs)
+
+
+def assert_same(a, b, what=""):
+    (paths, lens, st), (rp, rl, rs) = a, b
+    assert np.array_equal(lens, rl), "lens differ " + what
+    bad = np.nonzero((paths != rp).any(axis=1))[0]
+    assert bad.size == 0, "paths differ %s: first at walker %d\n gpu=%s\n ref=%s" % (
+        what, bad[0] if bad.size else -1, paths[bad[0]] if bad.size else None, rp[bad[0]] if bad.size else None)
+    assert st["n_steps"] == rs
+
+
+# ---- device arithmetic of RandomSample (T/RandomSampleTest.scala) ---------------------------------------
+@pytest.mark.parametrize("r,expect", [(0.1, 0), (0.4, 1), (0.7, 2)])
+def test_sample_kat(eng, r, expect):
+    assert eng.sample([1.0, 1.0, 1.0], r) == expect
+
+
+def test_second_order_kat(eng):
+    curr = ([1, 3, 4], [1.0, 1.0, 1.0])
+    assert eng.second_order_weights(1.0, 1.0, 1, [2, 4, 5], *curr).tolist() == [1.0, 1.0, 1.0]
+    assert eng.second_order_weights(2.0, 2.0, 1, [2, 5], *curr).tolist() == [0.5, 0.5, 0.5]
+    assert eng.second_order_weights(2.0, 2.0, 1, [2, 4, 5], *curr).tolist() == [0.5, 0.5, 1.0]
+    for r, expect in [(0.1, 1), (0.4, 3), (0.7, 4)]:
+        assert curr[0][eng.second_order_sample(1.0, 1.0, 1, [2, 4, 5], *curr, r)] == expect
+    for r, expect in [(0.24, 1), (0.26, 3), (0.51, 4), (0.99, 4)]:
+        assert curr[0][eng.second_order_sample(2.0, 2.0, 1, [2, 4, 5], *curr, r)] == expect
+
+
+@pytest.mark.parametrize("deg,r,expect", [(12, 0.5, 6), (14, 0.5, 7), (6, 0.5, 2), (3, 1.5, 0)])
+def test_rounding_known_answers(eng, oracle, deg, r, expect):
+    assert oracle.sample_index([1.0] * deg, r) == expect
+    assert eng.sample([1.0] * deg, r) == expect
+
+
+def test_sample_random_lists_match_oracle(eng, oracle):
+    rng = np.random.default_rng(1)
+    for trial in range(60):
+        n = int(rng.integers(1, 700))
+        kind = trial % 4
+        if kind == 0:
+            w = np.ones(n, dtype=np.float32)
+        elif kind == 1:
+            w = rng.integers(1, 17, n).astype(np.float32)
+        elif kind == 2:
+            w = rng.random(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-3, 4, n).astype(np.float32)
+        else:  # breaks the exact-sum certificate -> sequential fallback path
+            w = (rng.random(n).astype(np.float32) * np.float32(2.0) ** rng.integers(-60, 60, n).astype(np.float32))
+        for r in (0.0, 0.5, 0.25, float(np.float32(rng.random())), 0.99999994):
+            assert eng.sample(w, r) == oracle.sample_index(w, r), (trial, n, r)
+
+
+def test_sample_lattice_ties_all_degrees(eng, oracle):
+    # u on the 2^-24 lattice hits dyadic CDF boundaries exactly; the sequential f64 sum decides
+    for deg in list(range(1, 130)) + [255, 256, 1000, 4096]:
+        w = np.ones(deg, dtype=np.float32)
+        for r in (0.5, 0.25, 0.75, 0.125):
+            assert eng.sample(w, r) == oracle.sample_index(w, r), (deg, r)
+
+
+def test_sample_degenerate_weights(eng, oracle):
+    for w in ([0.0, 0.0, 0.0], [1.0, -1.0, 1.0], [float("nan"), 1.0], [float("inf"), 1.0], [-2.0, -3.0],
+              [0.0, 5.0, 0.0], [1e38, 1e38, 1e38, 1e38]):
+        for r in (0.0, 0.3, 0.9):
+            assert eng.sample(w, r) == oracle.sample_index(w, r), (w, r)
+
+
+def test_f32_division_bitwise(eng, oracle):
+    rng = np.random.default_rng(2)
+    ids = np.arange(512, dtype=np.int32) + 10
+    for p, q in [(0.3, 0.7), (3.0, 7.0), (0.25, 4.0), (1e-3, 1e3), (1.1, 0.9)]:
+        w = (rng.random(512).astype(np.float32) * 100).astype(np.float32)
+        prev_ids = ids[::3]
+        a = eng.second_order_weights(p, q, int(ids[5]), prev_ids, ids, w)
+        b = oracle.second_order_weights(p, q, int(ids[5]), prev_ids, ids, w)
+        assert a.view(np.uint32).tolist() == b.view(np.uint32).tolist()
+
+
+def test_rng_stream(eng, oracle):
+    it = np.array([0, 0, 0, 5, 123456], dtype=np.uint32)
+    src = np.array([1, 1, 1, 4000000000, 77], dtype=np.uint32)
+    st = np.array([1, 2, 3, 81, 9], dtype=np.uint32)
+    got = eng.rng_uniform(42, it, src, st)
+    assert got[:3].tolist() == [np.float32(0.2174382209777832), np.float32(0.21827632188796997),
+                                np.float32(0.9992966651916504)]
+    for k in range(5):
+        assert float(got[k]) == oracle.walk_uniform(42, int(it[k]), int(src[k]), int(st[k]))
+
+
+# ---- graph load (T/UniformRandomWalkTest.scala:33-86, T/GraphMapTest.scala) ------------------------------
+def test_load_karate(eng, oracle):
+    for directed, entries in ((False, 156), (True, 78)):
+        eng.load_edgelist(KARATE, directed=directed)
+        assert eng.stats() == (34, entries)
+        g = oracle.Graph.load(KARATE, directed=directed)
+        assert eng.vertices().tolist() == g.vertices().tolist()
+        for v in range(0, 36):
+            a, b = eng.neighbors(v), g.neighbors(v)
+            if b is None:
+                assert a is None
+            else:
+                assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+
+
+def test_first_step_testgraph(eng):
+    eng.load_edgelist(TESTGRAPH, directed=True)
+    paths, lens, st = eng.walk(walk_length=0, rng="const", const_r=0.3)
+    got = {int(p[0]): p[:n].tolist() for p, n in zip(paths, lens)}
+    assert got == {1: [1, 2], 2: [2]}
+
+
+def test_graphmap_adjacency_surface(eng):
+    # GraphMapTest.scala:7-33 through srw_load_adjacency
+    e1, e2, e3, e4 = [(2, 1.0)], [(3, 1.0)], [(3, 1.0)], [(1, 1.0)]
+    eng.load_adjacency([(2, e3 + e4), (1, e1 + e2), (3, []), (1, e4)])
+    assert eng.stats() == (3, 4)
+    assert eng.neighbors(1)[0].tolist() == [2, 3] and eng.neighbors(2)[0].tolist() == [3, 1]
+    assert eng.neighbors(3)[0].tolist() == [] and eng.neighbors(99) is None
+    eng.load_adjacency([(7, [(8, 3, 1.0), (9, 4, 2.0), (8, 5, 1.0)]), (8, []), (9, [])])
+    assert eng.partition(8) == 5 and eng.partition(9) == 4 and eng.partition(7) is None
+
+
+# ---- walks ------------------------------------------------------------------------------------------------
+REF_CASES = [(False, 1, 0.1), (False, 50, 0.1), (False, 50, 0.9), (True, 50, 0.9), (True, 50, 0.1)]
+
+
+@pytest.mark.parametrize("directed,L,r", REF_CASES)
+@pytest.mark.parametrize("force_general", [False, True])
+def test_karate_reference_cases(eng, oracle, directed, L, r, force_general):
+    # T/UniformRandomWalkTest.scala:181-291 — every path equals the sequential walk
+    g = oracle.Graph.load(KARATE, directed=directed)
+    eng.load_edgelist(KARATE, directed=directed)
+    a, b = both_walk(eng, g, walk_length=L, rng="const", const_r=r, force_general=force_general)
+    assert_same(a, b)
+    assert a[2]["kernel_kind"] == (2 if force_general else 1)
+    for p, n in zip(a[0], a[1]):
+        assert p[:n].tolist() == g.seq_walk(int(p[0]), walk_length=L, rng="const", const_r=r).tolist()
+
+
+DERIVED = [(False, 1, 0.1, 1.0, 1.0, "25b2f0fffab1481e"), (False, 50, 0.1, 1.0, 1.0, "7780f0ee2a73f2b9"),
+           (False, 50, 0.9, 1.0, 1.0, "fe0f7f858ba84ae3"), (False, 10, 0.5, 0.25, 4.0, "8b314af7cd74348c"),
+           (False, 10, 0.3, 4.0, 0.5, "b42487837425aa3a"), (True, 50, 0.1, 1.0, 1.0, "c21670d58f359860"),
+           (True, 50, 0.9, 1.0, 1.0, "bdef19b134fd9227")]
+
+
+@pytest.mark.parametrize("directed,L,r,p,q,dg", DERIVED)
+def test_karate_golden_digests(eng, directed, L, r, p, q, dg):
+    eng.load_edgelist(KARATE, directed=directed)
+    paths, lens, _ = eng.walk(walk_length=L, p=p, q=q, rng="const", const_r=r)
+    assert digest(paths, lens) == dg
+
+
+PQ = [(1.0, 1.0), (0.25, 4.0), (4.0, 0.5), (2.0, 2.0), (0.5, 1.0)]
+
+
+@pytest.mark.parametrize("p,q", PQ)
+@pytest.mark.parametrize("directed", [False, True])
+def test_karate_philox(eng, oracle, p, q, directed):
+    g = oracle.Graph.load(KARATE, directed=directed)
+    eng.load_edgelist(KARATE, directed=directed)
+    assert_same(*both_walk(eng, g, p=p, q=q, walk_length=80, num_walks=3, first_walk=2, seed=123))
+
+
+@pytest.mark.parametrize("scale,weighted,directed,p,q", [
+    (10, False, False, 1.0, 1.0), (12, False, False, 1.0, 1.0), (12, True, False, 1.0, 1.0),
+    (12, False, True, 1.0, 1.0), (10, False, False, 0.25, 4.0), (11, True, False, 0.25, 4.0),
+    (11, True, True, 4.0, 0.5), (10, True, False, 2.0, 2.0), (11, False, False, 0.5, 1.0)])
+def test_rmat_vs_oracle(eng, oracle, scale, weighted, directed, p, q):
+    s, d, w = rmat_lines(oracle, scale, edge_factor=8, weighted=weighted)
+    g = oracle.Graph.from_coo(s, d, w, directed=directed)
+    eng.load_coo(s, d, w, directed=directed)
+    assert eng.stats() == (g.num_vertices, g.num_entries)
+    assert_same(*both_walk(eng, g, p=p, q=q, walk_length=20, num_walks=2, seed=9, threads=8), what="rmat")
+
+
+def test_rmat_first_order_equals_general(eng, oracle):
+    s, d, w = rmat_lines(oracle, 12, edge_factor=16, weighted=True)
+    eng.load_coo(s, d, w)
+    a = eng.walk(walk_length=40, seed=5)
+    b = eng.walk(walk_length=40, seed=5, force_general=True)
+    assert a[2]["kernel_kind"] == 1 and b[2]["kernel_kind"] == 2
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_device_rmat_generator(eng, oracle):
+    scale, n = 11, 8 << 11
+    for weighted in (False, True):
+        s, d, w = rmat_lines(oracle, scale, edge_factor=8, weighted=weighted)
+        g = oracle.Graph.from_coo(s, d, w)
+        eng.generate_rmat(scale, n, seed=42, weighted=weighted)
+        assert eng.stats() == (g.num_vertices, g.num_entries)
+        assert eng.vertices().tolist() == g.vertices().tolist()
+        for v in g.vertices()[:50].tolist() + g.vertices()[-20:].tolist():
+            a, b = eng.neighbors(v), g.neighbors(v)
+            assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+        assert_same(*both_walk(eng, g, walk_length=10, seed=1, threads=8))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_multigraphs(eng, oracle, seed):
+    rng = np.random.default_rng(seed)
+    weighted = bool(seed % 2)
+    directed = bool((seed // 2) % 2)
+    s, d, w = random_multigraph(rng, 60, 300, weighted, id_lo=-20 if seed == 3 else 5)
+    g = oracle.Graph.from_coo(s, d, w, directed=directed)
+    eng.load_coo(s, d, w, directed=directed)
+    assert eng.stats() == (g.num_vertices, g.num_entries)
+    for p, q in PQ:
+        assert_same(*both_walk(eng, g, p=p, q=q, walk_length=30, num_walks=2, seed=seed), what="pq=%s,%s" % (p, q))
+        assert_same(*both_walk(eng, g, p=p, q=q, walk_length=12, rng="const", const_r=0.5), what="const .5")
+
+
+def test_irregular_weights(eng, oracle):
+    # negative / zero-sum / NaN rows: first-order kernel must take the literal sequential scan
+    s = np.array([1, 1, 1, 2, 2, 3, 3, 4, 4, 4], dtype=np.int32)
+    d = np.array([2, 3, 4, 1, 3, 1, 4, 1, 2, 3], dtype=np.int32)
+    w = np.array([1.0, -1.0, 2.0, 0.0, 0.0, np.nan, 1.0, 3.0, 1.0, 1.0], dtype=np.float32)
+    g = oracle.Graph.from_coo(s, d, w, directed=True)
+    eng.load_coo(s, d, w, directed=True)
+    for fg in (False, True):
+        a, b = both_walk(eng, g, walk_length=16, num_walks=4, seed=3, force_general=fg)
+        assert_same(a, b, what="irregular fg=%s" % fg)
+    assert eng.walk(walk_length=16, num_walks=4, seed=3)[2]["fallbacks"] > 0
+
+
+def test_high_degree_hub(eng, oracle):
+    # one hub with 50k neighbors: multi-chunk wave scan + large guide table
+    n = 50000
+    s = np.concatenate([np.zeros(n, dtype=np.int32), np.arange(1, 200, dtype=np.int32)])
+    d = np.concatenate([np.arange(1, n + 1, dtype=np.int32), np.arange(2, 201, dtype=np.int32)])
+    rng = np.random.default_rng(0)
+    w = rng.integers(1, 9, len(s)).astype(np.float32)
+    g = oracle.Graph.from_coo(s, d, w)
+    eng.load_coo(s, d, w)
+    src = np.arange(0, 64, dtype=np.int32)
+    for p, q in [(1.0, 1.0), (0.25, 4.0)]:
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=6, seed=11)
+        rp, rl, rs = g.walk(p=p, q=q, walk_length=6, seed=11, threads=8)
+        assert np.array_equal(paths, rp) and np.array_equal(lens, rl) and st["n_steps"] == rs
+
+
+def test_writer_matches_oracle(eng, oracle, tmp_path):
+    eng.load_edgelist(KARATE, directed=True)
+    paths, lens, _ = eng.walk(walk_length=10, num_walks=2, seed=3)
+    eng.write_paths(str(tmp_path / "gpu"), n_parts=3)
+    assert oracle.write_paths(paths, lens, str(tmp_path / "ref"), 3) == 0
+    for name in ("part-00000", "part-00001", "part-00002", "_SUCCESS"):
+        assert (tmp_path / "gpu" / "path" / name).read_bytes() == (tmp_path / "ref" / "path" / name).read_bytes()
+    with pytest.raises(pkg().SrwError) as ei:
+        eng.write_paths(str(tmp_path / "gpu"))
+    assert ei.value.code == pkg().ERR_EXISTS
+
+
+def test_cli_end_to_end(oracle, tmp_path):
+    import subprocess
+    out = tmp_path / "out"
+    r = subprocess.run([pkg().CLI_PATH, "--cmd", "randomwalk", "--numWalks", "1", "--p", "1", "--q", "1",
+                        "--walkLength", "10", "--rddPartitions", "10", "--input", KARATE, "--output", str(out),
+                        "--partitioned", "false", "--seed", "42"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == ["edges: 156", "vertices: 34", "E Partitions: 156", "V Partitions: 34",
+                                     "Unfinished Walkers: 0"]
+    g = oracle.Graph.load(KARATE)
+    rp, rl, _ = g.walk(walk_length=10, seed=42)
+    want = "".join("\t".join(str(int(x)) for x in p[:n]) + "\n" for p, n in zip(rp, rl))
+    assert (out / "path" / "part-00000").read_text() == want
+    assert (out / "path" / "_SUCCESS").read_bytes() == b""
+    r2 = subprocess.run([pkg().CLI_PATH, "--cmd", "randomwalk", "--input", KARATE, "--output", str(out)],
+                        capture_output=True, text=True)
+    assert r2.returncode == 1 and "already exists" in r2.stderr

@@ -22,7 +22,7 @@ def eng():
 
 
 def both_walk(eng, g, **kw):
-    paths, lens, st = eng.walk(**kw)
+    paths, lens, st = eng.walk(**{k: v for k, v in kw.items() if k != "threads"})
     okw = {k: v for k, v in kw.items() if k != "force_general"}
     rp, rl, rs = g.walk(**okw)
     return (paths, lens, st), (rp, rl, rs)

@@ -42,7 +42,7 @@ def cpu_baseline(args):
     g = oracle_py.Graph.from_coo(s, d, None, directed=False)
     t_build = time.time() - t0
     verts = g.vertices()
-    n_src = args.cpu_sources or 24 * cores
+    n_src = args.cpu_sources or max(64, 3 * cores)
     src = verts[np.linspace(0, len(verts) - 1, n_src).astype(np.int64)]
     # faithful = the reference's own O(deg(curr) * deg(prev)) computeSecondOrderWeights (linear `exists`)
     t0 = time.time()
@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--shard", choices=["replicate", "vertex"], default="replicate")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-scale", type=int, default=20)
-    ap.add_argument("--cpu-sources", type=int, default=0, help="0 = 24 per host core")
+    ap.add_argument("--cpu-sources", type=int, default=0, help="0 = max(64, 3 per host core)")
     ap.add_argument("--cpu-walk-length", type=int, default=80)
     args = ap.parse_args()
 

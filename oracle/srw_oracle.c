@@ -352,6 +352,7 @@ static orc_graph *graph_build(line_vec *lv, int directed) {
     if (lv->dst[i] < vmin) vmin = lv->dst[i]; if (lv->dst[i] > vmax) vmax = lv->dst[i];
   }
   g->vmin = vmin; g->vmax = vmax; g->n_slots = (int64_t)vmax - (int64_t)vmin + 1;
+  if (g->n_slots > ((int64_t)1 << 31)) { free(g); return NULL; } /* dense index would not fit; oracle is for small cases */
   g->present = (uint8_t *)calloc((size_t)g->n_slots, 1);
   g->off = (int64_t *)calloc((size_t)g->n_slots + 1, sizeof(int64_t));
   for (int64_t i = 0; i < lv->n; ++i) {

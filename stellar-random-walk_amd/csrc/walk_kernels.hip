@@ -327,6 +327,8 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
   if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
   check_params(P);
   const int32_t world = h->cfg.world;
+  if (world > 1 && P.q != 1.0f)
+    throw Error(SRW_ERR_INVALID, "vertex-sharded step needs q == 1 (N(prev) lives on another GPU); use the replicated mode");
   hipStream_t st = h->stream;
   h->counters.ensure(1);
   h->shard_counts.ensure((size_t)world * 2);

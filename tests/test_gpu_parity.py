@@ -295,3 +295,70 @@ def test_cli_end_to_end(oracle, tmp_path):
     r2 = subprocess.run([pkg().CLI_PATH, "--cmd", "randomwalk", "--input", KARATE, "--output", str(out)],
                         capture_output=True, text=True)
     assert r2.returncode == 1 and "already exists" in r2.stderr
+
+
+# ---- vertex-sharded path: two shard handles on one GPU, exchange done by hand ---------------------------
+@pytest.mark.parametrize("world,p,directed", [(2, 1.0, False), (2, 0.5, True), (3, 4.0, False)])
+def test_sharded_kernels_inprocess_exchange(oracle, world, p, directed):
+    import torch
+    from importlib import import_module
+    sharded = import_module("stellar_random_walk_amd.distributed")
+    s, d, w = rmat_lines(oracle, 10, edge_factor=8, weighted=True)
+    g = oracle.Graph.from_coo(s, d, w, directed=directed)
+    ses = [sharded.HipShardEngine(0, r, world) for r in range(world)]
+    for se in ses:
+        se.engine.load_coo(s, d, w, directed=directed)
+        assert se.engine.stats() == (g.num_vertices, g.num_entries)      # global counts on every shard
+    assert sum(se.capacity()[0] for se in ses) == g.num_vertices
+    L, it = 9, 4
+    stride, nv = L + 2, g.num_vertices
+    P = pkg().Engine.params(p=p, q=1.0, walk_length=L, first_walk=it, seed=21)
+    dev = ses[0].device
+    paths = [torch.full((nv, stride), sharded.UNWRITTEN, dtype=torch.int32, device=dev) for _ in range(world)]
+    cur = [torch.empty((nv, 4), dtype=torch.int32, device=dev) for _ in range(world)]
+    out = [torch.empty((nv, 4), dtype=torch.int32, device=dev) for _ in range(world)]
+    n = [ses[r].seed(0, cur[r], paths[r], stride) for r in range(world)]
+    steps = 0
+    for step in range(1, L + 2):
+        res = [ses[r].step(P, it, step, cur[r], n[r], out[r], paths[r], stride, world) for r in range(world)]
+        steps += sum(st["n_steps"] for _, st in res)
+        torch.cuda.synchronize()
+        newn = [0] * world
+        for r in range(world):                       # the all-to-all-v, by hand
+            counts, off = res[r][0], 0
+            for dst in range(world):
+                c = counts[dst]
+                cur[dst][newn[dst]:newn[dst] + c] = out[r][off:off + c]
+                newn[dst] += c
+                off += c
+        torch.cuda.synchronize()
+        n = newn
+    full = torch.stack(paths).max(dim=0).values
+    written = full != sharded.UNWRITTEN
+    lens = written.sum(dim=1).cpu().numpy().astype(np.int32)
+    got = torch.where(written, full, torch.full_like(full, -1)).cpu().numpy()
+    rp, rl, rs = g.walk(p=p, q=1.0, walk_length=L, first_walk=it, seed=21, threads=8)
+    assert np.array_equal(lens, rl) and np.array_equal(got, rp) and steps == rs
+    with pytest.raises(pkg().SrwError):               # q != 1 needs N(prev) from another shard
+        ses[0].step(pkg().Engine.params(q=4.0, walk_length=L), it, 2, cur[0], 0, out[0], paths[0], stride, world)
+    for se in ses:
+        se.engine.close()
+
+
+def test_sharded_walker_world1_nccl(oracle):
+    import torch.distributed as dist
+    from importlib import import_module
+    sharded = import_module("stellar_random_walk_amd.distributed")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        g = oracle.Graph.load(KARATE)
+        drv = sharded.ShardedWalker(device=0)
+        drv.load_edgelist(KARATE)
+        paths, lens, stats = drv.walk(num_walks=2, p=0.5, walk_length=20, seed=3)
+        rp, rl, rs = g.walk(num_walks=2, p=0.5, walk_length=20, seed=3)
+        assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
+        assert sum(s["n_steps_global"] for s in stats) == rs
+    finally:
+        dist.destroy_process_group()

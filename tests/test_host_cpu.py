@@ -1,0 +1,203 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports what include/stellar_rw.h declares, the host
+logic (edge-list tokenizer, path writer, CLI flag parser) follows the reference's rules, and the product fails
+loudly — never silently on a CPU path — when no GPU is present."""
+import os
+import re
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import KARATE, ROOT, TESTGRAPH
+from helpers import pkg
+
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    p = pkg()
+    L = p.lib()
+    header = open(os.path.join(ROOT, "include", "stellar_rw.h")).read()
+    declared = sorted(set(re.findall(r"\b(srw_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no declarations found"
+    for sym in declared:
+        assert hasattr(L, sym), "libstellar_rw.so lacks " + sym
+    assert sorted(p.EXPORTS) == declared
+    assert "gfx950" in p.version()
+
+
+def test_library_contains_gfx950_code_object():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", pkg().LIB_PATH],
+                         capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("llvm-objdump unavailable")
+    assert "gfx950" in out.stdout
+
+
+@pytest.mark.skipif(not NO_GPU, reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback():
+    p = pkg()
+    with pytest.raises(p.SrwError) as ei:
+        p.Engine(device=0)
+    assert ei.value.code == p.ERR_HIP
+    r = subprocess.run([p.CLI_PATH, "--cmd", "randomwalk", "--input", KARATE, "--output", "/tmp/never"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr
+
+
+# ---- edge-list tokenizer: UniformRandomWalk.scala:26-34 / VCutRandomWalk.scala:21-34 -----------------------
+def _write(tmp_path, text, name="g.txt"):
+    f = tmp_path / name
+    f.write_bytes(text if isinstance(text, bytes) else text.encode())
+    return str(f)
+
+
+GOOD = [
+    ("1 2\n2 3\n", False, False),
+    ("1   2", False, False),                                   # testgraph.txt: 3 spaces, no newline
+    ("1\t2\t0.5\r\n3 4 2.5\r\n", True, False),                 # CRLF, tabs
+    ("1 2 0.5\r3 4 1.5\r", True, False),                       # lone CR terminators (Hadoop LineReader)
+    ("1 2 abc\n3 4 1.5abc\n5 6 1e\n7 8 .5\n9 10 5.\n", True, False),   # unparsable weight -> 1.0f
+    ("1 2 1.5f\n3 4 2d\n5 6 NaN\n7 8 Infinity\n9 10 -Infinity\n11 12 0x1.8p1\n13 14 +3\n", True, False),
+    ("1 2 7 0.25\n3 4 9\n5 6 x 2.0\n", True, True),            # partitioned: pId col 2, weight last iff > 3 cols
+    ("1 2 7 0.25\n", False, True),
+    ("1 2 3 4 5 6.5\n", True, False),                          # weight = LAST column
+    ("-5 +7 2\n100000 -100000\n", True, False),               # signed ids
+    ("1 2 1e-50\n1 3 1e50\n1 4 16777217\n", True, False),      # float rounding / overflow to inf
+    ("1 2   \n3 4\t\n", False, False),                         # trailing blanks dropped by split
+    ("1 2\x0b3\x0c4\n", True, False),                          # VT and FF are \s
+]
+BAD = [
+    (" 1 2\n", "leading whitespace -> leading empty token -> NumberFormatException"),
+    ("1 2\n\n3 4\n", "empty line"),
+    ("1\n", "one column"),
+    ("a 2\n", "non-numeric id"),
+    ("1 2.0\n", "float id"),
+    ("1 2147483648\n", "int overflow"),
+    ("   \n", "blank line"),
+    ("1 2\n3 4\n5\n", "short last line"),
+]
+
+
+@pytest.mark.parametrize("text,weighted,partitioned", GOOD)
+def test_tokenizer_matches_oracle(oracle, tmp_path, text, weighted, partitioned):
+    path = _write(tmp_path, text)
+    s, d, w, pid = pkg().parse_edgelist(path, weighted=weighted, partitioned=partitioned)
+    g = oracle.Graph.load(path, directed=True, weighted=weighted, partitioned=partitioned)
+    os_, od, ow, opid = g.lines()
+    assert s.tolist() == os_.tolist() and d.tolist() == od.tolist() and pid.tolist() == opid.tolist()
+    assert w.view(np.uint32).tolist() == ow.view(np.uint32).tolist()
+
+
+def test_tokenizer_known_values(tmp_path):
+    s, d, w, pid = pkg().parse_edgelist(_write(tmp_path, "1 2 abc\n3 4 1.5f\n5 6 7 0.25\n"), weighted=True)
+    assert (s.tolist(), d.tolist()) == ([1, 3, 5], [2, 4, 6])
+    assert w.tolist() == [1.0, 1.5, 0.25]
+    s, d, w, pid = pkg().parse_edgelist(_write(tmp_path, "5 6 7 0.25\n8 9 x\n"), weighted=True, partitioned=True)
+    assert pid.tolist() == [7, -1] and w.tolist() == [0.25, 1.0]
+    s, d, w, pid = pkg().parse_edgelist(_write(tmp_path, "5 6 0.25\n"), weighted=False)
+    assert w.tolist() == [1.0]
+    s, d, w, pid = pkg().parse_edgelist(_write(tmp_path, "2147483647 -2147483648\n"))   # Integer.parseInt extremes
+    assert (s.tolist(), d.tolist()) == ([2147483647], [-2147483648])
+
+
+@pytest.mark.parametrize("text,why", BAD)
+def test_tokenizer_rejects_what_the_reference_throws_on(oracle, tmp_path, text, why):
+    path = _write(tmp_path, text)
+    with pytest.raises(pkg().SrwError) as ei:
+        pkg().parse_edgelist(path)
+    assert ei.value.code == pkg().ERR_PARSE, why
+    with pytest.raises(ValueError):
+        oracle.Graph.load(path)
+
+
+def test_tokenizer_fixtures_and_threads(oracle, tmp_path):
+    for f, n in ((KARATE, 78), (TESTGRAPH, 1)):
+        s, d, w, pid = pkg().parse_edgelist(f)
+        assert len(s) == n
+    # a file big enough to be split across parser threads, with CRLF line ends straddling the cuts
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 100000, size=(200000, 2))
+    ww = rng.integers(1, 100, size=200000)
+    text = "".join("%d %d %d.5\r\n" % (x, y, z) for (x, y), z in zip(a, ww))
+    path = _write(tmp_path, text, "big.txt")
+    s, d, w, pid = pkg().parse_edgelist(path)
+    assert s.tolist() == a[:, 0].tolist() and d.tolist() == a[:, 1].tolist()
+    assert w.tolist() == (ww + 0.5).astype(np.float32).tolist()
+    with pytest.raises(pkg().SrwError) as ei:   # the failing line number survives the multi-threaded split
+        pkg().parse_edgelist(_write(tmp_path, text + "oops\n", "bad.txt"))
+    assert "line 200001" in str(ei.value)
+
+
+def test_missing_file():
+    with pytest.raises(pkg().SrwError) as ei:
+        pkg().parse_edgelist("/nonexistent/edges.txt")
+    assert ei.value.code == pkg().ERR_IO
+
+
+# ---- writer: RandomWalk.save, RandomWalk.scala:234-241 -----------------------------------------------------
+def test_writer_matches_oracle_and_hadoop_layout(oracle, tmp_path):
+    g = oracle.Graph.load(KARATE, directed=True)
+    paths, lens, _ = g.walk(walk_length=10, num_walks=3, seed=5)
+    pkg().save_paths(paths, lens, str(tmp_path / "a"), n_parts=4, write_crc=True)
+    assert oracle.write_paths(paths, lens, str(tmp_path / "b"), 4) == 0
+    names = sorted(os.listdir(tmp_path / "a" / "path"))
+    assert names == sorted(["part-00000", "part-00001", "part-00002", "part-00003", "_SUCCESS",
+                            ".part-00000.crc", ".part-00001.crc", ".part-00002.crc", ".part-00003.crc",
+                            "._SUCCESS.crc"])
+    total = 0
+    for k in range(4):
+        a = (tmp_path / "a" / "path" / ("part-%05d" % k)).read_bytes()
+        assert a == (tmp_path / "b" / "path" / ("part-%05d" % k)).read_bytes()
+        total += a.count(b"\n")
+        crc = (tmp_path / "a" / "path" / (".part-%05d.crc" % k)).read_bytes()
+        assert crc[:8] == b"crc\x00\x00\x00\x02\x00"
+        want = b"".join(zlib.crc32(a[o:o + 512]).to_bytes(4, "big") for o in range(0, len(a), 512))
+        assert crc[8:] == want
+    assert total == len(lens)
+    assert (tmp_path / "a" / "path" / "_SUCCESS").read_bytes() == b""
+    assert (tmp_path / "a" / "path" / "._SUCCESS.crc").read_bytes() == b"crc\x00\x00\x00\x02\x00"
+    first = (tmp_path / "a" / "path" / "part-00000").read_text().splitlines()[0]
+    assert first == "\t".join(str(int(x)) for x in paths[0][:lens[0]])   # TAB-joined, no trailing TAB
+    with pytest.raises(pkg().SrwError) as ei:                             # FileAlreadyExistsException
+        pkg().save_paths(paths, lens, str(tmp_path / "a"))
+    assert ei.value.code == pkg().ERR_EXISTS
+
+
+def test_writer_negative_ids_and_single_vertex_paths(tmp_path):
+    paths = np.array([[-7, 3, -1], [5, -1, -1], [-2147483648, 2147483647, 0]], dtype=np.int32)
+    lens = np.array([2, 1, 3], dtype=np.int32)
+    pkg().save_paths(paths, lens, str(tmp_path / "o"))
+    assert (tmp_path / "o" / "path" / "part-00000").read_text() == "-7\t3\n5\n-2147483648\t2147483647\t0\n"
+
+
+# ---- CLI flag parser: M/common/CommandParser.scala:34-90, M/Main.scala:18-27 --------------------------------
+def _cli(*args):
+    return subprocess.run([pkg().CLI_PATH, *args], capture_output=True, text=True)
+
+
+def test_cli_required_options_and_usage():
+    r = _cli("--cmd", "randomwalk")
+    assert r.returncode == 1                                   # case None => sys.exit(1)
+    assert "Error: Missing option --input" in r.stderr and "Error: Missing option --output" in r.stderr
+    assert "Try --help for more information." in r.stderr
+    for flag in ("--walkLength", "--numWalks", "--p", "--q", "--rddPartitions", "--weighted", "--directed",
+                 "--w2vPartitions", "--input", "--output", "--singleOutput", "--cmd", "--partitioned", "--lr",
+                 "--iter", "--dim", "--window"):
+        assert flag + " <value>" in r.stderr
+    r = _cli("--input", "x", "--output", "y")
+    assert r.returncode == 1 and "Missing option --cmd" in r.stderr
+
+
+def test_cli_rejects_bad_values():
+    base = ["--cmd", "randomwalk", "--input", KARATE, "--output", "/tmp/unused_srw_out"]
+    assert _cli(*base, "--walkLength", "ten").returncode == 1
+    assert _cli(*base, "--weighted", "maybe").returncode == 1
+    assert _cli(*base, "--bogus", "1").returncode == 1
+    r = _cli("--cmd", "pagerank", "--input", KARATE, "--output", "/tmp/unused_srw_out")
+    assert r.returncode == 1 and "No value found for 'pagerank'" in r.stderr   # TaskName.withName throws
+    r = _cli("--cmd", "embedding", "--input", KARATE, "--output", "/tmp/unused_srw_out")
+    assert r.returncode == 2 and "Word2Vec" in r.stderr
+    assert _cli("--help").returncode == 0

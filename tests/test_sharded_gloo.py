@@ -1,0 +1,83 @@
+"""world_size-2 (and 3) gloo tests of the vertex-sharded walk driver on CPU.
+
+The product's step engine is HIP-only; here the CPU oracle is plugged in as the step engine so that the
+exchange protocol (counts all-to-all, record all-to-all-v, MAX path combine) is exercised for real across
+processes.  The sharded result must equal the single-process oracle walk bit for bit (keyed RNG => the result
+does not depend on the number of shards)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import KARATE
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, directed, p, L, rng, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    sys.path.insert(0, HERE)
+    import _pkg
+    _pkg.load()
+    from importlib import import_module
+    sharded = import_module("stellar_random_walk_amd.distributed")
+    import oracle_py
+    from oracle_shard_engine import OracleShardEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = oracle_py.Graph.load(KARATE, directed=directed)
+        drv = sharded.ShardedWalker(rank=rank, world=world, step_engine=OracleShardEngine(g, rank, world))
+        paths, lens, stats = drv.walk(num_walks=2, first_walk=3, p=p, q=1.0, walk_length=L, seed=11, rng=rng, const_r=0.4)
+        np.save(os.path.join(out_dir, "paths_%d.npy" % rank), paths)
+        np.save(os.path.join(out_dir, "lens_%d.npy" % rank), lens)
+        np.save(os.path.join(out_dir, "steps_%d.npy" % rank), np.array([sum(s["n_steps_global"] for s in stats),
+                                                                          sum(s["exchanged"] for s in stats)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,directed,p,rng", [(2, False, 1.0, "philox"), (2, True, 0.5, "philox"),
+                                                   (3, False, 4.0, "const")])
+def test_sharded_equals_single(oracle, tmp_path, world, directed, p, rng):
+    L = 12
+    mp.spawn(_worker, args=(world, _free_port(), directed, p, L, rng, str(tmp_path)), nprocs=world, join=True)
+    g = oracle.Graph.load(KARATE, directed=directed)
+    ref_paths, ref_lens, ref_steps = g.walk(p=p, q=1.0, walk_length=L, num_walks=2, first_walk=3, seed=11, rng=rng,
+                                            const_r=0.4)
+    for r in range(world):
+        paths = np.load(tmp_path / ("paths_%d.npy" % r))
+        lens = np.load(tmp_path / ("lens_%d.npy" % r))
+        steps, exchanged = np.load(tmp_path / ("steps_%d.npy" % r))
+        assert np.array_equal(lens, ref_lens)
+        assert np.array_equal(paths, ref_paths)
+        assert steps == ref_steps
+    assert exchanged > 0  # walkers really crossed shards
+
+
+def test_q_not_one_is_rejected(oracle):
+    sys.path.insert(0, os.path.dirname(HERE))
+    import _pkg
+    pkg = _pkg.load()
+    from importlib import import_module
+    sharded = import_module("stellar_random_walk_amd.distributed")
+    from oracle_shard_engine import OracleShardEngine
+    g = oracle.Graph.load(KARATE)
+    drv = sharded.ShardedWalker(rank=0, world=2, step_engine=OracleShardEngine(g, 0, 2))
+    with pytest.raises(pkg.SrwError):
+        drv.walk_iteration(q=4.0)

@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--q", type=float, default=1.0)
     ap.add_argument("--weighted", type=int, default=0)
     ap.add_argument("--shard", choices=["replicate", "vertex"], default="replicate")
+    ap.add_argument("--nt-loads", type=int, default=-1, help="-1 auto, 0 cached, 1 nontemporal record loads")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-scale", type=int, default=20)
     ap.add_argument("--cpu-sources", type=int, default=0, help="0 = max(64, 3 per host core)")
@@ -100,6 +101,8 @@ def main():
     n_edges = args.edge_factor << args.scale
     K, W = args.steps, args.warmup
     walk_kw = dict(p=args.p, q=args.q, walk_length=args.walk_length, num_walks=1, seed=42)
+    if args.nt_loads >= 0:
+        walk_kw["nt_loads"] = bool(args.nt_loads)
 
     if args.shard == "vertex" and world > 1:
         from importlib import import_module
@@ -156,10 +159,10 @@ def main():
     if rank == 0:
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         if stats["kernel_kind"] == 1:
-            # first-order guide-table kernel, per launch: per step one 16 B row record + the CDF/guide
-            # records actually read (counted by the kernel, 16 B each) + 4 B path store; per walker 4 B seed + 4 B len
+            # first-order guide-table kernel, per launch: the linked CDF/guide records actually read
+            # (counted by the kernel, 32 B each) + 4 B path store per step; per walker 4 B seed + 16 B row + 4 B len
             per_launch_steps = steps / max(K, 1)
-            alg_bytes = per_launch_steps * (16 + 4) + stats["ent_reads"] * 16 + stats["n_walkers"] * 8
+            alg_bytes = per_launch_steps * 4 + stats["ent_reads"] * 32 + stats["n_walkers"] * 24
             kernel_name = "k_walk_first_order"
         else:
             # general kernel (SURVEY §8d Mode R): 16 + 8*deg(curr) + 4 per step (+ 16 + 4*deg(prev) when q != 1)

@@ -107,7 +107,9 @@ typedef struct {
   int32_t flags;       /* SRW_WALK_* */
 } srw_walk_params;
 enum {
-  SRW_WALK_FORCE_GENERAL = 1 /* use the general second-order kernel even when p == q == 1 (testing) */
+  SRW_WALK_FORCE_GENERAL = 1, /* use the general second-order kernel even when p == q == 1 (testing) */
+  SRW_WALK_NT_LOADS = 2,      /* first-order kernel: force L1-bypassing (nontemporal) record loads */
+  SRW_WALK_CACHED_LOADS = 4   /* first-order kernel: force default-policy loads (default: chosen from the table size) */
 };
 
 typedef struct {

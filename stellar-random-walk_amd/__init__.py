@@ -18,6 +18,8 @@ OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_HIP, ERR_EXISTS, ERR_NOMEM = range(7)
 SAMPLER_REFERENCE, SAMPLER_ALIAS = 0, 1
 RNG_CONST, RNG_PHILOX = 0, 1
 WALK_FORCE_GENERAL = 1
+WALK_NT_LOADS = 2
+WALK_CACHED_LOADS = 4
 
 
 class SrwError(RuntimeError):
@@ -267,10 +269,10 @@ class Engine:
     # ---- walk ----
     @staticmethod
     def params(p=1.0, q=1.0, walk_length=80, num_walks=1, first_walk=0, rng="philox", const_r=0.0, seed=42,
-               sampler=SAMPLER_REFERENCE, force_general=False):
+               sampler=SAMPLER_REFERENCE, force_general=False, nt_loads=None):
         return WalkParams(np.float32(p), np.float32(q), walk_length, num_walks, first_walk,
                           RNG_CONST if rng == "const" else RNG_PHILOX, np.float32(const_r), seed, sampler,
-                          WALK_FORCE_GENERAL if force_general else 0)
+                          (WALK_FORCE_GENERAL if force_general else 0) | (0 if nt_loads is None else WALK_NT_LOADS if nt_loads else WALK_CACHED_LOADS))
 
     def walk(self, fetch=True, **kw):
         """Runs srw_walk.  Returns (paths [nWalkers, L+2] int32 (-1 tail), lens, stats dict) or just stats."""

@@ -4,7 +4,8 @@
 //   rows[slot]  16 B  {off:int64, deg:int32, flags:u32}   slot = vertex id - vmin, dense
 //   ent[e]       8 B  {id:int32, w:f32}                   adjacency in input-line order (CSR payload)
 //   sids[e]      4 B  u32 (id - vmin) sorted inside each row   (membership test of computeSecondOrderWeights)
-//   fo[e]       16 B  {cdf:f64, id:int32, guide:int32}    first-order exact CDF + guide table (p = q = 1)
+//   fo[e]       32 B  {cdf:f64, id:int32, guide:int32, noff:int64, ndeg:int32, nflags:u32}
+//                     first-order exact CDF + guide table + the neighbor's row descriptor (p = q = 1)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,10 +24,15 @@ struct alignas(8) Ent {
   float w;
 };
 
-struct alignas(16) FoEnt {
+struct alignas(32) FoEnt {
   double cdf;    // acc after adding this entry, computed exactly as RandomSample.sample does (:18-20)
   int32_t id;
   int32_t guide; // first k with cdf_k >= ceil(j * 2^24 / deg) * 2^-24, for bucket j = this position
+  // row descriptor of the neighbor `id` ("linked" record): the walker that picks this entry already holds
+  // the next vertex's row, so a step costs ONE random 32-byte access instead of a row load + a record load
+  int64_t noff;
+  int32_t ndeg;
+  uint32_t nflags;
 };
 
 struct alignas(16) Walker {

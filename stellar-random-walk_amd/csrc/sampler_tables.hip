@@ -41,7 +41,7 @@ __global__ void k_fo_small(Row *rows, const Ent *__restrict__ ent, FoEnt *__rest
     for (int32_t k = 0; k < r.deg; ++k) {
       Ent e = row[k];
       acc += (double)e.w / sum;
-      FoEnt f; f.cdf = acc; f.id = e.id; f.guide = 0;
+      FoEnt f; f.cdf = acc; f.id = e.id; f.guide = 0; f.noff = 0; f.ndeg = 0; f.nflags = 0;
       out[k] = f;
     }
     if (irr) rows[v].flags = r.flags | ROW_IRREGULAR;
@@ -98,7 +98,7 @@ __global__ void k_fo_large(Row *rows, const Ent *__restrict__ ent, FoEnt *__rest
         acc = acc + readlane_f64(d, i);
         if (lane == i) mine = acc;
       }
-      if (k < r.deg) { FoEnt f; f.cdf = mine; f.id = e.id; f.guide = 0; out[k] = f; }
+      if (k < r.deg) { FoEnt f; f.cdf = mine; f.id = e.id; f.guide = 0; f.noff = 0; f.ndeg = 0; f.nflags = 0; out[k] = f; }
     }
     if (irr && lane == 0) rows[v].flags = r.flags | ROW_IRREGULAR;
   }
@@ -143,6 +143,17 @@ __global__ void k_guide_large(const Row *__restrict__ rows, FoEnt *__restrict__ 
   }
 }
 
+// Link pass: copy the row descriptor of every neighbor into its record (after the irregular flags are final).
+__global__ void k_fo_link(const Row *__restrict__ rows, FoEnt *__restrict__ fo, int64_t n_entries, int32_t vmin,
+                          int64_t n_slots) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_entries; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t s = (int64_t)fo[e].id - vmin;
+    Row r; r.off = 0; r.deg = 0; r.flags = 0;
+    if (s >= 0 && s < n_slots) r = rows[s];
+    fo[e].noff = r.off; fo[e].ndeg = r.deg; fo[e].nflags = r.flags;
+  }
+}
+
 }  // namespace
 
 void build_first_order_tables(srw_handle *h) {
@@ -158,6 +169,10 @@ void build_first_order_tables(srw_handle *h) {
   hipLaunchKernelGGL(k_fo_large, dim3(gl), dim3(256), 0, st, g.rows.p, g.ent.p, g.fo.p, g.n_slots);
   hipLaunchKernelGGL(k_guide_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_slots);
   hipLaunchKernelGGL(k_guide_large, dim3(gl), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_slots);
+  if (g.n_entries > 0) {
+    int ge = (int)std::min<int64_t>((g.n_entries + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_fo_link, dim3(ge), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_entries, g.vmin, g.n_slots);
+  }
   SRW_HIP(hipGetLastError());
   SRW_HIP(hipStreamSynchronize(st));
   g.has_fo = true;

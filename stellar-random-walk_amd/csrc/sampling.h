@@ -54,27 +54,46 @@ __device__ inline int32_t lane_pick_sequential(const Ent *row, int32_t deg, cons
 // order, so "first k with cdf_k >= p" is the reference's answer.  The guide entry of bucket
 // j = floor(m * deg / 2^24), m = floor(r * 2^24), is a proven lower bound of that k (sampler_tables.hip),
 // so the forward scan from it returns the same k as the reference's scan from 0.
-__device__ inline int32_t fo_pick(const FoEnt *row, int32_t deg, float r, int32_t &next_id, unsigned &reads) {
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ inline FoEnt load_fo(const FoEnt *p) {
+  if (NT) {  // L1-bypassing 2 x 16-byte loads: the record is used once, do not pull its 128-B line into the TCP
+    const int4v *q = reinterpret_cast<const int4v *>(p);
+    int4v a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+    FoEnt e;
+    e.cdf = __longlong_as_double((long long)(((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x));
+    e.id = a.z; e.guide = a.w;
+    e.noff = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
+    e.ndeg = b.z; e.nflags = (uint32_t)b.w;
+    return e;
+  }
+  return *p;
+}
+
+// Returns the chosen record (id + the neighbor's row descriptor); k_out = its position.
+template <bool NT>
+__device__ inline FoEnt fo_pick(const FoEnt *row, int32_t deg, float r, int32_t &k_out, unsigned &reads) {
   double p = (double)r;
   float rs = r * 16777216.0f;
   uint32_t m = (rs >= 16777215.0f) ? 16777215u : (rs > 0.0f ? (uint32_t)rs : 0u);
   uint32_t j = (uint32_t)(((uint64_t)m * (uint64_t)(uint32_t)deg) >> 24);
-  FoEnt e = row[j];
+  FoEnt e = load_fo<NT>(row + j);
   reads = 1;
   int32_t k = e.guide;
-  if (k != (int32_t)j) {
-    if (k >= deg) { FoEnt h0 = row[0]; ++reads; next_id = h0.id; return 0; }
-    e = row[k]; ++reads;
+  bool found = false;
+  if (k != (int32_t)j && k < deg) { e = load_fo<NT>(row + k); ++reads; }
+  if (k < deg) {
+    while (true) {
+      if (e.cdf >= p) { found = true; break; }
+      ++k;
+      if (k >= deg) break;
+      e = load_fo<NT>(row + k); ++reads;
+    }
   }
-  while (true) {
-    if (e.cdf >= p) { next_id = e.id; return k; }
-    ++k;
-    if (k >= deg) break;
-    e = row[k]; ++reads;
-  }
-  FoEnt h0 = row[0]; ++reads;   // edges.head fallback (:24)
-  next_id = h0.id;
-  return 0;
+  if (!found) { k = 0; e = load_fo<NT>(row); ++reads; }   // edges.head fallback (:24)
+  k_out = k;
+  return e;
 }
 
 // ---- exact pick, one wave per walker (general p, q) -----------------------------------------------------

@@ -44,6 +44,7 @@ __device__ inline void flush_counters(DevCounters *ctr, unsigned long long steps
 }
 
 // ---------------------------------------------------------------------------------------------------------
+template <bool NT>
 __global__ __launch_bounds__(TPB) void k_walk_first_order(GraphView g, const int32_t *__restrict__ verts,
                                                           int64_t n_verts, int64_t n_walkers, int32_t L,
                                                           int32_t first_walk, RngSpec rng,
@@ -56,12 +57,15 @@ __global__ __launch_bounds__(TPB) void k_walk_first_order(GraphView g, const int
   const int64_t stride = (int64_t)L + 2;
   bool alive = wi < n_walkers;
   uint32_t iter = 0; int32_t src = 0;
+  Row r; r.off = 0; r.deg = 0; r.flags = 0;           // row descriptor of the current vertex
   if (alive) {
     int64_t it = wi / n_verts, vi = wi - it * n_verts;
     iter = (uint32_t)(first_walk + it);
     src = verts[vi];
+    const Row *rp = row_of(g, src);
+    if (rp) r = *rp;                                     // the only row-table access of the whole walk
   }
-  int32_t curr = src, len = 1;
+  int32_t len = 1;
   unsigned long long reads = 0, dead = 0, fb = 0;
   Bias nobias; nobias.second_order = false; nobias.need_member = false; nobias.p = nobias.q = 1.0f;
   nobias.prev = 0; nobias.prev_sids = nullptr; nobias.prev_deg = 0; nobias.vmin = g.vmin;
@@ -70,21 +74,20 @@ __global__ __launch_bounds__(TPB) void k_walk_first_order(GraphView g, const int
     const int c = s & (TILE - 1);
     int32_t val = -1;
     if (alive) {
-      const Row *rp = row_of(g, curr);
-      Row r; r.off = 0; r.deg = 0; r.flags = 0;
-      if (rp) r = *rp;
       if (r.deg == 0) {
         alive = false; if (s > 1) ++dead;                      // dead end, RandomWalk.scala:115-120 (acc2 counts the loop only)
       } else {
         float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
-        int32_t next;
+        FoEnt e;
         if (r.flags & ROW_IRREGULAR) {
           int32_t k = lane_pick_sequential(g.ent + r.off, r.deg, nobias, u);
-          next = g.ent[r.off + k].id; ++fb;
+          e = g.fo[r.off + k]; ++fb;
         } else {
-          unsigned rd; fo_pick(g.fo + r.off, r.deg, u, next, rd); reads += rd;
+          unsigned rd; int32_t k;
+          e = fo_pick<NT>(g.fo + r.off, r.deg, u, k, rd); reads += rd;
         }
-        val = next; curr = next; ++len;
+        val = e.id; ++len;
+        r.off = e.noff; r.deg = e.ndeg; r.flags = e.nflags;     // the picked record carries the next row
       }
     }
     tile[wv][lane][c] = val;
@@ -285,8 +288,18 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   SRW_HIP(hipEventRecord(h->ev0, st));
   if (first_order) {
     int64_t blocks = (n_walkers + TPB - 1) / TPB;
-    hipLaunchKernelGGL(k_walk_first_order, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices,
-                       n_walkers, P.walk_length, P.first_walk, rng, h->res.paths.p, h->res.lens.p, h->counters.p);
+    // Load policy for the linked records: once the table is far larger than L2 + Infinity Cache (32 + 256 MiB) a
+    // record is used once per fetch, and an L1-bypassing load avoids pulling its whole 128-B line (measured on
+    // MI355X: RMAT-26 19.6 -> 27.1 G steps/s); cache-resident tables keep the default policy (RMAT-20 35 vs 29).
+    const size_t fo_bytes = (size_t)g.n_entries * sizeof(FoEnt);
+    const bool nt = (P.flags & SRW_WALK_NT_LOADS) ? true
+                    : (P.flags & SRW_WALK_CACHED_LOADS) ? false : fo_bytes > ((size_t)2 << 30);
+    if (nt)
+      hipLaunchKernelGGL(k_walk_first_order<true>, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices,
+                         n_walkers, P.walk_length, P.first_walk, rng, h->res.paths.p, h->res.lens.p, h->counters.p);
+    else
+      hipLaunchKernelGGL(k_walk_first_order<false>, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices,
+                         n_walkers, P.walk_length, P.first_walk, rng, h->res.paths.p, h->res.lens.p, h->counters.p);
   } else {
     int64_t blocks = (n_walkers * 64 + TPB - 1) / TPB;
     hipLaunchKernelGGL(k_walk_general, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,

@@ -207,6 +207,29 @@ def test_rmat_first_order_equals_general(eng, oracle):
     b = eng.walk(walk_length=40, seed=5, force_general=True)
     assert a[2]["kernel_kind"] == 1 and b[2]["kernel_kind"] == 2
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for nt in (True, False):    # both record-load policies of the first-order kernel
+        c = eng.walk(walk_length=40, seed=5, nt_loads=nt)
+        assert c[2]["kernel_kind"] == 1 and np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+def test_full_size_properties(eng):
+    # size-independent properties at a BASELINE-sized graph (RMAT-20, config 2): every path starts at its
+    # source, has full length (undirected => no dead ends), every hop is an edge, and the two record-load
+    # policies and the iteration-sharded call pattern give identical bytes.
+    eng.generate_rmat(20, 16 << 20, seed=42)
+    nv, ne = eng.stats()
+    assert ne == 2 * (16 << 20)
+    verts = eng.vertices()
+    p1, l1, st = eng.walk(walk_length=80, num_walks=2, first_walk=0, seed=42, nt_loads=True)
+    assert st["n_steps"] == 2 * nv * 81 and (l1 == 82).all()
+    assert np.array_equal(p1[:nv, 0], verts) and np.array_equal(p1[nv:, 0], verts)
+    p2, l2, _ = eng.walk(walk_length=80, num_walks=1, first_walk=1, seed=42, nt_loads=False)
+    assert np.array_equal(p2, p1[nv:])            # iteration 1 alone == second half of the 2-iteration call
+    rng = np.random.default_rng(0)
+    for wi in rng.integers(0, 2 * nv, 40):         # spot-check that every hop is an adjacency entry
+        path = p1[wi]
+        for a, b in zip(path[:12], path[1:13]):
+            assert int(b) in set(eng.neighbors(int(a))[0].tolist())
 
 
 def test_device_rmat_generator(eng, oracle):

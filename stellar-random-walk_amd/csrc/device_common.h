@@ -4,6 +4,7 @@
 //   rows[slot]  16 B  {off:int64, deg:int32, flags:u32}   slot = vertex id - vmin, dense
 //   ent[e]       8 B  {id:int32, w:f32}                   adjacency in input-line order (CSR payload)
 //   sids[e]      4 B  u32 (id - vmin) sorted inside each row   (membership test of computeSecondOrderWeights)
+//   sperm[e]     4 B  u32 input-order position inside the row of sorted entry e (reverse membership marking)
 //   fo[e]       32 B  {cdf:f64, id:int32, guide:int32, noff:int64, ndeg:int32, nflags:u32}
 //                     first-order exact CDF + guide table + the neighbor's row descriptor (p = q = 1)
 #pragma once
@@ -43,6 +44,7 @@ struct GraphView {
   const Row *rows;
   const Ent *ent;
   const uint32_t *sids;
+  const uint32_t *sperm;
   const FoEnt *fo;
   int32_t vmin;
   int64_t n_slots;

@@ -65,13 +65,14 @@ struct Graph {
   int64_t n_local_vertices = 0;   // present vertices owned by this handle
   DevBuf<Row> rows;               // [n_slots]
   DevBuf<Ent> ent;                // [n_entries]
-  DevBuf<uint32_t> sids;          // [n_entries]
+  DevBuf<uint32_t> sids;          // [n_entries] (id - vmin), sorted inside each row
+  DevBuf<uint32_t> sperm;         // [n_entries] input-order position (inside the row) of each sorted entry
   DevBuf<FoEnt> fo;               // [n_entries], built lazily
   bool has_fo = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
-  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, has_fo ? fo.p : nullptr, vmin, n_slots}; }
+  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, vmin, n_slots}; }
 };
 
 struct WalkResult {

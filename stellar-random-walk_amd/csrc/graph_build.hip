@@ -84,6 +84,12 @@ __global__ void k_low32(const uint64_t *__restrict__ in, int64_t n, uint32_t *__
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
     out[e] = (uint32_t)in[e];
 }
+// value of the membership sort: position of the entry inside its row (input order)
+__global__ void k_local_index(const uint32_t *__restrict__ keys, const Row *__restrict__ rows, int64_t n,
+                              uint32_t *__restrict__ out) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = (uint32_t)(e - rows[keys[e]].off);
+}
 
 __global__ void k_owned_flags(const uint32_t *__restrict__ present, int64_t n_slots, int32_t vmin, int32_t rank,
                               int32_t world, uint32_t *__restrict__ out) {
@@ -181,15 +187,20 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
 
   // 4. per-row sorted ids (membership structure for computeSecondOrderWeights' `exists`)
   g.sids.alloc((size_t)n_owned);
+  g.sperm.alloc((size_t)std::max<int64_t>(n_owned, 1));
   if (n_owned) {
-    DevBuf<uint64_t> mk, mk2;
-    mk.alloc((size_t)n_owned); mk2.alloc((size_t)n_owned);
+    DevBuf<uint64_t> mk, mk2; DevBuf<uint32_t> li;
+    mk.alloc((size_t)n_owned); mk2.alloc((size_t)n_owned); li.alloc((size_t)n_owned);
+    g.sperm.alloc((size_t)n_owned);
     hipLaunchKernelGGL(k_member_keys, dim3(grid_for(n_owned)), dim3(TPB), 0, st, keys2.p, g.ent.p, n_owned, vmin, mk.p);
+    hipLaunchKernelGGL(k_local_index, dim3(grid_for(n_owned)), dim3(TPB), 0, st, keys2.p, g.rows.p, n_owned, li.p);
     int id_bits = bits_for((uint64_t)std::max<int64_t>(g.n_slots - 1, 1));
     size_t tb = 0;
-    SRW_HIP(rocprim::radix_sort_keys(nullptr, tb, mk.p, mk2.p, (size_t)n_owned, 0u, (unsigned)(32 + id_bits), st));
+    SRW_HIP(rocprim::radix_sort_pairs(nullptr, tb, mk.p, mk2.p, li.p, g.sperm.p, (size_t)n_owned, 0u,
+                                      (unsigned)(32 + id_bits), st));
     temp.alloc(tb);
-    SRW_HIP(rocprim::radix_sort_keys((void *)temp.p, tb, mk.p, mk2.p, (size_t)n_owned, 0u, (unsigned)(32 + id_bits), st));
+    SRW_HIP(rocprim::radix_sort_pairs((void *)temp.p, tb, mk.p, mk2.p, li.p, g.sperm.p, (size_t)n_owned, 0u,
+                                      (unsigned)(32 + id_bits), st));
     hipLaunchKernelGGL(k_low32, dim3(grid_for(n_owned)), dim3(TPB), 0, st, mk2.p, n_owned, g.sids.p);
     SRW_HIP(hipStreamSynchronize(st));
   }

@@ -97,10 +97,10 @@ __device__ inline FoEnt fo_pick(const FoEnt *row, int32_t deg, float r, int32_t 
 }
 
 // ---- exact pick, one wave per walker (general p, q) -----------------------------------------------------
-// All 64 lanes must call this with identical arguments.  Returns the chosen position (wave-uniform).
-__device__ inline int32_t wave_pick(const Ent *row, int32_t deg, const Bias &b, float r, unsigned &fallback) {
+// Sequential-chain form: all 64 lanes call with identical arguments.  Returns the chosen position
+// (wave-uniform).  S_known: pass the already-computed sum (fallback of wave_pick_scan) or NaN to compute it.
+__device__ inline double wave_sum_exact_or_chain(const Ent *row, int32_t deg, const Bias &b, unsigned &fallback) {
   const int lane = lane_id();
-  // pass 1: S = foldLeft(0.0)(_ + w')      (:14)
   double part = 0.0;
   SumCert cert;
   for (int32_t base = 0; base < deg; base += 64) {
@@ -114,24 +114,24 @@ __device__ inline int32_t wave_pick(const Ent *row, int32_t deg, const Bias &b, 
   }
   int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
   bool bad = __any(cert.bad);
-  double S;
-  if (sum_is_exact(emin, emax, bad, deg)) {
-    S = wave_sum_f64(part);
-  } else {
-    fallback = 1;
-    S = 0.0;
-    for (int32_t base = 0; base < deg; base += 64) {
-      int32_t k = base + lane;
-      double wd = 0.0;
-      if (k < deg) { Ent e = row[k]; wd = (double)biased_weight(b, e.id, e.w); }
-      int cnt = min(64, deg - base);
-      for (int i = 0; i < cnt; ++i) S = S + readlane_f64(wd, i);
-    }
+  if (sum_is_exact(emin, emax, bad, deg)) return wave_sum_f64(part);
+  fallback = 1;
+  double S = 0.0;
+  for (int32_t base = 0; base < deg; base += 64) {
+    int32_t k = base + lane;
+    double wd = 0.0;
+    if (k < deg) { Ent e = row[k]; wd = (double)biased_weight(b, e.id, e.w); }
+    int cnt = min(64, deg - base);
+    for (int i = 0; i < cnt; ++i) S = S + readlane_f64(wd, i);
   }
-  // pass 2: acc += w' / S ; first acc >= p   (:18-22)
+  return S;
+}
+
+__device__ inline int32_t wave_chain_pick(const Ent *row, int32_t deg, const Bias &b, float r, double S) {
+  const int lane = lane_id();
   const double p = (double)r;
   double acc = 0.0;
-  for (int32_t base = 0; base < deg; base += 64) {
+  for (int32_t base = 0; base < deg; base += 64) {     // acc += w' / S ; first acc >= p   (:18-22)
     int32_t k = base + lane;
     double d = 0.0;
     if (k < deg) { Ent e = row[k]; d = (double)biased_weight(b, e.id, e.w) / S; }
@@ -139,6 +139,171 @@ __device__ inline int32_t wave_pick(const Ent *row, int32_t deg, const Bias &b, 
     for (int i = 0; i < cnt; ++i) {
       acc = acc + readlane_f64(d, i);
       if (__builtin_amdgcn_readfirstlane((int)(acc >= p))) return base + i;  // acc is wave-uniform
+    }
+  }
+  return 0;  // edges.head (:24)
+}
+
+__device__ inline int32_t wave_pick(const Ent *row, int32_t deg, const Bias &b, float r, unsigned &fallback) {
+  double S = wave_sum_exact_or_chain(row, deg, b, fallback);   // S = foldLeft(0.0)(_ + w')  (:14)
+  return wave_chain_pick(row, deg, b, r, S);
+}
+
+// ---- certified parallel form -----------------------------------------------------------------------------
+// Membership of the candidates in N(prev), resolved once per step into an LDS bitmap over the candidate
+// positions ("reverse" marking: each element of the usually short N(prev) is looked up in the sorted N(curr)
+// and its occurrences' input-order positions are marked), or per candidate by binary search when that is
+// cheaper.  Both give the same booleans as prevNeighbors.exists(_._1 == dstId) (:37).
+constexpr int BM_WORDS = 2048;               // per-wave LDS bitmap: 65536 candidate positions per segment
+constexpr int BM_BITS = BM_WORDS * 32;
+
+struct Member {
+  int mode;            // 0: not needed, 1: binary search per candidate, 2: bitmap
+  uint32_t *bm;        // LDS, BM_WORDS words, private to the wave
+  int32_t seg_base;    // first candidate position covered by the bitmap
+};
+
+__device__ inline float biased_weight_m(const Bias &b, const Member &m, int32_t pos, int32_t id, float w) {
+  if (!b.second_order) return w;
+  if (id == b.prev) return w / b.p;
+  if (m.mode == 0) return w / b.q;
+  bool in;
+  if (m.mode == 2) { uint32_t t = (uint32_t)(pos - m.seg_base); in = (m.bm[t >> 5] >> (t & 31)) & 1u; }
+  else in = sorted_contains(b.prev_sids, b.prev_deg, (uint32_t)((int64_t)id - b.vmin));
+  return in ? w : w / b.q;
+}
+
+// Mark the candidates of segment [seg_base, seg_base + seg_len) that occur in N(prev).
+__device__ inline void fill_member_bitmap(const Bias &b, Member &m, const uint32_t *curr_sids,
+                                          const uint32_t *curr_sperm, int32_t deg, int32_t seg_base, int32_t seg_len) {
+  const int lane = lane_id();
+  m.seg_base = seg_base;
+  const int words = (seg_len + 31) >> 5;
+  for (int t = lane; t < words; t += 64) m.bm[t] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  for (int32_t t = lane; t < b.prev_deg; t += 64) {
+    uint32_t x = b.prev_sids[t];
+    if (t > 0 && b.prev_sids[t - 1] == x) continue;            // duplicates of a multi-edge: once is enough
+    int32_t lo = 0, hi = deg;
+    while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (curr_sids[mid] < x) lo = mid + 1; else hi = mid; }
+    for (int32_t pos = lo; pos < deg && curr_sids[pos] == x; ++pos) {
+      int32_t orig = (int32_t)curr_sperm[pos] - seg_base;
+      if (orig >= 0 && orig < seg_len) atomicOr(&m.bm[orig >> 5], 1u << (orig & 31));
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ inline double wave_incl_scan_f64(double v) {
+  const int lane = lane_id();
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// Certified parallel evaluation of RandomSample.sample on the biased row.
+//   S: certified-exact parallel sum (else the sequential chain).
+//   acc: ANY summation order of the same quotients d_k = w'_k / S differs from the reference's left-to-right
+//   acc_k by at most 2*gamma_k*sum(d_i) (Higham, d_i >= 0); with tol_k = (k + 1) * 2^-51 * acc_k a candidate is a
+//   CERTAIN miss if acc_k + tol_k < p and a CERTAIN hit if acc_k - tol_k >= p.  The reference's answer is the
+//   first index that is not a miss; if the first index that is not a certain miss is a certain hit it IS that
+//   answer, otherwise (a draw within rounding distance of a CDF boundary, an exact lattice tie, NaN) the step is
+//   redone with the exact sequential chain.  Rows with a negative/NaN/Inf weight go straight to the chain.
+__device__ inline int32_t wave_pick_scan(const GraphView &g, const Row &rc, const Bias &b, Member &m, float r,
+                                         unsigned &fallback) {
+  const int lane = lane_id();
+  const Ent *row = g.ent + rc.off;
+  const int32_t deg = rc.deg;
+  const uint32_t *csids = g.sids + rc.off, *csperm = g.sperm + rc.off;
+  // membership strategy
+  m.mode = 0;
+  if (b.need_member) {
+    // cost model (in binary-search probes): per-candidate search twice (two passes) vs reverse marking per segment
+    int lp = 32 - __clz(b.prev_deg | 1), lc = 32 - __clz(deg | 1);
+    int64_t nseg = ((int64_t)deg + BM_BITS - 1) / BM_BITS;
+    int64_t direct = 2ll * deg * lp, reverse = 2ll * nseg * b.prev_deg * lc + deg / 16;
+    m.mode = reverse < direct ? 2 : 1;
+  }
+  const int32_t seg_cap = (m.mode == 2) ? BM_BITS : 0x7FFFFFFF;
+  // ---- pass 1: S ----
+  double part = 0.0;
+  SumCert cert;
+  bool neg = false;
+  for (int32_t sb = 0; sb < deg; sb += seg_cap) {
+    int32_t sl = min(seg_cap, deg - sb);
+    if (m.mode == 2) fill_member_bitmap(b, m, csids, csperm, deg, sb, sl);
+    for (int32_t base = sb; base < sb + sl; base += 256) {
+      int32_t k0 = base + lane * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int32_t k = k0 + i;
+        if (k < sb + sl) {
+          Ent e = row[k];
+          float w = biased_weight_m(b, m, k, e.id, e.w);
+          part += (double)w;
+          cert.add(w);
+          neg |= !(w >= 0.0f);
+        }
+      }
+    }
+  }
+  int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
+  bool bad = __any(cert.bad) || __any(neg);
+  double S;
+  if (!bad && sum_is_exact(emin, emax, false, deg)) {
+    S = wave_sum_f64(part);
+  } else {
+    unsigned f = 0;
+    S = wave_sum_exact_or_chain(row, deg, b, f);
+    fallback = 1;
+    return wave_chain_pick(row, deg, b, r, S);
+  }
+  // ---- pass 2: certified scan ----
+  const double p = (double)r;
+  double carry = 0.0;
+  const bool single_seg = deg <= seg_cap;
+  for (int32_t sb = 0; sb < deg; sb += seg_cap) {
+    int32_t sl = min(seg_cap, deg - sb);
+    if (m.mode == 2 && !single_seg) fill_member_bitmap(b, m, csids, csperm, deg, sb, sl);
+    for (int32_t base = sb; base < sb + sl; base += 256) {
+      int32_t k0 = base + lane * 4;
+      double l[4];
+      double run = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int32_t k = k0 + i;
+        double d = 0.0;
+        if (k < sb + sl) { Ent e = row[k]; d = (double)biased_weight_m(b, m, k, e.id, e.w) / S; }
+        run += d;
+        l[i] = run;
+      }
+      double incl = wave_incl_scan_f64(run);
+      double excl = __shfl_up(incl, 1);               // pure additions only: no (incl - run) cancellation
+      if (lane == 0) excl = 0.0;
+      double lane_base = carry + excl;
+      int first = 4;          // first of my 4 candidates that is not a certain miss
+      bool sure = false;
+#pragma unroll
+      for (int i = 3; i >= 0; --i) {
+        int32_t k = k0 + i;
+        double acc = lane_base + l[i];
+        double tol = (double)(k + 1) * 0x1p-51 * acc;
+        bool valid = k < sb + sl;
+        bool miss = acc + tol < p;
+        if (valid && !miss) { first = i; sure = (acc - tol >= p); }
+      }
+      unsigned long long cand = __ballot(first < 4);
+      if (cand) {
+        int fl = __ffsll((long long)cand) - 1;
+        int fi = __builtin_amdgcn_readlane(first, fl);
+        int fs = __builtin_amdgcn_readlane((int)sure, fl);
+        if (fs) return base + fl * 4 + fi;
+        fallback = 1;                                     // within rounding distance of a boundary: exact chain
+        return wave_chain_pick(row, deg, b, r, S);
+      }
+      carry += readlane_f64(incl, 63);
     }
   }
   return 0;  // edges.head (:24)

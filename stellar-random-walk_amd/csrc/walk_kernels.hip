@@ -44,8 +44,8 @@ __device__ inline void flush_counters(DevCounters *ctr, unsigned long long steps
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <bool NT>
-__global__ __launch_bounds__(TPB) void k_walk_first_order(GraphView g, const int32_t *__restrict__ verts,
+template <bool NT, int MINW>
+__global__ __launch_bounds__(TPB, MINW) void k_walk_first_order(GraphView g, const int32_t *__restrict__ verts,
                                                           int64_t n_verts, int64_t n_walkers, int32_t L,
                                                           int32_t first_walk, RngSpec rng,
                                                           int32_t *__restrict__ paths, int32_t *__restrict__ lens,
@@ -126,9 +126,11 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
                                                       int32_t first_walk, RngSpec rng, float p, float q,
                                                       int32_t *__restrict__ paths, int32_t *__restrict__ lens,
                                                       DevCounters *ctr) {
+  __shared__ uint32_t bitmap[TPB / 64][BM_WORDS];
   const int lane = lane_id();
   const int64_t wi = (blockIdx.x * (int64_t)TPB + threadIdx.x) >> 6;  // one wave per walker
   if (wi >= n_walkers) return;
+  Member mem; mem.mode = 0; mem.bm = bitmap[threadIdx.x >> 6]; mem.seg_base = 0;
   const int64_t stride = (int64_t)L + 2;
   int64_t it = wi / n_verts, vi = wi - it * n_verts;
   const uint32_t iter = (uint32_t)(first_walk + it);
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
     Bias b = make_bias(g, p, q, prev, s > 1);
     float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
     unsigned f = 0;
-    int32_t k = wave_pick(g.ent + r.off, r.deg, b, u, f);
+    int32_t k = wave_pick_scan(g, r, b, mem, u, f);
     int32_t next = g.ent[r.off + k].id;
     degc += (unsigned long long)r.deg; fb += f;
     if (b.need_member) degp += (unsigned long long)b.prev_deg;
@@ -171,9 +173,11 @@ __global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *_
                                                     RngSpec rng, float p, float q, int32_t world,
                                                     Walker *__restrict__ out, unsigned long long *cursors,
                                                     int32_t *__restrict__ paths, int64_t stride, DevCounters *ctr) {
+  __shared__ uint32_t bitmap[TPB / 64][BM_WORDS];
   const int lane = lane_id();
   const int64_t ri = (blockIdx.x * (int64_t)TPB + threadIdx.x) >> 6;
   if (ri >= n_in) return;
+  Member mem; mem.mode = 0; mem.bm = bitmap[threadIdx.x >> 6]; mem.seg_base = 0;
   Walker wk = in[ri];
   const Row *rp = row_of(g, wk.curr);
   Row r; r.off = 0; r.deg = 0; r.flags = 0;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *_
   Bias b = make_bias(g, p, q, wk.prev, step > 1);
   float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
   unsigned f = 0;
-  int32_t k = wave_pick(g.ent + r.off, r.deg, b, u, f);
+  int32_t k = wave_pick_scan(g, r, b, mem, u, f);
   int32_t next = g.ent[r.off + k].id;
   if (lane == 0) {
     paths[(int64_t)wk.wid * stride + step] = next;
@@ -294,12 +298,14 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
     const size_t fo_bytes = (size_t)g.n_entries * sizeof(FoEnt);
     const bool nt = (P.flags & SRW_WALK_NT_LOADS) ? true
                     : (P.flags & SRW_WALK_CACHED_LOADS) ? false : fo_bytes > ((size_t)2 << 30);
-    if (nt)
-      hipLaunchKernelGGL(k_walk_first_order<true>, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices,
-                         n_walkers, P.walk_length, P.first_walk, rng, h->res.paths.p, h->res.lens.p, h->counters.p);
-    else
-      hipLaunchKernelGGL(k_walk_first_order<false>, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices,
-                         n_walkers, P.walk_length, P.first_walk, rng, h->res.paths.p, h->res.lens.p, h->counters.p);
+    const int occ = (P.flags >> 8) & 0xF;   // experiment switch: requested min waves/SIMD (0 = compiler's choice)
+#define SRW_LAUNCH_FO(NTV, MW)                                                                                      \
+  hipLaunchKernelGGL((k_walk_first_order<NTV, MW>), dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p,         \
+                     g.n_vertices, n_walkers, P.walk_length, P.first_walk, rng, h->res.paths.p, h->res.lens.p,      \
+                     h->counters.p)
+    if (nt) { if (occ == 8) SRW_LAUNCH_FO(true, 8); else if (occ == 7) SRW_LAUNCH_FO(true, 7); else SRW_LAUNCH_FO(true, 1); }
+    else    { if (occ == 8) SRW_LAUNCH_FO(false, 8); else if (occ == 7) SRW_LAUNCH_FO(false, 7); else SRW_LAUNCH_FO(false, 1); }
+#undef SRW_LAUNCH_FO
   } else {
     int64_t blocks = (n_walkers * 64 + TPB - 1) / TPB;
     hipLaunchKernelGGL(k_walk_general, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,

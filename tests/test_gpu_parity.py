@@ -385,3 +385,23 @@ def test_sharded_walker_world1_nccl(oracle):
         assert sum(s["n_steps_global"] for s in stats) == rs
     finally:
         dist.destroy_process_group()
+
+
+def test_giant_hub_multi_segment_membership(eng, oracle):
+    # deg(hub) = 150 000 > 65 536: the membership bitmap is built in three segments; leaves are chained so that
+    # N(prev) members fall into different segments; q != 1 exercises reverse marking AND per-candidate search
+    n = 150000
+    leaves = np.arange(1, n + 1, dtype=np.int32)
+    s = np.concatenate([np.zeros(n, dtype=np.int32), leaves[:-1][::3]])
+    d = np.concatenate([leaves, (leaves[:-1] + 1)[::3]])
+    rng = np.random.default_rng(5)
+    w = rng.integers(1, 5, len(s)).astype(np.float32)
+    g = oracle.Graph.from_coo(s, d, w)
+    eng.load_coo(s, d, w)
+    src = np.concatenate([[0], leaves[::9973]]).astype(np.int32)
+    for p, q in [(0.25, 4.0), (4.0, 0.5)]:
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=5, seed=17)
+        rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=5, seed=17, threads=8)
+        verts = eng.vertices()
+        idx = np.searchsorted(verts, src)
+        assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl)

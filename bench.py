@@ -88,10 +88,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:  # launched by torch.distributed.run (any world size, including 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        try:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        except TypeError:  # older signature without device_id
+            dist.init_process_group(backend="nccl")
 
     def barrier_sync():
         if dist is not None:

@@ -120,6 +120,7 @@ typedef struct {
   int64_t sum_deg_prev; /* general kernel: sum of deg(prev) over second-order steps with q != 1 */
   int64_t ent_reads;    /* first-order kernel: CDF records read */
   int64_t fallbacks;    /* steps that needed the exact sequential fallback */
+  int64_t trials;       /* Mode A: alias draws (accepted + rejected) */
   double kernel_ms;     /* hipEvent time of the walk kernels of this call, on the handle's stream */
   int32_t kernel_kind;  /* 1 = first-order guide-table kernel, 2 = general second-order kernel, 3 = alias */
   int32_t reserved;
@@ -138,6 +139,11 @@ int32_t srw_device_paths(const srw_handle *h, void **d_paths, void **d_lens, int
  * <output_dir>/path/part-00000.. (TAB-joined ids, one '\n' per path) and _SUCCESS; canonical line
  * order (walk iteration major, source id ascending).  write_crc != 0 adds Hadoop .crc side files. */
 int32_t srw_write_paths(const srw_handle *h, const char *output_dir, int32_t n_parts, int32_t write_crc);
+
+/* Mode A table of vertex v (build-defined exact-integer alias construction): prob/alias of each
+ * neighbor slot (alias = position inside the row); *regular = 0 when the row is not alias-regular (Mode A
+ * then samples it by CDF inversion).  *n as srw_graph_neighbors. */
+int32_t srw_alias_row(srw_handle *h, int32_t v, float *prob, int32_t *alias, int64_t cap, int64_t *n, int32_t *regular);
 
 /* ---- vertex-sharded multi-GPU path (one handle per GPU, world > 1) -------------------------- */
 typedef struct { int32_t wid, src, prev, curr; } srw_walker; /* 16-byte record exchanged over xGMI */

@@ -26,7 +26,7 @@ def build(force=False):
 class WalkParams(C.Structure):
     _fields_ = [("p", C.c_float), ("q", C.c_float), ("walk_length", C.c_int32), ("num_walks", C.c_int32),
                 ("rng_mode", C.c_int32), ("const_r", C.c_float), ("seed", C.c_uint32),
-                ("first_walk", C.c_int32), ("faithful", C.c_int32), ("threads", C.c_int32)]
+                ("first_walk", C.c_int32), ("faithful", C.c_int32), ("threads", C.c_int32), ("sampler", C.c_int32)]
 
 
 _lib = None
@@ -81,6 +81,8 @@ def lib():
     L.orc_seq_walk.restype = C.c_int32
     L.orc_seq_walk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(WalkParams), i32p]
     L.orc_write_paths.argtypes = [i32p, i32p, C.c_int64, C.c_int64, C.c_char_p, C.c_int]
+    L.orc_alias_row.argtypes = [f32p, C.c_int64, f32p, i32p]
+    L.orc_graph_alias_row.argtypes = [C.c_void_p, C.c_int32, f32p, i32p]
     L.orc_rmat_edges.argtypes = [C.c_int, C.c_uint32, C.c_int64, C.c_int64, i32p, i32p]
     L.orc_rmat_weight.restype = C.c_float
     L.orc_rmat_weight.argtypes = [C.c_int32, C.c_int32, C.c_uint32]
@@ -243,6 +245,15 @@ class Graph:
         lib().orc_graph_neighbors(self.h, v, _i32(ids), _f32(w), n)
         return ids[:n], w[:n]
 
+    def alias_row(self, v):
+        n = self.degree(v)
+        if n < 0:
+            return None
+        prob = np.zeros(max(n, 1), dtype=np.float32)
+        alias = np.zeros(max(n, 1), dtype=np.int32)
+        reg = int(lib().orc_graph_alias_row(self.h, v, _f32(prob), _i32(alias)))
+        return reg, prob[:n], alias[:n]
+
     def lines(self):
         n = self.num_lines
         s, d, p = (np.zeros(max(n, 1), dtype=np.int32) for _ in range(3))
@@ -251,10 +262,10 @@ class Graph:
         return s[:n], d[:n], w[:n], p[:n]
 
     def params(self, p=1.0, q=1.0, walk_length=80, num_walks=1, rng="philox", const_r=0.0, seed=42,
-               first_walk=0, faithful=False, threads=1):
+               first_walk=0, faithful=False, threads=1, sampler=0):
         return WalkParams(np.float32(p), np.float32(q), walk_length, num_walks,
                           RNG_CONST if rng == "const" else RNG_PHILOX, np.float32(const_r), seed, first_walk,
-                          int(faithful), threads)
+                          int(faithful), threads, int(sampler))
 
     def walk(self, sources=None, **kw):
         """Returns (paths [nWalkers, L+2] int32 with -1 padding, lens, steps)."""
@@ -275,6 +286,15 @@ class Graph:
         out = np.full(P.walk_length + 2, -1, dtype=np.int32)
         n = int(lib().orc_seq_walk(self.h, src, it, C.byref(P), _i32(out)))
         return out[:n]
+
+
+def alias_row(w):
+    """Mode A exact-integer alias table of one weight list: (regular, prob, alias)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    prob = np.zeros(max(len(w), 1), dtype=np.float32)
+    alias = np.zeros(max(len(w), 1), dtype=np.int32)
+    reg = int(lib().orc_alias_row(_f32(w), len(w), _f32(prob), _i32(alias)))
+    return reg, prob[:len(w)], alias[:len(w)]
 
 
 def write_paths(paths, lens, output_dir, n_parts=1):

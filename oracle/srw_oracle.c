@@ -336,6 +336,7 @@ struct orc_graph {
   uint8_t *present; int64_t *off; /* n_slots + 1 */
   int32_t *ids; float *w; int32_t *sorted_ids;
   int64_t n_entries, n_vertices;
+  float *a_prob; int32_t *a_alias; uint8_t *a_regular; /* Mode A tables, built lazily */
 };
 
 static int cmp_i32(const void *a, const void *b) { int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return (x > y) - (x < y); }
@@ -418,7 +419,8 @@ orc_graph *orc_graph_load_edgelist(const char *path, int directed, int weighted,
 void orc_graph_free(orc_graph *g) {
   if (!g) return;
   free(g->l_src); free(g->l_dst); free(g->l_pid); free(g->l_w);
-  free(g->present); free(g->off); free(g->ids); free(g->w); free(g->sorted_ids); free(g);
+  free(g->present); free(g->off); free(g->ids); free(g->w); free(g->sorted_ids);
+  free(g->a_prob); free(g->a_alias); free(g->a_regular); free(g);
 }
 int64_t orc_graph_num_vertices(const orc_graph *g) { return g->n_vertices; }
 int64_t orc_graph_num_entries(const orc_graph *g) { return g->n_entries; }
@@ -446,6 +448,86 @@ void orc_graph_lines(const orc_graph *g, int32_t *src, int32_t *dst, float *w, i
     if (src) src[i] = g->l_src[i]; if (dst) dst[i] = g->l_dst[i];
     if (w) w[i] = g->l_w[i]; if (pid) pid[i] = g->l_pid[i];
   }
+}
+
+/* ============================================================================================ */
+/* Mode A — exact-integer alias tables + rejection (build-defined)              */
+/* ============================================================================================ */
+typedef unsigned __int128 u128;
+
+/* Alias-regular: every weight finite and >= 0, some weight > 0, and ceil_log2(n) + e_max - e_min <= 29 (the
+ * exactness certificate of the Mode R sum).  Then W_k = w_k * 2^(23 - e_min) are exact integers,
+ * T = sum W_k < 2^53, m_k = W_k * n < 2^53, and the table is defined by integer prefix sums:
+ *   lights (m_k < T) in index order, deficits d_i = T - m, D_i = prefix sums; heavies (m_k >= T), excesses
+ *   e_j = m - T, E_j = prefix sums;
+ *   light i : keeps m, alias = first heavy j with E_j > D_{i-1};
+ *   heavy j : first light i with D_i > E_j; if D_{i-1} < E_j it keeps T - (D_i - E_j), alias = heavy j+1;
+ *             otherwise (no such light, or the previous light ended exactly at E_j) it keeps T. */
+int orc_alias_row(const float *w, int64_t n, float *prob, int32_t *alias) {
+  if (n <= 0) return 0;
+  int emin = 1 << 20, emax = -(1 << 20);
+  for (int64_t k = 0; k < n; ++k) {
+    uint32_t b; memcpy(&b, &w[k], 4);
+    int ex = (int)((b >> 23) & 0xFF);
+    if (ex == 255) return 0;                 /* NaN / Inf */
+    if ((b & 0x7FFFFFFFu) == 0) continue;
+    if (b >> 31) return 0;                   /* negative */
+    int e = ex ? ex - 127 : -126;
+    if (e < emin) emin = e; if (e > emax) emax = e;
+  }
+  if (emax < emin) return 0;                 /* all zero */
+  int cl = 0; while (((int64_t)1 << cl) < n) ++cl;
+  if (cl + emax - emin > 29) return 0;
+  uint64_t *W = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+  uint64_t T = 0;
+  for (int64_t k = 0; k < n; ++k) { W[k] = (uint64_t)ldexp((double)w[k], 23 - emin); T += W[k]; }
+  int64_t a = 0, b = 0;
+  int64_t *L = (int64_t *)malloc(sizeof(int64_t) * (size_t)n), *H = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+  u128 *D = (u128 *)malloc(sizeof(u128) * (size_t)(n + 1)), *E = (u128 *)malloc(sizeof(u128) * (size_t)(n + 1));
+  D[0] = 0; E[0] = 0;
+  for (int64_t k = 0; k < n; ++k) {
+    uint64_t m = W[k] * (uint64_t)n;
+    if (m >= T) { H[b] = k; E[b + 1] = E[b] + (u128)(m - T); ++b; }
+    else { L[a] = k; D[a + 1] = D[a] + (u128)(T - m); ++a; }
+  }
+  int64_t j = 0;                                   /* lights: two-pointer over E */
+  for (int64_t i = 0; i < a; ++i) {
+    while (j < b && E[j + 1] <= D[i]) ++j;        /* first heavy with E_j > D_{i-1} */
+    int64_t k = L[i];
+    alias[k] = (int32_t)H[j];
+    prob[k] = (float)((double)(W[k] * (uint64_t)n) / (double)T);
+  }
+  int64_t i = 0;                                   /* heavies: two-pointer over D */
+  for (j = 0; j < b; ++j) {
+    while (i < a && D[i + 1] <= E[j + 1]) ++i;    /* first light with D_i > E_j */
+    int64_t k = H[j];
+    if (i < a && D[i] < E[j + 1]) {                /* that light started inside this heavy's excess interval */
+      uint64_t x = (uint64_t)(D[i + 1] - E[j + 1]);
+      alias[k] = (int32_t)H[j + 1];
+      prob[k] = (float)((double)(T - x) / (double)T);
+    } else { alias[k] = (int32_t)k; prob[k] = 1.0f; }
+  }
+  free(W); free(L); free(H); free(D); free(E);
+  return 1;
+}
+
+static void graph_build_alias(orc_graph *g) {
+  if (g->a_prob) return;
+  g->a_prob = (float *)malloc(sizeof(float) * (size_t)(g->n_entries ? g->n_entries : 1));
+  g->a_alias = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->n_entries ? g->n_entries : 1));
+  g->a_regular = (uint8_t *)calloc((size_t)(g->n_slots ? g->n_slots : 1), 1);
+  for (int64_t v = 0; v < g->n_slots; ++v) {
+    int64_t n = g->off[v + 1] - g->off[v];
+    if (n > 0) g->a_regular[v] = (uint8_t)orc_alias_row(g->w + g->off[v], n, g->a_prob + g->off[v], g->a_alias + g->off[v]);
+  }
+}
+
+int orc_graph_alias_row(const orc_graph *g, int32_t v, float *prob, int32_t *alias) {
+  if (g->n_slots == 0 || v < g->vmin || v > g->vmax || !g->present[(int64_t)v - g->vmin]) return -1;
+  graph_build_alias((orc_graph *)g);
+  int64_t s = (int64_t)v - g->vmin, n = g->off[s + 1] - g->off[s];
+  for (int64_t k = 0; k < n; ++k) { prob[k] = g->a_prob[g->off[s] + k]; alias[k] = g->a_alias[g->off[s] + k]; }
+  return g->a_regular[s];
 }
 
 /* ============================================================================================ */
@@ -482,6 +564,48 @@ static int64_t second_order_pick(const orc_graph *g, const orc_walk_params *P, i
   return orc_sample_index(scratch, n, r);
 }
 
+/* Mode A step: trial t draws (x0..x3) = Philox(ctr = (iter, src, step, t), key = (seed, 0xA11A5));
+ * slot j = ((x0:x1) * n) >> 64, coin u2 = (x2 >> 8) * 2^-24 picks j or alias[j]; a second-order step accepts
+ * the candidate iff u3 * M < bias with u3 = (x3 >> 8) * 2^-24, M = max(1/p, 1, 1/q),
+ * bias = 1/p (dst == prev), 1 (dst in N(prev)), 1/q (else).  An irregular row uses the reference's CDF
+ * inversion with u2 of trial 0. */
+static int sorted_contains(const int32_t *a, int64_t n, int32_t x);
+static int64_t second_order_pick(const orc_graph *g, const orc_walk_params *P, int32_t prev, int64_t ps,
+                                 int64_t cs, float r, float *scratch);
+static int64_t alias_pick(const orc_graph *g, const orc_walk_params *P, int second_order, int32_t prev, int64_t ps,
+                          int64_t cs, uint32_t iter, int32_t src, uint32_t step, float *scratch) {
+  int64_t n = g->off[cs + 1] - g->off[cs];
+  const int32_t *cid = g->ids + g->off[cs];
+  uint32_t key[2] = {P->seed, 0xA11A5u}, o[4];
+  if (!g->a_regular[cs]) {
+    uint32_t ctr[4] = {iter, (uint32_t)src, step, 0u};
+    orc_philox4x32_10(ctr, key, o);
+    float u = (float)(o[2] >> 8) * (1.0f / 16777216.0f);
+    if (!second_order) return orc_sample_index(g->w + g->off[cs], n, u);
+    orc_walk_params Q = *P; Q.faithful = 0;
+    return second_order_pick(g, &Q, prev, ps, cs, u, scratch);
+  }
+  const float inv_p = 1.0f / P->p, inv_q = 1.0f / P->q;
+  float M = inv_p > 1.0f ? inv_p : 1.0f; if (inv_q > M) M = inv_q;
+  const int biased = second_order && !(P->p == 1.0f && P->q == 1.0f);
+  int64_t k = 0;
+  for (uint32_t t = 0; t < 65536u; ++t) {
+    uint32_t ctr[4] = {iter, (uint32_t)src, step, t};
+    orc_philox4x32_10(ctr, key, o);
+    uint64_t r64 = ((uint64_t)o[0] << 32) | o[1];
+    int64_t j = (int64_t)(((u128)r64 * (u128)(uint64_t)n) >> 64);
+    float u2 = (float)(o[2] >> 8) * (1.0f / 16777216.0f);
+    k = (u2 < g->a_prob[g->off[cs] + j]) ? j : g->a_alias[g->off[cs] + j];
+    if (!biased) return k;
+    float bias = inv_q;
+    if (cid[k] == prev) bias = inv_p;
+    else if (sorted_contains(g->sorted_ids + g->off[ps], g->off[ps + 1] - g->off[ps], cid[k])) bias = 1.0f;
+    float u3 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
+    if (u3 * M < bias) return k;
+  }
+  return k;
+}
+
 static int32_t walk_one(const orc_graph *g, const orc_walk_params *P, int32_t src, uint32_t iter,
                         int32_t *path, float **scratch, int64_t *scratch_cap) {
   int32_t L2 = P->walk_length + 2;
@@ -491,7 +615,8 @@ static int32_t walk_one(const orc_graph *g, const orc_walk_params *P, int32_t sr
   if (cs < 0) return len;
   int64_t n = g->off[cs + 1] - g->off[cs];
   if (n == 0) return len;                                       /* dead end, RandomWalk.scala:59-62 */
-  int64_t k = orc_sample_index(g->w + g->off[cs], n, draw(P, iter, src, 1)); /* :57 */
+  int64_t k = P->sampler == 1 ? alias_pick(g, P, 0, src, cs, cs, iter, src, 1, *scratch)
+                              : orc_sample_index(g->w + g->off[cs], n, draw(P, iter, src, 1)); /* :57 */
   int32_t prev = src; int64_t ps = cs;
   int32_t curr = g->ids[g->off[cs] + k];
   path[len++] = curr;
@@ -500,7 +625,8 @@ static int32_t walk_one(const orc_graph *g, const orc_walk_params *P, int32_t sr
     n = g->off[cs + 1] - g->off[cs];
     if (n == 0) break;                                          /* :115-120 */
     if (n > *scratch_cap) { *scratch_cap = n * 2; *scratch = (float *)realloc(*scratch, sizeof(float) * (size_t)*scratch_cap); }
-    k = second_order_pick(g, P, prev, ps, cs, draw(P, iter, src, (uint32_t)len), *scratch); /* :112-113 */
+    k = P->sampler == 1 ? alias_pick(g, P, 1, prev, ps, cs, iter, src, (uint32_t)len, *scratch)
+                        : second_order_pick(g, P, prev, ps, cs, draw(P, iter, src, (uint32_t)len), *scratch); /* :112-113 */
     prev = curr; ps = cs;
     curr = g->ids[g->off[cs] + k];
     path[len++] = curr;                                         /* :114 */
@@ -561,6 +687,7 @@ static void *walk_thread(void *arg) {
 int64_t orc_walk(const orc_graph *g, const orc_walk_params *P, const int32_t *sources, int64_t n_sources,
                  int32_t *paths, int32_t *lens) {
   int32_t *all = NULL;
+  if (P->sampler == 1) graph_build_alias((orc_graph *)g);
   if (!sources) {
     n_sources = g->n_vertices;
     all = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_sources ? n_sources : 1));

@@ -93,6 +93,7 @@ typedef struct {
   int32_t first_walk;  /* first walk-iteration index (for the philox counter) */
   int32_t faithful;    /* 1: linear `exists` membership as in the reference; 0: sorted membership */
   int32_t threads;     /* >= 1 */
+  int32_t sampler;     /* 0: Mode R (reference CDF inversion); 1: Mode A (alias + rejection, build-defined) */
 } orc_walk_params;
 /* Whole job: for each walk iteration, one walker per present vertex (ascending id).  paths is
  * [num_walks * nVertices][walk_length + 2] (unused tail = -1), lens per walker.  If `sources` is
@@ -102,6 +103,14 @@ int64_t orc_walk(const orc_graph *, const orc_walk_params *, const int32_t *sour
                  int32_t *paths, int32_t *lens);
 /* Restatement of the reference's own test oracle doSecondOrderRandomWalk for a single source. */
 int32_t orc_seq_walk(const orc_graph *, int32_t src, int32_t iter, const orc_walk_params *, int32_t *out_path);
+
+/* ---- Mode A (build-defined; NOT in the reference, which has no alias tables — SURVEY §0-1) ------------------
+ * Exact-integer alias table of one neighbor list (spec in DESIGN.md §4.6): returns 1 and fills prob/alias
+ * (alias = position inside the list) when the list is alias-regular, else 0 (Mode A then samples that vertex
+ * with the reference's CDF inversion). */
+int orc_alias_row(const float *w, int64_t n, float *prob, int32_t *alias);
+/* alias table of vertex v of a graph (same construction), -1 if v is absent */
+int orc_graph_alias_row(const orc_graph *, int32_t v, float *prob, int32_t *alias);
 
 /* ---- writer: M/algorithm/RandomWalk.scala:234-241, M/common/Property.scala:6 ------------------ */
 /* Writes <output>/path/part-%05d + _SUCCESS.  Fails (-1) if <output>/path exists. */

@@ -41,7 +41,7 @@ class WalkParams(C.Structure):
 class WalkStats(C.Structure):
     _fields_ = [("n_walkers", C.c_int64), ("n_steps", C.c_int64), ("dead_ends", C.c_int64),
                 ("sum_deg_curr", C.c_int64), ("sum_deg_prev", C.c_int64), ("ent_reads", C.c_int64),
-                ("fallbacks", C.c_int64), ("kernel_ms", C.c_double), ("kernel_kind", C.c_int32),
+                ("fallbacks", C.c_int64), ("trials", C.c_int64), ("kernel_ms", C.c_double), ("kernel_kind", C.c_int32),
                 ("reserved", C.c_int32)]
 
     def as_dict(self):
@@ -52,7 +52,7 @@ class WalkStats(C.Structure):
 EXPORTS = [
     "srw_create", "srw_destroy", "srw_last_error", "srw_set_stream", "srw_load_edgelist", "srw_load_coo",
     "srw_load_adjacency", "srw_generate_rmat", "srw_graph_stats", "srw_graph_vertices", "srw_graph_neighbors",
-    "srw_graph_partition", "srw_walk", "srw_fetch_paths", "srw_device_paths", "srw_write_paths",
+    "srw_graph_partition", "srw_alias_row", "srw_walk", "srw_fetch_paths", "srw_device_paths", "srw_write_paths",
     "srw_shard_capacity", "srw_shard_seed", "srw_shard_step", "srw_sample", "srw_second_order_weights",
     "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_version",
 ]
@@ -85,6 +85,7 @@ def lib():
     L.srw_graph_vertices.argtypes = [vp, i32p]
     L.srw_graph_neighbors.argtypes = [vp, C.c_int32, i32p, f32p, C.c_int64, i64p]
     L.srw_graph_partition.argtypes = [vp, C.c_int32, i32p, i32p]
+    L.srw_alias_row.argtypes = [vp, C.c_int32, f32p, i32p, C.c_int64, i64p, i32p]
     L.srw_walk.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(WalkStats)]
     L.srw_fetch_paths.argtypes = [vp, i32p, i32p]
     L.srw_device_paths.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i64p, i32p]
@@ -266,10 +267,25 @@ class Engine:
         self._ck(lib().srw_graph_partition(self.h, v, C.byref(pid), C.byref(known)))
         return pid.value if known.value else None
 
+    def alias_row(self, v):
+        """Mode A table of vertex v: None if absent, else (regular, prob, alias)."""
+        n, reg = C.c_int64(0), C.c_int32(0)
+        self._ck(lib().srw_alias_row(self.h, v, None, None, 0, C.byref(n), C.byref(reg)))
+        if n.value < 0:
+            return None
+        prob = np.zeros(max(n.value, 1), dtype=np.float32)
+        alias = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._ck(lib().srw_alias_row(self.h, v, _f32(prob), _i32(alias), n.value, C.byref(n), C.byref(reg)))
+        return reg.value, prob[:n.value], alias[:n.value]
+
     # ---- walk ----
     @staticmethod
     def params(p=1.0, q=1.0, walk_length=80, num_walks=1, first_walk=0, rng="philox", const_r=0.0, seed=42,
                sampler=SAMPLER_REFERENCE, force_general=False, nt_loads=None, occ=0):
+        if sampler == "alias":
+            sampler = SAMPLER_ALIAS
+        elif sampler == "reference":
+            sampler = SAMPLER_REFERENCE
         return WalkParams(np.float32(p), np.float32(q), walk_length, num_walks, first_walk,
                           RNG_CONST if rng == "const" else RNG_PHILOX, np.float32(const_r), seed, sampler,
                           (WALK_FORCE_GENERAL if force_general else 0) | (0 if nt_loads is None else WALK_NT_LOADS if nt_loads else WALK_CACHED_LOADS) | (occ << 8))

@@ -224,6 +224,28 @@ int32_t srw_graph_partition(const srw_handle *h, int32_t v, int32_t *pid, int32_
   return SRW_OK;
 }
 
+int32_t srw_alias_row(srw_handle *h, int32_t v, float *prob, int32_t *alias, int64_t cap, int64_t *n, int32_t *regular) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(h->g.loaded && n, "no graph / null n");
+    build_alias_tables(h);
+    const Graph &g = h->g;
+    int64_t s = (int64_t)v - g.vmin;
+    if (s < 0 || s >= g.n_slots) { *n = -1; return; }
+    Row r;
+    SRW_HIP(hipMemcpy(&r, g.rows.p + s, sizeof(Row), hipMemcpyDeviceToHost));
+    if (!(r.flags & ROW_PRESENT)) { *n = -1; return; }
+    *n = r.deg;
+    if (regular) *regular = (r.flags & ROW_ALIAS_IRREGULAR) ? 0 : 1;
+    int64_t m = std::min<int64_t>(cap, r.deg);
+    if (m > 0) {
+      std::vector<AEnt> tmp((size_t)m);
+      SRW_HIP(hipMemcpy(tmp.data(), g.al.p + r.off, (size_t)m * sizeof(AEnt), hipMemcpyDeviceToHost));
+      for (int64_t k = 0; k < m; ++k) { if (prob) prob[k] = tmp[k].prob; if (alias) alias[k] = tmp[k].alias; }
+    }
+  });
+}
+
 int32_t srw_walk(srw_handle *h, const srw_walk_params *params, srw_walk_stats *stats) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] { need(params != nullptr, "params is null"); run_walk(h, *params, stats); });

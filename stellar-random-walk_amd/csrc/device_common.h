@@ -18,7 +18,7 @@ struct alignas(16) Row {
   int32_t deg;
   uint32_t flags;
 };
-enum : uint32_t { ROW_PRESENT = 1u, ROW_IRREGULAR = 2u };
+enum : uint32_t { ROW_PRESENT = 1u, ROW_IRREGULAR = 2u, ROW_ALIAS_IRREGULAR = 4u };
 
 struct alignas(8) Ent {
   int32_t id;
@@ -36,6 +36,17 @@ struct alignas(32) FoEnt {
   uint32_t nflags;
 };
 
+// Mode A record: alias slot of entry k of a row + the neighbor's id / weight / row descriptor (linked).
+struct alignas(32) AEnt {
+  float prob;    // P(keep slot k | slot k drawn) = kept_k / T, exact-integer construction (alias_tables.hip)
+  int32_t alias; // position (inside the row) used otherwise
+  int32_t id;
+  float w;
+  int64_t noff;
+  int32_t ndeg;
+  uint32_t nflags;
+};
+
 struct alignas(16) Walker {
   int32_t wid, src, prev, curr;
 };
@@ -46,6 +57,7 @@ struct GraphView {
   const uint32_t *sids;
   const uint32_t *sperm;
   const FoEnt *fo;
+  const AEnt *al;
   int32_t vmin;
   int64_t n_slots;
 };

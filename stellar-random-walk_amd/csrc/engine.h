@@ -69,10 +69,12 @@ struct Graph {
   DevBuf<uint32_t> sperm;         // [n_entries] input-order position (inside the row) of each sorted entry
   DevBuf<FoEnt> fo;               // [n_entries], built lazily
   bool has_fo = false;
+  DevBuf<AEnt> al;                // [n_entries] Mode A alias records, built lazily
+  bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
-  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, vmin, n_slots}; }
+  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_al ? al.p : nullptr, vmin, n_slots}; }
 };
 
 struct WalkResult {
@@ -83,7 +85,7 @@ struct WalkResult {
 };
 
 struct DevCounters {  // device-side accumulators, one 64-bit word each
-  unsigned long long steps, dead_ends, sum_deg_curr, sum_deg_prev, ent_reads, fallbacks, owned_entries, pad;
+  unsigned long long steps, dead_ends, sum_deg_curr, sum_deg_prev, ent_reads, fallbacks, owned_entries, trials;
 };
 
 }  // namespace srw
@@ -122,6 +124,9 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,
                          DevBuf<int32_t> &d_src, DevBuf<int32_t> &d_dst, DevBuf<float> &d_w);
 void build_first_order_tables(srw_handle *h);
+
+// ---- alias_tables.hip ----
+void build_alias_tables(srw_handle *h);
 
 // ---- walk_kernels.hip ----
 void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats);

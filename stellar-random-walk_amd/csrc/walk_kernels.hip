@@ -166,6 +166,95 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Mode A: per-vertex alias draw + rejection for the p/q bias (KnightKing-style), one walker per lane, each lane
+// its own (step, trial) state machine so that lanes do not wait for each other's rejections.  Spec shared with
+// oracle/srw_oracle.c:alias_pick — trial t of step s draws Philox(ctr = (iter, src, s, t), key = (seed, 0xA11A5)):
+// slot j = ((x0:x1) * deg) >> 64, coin u2 = (x2 >> 8) 2^-24 keeps j or takes alias[j]; a second-order step accepts
+// iff u3 * M < bias, u3 = (x3 >> 8) 2^-24, M = max(1/p, 1, 1/q), bias = 1/p | 1 | 1/q.
+template <bool NT>
+__device__ inline AEnt load_al(const AEnt *p) {
+  if (NT) {
+    const int4v *q = reinterpret_cast<const int4v *>(p);
+    int4v a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+    AEnt e;
+    e.prob = __int_as_float(a.x); e.alias = a.y; e.id = a.z; e.w = __int_as_float(a.w);
+    e.noff = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
+    e.ndeg = b.z; e.nflags = (uint32_t)b.w;
+    return e;
+  }
+  return *p;
+}
+
+template <bool NT>
+__global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
+                                                    int64_t n_walkers, int32_t L, int32_t first_walk, uint32_t seed,
+                                                    float p, float q, int32_t *__restrict__ paths,
+                                                    int32_t *__restrict__ lens, DevCounters *ctr) {
+  const int64_t wi = blockIdx.x * (int64_t)TPB + threadIdx.x;
+  unsigned long long reads = 0, dead = 0, fb = 0, trials = 0;
+  int32_t len = 0;
+  if (wi < n_walkers) {
+    const int64_t stride = (int64_t)L + 2;
+    const int64_t it = wi / n_verts, vi = wi - it * n_verts;
+    const uint32_t iter = (uint32_t)(first_walk + it);
+    const int32_t src = verts[vi];
+    int32_t *path = paths + wi * stride;
+    Row rc; rc.off = 0; rc.deg = 0; rc.flags = 0;
+    { const Row *rp0 = row_of(g, src); if (rp0) rc = *rp0; }
+    Row rp = rc;
+    int32_t curr = src, prev = src;
+    path[0] = src; len = 1;
+    const float inv_p = 1.0f / p, inv_q = 1.0f / q;
+    const float M = fmaxf(fmaxf(inv_p, 1.0f), inv_q);
+    const bool biased_cfg = !(p == 1.0f && q == 1.0f);
+    int32_t s = 1; uint32_t t = 0;
+    while (s <= L + 1) {
+      if (rc.deg == 0) { if (s > 1) ++dead; break; }
+      const bool second = s > 1, biased = second && biased_cfg;
+      uint32_t o[4];
+      philox4x32_10(iter, (uint32_t)src, (uint32_t)s, t, seed, 0xA11A5u, o);
+      AEnt e;
+      bool accepted = true;
+      if (rc.flags & ROW_ALIAS_IRREGULAR) {     // not alias-regular: the reference's CDF inversion, literally
+        Bias b; b.p = p; b.q = q; b.prev = prev; b.second_order = second; b.need_member = second && q != 1.0f;
+        b.prev_sids = g.sids + rp.off; b.prev_deg = rp.deg; b.vmin = g.vmin;
+        float u = (float)(o[2] >> 8) * (1.0f / 16777216.0f);
+        int32_t k = lane_pick_sequential(g.ent + rc.off, rc.deg, b, u);
+        e = g.al[rc.off + k]; ++fb;
+      } else {
+        const uint64_t r64 = ((uint64_t)o[0] << 32) | o[1];
+        const int64_t j = (int64_t)__umul64hi(r64, (uint64_t)(uint32_t)rc.deg);
+        e = load_al<NT>(g.al + rc.off + j); ++reads;
+        const float u2 = (float)(o[2] >> 8) * (1.0f / 16777216.0f);
+        if (!(u2 < e.prob)) { e = load_al<NT>(g.al + rc.off + e.alias); ++reads; }
+        ++trials;
+        if (biased) {
+          float bias = inv_q;
+          if (e.id == prev) bias = inv_p;
+          else if (sorted_contains(g.sids + rp.off, rp.deg, (uint32_t)((int64_t)e.id - g.vmin))) bias = 1.0f;
+          const float u3 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
+          accepted = (u3 * M < bias) || (t + 1u >= 65536u);
+        }
+      }
+      if (accepted) {
+        path[s] = e.id;
+        prev = curr; rp = rc; curr = e.id;
+        rc.off = e.noff; rc.deg = e.ndeg; rc.flags = e.nflags;
+        ++s; ++len; t = 0;
+      } else {
+        ++t;
+      }
+    }
+    for (int64_t t2 = len; t2 < stride; ++t2) path[t2] = -1;
+    lens[wi] = len;
+  }
+  unsigned long long steps = len > 0 ? (unsigned long long)(len - 1) : 0ull;
+  flush_counters(ctr, steps, dead, 0, 0, reads, fb);
+  trials = wave_sum_u64(trials);
+  if (lane_id() == 0 && trials) atomicAdd(&ctr->trials, trials);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Vertex-sharded super-step.  mode 0: count survivors per destination owner; mode 1: emit them.
 // One wave per record keeps the sampler identical to k_walk_general (bit-identical paths for any world).
 __global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *__restrict__ in, int64_t n_in,
@@ -257,15 +346,16 @@ void read_counters(srw_handle *h, srw_walk_stats *stats) {
   if (!stats) return;
   stats->n_steps = (int64_t)c.steps; stats->dead_ends = (int64_t)c.dead_ends;
   stats->sum_deg_curr = (int64_t)c.sum_deg_curr; stats->sum_deg_prev = (int64_t)c.sum_deg_prev;
-  stats->ent_reads = (int64_t)c.ent_reads; stats->fallbacks = (int64_t)c.fallbacks;
+  stats->ent_reads = (int64_t)c.ent_reads; stats->fallbacks = (int64_t)c.fallbacks; stats->trials = (int64_t)c.trials;
 }
 
 void check_params(const srw_walk_params &P) {
   if (P.walk_length < 0) throw Error(SRW_ERR_INVALID, "walk_length must be >= 0");
   if (P.num_walks < 1) throw Error(SRW_ERR_INVALID, "num_walks must be >= 1");
   if (P.rng_mode != SRW_RNG_CONST && P.rng_mode != SRW_RNG_PHILOX) throw Error(SRW_ERR_INVALID, "bad rng_mode");
-  if (P.sampler != SRW_SAMPLER_REFERENCE)
-    throw Error(SRW_ERR_INVALID, "sampler: only SRW_SAMPLER_REFERENCE (Mode R) is built in this round");
+  if (P.sampler != SRW_SAMPLER_REFERENCE && P.sampler != SRW_SAMPLER_ALIAS) throw Error(SRW_ERR_INVALID, "bad sampler");
+  if (P.sampler == SRW_SAMPLER_ALIAS && P.rng_mode != SRW_RNG_PHILOX)
+    throw Error(SRW_ERR_INVALID, "Mode A draws several uniforms per step: it needs SRW_RNG_PHILOX");
 }
 
 }  // namespace
@@ -279,8 +369,10 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   const int64_t n_walkers = (int64_t)P.num_walks * g.n_vertices;
   if (n_walkers >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "more than 2^31 walkers in one call: lower num_walks");
   const int32_t stride = P.walk_length + 2;
-  const bool first_order = (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
+  const bool alias = P.sampler == SRW_SAMPLER_ALIAS;
+  const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
   if (first_order) build_first_order_tables(h);
+  if (alias) build_alias_tables(h);
   h->res.valid = false;
   h->res.paths.ensure((size_t)n_walkers * stride);
   h->res.lens.ensure((size_t)n_walkers);
@@ -290,7 +382,17 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
   GraphView gv = g.view();
   SRW_HIP(hipEventRecord(h->ev0, st));
-  if (first_order) {
+  if (alias) {
+    int64_t blocks = (n_walkers + TPB - 1) / TPB;
+    const size_t al_bytes = (size_t)g.n_entries * sizeof(AEnt);
+    const bool nt = (P.flags & SRW_WALK_NT_LOADS) ? true : (P.flags & SRW_WALK_CACHED_LOADS) ? false : al_bytes > ((size_t)2 << 30);
+    if (nt)
+      hipLaunchKernelGGL(k_walk_alias<true>, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
+                         P.walk_length, P.first_walk, P.seed, P.p, P.q, h->res.paths.p, h->res.lens.p, h->counters.p);
+    else
+      hipLaunchKernelGGL(k_walk_alias<false>, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
+                         P.walk_length, P.first_walk, P.seed, P.p, P.q, h->res.paths.p, h->res.lens.p, h->counters.p);
+  } else if (first_order) {
     int64_t blocks = (n_walkers + TPB - 1) / TPB;
     // Load policy for the linked records: once the table is far larger than L2 + Infinity Cache (32 + 256 MiB) a
     // record is used once per fetch, and an L1-bypassing load avoids pulling its whole 128-B line (measured on
@@ -319,7 +421,7 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   read_counters(h, s);
   float ms = 0.f;
   SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  s->kernel_ms = ms; s->n_walkers = n_walkers; s->kernel_kind = first_order ? 1 : 2;
+  s->kernel_ms = ms; s->n_walkers = n_walkers; s->kernel_kind = alias ? 3 : first_order ? 1 : 2;
   h->res.valid = true;
 }
 

@@ -566,9 +566,10 @@ static int64_t second_order_pick(const orc_graph *g, const orc_walk_params *P, i
 
 /* Mode A step: trial t draws (x0..x3) = Philox(ctr = (iter, src, step, t), key = (seed, 0xA11A5));
  * slot j = ((x0:x1) * n) >> 64, coin u2 = (x2 >> 8) * 2^-24 picks j or alias[j]; a second-order step accepts
- * the candidate iff u3 * M < bias with u3 = (x3 >> 8) * 2^-24, M = max(1/p, 1, 1/q),
- * bias = 1/p (dst == prev), 1 (dst in N(prev)), 1/q (else).  An irregular row uses the reference's CDF
- * inversion with u2 of trial 0. */
+ * the candidate iff u3 * Q < bias with u3 = (x3 >> 8) * 2^-24, Q = max(1, 1/q),
+ * bias = 1/p (dst == prev), 1 (dst in N(prev)), 1/q (else); when 1/p > Q the excess (1/p - Q) * w of the return
+ * edge(s) is sampled through an appendix branch (second Philox call, key word 0xA11A6).  An irregular row uses the
+ * reference's CDF inversion with u2 of trial 0. */
 static int sorted_contains(const int32_t *a, int64_t n, int32_t x);
 static int64_t second_order_pick(const orc_graph *g, const orc_walk_params *P, int32_t prev, int64_t ps,
                                  int64_t cs, float r, float *scratch);
@@ -586,12 +587,35 @@ static int64_t alias_pick(const orc_graph *g, const orc_walk_params *P, int seco
     return second_order_pick(g, &Q, prev, ps, cs, u, scratch);
   }
   const float inv_p = 1.0f / P->p, inv_q = 1.0f / P->q;
-  float M = inv_p > 1.0f ? inv_p : 1.0f; if (inv_q > M) M = inv_q;
+  const float Q = inv_q > 1.0f ? inv_q : 1.0f;           /* envelope WITHOUT the return edge */
   const int biased = second_order && !(P->p == 1.0f && P->q == 1.0f);
+  const float *cw = g->w + g->off[cs];
+  /* outlier folding (KnightKing): when 1/p > Q the return edge(s) get an "appendix" of area (1/p - Q) * Wprev on top
+   * of the envelope area Q * S; a trial first chooses appendix vs envelope by area. */
+  int fold = 0; double a = 0.0, tot = 0.0, Wprev = 0.0;
+  if (biased && inv_p > Q) {
+    for (int64_t k2 = 0; k2 < n; ++k2) if (cid[k2] == prev) Wprev += (double)cw[k2];
+    if (Wprev > 0.0) {
+      double S = 0.0;
+      for (int64_t k2 = 0; k2 < n; ++k2) S += (double)cw[k2];   /* exact: the row is alias-regular */
+      a = ((double)inv_p - (double)Q) * Wprev; tot = (double)Q * S + a; fold = 1;
+    }
+  }
   int64_t k = 0;
   for (uint32_t t = 0; t < 65536u; ++t) {
     uint32_t ctr[4] = {iter, (uint32_t)src, step, t};
     orc_philox4x32_10(ctr, key, o);
+    if (fold) {
+      uint32_t key2[2] = {P->seed, 0xA11A6u}, y[4];
+      orc_philox4x32_10(ctr, key2, y);
+      float u5 = (float)(y[0] >> 8) * (1.0f / 16777216.0f);
+      if ((double)u5 * tot < a) {                          /* appendix: return to prev, occurrence ~ w, input order */
+        float u6 = (float)(y[1] >> 8) * (1.0f / 16777216.0f);
+        double target = (double)u6 * Wprev, cum = 0.0; int64_t last = 0;
+        for (int64_t k2 = 0; k2 < n; ++k2) if (cid[k2] == prev) { cum += (double)cw[k2]; last = k2; if (cum >= target) return k2; }
+        return last;
+      }
+    }
     uint64_t r64 = ((uint64_t)o[0] << 32) | o[1];
     int64_t j = (int64_t)(((u128)r64 * (u128)(uint64_t)n) >> 64);
     float u2 = (float)(o[2] >> 8) * (1.0f / 16777216.0f);
@@ -601,7 +625,7 @@ static int64_t alias_pick(const orc_graph *g, const orc_walk_params *P, int seco
     if (cid[k] == prev) bias = inv_p;
     else if (sorted_contains(g->sorted_ids + g->off[ps], g->off[ps + 1] - g->off[ps], cid[k])) bias = 1.0f;
     float u3 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
-    if (u3 * M < bias) return k;
+    if (u3 * Q < bias) return k;
   }
   return k;
 }

@@ -79,8 +79,8 @@ __device__ inline unsigned long long weight_to_int(float w, int emin) {
 }
 
 __global__ __launch_bounds__(TPB) void k_alias_build(Row *rows, const Ent *__restrict__ ent, AEnt *__restrict__ al,
-                                                     int64_t n_slots, uint32_t *__restrict__ g_idx,
-                                                     u128 *__restrict__ g_de) {
+                                                     double *__restrict__ rsum, int64_t n_slots,
+                                                     uint32_t *__restrict__ g_idx, u128 *__restrict__ g_de) {
   __shared__ BlockShared sh;
   __shared__ uint32_t l_idx[LDS_ROW_CAP];
   __shared__ u128 l_de[LDS_ROW_CAP];
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(TPB) void k_alias_build(Row *rows, const Ent *__res
     unsigned long long T = 0;
     for (int w = 0; w < TPB / 64; ++w) T += sh.red_u64[w];
     __syncthreads();
+    if (tid == 0) rsum[v] = ldexp((double)T, emin - 23);    // = foldLeft(0.0)(_ + w), exact for a regular row
     // ---- 3. stable split into lights (front) / heavies (back) + their prefix sums ----
     uint32_t carry_a = 0; u128 carry_d = 0, carry_e = 0;
     for (int32_t base = 0; base < n; base += TPB) {
@@ -199,10 +200,12 @@ void build_alias_tables(srw_handle *h) {
   if (g.has_al) return;
   hipStream_t st = h->stream;
   g.al.alloc((size_t)g.n_entries);
+  g.rsum.alloc((size_t)g.n_slots);
+  SRW_HIP(hipMemsetAsync(g.rsum.p, 0, (size_t)g.n_slots * sizeof(double), st));
   DevBuf<uint32_t> g_idx; DevBuf<unsigned __int128> g_de;   // HBM staging for rows beyond the LDS capacity
   g_idx.alloc((size_t)g.n_entries); g_de.alloc((size_t)g.n_entries);
   int blocks = (int)std::min<int64_t>(std::max<int64_t>(g.n_slots, 1), 256 * 64);
-  hipLaunchKernelGGL(k_alias_build, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.al.p, g.n_slots, g_idx.p, g_de.p);
+  hipLaunchKernelGGL(k_alias_build, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.al.p, g.rsum.p, g.n_slots, g_idx.p, g_de.p);
   if (g.n_entries > 0) {
     int ge = (int)std::min<int64_t>((g.n_entries + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(k_alias_link, dim3(ge), dim3(256), 0, st, g.rows.p, g.al.p, g.n_entries, g.vmin, g.n_slots);

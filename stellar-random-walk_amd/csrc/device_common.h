@@ -58,6 +58,7 @@ struct GraphView {
   const uint32_t *sperm;
   const FoEnt *fo;
   const AEnt *al;
+  const double *rsum;   // Mode A: exact weight sum of each alias-regular row
   int32_t vmin;
   int64_t n_slots;
 };

@@ -70,11 +70,12 @@ struct Graph {
   DevBuf<FoEnt> fo;               // [n_entries], built lazily
   bool has_fo = false;
   DevBuf<AEnt> al;                // [n_entries] Mode A alias records, built lazily
+  DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
   bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
-  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_al ? al.p : nullptr, vmin, n_slots}; }
+  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr, vmin, n_slots}; }
 };
 
 struct WalkResult {

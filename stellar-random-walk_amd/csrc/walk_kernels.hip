@@ -170,7 +170,8 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
 // its own (step, trial) state machine so that lanes do not wait for each other's rejections.  Spec shared with
 // oracle/srw_oracle.c:alias_pick — trial t of step s draws Philox(ctr = (iter, src, s, t), key = (seed, 0xA11A5)):
 // slot j = ((x0:x1) * deg) >> 64, coin u2 = (x2 >> 8) 2^-24 keeps j or takes alias[j]; a second-order step accepts
-// iff u3 * M < bias, u3 = (x3 >> 8) 2^-24, M = max(1/p, 1, 1/q), bias = 1/p | 1 | 1/q.
+// iff u3 * Q < bias, u3 = (x3 >> 8) 2^-24, Q = max(1, 1/q), bias = 1/p | 1 | 1/q; when 1/p > Q the excess
+// (1/p - Q) * w of the return edge(s) is sampled by an appendix branch chosen by area (KnightKing's outlier folding).
 template <bool NT>
 __device__ inline AEnt load_al(const AEnt *p) {
   if (NT) {
@@ -205,9 +206,11 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
     int32_t curr = src, prev = src;
     path[0] = src; len = 1;
     const float inv_p = 1.0f / p, inv_q = 1.0f / q;
-    const float M = fmaxf(fmaxf(inv_p, 1.0f), inv_q);
+    const float Q = inv_q > 1.0f ? inv_q : 1.0f;                  // envelope WITHOUT the return edge
     const bool biased_cfg = !(p == 1.0f && q == 1.0f);
     int32_t s = 1; uint32_t t = 0;
+    // outlier folding state of the current step (valid while t > 0)
+    bool fold = false; double fa = 0.0, ftot = 0.0, fw = 0.0; int32_t flo = 0, fhi = 0;
     while (s <= L + 1) {
       if (rc.deg == 0) { if (s > 1) ++dead; break; }
       const bool second = s > 1, biased = second && biased_cfg;
@@ -222,18 +225,54 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
         int32_t k = lane_pick_sequential(g.ent + rc.off, rc.deg, b, u);
         e = g.al[rc.off + k]; ++fb;
       } else {
-        const uint64_t r64 = ((uint64_t)o[0] << 32) | o[1];
-        const int64_t j = (int64_t)__umul64hi(r64, (uint64_t)(uint32_t)rc.deg);
-        e = load_al<NT>(g.al + rc.off + j); ++reads;
-        const float u2 = (float)(o[2] >> 8) * (1.0f / 16777216.0f);
-        if (!(u2 < e.prob)) { e = load_al<NT>(g.al + rc.off + e.alias); ++reads; }
+        if (t == 0) {            // once per step: does the return edge stick out of the envelope?
+          fold = false;
+          if (biased && inv_p > Q) {
+            // occurrences of prev in N(curr): equal range in the sorted row; weights in input order via sperm
+            const uint32_t *cs = g.sids + rc.off;
+            const uint32_t x = (uint32_t)((int64_t)prev - g.vmin);
+            int32_t lo = 0, hi = rc.deg;
+            while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < x) lo = mid + 1; else hi = mid; }
+            flo = lo; fhi = lo; fw = 0.0;
+            while (fhi < rc.deg && cs[fhi] == x) { fw += (double)g.ent[rc.off + g.sperm[rc.off + fhi]].w; ++fhi; }
+            if (fw > 0.0) {
+              const double S = g.rsum[(int64_t)curr - g.vmin];
+              fa = ((double)inv_p - (double)Q) * fw; ftot = (double)Q * S + fa; fold = true;
+            }
+          }
+        }
+        bool appendix = false;
+        if (fold) {
+          uint32_t y[4];
+          philox4x32_10(iter, (uint32_t)src, (uint32_t)s, t, seed, 0xA11A6u, y);
+          const float u5 = (float)(y[0] >> 8) * (1.0f / 16777216.0f);
+          if ((double)u5 * ftot < fa) {       // appendix: return to prev; occurrence ~ w in input order
+            appendix = true;
+            const float u6 = (float)(y[1] >> 8) * (1.0f / 16777216.0f);
+            const double target = (double)u6 * fw;
+            double cum = 0.0; int32_t pos = g.sperm[rc.off + flo];
+            for (int32_t c = flo; c < fhi; ++c) {
+              pos = (int32_t)g.sperm[rc.off + c];
+              cum += (double)g.ent[rc.off + pos].w;
+              if (cum >= target) break;
+            }
+            e = load_al<NT>(g.al + rc.off + pos); ++reads;
+          }
+        }
         ++trials;
-        if (biased) {
-          float bias = inv_q;
-          if (e.id == prev) bias = inv_p;
-          else if (sorted_contains(g.sids + rp.off, rp.deg, (uint32_t)((int64_t)e.id - g.vmin))) bias = 1.0f;
-          const float u3 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
-          accepted = (u3 * M < bias) || (t + 1u >= 65536u);
+        if (!appendix) {
+          const uint64_t r64 = ((uint64_t)o[0] << 32) | o[1];
+          const int64_t j = (int64_t)__umul64hi(r64, (uint64_t)(uint32_t)rc.deg);
+          e = load_al<NT>(g.al + rc.off + j); ++reads;
+          const float u2 = (float)(o[2] >> 8) * (1.0f / 16777216.0f);
+          if (!(u2 < e.prob)) { e = load_al<NT>(g.al + rc.off + e.alias); ++reads; }
+          if (biased) {
+            float bias = inv_q;
+            if (e.id == prev) bias = inv_p;
+            else if (sorted_contains(g.sids + rp.off, rp.deg, (uint32_t)((int64_t)e.id - g.vmin))) bias = 1.0f;
+            const float u3 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
+            accepted = (u3 * Q < bias) || (t + 1u >= 65536u);
+          }
         }
       }
       if (accepted) {

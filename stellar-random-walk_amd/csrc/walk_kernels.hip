@@ -333,6 +333,44 @@ __global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *_
   }
 }
 
+// First-order (p == q == 1) super-step: one record per LANE through the exact CDF + guide records of the local rows.
+__global__ __launch_bounds__(TPB) void k_shard_step_fo(GraphView g, const Walker *__restrict__ in, int64_t n_in,
+                                                       int64_t n_verts_global, int32_t first_walk, int32_t step,
+                                                       RngSpec rng, Walker *__restrict__ out,
+                                                       unsigned long long *cursor, int32_t *__restrict__ paths,
+                                                       int64_t stride, DevCounters *ctr) {
+  const int64_t ri = blockIdx.x * (int64_t)TPB + threadIdx.x;
+  unsigned long long steps = 0, dead = 0, reads = 0, fb = 0;
+  if (ri < n_in) {
+    Walker wk = in[ri];
+    const Row *rp = row_of(g, wk.curr);
+    Row r; r.off = 0; r.deg = 0; r.flags = 0;
+    if (rp) r = *rp;
+    if (r.deg == 0) {
+      if (step > 1) dead = 1;
+    } else {
+      const uint32_t iter = (uint32_t)(first_walk + (int64_t)wk.wid / n_verts_global);
+      float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
+      int32_t next;
+      if (r.flags & ROW_IRREGULAR) {
+        Bias nb; nb.second_order = false; nb.need_member = false; nb.p = nb.q = 1.0f; nb.prev = 0;
+        nb.prev_sids = nullptr; nb.prev_deg = 0; nb.vmin = g.vmin;
+        next = g.ent[r.off + lane_pick_sequential(g.ent + r.off, r.deg, nb, u)].id; fb = 1;
+      } else {
+        unsigned rd; int32_t k;
+        FoEnt e = fo_pick<false>(g.fo + r.off, r.deg, u, k, rd); reads = rd;
+        next = e.id;
+      }
+      paths[(int64_t)wk.wid * stride + step] = next;
+      unsigned long long pos = atomicAdd(cursor, 1ull);
+      Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
+      out[pos] = nw;
+      steps = 1;
+    }
+  }
+  flush_counters(ctr, steps, dead, 0, 0, reads, fb);
+}
+
 // pre-pass of the super-step: where will each record go?  (needs the sampled vertex, so the step kernel runs
 // once into a scratch ordering and k_shard_bucket reorders — see run_shard_step)
 __global__ void k_shard_count(const Walker *__restrict__ recs, int64_t n, int32_t world, unsigned long long *counts) {
@@ -500,11 +538,19 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
     // pass A: sample into a scratch buffer (cursor 0 only => dense, arbitrary order)
     DevBuf<Walker> scratch; scratch.alloc((size_t)n_in);
     RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
-    int64_t blocks = (n_in * 64 + TPB - 1) / TPB;
+    const bool first_order = P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL);
+    if (first_order) build_first_order_tables(h);
     SRW_HIP(hipEventRecord(h->ev0, st));
-    hipLaunchKernelGGL(k_shard_step, dim3((unsigned)blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, g.n_vertices,
-                       P.first_walk, step, rng, P.p, P.q, /*world=*/1, scratch.p, h->shard_counts.p + world, d_paths,
-                       stride, h->counters.p);
+    if (first_order) {
+      int64_t blocks = (n_in + TPB - 1) / TPB;
+      hipLaunchKernelGGL(k_shard_step_fo, dim3((unsigned)blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, g.n_vertices,
+                         P.first_walk, step, rng, scratch.p, h->shard_counts.p + world, d_paths, stride, h->counters.p);
+    } else {
+      int64_t blocks = (n_in * 64 + TPB - 1) / TPB;
+      hipLaunchKernelGGL(k_shard_step, dim3((unsigned)blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, g.n_vertices,
+                         P.first_walk, step, rng, P.p, P.q, /*world=*/1, scratch.p, h->shard_counts.p + world, d_paths,
+                         stride, h->counters.p);
+    }
     SRW_HIP(hipEventRecord(h->ev1, st));
     unsigned long long survivors = 0;
     SRW_HIP(hipMemcpyAsync(&survivors, h->shard_counts.p + world, 8, hipMemcpyDeviceToHost, st));
@@ -527,7 +573,7 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
     s->kernel_ms = ms;
   }
   read_counters(h, s);
-  s->kernel_kind = 2; s->n_walkers = n_in;
+  s->kernel_kind = (P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL)) ? 1 : 2; s->n_walkers = n_in;
   for (int r = 0; r < world; ++r) counts_out[r] = (int64_t)counts[r];
 }
 

@@ -325,6 +325,7 @@ def test_cli_end_to_end(oracle, tmp_path):
 def test_sharded_kernels_inprocess_exchange(oracle, world, p, directed):
     import torch
     from importlib import import_module
+    pkg()
     sharded = import_module("stellar_random_walk_amd.distributed")
     s, d, w = rmat_lines(oracle, 10, edge_factor=8, weighted=True)
     g = oracle.Graph.from_coo(s, d, w, directed=directed)
@@ -371,6 +372,7 @@ def test_sharded_kernels_inprocess_exchange(oracle, world, p, directed):
 def test_sharded_walker_world1_nccl(oracle):
     import torch.distributed as dist
     from importlib import import_module
+    pkg()
     sharded = import_module("stellar_random_walk_amd.distributed")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")

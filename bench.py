@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--p", type=float, default=1.0)
     ap.add_argument("--q", type=float, default=1.0)
     ap.add_argument("--weighted", type=int, default=0)
+    ap.add_argument("--sampler", choices=["reference", "alias"], default="reference")
     ap.add_argument("--shard", choices=["replicate", "vertex"], default="replicate")
     ap.add_argument("--nt-loads", type=int, default=-1, help="-1 auto, 0 cached, 1 nontemporal record loads")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -107,6 +108,8 @@ def main():
     walk_kw = dict(p=args.p, q=args.q, walk_length=args.walk_length, num_walks=1, seed=42)
     if args.nt_loads >= 0:
         walk_kw["nt_loads"] = bool(args.nt_loads)
+    if args.sampler == "alias":
+        walk_kw["sampler"] = "alias"
 
     if args.shard == "vertex" and world > 1:
         from importlib import import_module
@@ -168,6 +171,12 @@ def main():
             per_launch_steps = steps / max(K, 1)
             alg_bytes = per_launch_steps * 4 + stats["ent_reads"] * 32 + stats["n_walkers"] * 24
             kernel_name = "k_walk_first_order"
+        elif stats["kernel_kind"] == 3:
+            # Mode A: 32-B alias records read (counted) + 4 B path store per step; membership probes of
+            # rejected/accepted candidates are not counted (lower bound)
+            per_launch_steps = steps / max(K, 1)
+            alg_bytes = per_launch_steps * 4 + stats["ent_reads"] * 32 + stats["n_walkers"] * 24
+            kernel_name = "k_walk_alias"
         else:
             # general kernel (SURVEY §8d Mode R): 16 + 8*deg(curr) + 4 per step (+ 16 + 4*deg(prev) when q != 1)
             per_launch_steps = steps / max(K, 1)
@@ -188,7 +197,7 @@ def main():
             "steps": K, "warmup": W, "ms_per_step": max_dt / max(K, 1) * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "int32 ids / f64 CDF", "data": "synthetic",
             "config": {"workload": "RMAT scale-%d ef%d (%d edge lines, %d adjacency entries, %d vertices) undirected "
-                                   "%s p=%g q=%g walkLength=%d, 1 walk iteration per step, Mode R (reference-exact)"
+                                   "%s p=%g q=%g walkLength=%d, 1 walk iteration per step, " + ("Mode A (alias + rejection)" if args.sampler == "alias" else "Mode R (reference-exact)")
                                    % (args.scale, args.edge_factor, n_edges, ne, nv,
                                       "weighted" if args.weighted else "unweighted", args.p, args.q, args.walk_length),
                        "walk_steps_per_bench_step": int(steps / max(K, 1)), "parallelism": parallelism,

@@ -74,7 +74,8 @@ std::string CommandParser::usage() {
     << "  --seed <value>           Philox seed of the walk RNG: 42\n"
     << "  --constR <value>         inject a constant nextFloat (test hook of the reference)\n"
     << "  --device <value>         HIP device ordinal: 0\n"
-    << "  --crc <value>            also write Hadoop .crc side files: false\n";
+    << "  --crc <value>            also write Hadoop .crc side files: false\n"
+    << "  --sampler <value>        reference (bit-identical CDF inversion) | alias (alias tables + rejection): reference\n";
   return o.str();
 }
 
@@ -92,7 +93,7 @@ std::optional<Params> CommandParser::parse(const std::vector<std::string> &args,
     if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); inline_val = true; }
     static const char *known[] = {WALK_LENGTH, NUM_WALKS, P, Q, RDD_PARTITIONS, WEIGHTED, DIRECTED, SINGLE_OUTPUT,
                                   W2V_PARTITIONS, INPUT, OUTPUT, CMD, PARTITIONED, LEARNING_RATE, ITERATION, DIMENSION,
-                                  WINDOW, "seed", "constR", "device", "crc"};
+                                  WINDOW, "seed", "constR", "device", "crc", "sampler"};
     if (std::find_if(std::begin(known), std::end(known), [&](const char *k) { return name == k; }) == std::end(known)) {
       fail("Unknown option " + a);
       continue;
@@ -131,6 +132,10 @@ std::optional<Params> CommandParser::parse(const std::vector<std::string> &args,
     else if (name == "constR") { double d; if (readDouble(val, d)) { c.constR = (float)d; c.hasConstR = true; } else fail("Option --constR failed when given '" + val + "'"); }
     else if (name == "device") asInt(c.device);
     else if (name == "crc") asBool(c.crc);
+    else if (name == "sampler") {
+      if (val == "alias") c.alias = true; else if (val == "reference") c.alias = false;
+      else fail("Option --sampler failed when given '" + val + "' (reference | alias)");
+    }
   }
   if (!c.hasInput) fail("Missing option --input");    // .required(), CommandParser.scala:64-67
   if (!c.hasOutput) fail("Missing option --output");  // :68-71

@@ -43,6 +43,7 @@ struct Params {
   float constR = 0.0f;
   int device = 0;           // --device: HIP ordinal
   bool crc = false;         // --crc: also write Hadoop .crc side files
+  bool alias = false;       // --sampler alias: Mode A (alias tables + rejection) instead of the reference-exact Mode R
 };
 
 }  // namespace common

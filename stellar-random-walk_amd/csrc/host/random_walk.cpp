@@ -1,11 +1,23 @@
 // random_walk.cpp — see random_walk.h.
 #include "random_walk.h"
 
+#include <chrono>
+#include <cstdlib>
 #include <iostream>
 
 namespace randomwalk {
 namespace algorithm {
 namespace {
+// SRW_TIMING=1: phase wall times on stderr (stdout stays the reference's lines)
+struct Phase {
+  const char *name; std::chrono::steady_clock::time_point t0;
+  explicit Phase(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+  ~Phase() {
+    if (!getenv("SRW_TIMING")) return;
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::cerr << "[timing] " << name << ": " << ms << " ms\n";
+  }
+};
 void check(srw_handle *h, int32_t rc, const char *what) {
   if (rc != SRW_OK) throw std::runtime_error(std::string(what) + ": " + srw_last_error(h));
 }
@@ -81,17 +93,20 @@ void RandomWalk::printGraphStats() {
 }
 
 void UniformRandomWalk::loadGraph() {
+  Phase ph("loadGraph (parse + upload + device CSR build)");
   check(h_, srw_load_edgelist(h_, config_.input.c_str(), config_.directed, config_.weighted, /*partitioned=*/0,
                               config_.rddPartitions), "loadGraph");
   printGraphStats();
 }
 void VCutRandomWalk::loadGraph() {
+  Phase ph("loadGraph (parse + upload + device CSR build)");
   check(h_, srw_load_edgelist(h_, config_.input.c_str(), config_.directed, config_.weighted, config_.partitioned ? 1 : 0,
                               config_.rddPartitions), "loadGraph");
   printGraphStats();
 }
 
 Paths RandomWalk::walkImpl(bool useConst, float constR) {
+  Phase ph("randomWalk (kernels + path fetch)");
   Paths out;
   out.stride = config_.walkLength + 2;
   out.n = (int64_t)config_.numWalks * nVertices;
@@ -102,7 +117,7 @@ Paths RandomWalk::walkImpl(bool useConst, float constR) {
     P.p = (float)config_.p; P.q = (float)config_.q;             // .toFloat, :112
     P.walk_length = config_.walkLength; P.num_walks = 1; P.first_walk = it;
     P.rng_mode = useConst ? SRW_RNG_CONST : SRW_RNG_PHILOX; P.const_r = constR; P.seed = (uint32_t)config_.seed;
-    P.sampler = SRW_SAMPLER_REFERENCE;
+    P.sampler = (config_.alias && !useConst) ? SRW_SAMPLER_ALIAS : SRW_SAMPLER_REFERENCE;
     srw_walk_stats st{};
     check(h_, srw_walk(h_, &P, &st), "randomWalk");
     check(h_, srw_fetch_paths(h_, out.ids.data() + (size_t)it * nVertices * out.stride,
@@ -118,6 +133,7 @@ Paths RandomWalk::randomWalk() { return walkImpl(config_.hasConstR, config_.cons
 Paths RandomWalk::randomWalk(float constR) { return walkImpl(true, constR); }
 
 void RandomWalk::save(const Paths &paths, int partitions, const std::string &output) const {
+  Phase ph("save (format + write)");
   int32_t rc = srw_save_paths(paths.ids.data(), paths.lens.data(), paths.n, paths.stride, output.c_str(), partitions,
                               config_.crc ? 1 : 0);
   if (rc == SRW_ERR_EXISTS)

@@ -5,11 +5,14 @@
 // The job fails if <output>/path already exists.  The reference's line order is unspecified (repartition
 // after union); this writer emits the canonical order (walk iteration major, source id ascending) in
 // contiguous slices per part.  Formatting is done by one std::thread per slice of walkers.
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <thread>
 
 #include "engine.h"
@@ -59,11 +62,16 @@ void write_crc_file(const std::string &dir, const std::string &name, const std::
   fclose(f);
 }
 
-void format_range(const int32_t *paths, const int32_t *lens, int64_t stride, int64_t b, int64_t e, std::string &out) {
-  size_t cap = 0;
+struct Piece {
+  std::unique_ptr<char[]> buf;  // uninitialised storage: no zero-fill pass over gigabytes
+  size_t len = 0;
+};
+
+void format_range(const int32_t *paths, const int32_t *lens, int64_t stride, int64_t b, int64_t e, Piece &out) {
+  size_t cap = 1;
   for (int64_t w = b; w < e; ++w) cap += (size_t)lens[w] * 12 + 1;
-  out.resize(cap);
-  char *p = &out[0];
+  out.buf.reset(new char[cap]);
+  char *p = out.buf.get();
   for (int64_t w = b; w < e; ++w) {
     const int32_t *row = paths + w * stride;
     for (int32_t t = 0; t < lens[w]; ++t) {
@@ -72,7 +80,15 @@ void format_range(const int32_t *paths, const int32_t *lens, int64_t stride, int
     }
     *p++ = '\n';
   }
-  out.resize((size_t)(p - out.data()));
+  out.len = (size_t)(p - out.buf.get());
+}
+
+void pwrite_all(int fd, const char *p, size_t n, off_t off, const std::string &fn) {
+  while (n) {
+    ssize_t k = pwrite(fd, p, n, off);
+    if (k <= 0) throw Error(SRW_ERR_IO, "short write " + fn);
+    p += k; n -= (size_t)k; off += k;
+  }
 }
 
 }  // namespace
@@ -94,25 +110,41 @@ void write_path_files(const int32_t *paths, const int32_t *lens, int64_t n_walke
     int64_t b = std::min<int64_t>((int64_t)part * per, n_walkers), e = std::min<int64_t>(b + per, n_walkers);
     int64_t n = e - b;
     int nt = (int)std::max<int64_t>(1, std::min<int64_t>(hw, n / 4096 + 1));
-    std::vector<std::string> pieces((size_t)nt);
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t) {
-      int64_t tb = b + n * t / nt, te = b + n * (t + 1) / nt;
-      th.emplace_back([&, t, tb, te] { format_range(paths, lens, stride, tb, te, pieces[(size_t)t]); });
+    std::vector<Piece> pieces((size_t)nt);
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; ++t) {
+        int64_t tb = b + n * t / nt, te = b + n * (t + 1) / nt;
+        th.emplace_back([&, t, tb, te] { format_range(paths, lens, stride, tb, te, pieces[(size_t)t]); });
+      }
+      for (auto &x : th) x.join();
     }
-    for (auto &x : th) x.join();
     char name[32];
     snprintf(name, sizeof(name), "part-%05d", part);
     std::string fn = dir + "/" + name;
-    FILE *f = fopen(fn.c_str(), "wb");
-    if (!f) throw Error(SRW_ERR_IO, "cannot write " + fn);
-    std::string all;
-    for (auto &s : pieces) {
-      if (fwrite(s.data(), 1, s.size(), f) != s.size()) { fclose(f); throw Error(SRW_ERR_IO, "short write " + fn); }
-      if (write_crc) all += s;
+    int fd = open(fn.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) throw Error(SRW_ERR_IO, "cannot write " + fn);
+    // every piece knows its byte offset once all are formatted: the threads write their pieces concurrently
+    std::vector<off_t> offs((size_t)nt + 1, 0);
+    for (int t = 0; t < nt; ++t) offs[(size_t)t + 1] = offs[(size_t)t] + (off_t)pieces[(size_t)t].len;
+    std::vector<std::string> errs((size_t)nt);
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+          try { pwrite_all(fd, pieces[(size_t)t].buf.get(), pieces[(size_t)t].len, offs[(size_t)t], fn); }
+          catch (const Error &e) { errs[(size_t)t] = e.what(); }
+        });
+      for (auto &x : th) x.join();
     }
-    fclose(f);
-    if (write_crc) write_crc_file(dir, name, all);
+    close(fd);
+    for (auto &e : errs) if (!e.empty()) throw Error(SRW_ERR_IO, e);
+    if (write_crc) {
+      std::string all;
+      all.reserve((size_t)offs[(size_t)nt]);
+      for (auto &pc : pieces) all.append(pc.buf.get(), pc.len);
+      write_crc_file(dir, name, all);
+    }
   }
   std::string ok = dir + "/_SUCCESS";
   FILE *f = fopen(ok.c_str(), "wb");

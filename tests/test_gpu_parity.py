@@ -407,3 +407,35 @@ def test_giant_hub_multi_segment_membership(eng, oracle):
         verts = eng.vertices()
         idx = np.searchsorted(verts, src)
         assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl)
+
+
+@pytest.mark.parametrize("pattern", ["uniform", "dyadic", "integer", "mixed"])
+def test_certified_scan_on_lattice_ties(eng, oracle, pattern):
+    # one source vertex per degree 1..400 (+ a few large ones); a single first step through the GENERAL kernel
+    # (certified parallel scan) with draws that sit exactly on CDF boundaries; must equal the sequential oracle
+    rng = np.random.default_rng(7)
+    degs = list(range(1, 401)) + [512, 1000, 1024, 4096, 5000]
+    src, dst, w = [], [], []
+    base = 100000
+    for i, dg in enumerate(degs):
+        if pattern == "uniform":
+            ww = np.ones(dg)
+        elif pattern == "dyadic":
+            ww = rng.choice([0.25, 0.5, 1.0, 2.0, 4.0], dg)
+        elif pattern == "integer":
+            ww = rng.integers(1, 17, dg).astype(float)
+        else:
+            ww = rng.random(dg) * 10.0 ** rng.integers(-2, 3, dg)
+        src += [i + 1] * dg
+        dst += list(range(base, base + dg))
+        w += ww.tolist()
+    s, d, w = np.array(src, np.int32), np.array(dst, np.int32), np.array(w, np.float32)
+    g = oracle.Graph.from_coo(s, d, w, directed=True)
+    eng.load_coo(s, d, w, directed=True)
+    for r in (0.5, 0.25, 0.75, 0.125, 0.0, 0.99999994, 0.3333333432674408):
+        a = eng.walk(walk_length=0, rng="const", const_r=r, force_general=True)
+        b = g.walk(walk_length=0, rng="const", const_r=r)
+        assert a[2]["kernel_kind"] == 2
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (pattern, r)
+        c = eng.walk(walk_length=0, rng="const", const_r=r)           # first-order guide-table kernel, same draws
+        assert np.array_equal(c[0], b[0])

@@ -80,12 +80,21 @@ __device__ inline unsigned long long weight_to_int(float w, int emin) {
 
 __global__ __launch_bounds__(TPB) void k_alias_build(Row *rows, const Ent *__restrict__ ent, AEnt *__restrict__ al,
                                                      double *__restrict__ rsum, int64_t n_slots,
-                                                     uint32_t *__restrict__ g_idx, u128 *__restrict__ g_de) {
+                                                     uint32_t *__restrict__ g_idx, u128 *__restrict__ g_de,
+                                                     unsigned long long *next_slot) {
   __shared__ BlockShared sh;
   __shared__ uint32_t l_idx[LDS_ROW_CAP];
   __shared__ u128 l_de[LDS_ROW_CAP];
+  __shared__ unsigned long long s_grab;
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-  for (int64_t v = blockIdx.x; v < n_slots; v += gridDim.x) {
+  // dynamic row hand-out (see sampler_tables.hip:k_fo_large: a fixed stride piles the RMAT hubs onto a few blocks)
+  while (true) {
+    __syncthreads();
+    if (tid == 0) s_grab = atomicAdd(next_slot, 8ull);
+    __syncthreads();
+    const int64_t grab = (int64_t)s_grab;
+    if (grab >= n_slots) break;
+   for (int64_t v = grab; v < grab + 8 && v < n_slots; ++v) {
     const Row r = rows[v];
     const int32_t n = r.deg;
     if (n <= 0) continue;
@@ -180,6 +189,7 @@ __global__ __launch_bounds__(TPB) void k_alias_build(Row *rows, const Ent *__res
       out[k] = o;
     }
     __syncthreads();
+   }
   }
 }
 
@@ -204,8 +214,10 @@ void build_alias_tables(srw_handle *h) {
   SRW_HIP(hipMemsetAsync(g.rsum.p, 0, (size_t)g.n_slots * sizeof(double), st));
   DevBuf<uint32_t> g_idx; DevBuf<unsigned __int128> g_de;   // HBM staging for rows beyond the LDS capacity
   g_idx.alloc((size_t)g.n_entries); g_de.alloc((size_t)g.n_entries);
-  int blocks = (int)std::min<int64_t>(std::max<int64_t>(g.n_slots, 1), 256 * 64);
-  hipLaunchKernelGGL(k_alias_build, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.al.p, g.rsum.p, g.n_slots, g_idx.p, g_de.p);
+  DevBuf<unsigned long long> next_slot; next_slot.alloc(1);
+  SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
+  hipLaunchKernelGGL(k_alias_build, dim3(256 * 4), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.al.p, g.rsum.p, g.n_slots, g_idx.p,
+                     g_de.p, next_slot.p);
   if (g.n_entries > 0) {
     int ge = (int)std::min<int64_t>((g.n_entries + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(k_alias_link, dim3(ge), dim3(256), 0, st, g.rows.p, g.al.p, g.n_entries, g.vmin, g.n_slots);

@@ -49,11 +49,19 @@ __global__ void k_fo_small(Row *rows, const Ent *__restrict__ ent, FoEnt *__rest
 }
 
 // deg > SMALL_DEG: one wave per row.
-__global__ void k_fo_large(Row *rows, const Ent *__restrict__ ent, FoEnt *__restrict__ fo, int64_t n_slots) {
+// Rows are handed out through a global counter (4 slots per grab, ascending id): a fixed wave stride would give
+// wave w every id == w (mod #waves), and in RMAT the ids with few set low bits are ALL hubs (one wave then owns
+// ~5 % of the graph).  Ascending order also starts the longest rows (low ids) first.
+__global__ void k_fo_large(Row *rows, const Ent *__restrict__ ent, FoEnt *__restrict__ fo, int64_t n_slots,
+                           unsigned long long *next_slot) {
   const int lane = lane_id();
-  int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t v = wave; v < n_slots; v += n_waves) {
+  while (true) {
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(next_slot, 4ull);
+    grab = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab);
+    if ((int64_t)grab >= n_slots) break;
+   for (int64_t v = (int64_t)grab; v < (int64_t)grab + 4 && v < n_slots; ++v) {
     Row r = rows[v];
     if (r.deg <= SMALL_DEG) continue;
     const Ent *row = ent + r.off;
@@ -61,14 +69,17 @@ __global__ void k_fo_large(Row *rows, const Ent *__restrict__ ent, FoEnt *__rest
     double part = 0.0;
     SumCert cert;
     bool irr = false;
-    for (int32_t base = 0; base < r.deg; base += 64) {
-      int32_t k = base + lane;
-      if (k < r.deg) {
-        float w = row[k].w;
-        part += (double)w;
-        cert.add(w);
-        irr |= !weight_regular(w);
+    for (int32_t base = 0; base < r.deg; base += 256) {     // 4 independent loads in flight per lane
+      float wv[4]; bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int32_t k = base + u * 64 + lane;
+        ok[u] = k < r.deg;
+        wv[u] = row[ok[u] ? k : r.deg - 1].w;
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) { part += (double)wv[u]; cert.add(wv[u]); irr |= !weight_regular(wv[u]); }
     }
     int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
     bool bad = __any(cert.bad);
@@ -87,20 +98,44 @@ __global__ void k_fo_large(Row *rows, const Ent *__restrict__ ent, FoEnt *__rest
     }
     irr |= !(S > 0.0) || isinf(S);
     double acc = 0.0;
-    for (int32_t base = 0; base < r.deg; base += 64) {
-      int32_t k = base + lane;
-      Ent e; e.id = 0; e.w = 0.0f;
-      if (k < r.deg) e = row[k];
-      double d = (k < r.deg) ? (double)e.w / S : 0.0;
-      int cnt = min(64, r.deg - base);
-      double mine = 0.0;
-      for (int i = 0; i < cnt; ++i) {
-        acc = acc + readlane_f64(d, i);
-        if (lane == i) mine = acc;
+    // A hub row is walked by ONE wave (the chain is sequential by definition), so its loads are software-pipelined:
+    // the 4 chunks of group g+1 are requested before the 4 chunks of group g are chained.
+    Ent z; z.id = 0; z.w = 0.0f;
+    Ent cur[4], nxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { int32_t k = u * 64 + lane; cur[u] = k < r.deg ? row[k] : z; }
+    for (int32_t base = 0; base < r.deg; base += 256) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { int64_t k = (int64_t)base + 256 + u * 64 + lane; nxt[u] = k < r.deg ? row[k] : z; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int32_t cb = base + u * 64;
+        if (cb < r.deg) {
+          const int32_t k = cb + lane;
+          const Ent e = cur[u];
+          const double d = (k < r.deg) ? (double)e.w / S : 0.0;
+          const int cnt = min(64, r.deg - cb);
+          double mine = 0.0;
+          if (cnt == 64) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {       // fully unrolled: readlanes hoist ahead of the dependent adds
+              acc = acc + readlane_f64(d, i);
+              if (lane == i) mine = acc;
+            }
+          } else {
+            for (int i = 0; i < cnt; ++i) {
+              acc = acc + readlane_f64(d, i);
+              if (lane == i) mine = acc;
+            }
+          }
+          if (k < r.deg) { FoEnt f; f.cdf = mine; f.id = e.id; f.guide = 0; f.noff = 0; f.ndeg = 0; f.nflags = 0; out[k] = f; }
+        }
       }
-      if (k < r.deg) { FoEnt f; f.cdf = mine; f.id = e.id; f.guide = 0; f.noff = 0; f.ndeg = 0; f.nflags = 0; out[k] = f; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     }
     if (irr && lane == 0) rows[v].flags = r.flags | ROW_IRREGULAR;
+   }
   }
 }
 
@@ -123,22 +158,62 @@ __global__ void k_guide_small(const Row *__restrict__ rows, FoEnt *__restrict__ 
   }
 }
 
-__global__ void k_guide_large(const Row *__restrict__ rows, FoEnt *__restrict__ fo, int64_t n_slots) {
-  const int lane = lane_id();
-  int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t v = wave; v < n_slots; v += n_waves) {
+// Guide entries of rows with deg > SMALL_DEG.  Rows are cut into work items of GUIDE_ITEM consecutive buckets so
+// that a hub is spread over many waves; inside an item the answers are non-decreasing in j, so after the first
+// chunk (plain binary search) every lane gallops from the previous chunk's last answer: ~log2(64) probes inside a
+// couple of cache lines instead of log2(deg) probes across the whole row.
+constexpr int GUIDE_ITEM = 8192;
+struct GuideItem { uint32_t slot_lo, slot_hi_part; };   // {slot (low 32), slot (high 8) << 24 | part}
+
+__global__ void k_guide_make_items(const Row *__restrict__ rows, int64_t n_slots, unsigned long long *counter,
+                                   uint2 *__restrict__ items, unsigned long long cap) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
     Row r = rows[v];
     if (r.deg <= SMALL_DEG || (r.flags & ROW_IRREGULAR)) continue;
+    unsigned n = (unsigned)((r.deg + GUIDE_ITEM - 1) / GUIDE_ITEM);
+    unsigned long long b = atomicAdd(counter, (unsigned long long)n);
+    for (unsigned i = 0; i < n && b + i < cap; ++i) items[b + i] = make_uint2((uint32_t)v, ((uint32_t)(v >> 32) << 24) | i);
+  }
+}
+
+__device__ inline int32_t lower_bound_cdf(const FoEnt *row, int32_t lo, int32_t hi, double t) {
+  while (lo < hi) {
+    int32_t mid = lo + ((hi - lo) >> 1);
+    if (row[mid].cdf >= t) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__global__ void k_guide_large(const Row *__restrict__ rows, FoEnt *__restrict__ fo, const uint2 *__restrict__ items,
+                              const unsigned long long *n_items_p) {
+  const int lane = lane_id();
+  const unsigned long long n_items = *n_items_p;
+  unsigned long long wave = (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) >> 6;
+  const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+  for (unsigned long long it = wave; it < n_items; it += n_waves) {
+    uint2 item = items[it];
+    const int64_t v = (int64_t)item.x | ((int64_t)(item.y >> 24) << 32);
+    const int32_t part = (int32_t)(item.y & 0xFFFFFFu);
+    Row r = rows[v];
     FoEnt *row = fo + r.off;
-    for (int32_t j = lane; j < r.deg; j += 64) {
-      double t = bucket_threshold((uint32_t)j, (uint32_t)r.deg);
-      int32_t lo = 0, hi = r.deg;
-      while (lo < hi) {
-        int32_t mid = lo + ((hi - lo) >> 1);
-        if (row[mid].cdf >= t) hi = mid; else lo = mid + 1;
+    const int32_t jb = part * GUIDE_ITEM, je = min(r.deg, jb + GUIDE_ITEM);
+    int32_t start = -1;                                   // answer of the previous chunk's last lane
+    for (int32_t j0 = jb; j0 < je; j0 += 64) {
+      const int32_t j = j0 + lane;
+      int32_t ans = r.deg;
+      if (j < je) {
+        const double t = bucket_threshold((uint32_t)j, (uint32_t)r.deg);
+        if (start < 0) {
+          ans = lower_bound_cdf(row, 0, r.deg, t);
+        } else {                                           // gallop: answer >= start (monotone in j)
+          int32_t lo = start, step = 1;
+          while (lo + step < r.deg && !(row[lo + step - 1].cdf >= t)) { lo += step; step <<= 1; }
+          ans = lower_bound_cdf(row, lo, min(r.deg, lo + step), t);
+        }
+        row[j].guide = ans;
       }
-      row[j].guide = lo;
+      const int last = min(63, je - j0 - 1);
+      start = __builtin_amdgcn_readlane(ans, last);
     }
   }
 }
@@ -163,12 +238,20 @@ void build_first_order_tables(srw_handle *h) {
   g.fo.alloc((size_t)g.n_entries);
   int64_t tb = (g.n_slots + 255) / 256;
   int gs = (int)std::min<int64_t>(std::max<int64_t>(tb, 1), 256 * 32);
-  int64_t wb = (g.n_slots + 3) / 4;  // 4 waves per block
-  int gl = (int)std::min<int64_t>(std::max<int64_t>(wb, 1), 256 * 64);
   hipLaunchKernelGGL(k_fo_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.ent.p, g.fo.p, g.n_slots);
-  hipLaunchKernelGGL(k_fo_large, dim3(gl), dim3(256), 0, st, g.rows.p, g.ent.p, g.fo.p, g.n_slots);
+  DevBuf<unsigned long long> next_slot; next_slot.alloc(1);
+  SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
+  hipLaunchKernelGGL(k_fo_large, dim3(256 * 8), dim3(256), 0, st, g.rows.p, g.ent.p, g.fo.p, g.n_slots, next_slot.p);
   hipLaunchKernelGGL(k_guide_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_slots);
-  hipLaunchKernelGGL(k_guide_large, dim3(gl), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_slots);
+  {
+    const unsigned long long cap = (unsigned long long)g.n_entries / SMALL_DEG + 1024;
+    DevBuf<uint2> items; DevBuf<unsigned long long> n_items;
+    items.alloc((size_t)cap); n_items.alloc(1);
+    SRW_HIP(hipMemsetAsync(n_items.p, 0, 8, st));
+    hipLaunchKernelGGL(k_guide_make_items, dim3(gs), dim3(256), 0, st, g.rows.p, g.n_slots, n_items.p, items.p, cap);
+    hipLaunchKernelGGL(k_guide_large, dim3(256 * 16), dim3(256), 0, st, g.rows.p, g.fo.p, items.p, n_items.p);
+    SRW_HIP(hipStreamSynchronize(st));
+  }
   if (g.n_entries > 0) {
     int ge = (int)std::min<int64_t>((g.n_entries + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(k_fo_link, dim3(ge), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_entries, g.vmin, g.n_slots);

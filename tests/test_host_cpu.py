@@ -201,3 +201,20 @@ def test_cli_rejects_bad_values():
     r = _cli("--cmd", "embedding", "--input", KARATE, "--output", "/tmp/unused_srw_out")
     assert r.returncode == 2 and "Word2Vec" in r.stderr
     assert _cli("--help").returncode == 0
+
+
+def test_product_never_references_the_oracle():
+    # the oracle is test infrastructure: nothing under the product package, include/ or the CLI may import, link or
+    # exec anything from oracle/ (bench.py uses it only in its cpu_baseline leg, __graft_entry__ only in smoke/build)
+    import glob
+    prod = os.path.join(ROOT, "stellar-random-walk_amd")
+    files = glob.glob(os.path.join(prod, "**", "*"), recursive=True) + glob.glob(os.path.join(ROOT, "include", "*"))
+    for f in files:
+        if os.path.isfile(f) and f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+            text = open(f, errors="ignore").read()
+            for needle in ("oracle_py", "srw_oracle", "libsrw_oracle", "import oracle", "oracle/"):
+                hits = [ln for ln in text.splitlines() if needle in ln and not ln.lstrip().startswith(("//", "#", "*", "\"\"\""))
+                        and "oracle/srw_oracle.c" not in ln and "tests plug" not in ln]
+                assert not hits, (f, needle, hits[:2])
+    out = subprocess.run(["ldd", pkg().LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out

@@ -59,6 +59,8 @@ struct GraphView {
   const FoEnt *fo;
   const AEnt *al;
   const double *rsum;   // Mode A: exact weight sum of each alias-regular row
+  const Row *mrows;     // membership structure: rows/sids of the WHOLE graph (== rows/sids when world == 1;
+  const uint32_t *msids;  //   replicated on every shard so that N(prev) is available wherever curr lives)
   int32_t vmin;
   int64_t n_slots;
 };

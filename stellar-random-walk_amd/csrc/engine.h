@@ -66,6 +66,8 @@ struct Graph {
   DevBuf<Row> rows;               // [n_slots]
   DevBuf<Ent> ent;                // [n_entries]
   DevBuf<uint32_t> sids;          // [n_entries] (id - vmin), sorted inside each row
+  DevBuf<Row> mrows;              // sharded mode only: row table of the whole graph for the membership test
+  DevBuf<uint32_t> msids;         // sharded mode only: sorted ids of the whole graph
   DevBuf<uint32_t> sperm;         // [n_entries] input-order position (inside the row) of each sorted entry
   DevBuf<FoEnt> fo;               // [n_entries], built lazily
   bool has_fo = false;
@@ -75,7 +77,8 @@ struct Graph {
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
-  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr, vmin, n_slots}; }
+  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
+                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, vmin, n_slots}; }
 };
 
 struct WalkResult {

@@ -34,7 +34,7 @@ __device__ inline uint64_t pack_ent(int32_t id, float w) {
 __global__ void k_expand(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
                          const float *__restrict__ w, int64_t n_lines, int directed, int32_t vmin, int32_t rank,
                          int32_t world, uint32_t *__restrict__ keys, uint64_t *__restrict__ vals,
-                         uint32_t *__restrict__ present, unsigned long long *owned) {
+                         uint32_t *__restrict__ present, unsigned long long *owned, uint32_t *__restrict__ gkeys) {
   unsigned long long cnt = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_lines; i += (int64_t)gridDim.x * blockDim.x) {
     int32_t s = src[i], d = dst[i];
@@ -46,6 +46,7 @@ __global__ void k_expand(const int32_t *__restrict__ src, const int32_t *__restr
     if (directed) {
       keys[i] = os ? ks : KEY_SENTINEL;
       vals[i] = pack_ent(d, ww);
+      if (gkeys) gkeys[i] = ks;
       cnt += os;
     } else {
       bool od = world == 1 || owner_of(d, world) == rank;
@@ -53,6 +54,7 @@ __global__ void k_expand(const int32_t *__restrict__ src, const int32_t *__restr
       vals[2 * i] = pack_ent(d, ww);
       keys[2 * i + 1] = od ? kd : KEY_SENTINEL;
       vals[2 * i + 1] = pack_ent(s, ww);
+      if (gkeys) { gkeys[2 * i] = ks; gkeys[2 * i + 1] = kd; }
       cnt += (unsigned)os + (unsigned)od;
     }
   }
@@ -131,6 +133,25 @@ __global__ void k_rmat(int32_t scale, uint32_t seed, int64_t n_edges, int weight
       w[i] = (float)(1u + (hsh & 15u));
     }
   }
+}
+
+__global__ void k_gmember_keys(const uint32_t *__restrict__ gkeys, const uint64_t *__restrict__ vals, int64_t n, int32_t vmin,
+                               uint64_t *__restrict__ out) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = ((uint64_t)gkeys[e] << 32) | (uint32_t)((int64_t)(int32_t)(uint32_t)vals[e] - vmin);
+}
+__global__ void k_mrows_init(Row *rows, int64_t n_slots) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
+    Row r; r.off = 0; r.deg = 0; r.flags = 0; rows[v] = r;
+  }
+}
+__global__ void k_mrows_start(const uint64_t *__restrict__ k64, int64_t n, Row *rows) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    if (e == 0 || (k64[e] >> 32) != (k64[e - 1] >> 32)) rows[k64[e] >> 32].off = e;
+}
+__global__ void k_mrows_deg(const uint64_t *__restrict__ k64, int64_t n, Row *rows) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    if (e == n - 1 || (k64[e + 1] >> 32) != (k64[e] >> 32)) rows[k64[e] >> 32].deg = (int32_t)(e + 1 - rows[k64[e] >> 32].off);
 }
 
 int bits_for(uint64_t max_value) {
@@ -257,17 +278,40 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
   g.n_entries_global = n_total;
   bool sharded = h->cfg.world > 1;
 
-  DevBuf<uint32_t> keys, present; DevBuf<uint64_t> vals;
+  DevBuf<uint32_t> keys, present, gkeys; DevBuf<uint64_t> vals;
   keys.alloc((size_t)n_total); vals.alloc((size_t)n_total); present.alloc((size_t)n_slots);
+  if (sharded) gkeys.alloc((size_t)n_total);
   SRW_HIP(hipMemsetAsync(present.p, 0, (size_t)n_slots * 4, st));
   h->counters.ensure(1);
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   hipLaunchKernelGGL(k_expand, dim3(grid_for(n_lines)), dim3(TPB), 0, st, d_src, d_dst, d_w, n_lines, directed ? 1 : 0,
-                     vmin, h->cfg.rank, h->cfg.world, keys.p, vals.p, present.p, &h->counters.p->owned_entries);
+                     vmin, h->cfg.rank, h->cfg.world, keys.p, vals.p, present.p, &h->counters.p->owned_entries,
+                     sharded ? gkeys.p : (uint32_t *)nullptr);
   unsigned long long owned = 0;
   SRW_HIP(hipMemcpyAsync(&owned, &h->counters.p->owned_entries, 8, hipMemcpyDeviceToHost, st));
   SRW_HIP(hipStreamSynchronize(st));
+  DevBuf<Row> mrows; DevBuf<uint32_t> msids;
+  if (sharded) {
+    // replicated membership structure of the WHOLE graph (N(prev) must be testable on the shard that owns curr):
+    // sort every entry by (row, id - vmin); keep the row boundaries and the sorted ids (4 B/entry)
+    DevBuf<uint64_t> mk, mk2; DevBuf<char> temp;
+    mk.alloc((size_t)n_total); mk2.alloc((size_t)n_total);
+    hipLaunchKernelGGL(k_gmember_keys, dim3(grid_for(n_total)), dim3(TPB), 0, st, gkeys.p, vals.p, n_total, vmin, mk.p);
+    int id_bits = bits_for((uint64_t)std::max<int64_t>(n_slots - 1, 1));
+    size_t tb = 0;
+    SRW_HIP(rocprim::radix_sort_keys(nullptr, tb, mk.p, mk2.p, (size_t)n_total, 0u, (unsigned)(32 + id_bits), st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::radix_sort_keys((void *)temp.p, tb, mk.p, mk2.p, (size_t)n_total, 0u, (unsigned)(32 + id_bits), st));
+    mrows.alloc((size_t)n_slots); msids.alloc((size_t)n_total);
+    hipLaunchKernelGGL(k_mrows_init, dim3(grid_for(n_slots)), dim3(TPB), 0, st, mrows.p, n_slots);
+    hipLaunchKernelGGL(k_mrows_start, dim3(grid_for(n_total)), dim3(TPB), 0, st, mk2.p, n_total, mrows.p);
+    hipLaunchKernelGGL(k_mrows_deg, dim3(grid_for(n_total)), dim3(TPB), 0, st, mk2.p, n_total, mrows.p);
+    hipLaunchKernelGGL(k_low32, dim3(grid_for(n_total)), dim3(TPB), 0, st, mk2.p, n_total, msids.p);
+    SRW_HIP(hipStreamSynchronize(st));
+    gkeys.release();
+  }
   finish_build(h, keys, vals, n_total, (int64_t)owned, present, vmin, vmax, sharded);
+  if (sharded) { g.mrows = std::move(mrows); g.msids = std::move(msids); }
 }
 
 void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_t *offs, int64_t n_rows,

@@ -114,9 +114,9 @@ __device__ inline Bias make_bias(const GraphView &g, float p, float q, int32_t p
   b.p = p; b.q = q; b.prev = prev; b.second_order = second_order;
   b.need_member = second_order && (q != 1.0f);
   b.prev_sids = nullptr; b.prev_deg = 0; b.vmin = g.vmin;
-  if (b.need_member) {
-    const Row *pr = row_of(g, prev);
-    if (pr) { Row r = *pr; b.prev_sids = g.sids + r.off; b.prev_deg = r.deg; }
+  if (b.need_member) {   // N(prev) through the membership structure (replicated on every shard)
+    int64_t s = (int64_t)prev - g.vmin;
+    if (s >= 0 && s < g.n_slots) { Row r = g.mrows[s]; b.prev_sids = g.msids + r.off; b.prev_deg = r.deg; }
   }
   return b;
 }
@@ -525,8 +525,6 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
   if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
   check_params(P);
   const int32_t world = h->cfg.world;
-  if (world > 1 && P.q != 1.0f)
-    throw Error(SRW_ERR_INVALID, "vertex-sharded step needs q == 1 (N(prev) lives on another GPU); use the replicated mode");
   hipStream_t st = h->stream;
   h->counters.ensure(1);
   h->shard_counts.ensure((size_t)world * 2);

@@ -11,8 +11,9 @@ copy of the path matrix (slot (wid, step) is written by exactly one rank); one M
 iteration assembles the paths.  Because the RNG is keyed by (iteration, source vertex, step), the result is
 bit-identical to the single-GPU walk for any world size — tests assert exactly that.
 
-q != 1 needs N(prev), which lives on owner(prev): in this round the sharded path serves q == 1 (any p); for
-q != 1 use the replicated mode (whole graph per GPU, walk iterations sharded, no collective) — see DESIGN.md §6.
+q != 1 needs N(prev), which lives on owner(prev): every shard therefore also keeps a replicated *membership
+structure* of the whole graph (row boundaries + sorted neighbor ids, 4 B/entry; graph_build.hip), so the p/q bias is
+evaluated locally and the exchanged record stays 16 bytes — see DESIGN.md §6.
 
 The step engine is injectable so that the exchange protocol can be tested with the gloo backend on CPU (the
 tests plug the CPU oracle in; the product default is the HIP engine, which needs a GPU).
@@ -80,8 +81,6 @@ class ShardedWalker:
     # ---- one walk iteration = walk_length + 1 super-steps ----
     def walk_iteration(self, iteration=0, p=1.0, q=1.0, walk_length=80, num_walks=1, seed=42, rng="philox",
                        const_r=0.0, gather=False):
-        if float(np.float32(q)) != 1.0:
-            raise SrwError(1, "the vertex-sharded path serves q == 1 in this round; use the replicated mode for q != 1")
         world = self.world
         n_local, n_global = self.se.capacity()
         stride = walk_length + 2

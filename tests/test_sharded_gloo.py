@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, directed, p, L, rng, out_dir):
+def _worker(rank, world, port, directed, p, q, L, rng, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.dirname(HERE))
@@ -43,7 +43,7 @@ def _worker(rank, world, port, directed, p, L, rng, out_dir):
     try:
         g = oracle_py.Graph.load(KARATE, directed=directed)
         drv = sharded.ShardedWalker(rank=rank, world=world, step_engine=OracleShardEngine(g, rank, world))
-        paths, lens, stats = drv.walk(num_walks=2, first_walk=3, p=p, q=1.0, walk_length=L, seed=11, rng=rng, const_r=0.4)
+        paths, lens, stats = drv.walk(num_walks=2, first_walk=3, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
         np.save(os.path.join(out_dir, "paths_%d.npy" % rank), paths)
         np.save(os.path.join(out_dir, "lens_%d.npy" % rank), lens)
         np.save(os.path.join(out_dir, "steps_%d.npy" % rank), np.array([sum(s["n_steps_global"] for s in stats),
@@ -52,13 +52,13 @@ def _worker(rank, world, port, directed, p, L, rng, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,directed,p,rng", [(2, False, 1.0, "philox"), (2, True, 0.5, "philox"),
-                                                   (3, False, 4.0, "const")])
-def test_sharded_equals_single(oracle, tmp_path, world, directed, p, rng):
+@pytest.mark.parametrize("world,directed,p,q,rng", [(2, False, 1.0, 1.0, "philox"), (2, True, 0.5, 1.0, "philox"),
+                                                     (3, False, 4.0, 1.0, "const"), (2, False, 0.25, 4.0, "philox")])
+def test_sharded_equals_single(oracle, tmp_path, world, directed, p, q, rng):
     L = 12
-    mp.spawn(_worker, args=(world, _free_port(), directed, p, L, rng, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), directed, p, q, L, rng, str(tmp_path)), nprocs=world, join=True)
     g = oracle.Graph.load(KARATE, directed=directed)
-    ref_paths, ref_lens, ref_steps = g.walk(p=p, q=1.0, walk_length=L, num_walks=2, first_walk=3, seed=11, rng=rng,
+    ref_paths, ref_lens, ref_steps = g.walk(p=p, q=q, walk_length=L, num_walks=2, first_walk=3, seed=11, rng=rng,
                                             const_r=0.4)
     for r in range(world):
         paths = np.load(tmp_path / ("paths_%d.npy" % r))
@@ -68,16 +68,3 @@ def test_sharded_equals_single(oracle, tmp_path, world, directed, p, rng):
         assert np.array_equal(paths, ref_paths)
         assert steps == ref_steps
     assert exchanged > 0  # walkers really crossed shards
-
-
-def test_q_not_one_is_rejected(oracle):
-    sys.path.insert(0, os.path.dirname(HERE))
-    import _pkg
-    pkg = _pkg.load()
-    from importlib import import_module
-    sharded = import_module("stellar_random_walk_amd.distributed")
-    from oracle_shard_engine import OracleShardEngine
-    g = oracle.Graph.load(KARATE)
-    drv = sharded.ShardedWalker(rank=0, world=2, step_engine=OracleShardEngine(g, 0, 2))
-    with pytest.raises(pkg.SrwError):
-        drv.walk_iteration(q=4.0)

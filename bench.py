@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--sampler", choices=["reference", "alias"], default="reference")
     ap.add_argument("--shard", choices=["replicate", "vertex"], default="replicate")
     ap.add_argument("--nt-loads", type=int, default=-1, help="-1 auto, 0 cached, 1 nontemporal record loads")
+    ap.add_argument("--compact", type=int, default=1, help="0: do not use the 16-byte lattice records")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-scale", type=int, default=20)
     ap.add_argument("--cpu-sources", type=int, default=0, help="0 = max(64, 3 per host core)")
@@ -110,6 +111,8 @@ def main():
         walk_kw["nt_loads"] = bool(args.nt_loads)
     if args.sampler == "alias":
         walk_kw["sampler"] = "alias"
+    if not args.compact:
+        walk_kw["compact"] = False
 
     if args.shard == "vertex" and world > 1:
         from importlib import import_module
@@ -167,9 +170,9 @@ def main():
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         if stats["kernel_kind"] == 1:
             # first-order guide-table kernel, per launch: the linked CDF/guide records actually read
-            # (counted by the kernel, 32 B each) + 4 B path store per step; per walker 4 B seed + 16 B row + 4 B len
+            # (counted by the kernel; 16 B compact lattice records or 32 B exact records) + 4 B path store per step; per walker 4 B seed + 16 B row + 4 B len
             per_launch_steps = steps / max(K, 1)
-            alg_bytes = per_launch_steps * 4 + stats["ent_reads"] * 32 + stats["n_walkers"] * 24
+            alg_bytes = per_launch_steps * 4 + stats["ent_reads"] * stats["record_bytes"] + stats["n_walkers"] * 24
             kernel_name = "k_walk_first_order"
         elif stats["kernel_kind"] == 3:
             # Mode A: 32-B alias records read (counted) + 4 B path store per step; membership probes of
@@ -197,14 +200,19 @@ def main():
             "steps": K, "warmup": W, "ms_per_step": max_dt / max(K, 1) * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "int32 ids / f64 CDF", "data": "synthetic",
             "config": {"workload": "RMAT scale-%d ef%d (%d edge lines, %d adjacency entries, %d vertices) undirected "
-                                   "%s p=%g q=%g walkLength=%d, 1 walk iteration per step, " + ("Mode A (alias + rejection)" if args.sampler == "alias" else "Mode R (reference-exact)")
+                                   "%s p=%g q=%g walkLength=%d, 1 walk iteration per step, %s"
                                    % (args.scale, args.edge_factor, n_edges, ne, nv,
-                                      "weighted" if args.weighted else "unweighted", args.p, args.q, args.walk_length),
+                                      "weighted" if args.weighted else "unweighted", args.p, args.q, args.walk_length,
+                                      "Mode A (alias + rejection)" if args.sampler == "alias" else "Mode R (reference-exact)"),
                        "walk_steps_per_bench_step": int(steps / max(K, 1)), "parallelism": parallelism,
                        "rng": "Philox4x32-10 keyed (iteration, source, step)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
-                         "kernel_ms_avg": avg_ms, "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "kernel_ms_avg": avg_ms, "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "record_bytes": stats.get("record_bytes", 0),
+                         # context (profiles/r01_microbench_random_gather.txt): measured MI355X ceiling of dependent random
+                         # reads, the access pattern of this kernel: 51.2e9 16-B records/s, 40.3e9 32-B records/s
+                         "random_gather_ceiling_records_per_s": {16: 51.2e9, 32: 40.3e9}.get(stats.get("record_bytes", 0))},
         }
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -109,7 +109,8 @@ typedef struct {
 enum {
   SRW_WALK_FORCE_GENERAL = 1, /* use the general second-order kernel even when p == q == 1 (testing) */
   SRW_WALK_NT_LOADS = 2,      /* first-order kernel: force L1-bypassing (nontemporal) record loads */
-  SRW_WALK_CACHED_LOADS = 4   /* first-order kernel: force default-policy loads (default: chosen from the table size) */
+  SRW_WALK_CACHED_LOADS = 4,  /* first-order kernel: force default-policy loads (default: chosen from the table size) */
+  SRW_WALK_NO_COMPACT = 16    /* first-order kernel: do not use the 16-byte lattice records even when available */
 };
 
 typedef struct {
@@ -123,7 +124,7 @@ typedef struct {
   int64_t trials;       /* Mode A: alias draws (accepted + rejected) */
   double kernel_ms;     /* hipEvent time of the walk kernels of this call, on the handle's stream */
   int32_t kernel_kind;  /* 1 = first-order guide-table kernel, 2 = general second-order kernel, 3 = alias */
-  int32_t reserved;
+  int32_t record_bytes; /* bytes of one sampling-table record read by this kernel (16 compact / 32 / 0) */
 } srw_walk_stats;
 
 /* Replaces RandomWalk.randomWalk (M/algorithm/RandomWalk.scala:75-176) incl. initFirstStep (:51-66):

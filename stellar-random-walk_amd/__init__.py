@@ -20,6 +20,7 @@ RNG_CONST, RNG_PHILOX = 0, 1
 WALK_FORCE_GENERAL = 1
 WALK_NT_LOADS = 2
 WALK_CACHED_LOADS = 4
+WALK_NO_COMPACT = 16
 
 
 class SrwError(RuntimeError):
@@ -42,10 +43,10 @@ class WalkStats(C.Structure):
     _fields_ = [("n_walkers", C.c_int64), ("n_steps", C.c_int64), ("dead_ends", C.c_int64),
                 ("sum_deg_curr", C.c_int64), ("sum_deg_prev", C.c_int64), ("ent_reads", C.c_int64),
                 ("fallbacks", C.c_int64), ("trials", C.c_int64), ("kernel_ms", C.c_double), ("kernel_kind", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("record_bytes", C.c_int32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 # every symbol include/stellar_rw.h declares
@@ -281,14 +282,14 @@ class Engine:
     # ---- walk ----
     @staticmethod
     def params(p=1.0, q=1.0, walk_length=80, num_walks=1, first_walk=0, rng="philox", const_r=0.0, seed=42,
-               sampler=SAMPLER_REFERENCE, force_general=False, nt_loads=None, occ=0):
+               sampler=SAMPLER_REFERENCE, force_general=False, nt_loads=None, occ=0, compact=True):
         if sampler == "alias":
             sampler = SAMPLER_ALIAS
         elif sampler == "reference":
             sampler = SAMPLER_REFERENCE
         return WalkParams(np.float32(p), np.float32(q), walk_length, num_walks, first_walk,
                           RNG_CONST if rng == "const" else RNG_PHILOX, np.float32(const_r), seed, sampler,
-                          (WALK_FORCE_GENERAL if force_general else 0) | (0 if nt_loads is None else WALK_NT_LOADS if nt_loads else WALK_CACHED_LOADS) | (occ << 8))
+                          (WALK_FORCE_GENERAL if force_general else 0) | (0 if nt_loads is None else WALK_NT_LOADS if nt_loads else WALK_CACHED_LOADS) | (occ << 8) | (0 if compact else WALK_NO_COMPACT))
 
     def walk(self, fetch=True, **kw):
         """Runs srw_walk.  Returns (paths [nWalkers, L+2] int32 (-1 tail), lens, stats dict) or just stats."""

@@ -36,6 +36,19 @@ struct alignas(32) FoEnt {
   uint32_t nflags;
 };
 
+// Compact first-order record for LATTICE draws (p = m * 2^-24, i.e. the Philox stream): cdf >= p  <=>
+// floor(cdf * 2^24) >= m, so 25 bits of the exact f64 CDF decide exactly like the f64 compare.  One 16-byte load.
+//   cg   : bits 0..24  c = min(floor(cdf * 2^24), 2^24)      bits 26..31  guide delta gd = j - guide[j] (0..62)
+//   id   : neighbor id
+//   link : bits 0..39 noff | bits 40..62 ndeg (< 2^23 - 1) | bit 63 next row needs the generic path
+// Built from the exact 32-byte table and used only if no entry needs an escape (sampler_tables.hip).
+struct alignas(16) CfoEnt {
+  uint32_t cg;
+  int32_t id;
+  uint64_t link;
+};
+constexpr uint32_t CFO_NDEG_MAX = (1u << 23) - 2u;
+
 // Mode A record: alias slot of entry k of a row + the neighbor's id / weight / row descriptor (linked).
 struct alignas(32) AEnt {
   float prob;    // P(keep slot k | slot k drawn) = kept_k / T, exact-integer construction (alias_tables.hip)
@@ -57,6 +70,7 @@ struct GraphView {
   const uint32_t *sids;
   const uint32_t *sperm;
   const FoEnt *fo;
+  const CfoEnt *cfo;    // null unless the compact table is valid for the whole graph
   const AEnt *al;
   const double *rsum;   // Mode A: exact weight sum of each alias-regular row
   const Row *mrows;     // membership structure: rows/sids of the WHOLE graph (== rows/sids when world == 1;

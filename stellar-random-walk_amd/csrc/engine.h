@@ -71,13 +71,15 @@ struct Graph {
   DevBuf<uint32_t> sperm;         // [n_entries] input-order position (inside the row) of each sorted entry
   DevBuf<FoEnt> fo;               // [n_entries], built lazily
   bool has_fo = false;
+  DevBuf<CfoEnt> cfo;             // [n_entries] compact lattice records (optional)
+  bool has_cfo = false;
   DevBuf<AEnt> al;                // [n_entries] Mode A alias records, built lazily
   DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
   bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
-  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
+  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_cfo ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, vmin, n_slots}; }
 };
 

@@ -170,6 +170,8 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
   g.n_entries = n_owned;
   g.has_fo = false;
   g.fo.release();
+  g.has_cfo = false;
+  g.cfo.release();
   g.has_al = false;
   g.al.release();
 

@@ -229,6 +229,53 @@ __global__ void k_fo_link(const Row *__restrict__ rows, FoEnt *__restrict__ fo, 
   }
 }
 
+// ---- compact 16-byte records (lattice draws) derived from the exact table --------------------------------------
+__device__ inline void cfo_write(const FoEnt *row, CfoEnt *crow, int32_t j, unsigned long long *escapes) {
+  const FoEnt f = row[j];
+  const double sc = f.cdf * 16777216.0;                       // exact scaling
+  const uint32_t c = sc >= 16777216.0 ? 16777216u : (uint32_t)sc;   // floor; cdf >= 0 on a regular row
+  const int32_t delta = j - f.guide;
+  bool esc = delta < 0 || delta > 62 || f.ndeg > (int32_t)CFO_NDEG_MAX || f.noff >= ((int64_t)1 << 40);
+  // a start below guide[j] stays a valid lower bound, so a small negative delta could use 0; be strict instead
+  CfoEnt o;
+  o.cg = c | ((uint32_t)(esc ? 63 : delta) << 26);
+  o.id = f.id;
+  const bool generic = (f.nflags & ROW_IRREGULAR) != 0;
+  o.link = (uint64_t)f.noff | ((uint64_t)(uint32_t)f.ndeg << 40) | ((uint64_t)generic << 63);
+  crow[j] = o;
+  if (esc) atomicAdd(escapes, 1ull);
+}
+__global__ void k_cfo_small(const Row *__restrict__ rows, const FoEnt *__restrict__ fo, CfoEnt *__restrict__ cfo,
+                            int64_t n_slots, unsigned long long *escapes) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
+    Row r = rows[v];
+    if (r.deg <= 0 || r.deg > SMALL_DEG) continue;
+    if (r.flags & ROW_IRREGULAR) {      // never sampled through the compact table; keep the link usable
+      for (int32_t j = 0; j < r.deg; ++j) { FoEnt f = fo[r.off + j]; CfoEnt o; o.cg = 0; o.id = f.id;
+        o.link = (uint64_t)f.noff | ((uint64_t)(uint32_t)min(f.ndeg, (int32_t)CFO_NDEG_MAX) << 40) | ((uint64_t)((f.nflags & ROW_IRREGULAR) != 0) << 63);
+        cfo[r.off + j] = o; if (f.ndeg > (int32_t)CFO_NDEG_MAX) atomicAdd(escapes, 1ull); }
+      continue;
+    }
+    for (int32_t j = 0; j < r.deg; ++j) cfo_write(fo + r.off, cfo + r.off, j, escapes);
+  }
+}
+__global__ void k_cfo_large(const Row *__restrict__ rows, const FoEnt *__restrict__ fo, CfoEnt *__restrict__ cfo,
+                            const uint2 *__restrict__ items, const unsigned long long *n_items_p,
+                            unsigned long long *escapes) {
+  const int lane = lane_id();
+  const unsigned long long n_items = *n_items_p;
+  unsigned long long wave = (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) >> 6;
+  const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+  for (unsigned long long it = wave; it < n_items; it += n_waves) {
+    uint2 item = items[it];
+    const int64_t v = (int64_t)item.x | ((int64_t)(item.y >> 24) << 32);
+    const int32_t part = (int32_t)(item.y & 0xFFFFFFu);
+    Row r = rows[v];
+    const int32_t jb = part * GUIDE_ITEM, je = min(r.deg, jb + GUIDE_ITEM);
+    for (int32_t j = jb + lane; j < je; j += 64) cfo_write(fo + r.off, cfo + r.off, j, escapes);
+  }
+}
+
 }  // namespace
 
 void build_first_order_tables(srw_handle *h) {
@@ -243,15 +290,12 @@ void build_first_order_tables(srw_handle *h) {
   SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
   hipLaunchKernelGGL(k_fo_large, dim3(256 * 8), dim3(256), 0, st, g.rows.p, g.ent.p, g.fo.p, g.n_slots, next_slot.p);
   hipLaunchKernelGGL(k_guide_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_slots);
-  {
-    const unsigned long long cap = (unsigned long long)g.n_entries / SMALL_DEG + 1024;
-    DevBuf<uint2> items; DevBuf<unsigned long long> n_items;
-    items.alloc((size_t)cap); n_items.alloc(1);
-    SRW_HIP(hipMemsetAsync(n_items.p, 0, 8, st));
-    hipLaunchKernelGGL(k_guide_make_items, dim3(gs), dim3(256), 0, st, g.rows.p, g.n_slots, n_items.p, items.p, cap);
-    hipLaunchKernelGGL(k_guide_large, dim3(256 * 16), dim3(256), 0, st, g.rows.p, g.fo.p, items.p, n_items.p);
-    SRW_HIP(hipStreamSynchronize(st));
-  }
+  const unsigned long long cap = (unsigned long long)g.n_entries / SMALL_DEG + 1024;
+  DevBuf<uint2> items; DevBuf<unsigned long long> n_items;
+  items.alloc((size_t)cap); n_items.alloc(2);
+  SRW_HIP(hipMemsetAsync(n_items.p, 0, 16, st));
+  hipLaunchKernelGGL(k_guide_make_items, dim3(gs), dim3(256), 0, st, g.rows.p, g.n_slots, n_items.p, items.p, cap);
+  hipLaunchKernelGGL(k_guide_large, dim3(256 * 16), dim3(256), 0, st, g.rows.p, g.fo.p, items.p, n_items.p);
   if (g.n_entries > 0) {
     int ge = (int)std::min<int64_t>((g.n_entries + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(k_fo_link, dim3(ge), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_entries, g.vmin, g.n_slots);
@@ -259,6 +303,22 @@ void build_first_order_tables(srw_handle *h) {
   SRW_HIP(hipGetLastError());
   SRW_HIP(hipStreamSynchronize(st));
   g.has_fo = true;
+  // compact lattice table: only when it fits comfortably and no entry needs an escape
+  g.has_cfo = false;
+  size_t free_b = 0, total_b = 0;
+  SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+  const size_t need = (size_t)g.n_entries * sizeof(CfoEnt);
+  if (g.n_entries > 0 && h->cfg.world == 1 && free_b > need + need / 2 + ((size_t)16 << 30)) {
+    g.cfo.alloc((size_t)g.n_entries);
+    unsigned long long *esc = n_items.p + 1;
+    hipLaunchKernelGGL(k_cfo_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.fo.p, g.cfo.p, g.n_slots, esc);
+    hipLaunchKernelGGL(k_cfo_large, dim3(256 * 16), dim3(256), 0, st, g.rows.p, g.fo.p, g.cfo.p, items.p, n_items.p, esc);
+    unsigned long long n_esc = 0;
+    SRW_HIP(hipMemcpyAsync(&n_esc, esc, 8, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    SRW_HIP(hipGetLastError());
+    if (n_esc == 0) g.has_cfo = true; else g.cfo.release();
+  }
 }
 
 }  // namespace srw

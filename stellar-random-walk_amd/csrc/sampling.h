@@ -71,6 +71,33 @@ __device__ inline FoEnt load_fo(const FoEnt *p) {
   return *p;
 }
 
+template <bool NT>
+__device__ inline CfoEnt load_cfo(const CfoEnt *p) {
+  const int4v *q = reinterpret_cast<const int4v *>(p);
+  int4v a = NT ? __builtin_nontemporal_load(q) : *q;
+  CfoEnt e;
+  e.cg = (uint32_t)a.x; e.id = a.y;
+  e.link = ((uint64_t)(uint32_t)a.w << 32) | (uint32_t)a.z;
+  return e;
+}
+
+// Lattice draw (p = m * 2^-24) through the compact table: same index as fo_pick, one 16-byte load per probe.
+template <bool NT>
+__device__ inline CfoEnt cfo_pick(const CfoEnt *row, int32_t deg, uint32_t m, unsigned &reads) {
+  const uint32_t j = (uint32_t)(((uint64_t)m * (uint64_t)(uint32_t)deg) >> 24);
+  CfoEnt e = load_cfo<NT>(row + j);
+  reads = 1;
+  const uint32_t gd = e.cg >> 26;
+  int32_t k = (int32_t)j - (int32_t)gd;
+  if (gd) { e = load_cfo<NT>(row + k); ++reads; }
+  while ((e.cg & 0x3FFFFFFu) < m) {           // floor(cdf * 2^24) < m  <=>  cdf < p
+    ++k;
+    if (k >= deg) { e = load_cfo<NT>(row); ++reads; break; }   // edges.head fallback (:24)
+    e = load_cfo<NT>(row + k); ++reads;
+  }
+  return e;
+}
+
 // Returns the chosen record (id + the neighbor's row descriptor); k_out = its position.
 template <bool NT>
 __device__ inline FoEnt fo_pick(const FoEnt *row, int32_t deg, float r, int32_t &k_out, unsigned &reads) {

@@ -44,7 +44,7 @@ __device__ inline void flush_counters(DevCounters *ctr, unsigned long long steps
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <bool NT, int MINW>
+template <bool NT, int MINW, bool COMPACT>
 __global__ __launch_bounds__(TPB, MINW) void k_walk_first_order(GraphView g, const int32_t *__restrict__ verts,
                                                           int64_t n_verts, int64_t n_walkers, int32_t L,
                                                           int32_t first_walk, RngSpec rng,
@@ -77,17 +77,26 @@ __global__ __launch_bounds__(TPB, MINW) void k_walk_first_order(GraphView g, con
       if (r.deg == 0) {
         alive = false; if (s > 1) ++dead;                      // dead end, RandomWalk.scala:115-120 (acc2 counts the loop only)
       } else {
-        float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
-        FoEnt e;
-        if (r.flags & ROW_IRREGULAR) {
-          int32_t k = lane_pick_sequential(g.ent + r.off, r.deg, nobias, u);
-          e = g.fo[r.off + k]; ++fb;
+        if (COMPACT && !(r.flags & ROW_IRREGULAR)) {          // Philox draw on the 2^-24 lattice: 16-byte records
+          const uint32_t m = walk_bits24(rng.seed, iter, (uint32_t)src, (uint32_t)s);
+          unsigned rd;
+          const CfoEnt e = cfo_pick<NT>(g.cfo + r.off, r.deg, m, rd); reads += rd;
+          val = e.id; ++len;
+          r.off = (int64_t)(e.link & 0xFFFFFFFFFFull); r.deg = (int32_t)((e.link >> 40) & 0x7FFFFFu);
+          r.flags = (e.link >> 63) ? ROW_IRREGULAR : 0u;
         } else {
-          unsigned rd; int32_t k;
-          e = fo_pick<NT>(g.fo + r.off, r.deg, u, k, rd); reads += rd;
+          float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
+          FoEnt e;
+          if (r.flags & ROW_IRREGULAR) {
+            int32_t k = lane_pick_sequential(g.ent + r.off, r.deg, nobias, u);
+            e = g.fo[r.off + k]; ++fb;
+          } else {
+            unsigned rd; int32_t k;
+            e = fo_pick<NT>(g.fo + r.off, r.deg, u, k, rd); reads += rd;
+          }
+          val = e.id; ++len;
+          r.off = e.noff; r.deg = e.ndeg; r.flags = e.nflags;   // the picked record carries the next row
         }
-        val = e.id; ++len;
-        r.off = e.noff; r.deg = e.ndeg; r.flags = e.nflags;     // the picked record carries the next row
       }
     }
     tile[wv][lane][c] = val;
@@ -447,6 +456,7 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   if (n_walkers >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "more than 2^31 walkers in one call: lower num_walks");
   const int32_t stride = P.walk_length + 2;
   const bool alias = P.sampler == SRW_SAMPLER_ALIAS;
+  bool first_order_compact = false;
   const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
   if (first_order) build_first_order_tables(h);
   if (alias) build_alias_tables(h);
@@ -478,12 +488,19 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
     const bool nt = (P.flags & SRW_WALK_NT_LOADS) ? true
                     : (P.flags & SRW_WALK_CACHED_LOADS) ? false : fo_bytes > ((size_t)2 << 30);
     const int occ = (P.flags >> 8) & 0xF;   // experiment switch: requested min waves/SIMD (0 = compiler's choice)
-#define SRW_LAUNCH_FO(NTV, MW)                                                                                      \
-  hipLaunchKernelGGL((k_walk_first_order<NTV, MW>), dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p,         \
+    // 16-byte compact records: Philox draws only (p = m * 2^-24), and only if the whole graph qualified at build time
+    const bool compact = g.has_cfo && P.rng_mode == SRW_RNG_PHILOX && !(P.flags & SRW_WALK_NO_COMPACT);
+    first_order_compact = compact;
+#define SRW_LAUNCH_FO(NTV, MW, CP)                                                                                  \
+  hipLaunchKernelGGL((k_walk_first_order<NTV, MW, CP>), dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p,     \
                      g.n_vertices, n_walkers, P.walk_length, P.first_walk, rng, h->res.paths.p, h->res.lens.p,      \
                      h->counters.p)
-    if (nt) { if (occ == 8) SRW_LAUNCH_FO(true, 8); else if (occ == 7) SRW_LAUNCH_FO(true, 7); else SRW_LAUNCH_FO(true, 1); }
-    else    { if (occ == 8) SRW_LAUNCH_FO(false, 8); else if (occ == 7) SRW_LAUNCH_FO(false, 7); else SRW_LAUNCH_FO(false, 1); }
+    if (compact) {
+      const bool ntc = (P.flags & SRW_WALK_NT_LOADS) ? true : (P.flags & SRW_WALK_CACHED_LOADS) ? false
+                       : (size_t)g.n_entries * sizeof(CfoEnt) > ((size_t)2 << 30);
+      if (ntc) SRW_LAUNCH_FO(true, 1, true); else SRW_LAUNCH_FO(false, 1, true);
+    } else if (nt) { if (occ == 8) SRW_LAUNCH_FO(true, 8, false); else if (occ == 7) SRW_LAUNCH_FO(true, 7, false); else SRW_LAUNCH_FO(true, 1, false); }
+    else    { if (occ == 8) SRW_LAUNCH_FO(false, 8, false); else if (occ == 7) SRW_LAUNCH_FO(false, 7, false); else SRW_LAUNCH_FO(false, 1, false); }
 #undef SRW_LAUNCH_FO
   } else {
     int64_t blocks = (n_walkers * 64 + TPB - 1) / TPB;
@@ -499,6 +516,7 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   float ms = 0.f;
   SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   s->kernel_ms = ms; s->n_walkers = n_walkers; s->kernel_kind = alias ? 3 : first_order ? 1 : 2;
+  s->record_bytes = first_order_compact ? 16 : (first_order || alias) ? 32 : 0;   // bytes per table record read
   h->res.valid = true;
 }
 

@@ -438,3 +438,28 @@ def test_certified_scan_on_lattice_ties(eng, oracle, pattern):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (pattern, r)
         c = eng.walk(walk_length=0, rng="const", const_r=r)           # first-order guide-table kernel, same draws
         assert np.array_equal(c[0], b[0])
+
+
+def test_compact_lattice_records(eng, oracle):
+    # unweighted graphs qualify for the 16-byte records (Philox draws); results must equal the exact 32-byte path
+    # and the oracle; weighted graphs with large guide deltas must fall back to the exact records automatically
+    s, d, _ = rmat_lines(oracle, 13, edge_factor=16)
+    g = oracle.Graph.from_coo(s, d, None)
+    eng.load_coo(s, d, None)
+    a = eng.walk(walk_length=30, num_walks=2, seed=77)
+    b = eng.walk(walk_length=30, num_walks=2, seed=77, compact=False)
+    assert a[2]["record_bytes"] == 16 and b[2]["record_bytes"] == 32
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    rp, rl, _ = g.walk(walk_length=30, num_walks=2, seed=77, threads=8)
+    assert np.array_equal(a[0], rp) and np.array_equal(a[1], rl)
+    for nt in (True, False):
+        c = eng.walk(walk_length=30, num_walks=2, seed=77, nt_loads=nt)
+        assert c[2]["record_bytes"] == 16 and np.array_equal(c[0], rp)
+    assert eng.walk(walk_length=5, rng="const", const_r=0.5)[2]["record_bytes"] == 32     # const-r: exact records
+    eng.load_edgelist(KARATE, directed=True)                                            # dead ends + compact
+    a = eng.walk(walk_length=20, num_walks=3, seed=5)
+    rp, rl, _ = oracle.Graph.load(KARATE, directed=True).walk(walk_length=20, num_walks=3, seed=5)
+    assert a[2]["record_bytes"] == 16 and np.array_equal(a[0], rp) and np.array_equal(a[1], rl)
+    s, d, w = rmat_lines(oracle, 13, edge_factor=16, weighted=True)                     # escapes -> exact records
+    eng.load_coo(s, d, w)
+    assert eng.walk(walk_length=5, seed=1)[2]["record_bytes"] == 32

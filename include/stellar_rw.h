@@ -132,6 +132,23 @@ typedef struct {
  * iteration * nVertices + rank(vertex).  Paths stay in HBM as int32 [n_walkers][walk_length + 2]
  * (unused tail = -1) plus int32 lens[n_walkers]. */
 int32_t srw_walk(srw_handle *h, const srw_walk_params *params, srw_walk_stats *stats);
+/* The whole randomWalk loop with the results streamed to HOST buffers: iteration i's kernel runs while iteration
+ * i-1's paths travel over PCIe on a second HIP stream (two device staging buffers).  paths is
+ * [num_walks * nVertices][walk_length + 2], lens [num_walks * nVertices]; allocate them with srw_host_alloc
+ * (pinned) for full PCIe rate — pageable buffers work but serialise.  Replaces RandomWalk.randomWalk returning
+ * the union of all iterations' paths (M/algorithm/RandomWalk.scala:168,175). */
+int32_t srw_walk_to_host(srw_handle *h, const srw_walk_params *params, int32_t *paths, int32_t *lens,
+                         srw_walk_stats *stats);
+/* Main.doRandomWalk fused (M/Main.scala:53-62: rw.execute() then rw.save(...)): walks num_walks iterations and
+ * writes <output_dir>/path/part-* + _SUCCESS while streaming — iteration i's kernel and PCIe transfer overlap the host's
+ * formatting of iteration i-1 (pinned ring of two slices); the paths are never held as a whole in host memory.
+ * dead_ends_per_iteration (optional, [num_walks]) receives the reference's per-iteration "Zero Neighbors" count.
+ * Fails with SRW_ERR_EXISTS before any work if <output_dir>/path exists. */
+int32_t srw_walk_and_save(srw_handle *h, const srw_walk_params *params, const char *output_dir, int32_t n_parts,
+                          int32_t write_crc, srw_walk_stats *stats, int64_t *dead_ends_per_iteration);
+/* Pinned (page-locked) host memory for srw_walk_to_host / srw_fetch_paths destinations. */
+int32_t srw_host_alloc(size_t bytes, void **out);
+void srw_host_free(void *p);
 /* Copy the last walk's paths / lens to host buffers (either may be NULL). */
 int32_t srw_fetch_paths(const srw_handle *h, int32_t *paths, int32_t *lens);
 /* Device pointers of the last walk's result (valid until the next srw_walk / destroy). */

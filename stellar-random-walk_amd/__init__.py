@@ -53,7 +53,7 @@ class WalkStats(C.Structure):
 EXPORTS = [
     "srw_create", "srw_destroy", "srw_last_error", "srw_set_stream", "srw_load_edgelist", "srw_load_coo",
     "srw_load_adjacency", "srw_generate_rmat", "srw_graph_stats", "srw_graph_vertices", "srw_graph_neighbors",
-    "srw_graph_partition", "srw_alias_row", "srw_walk", "srw_fetch_paths", "srw_device_paths", "srw_write_paths",
+    "srw_graph_partition", "srw_alias_row", "srw_walk", "srw_walk_to_host", "srw_walk_and_save", "srw_host_alloc", "srw_host_free", "srw_fetch_paths", "srw_device_paths", "srw_write_paths",
     "srw_shard_capacity", "srw_shard_seed", "srw_shard_step", "srw_sample", "srw_second_order_weights",
     "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_version",
 ]
@@ -88,6 +88,11 @@ def lib():
     L.srw_graph_partition.argtypes = [vp, C.c_int32, i32p, i32p]
     L.srw_alias_row.argtypes = [vp, C.c_int32, f32p, i32p, C.c_int64, i64p, i32p]
     L.srw_walk.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(WalkStats)]
+    L.srw_walk_to_host.argtypes = [vp, C.POINTER(WalkParams), i32p, i32p, C.POINTER(WalkStats)]
+    L.srw_walk_and_save.argtypes = [vp, C.POINTER(WalkParams), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(WalkStats), i64p]
+    L.srw_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.srw_host_free.argtypes = [vp]
+    L.srw_host_free.restype = None
     L.srw_fetch_paths.argtypes = [vp, i32p, i32p]
     L.srw_device_paths.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i64p, i32p]
     L.srw_write_paths.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
@@ -302,6 +307,42 @@ class Engine:
         lens = np.empty(max(st.n_walkers, 1), dtype=np.int32)
         self._ck(lib().srw_fetch_paths(self.h, _i32(paths), _i32(lens)))
         return paths[:st.n_walkers], lens[:st.n_walkers], st.as_dict()
+
+    def walk_to_host(self, pinned=True, **kw):
+        """srw_walk_to_host: all num_walks iterations streamed into host buffers (kernel i overlaps the copy of i-1).
+        Returns (paths, lens, stats); with pinned=True the arrays are copies of pinned staging memory."""
+        P = self.params(**kw)
+        nv = self.num_vertices
+        n, stride = P.num_walks * nv, P.walk_length + 2
+        st = WalkStats()
+        if pinned:
+            pp, pl = C.c_void_p(), C.c_void_p()
+            if lib().srw_host_alloc(max(n * stride * 4, 4), C.byref(pp)) != OK or \
+                    lib().srw_host_alloc(max(n * 4, 4), C.byref(pl)) != OK:
+                raise SrwError(ERR_NOMEM, "pinned host allocation failed")
+            try:
+                self._ck(lib().srw_walk_to_host(self.h, C.byref(P), C.cast(pp, C.POINTER(C.c_int32)),
+                                                C.cast(pl, C.POINTER(C.c_int32)), C.byref(st)))
+                paths = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_int32)), shape=(max(n, 1), stride))[:n].copy()
+                lens = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy()
+            finally:
+                lib().srw_host_free(pp)
+                lib().srw_host_free(pl)
+        else:
+            paths = np.empty((max(n, 1), stride), dtype=np.int32)
+            lens = np.empty(max(n, 1), dtype=np.int32)
+            self._ck(lib().srw_walk_to_host(self.h, C.byref(P), _i32(paths), _i32(lens), C.byref(st)))
+            paths, lens = paths[:n], lens[:n]
+        return paths, lens, st.as_dict()
+
+    def walk_and_save(self, output_dir, n_parts=1, write_crc=False, **kw):
+        """srw_walk_and_save: Main.doRandomWalk fused and streamed.  Returns (stats, dead_ends_per_iteration)."""
+        P = self.params(**kw)
+        st = WalkStats()
+        dead = (C.c_int64 * max(P.num_walks, 1))()
+        self._ck(lib().srw_walk_and_save(self.h, C.byref(P), os.fsencode(output_dir), n_parts, int(write_crc),
+                                         C.byref(st), dead))
+        return st.as_dict(), list(dead)[:P.num_walks]
 
     def device_paths(self):
         dp, dl, n, s = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.c_int32(0)

@@ -98,6 +98,12 @@ void srw_destroy(srw_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (int i = 0; i < 2; ++i) {
+    if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
+    if (h->kernel_done[i]) (void)hipEventDestroy(h->kernel_done[i]);
+  }
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  for (int i = 0; i < 2; ++i) { if (h->pin_paths[i]) (void)hipHostFree(h->pin_paths[i]); if (h->pin_lens[i]) (void)hipHostFree(h->pin_lens[i]); }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -250,6 +256,29 @@ int32_t srw_walk(srw_handle *h, const srw_walk_params *params, srw_walk_stats *s
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] { need(params != nullptr, "params is null"); run_walk(h, *params, stats); });
 }
+
+int32_t srw_walk_to_host(srw_handle *h, const srw_walk_params *params, int32_t *paths, int32_t *lens, srw_walk_stats *stats) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { need(params && paths && lens, "null argument"); run_walk_to_host(h, *params, paths, lens, stats); });
+}
+
+int32_t srw_walk_and_save(srw_handle *h, const srw_walk_params *params, const char *output_dir, int32_t n_parts,
+                          int32_t write_crc, srw_walk_stats *stats, int64_t *dead_ends_per_iteration) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(params && output_dir, "null argument");
+    run_walk_and_save(h, *params, output_dir, n_parts, write_crc != 0, stats, dead_ends_per_iteration);
+  });
+}
+
+int32_t srw_host_alloc(size_t bytes, void **out) {
+  if (!out) return SRW_ERR_INVALID;
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? SRW_ERR_NOMEM : SRW_ERR_HIP; }
+  return SRW_OK;
+}
+void srw_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int32_t srw_fetch_paths(const srw_handle *ch, int32_t *paths, int32_t *lens) {
   srw_handle *h = const_cast<srw_handle *>(ch);

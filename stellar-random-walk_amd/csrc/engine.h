@@ -106,6 +106,12 @@ struct srw_handle {
   srw::DevBuf<srw::DevCounters> counters;
   srw::DevBuf<unsigned long long> shard_counts;  // [world] bucket counters / cursors for srw_shard_step
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // srw_walk_to_host: second stream + two staging buffers for compute/copy overlap
+  hipStream_t copy_stream = nullptr;
+  srw::DevBuf<int32_t> stage_paths[2], stage_lens[2];
+  hipEvent_t stage_done[2] = {nullptr, nullptr}, kernel_done[2] = {nullptr, nullptr};
+  int32_t *pin_paths[2] = {nullptr, nullptr}, *pin_lens[2] = {nullptr, nullptr};  // pinned ring of srw_walk_and_save
+  size_t pin_cap = 0;
 };
 
 namespace srw {
@@ -120,6 +126,17 @@ void parse_edgelist_file(const char *path, bool weighted, bool partitioned, Pars
 // ---- writer.cpp (host) ----
 void write_path_files(const int32_t *paths, const int32_t *lens, int64_t n_walkers, int64_t stride,
                       const char *output_dir, int n_parts, bool write_crc);
+// Incremental form: consecutive slices of the canonical walker order are appended as they arrive from the GPU.
+class PathWriter {
+ public:
+  PathWriter(const char *output_dir, int n_parts, int64_t total_walkers, bool write_crc);  // throws SRW_ERR_EXISTS
+  ~PathWriter();
+  void append(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride);
+  void close();  // finishes the parts, writes _SUCCESS
+ private:
+  struct Impl;
+  Impl *p_;
+};
 
 // ---- graph_build.hip ----
 // Lines already on the device (d_src/d_dst/d_w; d_w may be null = 1.0f).  Builds rows/ent/sids/verts.
@@ -136,6 +153,9 @@ void build_alias_tables(srw_handle *h);
 
 // ---- walk_kernels.hip ----
 void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats);
+void run_walk_to_host(srw_handle *h, const srw_walk_params &P, int32_t *paths, int32_t *lens, srw_walk_stats *stats);
+void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *output_dir, int n_parts, bool write_crc,
+                       srw_walk_stats *stats, int64_t *dead_per_iter);
 void run_shard_seed(srw_handle *h, int32_t iter_in_call, Walker *d_out, int64_t *n_out, int32_t *d_paths,
                     int64_t stride);
 void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32_t step, const Walker *d_in,

@@ -17,13 +17,12 @@ static int getNumOutputPartition(const Params &param) {  // Main.scala:64-69
   return param.singleOutput ? 1 : param.rddPartitions;
 }
 
-static algorithm::Paths doRandomWalk(const Params &param) {  // Main.scala:53-62
+static void doRandomWalk(const Params &param) {  // Main.scala:53-62
   std::unique_ptr<algorithm::RandomWalk> rw;
   if (param.partitioned) rw.reset(new algorithm::VCutRandomWalk(param, &std::cout));
   else rw.reset(new algorithm::UniformRandomWalk(param, &std::cout));
-  algorithm::Paths paths = rw->execute();
-  rw->save(paths, getNumOutputPartition(param), param.output);
-  return paths;
+  // rw.execute() followed by rw.save(paths, n, output), fused: the paths stream GPU -> pinned ring -> part files
+  rw->executeAndSave(getNumOutputPartition(param), param.output);
 }
 
 int main(int argc, char **argv) {

@@ -106,35 +106,62 @@ void VCutRandomWalk::loadGraph() {
 }
 
 Paths RandomWalk::walkImpl(bool useConst, float constR) {
-  Phase ph("randomWalk (kernels + path fetch)");
+  Phase ph("randomWalk (kernels + path transfer, overlapped)");
   Paths out;
   out.stride = config_.walkLength + 2;
   out.n = (int64_t)config_.numWalks * nVertices;
-  out.ids.resize((size_t)out.n * out.stride);
-  out.lens.resize((size_t)out.n);
-  for (int it = 0; it < config_.numWalks; ++it) {               // for (_ <- 0 until config.numWalks), :82
-    srw_walk_params P{};
-    P.p = (float)config_.p; P.q = (float)config_.q;             // .toFloat, :112
-    P.walk_length = config_.walkLength; P.num_walks = 1; P.first_walk = it;
-    P.rng_mode = useConst ? SRW_RNG_CONST : SRW_RNG_PHILOX; P.const_r = constR; P.seed = (uint32_t)config_.seed;
-    P.sampler = (config_.alias && !useConst) ? SRW_SAMPLER_ALIAS : SRW_SAMPLER_REFERENCE;
-    srw_walk_stats st{};
-    check(h_, srw_walk(h_, &P, &st), "randomWalk");
-    check(h_, srw_fetch_paths(h_, out.ids.data() + (size_t)it * nVertices * out.stride,
-                              out.lens.data() + (size_t)it * nVertices), "fetch paths");
-    if (log_) {
+  if (srw_host_alloc((size_t)out.n * out.stride * 4, (void **)&out.ids) != SRW_OK ||
+      srw_host_alloc((size_t)out.n * 4, (void **)&out.lens) != SRW_OK)
+    throw std::runtime_error("cannot allocate pinned host memory for the paths");
+  // for (_ <- 0 until config.numWalks) (:82): all iterations in one call; iteration i's kernel overlaps the PCIe
+  // transfer of iteration i-1
+  srw_walk_params P{};
+  P.p = (float)config_.p; P.q = (float)config_.q;               // .toFloat, :112
+  P.walk_length = config_.walkLength; P.num_walks = config_.numWalks; P.first_walk = 0;
+  P.rng_mode = useConst ? SRW_RNG_CONST : SRW_RNG_PHILOX; P.const_r = constR; P.seed = (uint32_t)config_.seed;
+  P.sampler = (config_.alias && !useConst) ? SRW_SAMPLER_ALIAS : SRW_SAMPLER_REFERENCE;
+  srw_walk_stats st{};
+  check(h_, srw_walk_to_host(h_, &P, out.ids, out.lens, &st), "randomWalk");
+  if (log_) {
+    for (int it = 0; it < config_.numWalks; ++it) {
+      // acc2 ("Zero Neighbors", :117): walkers that hit a dead end inside the second-order loop of this iteration
+      int64_t dead = 0;
+      const int32_t *ln = out.lens + (size_t)it * nVertices;
+      for (int64_t i = 0; i < nVertices; ++i) dead += (ln[i] >= 2 && ln[i] < out.stride);
       *log_ << "Unfinished Walkers: 0\n";                       // :154 (one super-step per iteration on one GPU)
-      if (st.dead_ends) *log_ << "Wrong Transports: 0\n" << "Zero Neighbors: " << st.dead_ends << "\n";  // :155-160
+      if (dead) *log_ << "Wrong Transports: 0\n" << "Zero Neighbors: " << dead << "\n";  // :155-160
     }
   }
   return out;
 }
+void RandomWalk::executeAndSave(int partitions, const std::string &output) {
+  loadGraph();
+  Phase ph("randomWalk + save (kernel / PCIe / format+write pipelined)");
+  srw_walk_params P{};
+  P.p = (float)config_.p; P.q = (float)config_.q;
+  P.walk_length = config_.walkLength; P.num_walks = config_.numWalks; P.first_walk = 0;
+  P.rng_mode = config_.hasConstR ? SRW_RNG_CONST : SRW_RNG_PHILOX; P.const_r = config_.constR; P.seed = (uint32_t)config_.seed;
+  P.sampler = (config_.alias && !config_.hasConstR) ? SRW_SAMPLER_ALIAS : SRW_SAMPLER_REFERENCE;
+  srw_walk_stats st{};
+  std::vector<int64_t> dead((size_t)std::max(config_.numWalks, 1), 0);
+  int32_t rc = srw_walk_and_save(h_, &P, output.c_str(), partitions, config_.crc ? 1 : 0, &st, dead.data());
+  if (rc == SRW_ERR_EXISTS)
+    throw std::runtime_error("org.apache.hadoop.mapred.FileAlreadyExistsException: Output directory " + output + "/" +
+                             common::Property::pathSuffix + " already exists");
+  check(h_, rc, "randomWalk");
+  if (log_)
+    for (int it = 0; it < config_.numWalks; ++it) {
+      *log_ << "Unfinished Walkers: 0\n";
+      if (dead[(size_t)it]) *log_ << "Wrong Transports: 0\n" << "Zero Neighbors: " << dead[(size_t)it] << "\n";
+    }
+}
+
 Paths RandomWalk::randomWalk() { return walkImpl(config_.hasConstR, config_.constR); }
 Paths RandomWalk::randomWalk(float constR) { return walkImpl(true, constR); }
 
 void RandomWalk::save(const Paths &paths, int partitions, const std::string &output) const {
   Phase ph("save (format + write)");
-  int32_t rc = srw_save_paths(paths.ids.data(), paths.lens.data(), paths.n, paths.stride, output.c_str(), partitions,
+  int32_t rc = srw_save_paths(paths.ids, paths.lens, paths.n, paths.stride, output.c_str(), partitions,
                               config_.crc ? 1 : 0);
   if (rc == SRW_ERR_EXISTS)
     throw std::runtime_error("org.apache.hadoop.mapred.FileAlreadyExistsException: Output directory " + output + "/" +

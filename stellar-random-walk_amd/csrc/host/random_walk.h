@@ -22,14 +22,17 @@ namespace algorithm {
 
 using common::Params;
 
-struct Paths {  // RDD[Array[Int]]: n paths of up to stride ids
-  std::vector<int32_t> ids;   // [n][stride], unused tail -1
-  std::vector<int32_t> lens;  // [n]
+struct Paths {  // RDD[Array[Int]]: n paths of up to stride ids, in pinned host memory (srw_host_alloc)
+  int32_t *ids = nullptr;   // [n][stride], unused tail -1
+  int32_t *lens = nullptr;  // [n]
   int64_t n = 0;
   int32_t stride = 0;
-  std::vector<int32_t> path(int64_t i) const {
-    return std::vector<int32_t>(ids.begin() + i * stride, ids.begin() + i * stride + lens[(size_t)i]);
-  }
+  Paths() = default;
+  Paths(const Paths &) = delete;
+  Paths &operator=(const Paths &) = delete;
+  Paths(Paths &&o) noexcept : ids(o.ids), lens(o.lens), n(o.n), stride(o.stride) { o.ids = nullptr; o.lens = nullptr; }
+  ~Paths() { srw_host_free(ids); srw_host_free(lens); }
+  std::vector<int32_t> path(int64_t i) const { return std::vector<int32_t>(ids + i * stride, ids + i * stride + lens[i]); }
 };
 
 // object GraphMap: the per-process adjacency store.  Backed by the handle's CSR in HBM.
@@ -78,6 +81,9 @@ class RandomWalk {  // trait RandomWalk
   Paths randomWalk();
   Paths randomWalk(float constR);
   void save(const Paths &paths, int partitions, const std::string &output) const;  // :234-241
+  // loadGraph + randomWalk + save fused and streamed (what Main.doRandomWalk does, M/Main.scala:53-62), without
+  // materialising the paths on the host
+  void executeAndSave(int partitions, const std::string &output);
   GraphMap graphMap() const { return GraphMap(h_); }
   srw_handle *handle() const { return h_; }
 

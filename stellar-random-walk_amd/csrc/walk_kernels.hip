@@ -446,39 +446,30 @@ void check_params(const srw_walk_params &P) {
 
 }  // namespace
 
-void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
+namespace {
+struct LaunchInfo { int kind; int record_bytes; };
+
+// Enqueue the walk kernel(s) of num_walks iterations starting at P.first_walk into d_paths / d_lens.
+LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walks, int32_t first_walk, int32_t *d_paths,
+                       int32_t *d_lens) {
   Graph &g = h->g;
-  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
-  if (h->cfg.world != 1) throw Error(SRW_ERR_INVALID, "srw_walk needs a whole-graph handle (world == 1); use srw_shard_*");
-  check_params(P);
   hipStream_t st = h->stream;
-  const int64_t n_walkers = (int64_t)P.num_walks * g.n_vertices;
-  if (n_walkers >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "more than 2^31 walkers in one call: lower num_walks");
-  const int32_t stride = P.walk_length + 2;
+  const int64_t n_walkers = (int64_t)num_walks * g.n_vertices;
   const bool alias = P.sampler == SRW_SAMPLER_ALIAS;
   bool first_order_compact = false;
   const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
-  if (first_order) build_first_order_tables(h);
-  if (alias) build_alias_tables(h);
-  h->res.valid = false;
-  h->res.paths.ensure((size_t)n_walkers * stride);
-  h->res.lens.ensure((size_t)n_walkers);
-  h->res.n_walkers = n_walkers; h->res.stride = stride;
-  h->counters.ensure(1);
-  SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
   GraphView gv = g.view();
-  SRW_HIP(hipEventRecord(h->ev0, st));
   if (alias) {
     int64_t blocks = (n_walkers + TPB - 1) / TPB;
     const size_t al_bytes = (size_t)g.n_entries * sizeof(AEnt);
     const bool nt = (P.flags & SRW_WALK_NT_LOADS) ? true : (P.flags & SRW_WALK_CACHED_LOADS) ? false : al_bytes > ((size_t)2 << 30);
     if (nt)
       hipLaunchKernelGGL(k_walk_alias<true>, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
-                         P.walk_length, P.first_walk, P.seed, P.p, P.q, h->res.paths.p, h->res.lens.p, h->counters.p);
+                         P.walk_length, first_walk, P.seed, P.p, P.q, d_paths, d_lens, h->counters.p);
     else
       hipLaunchKernelGGL(k_walk_alias<false>, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
-                         P.walk_length, P.first_walk, P.seed, P.p, P.q, h->res.paths.p, h->res.lens.p, h->counters.p);
+                         P.walk_length, first_walk, P.seed, P.p, P.q, d_paths, d_lens, h->counters.p);
   } else if (first_order) {
     int64_t blocks = (n_walkers + TPB - 1) / TPB;
     // Load policy for the linked records: once the table is far larger than L2 + Infinity Cache (32 + 256 MiB) a
@@ -493,8 +484,7 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
     first_order_compact = compact;
 #define SRW_LAUNCH_FO(NTV, MW, CP)                                                                                  \
   hipLaunchKernelGGL((k_walk_first_order<NTV, MW, CP>), dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p,     \
-                     g.n_vertices, n_walkers, P.walk_length, P.first_walk, rng, h->res.paths.p, h->res.lens.p,      \
-                     h->counters.p)
+                     g.n_vertices, n_walkers, P.walk_length, first_walk, rng, d_paths, d_lens, h->counters.p)
     if (compact) {
       const bool ntc = (P.flags & SRW_WALK_NT_LOADS) ? true : (P.flags & SRW_WALK_CACHED_LOADS) ? false
                        : (size_t)g.n_entries * sizeof(CfoEnt) > ((size_t)2 << 30);
@@ -505,9 +495,41 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   } else {
     int64_t blocks = (n_walkers * 64 + TPB - 1) / TPB;
     hipLaunchKernelGGL(k_walk_general, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
-                       P.walk_length, P.first_walk, rng, P.p, P.q, h->res.paths.p, h->res.lens.p, h->counters.p);
+                       P.walk_length, first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p);
   }
   SRW_HIP(hipGetLastError());
+  LaunchInfo li;
+  li.kind = alias ? 3 : first_order ? 1 : 2;
+  li.record_bytes = first_order_compact ? 16 : (first_order || alias) ? 32 : 0;
+  return li;
+}
+
+void prepare_tables(srw_handle *h, const srw_walk_params &P) {
+  const bool alias = P.sampler == SRW_SAMPLER_ALIAS;
+  const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
+  if (first_order) build_first_order_tables(h);
+  if (alias) build_alias_tables(h);
+}
+}  // namespace
+
+void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
+  Graph &g = h->g;
+  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
+  if (h->cfg.world != 1) throw Error(SRW_ERR_INVALID, "srw_walk needs a whole-graph handle (world == 1); use srw_shard_*");
+  check_params(P);
+  hipStream_t st = h->stream;
+  const int64_t n_walkers = (int64_t)P.num_walks * g.n_vertices;
+  if (n_walkers >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "more than 2^31 walkers in one call: lower num_walks");
+  const int32_t stride = P.walk_length + 2;
+  prepare_tables(h, P);
+  h->res.valid = false;
+  h->res.paths.ensure((size_t)n_walkers * stride);
+  h->res.lens.ensure((size_t)n_walkers);
+  h->res.n_walkers = n_walkers; h->res.stride = stride;
+  h->counters.ensure(1);
+  SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
+  SRW_HIP(hipEventRecord(h->ev0, st));
+  LaunchInfo li = launch_walk(h, P, P.num_walks, P.first_walk, h->res.paths.p, h->res.lens.p);
   SRW_HIP(hipEventRecord(h->ev1, st));
   srw_walk_stats local;
   srw_walk_stats *s = stats ? stats : &local;
@@ -515,9 +537,122 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   read_counters(h, s);
   float ms = 0.f;
   SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  s->kernel_ms = ms; s->n_walkers = n_walkers; s->kernel_kind = alias ? 3 : first_order ? 1 : 2;
-  s->record_bytes = first_order_compact ? 16 : (first_order || alias) ? 32 : 0;   // bytes per table record read
+  s->kernel_ms = ms; s->n_walkers = n_walkers; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
   h->res.valid = true;
+}
+
+// numWalks iterations streamed to the host: kernel of iteration i on the compute stream, D2H of iteration i-1 on the
+// copy stream, two staging buffers; events order "kernel done -> copy" and "copy done -> buffer reuse".
+void run_walk_to_host(srw_handle *h, const srw_walk_params &P, int32_t *paths, int32_t *lens, srw_walk_stats *stats) {
+  Graph &g = h->g;
+  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
+  if (h->cfg.world != 1) throw Error(SRW_ERR_INVALID, "srw_walk_to_host needs a whole-graph handle (world == 1)");
+  check_params(P);
+  hipStream_t st = h->stream;
+  const int64_t nv = g.n_vertices;
+  if (nv >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "too many vertices");
+  const int32_t stride = P.walk_length + 2;
+  prepare_tables(h, P);
+  if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    h->stage_paths[i].ensure((size_t)nv * stride);
+    h->stage_lens[i].ensure((size_t)nv);
+    if (!h->stage_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming));
+    if (!h->kernel_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->kernel_done[i], hipEventDisableTiming));
+  }
+  h->res.valid = false;
+  h->counters.ensure(1);
+  SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
+  SRW_HIP(hipEventRecord(h->ev0, st));
+  LaunchInfo li{0, 0};
+  for (int32_t it = 0; it < P.num_walks; ++it) {
+    const int b = it & 1;
+    if (it >= 2) SRW_HIP(hipStreamWaitEvent(st, h->stage_done[b], 0));           // buffer b was copied out
+    li = launch_walk(h, P, 1, P.first_walk + it, h->stage_paths[b].p, h->stage_lens[b].p);
+    SRW_HIP(hipEventRecord(h->kernel_done[b], st));
+    SRW_HIP(hipStreamWaitEvent(h->copy_stream, h->kernel_done[b], 0));
+    SRW_HIP(hipMemcpyAsync(paths + (size_t)it * nv * stride, h->stage_paths[b].p, (size_t)nv * stride * 4,
+                           hipMemcpyDeviceToHost, h->copy_stream));
+    SRW_HIP(hipMemcpyAsync(lens + (size_t)it * nv, h->stage_lens[b].p, (size_t)nv * 4, hipMemcpyDeviceToHost, h->copy_stream));
+    SRW_HIP(hipEventRecord(h->stage_done[b], h->copy_stream));
+  }
+  SRW_HIP(hipEventRecord(h->ev1, st));
+  SRW_HIP(hipStreamSynchronize(h->copy_stream));
+  srw_walk_stats local;
+  srw_walk_stats *s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  read_counters(h, s);
+  float ms = 0.f;
+  SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  s->kernel_ms = ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
+}
+
+// randomWalk + save fused and streamed (Main.doRandomWalk, M/Main.scala:53-62): the paths never exist as a whole on
+// the host.  Per walk iteration: kernel on the compute stream -> D2H into a pinned ring slot on the copy stream ->
+// the host formats and appends the PREVIOUS iteration's slice to <output>/path/part-* while the GPU works on this one.
+void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *output_dir, int n_parts, bool write_crc,
+                       srw_walk_stats *stats, int64_t *dead_per_iter) {
+  Graph &g = h->g;
+  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
+  if (h->cfg.world != 1) throw Error(SRW_ERR_INVALID, "srw_walk_and_save needs a whole-graph handle (world == 1)");
+  check_params(P);
+  hipStream_t st = h->stream;
+  const int64_t nv = g.n_vertices;
+  const int32_t stride = P.walk_length + 2;
+  PathWriter writer(output_dir, n_parts, (int64_t)P.num_walks * nv, write_crc);   // fails first if <output>/path exists
+  prepare_tables(h, P);
+  if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  const size_t need = (size_t)nv * stride * 4;
+  for (int i = 0; i < 2; ++i) {
+    h->stage_paths[i].ensure((size_t)nv * stride);
+    h->stage_lens[i].ensure((size_t)nv);
+    if (!h->stage_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming));
+    if (!h->kernel_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->kernel_done[i], hipEventDisableTiming));
+    if (h->pin_cap < need) {
+      if (h->pin_paths[i]) (void)hipHostFree(h->pin_paths[i]);
+      if (h->pin_lens[i]) (void)hipHostFree(h->pin_lens[i]);
+      SRW_HIP(hipHostMalloc((void **)&h->pin_paths[i], need ? need : 4, hipHostMallocDefault));
+      SRW_HIP(hipHostMalloc((void **)&h->pin_lens[i], (size_t)nv * 4 + 4, hipHostMallocDefault));
+    }
+  }
+  h->pin_cap = std::max(h->pin_cap, need);
+  h->res.valid = false;
+  h->counters.ensure(1);
+  SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
+  SRW_HIP(hipEventRecord(h->ev0, st));
+  LaunchInfo li{0, 0};
+  auto consume = [&](int32_t it) {      // host side of iteration `it`: wait for its slice, format + append
+    const int b = it & 1;
+    SRW_HIP(hipEventSynchronize(h->stage_done[b]));
+    if (dead_per_iter) {
+      int64_t dead = 0;
+      for (int64_t i = 0; i < nv; ++i) dead += (h->pin_lens[b][i] >= 2 && h->pin_lens[b][i] < stride);
+      dead_per_iter[it] = dead;
+    }
+    writer.append(h->pin_paths[b], h->pin_lens[b], nv, stride);
+  };
+  for (int32_t it = 0; it < P.num_walks; ++it) {
+    const int b = it & 1;
+    // device staging slot b is free once its previous copy finished; the pinned slot b once the host consumed it
+    if (it >= 2) SRW_HIP(hipStreamWaitEvent(st, h->stage_done[b], 0));
+    li = launch_walk(h, P, 1, P.first_walk + it, h->stage_paths[b].p, h->stage_lens[b].p);
+    SRW_HIP(hipEventRecord(h->kernel_done[b], st));
+    if (it >= 2) consume(it - 2);                                   // frees pinned slot b before it is overwritten
+    SRW_HIP(hipStreamWaitEvent(h->copy_stream, h->kernel_done[b], 0));
+    SRW_HIP(hipMemcpyAsync(h->pin_paths[b], h->stage_paths[b].p, need, hipMemcpyDeviceToHost, h->copy_stream));
+    SRW_HIP(hipMemcpyAsync(h->pin_lens[b], h->stage_lens[b].p, (size_t)nv * 4, hipMemcpyDeviceToHost, h->copy_stream));
+    SRW_HIP(hipEventRecord(h->stage_done[b], h->copy_stream));
+  }
+  SRW_HIP(hipEventRecord(h->ev1, st));
+  for (int32_t it = std::max(0, P.num_walks - 2); it < P.num_walks; ++it) consume(it);
+  writer.close();
+  srw_walk_stats local;
+  srw_walk_stats *s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  read_counters(h, s);
+  float ms = 0.f;
+  SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  s->kernel_ms = ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
 }
 
 void run_shard_seed(srw_handle *h, int32_t iter_in_call, Walker *d_out, int64_t *n_out, int32_t *d_paths,

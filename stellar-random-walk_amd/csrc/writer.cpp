@@ -93,23 +93,54 @@ void pwrite_all(int fd, const char *p, size_t n, off_t off, const std::string &f
 
 }  // namespace
 
-void write_path_files(const int32_t *paths, const int32_t *lens, int64_t n_walkers, int64_t stride,
-                      const char *output_dir, int n_parts, bool write_crc) {
-  if (n_parts < 1) n_parts = 1;
-  std::string out(output_dir);
-  mkdir(out.c_str(), 0777);  // the output root may exist
-  std::string dir = out + "/path";
-  if (mkdir(dir.c_str(), 0777) != 0) {
-    if (errno == EEXIST) throw Error(SRW_ERR_EXISTS, "Output directory " + dir + " already exists");
-    throw Error(SRW_ERR_IO, "cannot create " + dir + ": " + strerror(errno));
+// ---- incremental writer: slices of the canonical walker order are appended as they arrive -------------------------
+struct PathWriter::Impl {
+  std::string dir;
+  int n_parts = 1;
+  int64_t total = 0, per = 0, next = 0;     // walkers: total, per part, already written
+  bool write_crc = false;
+  int fd = -1; int cur_part = -1; off_t file_off = 0;
+  std::string crc_tail;                      // bytes of the current part not yet covered by a full 512-byte chunk
+  std::vector<uint32_t> crcs;
+  unsigned hw = 1;
+  std::string part_name(int p) const { char b[32]; snprintf(b, sizeof(b), "part-%05d", p); return b; }
+  void open_part(int p) {
+    close_part();
+    std::string fn = dir + "/" + part_name(p);
+    fd = ::open(fn.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) throw Error(SRW_ERR_IO, "cannot write " + fn);
+    cur_part = p; file_off = 0; crc_tail.clear(); crcs.clear();
   }
-  const int64_t per = (n_walkers + n_parts - 1) / n_parts;
-  unsigned hw = std::thread::hardware_concurrency();
-  if (!hw) hw = 1;
-  for (int part = 0; part < n_parts; ++part) {
-    int64_t b = std::min<int64_t>((int64_t)part * per, n_walkers), e = std::min<int64_t>(b + per, n_walkers);
-    int64_t n = e - b;
-    int nt = (int)std::max<int64_t>(1, std::min<int64_t>(hw, n / 4096 + 1));
+  void crc_feed(const char *p, size_t n) {
+    if (!write_crc) return;
+    size_t i = 0;
+    if (!crc_tail.empty()) {
+      size_t take = std::min(n, 512 - crc_tail.size());
+      crc_tail.append(p, take); i = take;
+      if (crc_tail.size() == 512) { crcs.push_back(crc32_ieee((const unsigned char *)crc_tail.data(), 512)); crc_tail.clear(); }
+    }
+    for (; i + 512 <= n; i += 512) crcs.push_back(crc32_ieee((const unsigned char *)p + i, 512));
+    if (i < n) crc_tail.append(p + i, n - i);
+  }
+  void close_part() {
+    if (fd < 0) return;
+    ::close(fd); fd = -1;
+    if (write_crc) {
+      if (!crc_tail.empty()) crcs.push_back(crc32_ieee((const unsigned char *)crc_tail.data(), crc_tail.size()));
+      std::string fn = dir + "/." + part_name(cur_part) + ".crc";
+      FILE *f = fopen(fn.c_str(), "wb");
+      if (!f) throw Error(SRW_ERR_IO, "cannot write " + fn);
+      const unsigned char hdr[8] = {'c', 'r', 'c', 0, 0, 0, 2, 0};
+      fwrite(hdr, 1, 8, f);
+      for (uint32_t c : crcs) { unsigned char be[4] = {(unsigned char)(c >> 24), (unsigned char)(c >> 16), (unsigned char)(c >> 8), (unsigned char)c}; fwrite(be, 1, 4, f); }
+      fclose(f);
+    }
+  }
+  // append walkers [b, e) of `paths` (local indices) to the currently open part
+  void append_range(const int32_t *paths, const int32_t *lens, int64_t stride, int64_t b, int64_t e) {
+    const int64_t n = e - b;
+    if (n <= 0) return;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(hw, n / 4096 + 1));
     std::vector<Piece> pieces((size_t)nt);
     {
       std::vector<std::thread> th;
@@ -119,38 +150,71 @@ void write_path_files(const int32_t *paths, const int32_t *lens, int64_t n_walke
       }
       for (auto &x : th) x.join();
     }
-    char name[32];
-    snprintf(name, sizeof(name), "part-%05d", part);
-    std::string fn = dir + "/" + name;
-    int fd = open(fn.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd < 0) throw Error(SRW_ERR_IO, "cannot write " + fn);
-    // every piece knows its byte offset once all are formatted: the threads write their pieces concurrently
-    std::vector<off_t> offs((size_t)nt + 1, 0);
+    std::vector<off_t> offs((size_t)nt + 1, file_off);
     for (int t = 0; t < nt; ++t) offs[(size_t)t + 1] = offs[(size_t)t] + (off_t)pieces[(size_t)t].len;
     std::vector<std::string> errs((size_t)nt);
+    const std::string fn = dir + "/" + part_name(cur_part);
     {
       std::vector<std::thread> th;
       for (int t = 0; t < nt; ++t)
         th.emplace_back([&, t] {
           try { pwrite_all(fd, pieces[(size_t)t].buf.get(), pieces[(size_t)t].len, offs[(size_t)t], fn); }
-          catch (const Error &e) { errs[(size_t)t] = e.what(); }
+          catch (const Error &er) { errs[(size_t)t] = er.what(); }
         });
       for (auto &x : th) x.join();
     }
-    close(fd);
-    for (auto &e : errs) if (!e.empty()) throw Error(SRW_ERR_IO, e);
-    if (write_crc) {
-      std::string all;
-      all.reserve((size_t)offs[(size_t)nt]);
-      for (auto &pc : pieces) all.append(pc.buf.get(), pc.len);
-      write_crc_file(dir, name, all);
-    }
+    for (auto &er : errs) if (!er.empty()) throw Error(SRW_ERR_IO, er);
+    file_off = offs[(size_t)nt];
+    for (auto &pc : pieces) crc_feed(pc.buf.get(), pc.len);
   }
-  std::string ok = dir + "/_SUCCESS";
+};
+
+PathWriter::PathWriter(const char *output_dir, int n_parts, int64_t total_walkers, bool write_crc) : p_(new Impl()) {
+  p_->n_parts = n_parts < 1 ? 1 : n_parts;
+  p_->total = total_walkers; p_->write_crc = write_crc;
+  p_->per = (total_walkers + p_->n_parts - 1) / p_->n_parts;
+  p_->hw = std::max(1u, std::thread::hardware_concurrency());
+  std::string out(output_dir);
+  mkdir(out.c_str(), 0777);  // the output root may exist
+  p_->dir = out + "/path";
+  if (mkdir(p_->dir.c_str(), 0777) != 0) {
+    std::string d = p_->dir;
+    delete p_; p_ = nullptr;
+    if (errno == EEXIST) throw Error(SRW_ERR_EXISTS, "Output directory " + d + " already exists");
+    throw Error(SRW_ERR_IO, "cannot create " + d + ": " + strerror(errno));
+  }
+}
+PathWriter::~PathWriter() { if (p_) { if (p_->fd >= 0) ::close(p_->fd); delete p_; } }
+
+void PathWriter::append(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride) {
+  int64_t done = 0;
+  while (done < n) {
+    const int64_t g = p_->next;                                   // global index of the next walker
+    const int part = p_->per > 0 ? (int)std::min<int64_t>(g / p_->per, p_->n_parts - 1) : 0;
+    if (part != p_->cur_part) p_->open_part(part);
+    const int64_t part_end = std::min<int64_t>((int64_t)(part + 1) * p_->per, p_->total);
+    const int64_t take = std::min<int64_t>(n - done, std::max<int64_t>(part_end - g, 1));
+    p_->append_range(paths, lens, stride, done, done + take);
+    done += take; p_->next += take;
+  }
+}
+
+void PathWriter::close() {
+  // parts that received no walker still exist as empty files, as with repartition(n)
+  for (int part = p_->cur_part + 1; part < p_->n_parts; ++part) p_->open_part(part);
+  p_->close_part();
+  std::string ok = p_->dir + "/_SUCCESS";
   FILE *f = fopen(ok.c_str(), "wb");
   if (!f) throw Error(SRW_ERR_IO, "cannot write " + ok);
   fclose(f);
-  if (write_crc) write_crc_file(dir, "_SUCCESS", std::string());
+  if (p_->write_crc) write_crc_file(p_->dir, "_SUCCESS", std::string());
+}
+
+void write_path_files(const int32_t *paths, const int32_t *lens, int64_t n_walkers, int64_t stride,
+                      const char *output_dir, int n_parts, bool write_crc) {
+  PathWriter w(output_dir, n_parts, n_walkers, write_crc);
+  w.append(paths, lens, n_walkers, stride);
+  w.close();
 }
 
 }  // namespace srw

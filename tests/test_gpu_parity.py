@@ -463,3 +463,41 @@ def test_compact_lattice_records(eng, oracle):
     s, d, w = rmat_lines(oracle, 13, edge_factor=16, weighted=True)                     # escapes -> exact records
     eng.load_coo(s, d, w)
     assert eng.walk(walk_length=5, seed=1)[2]["record_bytes"] == 32
+
+
+@pytest.mark.parametrize("p,q,sampler", [(1.0, 1.0, "reference"), (0.25, 4.0, "reference"), (0.25, 4.0, "alias")])
+def test_walk_to_host_overlapped_equals_walk(eng, oracle, p, q, sampler):
+    # srw_walk_to_host (per-iteration kernels, D2H on a second stream, two staging buffers) == srw_walk + fetch
+    s, d, w = rmat_lines(oracle, 11, edge_factor=8, weighted=True)
+    eng.load_coo(s, d, w)
+    a = eng.walk(p=p, q=q, walk_length=20, num_walks=5, first_walk=2, seed=4, sampler=sampler)
+    for pinned in (True, False):
+        b = eng.walk_to_host(pinned=pinned, p=p, q=q, walk_length=20, num_walks=5, first_walk=2, seed=4, sampler=sampler)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert a[2]["n_steps"] == b[2]["n_steps"] and a[2]["kernel_kind"] == b[2]["kernel_kind"]
+
+
+@pytest.mark.parametrize("n_parts,num_walks", [(1, 4), (3, 5), (7, 1)])
+def test_walk_and_save_streamed(eng, oracle, tmp_path, n_parts, num_walks):
+    # fused streaming pipeline == walk + oracle writer, byte for byte (incl. part boundaries inside an iteration)
+    eng.load_edgelist(KARATE, directed=True)
+    g = oracle.Graph.load(KARATE, directed=True)
+    st, dead = eng.walk_and_save(str(tmp_path / "gpu"), n_parts=n_parts, write_crc=True, walk_length=15,
+                                 num_walks=num_walks, seed=9)
+    rp, rl, rs = g.walk(walk_length=15, num_walks=num_walks, seed=9)
+    assert st["n_steps"] == rs
+    assert oracle.write_paths(rp, rl, str(tmp_path / "ref"), n_parts) == 0
+    for k in range(n_parts):
+        name = "part-%05d" % k
+        a = (tmp_path / "gpu" / "path" / name).read_bytes()
+        assert a == (tmp_path / "ref" / "path" / name).read_bytes()
+        crc = (tmp_path / "gpu" / "path" / ("." + name + ".crc")).read_bytes()
+        import zlib
+        assert crc[8:] == b"".join(zlib.crc32(a[o:o + 512]).to_bytes(4, "big") for o in range(0, len(a), 512))
+    assert (tmp_path / "gpu" / "path" / "_SUCCESS").read_bytes() == b""
+    nv = g.num_vertices
+    want_dead = [int(((rl[i * nv:(i + 1) * nv] >= 2) & (rl[i * nv:(i + 1) * nv] < 17)).sum()) for i in range(num_walks)]
+    assert dead == want_dead
+    with pytest.raises(pkg().SrwError) as ei:
+        eng.walk_and_save(str(tmp_path / "gpu"), walk_length=5)
+    assert ei.value.code == pkg().ERR_EXISTS

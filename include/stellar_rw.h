@@ -52,8 +52,14 @@ typedef struct {
   int32_t rank;   /* vertex sharding: this handle stores the rows of vertices v with            */
   int32_t world;  /*   nonNegativeMod(v, world) == rank (HashPartitioner, RandomWalk.scala:16); */
                   /*   world = 1 keeps the whole graph (single-GPU and replicated modes)         */
-  int32_t flags;  /* reserved, 0 */
+  int32_t flags;  /* SRW_CFG_* */
 } srw_config;
+enum {
+  /* sharded handles (world > 1): a vertex is owned by the partition id recorded for it by a partitioned load
+   * (VCutRandomWalk: GraphMap.getPartition(steps.last), M/algorithm/VCutRandomWalk.scala:121-134), modulo world;
+   * vertices without a recorded partition fall back to nonNegativeMod(v, world). */
+  SRW_CFG_OWNER_FROM_PARTITIONS = 1
+};
 
 /* Replaces: SparkContext + GraphMap singleton lifetime (M/Main.scala:21-23, M/algorithm/GraphMap.scala:11). */
 int32_t srw_create(const srw_config *cfg, srw_handle **out);

@@ -48,16 +48,18 @@ void load_lines(srw_handle *h, const int32_t *src, const int32_t *dst, const flo
   SRW_HIP(hipMemcpyAsync(d_dst.p, dst, (size_t)n * 4, hipMemcpyHostToDevice, st));
   if (w) { d_w.alloc((size_t)n); SRW_HIP(hipMemcpyAsync(d_w.p, w, (size_t)n * 4, hipMemcpyHostToDevice, st)); }
   SRW_HIP(hipStreamSynchronize(st));
-  build_graph_from_device_lines(h, d_src.p, d_dst.p, w ? d_w.p : nullptr, n, directed, vmin, vmax);
   // VCut: vertexPartitionMap.put(dst, pId) for every adjacency entry, last put wins (GraphMap.scala:28-32).
-  h->g.part_of.clear();
+  std::vector<int32_t> part_of;
   if (pid) {
-    h->g.part_of.assign((size_t)h->g.n_slots, -1);
+    part_of.assign((size_t)((int64_t)vmax - vmin + 1), -1);
     for (int64_t i = 0; i < n; ++i) {
-      h->g.part_of[(size_t)((int64_t)dst[i] - vmin)] = pid[i];
-      if (!directed) h->g.part_of[(size_t)((int64_t)src[i] - vmin)] = pid[i];
+      part_of[(size_t)((int64_t)dst[i] - vmin)] = pid[i];
+      if (!directed) part_of[(size_t)((int64_t)src[i] - vmin)] = pid[i];
     }
   }
+  build_graph_from_device_lines(h, d_src.p, d_dst.p, w ? d_w.p : nullptr, n, directed, vmin, vmax,
+                                part_of.empty() ? nullptr : part_of.data());
+  h->g.part_of = std::move(part_of);
 }
 }  // namespace
 

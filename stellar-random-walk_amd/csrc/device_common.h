@@ -75,6 +75,7 @@ struct GraphView {
   const double *rsum;   // Mode A: exact weight sum of each alias-regular row
   const Row *mrows;     // membership structure: rows/sids of the WHOLE graph (== rows/sids when world == 1;
   const uint32_t *msids;  //   replicated on every shard so that N(prev) is available wherever curr lives)
+  const int32_t *owner_tab;  // sharded + SRW_CFG_OWNER_FROM_PARTITIONS: partition id per slot (-1 unknown), else null
   int32_t vmin;
   int64_t n_slots;
 };
@@ -118,6 +119,14 @@ __device__ inline float draw_uniform(const RngSpec &rng, uint32_t iter, uint32_t
 __host__ __device__ inline int32_t owner_of(int32_t v, int32_t world) {
   int32_t m = v % world;   // Utils.nonNegativeMod of HashPartitioner (RandomWalk.scala:16)
   return m < 0 ? m + world : m;
+}
+// Owner with an optional partition table (VCut routing: the partition recorded for the vertex, modulo world).
+__host__ __device__ inline int32_t owner_of_tab(int32_t v, int32_t world, const int32_t *tab, int32_t vmin, int64_t n_slots) {
+  if (tab) {
+    int64_t s = (int64_t)v - vmin;
+    if (s >= 0 && s < n_slots && tab[s] >= 0) return tab[s] % world;
+  }
+  return owner_of(v, world);
 }
 
 }  // namespace srw

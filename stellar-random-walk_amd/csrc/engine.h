@@ -68,6 +68,7 @@ struct Graph {
   DevBuf<uint32_t> sids;          // [n_entries] (id - vmin), sorted inside each row
   DevBuf<Row> mrows;              // sharded mode only: row table of the whole graph for the membership test
   DevBuf<uint32_t> msids;         // sharded mode only: sorted ids of the whole graph
+  DevBuf<int32_t> owner_tab;      // sharded + SRW_CFG_OWNER_FROM_PARTITIONS: partition id per slot
   DevBuf<uint32_t> sperm;         // [n_entries] input-order position (inside the row) of each sorted entry
   DevBuf<FoEnt> fo;               // [n_entries], built lazily
   bool has_fo = false;
@@ -80,7 +81,7 @@ struct Graph {
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
   GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_cfo ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
-                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, vmin, n_slots}; }
+                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, owner_tab.p, vmin, n_slots}; }
 };
 
 struct WalkResult {
@@ -141,7 +142,8 @@ class PathWriter {
 // ---- graph_build.hip ----
 // Lines already on the device (d_src/d_dst/d_w; d_w may be null = 1.0f).  Builds rows/ent/sids/verts.
 void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
-                                   int64_t n_lines, bool directed, int32_t vmin, int32_t vmax);
+                                   int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
+                                   const int32_t *host_owner_tab = nullptr);
 void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_t *offs, int64_t n_rows,
                                 const int32_t *ids, const float *w);
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,

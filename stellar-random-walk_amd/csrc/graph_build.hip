@@ -34,7 +34,8 @@ __device__ inline uint64_t pack_ent(int32_t id, float w) {
 __global__ void k_expand(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
                          const float *__restrict__ w, int64_t n_lines, int directed, int32_t vmin, int32_t rank,
                          int32_t world, uint32_t *__restrict__ keys, uint64_t *__restrict__ vals,
-                         uint32_t *__restrict__ present, unsigned long long *owned, uint32_t *__restrict__ gkeys) {
+                         uint32_t *__restrict__ present, unsigned long long *owned, uint32_t *__restrict__ gkeys,
+                         const int32_t *__restrict__ otab, int64_t n_slots) {
   unsigned long long cnt = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_lines; i += (int64_t)gridDim.x * blockDim.x) {
     int32_t s = src[i], d = dst[i];
@@ -42,14 +43,14 @@ __global__ void k_expand(const int32_t *__restrict__ src, const int32_t *__restr
     uint32_t ks = (uint32_t)((int64_t)s - vmin), kd = (uint32_t)((int64_t)d - vmin);
     present[ks] = 1u;
     present[kd] = 1u;
-    bool os = world == 1 || owner_of(s, world) == rank;
+    bool os = world == 1 || owner_of_tab(s, world, otab, vmin, n_slots) == rank;
     if (directed) {
       keys[i] = os ? ks : KEY_SENTINEL;
       vals[i] = pack_ent(d, ww);
       if (gkeys) gkeys[i] = ks;
       cnt += os;
     } else {
-      bool od = world == 1 || owner_of(d, world) == rank;
+      bool od = world == 1 || owner_of_tab(d, world, otab, vmin, n_slots) == rank;
       keys[2 * i] = os ? ks : KEY_SENTINEL;
       vals[2 * i] = pack_ent(d, ww);
       keys[2 * i + 1] = od ? kd : KEY_SENTINEL;
@@ -94,9 +95,9 @@ __global__ void k_local_index(const uint32_t *__restrict__ keys, const Row *__re
 }
 
 __global__ void k_owned_flags(const uint32_t *__restrict__ present, int64_t n_slots, int32_t vmin, int32_t rank,
-                              int32_t world, uint32_t *__restrict__ out) {
+                              int32_t world, const int32_t *__restrict__ otab, uint32_t *__restrict__ out) {
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x)
-    out[v] = (present[v] && owner_of((int32_t)(v + vmin), world) == rank) ? 1u : 0u;
+    out[v] = (present[v] && owner_of_tab((int32_t)(v + vmin), world, otab, vmin, n_slots) == rank) ? 1u : 0u;
 }
 __global__ void k_scatter_verts(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ local_pos,
                                 const uint32_t *__restrict__ global_pos, int64_t n_slots, int32_t vmin,
@@ -248,7 +249,7 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
   if (sharded) {
     lflags.alloc((size_t)g.n_slots); lpos.alloc((size_t)g.n_slots);
     hipLaunchKernelGGL(k_owned_flags, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, present.p, g.n_slots, vmin,
-                       h->cfg.rank, h->cfg.world, lflags.p);
+                       h->cfg.rank, h->cfg.world, (const int32_t *)g.owner_tab.p, lflags.p);
     SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, lflags.p, lpos.p, 0u, (size_t)g.n_slots, rocprim::plus<uint32_t>(), st));
     SRW_HIP(hipMemcpyAsync(&last_pos, lpos.p + (g.n_slots - 1), 4, hipMemcpyDeviceToHost, st));
     SRW_HIP(hipMemcpyAsync(&last_flag, lflags.p + (g.n_slots - 1), 4, hipMemcpyDeviceToHost, st));
@@ -268,7 +269,8 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
 }  // namespace
 
 void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
-                                   int64_t n_lines, bool directed, int32_t vmin, int32_t vmax) {
+                                   int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
+                                   const int32_t *host_owner_tab) {
   if (n_lines <= 0) throw Error(SRW_ERR_INVALID, "empty edge list");
   int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
   if (n_slots <= 0 || n_slots >= (int64_t)0xFFFFFFFEll) throw Error(SRW_ERR_INVALID, "vertex id range too large");
@@ -279,6 +281,10 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
   int64_t n_total = directed ? n_lines : 2 * n_lines;
   g.n_entries_global = n_total;
   bool sharded = h->cfg.world > 1;
+  if (sharded && host_owner_tab && (h->cfg.flags & SRW_CFG_OWNER_FROM_PARTITIONS)) {
+    g.owner_tab.alloc((size_t)n_slots);
+    SRW_HIP(hipMemcpyAsync(g.owner_tab.p, host_owner_tab, (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
+  }
 
   DevBuf<uint32_t> keys, present, gkeys; DevBuf<uint64_t> vals;
   keys.alloc((size_t)n_total); vals.alloc((size_t)n_total); present.alloc((size_t)n_slots);
@@ -288,7 +294,7 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   hipLaunchKernelGGL(k_expand, dim3(grid_for(n_lines)), dim3(TPB), 0, st, d_src, d_dst, d_w, n_lines, directed ? 1 : 0,
                      vmin, h->cfg.rank, h->cfg.world, keys.p, vals.p, present.p, &h->counters.p->owned_entries,
-                     sharded ? gkeys.p : (uint32_t *)nullptr);
+                     sharded ? gkeys.p : (uint32_t *)nullptr, (const int32_t *)g.owner_tab.p, n_slots);
   unsigned long long owned = 0;
   SRW_HIP(hipMemcpyAsync(&owned, &h->counters.p->owned_entries, 8, hipMemcpyDeviceToHost, st));
   SRW_HIP(hipStreamSynchronize(st));

@@ -382,15 +382,15 @@ __global__ __launch_bounds__(TPB) void k_shard_step_fo(GraphView g, const Walker
 
 // pre-pass of the super-step: where will each record go?  (needs the sampled vertex, so the step kernel runs
 // once into a scratch ordering and k_shard_bucket reorders — see run_shard_step)
-__global__ void k_shard_count(const Walker *__restrict__ recs, int64_t n, int32_t world, unsigned long long *counts) {
+__global__ void k_shard_count(GraphView g, const Walker *__restrict__ recs, int64_t n, int32_t world, unsigned long long *counts) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    atomicAdd(&counts[owner_of(recs[i].curr, world)], 1ull);
+    atomicAdd(&counts[owner_of_tab(recs[i].curr, world, g.owner_tab, g.vmin, g.n_slots)], 1ull);
 }
-__global__ void k_shard_bucket(const Walker *__restrict__ recs, int64_t n, int32_t world, unsigned long long *cursors,
+__global__ void k_shard_bucket(GraphView g, const Walker *__restrict__ recs, int64_t n, int32_t world, unsigned long long *cursors,
                                Walker *__restrict__ out) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     Walker w = recs[i];
-    unsigned long long pos = atomicAdd(&cursors[owner_of(w.curr, world)], 1ull);
+    unsigned long long pos = atomicAdd(&cursors[owner_of_tab(w.curr, world, g.owner_tab, g.vmin, g.n_slots)], 1ull);
     out[pos] = w;
   }
 }
@@ -709,14 +709,14 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
     // pass B: bucket by owner(next): count -> exclusive offsets -> scatter
     if (survivors) {
       int gb = (int)std::min<int64_t>(((int64_t)survivors + TPB - 1) / TPB, 8192);
-      hipLaunchKernelGGL(k_shard_count, dim3(gb), dim3(TPB), 0, st, scratch.p, (int64_t)survivors, world, h->shard_counts.p);
+      hipLaunchKernelGGL(k_shard_count, dim3(gb), dim3(TPB), 0, st, g.view(), scratch.p, (int64_t)survivors, world, h->shard_counts.p);
       SRW_HIP(hipMemcpyAsync(counts.data(), h->shard_counts.p, 8 * world, hipMemcpyDeviceToHost, st));
       SRW_HIP(hipStreamSynchronize(st));
       std::vector<unsigned long long> cur((size_t)world, 0ull);
       unsigned long long acc = 0;
       for (int r = 0; r < world; ++r) { cur[r] = acc; acc += counts[r]; }
       SRW_HIP(hipMemcpyAsync(h->shard_counts.p, cur.data(), 8 * world, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_shard_bucket, dim3(gb), dim3(TPB), 0, st, scratch.p, (int64_t)survivors, world, h->shard_counts.p, d_out);
+      hipLaunchKernelGGL(k_shard_bucket, dim3(gb), dim3(TPB), 0, st, g.view(), scratch.p, (int64_t)survivors, world, h->shard_counts.p, d_out);
       SRW_HIP(hipStreamSynchronize(st));
     }
     SRW_HIP(hipGetLastError());

@@ -32,8 +32,8 @@ UNWRITTEN = -(2 ** 31)  # path-slot filler for the MAX-combine (every real id is
 class HipShardEngine:
     """Thin adapter: srw_shard_* on torch CUDA tensors (device pointers), kernels on torch's current stream."""
 
-    def __init__(self, device, rank, world):
-        self.engine = Engine(device=device, rank=rank, world=world)
+    def __init__(self, device, rank, world, owner_from_partitions=False):
+        self.engine = Engine(device=device, rank=rank, world=world, owner_from_partitions=owner_from_partitions)
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
@@ -57,11 +57,12 @@ class HipShardEngine:
 
 
 class ShardedWalker:
-    def __init__(self, device=0, rank=None, world=None, step_engine=None, group=None):
+    def __init__(self, device=0, rank=None, world=None, step_engine=None, group=None, owner_from_partitions=False):
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
-        self.se = step_engine if step_engine is not None else HipShardEngine(device, self.rank, self.world)
+        self.se = step_engine if step_engine is not None else HipShardEngine(device, self.rank, self.world,
+                                                                            owner_from_partitions)
         self.engine = getattr(self.se, "engine", None)
         self.device = self.se.device
 
@@ -74,8 +75,8 @@ class ShardedWalker:
         self.engine.load_edgelist(path, **kw)
         return self
 
-    def load_coo(self, src, dst, w=None, directed=False):
-        self.engine.load_coo(src, dst, w, directed=directed)
+    def load_coo(self, src, dst, w=None, pid=None, directed=False):
+        self.engine.load_coo(src, dst, w, pid=pid, directed=directed)
         return self
 
     # ---- one walk iteration = walk_length + 1 super-steps ----

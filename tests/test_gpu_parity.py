@@ -501,3 +501,56 @@ def test_walk_and_save_streamed(eng, oracle, tmp_path, n_parts, num_walks):
     with pytest.raises(pkg().SrwError) as ei:
         eng.walk_and_save(str(tmp_path / "gpu"), walk_length=5)
     assert ei.value.code == pkg().ERR_EXISTS
+
+
+@pytest.mark.parametrize("world,p,q", [(2, 1.0, 1.0), (3, 0.5, 2.0)])
+def test_sharded_by_user_partitions(oracle, tmp_path, world, p, q):
+    # VCut input (src dst pId [w]): shards own the vertices of "their" partition (SRW_CFG_OWNER_FROM_PARTITIONS);
+    # the walk result must not depend on the partitioning (what T/VCutRandomWalkTest asserts for the reference)
+    import torch
+    from importlib import import_module
+    pkg()
+    sharded = import_module("stellar_random_walk_amd.distributed")
+    rng = np.random.default_rng(4)
+    s, d, w = rmat_lines(oracle, 9, edge_factor=8, weighted=True)
+    pid = rng.integers(0, 5, len(s)).astype(np.int32)                      # 5 user partitions on `world` GPUs
+    f = tmp_path / "vcut.txt"
+    f.write_text("".join("%d %d %d %g\n" % (a, b, c, x) for a, b, c, x in zip(s, d, pid, w)))
+    g = oracle.Graph.load(str(f), partitioned=True)
+    ses = [sharded.HipShardEngine(0, r, world, owner_from_partitions=True) for r in range(world)]
+    for se in ses:
+        se.engine.load_edgelist(str(f), partitioned=True)
+        assert se.engine.stats() == (g.num_vertices, g.num_entries)
+    # ownership follows the recorded partition (last pId seen for the vertex), modulo world
+    owned = [set(se.engine.vertices().tolist()) for se in ses]
+    assert sum(len(o) for o in owned) == g.num_vertices and not (owned[0] & owned[1])
+    for v in list(owned[0])[:50]:
+        assert ses[0].engine.partition(v) % world == 0
+    L, it = 8, 1
+    stride, nv = L + 2, g.num_vertices
+    P = pkg().Engine.params(p=p, q=q, walk_length=L, first_walk=it, seed=33)
+    dev = ses[0].device
+    paths = [torch.full((nv, stride), sharded.UNWRITTEN, dtype=torch.int32, device=dev) for _ in range(world)]
+    cur = [torch.empty((nv, 4), dtype=torch.int32, device=dev) for _ in range(world)]
+    out = [torch.empty((nv, 4), dtype=torch.int32, device=dev) for _ in range(world)]
+    n = [ses[r].seed(0, cur[r], paths[r], stride) for r in range(world)]
+    for step in range(1, L + 2):
+        res = [ses[r].step(P, it, step, cur[r], n[r], out[r], paths[r], stride, world) for r in range(world)]
+        torch.cuda.synchronize()
+        newn = [0] * world
+        for r in range(world):
+            counts, off = res[r][0], 0
+            for dst in range(world):
+                c = counts[dst]
+                cur[dst][newn[dst]:newn[dst] + c] = out[r][off:off + c]
+                newn[dst] += c
+                off += c
+        torch.cuda.synchronize()
+        n = newn
+    full = torch.stack(paths).max(dim=0).values
+    written = full != sharded.UNWRITTEN
+    got = torch.where(written, full, torch.full_like(full, -1)).cpu().numpy()
+    rp, rl, _ = g.walk(p=p, q=q, walk_length=L, first_walk=it, seed=33, threads=8)
+    assert np.array_equal(got, rp) and np.array_equal(written.sum(dim=1).cpu().numpy().astype(np.int32), rl)
+    for se in ses:
+        se.engine.close()

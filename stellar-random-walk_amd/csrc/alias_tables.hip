@@ -125,7 +125,7 @@ __global__ __launch_bounds__(TPB) void k_alias_build(Row *rows, const Ent *__res
     if (!regular) {
       for (int32_t k = tid; k < n; k += TPB) {
         Ent e = row[k];
-        AEnt a; a.prob = 1.0f; a.alias = k; a.id = e.id; a.w = e.w; a.noff = 0; a.ndeg = 0; a.nflags = 0;
+        AEnt a; a.prob = 1.0f; a.alias = k; a.id = e.id; a.wrev = __int_as_float(0x7FC00000); a.noff = 0; a.ndeg = 0; a.nflags = 0;
         out[k] = a;
       }
       if (tid == 0) rows[v].flags = r.flags | ROW_ALIAS_IRREGULAR;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(TPB) void k_alias_build(Row *rows, const Ent *__res
       const uint32_t k = idx[i];
       Ent e = row[k];
       unsigned long long m = weight_to_int(e.w, emin) * (unsigned long long)n;
-      AEnt o; o.prob = (float)((double)m / (double)T); o.alias = (int32_t)idx[n - 1 - lo]; o.id = e.id; o.w = e.w;
+      AEnt o; o.prob = (float)((double)m / (double)T); o.alias = (int32_t)idx[n - 1 - lo]; o.id = e.id; o.wrev = __int_as_float(0x7FC00000);
       o.noff = 0; o.ndeg = 0; o.nflags = 0;
       out[k] = o;
     }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(TPB) void k_alias_build(Row *rows, const Ent *__res
       while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (de[mid] <= ej) lo = mid + 1; else hi = mid; }
       const uint32_t k = idx[n - 1 - j];
       Ent e = row[k];
-      AEnt o; o.id = e.id; o.w = e.w; o.noff = 0; o.ndeg = 0; o.nflags = 0;
+      AEnt o; o.id = e.id; o.wrev = __int_as_float(0x7FC00000); o.noff = 0; o.ndeg = 0; o.nflags = 0;
       if (lo < a && (lo ? de[lo - 1] : (u128)0) < ej) {   // that light started inside this heavy's excess interval
         unsigned long long x = (unsigned long long)(de[lo] - ej);
         o.prob = (float)((double)(T - x) / (double)T); o.alias = (int32_t)idx[n - 1 - (j + 1)];
@@ -193,13 +193,38 @@ __global__ __launch_bounds__(TPB) void k_alias_build(Row *rows, const Ent *__res
   }
 }
 
-__global__ void k_alias_link(const Row *__restrict__ rows, AEnt *__restrict__ al, int64_t n_entries, int32_t vmin,
-                             int64_t n_slots) {
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_entries; e += (int64_t)gridDim.x * blockDim.x) {
-    int64_t s = (int64_t)al[e].id - vmin;
-    Row r; r.off = 0; r.deg = 0; r.flags = 0;
-    if (s >= 0 && s < n_slots) r = rows[s];
-    al[e].noff = r.off; al[e].ndeg = r.deg; al[e].nflags = r.flags;
+// Link pass: the neighbor's row descriptor, and the total weight of the reverse edge(s) id -> row vertex (the W_prev of
+// the next step's outlier folding), summed in f64 in input order exactly as the walk would; stored only when f32-exact.
+__global__ void k_alias_link(const Row *__restrict__ rows, const Ent *__restrict__ ent, const uint32_t *__restrict__ sids,
+                             const uint32_t *__restrict__ sperm, AEnt *__restrict__ al, int64_t n_slots, int32_t vmin,
+                             unsigned long long *next_slot) {
+  const int lane = lane_id();
+  while (true) {                                   // dynamic row hand-out (RMAT hubs would pile up on a fixed stride)
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(next_slot, 4ull);
+    grab = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab);
+    if ((int64_t)grab >= n_slots) break;
+    for (int64_t v = (int64_t)grab; v < (int64_t)grab + 4 && v < n_slots; ++v) {
+      const Row r = rows[v];
+      const uint32_t me = (uint32_t)v;              // (this vertex id) - vmin
+      for (int32_t k = lane; k < r.deg; k += 64) {
+        AEnt a = al[r.off + k];
+        int64_t s = (int64_t)a.id - vmin;
+        Row nr; nr.off = 0; nr.deg = 0; nr.flags = 0;
+        if (s >= 0 && s < n_slots) nr = rows[s];
+        // reverse edges: equal range of `me` in the sorted row of the neighbor
+        const uint32_t *cs = sids + nr.off;
+        int32_t lo = 0, hi = nr.deg;
+        while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < me) lo = mid + 1; else hi = mid; }
+        double wsum = 0.0;
+        for (int32_t c = lo; c < nr.deg && cs[c] == me; ++c) wsum += (double)ent[nr.off + sperm[nr.off + c]].w;
+        const float wf = (float)wsum;
+        a.wrev = ((double)wf == wsum) ? wf : __int_as_float(0x7FC00000);
+        a.noff = nr.off; a.ndeg = nr.deg; a.nflags = nr.flags;
+        al[r.off + k] = a;
+      }
+    }
   }
 }
 
@@ -219,8 +244,9 @@ void build_alias_tables(srw_handle *h) {
   hipLaunchKernelGGL(k_alias_build, dim3(256 * 4), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.al.p, g.rsum.p, g.n_slots, g_idx.p,
                      g_de.p, next_slot.p);
   if (g.n_entries > 0) {
-    int ge = (int)std::min<int64_t>((g.n_entries + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(k_alias_link, dim3(ge), dim3(256), 0, st, g.rows.p, g.al.p, g.n_entries, g.vmin, g.n_slots);
+    SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
+    hipLaunchKernelGGL(k_alias_link, dim3(256 * 8), dim3(256), 0, st, g.rows.p, g.ent.p, g.sids.p, g.sperm.p, g.al.p, g.n_slots,
+                       g.vmin, next_slot.p);
   }
   SRW_HIP(hipGetLastError());
   SRW_HIP(hipStreamSynchronize(st));

@@ -54,7 +54,8 @@ struct alignas(32) AEnt {
   float prob;    // P(keep slot k | slot k drawn) = kept_k / T, exact-integer construction (alias_tables.hip)
   int32_t alias; // position (inside the row) used otherwise
   int32_t id;
-  float w;
+  float wrev;    // total weight of the edge(s) id -> (this row's vertex) when exactly representable in f32 (it is the
+                 // return-edge weight W_prev of the NEXT step's outlier folding); NaN = look it up at walk time
   int64_t noff;
   int32_t ndeg;
   uint32_t nflags;
@@ -75,6 +76,7 @@ struct GraphView {
   const double *rsum;   // Mode A: exact weight sum of each alias-regular row
   const Row *mrows;     // membership structure: rows/sids of the WHOLE graph (== rows/sids when world == 1;
   const uint32_t *msids;  //   replicated on every shard so that N(prev) is available wherever curr lives)
+  int32_t symmetric;    // 1: undirected load (x in N(y) <=> y in N(x)): membership may probe the shorter row
   const int32_t *owner_tab;  // sharded + SRW_CFG_OWNER_FROM_PARTITIONS: partition id per slot (-1 unknown), else null
   int32_t vmin;
   int64_t n_slots;

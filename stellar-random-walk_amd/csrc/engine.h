@@ -59,6 +59,7 @@ struct Graph {
   int32_t vmin = 0, vmax = -1;
   int64_t n_slots = 0;
   int64_t n_lines = 0;
+  bool symmetric = false;         // built from an undirected edge list
   int64_t n_entries_global = 0;   // "edges: N" of the whole graph
   int64_t n_entries = 0;          // entries stored on this handle (== global when world == 1)
   int64_t n_vertices = 0;         // present vertices of the whole graph
@@ -81,7 +82,7 @@ struct Graph {
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
   GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_cfo ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
-                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, owner_tab.p, vmin, n_slots}; }
+                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, symmetric ? 1 : 0, owner_tab.p, vmin, n_slots}; }
 };
 
 struct WalkResult {

@@ -278,6 +278,7 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
   Graph &g = h->g;
   g = Graph();
   g.n_lines = n_lines;
+  g.symmetric = !directed;
   int64_t n_total = directed ? n_lines : 2 * n_lines;
   g.n_entries_global = n_total;
   bool sharded = h->cfg.world > 1;

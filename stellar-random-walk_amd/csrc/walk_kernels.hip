@@ -187,7 +187,7 @@ __device__ inline AEnt load_al(const AEnt *p) {
     const int4v *q = reinterpret_cast<const int4v *>(p);
     int4v a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
     AEnt e;
-    e.prob = __int_as_float(a.x); e.alias = a.y; e.id = a.z; e.w = __int_as_float(a.w);
+    e.prob = __int_as_float(a.x); e.alias = a.y; e.id = a.z; e.wrev = __int_as_float(a.w);
     e.noff = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
     e.ndeg = b.z; e.nflags = (uint32_t)b.w;
     return e;
@@ -219,7 +219,8 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
     const bool biased_cfg = !(p == 1.0f && q == 1.0f);
     int32_t s = 1; uint32_t t = 0;
     // outlier folding state of the current step (valid while t > 0)
-    bool fold = false; double fa = 0.0, ftot = 0.0, fw = 0.0; int32_t flo = 0, fhi = 0;
+    bool fold = false; double fa = 0.0, ftot = 0.0, fw = 0.0; int32_t flo = -1, fhi = -1;
+    float wprev_hint = __int_as_float(0x7FC00000);   // W_prev carried by the record that led here (NaN: unknown)
     while (s <= L + 1) {
       if (rc.deg == 0) { if (s > 1) ++dead; break; }
       const bool second = s > 1, biased = second && biased_cfg;
@@ -237,13 +238,18 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
         if (t == 0) {            // once per step: does the return edge stick out of the envelope?
           fold = false;
           if (biased && inv_p > Q) {
-            // occurrences of prev in N(curr): equal range in the sorted row; weights in input order via sperm
-            const uint32_t *cs = g.sids + rc.off;
-            const uint32_t x = (uint32_t)((int64_t)prev - g.vmin);
-            int32_t lo = 0, hi = rc.deg;
-            while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < x) lo = mid + 1; else hi = mid; }
-            flo = lo; fhi = lo; fw = 0.0;
-            while (fhi < rc.deg && cs[fhi] == x) { fw += (double)g.ent[rc.off + g.sperm[rc.off + fhi]].w; ++fhi; }
+            flo = -1; fhi = -1;
+            if (wprev_hint == wprev_hint) {
+              fw = (double)wprev_hint;          // exact: precomputed at build time with the same f64 sum
+            } else {
+              // occurrences of prev in N(curr): equal range in the sorted row; weights in input order via sperm
+              const uint32_t *cs = g.sids + rc.off;
+              const uint32_t x = (uint32_t)((int64_t)prev - g.vmin);
+              int32_t lo = 0, hi = rc.deg;
+              while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < x) lo = mid + 1; else hi = mid; }
+              flo = lo; fhi = lo; fw = 0.0;
+              while (fhi < rc.deg && cs[fhi] == x) { fw += (double)g.ent[rc.off + g.sperm[rc.off + fhi]].w; ++fhi; }
+            }
             if (fw > 0.0) {
               const double S = g.rsum[(int64_t)curr - g.vmin];
               fa = ((double)inv_p - (double)Q) * fw; ftot = (double)Q * S + fa; fold = true;
@@ -257,6 +263,14 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
           const float u5 = (float)(y[0] >> 8) * (1.0f / 16777216.0f);
           if ((double)u5 * ftot < fa) {       // appendix: return to prev; occurrence ~ w in input order
             appendix = true;
+            if (flo < 0) {                      // the occurrences were not needed until now: find them
+              const uint32_t *cs = g.sids + rc.off;
+              const uint32_t x = (uint32_t)((int64_t)prev - g.vmin);
+              int32_t lo = 0, hi = rc.deg;
+              while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < x) lo = mid + 1; else hi = mid; }
+              flo = lo; fhi = lo;
+              while (fhi < rc.deg && cs[fhi] == x) ++fhi;
+            }
             const float u6 = (float)(y[1] >> 8) * (1.0f / 16777216.0f);
             const double target = (double)u6 * fw;
             double cum = 0.0; int32_t pos = g.sperm[rc.off + flo];
@@ -278,7 +292,15 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
           if (biased) {
             float bias = inv_q;
             if (e.id == prev) bias = inv_p;
-            else if (sorted_contains(g.sids + rp.off, rp.deg, (uint32_t)((int64_t)e.id - g.vmin))) bias = 1.0f;
+            else {
+              // x in N(prev)?  On an undirected load this equals prev in N(x): probe the shorter sorted row
+              bool in;
+              if (g.symmetric && e.ndeg < rp.deg)
+                in = sorted_contains(g.sids + e.noff, e.ndeg, (uint32_t)((int64_t)prev - g.vmin));
+              else
+                in = sorted_contains(g.sids + rp.off, rp.deg, (uint32_t)((int64_t)e.id - g.vmin));
+              if (in) bias = 1.0f;
+            }
             const float u3 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
             accepted = (u3 * Q < bias) || (t + 1u >= 65536u);
           }
@@ -286,6 +308,7 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
       }
       if (accepted) {
         path[s] = e.id;
+        wprev_hint = e.wrev;
         prev = curr; rp = rc; curr = e.id;
         rc.off = e.noff; rc.deg = e.ndeg; rc.flags = e.nflags;
         ++s; ++len; t = 0;

@@ -116,7 +116,8 @@ enum {
   SRW_WALK_FORCE_GENERAL = 1, /* use the general second-order kernel even when p == q == 1 (testing) */
   SRW_WALK_NT_LOADS = 2,      /* first-order kernel: force L1-bypassing (nontemporal) record loads */
   SRW_WALK_CACHED_LOADS = 4,  /* first-order kernel: force default-policy loads (default: chosen from the table size) */
-  SRW_WALK_NO_COMPACT = 16    /* first-order kernel: do not use the 16-byte lattice records even when available */
+  SRW_WALK_NO_COMPACT = 16,   /* first-order kernel: do not use the 16-byte lattice records even when available */
+  SRW_WALK_NO_PREFIX = 32     /* general kernel: always stream N(curr); do not use the exact prefix-sum search */
 };
 
 typedef struct {
@@ -125,7 +126,7 @@ typedef struct {
   int64_t dead_ends;    /* "Zero Neighbors" accumulator, RandomWalk.scala:117 */
   int64_t sum_deg_curr; /* general kernel: sum of deg(curr) over steps (algorithmic bytes) */
   int64_t sum_deg_prev; /* general kernel: sum of deg(prev) over second-order steps with q != 1 */
-  int64_t ent_reads;    /* first-order kernel: CDF records read */
+  int64_t ent_reads;    /* first-order / alias kernels: table records read; general kernel: steps served by the prefix search */
   int64_t fallbacks;    /* steps that needed the exact sequential fallback */
   int64_t trials;       /* Mode A: alias draws (accepted + rejected) */
   double kernel_ms;     /* hipEvent time of the walk kernels of this call, on the handle's stream */

@@ -76,6 +76,8 @@ struct GraphView {
   const double *rsum;   // Mode A: exact weight sum of each alias-regular row
   const Row *mrows;     // membership structure: rows/sids of the WHOLE graph (== rows/sids when world == 1;
   const uint32_t *msids;  //   replicated on every shard so that N(prev) is available wherever curr lives)
+  const double *pq;     // per-call exact prefix sums of the base weights fl(w / q) inside each row (null if not built)
+  const uint8_t *pq_ok; // per slot: row certified for the prefix-sum sampler under the call's (p, q)
   int32_t symmetric;    // 1: undirected load (x in N(y) <=> y in N(x)): membership may probe the shorter row
   const int32_t *owner_tab;  // sharded + SRW_CFG_OWNER_FROM_PARTITIONS: partition id per slot (-1 unknown), else null
   int32_t vmin;

@@ -76,13 +76,16 @@ struct Graph {
   DevBuf<CfoEnt> cfo;             // [n_entries] compact lattice records (optional)
   bool has_cfo = false;
   DevBuf<AEnt> al;                // [n_entries] Mode A alias records, built lazily
+  DevBuf<double> pq;              // [n_entries] per-(p,q) exact base prefix sums (general kernel fast path)
+  DevBuf<uint8_t> pq_ok;          // [n_slots]
+  bool has_pq = false; uint32_t pq_pbits = 0, pq_qbits = 0;
   DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
   bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
   GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_cfo ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
-                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, symmetric ? 1 : 0, owner_tab.p, vmin, n_slots}; }
+                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, symmetric ? 1 : 0, owner_tab.p, vmin, n_slots}; }
 };
 
 struct WalkResult {
@@ -150,6 +153,7 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,
                          DevBuf<int32_t> &d_src, DevBuf<int32_t> &d_dst, DevBuf<float> &d_w);
 void build_first_order_tables(srw_handle *h);
+void build_pq_tables(srw_handle *h, float p, float q);
 
 // ---- alias_tables.hip ----
 void build_alias_tables(srw_handle *h);

@@ -175,6 +175,8 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
   g.cfo.release();
   g.has_al = false;
   g.al.release();
+  g.has_pq = false;
+  g.pq.release();
 
   // 1. stable sort of the entry stream by owning vertex
   DevBuf<uint32_t> keys2; DevBuf<uint64_t> vals2; DevBuf<char> temp;

@@ -12,6 +12,8 @@
 // 0 < S < inf), so scanning forward from guide[j] finds exactly that index.
 // Rows with a negative / NaN weight or a non-positive / non-finite sum are flagged ROW_IRREGULAR and
 // sampled by the literal sequential scan.
+#include <cstring>
+
 #include "engine.h"
 #include "sampling.h"
 
@@ -276,7 +278,97 @@ __global__ void k_cfo_large(const Row *__restrict__ rows, const FoEnt *__restric
   }
 }
 
+// ---- per-call exact prefix sums of the base weights fl(w / q) (general kernel, prefix-sum sampler) ---------------
+// A row qualifies when every variant a candidate can take — fl(w/q), w, fl(w/p) — is finite and >= 0 and the
+// exactness certificate holds over ALL of them: then every sum of any selection of variants, in any order, is exact.
+struct PqCert {
+  int emin, emax; bool bad;
+  __device__ PqCert() : emin(1 << 20), emax(-(1 << 20)), bad(false) {}
+  __device__ inline void add(float x) {
+    uint32_t b = __float_as_uint(x);
+    int ex = (int)((b >> 23) & 0xFFu);
+    if (ex == 255 || (b >> 31 && (b & 0x7FFFFFFFu))) { bad = true; return; }
+    if ((b & 0x7FFFFFFFu) == 0u) return;
+    int e = ex ? ex - 127 : -126;
+    emin = min(emin, e); emax = max(emax, e);
+  }
+};
+__device__ inline bool pq_row_ok(int emin, int emax, bool bad, int32_t n) {
+  if (bad) return false;
+  if (emax < emin) return false;                      // all-zero row: leave it to the literal sampler
+  return ceil_log2_i64(n) + 2 + emax - emin <= 29;    // +2: headroom for sums of differences of variants
+}
+
+__global__ void k_pq_small(const Row *__restrict__ rows, const Ent *__restrict__ ent, double *__restrict__ pq,
+                           uint8_t *__restrict__ ok, int64_t n_slots, float p, float q) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
+    Row r = rows[v];
+    ok[v] = 0;
+    if (r.deg <= 0 || r.deg > SMALL_DEG) continue;
+    PqCert c;
+    for (int32_t k = 0; k < r.deg; ++k) { float w = ent[r.off + k].w; c.add(w); c.add(w / q); c.add(w / p); }
+    if (!pq_row_ok(c.emin, c.emax, c.bad, r.deg)) continue;
+    double acc = 0.0;
+    for (int32_t k = 0; k < r.deg; ++k) { acc += (double)(ent[r.off + k].w / q); pq[r.off + k] = acc; }
+    ok[v] = 1;
+  }
+}
+
+__global__ void k_pq_large(const Row *__restrict__ rows, const Ent *__restrict__ ent, double *__restrict__ pq,
+                           uint8_t *__restrict__ ok, int64_t n_slots, float p, float q, unsigned long long *next_slot) {
+  const int lane = lane_id();
+  while (true) {
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(next_slot, 4ull);
+    grab = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab);
+    if ((int64_t)grab >= n_slots) break;
+    for (int64_t v = (int64_t)grab; v < (int64_t)grab + 4 && v < n_slots; ++v) {
+      Row r = rows[v];
+      if (r.deg <= SMALL_DEG) continue;
+      const Ent *row = ent + r.off;
+      PqCert c;
+      for (int32_t k = lane; k < r.deg; k += 64) { float w = row[k].w; c.add(w); c.add(w / q); c.add(w / p); }
+      int emin = wave_min_i32(c.emin), emax = wave_max_i32(c.emax);
+      bool bad = __any(c.bad);
+      if (!pq_row_ok(emin, emax, bad, r.deg)) continue;              // ok[v] stays 0 (set by k_pq_small)
+      double carry = 0.0;                                            // exact sums: any order gives the same bits
+      for (int32_t base = 0; base < r.deg; base += 64) {
+        int32_t k = base + lane;
+        double x = k < r.deg ? (double)(row[k].w / q) : 0.0;
+        for (int o = 1; o < 64; o <<= 1) { double t = __shfl_up(x, o); if (lane >= o) x += t; }
+        if (k < r.deg) pq[r.off + k] = carry + x;
+        carry += readlane_f64(x, 63);
+      }
+      if (lane == 0) ok[v] = 1;
+    }
+  }
+}
+
 }  // namespace
+
+void build_pq_tables(srw_handle *h, float p, float q) {
+  Graph &g = h->g;
+  uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);
+  if (g.has_pq && g.pq_pbits == pb && g.pq_qbits == qb) return;
+  hipStream_t st = h->stream;
+  g.has_pq = false;
+  size_t free_b = 0, total_b = 0;
+  SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+  const size_t need = (size_t)g.n_entries * sizeof(double) + (size_t)g.n_slots;
+  if (g.pq.n < (size_t)g.n_entries && free_b < need + ((size_t)8 << 30)) return;   // optional structure: skip when tight
+  g.pq.ensure((size_t)g.n_entries);
+  g.pq_ok.ensure((size_t)g.n_slots);
+  int gs = (int)std::min<int64_t>(std::max<int64_t>((g.n_slots + 255) / 256, 1), 256 * 32);
+  DevBuf<unsigned long long> next_slot; next_slot.alloc(1);
+  SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
+  hipLaunchKernelGGL(k_pq_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.ent.p, g.pq.p, g.pq_ok.p, g.n_slots, p, q);
+  hipLaunchKernelGGL(k_pq_large, dim3(256 * 8), dim3(256), 0, st, g.rows.p, g.ent.p, g.pq.p, g.pq_ok.p, g.n_slots, p, q,
+                     next_slot.p);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipStreamSynchronize(st));
+  g.pq_pbits = pb; g.pq_qbits = qb; g.has_pq = true;
+}
 
 void build_first_order_tables(srw_handle *h) {
   Graph &g = h->g;

@@ -336,4 +336,105 @@ __device__ inline int32_t wave_pick_scan(const GraphView &g, const Row &rc, cons
   return 0;  // edges.head (:24)
 }
 
+// ---- exact pick by SEARCH over exact prefix sums (general p, q; large rows) --------------------------------------
+// Under the row certificate of sampler_tables.hip:k_pq_* every sum of candidate variants is exact, so
+//   A'_k = sum_{i<=k} w'_i = PQ[k] + sum over the "special" positions <= k of (w'_i - fl(w_i/q))
+// is exact, where PQ is the per-call prefix sum of the base weights fl(w/q) and the specials are the return edges
+// (w' = fl(w/p)) and the members of N(prev) (w' = w) — found by looking the few elements of N(prev) up in the sorted
+// N(curr).  S = A'_{deg-1} is the reference's sum bit for bit.  The reference's acc_k = sum of fl(w'_i/S) differs from
+// X_k = A'_k / S by at most (k+2) u X_k (one rounding per quotient + the summation), so with
+// tol_k = (k+8) 2^-51 X_k the first k that is not a certain miss (X_k + tol_k < p) is found by a 64-ary search
+// (X, tol non-decreasing), and if it is a certain hit (X_k - tol_k >= p) it IS the reference's answer; otherwise the
+// step is redone with the sequential chain.  Cost: O(|N(prev)| log deg + |specials| log_64 deg) instead of O(deg).
+constexpr int SP_CAP = 512;   // specials kept in the wave's LDS scratch: pos[512] | corr[512] (f64) | counter
+
+__device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
+                                           uint32_t *lds, float r, unsigned &fallback, unsigned &served) {
+  if (!g.pq || !b.second_order) return -1;
+  const int32_t deg = rc.deg;
+  if (deg < 128 || !g.pq_ok[curr_slot]) return -1;
+  const int lc = 32 - __clz(deg | 1);
+  if (b.need_member && (int64_t)b.prev_deg * (lc + 2) > (int64_t)deg * 2) return -1;   // marking would cost more than streaming
+  const int lane = lane_id();
+  uint32_t *sp_pos = lds;
+  double *sp_corr = reinterpret_cast<double *>(lds + SP_CAP);
+  uint32_t *counter = lds + 3 * SP_CAP;
+  if (lane == 0) *counter = 0u;
+  __builtin_amdgcn_wave_barrier();
+  const Ent *row = g.ent + rc.off;
+  const uint32_t *cs = g.sids + rc.off, *cp = g.sperm + rc.off;
+  const uint32_t xprev = (uint32_t)((int64_t)b.prev - b.vmin);
+  // (a) return edges: occurrences of prev in N(curr)
+  {
+    int32_t lo = 0, hi = deg;
+    while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < xprev) lo = mid + 1; else hi = mid; }
+    for (int32_t c = lo + lane; c < deg && cs[c] == xprev; c += 64) {
+      const uint32_t orig = cp[c];
+      const float w = row[orig].w;
+      const uint32_t idx = atomicAdd(counter, 1u);
+      if (idx < (uint32_t)SP_CAP) { sp_pos[idx] = orig; sp_corr[idx] = (double)(w / b.p) - (double)(w / b.q); }
+    }
+  }
+  // (b) members of N(prev) (only matter when q != 1)
+  if (b.need_member) {
+    for (int32_t t = lane; t < b.prev_deg; t += 64) {
+      const uint32_t x = b.prev_sids[t];
+      if (x == xprev || (t > 0 && b.prev_sids[t - 1] == x)) continue;
+      int32_t lo = 0, hi = deg;
+      while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < x) lo = mid + 1; else hi = mid; }
+      for (int32_t c = lo; c < deg && cs[c] == x; ++c) {
+        const uint32_t orig = cp[c];
+        const float w = row[orig].w;
+        const uint32_t idx = atomicAdd(counter, 1u);
+        if (idx < (uint32_t)SP_CAP) { sp_pos[idx] = orig; sp_corr[idx] = (double)w - (double)(w / b.q); }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t n_sp = *counter;
+  if (n_sp > (uint32_t)SP_CAP) return -1;          // too many specials for the scratch: streaming scan instead
+  double csum = 0.0;
+  for (uint32_t j = lane; j < n_sp; j += 64) csum += sp_corr[j];
+  csum = wave_sum_f64(csum);                       // exact under the certificate
+  const double *PQ = g.pq + rc.off;
+  const double S = PQ[deg - 1] + csum;
+  const double p = (double)r;
+  auto not_miss = [&](int32_t k, bool &hit) {
+    double a = PQ[k];
+    for (uint32_t j = 0; j < n_sp; ++j) a += (sp_pos[j] <= (uint32_t)k) ? sp_corr[j] : 0.0;   // LDS broadcast reads
+    const double X = a / S;
+    const double tol = (double)(k + 8) * 0x1p-51 * X;
+    hit = X - tol >= p;
+    return !(X + tol < p);
+  };
+  int32_t lo = 0, hi = deg - 1;                    // the first not-certain-miss index, if any, lies in [lo, hi]
+  bool hit = false;
+  while (hi - lo >= 64) {
+    const int64_t span = (int64_t)hi - lo;
+    const int32_t k = lo + (int32_t)((span * (lane + 1)) >> 6);          // lane 63 probes hi
+    bool h;
+    const bool nm = not_miss(k, h);
+    const unsigned long long m = __ballot(nm);
+    if (!m) return 0;                               // even k = hi is a certain miss: no crossing -> edges.head
+    const int f = __ffsll((long long)m) - 1;
+    const int32_t kf = __builtin_amdgcn_readlane(k, f);
+    const int32_t kprev = f ? __builtin_amdgcn_readlane(k, f - 1) : lo - 1;
+    hi = kf; lo = kprev + 1;
+  }
+  {
+    const int32_t k = lo + lane;
+    bool h = false, nm = false;
+    if (k <= hi) nm = not_miss(k, h);
+    const unsigned long long m = __ballot(nm);
+    if (!m) return 0;
+    const int f = __ffsll((long long)m) - 1;
+    hit = __builtin_amdgcn_readlane((int)h, f) != 0;
+    const int32_t kf = lo + f;
+    served = 1;
+    if (hit) return kf;
+  }
+  fallback = 1;
+  return wave_chain_pick(row, deg, b, r, S);
+}
+
 }  // namespace srw

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
                                                       int32_t first_walk, RngSpec rng, float p, float q,
                                                       int32_t *__restrict__ paths, int32_t *__restrict__ lens,
                                                       DevCounters *ctr) {
-  __shared__ uint32_t bitmap[TPB / 64][BM_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BM_WORDS];
   const int lane = lane_id();
   const int64_t wi = (blockIdx.x * (int64_t)TPB + threadIdx.x) >> 6;  // one wave per walker
   if (wi >= n_walkers) return;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
   int32_t *path = paths + wi * stride;
   if (lane == 0) path[0] = src;
   int32_t prev = src, curr = src, len = 1;
-  unsigned long long degc = 0, degp = 0, fb = 0, dead = 0;
+  unsigned long long degc = 0, degp = 0, fb = 0, dead = 0, fast = 0;
   for (int32_t s = 1; s <= L + 1; ++s) {
     const Row *rp = row_of(g, curr);
     Row r; r.off = 0; r.deg = 0; r.flags = 0;
@@ -155,10 +155,12 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
     if (r.deg == 0) { dead = s > 1; break; }
     Bias b = make_bias(g, p, q, prev, s > 1);
     float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
-    unsigned f = 0;
-    int32_t k = wave_pick_scan(g, r, b, mem, u, f);
+    unsigned f = 0, sv = 0;
+    int32_t k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);   // search over exact prefix sums
+    if (k < 0) { k = wave_pick_scan(g, r, b, mem, u, f); degc += (unsigned long long)r.deg; }
+    else { fast += sv; }
     int32_t next = g.ent[r.off + k].id;
-    degc += (unsigned long long)r.deg; fb += f;
+    fb += f;
     if (b.need_member) degp += (unsigned long long)b.prev_deg;
     if (lane == 0) path[s] = next;
     prev = curr; curr = next; ++len;
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
     atomicAdd(&ctr->sum_deg_curr, degc);
     if (degp) atomicAdd(&ctr->sum_deg_prev, degp);
     if (fb) atomicAdd(&ctr->fallbacks, fb);
+    if (fast) atomicAdd(&ctr->ent_reads, fast);      // general kernel: steps served by the prefix-sum search
   }
 }
 
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *_
                                                     RngSpec rng, float p, float q, int32_t world,
                                                     Walker *__restrict__ out, unsigned long long *cursors,
                                                     int32_t *__restrict__ paths, int64_t stride, DevCounters *ctr) {
-  __shared__ uint32_t bitmap[TPB / 64][BM_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BM_WORDS];
   const int lane = lane_id();
   const int64_t ri = (blockIdx.x * (int64_t)TPB + threadIdx.x) >> 6;
   if (ri >= n_in) return;
@@ -349,8 +352,9 @@ __global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *_
   const uint32_t iter = (uint32_t)(first_walk + (int64_t)wk.wid / n_verts_global);
   Bias b = make_bias(g, p, q, wk.prev, step > 1);
   float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
-  unsigned f = 0;
-  int32_t k = wave_pick_scan(g, r, b, mem, u, f);
+  unsigned f = 0, sv = 0;
+  int32_t k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
+  if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
   int32_t next = g.ent[r.off + k].id;
   if (lane == 0) {
     paths[(int64_t)wk.wid * stride + step] = next;
@@ -532,6 +536,9 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
   if (first_order) build_first_order_tables(h);
   if (alias) build_alias_tables(h);
+  if (!alias && !first_order && !(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX))
+    build_pq_tables(h, P.p, P.q);                    // optional: exact base prefix sums for the search sampler
+  else if (!alias && !first_order) h->g.has_pq = false;
 }
 }  // namespace
 
@@ -714,6 +721,8 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
     RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
     const bool first_order = P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL);
     if (first_order) build_first_order_tables(h);
+    else if (!(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX)) build_pq_tables(h, P.p, P.q);
+    else h->g.has_pq = false;
     SRW_HIP(hipEventRecord(h->ev0, st));
     if (first_order) {
       int64_t blocks = (n_in + TPB - 1) / TPB;

@@ -114,7 +114,7 @@ def main():
     if not args.compact:
         walk_kw["compact"] = False
 
-    if args.shard == "vertex" and world > 1:
+    if args.shard == "vertex" and dist is not None:
         from importlib import import_module
         sharded = import_module("stellar_random_walk_amd.distributed")
         drv = sharded.ShardedWalker(device=local_rank, rank=rank, world=world)

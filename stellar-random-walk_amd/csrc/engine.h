@@ -110,6 +110,7 @@ struct srw_handle {
   srw::WalkResult res;
   srw::DevBuf<srw::DevCounters> counters;
   srw::DevBuf<unsigned long long> shard_counts;  // [world] bucket counters / cursors for srw_shard_step
+  srw::DevBuf<srw::Walker> shard_scratch;        // sampled records before bucketing (persistent)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // srw_walk_to_host: second stream + two staging buffers for compute/copy overlap
   hipStream_t copy_stream = nullptr;

@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--p", type=float, default=1.0)
     ap.add_argument("--q", type=float, default=1.0)
     ap.add_argument("--weighted", type=int, default=0)
+    ap.add_argument("--directed", type=int, default=0)
     ap.add_argument("--sampler", choices=["reference", "alias"], default="reference")
     ap.add_argument("--shard", choices=["replicate", "vertex"], default="replicate")
     ap.add_argument("--nt-loads", type=int, default=-1, help="-1 auto, 0 cached, 1 nontemporal record loads")
@@ -118,7 +119,7 @@ def main():
         from importlib import import_module
         sharded = import_module("stellar_random_walk_amd.distributed")
         drv = sharded.ShardedWalker(device=local_rank, rank=rank, world=world)
-        drv.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted))
+        drv.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
         nv, ne = drv.engine.stats()
         for it in range(W):
             drv.walk_iteration(iteration=it, **walk_kw)
@@ -137,7 +138,7 @@ def main():
         scaling = "strong"
     else:
         eng = pkg.Engine(device=local_rank)
-        eng.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted))
+        eng.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
         nv, ne = eng.stats()
         base = rank * (W + K)  # disjoint walk-iteration indices per rank: numWalks = world * K in total
         for it in range(W):
@@ -199,9 +200,10 @@ def main():
             "metric": "walk-steps/sec", "value": total_steps / max_dt, "unit": "walk-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": max_dt / max(K, 1) * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "int32 ids / f64 CDF", "data": "synthetic",
-            "config": {"workload": "RMAT scale-%d ef%d (%d edge lines, %d adjacency entries, %d vertices) undirected "
+            "config": {"workload": "RMAT scale-%d ef%d (%d edge lines, %d adjacency entries, %d vertices) %s "
                                    "%s p=%g q=%g walkLength=%d, 1 walk iteration per step, %s"
                                    % (args.scale, args.edge_factor, n_edges, ne, nv,
+                                      "directed" if args.directed else "undirected",
                                       "weighted" if args.weighted else "unweighted", args.p, args.q, args.walk_length,
                                       "Mode A (alias + rejection)" if args.sampler == "alias" else "Mode R (reference-exact)"),
                        "walk_steps_per_bench_step": int(steps / max(K, 1)), "parallelism": parallelism,

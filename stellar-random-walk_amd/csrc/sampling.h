@@ -201,6 +201,11 @@ __device__ inline float biased_weight_m(const Bias &b, const Member &m, int32_t 
 }
 
 // Mark the candidates of segment [seg_base, seg_base + seg_len) that occur in N(prev).
+// Two strategies over the SORTED rows (both give the same bits):
+//   * probe : each (distinct) element of N(prev) is binary-searched in N(curr)      ~ |N(prev)| * log|N(curr)| probes
+//   * merge : N(curr) is cut into 64 contiguous slices, one per lane; each lane finds its start in N(prev) by one
+//             binary search and then advances both sorted lists linearly              ~ (|N(curr)| + |N(prev)|) / 64 steps
+// merge wins when both rows are large (hub -> hub steps, which dominate biased walks on power-law graphs).
 __device__ inline void fill_member_bitmap(const Bias &b, Member &m, const uint32_t *curr_sids,
                                           const uint32_t *curr_sperm, int32_t deg, int32_t seg_base, int32_t seg_len) {
   const int lane = lane_id();
@@ -208,14 +213,35 @@ __device__ inline void fill_member_bitmap(const Bias &b, Member &m, const uint32
   const int words = (seg_len + 31) >> 5;
   for (int t = lane; t < words; t += 64) m.bm[t] = 0u;
   __builtin_amdgcn_wave_barrier();
-  for (int32_t t = lane; t < b.prev_deg; t += 64) {
-    uint32_t x = b.prev_sids[t];
-    if (t > 0 && b.prev_sids[t - 1] == x) continue;            // duplicates of a multi-edge: once is enough
-    int32_t lo = 0, hi = deg;
-    while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (curr_sids[mid] < x) lo = mid + 1; else hi = mid; }
-    for (int32_t pos = lo; pos < deg && curr_sids[pos] == x; ++pos) {
-      int32_t orig = (int32_t)curr_sperm[pos] - seg_base;
-      if (orig >= 0 && orig < seg_len) atomicOr(&m.bm[orig >> 5], 1u << (orig & 31));
+  const int lc = 32 - __clz(deg | 1);
+  const bool merge = (int64_t)deg + b.prev_deg < (int64_t)b.prev_deg * lc * 2;
+  if (merge) {
+    const int32_t T = (deg + 63) >> 6;
+    const int32_t c0 = lane * T, c1 = min(deg, c0 + T);
+    if (c0 < c1) {
+      const uint32_t first = curr_sids[c0];
+      int32_t j = 0, hi = b.prev_deg;                       // lower_bound of my slice's first id in N(prev)
+      while (j < hi) { int32_t mid = j + ((hi - j) >> 1); if (b.prev_sids[mid] < first) j = mid + 1; else hi = mid; }
+      uint32_t pv = j < b.prev_deg ? b.prev_sids[j] : 0xFFFFFFFFu;
+      for (int32_t c = c0; c < c1; ++c) {
+        const uint32_t x = curr_sids[c];
+        while (pv < x) { ++j; pv = j < b.prev_deg ? b.prev_sids[j] : 0xFFFFFFFFu; }
+        if (pv == x && j < b.prev_deg) {
+          const int32_t orig = (int32_t)curr_sperm[c] - seg_base;
+          if (orig >= 0 && orig < seg_len) atomicOr(&m.bm[orig >> 5], 1u << (orig & 31));
+        }
+      }
+    }
+  } else {
+    for (int32_t t = lane; t < b.prev_deg; t += 64) {
+      uint32_t x = b.prev_sids[t];
+      if (t > 0 && b.prev_sids[t - 1] == x) continue;            // duplicates of a multi-edge: once is enough
+      int32_t lo = 0, hi = deg;
+      while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (curr_sids[mid] < x) lo = mid + 1; else hi = mid; }
+      for (int32_t pos = lo; pos < deg && curr_sids[pos] == x; ++pos) {
+        int32_t orig = (int32_t)curr_sperm[pos] - seg_base;
+        if (orig >= 0 && orig < seg_len) atomicOr(&m.bm[orig >> 5], 1u << (orig & 31));
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -250,7 +276,8 @@ __device__ inline int32_t wave_pick_scan(const GraphView &g, const Row &rc, cons
     // cost model (in binary-search probes): per-candidate search twice (two passes) vs reverse marking per segment
     int lp = 32 - __clz(b.prev_deg | 1), lc = 32 - __clz(deg | 1);
     int64_t nseg = ((int64_t)deg + BM_BITS - 1) / BM_BITS;
-    int64_t direct = 2ll * deg * lp, reverse = 2ll * nseg * b.prev_deg * lc + deg / 16;
+    const int64_t probe = (int64_t)b.prev_deg * lc, merged = ((int64_t)deg + b.prev_deg) / 2;
+    int64_t direct = 2ll * deg * lp, reverse = 2ll * nseg * (probe < merged ? probe : merged) + deg / 16;
     m.mode = reverse < direct ? 2 : 1;
   }
   const int32_t seg_cap = (m.mode == 2) ? BM_BITS : 0x7FFFFFFF;

@@ -216,19 +216,64 @@ __device__ inline void fill_member_bitmap(const Bias &b, Member &m, const uint32
   const int lc = 32 - __clz(deg | 1);
   const bool merge = (int64_t)deg + b.prev_deg < (int64_t)b.prev_deg * lc * 2;
   if (merge) {
-    const int32_t T = (deg + 63) >> 6;
+    // Block-wise sorted intersection, one contiguous slice of N(curr) per lane: 4 ids of each list are held in
+    // registers, all 16 pairs are compared, then the block with the smaller maximum is replaced by the next one,
+    // which was requested one step earlier (software prefetch) — no per-element dependent load.
+    const int32_t T = (((deg + 63) >> 6) + 3) & ~3;          // slice length, multiple of 4
     const int32_t c0 = lane * T, c1 = min(deg, c0 + T);
     if (c0 < c1) {
       const uint32_t first = curr_sids[c0];
       int32_t j = 0, hi = b.prev_deg;                       // lower_bound of my slice's first id in N(prev)
       while (j < hi) { int32_t mid = j + ((hi - j) >> 1); if (b.prev_sids[mid] < first) j = mid + 1; else hi = mid; }
-      uint32_t pv = j < b.prev_deg ? b.prev_sids[j] : 0xFFFFFFFFu;
-      for (int32_t c = c0; c < c1; ++c) {
-        const uint32_t x = curr_sids[c];
-        while (pv < x) { ++j; pv = j < b.prev_deg ? b.prev_sids[j] : 0xFFFFFFFFu; }
-        if (pv == x && j < b.prev_deg) {
-          const int32_t orig = (int32_t)curr_sperm[c] - seg_base;
-          if (orig >= 0 && orig < seg_len) atomicOr(&m.bm[orig >> 5], 1u << (orig & 31));
+      const uint32_t PAD = 0xFFFFFFFFu;
+      auto load4 = [](const uint32_t *p, int32_t i, int32_t n, uint32_t out[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[u] = (i + u < n) ? p[i + u] : 0xFFFFFFFFu;
+      };
+      uint32_t a[4], bb[4], an[4], bn[4];
+      int32_t ca = c0, jb = j;
+      load4(curr_sids, ca, c1, a);          load4(b.prev_sids, jb, b.prev_deg, bb);
+      load4(curr_sids, ca + 4, c1, an);     load4(b.prev_sids, jb + 4, b.prev_deg, bn);
+      unsigned fa = 0;                      // match flags of the current a block
+      while (true) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          fa |= ((a[u] == bb[0]) | (a[u] == bb[1]) | (a[u] == bb[2]) | (a[u] == bb[3])) ? (1u << u) : 0u;
+        const uint32_t amax = a[3], bmax = bb[3];
+        // on a tie only A advances: the next A block may start with more copies of that id (multi-edges) and must
+        // still meet the current B block
+        const bool adv_a = amax <= bmax, adv_b = !adv_a;
+        if (adv_a) {
+          if (fa) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (((fa >> u) & 1u) && a[u] != PAD) {
+                const int32_t orig = (int32_t)curr_sperm[ca + u] - seg_base;
+                if (orig >= 0 && orig < seg_len) atomicOr(&m.bm[orig >> 5], 1u << (orig & 31));
+              }
+          }
+          fa = 0; ca += 4;
+          if (ca >= c1) break;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a[u] = an[u];
+          load4(curr_sids, ca + 4, c1, an);
+        }
+        if (adv_b) {
+          jb += 4;
+          if (jb >= b.prev_deg) {            // N(prev) exhausted: flush the flags gathered so far and stop
+            if (fa) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (((fa >> u) & 1u) && a[u] != PAD) {
+                  const int32_t orig = (int32_t)curr_sperm[ca + u] - seg_base;
+                  if (orig >= 0 && orig < seg_len) atomicOr(&m.bm[orig >> 5], 1u << (orig & 31));
+                }
+            }
+            break;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bb[u] = bn[u];
+          load4(b.prev_sids, jb + 4, b.prev_deg, bn);
         }
       }
     }
@@ -382,6 +427,7 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
   if (deg < 128 || !g.pq_ok[curr_slot]) return -1;
   const int lc = 32 - __clz(deg | 1);
   if (b.need_member && (int64_t)b.prev_deg * (lc + 2) > (int64_t)deg * 2) return -1;   // marking would cost more than streaming
+  if (b.need_member && b.prev_deg > 2048) return -1;   // two large rows share too many neighbors for the LDS list
   const int lane = lane_id();
   uint32_t *sp_pos = lds;
   double *sp_corr = reinterpret_cast<double *>(lds + SP_CAP);

@@ -117,7 +117,8 @@ enum {
   SRW_WALK_NT_LOADS = 2,      /* first-order kernel: force L1-bypassing (nontemporal) record loads */
   SRW_WALK_CACHED_LOADS = 4,  /* first-order kernel: force default-policy loads (default: chosen from the table size) */
   SRW_WALK_NO_COMPACT = 16,   /* first-order kernel: do not use the 16-byte lattice records even when available */
-  SRW_WALK_NO_PREFIX = 32     /* general kernel: always stream N(curr); do not use the exact prefix-sum search */
+  SRW_WALK_NO_PREFIX = 32,    /* general kernel: always stream N(curr); do not use the exact prefix-sum search */
+  SRW_WALK_NO_EDGE_HASH = 64  /* Mode A: membership by binary search in the sorted rows instead of the edge hash set */
 };
 
 typedef struct {

@@ -78,6 +78,8 @@ struct GraphView {
   const uint32_t *msids;  //   replicated on every shard so that N(prev) is available wherever curr lives)
   const double *pq;     // per-call exact prefix sums of the base weights fl(w / q) inside each row (null if not built)
   const uint8_t *pq_ok; // per slot: row certified for the prefix-sum sampler under the call's (p, q)
+  const uint64_t *ehash;  // Mode A: open-addressing set of directed edges, key = (row slot << 32) | (id - vmin); null if absent
+  uint64_t ehash_mask;
   int32_t symmetric;    // 1: undirected load (x in N(y) <=> y in N(x)): membership may probe the shorter row
   const int32_t *owner_tab;  // sharded + SRW_CFG_OWNER_FROM_PARTITIONS: partition id per slot (-1 unknown), else null
   int32_t vmin;
@@ -124,6 +126,22 @@ __host__ __device__ inline int32_t owner_of(int32_t v, int32_t world) {
   int32_t m = v % world;   // Utils.nonNegativeMod of HashPartitioner (RandomWalk.scala:16)
   return m < 0 ? m + world : m;
 }
+// Edge-existence test through the hash set (linear probing, EMPTY = all ones).
+__device__ inline uint64_t edge_hash(uint64_t k) {
+  k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull; k ^= k >> 27; k *= 0x94D049BB133111EBull; k ^= k >> 31;
+  return k;
+}
+__device__ inline bool edge_exists(const uint64_t *tab, uint64_t mask, uint32_t row_slot, uint32_t id_slot) {
+  const uint64_t key = ((uint64_t)row_slot << 32) | id_slot;
+  uint64_t s = edge_hash(key) & mask;
+  while (true) {
+    const uint64_t v = tab[s];
+    if (v == key) return true;
+    if (v == 0xFFFFFFFFFFFFFFFFull) return false;
+    s = (s + 1) & mask;
+  }
+}
+
 // Owner with an optional partition table (VCut routing: the partition recorded for the vertex, modulo world).
 __host__ __device__ inline int32_t owner_of_tab(int32_t v, int32_t world, const int32_t *tab, int32_t vmin, int64_t n_slots) {
   if (tab) {

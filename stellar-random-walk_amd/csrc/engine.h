@@ -79,13 +79,16 @@ struct Graph {
   DevBuf<double> pq;              // [n_entries] per-(p,q) exact base prefix sums (general kernel fast path)
   DevBuf<uint8_t> pq_ok;          // [n_slots]
   bool has_pq = false; uint32_t pq_pbits = 0, pq_qbits = 0;
+  DevBuf<uint64_t> ehash;         // Mode A: edge hash set (optional, built lazily when q != 1)
+  uint64_t ehash_mask = 0; bool has_ehash = false;
   DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
   bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
   GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_cfo ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
-                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, symmetric ? 1 : 0, owner_tab.p, vmin, n_slots}; }
+                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, has_ehash ? ehash.p : nullptr, ehash_mask,
+                     symmetric ? 1 : 0, owner_tab.p, vmin, n_slots}; }
 };
 
 struct WalkResult {
@@ -158,6 +161,7 @@ void build_pq_tables(srw_handle *h, float p, float q);
 
 // ---- alias_tables.hip ----
 void build_alias_tables(srw_handle *h);
+void build_edge_hash(srw_handle *h);
 
 // ---- walk_kernels.hip ----
 void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats);

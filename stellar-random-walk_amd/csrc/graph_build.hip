@@ -177,6 +177,8 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
   g.al.release();
   g.has_pq = false;
   g.pq.release();
+  g.has_ehash = false;
+  g.ehash.release();
 
   // 1. stable sort of the entry stream by owning vertex
   DevBuf<uint32_t> keys2; DevBuf<uint64_t> vals2; DevBuf<char> temp;

@@ -298,7 +298,9 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
             else {
               // x in N(prev)?  On an undirected load this equals prev in N(x): probe the shorter sorted row
               bool in;
-              if (g.symmetric && e.ndeg < rp.deg)
+              if (g.ehash)                                  // one probe into the edge hash set: (prev -> x) exists?
+                in = edge_exists(g.ehash, g.ehash_mask, (uint32_t)((int64_t)prev - g.vmin), (uint32_t)((int64_t)e.id - g.vmin));
+              else if (g.symmetric && e.ndeg < rp.deg)
                 in = sorted_contains(g.sids + e.noff, e.ndeg, (uint32_t)((int64_t)prev - g.vmin));
               else
                 in = sorted_contains(g.sids + rp.off, rp.deg, (uint32_t)((int64_t)e.id - g.vmin));
@@ -556,6 +558,8 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
   if (first_order) build_first_order_tables(h);
   if (alias) build_alias_tables(h);
+  if (alias && P.q != 1.0f && !(P.flags & SRW_WALK_NO_EDGE_HASH)) build_edge_hash(h);
+  if (alias && (P.flags & SRW_WALK_NO_EDGE_HASH)) { h->g.has_ehash = false; }
   if (!alias && !first_order && !(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX))
     build_pq_tables(h, P.p, P.q);                    // optional: exact base prefix sums for the search sampler
   else if (!alias && !first_order) h->g.has_pq = false;

@@ -127,9 +127,10 @@ def test_gpu_mode_a_walk_equals_oracle(eng, oracle, p, q):
     g = oracle.Graph.from_coo(s, d, w)
     eng.load_coo(s, d, w)
     for nt in (True, False):
-        a = eng.walk(walk_length=20, seed=9, p=p, q=q, sampler="alias", nt_loads=nt)
-        b = g.walk(walk_length=20, seed=9, p=p, q=q, sampler=1, threads=8)
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+        for eh in (True, False):        # membership through the edge hash set / through the sorted rows
+            a = eng.walk(walk_length=20, seed=9, p=p, q=q, sampler="alias", nt_loads=nt, edge_hash=eh)
+            b = g.walk(walk_length=20, seed=9, p=p, q=q, sampler=1, threads=8)
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
 
 
 @gpu

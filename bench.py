@@ -199,7 +199,7 @@ def main():
         out = {
             "metric": "walk-steps/sec", "value": total_steps / max_dt, "unit": "walk-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": max_dt / max(K, 1) * 1e3, "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "int32 ids / f64 CDF", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": "f64 CDF tables (u32 lattice compares in the walk), int32 ids", "data": "synthetic",
             "config": {"workload": "RMAT scale-%d ef%d (%d edge lines, %d adjacency entries, %d vertices) %s "
                                    "%s p=%g q=%g walkLength=%d, 1 walk iteration per step, %s"
                                    % (args.scale, args.edge_factor, n_edges, ne, nv,

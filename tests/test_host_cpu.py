@@ -218,3 +218,51 @@ def test_product_never_references_the_oracle():
                 assert not hits, (f, needle, hits[:2])
     out = subprocess.run(["ldd", pkg().LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_tokenizer_fuzz_against_oracle(oracle, tmp_path):
+    # random files over a nasty alphabet: the product tokenizer (C++, multi-threaded) and the oracle tokenizer (plain C)
+    # must agree on accept/reject and, when accepting, on every parsed value bit for bit
+    rng = np.random.default_rng(123)
+    # (int32 extremes as ids are covered by test_tokenizer_known_values: the oracle's dense graph cannot span them)
+    tokens = ["1", "22", "-3", "+4", "007", "2147483648", "-2147483649", "1.5", ".5", "5.", "1e3", "1e", "e3",
+              "NaN", "Infinity", "-Infinity", "nan", "inf", "0x1p3", "0x1.8p1", "0x10", "1f", "2d", "1.5F", "3D", "1_0", "",
+              "abc", "1.5abc", "--1", "+-2", "1e+2", "1E-2", "9" * 12, "0.1", "1e40", "1e-50", "3.4028236e38", "16777217"]
+    seps = [" ", "  ", "\t", " \t ", "\x0b", "\x0c"]
+    eols = ["\n", "\r\n", "\r"]
+    n_accept = n_reject = 0
+    for trial in range(300):
+        lines = []
+        for _ in range(int(rng.integers(1, 6))):
+            k = int(rng.integers(1, 6))
+            toks = [tokens[int(i)] for i in rng.integers(0, len(tokens), k)]
+            if rng.random() < 0.7:                                   # mostly well-formed first two columns
+                toks[0] = str(int(rng.integers(-50, 50)))
+                if k > 1:
+                    toks[1] = str(int(rng.integers(-50, 50)))
+            line = (seps[int(rng.integers(0, len(seps)))] if rng.random() < 0.08 else "") + \
+                seps[int(rng.integers(0, len(seps)))].join(toks) + (" " if rng.random() < 0.2 else "")
+            lines.append(line)
+        eol = eols[int(rng.integers(0, 3))]
+        text = eol.join(lines) + (eol if rng.random() < 0.5 else "")
+        path = _write(tmp_path, text.encode("latin1"), "f%d.txt" % trial)
+        for weighted, partitioned in ((True, False), (True, True), (False, False)):
+            try:
+                got = pkg().parse_edgelist(path, weighted=weighted, partitioned=partitioned)
+            except pkg().SrwError as e:
+                assert e.code == pkg().ERR_PARSE, text
+                got = None
+            try:
+                g = oracle.Graph.load(path, directed=True, weighted=weighted, partitioned=partitioned)
+                want = g.lines()
+            except ValueError:
+                want = None
+            assert (got is None) == (want is None), (text, weighted, partitioned)
+            if got is None:
+                n_reject += 1
+                continue
+            n_accept += 1
+            assert got[0].tolist() == want[0].tolist() and got[1].tolist() == want[1].tolist(), text
+            assert got[2].view(np.uint32).tolist() == want[2].view(np.uint32).tolist(), text
+            assert got[3].tolist() == want[3].tolist(), text
+    assert n_accept > 100 and n_reject > 100

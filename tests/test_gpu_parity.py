@@ -554,3 +554,18 @@ def test_sharded_by_user_partitions(oracle, tmp_path, world, p, q):
     assert np.array_equal(got, rp) and np.array_equal(written.sum(dim=1).cpu().numpy().astype(np.int32), rl)
     for se in ses:
         se.engine.close()
+
+
+def test_table_variants_agree_beyond_cache_size(eng):
+    # RMAT-22 (4.3 GB exact table, 2.1 GB compact table: larger than L2 + Infinity Cache, so the L1-bypassing load
+    # policy is the default): compact/exact records x both load policies x general kernel give identical bytes
+    eng.generate_rmat(22, 16 << 22, seed=42)
+    nv, ne = eng.stats()
+    base = eng.walk(walk_length=40, seed=3)
+    assert base[2]["record_bytes"] == 16 and base[2]["n_steps"] == nv * 41
+    for kw in (dict(compact=False), dict(compact=False, nt_loads=False), dict(nt_loads=False)):
+        other = eng.walk(walk_length=40, seed=3, **kw)
+        assert np.array_equal(base[1], other[1]) and np.array_equal(base[0], other[0]), kw
+    st, dead = None, None
+    sub = eng.walk(walk_length=3, seed=3, force_general=True)           # exact streaming sampler on the same graph
+    assert np.array_equal(sub[0][:, :5], base[0][:, :5])

@@ -194,10 +194,14 @@ __global__ __launch_bounds__(TPB) void k_alias_build(Row *rows, const Ent *__res
 }
 
 // Link pass: the neighbor's row descriptor, and the total weight of the reverse edge(s) id -> row vertex (the W_prev of
-// the next step's outlier folding), summed in f64 in input order exactly as the walk would; stored only when f32-exact.
+// the next step's outlier folding).  On an undirected load every line (a, b, w) contributed a->b to row a and b->a to
+// row b, so the edges b->a seen from row b are, line for line and in the same order, the parallel edges a->b of row a:
+// W_rev(a->b) = f64 sum, in input order, of the weights of row a's own entries with id b (for a simple graph: w).
+// Runs of equal ids are adjacent in the row's sorted order (sids) and sperm lists them in input order.  Directed
+// loads store NaN and the walk looks the return edge up when it needs it.
 __global__ void k_alias_link(const Row *__restrict__ rows, const Ent *__restrict__ ent, const uint32_t *__restrict__ sids,
                              const uint32_t *__restrict__ sperm, AEnt *__restrict__ al, int64_t n_slots, int32_t vmin,
-                             unsigned long long *next_slot) {
+                             int32_t symmetric, unsigned long long *next_slot) {
   const int lane = lane_id();
   while (true) {                                   // dynamic row hand-out (RMAT hubs would pile up on a fixed stride)
     unsigned long long grab = 0;
@@ -207,22 +211,31 @@ __global__ void k_alias_link(const Row *__restrict__ rows, const Ent *__restrict
     if ((int64_t)grab >= n_slots) break;
     for (int64_t v = (int64_t)grab; v < (int64_t)grab + 4 && v < n_slots; ++v) {
       const Row r = rows[v];
-      const uint32_t me = (uint32_t)v;              // (this vertex id) - vmin
-      for (int32_t k = lane; k < r.deg; k += 64) {
-        AEnt a = al[r.off + k];
+      const uint32_t *cs = sids + r.off, *cp = sperm + r.off;
+      for (int32_t c = lane; c < r.deg; c += 64) {   // c: position in the row's sorted order
+        const uint32_t x = cs[c];
+        const uint32_t orig = cp[c];
+        AEnt a = al[r.off + orig];
         int64_t s = (int64_t)a.id - vmin;
         Row nr; nr.off = 0; nr.deg = 0; nr.flags = 0;
         if (s >= 0 && s < n_slots) nr = rows[s];
-        // reverse edges: equal range of `me` in the sorted row of the neighbor
-        const uint32_t *cs = sids + nr.off;
-        int32_t lo = 0, hi = nr.deg;
-        while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < me) lo = mid + 1; else hi = mid; }
-        double wsum = 0.0;
-        for (int32_t c = lo; c < nr.deg && cs[c] == me; ++c) wsum += (double)ent[nr.off + sperm[nr.off + c]].w;
-        const float wf = (float)wsum;
-        a.wrev = ((double)wf == wsum) ? wf : __int_as_float(0x7FC00000);
+        float wr = __int_as_float(0x7FC00000);
+        if (symmetric) {
+          const bool dup = (c > 0 && cs[c - 1] == x) || (c + 1 < r.deg && cs[c + 1] == x);
+          if (!dup) {
+            wr = ent[r.off + orig].w;
+          } else {
+            int32_t b = c;
+            while (b > 0 && cs[b - 1] == x) --b;
+            double wsum = 0.0;
+            for (int32_t t = b; t < r.deg && cs[t] == x; ++t) wsum += (double)ent[r.off + cp[t]].w;
+            const float wf = (float)wsum;
+            if ((double)wf == wsum) wr = wf;
+          }
+        }
+        a.wrev = wr;
         a.noff = nr.off; a.ndeg = nr.deg; a.nflags = nr.flags;
-        al[r.off + k] = a;
+        al[r.off + orig] = a;
       }
     }
   }
@@ -292,7 +305,7 @@ void build_alias_tables(srw_handle *h) {
   if (g.n_entries > 0) {
     SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
     hipLaunchKernelGGL(k_alias_link, dim3(256 * 8), dim3(256), 0, st, g.rows.p, g.ent.p, g.sids.p, g.sperm.p, g.al.p, g.n_slots,
-                       g.vmin, next_slot.p);
+                       g.vmin, g.symmetric ? 1 : 0, next_slot.p);
   }
   SRW_HIP(hipGetLastError());
   SRW_HIP(hipStreamSynchronize(st));

@@ -498,6 +498,17 @@ void check_params(const srw_walk_params &P) {
 namespace {
 struct LaunchInfo { int kind; int record_bytes; };
 
+// Leaves no asynchronous work behind (copies into caller / pinned buffers, kernels writing staging buffers) when a
+// pipelined entry point exits — normally or through an exception (I/O error in the writer, HIP error).
+struct StreamDrain {
+  srw_handle *h;
+  explicit StreamDrain(srw_handle *hh) : h(hh) {}
+  ~StreamDrain() {
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+  }
+};
+
 // Enqueue the walk kernel(s) of num_walks iterations starting at P.first_walk into d_paths / d_lens.
 LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walks, int32_t first_walk, int32_t *d_paths,
                        int32_t *d_lens) {
@@ -616,6 +627,7 @@ void run_walk_to_host(srw_handle *h, const srw_walk_params &P, int32_t *paths, i
   }
   h->res.valid = false;
   h->counters.ensure(1);
+  StreamDrain drain(h);
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   SRW_HIP(hipEventRecord(h->ev0, st));
   LaunchInfo li{0, 0};
@@ -672,6 +684,7 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   h->pin_cap = std::max(h->pin_cap, need);
   h->res.valid = false;
   h->counters.ensure(1);
+  StreamDrain drain(h);
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   SRW_HIP(hipEventRecord(h->ev0, st));
   LaunchInfo li{0, 0};

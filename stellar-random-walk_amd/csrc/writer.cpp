@@ -9,7 +9,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cerrno>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -137,9 +139,11 @@ struct PathWriter::Impl {
     }
   }
   // append walkers [b, e) of `paths` (local indices) to the currently open part
+  double t_format = 0, t_write = 0;   // SRW_TIMING: where the writer's wall time goes
   void append_range(const int32_t *paths, const int32_t *lens, int64_t stride, int64_t b, int64_t e) {
     const int64_t n = e - b;
     if (n <= 0) return;
+    auto t0 = std::chrono::steady_clock::now();
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(hw, n / 4096 + 1));
     std::vector<Piece> pieces((size_t)nt);
     {
@@ -150,6 +154,7 @@ struct PathWriter::Impl {
       }
       for (auto &x : th) x.join();
     }
+    auto t1 = std::chrono::steady_clock::now();
     std::vector<off_t> offs((size_t)nt + 1, file_off);
     for (int t = 0; t < nt; ++t) offs[(size_t)t + 1] = offs[(size_t)t] + (off_t)pieces[(size_t)t].len;
     std::vector<std::string> errs((size_t)nt);
@@ -166,6 +171,9 @@ struct PathWriter::Impl {
     for (auto &er : errs) if (!er.empty()) throw Error(SRW_ERR_IO, er);
     file_off = offs[(size_t)nt];
     for (auto &pc : pieces) crc_feed(pc.buf.get(), pc.len);
+    auto t2 = std::chrono::steady_clock::now();
+    t_format += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    t_write += std::chrono::duration<double, std::milli>(t2 - t1).count();
   }
 };
 
@@ -200,6 +208,8 @@ void PathWriter::append(const int32_t *paths, const int32_t *lens, int64_t n, in
 }
 
 void PathWriter::close() {
+  if (getenv("SRW_TIMING"))
+    fprintf(stderr, "[timing] writer: format %.1f ms, pwrite %.1f ms\n", p_->t_format, p_->t_write);
   // parts that received no walker still exist as empty files, as with repartition(n)
   for (int part = p_->cur_part + 1; part < p_->n_parts; ++part) p_->open_part(part);
   p_->close_part();

@@ -236,6 +236,7 @@ int32_t srw_alias_row(srw_handle *h, int32_t v, float *prob, int32_t *alias, int
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
     need(h->g.loaded && n, "no graph / null n");
+    build_membership(h);
     build_alias_tables(h);
     const Graph &g = h->g;
     int64_t s = (int64_t)v - g.vmin;

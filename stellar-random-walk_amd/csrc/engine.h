@@ -60,6 +60,7 @@ struct Graph {
   int64_t n_slots = 0;
   int64_t n_lines = 0;
   bool symmetric = false;         // built from an undirected edge list
+  bool has_member = false;        // sids / sperm built (lazily, build_membership)
   int64_t n_entries_global = 0;   // "edges: N" of the whole graph
   int64_t n_entries = 0;          // entries stored on this handle (== global when world == 1)
   int64_t n_vertices = 0;         // present vertices of the whole graph
@@ -156,6 +157,7 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
                                 const int32_t *ids, const float *w);
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,
                          DevBuf<int32_t> &d_src, DevBuf<int32_t> &d_dst, DevBuf<float> &d_w);
+void build_membership(srw_handle *h);
 void build_first_order_tables(srw_handle *h);
 void build_pq_tables(srw_handle *h, float p, float q);
 

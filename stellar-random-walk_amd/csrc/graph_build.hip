@@ -78,22 +78,10 @@ __global__ void k_rows_deg(const uint32_t *__restrict__ keys, int64_t n, Row *ro
     if (e == n - 1 || keys[e + 1] != keys[e]) rows[keys[e]].deg = (int32_t)(e + 1 - rows[keys[e]].off);
 }
 
-__global__ void k_member_keys(const uint32_t *__restrict__ keys, const Ent *__restrict__ ent, int64_t n, int32_t vmin,
-                              uint64_t *__restrict__ out) {
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
-    out[e] = ((uint64_t)keys[e] << 32) | (uint32_t)((int64_t)ent[e].id - vmin);
-}
 __global__ void k_low32(const uint64_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
     out[e] = (uint32_t)in[e];
 }
-// value of the membership sort: position of the entry inside its row (input order)
-__global__ void k_local_index(const uint32_t *__restrict__ keys, const Row *__restrict__ rows, int64_t n,
-                              uint32_t *__restrict__ out) {
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
-    out[e] = (uint32_t)(e - rows[keys[e]].off);
-}
-
 __global__ void k_owned_flags(const uint32_t *__restrict__ present, int64_t n_slots, int32_t vmin, int32_t rank,
                               int32_t world, const int32_t *__restrict__ otab, uint32_t *__restrict__ out) {
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x)
@@ -215,25 +203,9 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
     hipLaunchKernelGGL(k_rows_deg, dim3(grid_for(n_owned)), dim3(TPB), 0, st, keys2.p, n_owned, g.rows.p);
   }
 
-  // 4. per-row sorted ids (membership structure for computeSecondOrderWeights' `exists`)
-  g.sids.alloc((size_t)n_owned);
-  g.sperm.alloc((size_t)std::max<int64_t>(n_owned, 1));
-  if (n_owned) {
-    DevBuf<uint64_t> mk, mk2; DevBuf<uint32_t> li;
-    mk.alloc((size_t)n_owned); mk2.alloc((size_t)n_owned); li.alloc((size_t)n_owned);
-    g.sperm.alloc((size_t)n_owned);
-    hipLaunchKernelGGL(k_member_keys, dim3(grid_for(n_owned)), dim3(TPB), 0, st, keys2.p, g.ent.p, n_owned, vmin, mk.p);
-    hipLaunchKernelGGL(k_local_index, dim3(grid_for(n_owned)), dim3(TPB), 0, st, keys2.p, g.rows.p, n_owned, li.p);
-    int id_bits = bits_for((uint64_t)std::max<int64_t>(g.n_slots - 1, 1));
-    size_t tb = 0;
-    SRW_HIP(rocprim::radix_sort_pairs(nullptr, tb, mk.p, mk2.p, li.p, g.sperm.p, (size_t)n_owned, 0u,
-                                      (unsigned)(32 + id_bits), st));
-    temp.alloc(tb);
-    SRW_HIP(rocprim::radix_sort_pairs((void *)temp.p, tb, mk.p, mk2.p, li.p, g.sperm.p, (size_t)n_owned, 0u,
-                                      (unsigned)(32 + id_bits), st));
-    hipLaunchKernelGGL(k_low32, dim3(grid_for(n_owned)), dim3(TPB), 0, st, mk2.p, n_owned, g.sids.p);
-    SRW_HIP(hipStreamSynchronize(st));
-  }
+  // 4. per-row sorted ids: built lazily (build_membership) — first-order walks never need them
+  g.has_member = false;
+  g.sids.release(); g.sperm.release();
   keys2.release(); temp.release();
 
   // 5. vertex list (walker seeds, ascending id) + global ranks
@@ -364,6 +336,56 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
   SRW_HIP(hipMemcpyAsync(present.p, hpresent.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
   SRW_HIP(hipStreamSynchronize(st));
   finish_build(h, keys, vals, n_total, n_total, present, vmin, vmax, false);
+}
+
+namespace {
+// (row slot << 32 | id - vmin) and the input-order position of every entry, from the row table
+__global__ void k_member_keys_rows(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots, int32_t vmin,
+                                   uint64_t *__restrict__ mk, uint32_t *__restrict__ li, unsigned long long *next_slot) {
+  const int lane = threadIdx.x & 63;
+  while (true) {
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(next_slot, 4ull);
+    grab = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab);
+    if ((int64_t)grab >= n_slots) break;
+    for (int64_t v = (int64_t)grab; v < (int64_t)grab + 4 && v < n_slots; ++v) {
+      const Row r = rows[v];
+      for (int32_t k = lane; k < r.deg; k += 64) {
+        mk[r.off + k] = ((uint64_t)(uint32_t)v << 32) | (uint32_t)((int64_t)ent[r.off + k].id - vmin);
+        li[r.off + k] = (uint32_t)k;
+      }
+    }
+  }
+}
+}  // namespace
+
+// Membership structure of computeSecondOrderWeights' `exists` (RandomSample.scala:37): per-row sorted ids + the
+// input-order position of each sorted entry.  Needed by the general and alias kernels only, so it is built on first use.
+void build_membership(srw_handle *h) {
+  Graph &g = h->g;
+  if (g.has_member) return;
+  hipStream_t st = h->stream;
+  const int64_t n = g.n_entries;
+  g.sids.alloc((size_t)std::max<int64_t>(n, 1));
+  g.sperm.alloc((size_t)std::max<int64_t>(n, 1));
+  if (n > 0) {
+    DevBuf<uint64_t> mk, mk2; DevBuf<uint32_t> li; DevBuf<char> temp; DevBuf<unsigned long long> next_slot;
+    mk.alloc((size_t)n); mk2.alloc((size_t)n); li.alloc((size_t)n); next_slot.alloc(1);
+    SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
+    hipLaunchKernelGGL(k_member_keys_rows, dim3(256 * 8), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, mk.p, li.p,
+                       next_slot.p);
+    int id_bits = bits_for((uint64_t)std::max<int64_t>(g.n_slots - 1, 1));
+    size_t tb = 0;
+    SRW_HIP(rocprim::radix_sort_pairs(nullptr, tb, mk.p, mk2.p, li.p, g.sperm.p, (size_t)n, 0u, (unsigned)(32 + id_bits), st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::radix_sort_pairs((void *)temp.p, tb, mk.p, mk2.p, li.p, g.sperm.p, (size_t)n, 0u,
+                                      (unsigned)(32 + id_bits), st));
+    hipLaunchKernelGGL(k_low32, dim3(grid_for(n)), dim3(TPB), 0, st, mk2.p, n, g.sids.p);
+    SRW_HIP(hipStreamSynchronize(st));
+    SRW_HIP(hipGetLastError());
+  }
+  g.has_member = true;
 }
 
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,

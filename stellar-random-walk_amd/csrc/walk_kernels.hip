@@ -568,6 +568,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool alias = P.sampler == SRW_SAMPLER_ALIAS;
   const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
   if (first_order) build_first_order_tables(h);
+  else build_membership(h);                           // sorted rows: general and alias kernels only
   if (alias) build_alias_tables(h);
   if (alias && P.q != 1.0f && !(P.flags & SRW_WALK_NO_EDGE_HASH)) build_edge_hash(h);
   if (alias && (P.flags & SRW_WALK_NO_EDGE_HASH)) { h->g.has_ehash = false; }
@@ -759,8 +760,11 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
     RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
     const bool first_order = P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL);
     if (first_order) build_first_order_tables(h);
-    else if (!(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX)) build_pq_tables(h, P.p, P.q);
-    else h->g.has_pq = false;
+    else {
+      build_membership(h);
+      if (!(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX)) build_pq_tables(h, P.p, P.q);
+      else h->g.has_pq = false;
+    }
     SRW_HIP(hipEventRecord(h->ev0, st));
     if (first_order) {
       int64_t blocks = (n_in + TPB - 1) / TPB;

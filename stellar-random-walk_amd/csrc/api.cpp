@@ -35,7 +35,13 @@ void need(bool ok, const char *msg) { if (!ok) throw Error(SRW_ERR_INVALID, msg)
 
 void load_lines(srw_handle *h, const int32_t *src, const int32_t *dst, const float *w, const int32_t *pid,
                 int64_t n, bool directed) {
-  need(n > 0, "empty edge list");
+  if (n == 0) {   // an empty edge list is a valid (empty) graph: zero vertices, zero paths, an empty part-00000
+    h->g = Graph();
+    h->g.loaded = true; h->g.symmetric = !directed;
+    h->g.vmin = 0; h->g.vmax = -1; h->g.n_slots = 0;
+    h->res.valid = false;
+    return;
+  }
   int32_t vmin = src[0], vmax = src[0];
   for (int64_t i = 0; i < n; ++i) {
     vmin = std::min(vmin, std::min(src[i], dst[i]));
@@ -132,7 +138,6 @@ int32_t srw_load_edgelist(srw_handle *h, const char *path, int32_t directed, int
     need(path != nullptr, "path is null");
     ParsedLines L;
     parse_edgelist_file(path, weighted != 0, partitioned != 0, L);
-    if (L.src.empty()) throw Error(SRW_ERR_INVALID, "edge list has no lines");
     if (partitioned) {
       // a missing / unparsable pId is Random.nextInt(rddPartitions) in the reference (VCutRandomWalk.scala:24-25,
       // unseeded); partition ids never change walk results, so a deterministic hash stands in.
@@ -149,7 +154,7 @@ int32_t srw_load_coo(srw_handle *h, const int32_t *src, const int32_t *dst, cons
                      int64_t n_lines, int32_t directed) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
-    need(src && dst, "src/dst are null");
+    need(n_lines == 0 || (src && dst), "src/dst are null");
     load_lines(h, src, dst, w, pid, n_lines, directed != 0);
   });
 }
@@ -196,8 +201,9 @@ int32_t srw_graph_vertices(const srw_handle *ch, int32_t *out) {
   srw_handle *h = const_cast<srw_handle *>(ch);
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
-    need(h->g.loaded && out, "no graph / null out");
-    SRW_HIP(hipMemcpy(out, h->g.verts.p, (size_t)h->g.n_local_vertices * 4, hipMemcpyDeviceToHost));
+    need(h->g.loaded && (out || h->g.n_local_vertices == 0), "no graph / null out");
+    if (h->g.n_local_vertices > 0)
+      SRW_HIP(hipMemcpy(out, h->g.verts.p, (size_t)h->g.n_local_vertices * 4, hipMemcpyDeviceToHost));
   });
 }
 
@@ -288,6 +294,7 @@ int32_t srw_fetch_paths(const srw_handle *ch, int32_t *paths, int32_t *lens) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
     need(h->res.valid, "no walk result");
+    if (h->res.n_walkers == 0) return;
     if (paths) SRW_HIP(hipMemcpy(paths, h->res.paths.p, (size_t)h->res.n_walkers * h->res.stride * 4, hipMemcpyDeviceToHost));
     if (lens) SRW_HIP(hipMemcpy(lens, h->res.lens.p, (size_t)h->res.n_walkers * 4, hipMemcpyDeviceToHost));
   });
@@ -307,9 +314,11 @@ int32_t srw_write_paths(const srw_handle *ch, const char *output_dir, int32_t n_
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
     need(h->res.valid && output_dir, "no walk result / null output_dir");
-    std::vector<int32_t> paths((size_t)h->res.n_walkers * h->res.stride), lens((size_t)h->res.n_walkers);
-    SRW_HIP(hipMemcpy(paths.data(), h->res.paths.p, paths.size() * 4, hipMemcpyDeviceToHost));
-    SRW_HIP(hipMemcpy(lens.data(), h->res.lens.p, lens.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> paths((size_t)h->res.n_walkers * h->res.stride + 1), lens((size_t)h->res.n_walkers + 1);
+    if (h->res.n_walkers > 0) {
+      SRW_HIP(hipMemcpy(paths.data(), h->res.paths.p, (size_t)h->res.n_walkers * h->res.stride * 4, hipMemcpyDeviceToHost));
+      SRW_HIP(hipMemcpy(lens.data(), h->res.lens.p, (size_t)h->res.n_walkers * 4, hipMemcpyDeviceToHost));
+    }
     write_path_files(paths.data(), lens.data(), h->res.n_walkers, h->res.stride, output_dir, n_parts, write_crc != 0);
   });
 }

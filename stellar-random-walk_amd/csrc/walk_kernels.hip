@@ -587,6 +587,11 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   const int64_t n_walkers = (int64_t)P.num_walks * g.n_vertices;
   if (n_walkers >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "more than 2^31 walkers in one call: lower num_walks");
   const int32_t stride = P.walk_length + 2;
+  if (n_walkers == 0) {   // empty graph: nothing to walk
+    h->res.n_walkers = 0; h->res.stride = stride; h->res.valid = true;
+    if (stats) { memset(stats, 0, sizeof(*stats)); }
+    return;
+  }
   prepare_tables(h, P);
   h->res.valid = false;
   h->res.paths.ensure((size_t)n_walkers * stride);
@@ -618,6 +623,7 @@ void run_walk_to_host(srw_handle *h, const srw_walk_params &P, int32_t *paths, i
   const int64_t nv = g.n_vertices;
   if (nv >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "too many vertices");
   const int32_t stride = P.walk_length + 2;
+  if (nv == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return; }
   prepare_tables(h, P);
   if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   for (int i = 0; i < 2; ++i) {
@@ -667,6 +673,7 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   const int64_t nv = g.n_vertices;
   const int32_t stride = P.walk_length + 2;
   PathWriter writer(output_dir, n_parts, (int64_t)P.num_walks * nv, write_crc);   // fails first if <output>/path exists
+  if (nv == 0) { writer.close(); if (stats) memset(stats, 0, sizeof(*stats)); return; }
   prepare_tables(h, P);
   if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   const size_t need = (size_t)nv * stride * 4;

@@ -208,6 +208,7 @@ void PathWriter::append(const int32_t *paths, const int32_t *lens, int64_t n, in
 }
 
 void PathWriter::close() {
+  if (p_->cur_part < 0 && p_->n_parts > 0) p_->open_part(0);   // zero paths: still an (empty) part-00000
   if (getenv("SRW_TIMING"))
     fprintf(stderr, "[timing] writer: format %.1f ms, pwrite %.1f ms\n", p_->t_format, p_->t_write);
   // parts that received no walker still exist as empty files, as with repartition(n)

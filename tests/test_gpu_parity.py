@@ -569,3 +569,27 @@ def test_table_variants_agree_beyond_cache_size(eng):
     st, dead = None, None
     sub = eng.walk(walk_length=3, seed=3, force_general=True)           # exact streaming sampler on the same graph
     assert np.array_equal(sub[0][:, :5], base[0][:, :5])
+
+
+def test_empty_and_degenerate_inputs(eng, oracle, tmp_path):
+    # empty edge list: zero vertices, zero paths, an empty part-00000 + _SUCCESS (what saveAsTextFile leaves behind)
+    f = tmp_path / "empty.txt"
+    f.write_bytes(b"")
+    eng.load_edgelist(str(f))
+    assert eng.stats() == (0, 0) and len(eng.vertices()) == 0
+    paths, lens, st = eng.walk(walk_length=5, num_walks=3)
+    assert len(lens) == 0 and st["n_steps"] == 0
+    eng.write_paths(str(tmp_path / "o1"))
+    assert (tmp_path / "o1" / "path" / "part-00000").read_bytes() == b"" and (tmp_path / "o1" / "path" / "_SUCCESS").exists()
+    st, dead = eng.walk_and_save(str(tmp_path / "o2"), n_parts=2, walk_length=5)
+    assert sorted(os.listdir(tmp_path / "o2" / "path")) == ["_SUCCESS", "part-00000", "part-00001"]
+    # a single self-loop line, undirected: the vertex gets two entries (src->dst and dst->src) and walks on itself
+    f2 = tmp_path / "loop.txt"
+    f2.write_text("7 7 2.5\n")
+    eng.load_edgelist(str(f2))
+    g = oracle.Graph.load(str(f2))
+    assert eng.stats() == (1, 2) == (g.num_vertices, g.num_entries)
+    for p, q in ((1.0, 1.0), (0.25, 4.0)):
+        a = eng.walk(walk_length=6, num_walks=2, p=p, q=q, seed=1)
+        b = g.walk(walk_length=6, num_walks=2, p=p, q=q, seed=1)
+        assert np.array_equal(a[0], b[0]) and a[0].tolist() == [[7] * 8] * 2

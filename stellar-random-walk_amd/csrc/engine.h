@@ -76,6 +76,7 @@ struct Graph {
   bool has_fo = false;
   DevBuf<CfoEnt> cfo;             // [n_entries] compact lattice records (optional)
   bool has_cfo = false;
+  bool cfo_rejected = false;      // the compact table was tried and some entry needed an escape
   DevBuf<AEnt> al;                // [n_entries] Mode A alias records, built lazily
   DevBuf<double> pq;              // [n_entries] per-(p,q) exact base prefix sums (general kernel fast path)
   DevBuf<uint8_t> pq_ok;          // [n_slots]
@@ -158,7 +159,7 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,
                          DevBuf<int32_t> &d_src, DevBuf<int32_t> &d_dst, DevBuf<float> &d_w);
 void build_membership(srw_handle *h);
-void build_first_order_tables(srw_handle *h);
+void build_first_order_tables(srw_handle *h, bool want_exact);
 void build_pq_tables(srw_handle *h, float p, float q);
 
 // ---- alias_tables.hip ----

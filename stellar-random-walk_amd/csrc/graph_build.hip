@@ -160,6 +160,7 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
   g.has_fo = false;
   g.fo.release();
   g.has_cfo = false;
+  g.cfo_rejected = false;
   g.cfo.release();
   g.has_al = false;
   g.al.release();

@@ -24,13 +24,33 @@ constexpr int SMALL_DEG = 32;
 
 __device__ inline bool weight_regular(float w) { return w >= 0.0f; }  // false for NaN and negatives
 
+// Where the table kernels keep the running CDF and the guide entries: in the exact 32-byte records, or in slim
+// temporaries (8-byte CDF + 4-byte guide) from which the compact 16-byte records are derived without ever
+// materialising the exact table (build_first_order_tables, "compact first").
+struct FoStore {
+  FoEnt *fo;
+  __device__ inline void put(int64_t e, double cdf, int32_t id) const {
+    FoEnt f; f.cdf = cdf; f.id = id; f.guide = 0; f.noff = 0; f.ndeg = 0; f.nflags = 0; fo[e] = f;
+  }
+  __device__ inline double cdf(int64_t e) const { return fo[e].cdf; }
+  __device__ inline void set_guide(int64_t e, int32_t g) const { fo[e].guide = g; }
+  __device__ inline int32_t guide(int64_t e) const { return fo[e].guide; }
+};
+struct SlimStore {
+  double *c; int32_t *g;
+  __device__ inline void put(int64_t e, double cdf, int32_t) const { c[e] = cdf; }
+  __device__ inline double cdf(int64_t e) const { return c[e]; }
+  __device__ inline void set_guide(int64_t e, int32_t gg) const { g[e] = gg; }
+  __device__ inline int32_t guide(int64_t e) const { return g[e]; }
+};
+
 // deg <= SMALL_DEG: one lane per row, literal sequential evaluation.
-__global__ void k_fo_small(Row *rows, const Ent *__restrict__ ent, FoEnt *__restrict__ fo, int64_t n_slots) {
+template <class ST>
+__global__ void k_fo_small(Row *rows, const Ent *__restrict__ ent, ST st, int64_t n_slots) {
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
     Row r = rows[v];
     if (r.deg <= 0 || r.deg > SMALL_DEG) continue;
     const Ent *row = ent + r.off;
-    FoEnt *out = fo + r.off;
     double sum = 0.0;
     bool irr = false;
     for (int32_t k = 0; k < r.deg; ++k) {
@@ -43,8 +63,7 @@ __global__ void k_fo_small(Row *rows, const Ent *__restrict__ ent, FoEnt *__rest
     for (int32_t k = 0; k < r.deg; ++k) {
       Ent e = row[k];
       acc += (double)e.w / sum;
-      FoEnt f; f.cdf = acc; f.id = e.id; f.guide = 0; f.noff = 0; f.ndeg = 0; f.nflags = 0;
-      out[k] = f;
+      st.put(r.off + k, acc, e.id);
     }
     if (irr) rows[v].flags = r.flags | ROW_IRREGULAR;
   }
@@ -54,7 +73,8 @@ __global__ void k_fo_small(Row *rows, const Ent *__restrict__ ent, FoEnt *__rest
 // Rows are handed out through a global counter (4 slots per grab, ascending id): a fixed wave stride would give
 // wave w every id == w (mod #waves), and in RMAT the ids with few set low bits are ALL hubs (one wave then owns
 // ~5 % of the graph).  Ascending order also starts the longest rows (low ids) first.
-__global__ void k_fo_large(Row *rows, const Ent *__restrict__ ent, FoEnt *__restrict__ fo, int64_t n_slots,
+template <class ST>
+__global__ void k_fo_large(Row *rows, const Ent *__restrict__ ent, ST st, int64_t n_slots,
                            unsigned long long *next_slot) {
   const int lane = lane_id();
   while (true) {
@@ -67,7 +87,6 @@ __global__ void k_fo_large(Row *rows, const Ent *__restrict__ ent, FoEnt *__rest
     Row r = rows[v];
     if (r.deg <= SMALL_DEG) continue;
     const Ent *row = ent + r.off;
-    FoEnt *out = fo + r.off;
     double part = 0.0;
     SumCert cert;
     bool irr = false;
@@ -130,7 +149,7 @@ __global__ void k_fo_large(Row *rows, const Ent *__restrict__ ent, FoEnt *__rest
               if (lane == i) mine = acc;
             }
           }
-          if (k < r.deg) { FoEnt f; f.cdf = mine; f.id = e.id; f.guide = 0; f.noff = 0; f.ndeg = 0; f.nflags = 0; out[k] = f; }
+          if (k < r.deg) st.put(r.off + k, mine, e.id);
         }
       }
 #pragma unroll
@@ -146,16 +165,16 @@ __device__ inline double bucket_threshold(uint32_t j, uint32_t deg) {
   return (double)m * (1.0 / 16777216.0);               // exact
 }
 
-__global__ void k_guide_small(const Row *__restrict__ rows, FoEnt *__restrict__ fo, int64_t n_slots) {
+template <class ST>
+__global__ void k_guide_small(const Row *__restrict__ rows, ST st, int64_t n_slots) {
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
     Row r = rows[v];
     if (r.deg <= 0 || r.deg > SMALL_DEG || (r.flags & ROW_IRREGULAR)) continue;
-    FoEnt *row = fo + r.off;
     int32_t k = 0;
     for (int32_t j = 0; j < r.deg; ++j) {   // thresholds and cdf both non-decreasing: two-pointer merge
       double t = bucket_threshold((uint32_t)j, (uint32_t)r.deg);
-      while (k < r.deg && !(row[k].cdf >= t)) ++k;
-      row[j].guide = k;
+      while (k < r.deg && !(st.cdf(r.off + k) >= t)) ++k;
+      st.set_guide(r.off + j, k);
     }
   }
 }
@@ -178,15 +197,17 @@ __global__ void k_guide_make_items(const Row *__restrict__ rows, int64_t n_slots
   }
 }
 
-__device__ inline int32_t lower_bound_cdf(const FoEnt *row, int32_t lo, int32_t hi, double t) {
+template <class ST>
+__device__ inline int32_t lower_bound_cdf(const ST &st, int64_t off, int32_t lo, int32_t hi, double t) {
   while (lo < hi) {
     int32_t mid = lo + ((hi - lo) >> 1);
-    if (row[mid].cdf >= t) hi = mid; else lo = mid + 1;
+    if (st.cdf(off + mid) >= t) hi = mid; else lo = mid + 1;
   }
   return lo;
 }
 
-__global__ void k_guide_large(const Row *__restrict__ rows, FoEnt *__restrict__ fo, const uint2 *__restrict__ items,
+template <class ST>
+__global__ void k_guide_large(const Row *__restrict__ rows, ST st, const uint2 *__restrict__ items,
                               const unsigned long long *n_items_p) {
   const int lane = lane_id();
   const unsigned long long n_items = *n_items_p;
@@ -197,7 +218,6 @@ __global__ void k_guide_large(const Row *__restrict__ rows, FoEnt *__restrict__ 
     const int64_t v = (int64_t)item.x | ((int64_t)(item.y >> 24) << 32);
     const int32_t part = (int32_t)(item.y & 0xFFFFFFu);
     Row r = rows[v];
-    FoEnt *row = fo + r.off;
     const int32_t jb = part * GUIDE_ITEM, je = min(r.deg, jb + GUIDE_ITEM);
     int32_t start = -1;                                   // answer of the previous chunk's last lane
     for (int32_t j0 = jb; j0 < je; j0 += 64) {
@@ -206,13 +226,13 @@ __global__ void k_guide_large(const Row *__restrict__ rows, FoEnt *__restrict__ 
       if (j < je) {
         const double t = bucket_threshold((uint32_t)j, (uint32_t)r.deg);
         if (start < 0) {
-          ans = lower_bound_cdf(row, 0, r.deg, t);
+          ans = lower_bound_cdf(st, r.off, 0, r.deg, t);
         } else {                                           // gallop: answer >= start (monotone in j)
           int32_t lo = start, step = 1;
-          while (lo + step < r.deg && !(row[lo + step - 1].cdf >= t)) { lo += step; step <<= 1; }
-          ans = lower_bound_cdf(row, lo, min(r.deg, lo + step), t);
+          while (lo + step < r.deg && !(st.cdf(r.off + lo + step - 1) >= t)) { lo += step; step <<= 1; }
+          ans = lower_bound_cdf(st, r.off, lo, min(r.deg, lo + step), t);
         }
-        row[j].guide = ans;
+        st.set_guide(r.off + j, ans);
       }
       const int last = min(63, je - j0 - 1);
       start = __builtin_amdgcn_readlane(ans, last);
@@ -231,50 +251,63 @@ __global__ void k_fo_link(const Row *__restrict__ rows, FoEnt *__restrict__ fo, 
   }
 }
 
-// ---- compact 16-byte records (lattice draws) derived from the exact table --------------------------------------
-__device__ inline void cfo_write(const FoEnt *row, CfoEnt *crow, int32_t j, unsigned long long *escapes) {
-  const FoEnt f = row[j];
-  const double sc = f.cdf * 16777216.0;                       // exact scaling
-  const uint32_t c = sc >= 16777216.0 ? 16777216u : (uint32_t)sc;   // floor; cdf >= 0 on a regular row
-  const int32_t delta = j - f.guide;
-  bool esc = delta < 0 || delta > 62 || f.ndeg > (int32_t)CFO_NDEG_MAX || f.noff >= ((int64_t)1 << 40);
-  // a start below guide[j] stays a valid lower bound, so a small negative delta could use 0; be strict instead
+// ---- compact 16-byte records (lattice draws) derived from the CDF / guide store ------------------------------------
+template <class ST>
+__device__ inline void cfo_write(const ST &st, const Row *__restrict__ rows, const Ent *__restrict__ ent, int32_t vmin,
+                                 int64_t n_slots, const Row &r, int32_t j, bool regular, CfoEnt *__restrict__ cfo,
+                                 unsigned long long *escapes) {
+  const int64_t e = r.off + j;
+  const int32_t id = ent[e].id;
+  const int64_t s = (int64_t)id - vmin;
+  Row nr; nr.off = 0; nr.deg = 0; nr.flags = 0;
+  if (s >= 0 && s < n_slots) nr = rows[s];
+  bool esc = nr.deg > (int32_t)CFO_NDEG_MAX || nr.off >= ((int64_t)1 << 40);
+  uint32_t cg = 0;
+  if (regular) {
+    const double sc = st.cdf(e) * 16777216.0;                     // exact scaling
+    const uint32_t c = sc >= 16777216.0 ? 16777216u : (uint32_t)sc;   // floor; cdf >= 0 on a regular row
+    const int32_t delta = j - st.guide(e);
+    // a start below guide[j] stays a valid lower bound, so a small negative delta could use 0; be strict instead
+    const bool desc = delta < 0 || delta > 62;
+    esc |= desc;
+    cg = c | ((uint32_t)(desc ? 63 : delta) << 26);
+  }
   CfoEnt o;
-  o.cg = c | ((uint32_t)(esc ? 63 : delta) << 26);
-  o.id = f.id;
-  const bool generic = (f.nflags & ROW_IRREGULAR) != 0;
-  o.link = (uint64_t)f.noff | ((uint64_t)(uint32_t)f.ndeg << 40) | ((uint64_t)generic << 63);
-  crow[j] = o;
+  o.cg = cg; o.id = id;
+  o.link = (uint64_t)nr.off | ((uint64_t)(uint32_t)min(nr.deg, (int32_t)CFO_NDEG_MAX) << 40) |
+           ((uint64_t)((nr.flags & ROW_IRREGULAR) != 0) << 63);
+  cfo[e] = o;
   if (esc) atomicAdd(escapes, 1ull);
 }
-__global__ void k_cfo_small(const Row *__restrict__ rows, const FoEnt *__restrict__ fo, CfoEnt *__restrict__ cfo,
-                            int64_t n_slots, unsigned long long *escapes) {
-  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
-    Row r = rows[v];
-    if (r.deg <= 0 || r.deg > SMALL_DEG) continue;
-    if (r.flags & ROW_IRREGULAR) {      // never sampled through the compact table; keep the link usable
-      for (int32_t j = 0; j < r.deg; ++j) { FoEnt f = fo[r.off + j]; CfoEnt o; o.cg = 0; o.id = f.id;
-        o.link = (uint64_t)f.noff | ((uint64_t)(uint32_t)min(f.ndeg, (int32_t)CFO_NDEG_MAX) << 40) | ((uint64_t)((f.nflags & ROW_IRREGULAR) != 0) << 63);
-        cfo[r.off + j] = o; if (f.ndeg > (int32_t)CFO_NDEG_MAX) atomicAdd(escapes, 1ull); }
-      continue;
+// every row gets records (irregular rows are never sampled through cg, but their links are used)
+template <class ST>
+__global__ void k_cfo_rows(const Row *__restrict__ rows, const Ent *__restrict__ ent, ST st, CfoEnt *__restrict__ cfo,
+                           int64_t n_slots, int32_t vmin, unsigned long long *escapes, unsigned long long *next_slot) {
+  const int lane = lane_id();
+  while (true) {
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(next_slot, 4ull);
+    grab = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab);
+    if ((int64_t)grab >= n_slots) break;
+    for (int64_t v = (int64_t)grab; v < (int64_t)grab + 4 && v < n_slots; ++v) {
+      const Row r = rows[v];
+      const bool regular = !(r.flags & ROW_IRREGULAR);
+      for (int32_t j = lane; j < r.deg; j += 64) cfo_write(st, rows, ent, vmin, n_slots, r, j, regular, cfo, escapes);
     }
-    for (int32_t j = 0; j < r.deg; ++j) cfo_write(fo + r.off, cfo + r.off, j, escapes);
   }
 }
-__global__ void k_cfo_large(const Row *__restrict__ rows, const FoEnt *__restrict__ fo, CfoEnt *__restrict__ cfo,
-                            const uint2 *__restrict__ items, const unsigned long long *n_items_p,
-                            unsigned long long *escapes) {
-  const int lane = lane_id();
-  const unsigned long long n_items = *n_items_p;
-  unsigned long long wave = (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) >> 6;
-  const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
-  for (unsigned long long it = wave; it < n_items; it += n_waves) {
-    uint2 item = items[it];
-    const int64_t v = (int64_t)item.x | ((int64_t)(item.y >> 24) << 32);
-    const int32_t part = (int32_t)(item.y & 0xFFFFFFu);
-    Row r = rows[v];
-    const int32_t jb = part * GUIDE_ITEM, je = min(r.deg, jb + GUIDE_ITEM);
-    for (int32_t j = jb + lane; j < je; j += 64) cfo_write(fo + r.off, cfo + r.off, j, escapes);
+// exact records from the slim temporaries (only when the compact table had to be abandoned)
+__global__ void k_fo_from_slim(const Row *__restrict__ rows, const Ent *__restrict__ ent, const double *__restrict__ c,
+                               const int32_t *__restrict__ g, FoEnt *__restrict__ fo, int64_t n_entries, int32_t vmin,
+                               int64_t n_slots) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_entries; e += (int64_t)gridDim.x * blockDim.x) {
+    FoEnt f; f.cdf = c[e]; f.id = ent[e].id; f.guide = g[e];
+    int64_t s = (int64_t)f.id - vmin;
+    Row r; r.off = 0; r.deg = 0; r.flags = 0;
+    if (s >= 0 && s < n_slots) r = rows[s];
+    f.noff = r.off; f.ndeg = r.deg; f.nflags = r.flags;
+    fo[e] = f;
   }
 }
 
@@ -370,24 +403,81 @@ void build_pq_tables(srw_handle *h, float p, float q) {
   g.pq_pbits = pb; g.pq_qbits = qb; g.has_pq = true;
 }
 
-void build_first_order_tables(srw_handle *h) {
+// CDF + guide into `st` (exact records or slim temporaries); leaves the guide work items in `items`.
+template <class ST>
+static void run_cdf_and_guide(srw_handle *h, ST st, DevBuf<uint2> &items, DevBuf<unsigned long long> &n_items) {
   Graph &g = h->g;
-  if (g.has_fo) return;
-  hipStream_t st = h->stream;
-  g.fo.alloc((size_t)g.n_entries);
+  hipStream_t stq = h->stream;
   int64_t tb = (g.n_slots + 255) / 256;
   int gs = (int)std::min<int64_t>(std::max<int64_t>(tb, 1), 256 * 32);
-  hipLaunchKernelGGL(k_fo_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.ent.p, g.fo.p, g.n_slots);
   DevBuf<unsigned long long> next_slot; next_slot.alloc(1);
-  SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
-  hipLaunchKernelGGL(k_fo_large, dim3(256 * 8), dim3(256), 0, st, g.rows.p, g.ent.p, g.fo.p, g.n_slots, next_slot.p);
-  hipLaunchKernelGGL(k_guide_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_slots);
+  SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, stq));
+  hipLaunchKernelGGL((k_fo_small<ST>), dim3(gs), dim3(256), 0, stq, g.rows.p, g.ent.p, st, g.n_slots);
+  hipLaunchKernelGGL((k_fo_large<ST>), dim3(256 * 8), dim3(256), 0, stq, g.rows.p, g.ent.p, st, g.n_slots, next_slot.p);
+  hipLaunchKernelGGL((k_guide_small<ST>), dim3(gs), dim3(256), 0, stq, g.rows.p, st, g.n_slots);
   const unsigned long long cap = (unsigned long long)g.n_entries / SMALL_DEG + 1024;
-  DevBuf<uint2> items; DevBuf<unsigned long long> n_items;
   items.alloc((size_t)cap); n_items.alloc(2);
-  SRW_HIP(hipMemsetAsync(n_items.p, 0, 16, st));
-  hipLaunchKernelGGL(k_guide_make_items, dim3(gs), dim3(256), 0, st, g.rows.p, g.n_slots, n_items.p, items.p, cap);
-  hipLaunchKernelGGL(k_guide_large, dim3(256 * 16), dim3(256), 0, st, g.rows.p, g.fo.p, items.p, n_items.p);
+  SRW_HIP(hipMemsetAsync(n_items.p, 0, 16, stq));
+  hipLaunchKernelGGL(k_guide_make_items, dim3(gs), dim3(256), 0, stq, g.rows.p, g.n_slots, n_items.p, items.p, cap);
+  hipLaunchKernelGGL((k_guide_large<ST>), dim3(256 * 16), dim3(256), 0, stq, g.rows.p, st, items.p, n_items.p);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipStreamSynchronize(stq));   // next_slot goes out of scope
+}
+
+template <class ST>
+static unsigned long long run_cfo(srw_handle *h, ST st, unsigned long long *esc_word) {
+  Graph &g = h->g;
+  hipStream_t stq = h->stream;
+  DevBuf<unsigned long long> next_slot; next_slot.alloc(1);
+  SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, stq));
+  SRW_HIP(hipMemsetAsync(esc_word, 0, 8, stq));
+  hipLaunchKernelGGL((k_cfo_rows<ST>), dim3(256 * 8), dim3(256), 0, stq, g.rows.p, g.ent.p, st, g.cfo.p, g.n_slots, g.vmin,
+                     esc_word, next_slot.p);
+  unsigned long long n_esc = 0;
+  SRW_HIP(hipMemcpyAsync(&n_esc, esc_word, 8, hipMemcpyDeviceToHost, stq));
+  SRW_HIP(hipStreamSynchronize(stq));
+  SRW_HIP(hipGetLastError());
+  return n_esc;
+}
+
+// First-order tables.  want_exact = false (Philox draws): "compact first" — the running CDF and the guide entries go
+// into slim temporaries (12 B/entry), the 16-byte lattice records are derived from them, and the 32-byte exact table
+// is materialised only if some entry needs an escape.  want_exact = true (constant-r hook, SRW_WALK_NO_COMPACT,
+// sharded handles): the exact table is built (and kept next to the compact one when both exist).
+void build_first_order_tables(srw_handle *h, bool want_exact) {
+  Graph &g = h->g;
+  const bool sharded = h->cfg.world > 1;
+  if (want_exact ? g.has_fo : (g.has_cfo || sharded || g.cfo_rejected || g.n_entries == 0) && (g.has_cfo || g.has_fo)) return;
+  hipStream_t st = h->stream;
+  DevBuf<uint2> items; DevBuf<unsigned long long> n_items;
+  if (!want_exact && g.has_fo) {           // exact table already there (an earlier constant-r call): derive the compact one
+    n_items.alloc(2);
+    g.cfo.alloc((size_t)g.n_entries);
+    if (run_cfo(h, FoStore{g.fo.p}, n_items.p + 1) == 0) g.has_cfo = true;
+    else { g.cfo.release(); g.cfo_rejected = true; }
+    return;
+  }
+  if (!want_exact && !sharded && g.n_entries > 0 && !g.cfo_rejected) {
+    DevBuf<double> c; DevBuf<int32_t> gd;
+    c.alloc((size_t)g.n_entries); gd.alloc((size_t)g.n_entries);
+    SlimStore slim{c.p, gd.p};
+    run_cdf_and_guide(h, slim, items, n_items);
+    g.cfo.alloc((size_t)g.n_entries);
+    if (run_cfo(h, slim, n_items.p + 1) == 0) { g.has_cfo = true; return; }
+    // some entry needs an escape (large guide delta on weighted hubs, giant degree): exact records instead
+    g.cfo.release(); g.cfo_rejected = true;
+    g.fo.alloc((size_t)g.n_entries);
+    int ge = (int)std::min<int64_t>((g.n_entries + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_fo_from_slim, dim3(ge), dim3(256), 0, st, g.rows.p, g.ent.p, c.p, gd.p, g.fo.p, g.n_entries, g.vmin,
+                       g.n_slots);
+    SRW_HIP(hipGetLastError());
+    SRW_HIP(hipStreamSynchronize(st));
+    g.has_fo = true;
+    return;
+  }
+  g.fo.alloc((size_t)g.n_entries);
+  FoStore fs{g.fo.p};
+  run_cdf_and_guide(h, fs, items, n_items);
   if (g.n_entries > 0) {
     int ge = (int)std::min<int64_t>((g.n_entries + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(k_fo_link, dim3(ge), dim3(256), 0, st, g.rows.p, g.fo.p, g.n_entries, g.vmin, g.n_slots);
@@ -395,22 +485,6 @@ void build_first_order_tables(srw_handle *h) {
   SRW_HIP(hipGetLastError());
   SRW_HIP(hipStreamSynchronize(st));
   g.has_fo = true;
-  // compact lattice table: only when it fits comfortably and no entry needs an escape
-  g.has_cfo = false;
-  size_t free_b = 0, total_b = 0;
-  SRW_HIP(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = (size_t)g.n_entries * sizeof(CfoEnt);
-  if (g.n_entries > 0 && h->cfg.world == 1 && free_b > need + need / 2 + ((size_t)16 << 30)) {
-    g.cfo.alloc((size_t)g.n_entries);
-    unsigned long long *esc = n_items.p + 1;
-    hipLaunchKernelGGL(k_cfo_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.fo.p, g.cfo.p, g.n_slots, esc);
-    hipLaunchKernelGGL(k_cfo_large, dim3(256 * 16), dim3(256), 0, st, g.rows.p, g.fo.p, g.cfo.p, items.p, n_items.p, esc);
-    unsigned long long n_esc = 0;
-    SRW_HIP(hipMemcpyAsync(&n_esc, esc, 8, hipMemcpyDeviceToHost, st));
-    SRW_HIP(hipStreamSynchronize(st));
-    SRW_HIP(hipGetLastError());
-    if (n_esc == 0) g.has_cfo = true; else g.cfo.release();
-  }
 }
 
 }  // namespace srw

@@ -89,7 +89,14 @@ __global__ __launch_bounds__(TPB, MINW) void k_walk_first_order(GraphView g, con
           FoEnt e;
           if (r.flags & ROW_IRREGULAR) {
             int32_t k = lane_pick_sequential(g.ent + r.off, r.deg, nobias, u);
-            e = g.fo[r.off + k]; ++fb;
+            ++fb;
+            if (COMPACT) {                                   // only the compact table exists: its links are valid for every row
+              const CfoEnt ce = g.cfo[r.off + k];
+              e.id = ce.id; e.noff = (int64_t)(ce.link & 0xFFFFFFFFFFull); e.ndeg = (int32_t)((ce.link >> 40) & 0x7FFFFFu);
+              e.nflags = (ce.link >> 63) ? ROW_IRREGULAR : 0u;
+            } else {
+              e = g.fo[r.off + k];
+            }
           } else {
             unsigned rd; int32_t k;
             e = fo_pick<NT>(g.fo + r.off, r.deg, u, k, rd); reads += rd;
@@ -567,7 +574,7 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
 void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool alias = P.sampler == SRW_SAMPLER_ALIAS;
   const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
-  if (first_order) build_first_order_tables(h);
+  if (first_order) build_first_order_tables(h, P.rng_mode != SRW_RNG_PHILOX || (P.flags & SRW_WALK_NO_COMPACT));
   else build_membership(h);                           // sorted rows: general and alias kernels only
   if (alias) build_alias_tables(h);
   if (alias && P.q != 1.0f && !(P.flags & SRW_WALK_NO_EDGE_HASH)) build_edge_hash(h);
@@ -766,7 +773,7 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
     Walker *scratch = h->shard_scratch.p;
     RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
     const bool first_order = P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL);
-    if (first_order) build_first_order_tables(h);
+    if (first_order) build_first_order_tables(h, true);
     else {
       build_membership(h);
       if (!(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX)) build_pq_tables(h, P.p, P.q);

@@ -118,7 +118,10 @@ enum {
   SRW_WALK_CACHED_LOADS = 4,  /* first-order kernel: force default-policy loads (default: chosen from the table size) */
   SRW_WALK_NO_COMPACT = 16,   /* first-order kernel: do not use the 16-byte lattice records even when available */
   SRW_WALK_NO_PREFIX = 32,    /* general kernel: always stream N(curr); do not use the exact prefix-sum search */
-  SRW_WALK_NO_EDGE_HASH = 64  /* Mode A: membership by binary search in the sorted rows instead of the edge hash set */
+  SRW_WALK_NO_EDGE_HASH = 64, /* Mode A: membership by binary search in the sorted rows instead of the edge hash set */
+  SRW_WALK_NO_BINNED = 128    /* Mode R, q != 1: never use the binned prefix-sum search (streaming scan instead) */
+  /* bits 12-13: test switch, force the binned search's intersection strategy (1 = P1, 2 = P2, 3 = id-window);
+     bit 14: test switch, use the binned search on rows of any degree (default: degree >= 128) */
 };
 
 typedef struct {

@@ -94,6 +94,8 @@ int32_t srw_create(const srw_config *cfg, srw_handle **out) {
     SRW_HIP(hipEventCreate(&h->ev0));
     SRW_HIP(hipEventCreate(&h->ev1));
     h->counters.alloc(1);
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && ncu > 0) h->n_cus = ncu;
   });
   if (rc != SRW_OK) { delete h; return rc; }
   *out = h;

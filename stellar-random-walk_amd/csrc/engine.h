@@ -114,6 +114,8 @@ struct srw_handle {
   srw::Graph g;
   srw::WalkResult res;
   srw::DevBuf<srw::DevCounters> counters;
+  srw::DevBuf<unsigned long long> walk_cursor;   // next walker of the persistent general kernel
+  int n_cus = 256;
   srw::DevBuf<unsigned long long> shard_counts;  // [world] bucket counters / cursors for srw_shard_step
   srw::DevBuf<srw::Walker> shard_scratch;        // sampled records before bucketing (persistent)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -188,7 +188,17 @@ struct Member {
   int mode;            // 0: not needed, 1: binary search per candidate, 2: bitmap
   uint32_t *bm;        // LDS, BM_WORDS words, private to the wave
   int32_t seg_base;    // first candidate position covered by the bitmap
+#ifdef SRW_PHASE_TIMING
+  unsigned long long t_fill = 0, t_pass1 = 0, t_pass2 = 0, t_prefix = 0, t_mark;
+#endif
 };
+#ifdef SRW_PHASE_TIMING
+#define SRW_T0(m) ((m).t_mark = wall_clock64())
+#define SRW_T1(m, f) ((m).f += wall_clock64() - (m).t_mark)
+#else
+#define SRW_T0(m)
+#define SRW_T1(m, f)
+#endif
 
 __device__ inline float biased_weight_m(const Bias &b, const Member &m, int32_t pos, int32_t id, float w) {
   if (!b.second_order) return w;
@@ -332,7 +342,9 @@ __device__ inline int32_t wave_pick_scan(const GraphView &g, const Row &rc, cons
   bool neg = false;
   for (int32_t sb = 0; sb < deg; sb += seg_cap) {
     int32_t sl = min(seg_cap, deg - sb);
+    SRW_T0(m);
     if (m.mode == 2) fill_member_bitmap(b, m, csids, csperm, deg, sb, sl);
+    SRW_T1(m, t_fill); SRW_T0(m);
     for (int32_t base = sb; base < sb + sl; base += 256) {
       int32_t k0 = base + lane * 4;
 #pragma unroll
@@ -347,10 +359,12 @@ __device__ inline int32_t wave_pick_scan(const GraphView &g, const Row &rc, cons
         }
       }
     }
+    SRW_T1(m, t_pass1);
   }
   int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
   bool bad = __any(cert.bad) || __any(neg);
   double S;
+  SRW_T0(m);
   if (!bad && sum_is_exact(emin, emax, false, deg)) {
     S = wave_sum_f64(part);
   } else {
@@ -398,6 +412,7 @@ __device__ inline int32_t wave_pick_scan(const GraphView &g, const Row &rc, cons
         int fl = __ffsll((long long)cand) - 1;
         int fi = __builtin_amdgcn_readlane(first, fl);
         int fs = __builtin_amdgcn_readlane((int)sure, fl);
+        SRW_T1(m, t_pass2);
         if (fs) return base + fl * 4 + fi;
         fallback = 1;                                     // within rounding distance of a boundary: exact chain
         return wave_chain_pick(row, deg, b, r, S);
@@ -505,6 +520,236 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
     const int32_t kf = lo + f;
     served = 1;
     if (hit) return kf;
+  }
+  fallback = 1;
+  return wave_chain_pick(row, deg, b, r, S);
+}
+
+// ---- exact pick by search over exact prefix sums, ANY number of specials (q != 1; hub -> hub steps) ----------------
+// Same mathematics as wave_pick_prefix, but the corrections of the specials are not kept as a list: each one is
+// added (exactly — the row certificate makes every sum of variant differences exact in any order) into an LDS bin
+// of its input-order position, bins[pos >> csh].  Then
+//   A'_{end of chunk j} = PQ[end_j] + sum(bins[0..j])          (exact)
+// locates, by a 64-ary search over the chunk ends with the same certified tolerance, the ONE chunk that holds the
+// first not-certain-miss index; only that chunk (64 .. a few thousand candidates) is evaluated candidate by
+// candidate.  No pass over N(curr)'s entries at all: the step costs the sorted intersection plus O(chunk).
+// The members of N(prev) among the candidates are found by the cheapest of three strategies over the SORTED rows:
+//   P1  every distinct id of N(prev) is searched in N(curr)                    ~ |N(prev)| log |N(curr)| probes
+//   P2  every candidate (input order, no permutation needed) is searched in N(prev) ~ |N(curr)| log |N(prev)| probes
+//   W   id-window bitmap: both sorted id lists are streamed once, coalesced, 256 ids per iteration; the ids of
+//       N(prev) inside the current window of 32768 vertex ids set bits in LDS, the ids of N(curr) test them
+//                                                                                ~ (|N(curr)| + |N(prev)|) / 256 iterations
+constexpr int BIN_CAP = 1024;                 // f64 bins: 8 KB of the wave's LDS
+constexpr int WIN_WORDS = 1024;               // id-window bitmap: 4 KB behind the bins
+constexpr int WIN_BITS = WIN_WORDS * 32;
+constexpr int BINNED_LDS_WORDS = 2 * BIN_CAP + WIN_WORDS;
+
+__device__ inline int32_t wave_lower_bound_u32(const uint32_t *a, int32_t n, uint32_t x) {   // wave-uniform, 64-ary
+  const int lane = lane_id();
+  int32_t lo = 0, hi = n;
+  while (true) {
+    const int32_t span = hi - lo;
+    if (span <= 0) return lo;
+    if (span <= 64) {
+      const int32_t k = lo + lane;
+      const bool ge = k < hi && a[k] >= x;
+      const unsigned long long m = __ballot(ge);
+      return m ? lo + (__ffsll((long long)m) - 1) : hi;
+    }
+    const int32_t k = lo + (int32_t)(((int64_t)span * lane) >> 6);
+    const bool ge = a[k] >= x;
+    const unsigned long long m = __ballot(ge);
+    if (!m) { lo = __builtin_amdgcn_readlane(k, 63) + 1; continue; }
+    const int f = __ffsll((long long)m) - 1;
+    hi = __builtin_amdgcn_readlane(k, f);
+    if (f) lo = __builtin_amdgcn_readlane(k, f - 1) + 1;
+  }
+}
+
+// tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W (tests force each one); force_small: no minimum degree
+__device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
+                                           uint32_t *lds, float r, unsigned &fallback, unsigned &served, int tune,
+                                           bool force_small) {
+  if (!g.pq || !b.second_order || !b.need_member) return -1;
+  const int32_t deg = rc.deg;
+  if ((!force_small && deg < 128) || !g.pq_ok[curr_slot]) return -1;
+  const int lane = lane_id();
+  double *bins = reinterpret_cast<double *>(lds);
+  uint32_t *win = lds + 2 * BIN_CAP;
+  int csh = 6;
+  while ((((int64_t)deg + ((int64_t)1 << csh) - 1) >> csh) > BIN_CAP) ++csh;
+  const int32_t n_bins = (int32_t)(((int64_t)deg + ((int64_t)1 << csh) - 1) >> csh);
+  for (int t = lane; t < n_bins; t += 64) bins[t] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  const Ent *row = g.ent + rc.off;
+  const uint32_t *cs = g.sids + rc.off, *cp = g.sperm + rc.off;
+  const uint32_t *B = b.prev_sids;
+  const int32_t m = b.prev_deg;
+  const uint32_t xprev = (uint32_t)((int64_t)b.prev - b.vmin);
+  const float p_ = b.p, q_ = b.q;
+  // (a) return edges: occurrences of prev in N(curr)
+  {
+    const int32_t lo = wave_lower_bound_u32(cs, deg, xprev);
+    for (int32_t c = lo + lane; c < deg && cs[c] == xprev; c += 64) {
+      const uint32_t orig = cp[c];
+      const float w = row[orig].w;
+      atomicAdd(&bins[orig >> csh], (double)(w / p_) - (double)(w / q_));
+    }
+  }
+  // (b) members of N(prev)
+  if (m > 0) {
+    const int lc = 32 - __clz(deg | 1), lp = 32 - __clz(m | 1);
+    int strat = tune;
+    if (strat == 0) {
+      const uint32_t lo_id = max(cs[0], B[0]), hi_id = min(cs[deg - 1], B[m - 1]);
+      const int64_t nwin = lo_id > hi_id ? 0 : (int64_t)((hi_id - lo_id) >> 15) + 1;
+      const int64_t c1 = (int64_t)m * lc * 10, c2 = (int64_t)deg * lp * 10;
+      const int64_t cw = ((int64_t)deg + m) * 6 + (nwin < (int64_t)deg + m ? nwin : (int64_t)deg + m) * 300 + 4000;
+      strat = (cw < c1 && cw < c2) ? 3 : (c1 <= c2 ? 1 : 2);
+    }
+    if (strat == 1) {
+      for (int32_t t = lane; t < m; t += 64) {
+        const uint32_t x = B[t];
+        if (x == xprev || (t > 0 && B[t - 1] == x)) continue;
+        int32_t lo = 0, hi = deg;
+        while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < x) lo = mid + 1; else hi = mid; }
+        for (int32_t c = lo; c < deg && cs[c] == x; ++c) {
+          const uint32_t orig = cp[c];
+          const float w = row[orig].w;
+          atomicAdd(&bins[orig >> csh], (double)w - (double)(w / q_));
+        }
+      }
+    } else if (strat == 2) {
+      for (int32_t k = lane; k < deg; k += 64) {
+        const Ent e = row[k];
+        if (e.id == b.prev) continue;
+        if (sorted_contains(B, m, (uint32_t)((int64_t)e.id - b.vmin)))
+          atomicAdd(&bins[k >> csh], (double)e.w - (double)(e.w / q_));
+      }
+    } else {
+      const uint32_t lo_id = max(cs[0], B[0]), hi_id = min(cs[deg - 1], B[m - 1]);
+      if (lo_id <= hi_id) {
+        int32_t ia = wave_lower_bound_u32(cs, deg, lo_id), ib = wave_lower_bound_u32(B, m, lo_id);
+        while (ia < deg && ib < m) {
+          const uint32_t fa = cs[ia], fb = B[ib];
+          const uint32_t first = fa > fb ? fa : fb;
+          if (first > hi_id) break;
+          const uint32_t base = first & ~(uint32_t)(WIN_BITS - 1);
+          const uint64_t limit = (uint64_t)base + WIN_BITS;
+#pragma unroll
+          for (int t = 0; t < WIN_WORDS / 256; ++t) reinterpret_cast<uint4 *>(win)[lane + 64 * t] = make_uint4(0u, 0u, 0u, 0u);
+          __builtin_amdgcn_wave_barrier();
+          while (ib < m) {                                  // ids of N(prev) below the window end: set bits
+            uint32_t v[4]; bool below[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int32_t idx = ib + u * 64 + lane; v[u] = idx < m ? B[idx] : 0xFFFFFFFFu; below[u] = idx < m && (uint64_t)v[u] < limit; }
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (below[u] && v[u] >= base && v[u] != xprev) { const uint32_t t = v[u] - base; atomicOr(&win[t >> 5], 1u << (t & 31)); }
+              cnt += __popcll(__ballot(below[u]));
+            }
+            ib += cnt;
+            if (cnt < 256) break;
+          }
+          __builtin_amdgcn_wave_barrier();
+          while (ia < deg) {                                // candidates below the window end: test bits
+            uint32_t v[4]; bool below[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int32_t idx = ia + u * 64 + lane; v[u] = idx < deg ? cs[idx] : 0xFFFFFFFFu; below[u] = idx < deg && (uint64_t)v[u] < limit; }
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (below[u] && v[u] >= base) {
+                const uint32_t t = v[u] - base;
+                if ((win[t >> 5] >> (t & 31)) & 1u) {
+                  const uint32_t orig = cp[ia + u * 64 + lane];
+                  const float w = row[orig].w;
+                  atomicAdd(&bins[orig >> csh], (double)w - (double)(w / q_));
+                }
+              }
+              cnt += __popcll(__ballot(below[u]));
+            }
+            ia += cnt;
+            if (cnt < 256) break;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // inclusive prefix over the bins, in place (exact additions)
+  {
+    constexpr int PER = BIN_CAP / 64;
+    double loc[PER];
+    double run = 0.0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const int j = lane * PER + i; run += (j < n_bins) ? bins[j] : 0.0; loc[i] = run; }
+    const double incl = wave_incl_scan_f64(run);
+    double excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0.0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const int j = lane * PER + i; if (j < n_bins) bins[j] = excl + loc[i]; }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const double *PQ = g.pq + rc.off;
+  const double S = PQ[deg - 1] + bins[n_bins - 1];
+  if (!(S > 0.0)) return -1;
+  const double p = (double)r;
+  auto chunk_end = [&](int32_t j) { const int64_t e = (((int64_t)j + 1) << csh) - 1; return (int32_t)(e < deg ? e : deg - 1); };
+  auto not_miss_end = [&](int32_t j) {
+    const int32_t k = chunk_end(j);
+    const double X = (PQ[k] + bins[j]) / S;
+    const double tol = (double)(k + 8) * 0x1p-51 * X;
+    return !(X + tol < p);
+  };
+  int32_t lo = 0, hi = n_bins - 1;                 // the chunk of the first not-certain-miss index lies in [lo, hi]
+  while (hi - lo >= 64) {
+    const int64_t span = (int64_t)hi - lo;
+    const int32_t j = lo + (int32_t)((span * (lane + 1)) >> 6);          // lane 63 probes hi
+    const unsigned long long mm = __ballot(not_miss_end(j));
+    if (!mm) return 0;                              // even the last candidate is a certain miss -> edges.head
+    const int f = __ffsll((long long)mm) - 1;
+    const int32_t jf = __builtin_amdgcn_readlane(j, f);
+    const int32_t jprev = f ? __builtin_amdgcn_readlane(j, f - 1) : lo - 1;
+    hi = jf; lo = jprev + 1;
+  }
+  int32_t jc;
+  {
+    const int32_t j = lo + lane;
+    const bool nm = j <= hi && not_miss_end(j);
+    const unsigned long long mm = __ballot(nm);
+    if (!mm) return 0;
+    jc = lo + (__ffsll((long long)mm) - 1);
+  }
+  // candidate-by-candidate evaluation of chunk jc
+  const int32_t k0 = (int32_t)((int64_t)jc << csh), k1 = chunk_end(jc);
+  double carry = jc ? bins[jc - 1] : 0.0;
+  served = 1;
+  for (int32_t base = k0; base <= k1; base += 64) {
+    const int32_t k = base + lane;
+    const bool valid = k <= k1;
+    double corr = 0.0, pqk = 0.0;
+    if (valid) {
+      const Ent e = row[k];
+      pqk = PQ[k];
+      if (e.id == b.prev) corr = (double)(e.w / p_) - (double)(e.w / q_);
+      else if (sorted_contains(B, m, (uint32_t)((int64_t)e.id - b.vmin))) corr = (double)e.w - (double)(e.w / q_);
+    }
+    const double incl = wave_incl_scan_f64(corr);
+    const double X = (pqk + carry + incl) / S;
+    const double tol = (double)(k + 8) * 0x1p-51 * X;
+    const bool nm = valid && !(X + tol < p);
+    const bool hit = X - tol >= p;
+    const unsigned long long mm = __ballot(nm);
+    if (mm) {
+      const int f = __ffsll((long long)mm) - 1;
+      if (__builtin_amdgcn_readlane((int)hit, f)) return base + f;
+      break;
+    }
+    carry += readlane_f64(incl, 63);
   }
   fallback = 1;
   return wave_chain_pick(row, deg, b, r, S);

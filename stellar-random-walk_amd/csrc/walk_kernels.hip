@@ -141,46 +141,64 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
                                                       int64_t n_verts, int64_t n_walkers, int32_t L,
                                                       int32_t first_walk, RngSpec rng, float p, float q,
                                                       int32_t *__restrict__ paths, int32_t *__restrict__ lens,
-                                                      DevCounters *ctr) {
-  __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BM_WORDS];
+                                                      DevCounters *ctr, unsigned long long *cursor, int32_t tune) {
+  __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
   const int lane = lane_id();
-  const int64_t wi = (blockIdx.x * (int64_t)TPB + threadIdx.x) >> 6;  // one wave per walker
-  if (wi >= n_walkers) return;
   Member mem; mem.mode = 0; mem.bm = bitmap[threadIdx.x >> 6]; mem.seg_base = 0;
+#ifdef SRW_PHASE_TIMING
+  const unsigned long long t_begin = wall_clock64();
+#endif
   const int64_t stride = (int64_t)L + 2;
-  int64_t it = wi / n_verts, vi = wi - it * n_verts;
-  const uint32_t iter = (uint32_t)(first_walk + it);
-  const int32_t src = verts[vi];
-  int32_t *path = paths + wi * stride;
-  if (lane == 0) path[0] = src;
-  int32_t prev = src, curr = src, len = 1;
-  unsigned long long degc = 0, degp = 0, fb = 0, dead = 0, fast = 0;
-  for (int32_t s = 1; s <= L + 1; ++s) {
-    const Row *rp = row_of(g, curr);
-    Row r; r.off = 0; r.deg = 0; r.flags = 0;
-    if (rp) r = *rp;
-    if (r.deg == 0) { dead = s > 1; break; }
-    Bias b = make_bias(g, p, q, prev, s > 1);
-    float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
-    unsigned f = 0, sv = 0;
-    int32_t k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);   // search over exact prefix sums
-    if (k < 0) { k = wave_pick_scan(g, r, b, mem, u, f); degc += (unsigned long long)r.deg; }
-    else { fast += sv; }
-    int32_t next = g.ent[r.off + k].id;
-    fb += f;
-    if (b.need_member) degp += (unsigned long long)b.prev_deg;
-    if (lane == 0) path[s] = next;
-    prev = curr; curr = next; ++len;
+  unsigned long long steps = 0, degc = 0, degp = 0, fb = 0, dead = 0, fast = 0;
+  // Persistent waves: a walker costs anything from a few to millions of entry reads, and a block's LDS is only
+  // released when its slowest wave ends — so every wave takes the next walker from a counter instead of owning one.
+  while (true) {
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(cursor, 1ull);
+    const int64_t wi = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab));
+    if (wi >= n_walkers) break;
+    int64_t it = wi / n_verts, vi = wi - it * n_verts;
+    const uint32_t iter = (uint32_t)(first_walk + it);
+    const int32_t src = verts[vi];
+    int32_t *path = paths + wi * stride;
+    if (lane == 0) path[0] = src;
+    int32_t prev = src, curr = src, len = 1;
+    for (int32_t s = 1; s <= L + 1; ++s) {
+      const Row *rp = row_of(g, curr);
+      Row r; r.off = 0; r.deg = 0; r.flags = 0;
+      if (rp) r = *rp;
+      if (r.deg == 0) { dead += s > 1; break; }
+      Bias b = make_bias(g, p, q, prev, s > 1);
+      float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
+      unsigned f = 0, sv = 0;
+      SRW_T0(mem);
+      int32_t k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);   // search over exact prefix sums
+      SRW_T1(mem, t_prefix);
+      if (k < 0 && !(tune & 8)) k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 3, (tune & 4) != 0);
+      if (k < 0) { k = wave_pick_scan(g, r, b, mem, u, f); degc += (unsigned long long)r.deg; }
+      else { fast += sv; }
+      int32_t next = g.ent[r.off + k].id;
+      fb += f;
+      if (b.need_member) degp += (unsigned long long)b.prev_deg;
+      if (lane == 0) path[s] = next;
+      prev = curr; curr = next; ++len;
+    }
+    for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
+    if (lane == 0) lens[wi] = len;
+    steps += (unsigned long long)(len - 1);
   }
-  for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
   if (lane == 0) {
-    lens[wi] = len;
-    atomicAdd(&ctr->steps, (unsigned long long)(len - 1));
+    if (steps) atomicAdd(&ctr->steps, steps);
     if (dead) atomicAdd(&ctr->dead_ends, dead);
-    atomicAdd(&ctr->sum_deg_curr, degc);
+    if (degc) atomicAdd(&ctr->sum_deg_curr, degc);
     if (degp) atomicAdd(&ctr->sum_deg_prev, degp);
     if (fb) atomicAdd(&ctr->fallbacks, fb);
     if (fast) atomicAdd(&ctr->ent_reads, fast);      // general kernel: steps served by the prefix-sum search
+#ifdef SRW_PHASE_TIMING
+    atomicAdd(&ctr->trials, mem.t_fill >> 10); atomicAdd(&ctr->dead_ends, mem.t_pass1 >> 10);
+    atomicAdd(&ctr->fallbacks, mem.t_pass2 >> 10); atomicAdd(&ctr->ent_reads, (wall_clock64() - t_begin) >> 10);
+#endif
   }
 }
 
@@ -578,9 +596,13 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
     else    { if (occ == 8) SRW_LAUNCH_FO(false, 8, false); else if (occ == 7) SRW_LAUNCH_FO(false, 7, false); else SRW_LAUNCH_FO(false, 1, false); }
 #undef SRW_LAUNCH_FO
   } else {
-    int64_t blocks = (n_walkers * 64 + TPB - 1) / TPB;
+    // persistent waves taking walkers from a cursor: enough blocks to fill every CU at the kernel's occupancy
+    int64_t blocks = std::min<int64_t>((n_walkers * 64 + TPB - 1) / TPB, (int64_t)h->n_cus * 8);
+    h->walk_cursor.ensure(1);
+    SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_walk_general, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
-                       P.walk_length, first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p);
+                       P.walk_length, first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p,
+                       (int32_t)(((P.flags >> 12) & 7) | ((P.flags & SRW_WALK_NO_BINNED) ? 8 : 0)));
   }
   SRW_HIP(hipGetLastError());
   LaunchInfo li;

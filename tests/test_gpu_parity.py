@@ -593,3 +593,59 @@ def test_empty_and_degenerate_inputs(eng, oracle, tmp_path):
         a = eng.walk(walk_length=6, num_walks=2, p=p, q=q, seed=1)
         b = g.walk(walk_length=6, num_walks=2, p=p, q=q, seed=1)
         assert np.array_equal(a[0], b[0]) and a[0].tolist() == [[7] * 8] * 2
+
+
+# ---- binned prefix-sum search (Mode R, q != 1): every intersection strategy, every row size ---------------------
+BINNED_TUNES = [0, 4 | 1, 4 | 2, 4 | 3]     # automatic; forced P1 / P2 / id-window on rows of ANY degree
+
+
+@pytest.mark.parametrize("case", ["rmat12", "rmat12w", "rmat11wd", "multi", "multi_neg"])
+def test_binned_search_all_strategies(eng, oracle, case):
+    if case.startswith("rmat"):
+        sc = int(case[4:6])
+        weighted, directed = "w" in case[6:], case.endswith("d")
+        s, d, w = rmat_lines(oracle, sc, edge_factor=16, weighted=weighted)
+    else:
+        rng = np.random.default_rng(11)
+        weighted, directed = True, False
+        s, d, w = random_multigraph(rng, 80, 900, True, id_lo=-30 if case == "multi_neg" else 3)
+    g = oracle.Graph.from_coo(s, d, w, directed=directed)
+    eng.load_coo(s, d, w, directed=directed)
+    for p, q in [(0.25, 4.0), (4.0, 0.5), (2.0, 2.0)]:
+        ref = g.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, threads=8)
+        for tune in BINNED_TUNES:
+            paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, binned_tune=tune)
+            assert np.array_equal(lens, ref[1]) and np.array_equal(paths, ref[0]), (case, p, q, tune)
+            if tune:
+                assert st["ent_reads"] > 0, "binned search was not exercised"
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, binned=False)
+        assert np.array_equal(paths, ref[0])
+        # draws exactly on CDF boundaries (constant r on the 2^-24 lattice)
+        for r in (0.5, 0.25):
+            refc = g.walk(p=p, q=q, walk_length=8, rng="const", const_r=r, threads=8)
+            for tune in BINNED_TUNES:
+                pc, lc, _ = eng.walk(p=p, q=q, walk_length=8, rng="const", const_r=r, binned_tune=tune)
+                assert np.array_equal(pc, refc[0]) and np.array_equal(lc, refc[1]), (case, p, q, tune, r)
+
+
+def test_binned_search_two_giant_hubs(eng, oracle):
+    # hubs 0 and 1 (degree ~100 000 each, > 65 536 so chunks are wider than 64 candidates) share half of their
+    # leaves and are adjacent: hub -> hub steps take the id-window intersection with tens of thousands of members
+    n = 100000
+    leaves0 = np.arange(10, 10 + n, dtype=np.int32)
+    leaves1 = np.arange(10 + n // 2, 10 + n // 2 + n, dtype=np.int32)
+    s = np.concatenate([np.zeros(n, np.int32), np.ones(n, np.int32), [0, 0]]).astype(np.int32)
+    d = np.concatenate([leaves0, leaves1, [1, 1]]).astype(np.int32)        # double edge between the hubs
+    rng = np.random.default_rng(3)
+    w = rng.integers(1, 9, len(s)).astype(np.float32)
+    g = oracle.Graph.from_coo(s, d, w)
+    eng.load_coo(s, d, w)
+    src = np.concatenate([[0, 1], leaves0[::7919], leaves1[::7877]]).astype(np.int32)
+    verts = eng.vertices()
+    idx = np.searchsorted(verts, src)
+    for p, q in [(0.25, 4.0), (4.0, 0.5)]:
+        rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=8, seed=29, threads=8)
+        for tune in (0, 3, 1):
+            paths, lens, st = eng.walk(p=p, q=q, walk_length=8, seed=29, binned_tune=tune)
+            assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl), (p, q, tune)
+            assert st["ent_reads"] > 0

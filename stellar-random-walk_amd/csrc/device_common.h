@@ -84,6 +84,7 @@ struct GraphView {
   const int32_t *owner_tab;  // sharded + SRW_CFG_OWNER_FROM_PARTITIONS: partition id per slot (-1 unknown), else null
   int32_t vmin;
   int64_t n_slots;
+  const float *sw;      // weight of each sorted entry (same indexing as sids / sperm)
 };
 
 // Philox4x32-10 (Random123).  Same constants as oracle/srw_oracle.c:orc_philox4x32_10.

@@ -72,6 +72,7 @@ struct Graph {
   DevBuf<uint32_t> msids;         // sharded mode only: sorted ids of the whole graph
   DevBuf<int32_t> owner_tab;      // sharded + SRW_CFG_OWNER_FROM_PARTITIONS: partition id per slot
   DevBuf<uint32_t> sperm;         // [n_entries] input-order position (inside the row) of each sorted entry
+  DevBuf<float> sw;               // [n_entries] weight of each sorted entry (= ent[off + sperm].w)
   DevBuf<FoEnt> fo;               // [n_entries], built lazily
   bool has_fo = false;
   DevBuf<CfoEnt> cfo;             // [n_entries] compact lattice records (optional)
@@ -82,15 +83,15 @@ struct Graph {
   DevBuf<uint8_t> pq_ok;          // [n_slots]
   bool has_pq = false; uint32_t pq_pbits = 0, pq_qbits = 0;
   DevBuf<uint64_t> ehash;         // Mode A: edge hash set (optional, built lazily when q != 1)
-  uint64_t ehash_mask = 0; bool has_ehash = false;
+  uint64_t ehash_mask = 0; bool has_ehash = false; bool use_ehash = false;   // built / used by the current call
   DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
   bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
   GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_cfo ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
-                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, has_ehash ? ehash.p : nullptr, ehash_mask,
-                     symmetric ? 1 : 0, owner_tab.p, vmin, n_slots}; }
+                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
+                     symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p}; }
 };
 
 struct WalkResult {
@@ -102,6 +103,9 @@ struct WalkResult {
 
 struct DevCounters {  // device-side accumulators, one 64-bit word each
   unsigned long long steps, dead_ends, sum_deg_curr, sum_deg_prev, ent_reads, fallbacks, owned_entries, trials;
+#ifdef SRW_PHASE_TIMING
+  unsigned long long dbg[24];   // wave-time per phase of the general kernel, 100 MHz ticks >> 10 (tools/phase_timing.py)
+#endif
 };
 
 }  // namespace srw

@@ -82,6 +82,16 @@ __global__ void k_low32(const uint64_t *__restrict__ in, int64_t n, uint32_t *__
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
     out[e] = (uint32_t)in[e];
 }
+// sorted ids + the weight of each sorted entry (so that a match in the sorted row needs no second, dependent read)
+__global__ void k_member_finish(const uint64_t *__restrict__ mk2, const uint32_t *__restrict__ sperm,
+                                const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n,
+                                uint32_t *__restrict__ sids, float *__restrict__ sw) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = mk2[e];
+    sids[e] = (uint32_t)k;
+    sw[e] = ent[rows[k >> 32].off + sperm[e]].w;
+  }
+}
 __global__ void k_owned_flags(const uint32_t *__restrict__ present, int64_t n_slots, int32_t vmin, int32_t rank,
                               int32_t world, const int32_t *__restrict__ otab, uint32_t *__restrict__ out) {
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x)
@@ -206,7 +216,7 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
 
   // 4. per-row sorted ids: built lazily (build_membership) — first-order walks never need them
   g.has_member = false;
-  g.sids.release(); g.sperm.release();
+  g.sids.release(); g.sperm.release(); g.sw.release();
   keys2.release(); temp.release();
 
   // 5. vertex list (walker seeds, ascending id) + global ranks
@@ -370,6 +380,7 @@ void build_membership(srw_handle *h) {
   const int64_t n = g.n_entries;
   g.sids.alloc((size_t)std::max<int64_t>(n, 1));
   g.sperm.alloc((size_t)std::max<int64_t>(n, 1));
+  g.sw.alloc((size_t)std::max<int64_t>(n, 1));
   if (n > 0) {
     DevBuf<uint64_t> mk, mk2; DevBuf<uint32_t> li; DevBuf<char> temp; DevBuf<unsigned long long> next_slot;
     mk.alloc((size_t)n); mk2.alloc((size_t)n); li.alloc((size_t)n); next_slot.alloc(1);
@@ -382,7 +393,8 @@ void build_membership(srw_handle *h) {
     temp.alloc(tb);
     SRW_HIP(rocprim::radix_sort_pairs((void *)temp.p, tb, mk.p, mk2.p, li.p, g.sperm.p, (size_t)n, 0u,
                                       (unsigned)(32 + id_bits), st));
-    hipLaunchKernelGGL(k_low32, dim3(grid_for(n)), dim3(TPB), 0, st, mk2.p, n, g.sids.p);
+    hipLaunchKernelGGL(k_member_finish, dim3(grid_for(n)), dim3(TPB), 0, st, mk2.p, g.sperm.p, g.rows.p, g.ent.p, n, g.sids.p,
+                       g.sw.p);
     SRW_HIP(hipStreamSynchronize(st));
     SRW_HIP(hipGetLastError());
   }

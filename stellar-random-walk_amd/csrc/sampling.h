@@ -188,16 +188,26 @@ struct Member {
   int mode;            // 0: not needed, 1: binary search per candidate, 2: bitmap
   uint32_t *bm;        // LDS, BM_WORDS words, private to the wave
   int32_t seg_base;    // first candidate position covered by the bitmap
+  const uint64_t *ehash = nullptr; uint64_t ehash_mask = 0;   // edge hash set (whole-graph handles): mode 1 probes it
 #ifdef SRW_PHASE_TIMING
   unsigned long long t_fill = 0, t_pass1 = 0, t_pass2 = 0, t_prefix = 0, t_mark;
+  unsigned long long t_a = 0, t_p1 = 0, t_p2 = 0, t_w = 0, t_fin = 0;
+  unsigned long long t_w_lb = 0, t_w_ins = 0, t_w_la = 0, t_w_probe = 0, t_mark2;
+  unsigned long long n_w = 0, n_w_elems = 0, n_w_windows = 0, n_p1 = 0, n_p1_elems = 0, n_binned = 0;
 #endif
 };
 #ifdef SRW_PHASE_TIMING
 #define SRW_T0(m) ((m).t_mark = wall_clock64())
 #define SRW_T1(m, f) ((m).f += wall_clock64() - (m).t_mark)
+#define SRW_U0(m) ((m).t_mark2 = wall_clock64())
+#define SRW_U1(m, f) ((m).f += wall_clock64() - (m).t_mark2)
+#define SRW_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define SRW_T0(m)
 #define SRW_T1(m, f)
+#define SRW_U0(m)
+#define SRW_U1(m, f)
+#define SRW_DRAIN()
 #endif
 
 __device__ inline float biased_weight_m(const Bias &b, const Member &m, int32_t pos, int32_t id, float w) {
@@ -206,6 +216,7 @@ __device__ inline float biased_weight_m(const Bias &b, const Member &m, int32_t 
   if (m.mode == 0) return w / b.q;
   bool in;
   if (m.mode == 2) { uint32_t t = (uint32_t)(pos - m.seg_base); in = (m.bm[t >> 5] >> (t & 31)) & 1u; }
+  else if (m.ehash) in = edge_exists(m.ehash, m.ehash_mask, (uint32_t)((int64_t)b.prev - b.vmin), (uint32_t)((int64_t)id - b.vmin));
   else in = sorted_contains(b.prev_sids, b.prev_deg, (uint32_t)((int64_t)id - b.vmin));
   return in ? w : w / b.q;
 }
@@ -332,7 +343,7 @@ __device__ inline int32_t wave_pick_scan(const GraphView &g, const Row &rc, cons
     int lp = 32 - __clz(b.prev_deg | 1), lc = 32 - __clz(deg | 1);
     int64_t nseg = ((int64_t)deg + BM_BITS - 1) / BM_BITS;
     const int64_t probe = (int64_t)b.prev_deg * lc, merged = ((int64_t)deg + b.prev_deg) / 2;
-    int64_t direct = 2ll * deg * lp, reverse = 2ll * nseg * (probe < merged ? probe : merged) + deg / 16;
+    int64_t direct = 2ll * deg * (m.ehash ? 2 : lp), reverse = 2ll * nseg * (probe < merged ? probe : merged) + deg / 16;
     m.mode = reverse < direct ? 2 : 1;
   }
   const int32_t seg_cap = (m.mode == 2) ? BM_BITS : 0x7FFFFFFF;
@@ -536,13 +547,20 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
 // The members of N(prev) among the candidates are found by the cheapest of three strategies over the SORTED rows:
 //   P1  every distinct id of N(prev) is searched in N(curr)                    ~ |N(prev)| log |N(curr)| probes
 //   P2  every candidate (input order, no permutation needed) is searched in N(prev) ~ |N(curr)| log |N(prev)| probes
-//   W   id-window bitmap: both sorted id lists are streamed once, coalesced, 256 ids per iteration; the ids of
-//       N(prev) inside the current window of 32768 vertex ids set bits in LDS, the ids of N(curr) test them
-//                                                                                ~ (|N(curr)| + |N(prev)|) / 256 iterations
-constexpr int BIN_CAP = 1024;                 // f64 bins: 8 KB of the wave's LDS
-constexpr int WIN_WORDS = 1024;               // id-window bitmap: 4 KB behind the bins
+//   W   id-window bitmap: both sorted id lists are streamed once in chunks of 1024 ids (16-byte loads, 16 ids per
+//       lane, kept in registers until their last id is below the window end); the ids of N(prev) inside the current
+//       window of 49152 vertex ids set bits in LDS (one non-returning ds_or each), the candidates test them (one
+//       ds_read each).  The window starts at the smallest id both lists still have, so empty id ranges cost nothing.
+//       (A hash set per chunk was tried: 3x the LDS operations, slower.)
+constexpr int BIN_CAP = 512;                  // f64 bins: 4 KB of the wave's LDS
+constexpr int WIN_WORDS = 1536;               // id-window bitmap behind the bins: 6 KB (49152 vertex ids)
 constexpr int WIN_BITS = WIN_WORDS * 32;
+constexpr int NE = 8;                       // ids per lane and chunk
+constexpr int HCHUNK = 64 * NE;
+constexpr uint32_t HEMPTY = 0xFFFFFFFFu;
 constexpr int BINNED_LDS_WORDS = 2 * BIN_CAP + WIN_WORDS;
+struct __attribute__((packed, aligned(4))) U32x4 { uint32_t a, b, c, d; };   // 16-byte load at 4-byte alignment
+struct __attribute__((packed, aligned(4))) F32x4 { float a, b, c, d; };
 
 __device__ inline int32_t wave_lower_bound_u32(const uint32_t *a, int32_t n, uint32_t x) {   // wave-uniform, 64-ary
   const int lane = lane_id();
@@ -569,13 +587,14 @@ __device__ inline int32_t wave_lower_bound_u32(const uint32_t *a, int32_t n, uin
 // tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W (tests force each one); force_small: no minimum degree
 __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
                                            uint32_t *lds, float r, unsigned &fallback, unsigned &served, int tune,
-                                           bool force_small) {
+                                           bool force_small, Member &tm) {
   if (!g.pq || !b.second_order || !b.need_member) return -1;
   const int32_t deg = rc.deg;
   if ((!force_small && deg < 128) || !g.pq_ok[curr_slot]) return -1;
   const int lane = lane_id();
   double *bins = reinterpret_cast<double *>(lds);
   uint32_t *win = lds + 2 * BIN_CAP;
+  SRW_T0(tm);
   int csh = 6;
   while ((((int64_t)deg + ((int64_t)1 << csh) - 1) >> csh) > BIN_CAP) ++csh;
   const int32_t n_bins = (int32_t)(((int64_t)deg + ((int64_t)1 << csh) - 1) >> csh);
@@ -583,6 +602,7 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
   __builtin_amdgcn_wave_barrier();
   const Ent *row = g.ent + rc.off;
   const uint32_t *cs = g.sids + rc.off, *cp = g.sperm + rc.off;
+  const float *csw = g.sw + rc.off;
   const uint32_t *B = b.prev_sids;
   const int32_t m = b.prev_deg;
   const uint32_t xprev = (uint32_t)((int64_t)b.prev - b.vmin);
@@ -596,28 +616,49 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
       atomicAdd(&bins[orig >> csh], (double)(w / p_) - (double)(w / q_));
     }
   }
+  SRW_T1(tm, t_a); SRW_T0(tm);
+  int strat = tune;
   // (b) members of N(prev)
   if (m > 0) {
     const int lc = 32 - __clz(deg | 1), lp = 32 - __clz(m | 1);
-    int strat = tune;
     if (strat == 0) {
+      // rough wave-cycles: a dependent probe chain ~ 10 cycles per level per element (5 with two in lockstep)
+      const int64_t c1 = (int64_t)m * lc * 5, c2 = (int64_t)deg * lp * 10;
       const uint32_t lo_id = max(cs[0], B[0]), hi_id = min(cs[deg - 1], B[m - 1]);
-      const int64_t nwin = lo_id > hi_id ? 0 : (int64_t)((hi_id - lo_id) >> 15) + 1;
-      const int64_t c1 = (int64_t)m * lc * 10, c2 = (int64_t)deg * lp * 10;
-      const int64_t cw = ((int64_t)deg + m) * 6 + (nwin < (int64_t)deg + m ? nwin : (int64_t)deg + m) * 300 + 4000;
+      const int64_t span = lo_id > hi_id ? 0 : (int64_t)((hi_id - lo_id) / WIN_BITS) + 1;
+      const int64_t nwin = span < ((int64_t)deg + m) / 8 ? span : ((int64_t)deg + m) / 8;
+      const int64_t cw = ((int64_t)deg + m) * 2 + nwin * 1000 + 4000;
       strat = (cw < c1 && cw < c2) ? 3 : (c1 <= c2 ? 1 : 2);
     }
+#ifdef SRW_PHASE_TIMING
+    tm.n_binned += 1;
+    if (strat == 1) { tm.n_p1 += 1; tm.n_p1_elems += m; }
+#endif
     if (strat == 1) {
-      for (int32_t t = lane; t < m; t += 64) {
-        const uint32_t x = B[t];
-        if (x == xprev || (t > 0 && B[t - 1] == x)) continue;
-        int32_t lo = 0, hi = deg;
-        while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < x) lo = mid + 1; else hi = mid; }
-        for (int32_t c = lo; c < deg && cs[c] == x; ++c) {
-          const uint32_t orig = cp[c];
-          const float w = row[orig].w;
-          atomicAdd(&bins[orig >> csh], (double)w - (double)(w / q_));
+      // two searches per lane in lockstep: twice the loads in flight on the dependent probe chain
+      for (int32_t t0 = lane; t0 < m; t0 += 128) {
+        int32_t tt[2] = {t0, t0 + 64};
+        uint32_t x[2]; bool act[2]; int32_t lo[2], hi[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          act[i] = tt[i] < m;
+          x[i] = act[i] ? B[tt[i]] : 0u;
+          if (act[i] && (x[i] == xprev || (tt[i] > 0 && B[tt[i] - 1] == x[i]))) act[i] = false;
+          lo[i] = 0; hi[i] = act[i] ? deg : 0;
         }
+        while (lo[0] < hi[0] || lo[1] < hi[1]) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (lo[i] < hi[i]) { const int32_t mid = lo[i] + ((hi[i] - lo[i]) >> 1); if (cs[mid] < x[i]) lo[i] = mid + 1; else hi[i] = mid; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (act[i])
+            for (int32_t c = lo[i]; c < deg && cs[c] == x[i]; ++c) {
+              const uint32_t orig = cp[c];
+              const float w = csw[c];
+              atomicAdd(&bins[orig >> csh], (double)w - (double)(w / q_));
+            }
       }
     } else if (strat == 2) {
       for (int32_t k = lane; k < deg; k += 64) {
@@ -629,56 +670,118 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
     } else {
       const uint32_t lo_id = max(cs[0], B[0]), hi_id = min(cs[deg - 1], B[m - 1]);
       if (lo_id <= hi_id) {
-        int32_t ia = wave_lower_bound_u32(cs, deg, lo_id), ib = wave_lower_bound_u32(B, m, lo_id);
-        while (ia < deg && ib < m) {
-          const uint32_t fa = cs[ia], fb = B[ib];
-          const uint32_t first = fa > fb ? fa : fb;
-          if (first > hi_id) break;
-          const uint32_t base = first & ~(uint32_t)(WIN_BITS - 1);
-          const uint64_t limit = (uint64_t)base + WIN_BITS;
+        int32_t pa = wave_lower_bound_u32(cs, deg, lo_id), pb = wave_lower_bound_u32(B, m, lo_id);
+        uint32_t AI[NE], AC[NE], BI[NE];
+        float AW[NE];
+        // element e = 4 * u + j of a lane sits at list position pos + 256 * u + 4 * lane + j: sorted in (u, lane, j)
+        auto load_ids = [&](const uint32_t *a_, int32_t pos, int32_t n_, uint32_t v[NE]) {
 #pragma unroll
-          for (int t = 0; t < WIN_WORDS / 256; ++t) reinterpret_cast<uint4 *>(win)[lane + 64 * t] = make_uint4(0u, 0u, 0u, 0u);
-          __builtin_amdgcn_wave_barrier();
-          while (ib < m) {                                  // ids of N(prev) below the window end: set bits
-            uint32_t v[4]; bool below[4];
+          for (int u = 0; u < NE / 4; ++u) {
+            const int32_t i0 = pos + 256 * u + 4 * lane;
+            if (i0 + 3 < n_) {
+              const U32x4 q = *reinterpret_cast<const U32x4 *>(a_ + i0);
+              v[4 * u] = q.a; v[4 * u + 1] = q.b; v[4 * u + 2] = q.c; v[4 * u + 3] = q.d;
+            } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int32_t idx = ib + u * 64 + lane; v[u] = idx < m ? B[idx] : 0xFFFFFFFFu; below[u] = idx < m && (uint64_t)v[u] < limit; }
-            int cnt = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              if (below[u] && v[u] >= base && v[u] != xprev) { const uint32_t t = v[u] - base; atomicOr(&win[t >> 5], 1u << (t & 31)); }
-              cnt += __popcll(__ballot(below[u]));
+              for (int j = 0; j < 4; ++j) v[4 * u + j] = (i0 + j < n_) ? a_[i0 + j] : HEMPTY;
             }
-            ib += cnt;
-            if (cnt < 256) break;
           }
+        };
+        auto load_w = [&](int32_t pos, float v[NE]) {
+#pragma unroll
+          for (int u = 0; u < NE / 4; ++u) {
+            const int32_t i0 = pos + 256 * u + 4 * lane;
+            if (i0 + 3 < deg) {
+              const F32x4 q = *reinterpret_cast<const F32x4 *>(csw + i0);
+              v[4 * u] = q.a; v[4 * u + 1] = q.b; v[4 * u + 2] = q.c; v[4 * u + 3] = q.d;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[4 * u + j] = (i0 + j < deg) ? csw[i0 + j] : 0.0f;
+            }
+          }
+        };
+        auto chunk_max = [&](const uint32_t v[NE], int32_t pos, int32_t n_) {       // last (= largest) valid id
+          uint32_t l = 0;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) if (pos + 256 * (e >> 2) + 4 * lane + (e & 3) < n_) l = max(l, v[e]);
+          return wave_max_u32(l);
+        };
+        auto chunk_next = [&](const uint32_t v[NE], int32_t pos, int32_t n_, uint64_t limit) {   // smallest id >= limit
+          uint32_t l = HEMPTY;
+#pragma unroll
+          for (int e = 0; e < NE; ++e)
+            if (pos + 256 * (e >> 2) + 4 * lane + (e & 3) < n_ && (uint64_t)v[e] >= limit) l = min(l, v[e]);
+          return wave_min_u32(l);
+        };
+        load_ids(B, pb, m, BI);
+        load_ids(cs, pa, deg, AI); load_ids(cp, pa, deg, AC); load_w(pa, AW);
+        SRW_U0(tm); SRW_DRAIN(); SRW_U1(tm, t_w_lb);
+        uint32_t amax = chunk_max(AI, pa, deg), bmax = chunk_max(BI, pb, m);
+        uint32_t next_a = lo_id, next_b = lo_id;      // lower bounds of the smallest ids not consumed yet
+        bool dirty = true;
+#ifdef SRW_PHASE_TIMING
+        tm.n_w += 1; tm.n_w_elems += (unsigned long long)(deg - pa) + (m - pb);
+#endif
+        while (true) {
+          const uint32_t base = next_a > next_b ? next_a : next_b;
+          if (base > hi_id) break;
+          const uint64_t limit = (uint64_t)base + WIN_BITS;
+#ifdef SRW_PHASE_TIMING
+          tm.n_w_windows += 1;
+#endif
+          SRW_U0(tm);
+          if (dirty) {
+#pragma unroll
+            for (int t = 0; t < WIN_WORDS / 256; ++t) reinterpret_cast<uint4 *>(win)[lane + 64 * t] = make_uint4(0u, 0u, 0u, 0u);
+            __builtin_amdgcn_wave_barrier();
+          }
+          bool marked = false, a_done = false, b_done = false;
+          while (true) {                                     // ids of N(prev) inside the window: set bits
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+              const bool in = (pb + 256 * (e >> 2) + 4 * lane + (e & 3)) < m && BI[e] >= base && (uint64_t)BI[e] < limit && BI[e] != xprev;
+              if (in) { const uint32_t t = BI[e] - base; atomicOr(&win[t >> 5], 1u << (t & 31)); marked = true; }
+            }
+            if ((uint64_t)bmax >= limit) { next_b = chunk_next(BI, pb, m, limit); break; }
+            pb += HCHUNK;
+            if (pb >= m) { b_done = true; break; }
+            load_ids(B, pb, m, BI);
+            SRW_U1(tm, t_w_ins); SRW_U0(tm); SRW_DRAIN(); SRW_U1(tm, t_w_lb); SRW_U0(tm);
+            bmax = chunk_max(BI, pb, m);
+          }
+          dirty = __any(marked);
           __builtin_amdgcn_wave_barrier();
-          while (ia < deg) {                                // candidates below the window end: test bits
-            uint32_t v[4]; bool below[4];
+          SRW_U1(tm, t_w_ins); SRW_U0(tm);
+          while (true) {                                     // candidates inside the window: test bits
+            if (dirty) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int32_t idx = ia + u * 64 + lane; v[u] = idx < deg ? cs[idx] : 0xFFFFFFFFu; below[u] = idx < deg && (uint64_t)v[u] < limit; }
-            int cnt = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              if (below[u] && v[u] >= base) {
-                const uint32_t t = v[u] - base;
-                if ((win[t >> 5] >> (t & 31)) & 1u) {
-                  const uint32_t orig = cp[ia + u * 64 + lane];
-                  const float w = row[orig].w;
-                  atomicAdd(&bins[orig >> csh], (double)w - (double)(w / q_));
+              for (int e = 0; e < NE; ++e) {
+                const bool in = (pa + 256 * (e >> 2) + 4 * lane + (e & 3)) < deg && AI[e] >= base && (uint64_t)AI[e] < limit;
+                if (in) {
+                  const uint32_t t = AI[e] - base;
+                  if ((win[t >> 5] >> (t & 31)) & 1u) atomicAdd(&bins[AC[e] >> csh], (double)AW[e] - (double)(AW[e] / q_));
                 }
               }
-              cnt += __popcll(__ballot(below[u]));
             }
-            ia += cnt;
-            if (cnt < 256) break;
+            if ((uint64_t)amax >= limit) { next_a = chunk_next(AI, pa, deg, limit); break; }
+            pa += HCHUNK;
+            if (pa >= deg) { a_done = true; break; }
+            load_ids(cs, pa, deg, AI); load_ids(cp, pa, deg, AC); load_w(pa, AW);
+            SRW_U1(tm, t_w_probe); SRW_U0(tm); SRW_DRAIN(); SRW_U1(tm, t_w_la); SRW_U0(tm);
+            amax = chunk_max(AI, pa, deg);
           }
           __builtin_amdgcn_wave_barrier();
+          SRW_U1(tm, t_w_probe);
+          if (a_done || b_done) break;
         }
       }
     }
   }
   __builtin_amdgcn_wave_barrier();
+#ifdef SRW_PHASE_TIMING
+  if (strat == 1) SRW_T1(tm, t_p1); else if (strat == 2) SRW_T1(tm, t_p2); else SRW_T1(tm, t_w);
+  SRW_T0(tm);
+#endif
   // inclusive prefix over the bins, in place (exact additions)
   {
     constexpr int PER = BIN_CAP / 64;
@@ -736,7 +839,12 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
       const Ent e = row[k];
       pqk = PQ[k];
       if (e.id == b.prev) corr = (double)(e.w / p_) - (double)(e.w / q_);
-      else if (sorted_contains(B, m, (uint32_t)((int64_t)e.id - b.vmin))) corr = (double)e.w - (double)(e.w / q_);
+      else {
+        const uint32_t xs = (uint32_t)((int64_t)e.id - b.vmin);
+        // one probe of the edge hash set (prev -> x) instead of a log2|N(prev)|-deep dependent search
+        const bool in = g.ehash ? edge_exists(g.ehash, g.ehash_mask, xprev, xs) : sorted_contains(B, m, xs);
+        if (in) corr = (double)e.w - (double)(e.w / q_);
+      }
     }
     const double incl = wave_incl_scan_f64(corr);
     const double X = (pqk + carry + incl) / S;
@@ -746,6 +854,7 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
     const unsigned long long mm = __ballot(nm);
     if (mm) {
       const int f = __ffsll((long long)mm) - 1;
+      SRW_T1(tm, t_fin);
       if (__builtin_amdgcn_readlane((int)hit, f)) return base + f;
       break;
     }

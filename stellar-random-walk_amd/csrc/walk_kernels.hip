@@ -137,7 +137,7 @@ __device__ inline Bias make_bias(const GraphView &g, float p, float q, int32_t p
   return b;
 }
 
-__global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t *__restrict__ verts,
+__global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int32_t *__restrict__ verts,
                                                       int64_t n_verts, int64_t n_walkers, int32_t L,
                                                       int32_t first_walk, RngSpec rng, float p, float q,
                                                       int32_t *__restrict__ paths, int32_t *__restrict__ lens,
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
   __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
   const int lane = lane_id();
   Member mem; mem.mode = 0; mem.bm = bitmap[threadIdx.x >> 6]; mem.seg_base = 0;
+  mem.ehash = g.ehash; mem.ehash_mask = g.ehash_mask;
 #ifdef SRW_PHASE_TIMING
   const unsigned long long t_begin = wall_clock64();
 #endif
@@ -173,9 +174,11 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
       float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
       unsigned f = 0, sv = 0;
       SRW_T0(mem);
-      int32_t k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);   // search over exact prefix sums
+      // search over exact prefix sums: a short list of specials (return edges only) when q == 1, position bins else
+      int32_t k = -1;
+      if (!b.need_member || (tune & 8)) k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);
       SRW_T1(mem, t_prefix);
-      if (k < 0 && !(tune & 8)) k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 3, (tune & 4) != 0);
+      if (k < 0 && !(tune & 8)) k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 3, (tune & 4) != 0, mem);
       if (k < 0) { k = wave_pick_scan(g, r, b, mem, u, f); degc += (unsigned long long)r.deg; }
       else { fast += sv; }
       int32_t next = g.ent[r.off + k].id;
@@ -196,8 +199,12 @@ __global__ __launch_bounds__(TPB) void k_walk_general(GraphView g, const int32_t
     if (fb) atomicAdd(&ctr->fallbacks, fb);
     if (fast) atomicAdd(&ctr->ent_reads, fast);      // general kernel: steps served by the prefix-sum search
 #ifdef SRW_PHASE_TIMING
-    atomicAdd(&ctr->trials, mem.t_fill >> 10); atomicAdd(&ctr->dead_ends, mem.t_pass1 >> 10);
-    atomicAdd(&ctr->fallbacks, mem.t_pass2 >> 10); atomicAdd(&ctr->ent_reads, (wall_clock64() - t_begin) >> 10);
+    const unsigned long long tv[10] = {wall_clock64() - t_begin, mem.t_prefix, mem.t_a, mem.t_p1, mem.t_p2, mem.t_w,
+                                       mem.t_fin, mem.t_fill, mem.t_pass1, mem.t_pass2};
+    for (int i = 0; i < 10; ++i) atomicAdd(&ctr->dbg[i], tv[i] >> 10);
+    atomicAdd(&ctr->dbg[10], mem.n_w); atomicAdd(&ctr->dbg[11], mem.n_w_elems); atomicAdd(&ctr->dbg[12], mem.n_w_windows);
+    atomicAdd(&ctr->dbg[13], mem.n_p1); atomicAdd(&ctr->dbg[14], mem.n_p1_elems); atomicAdd(&ctr->dbg[15], mem.n_binned);
+    atomicAdd(&ctr->dbg[16], mem.t_w_lb >> 10); atomicAdd(&ctr->dbg[17], mem.t_w_ins >> 10); atomicAdd(&ctr->dbg[18], mem.t_w_la >> 10); atomicAdd(&ctr->dbg[19], mem.t_w_probe >> 10);
 #endif
   }
 }
@@ -521,6 +528,18 @@ void read_counters(srw_handle *h, srw_walk_stats *stats) {
   DevCounters c;
   SRW_HIP(hipMemcpyAsync(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   SRW_HIP(hipStreamSynchronize(h->stream));
+#ifdef SRW_PHASE_TIMING
+  {
+    static const char *nm[10] = {"total", "prefix", "binned:ret-edges", "binned:P1", "binned:P2", "binned:W", "binned:search+resolve",
+                                 "scan:fill", "scan:pass1", "scan:pass2"};
+    fprintf(stderr, "[phase] wave-ms:");
+    for (int i = 0; i < 10; ++i) fprintf(stderr, " %s %.0f", nm[i], (double)c.dbg[i] * 1024.0 / 100e3);
+    fprintf(stderr, "\n[phase] W calls %llu elems %llu windows %llu | P1 calls %llu elems %llu | binned steps %llu\n", c.dbg[10], c.dbg[11],
+            c.dbg[12], c.dbg[13], c.dbg[14], c.dbg[15]);
+    fprintf(stderr, "[phase] W detail wave-ms: wait-B %.0f clear+insert %.0f wait-A %.0f probe %.0f\n", (double)c.dbg[16] * 1024.0 / 100e3,
+            (double)c.dbg[17] * 1024.0 / 100e3, (double)c.dbg[18] * 1024.0 / 100e3, (double)c.dbg[19] * 1024.0 / 100e3);
+  }
+#endif
   if (!stats) return;
   stats->n_steps = (int64_t)c.steps; stats->dead_ends = (int64_t)c.dead_ends;
   stats->sum_deg_curr = (int64_t)c.sum_deg_curr; stats->sum_deg_prev = (int64_t)c.sum_deg_prev;
@@ -617,8 +636,12 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   if (first_order) build_first_order_tables(h, P.rng_mode != SRW_RNG_PHILOX || (P.flags & SRW_WALK_NO_COMPACT));
   else build_membership(h);                           // sorted rows: general and alias kernels only
   if (alias) build_alias_tables(h);
-  if (alias && P.q != 1.0f && !(P.flags & SRW_WALK_NO_EDGE_HASH)) build_edge_hash(h);
-  if (alias && (P.flags & SRW_WALK_NO_EDGE_HASH)) { h->g.has_ehash = false; }
+  const bool general = !alias && !first_order;
+  // the edge hash set answers "x in N(prev)?" in one probe: Mode A's rejection test, and the general kernel's
+  // candidate-by-candidate membership (small rows, the located chunk of the binned search)
+  const bool want_ehash = P.q != 1.0f && !(P.flags & SRW_WALK_NO_EDGE_HASH) && (alias || (general && h->cfg.world == 1));
+  if (want_ehash) build_edge_hash(h);
+  h->g.use_ehash = want_ehash;
   if (!alias && !first_order && !(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX))
     build_pq_tables(h, P.p, P.q);                    // optional: exact base prefix sums for the search sampler
   else if (!alias && !first_order) h->g.has_pq = false;

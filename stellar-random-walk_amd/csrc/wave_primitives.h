@@ -34,6 +34,14 @@ __device__ inline int wave_max_i32(int v) {
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   return v;
 }
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+  return v;
+}
+__device__ inline uint32_t wave_max_u32(uint32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  return v;
+}
 __device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;

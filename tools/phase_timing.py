@@ -11,5 +11,4 @@ for (p, q) in ((0.25, 4.0), (4.0, 0.5)):
     ms = st["kernel_ms"]
     # wall_clock64 ticks at 100 MHz; counters were >> 10
     tick = 1024 / 100e6 * 1e3  # ms of one wave per counter unit
-    print(f"p={p} q={q}: {st['n_steps']/ms/1e3:.1f} Msteps/s, kernel {ms:.0f} ms; wave-ms: fill {st['trials']*tick:.0f} pass1 {st['dead_ends']*tick:.0f} "
-          f"pass2 {st['fallbacks']*tick:.0f} total {st['ent_reads']*tick:.0f}; scanned entries/step {st['sum_deg_curr']/st['n_steps']:.0f}", flush=True)
+    print(f"p={p} q={q}: {st['n_steps']/ms/1e3:.1f} Msteps/s, kernel {ms:.0f} ms", flush=True)

@@ -18,7 +18,8 @@ struct alignas(16) Row {
   int32_t deg;
   uint32_t flags;
 };
-enum : uint32_t { ROW_PRESENT = 1u, ROW_IRREGULAR = 2u, ROW_ALIAS_IRREGULAR = 4u };
+enum : uint32_t { ROW_PRESENT = 1u, ROW_IRREGULAR = 2u, ROW_ALIAS_IRREGULAR = 4u,
+                  ROW_PQ_OK = 8u };   // certified for the prefix-sum samplers under the current call's (p, q); set by k_pq_*
 
 struct alignas(8) Ent {
   int32_t id;

@@ -332,11 +332,12 @@ __device__ inline bool pq_row_ok(int emin, int emax, bool bad, int32_t n) {
   return ceil_log2_i64(n) + 2 + emax - emin <= 29;    // +2: headroom for sums of differences of variants
 }
 
-__global__ void k_pq_small(const Row *__restrict__ rows, const Ent *__restrict__ ent, double *__restrict__ pq,
+__global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, double *__restrict__ pq,
                            uint8_t *__restrict__ ok, int64_t n_slots, float p, float q) {
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
     Row r = rows[v];
     ok[v] = 0;
+    if (r.flags & ROW_PQ_OK) rows[v].flags = r.flags & ~ROW_PQ_OK;   // the flag mirrors ok[v] (one load less per step)
     if (r.deg <= 0 || r.deg > SMALL_DEG) continue;
     PqCert c;
     for (int32_t k = 0; k < r.deg; ++k) { float w = ent[r.off + k].w; c.add(w); c.add(w / q); c.add(w / p); }
@@ -344,10 +345,11 @@ __global__ void k_pq_small(const Row *__restrict__ rows, const Ent *__restrict__
     double acc = 0.0;
     for (int32_t k = 0; k < r.deg; ++k) { acc += (double)(ent[r.off + k].w / q); pq[r.off + k] = acc; }
     ok[v] = 1;
+    rows[v].flags = r.flags | ROW_PQ_OK;
   }
 }
 
-__global__ void k_pq_large(const Row *__restrict__ rows, const Ent *__restrict__ ent, double *__restrict__ pq,
+__global__ void k_pq_large(Row *__restrict__ rows, const Ent *__restrict__ ent, double *__restrict__ pq,
                            uint8_t *__restrict__ ok, int64_t n_slots, float p, float q, unsigned long long *next_slot) {
   const int lane = lane_id();
   while (true) {
@@ -373,7 +375,7 @@ __global__ void k_pq_large(const Row *__restrict__ rows, const Ent *__restrict__
         if (k < r.deg) pq[r.off + k] = carry + x;
         carry += readlane_f64(x, 63);
       }
-      if (lane == 0) ok[v] = 1;
+      if (lane == 0) { ok[v] = 1; rows[v].flags = r.flags | ROW_PQ_OK; }
     }
   }
 }

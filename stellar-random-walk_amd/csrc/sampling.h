@@ -450,7 +450,7 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
                                            uint32_t *lds, float r, unsigned &fallback, unsigned &served) {
   if (!g.pq || !b.second_order) return -1;
   const int32_t deg = rc.deg;
-  if (deg < 128 || !g.pq_ok[curr_slot]) return -1;
+  if (deg < 128 || !(rc.flags & ROW_PQ_OK)) return -1;
   const int lc = 32 - __clz(deg | 1);
   if (b.need_member && (int64_t)b.prev_deg * (lc + 2) > (int64_t)deg * 2) return -1;   // marking would cost more than streaming
   if (b.need_member && b.prev_deg > 2048) return -1;   // two large rows share too many neighbors for the LDS list
@@ -584,13 +584,48 @@ __device__ inline int32_t wave_lower_bound_u32(const uint32_t *a, int32_t n, uin
   }
 }
 
+// K wave-uniform lower bounds advanced in lockstep: the probes of one round are independent loads, so K searches cost
+// the round trips of one.
+struct LowerBound { const uint32_t *a; int32_t lo, hi; uint32_t x; bool done; };
+template <int K>
+__device__ inline void wave_lower_bound_multi(LowerBound (&s)[K]) {
+  const int lane = lane_id();
+  while (true) {
+    bool act[K], ge[K];
+    int32_t k[K];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      act[i] = false; ge[i] = false; k[i] = 0;
+      if (s[i].done) continue;
+      const int32_t span = s[i].hi - s[i].lo;
+      if (span <= 0) { s[i].done = true; continue; }
+      act[i] = true; any = true;
+      k[i] = span <= 64 ? s[i].lo + lane : s[i].lo + (int32_t)(((int64_t)span * lane) >> 6);
+      ge[i] = k[i] < s[i].hi && s[i].a[k[i]] >= s[i].x;
+    }
+    if (!any) break;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      if (!act[i]) continue;
+      const int32_t span = s[i].hi - s[i].lo;
+      const unsigned long long m = __ballot(ge[i]);
+      if (span <= 64) { s[i].lo = m ? s[i].lo + (__ffsll((long long)m) - 1) : s[i].hi; s[i].done = true; continue; }
+      if (!m) { s[i].lo = __builtin_amdgcn_readlane(k[i], 63) + 1; continue; }
+      const int f = __ffsll((long long)m) - 1;
+      s[i].hi = __builtin_amdgcn_readlane(k[i], f);
+      if (f) s[i].lo = __builtin_amdgcn_readlane(k[i], f - 1) + 1;
+    }
+  }
+}
+
 // tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W (tests force each one); force_small: no minimum degree
 __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
                                            uint32_t *lds, float r, unsigned &fallback, unsigned &served, int tune,
                                            bool force_small, Member &tm) {
   if (!g.pq || !b.second_order || !b.need_member) return -1;
   const int32_t deg = rc.deg;
-  if ((!force_small && deg < 128) || !g.pq_ok[curr_slot]) return -1;
+  if ((!force_small && deg < 128) || !(rc.flags & ROW_PQ_OK)) return -1;
   const int lane = lane_id();
   double *bins = reinterpret_cast<double *>(lds);
   uint32_t *win = lds + 2 * BIN_CAP;
@@ -607,29 +642,35 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
   const int32_t m = b.prev_deg;
   const uint32_t xprev = (uint32_t)((int64_t)b.prev - b.vmin);
   const float p_ = b.p, q_ = b.q;
-  // (a) return edges: occurrences of prev in N(curr)
-  {
-    const int32_t lo = wave_lower_bound_u32(cs, deg, xprev);
-    for (int32_t c = lo + lane; c < deg && cs[c] == xprev; c += 64) {
-      const uint32_t orig = cp[c];
-      const float w = row[orig].w;
-      atomicAdd(&bins[orig >> csh], (double)(w / p_) - (double)(w / q_));
-    }
-  }
-  SRW_T1(tm, t_a); SRW_T0(tm);
+  // strategy for (b) first, so that every wave-uniform lower bound this step needs is searched in one lockstep pass
   int strat = tune;
-  // (b) members of N(prev)
-  if (m > 0) {
-    const int lc = 32 - __clz(deg | 1), lp = 32 - __clz(m | 1);
+  uint32_t lo_id = 1u, hi_id = 0u;
+  if (m > 0 && (strat == 0 || strat == 3)) {
+    lo_id = max(cs[0], B[0]); hi_id = min(cs[deg - 1], B[m - 1]);
     if (strat == 0) {
+      const int lc = 32 - __clz(deg | 1), lp = 32 - __clz(m | 1);
       // rough wave-cycles: a dependent probe chain ~ 10 cycles per level per element (5 with two in lockstep)
-      const int64_t c1 = (int64_t)m * lc * 5, c2 = (int64_t)deg * lp * 10;
-      const uint32_t lo_id = max(cs[0], B[0]), hi_id = min(cs[deg - 1], B[m - 1]);
+      const int64_t c1 = (int64_t)m * lc * 5, c2 = (int64_t)deg * (g.ehash ? 6 : lp) * 10;
       const int64_t span = lo_id > hi_id ? 0 : (int64_t)((hi_id - lo_id) / WIN_BITS) + 1;
       const int64_t nwin = span < ((int64_t)deg + m) / 8 ? span : ((int64_t)deg + m) / 8;
       const int64_t cw = ((int64_t)deg + m) * 2 + nwin * 1000 + 4000;
       strat = (cw < c1 && cw < c2) ? 3 : (c1 <= c2 ? 1 : 2);
     }
+  }
+  int32_t ret_lo, pa = 0, pb = 0;
+  if (strat == 3 && lo_id <= hi_id) {
+    LowerBound lb[3] = {{cs, 0, deg, xprev, false}, {cs, 0, deg, lo_id, false}, {B, 0, m, lo_id, false}};
+    wave_lower_bound_multi<3>(lb);
+    ret_lo = lb[0].lo; pa = lb[1].lo; pb = lb[2].lo;
+  } else {
+    ret_lo = wave_lower_bound_u32(cs, deg, xprev);
+  }
+  // (a) return edges: occurrences of prev in N(curr)
+  for (int32_t c = ret_lo + lane; c < deg && cs[c] == xprev; c += 64)
+    atomicAdd(&bins[cp[c] >> csh], (double)(csw[c] / p_) - (double)(csw[c] / q_));
+  SRW_T1(tm, t_a); SRW_T0(tm);
+  // (b) members of N(prev)
+  if (m > 0) {
 #ifdef SRW_PHASE_TIMING
     tm.n_binned += 1;
     if (strat == 1) { tm.n_p1 += 1; tm.n_p1_elems += m; }
@@ -668,9 +709,7 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
           atomicAdd(&bins[k >> csh], (double)e.w - (double)(e.w / q_));
       }
     } else {
-      const uint32_t lo_id = max(cs[0], B[0]), hi_id = min(cs[deg - 1], B[m - 1]);
       if (lo_id <= hi_id) {
-        int32_t pa = wave_lower_bound_u32(cs, deg, lo_id), pb = wave_lower_bound_u32(B, m, lo_id);
         uint32_t AI[NE], AC[NE], BI[NE];
         float AW[NE];
         // element e = 4 * u + j of a lane sits at list position pos + 256 * u + 4 * lane + j: sorted in (u, lane, j)
@@ -715,7 +754,6 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
         };
         load_ids(B, pb, m, BI);
         load_ids(cs, pa, deg, AI); load_ids(cp, pa, deg, AC); load_w(pa, AW);
-        SRW_U0(tm); SRW_DRAIN(); SRW_U1(tm, t_w_lb);
         uint32_t amax = chunk_max(AI, pa, deg), bmax = chunk_max(BI, pb, m);
         uint32_t next_a = lo_id, next_b = lo_id;      // lower bounds of the smallest ids not consumed yet
         bool dirty = true;
@@ -729,49 +767,48 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
 #ifdef SRW_PHASE_TIMING
           tm.n_w_windows += 1;
 #endif
-          SRW_U0(tm);
           if (dirty) {
 #pragma unroll
             for (int t = 0; t < WIN_WORDS / 256; ++t) reinterpret_cast<uint4 *>(win)[lane + 64 * t] = make_uint4(0u, 0u, 0u, 0u);
             __builtin_amdgcn_wave_barrier();
           }
           bool marked = false, a_done = false, b_done = false;
+          // v in [base, limit)  <=>  (uint32)(v - base) < width (unsigned wrap); padding ids (0xFFFFFFFF) never qualify
+          const uint32_t width = (uint32_t)((limit > 0xFFFFFFFFull ? 0xFFFFFFFFull : limit) - base);
           while (true) {                                     // ids of N(prev) inside the window: set bits
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-              const bool in = (pb + 256 * (e >> 2) + 4 * lane + (e & 3)) < m && BI[e] >= base && (uint64_t)BI[e] < limit && BI[e] != xprev;
-              if (in) { const uint32_t t = BI[e] - base; atomicOr(&win[t >> 5], 1u << (t & 31)); marked = true; }
+              const uint32_t t = BI[e] - base;
+              if (t < width) { atomicOr(&win[t >> 5], 1u << (t & 31)); marked = true; }
             }
             if ((uint64_t)bmax >= limit) { next_b = chunk_next(BI, pb, m, limit); break; }
             pb += HCHUNK;
             if (pb >= m) { b_done = true; break; }
             load_ids(B, pb, m, BI);
-            SRW_U1(tm, t_w_ins); SRW_U0(tm); SRW_DRAIN(); SRW_U1(tm, t_w_lb); SRW_U0(tm);
             bmax = chunk_max(BI, pb, m);
+          }
+          {                                                  // prev itself is a return edge, not a member
+            const uint32_t t = xprev - base;
+            if (t < width && lane == 0) atomicAnd(&win[t >> 5], ~(1u << (t & 31)));
           }
           dirty = __any(marked);
           __builtin_amdgcn_wave_barrier();
-          SRW_U1(tm, t_w_ins); SRW_U0(tm);
           while (true) {                                     // candidates inside the window: test bits
             if (dirty) {
 #pragma unroll
               for (int e = 0; e < NE; ++e) {
-                const bool in = (pa + 256 * (e >> 2) + 4 * lane + (e & 3)) < deg && AI[e] >= base && (uint64_t)AI[e] < limit;
-                if (in) {
-                  const uint32_t t = AI[e] - base;
-                  if ((win[t >> 5] >> (t & 31)) & 1u) atomicAdd(&bins[AC[e] >> csh], (double)AW[e] - (double)(AW[e] / q_));
-                }
+                const uint32_t t = AI[e] - base;
+                if (t < width && ((win[t >> 5] >> (t & 31)) & 1u))
+                  atomicAdd(&bins[AC[e] >> csh], (double)AW[e] - (double)(AW[e] / q_));
               }
             }
             if ((uint64_t)amax >= limit) { next_a = chunk_next(AI, pa, deg, limit); break; }
             pa += HCHUNK;
             if (pa >= deg) { a_done = true; break; }
             load_ids(cs, pa, deg, AI); load_ids(cp, pa, deg, AC); load_w(pa, AW);
-            SRW_U1(tm, t_w_probe); SRW_U0(tm); SRW_DRAIN(); SRW_U1(tm, t_w_la); SRW_U0(tm);
             amax = chunk_max(AI, pa, deg);
           }
           __builtin_amdgcn_wave_barrier();
-          SRW_U1(tm, t_w_probe);
           if (a_done || b_done) break;
         }
       }

@@ -165,12 +165,14 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     int32_t *path = paths + wi * stride;
     if (lane == 0) path[0] = src;
     int32_t prev = src, curr = src, len = 1;
+    Row rprev; rprev.off = 0; rprev.deg = 0; rprev.flags = 0;
     for (int32_t s = 1; s <= L + 1; ++s) {
       const Row *rp = row_of(g, curr);
       Row r; r.off = 0; r.deg = 0; r.flags = 0;
       if (rp) r = *rp;
       if (r.deg == 0) { dead += s > 1; break; }
-      Bias b = make_bias(g, p, q, prev, s > 1);
+      Bias b = make_bias(g, p, q, prev, s > 1);     // need_member: N(prev) from the membership structure ...
+      if (b.need_member) { b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; }   // ... = last step's row here
       float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
       unsigned f = 0, sv = 0;
       SRW_T0(mem);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
       fb += f;
       if (b.need_member) degp += (unsigned long long)b.prev_deg;
       if (lane == 0) path[s] = next;
-      prev = curr; curr = next; ++len;
+      prev = curr; curr = next; ++len; rprev = r;
     }
     for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
     if (lane == 0) lens[wi] = len;
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *_
                                                     RngSpec rng, float p, float q, int32_t world,
                                                     Walker *__restrict__ out, unsigned long long *cursors,
                                                     int32_t *__restrict__ paths, int64_t stride, DevCounters *ctr) {
-  __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BM_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
   const int lane = lane_id();
   const int64_t ri = (blockIdx.x * (int64_t)TPB + threadIdx.x) >> 6;
   if (ri >= n_in) return;
@@ -405,7 +407,9 @@ __global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *_
   Bias b = make_bias(g, p, q, wk.prev, step > 1);
   float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
   unsigned f = 0, sv = 0;
-  int32_t k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
+  int32_t k = -1;                                  // same routing as k_walk_general
+  if (!b.need_member) k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
+  else k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem);
   if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
   int32_t next = g.ent[r.off + k].id;
   if (lane == 0) {

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
   const unsigned long long t_begin = wall_clock64();
 #endif
   const int64_t stride = (int64_t)L + 2;
-  unsigned long long steps = 0, degc = 0, degp = 0, fb = 0, dead = 0, fast = 0;
+  unsigned long long steps = 0, degc = 0, degp = 0, fb = 0, dead = 0, fast = 0, srch = 0;
   // Persistent waves: a walker costs anything from a few to millions of entry reads, and a block's LDS is only
   // released when its slowest wave ends — so every wave takes the next walker from a counter instead of owning one.
   while (true) {
@@ -180,7 +180,10 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
       int32_t k = -1;
       if (!b.need_member || (tune & 8)) k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);
       SRW_T1(mem, t_prefix);
-      if (k < 0 && !(tune & 8)) k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 3, (tune & 4) != 0, mem);
+      if (k < 0 && !(tune & 8)) {
+        k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 3, (tune & 4) != 0, mem);
+        if (k >= 0) srch += (unsigned long long)r.deg;       // the sorted ids of N(curr) were read instead of its entries
+      }
       if (k < 0) { k = wave_pick_scan(g, r, b, mem, u, f); degc += (unsigned long long)r.deg; }
       else { fast += sv; }
       int32_t next = g.ent[r.off + k].id;
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     if (degp) atomicAdd(&ctr->sum_deg_prev, degp);
     if (fb) atomicAdd(&ctr->fallbacks, fb);
     if (fast) atomicAdd(&ctr->ent_reads, fast);      // general kernel: steps served by the prefix-sum search
+    if (srch) atomicAdd(&ctr->trials, srch);         // ... and the sum of deg(curr) over the binned ones
 #ifdef SRW_PHASE_TIMING
     const unsigned long long tv[10] = {wall_clock64() - t_begin, mem.t_prefix, mem.t_a, mem.t_p1, mem.t_p2, mem.t_w,
                                        mem.t_fin, mem.t_fill, mem.t_pass1, mem.t_pass2};

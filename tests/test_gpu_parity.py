@@ -599,12 +599,16 @@ def test_empty_and_degenerate_inputs(eng, oracle, tmp_path):
 BINNED_TUNES = [0, 4 | 1, 4 | 2, 4 | 3]     # automatic; forced P1 / P2 / id-window on rows of ANY degree
 
 
-@pytest.mark.parametrize("case", ["rmat12", "rmat12w", "rmat11wd", "multi", "multi_neg"])
+@pytest.mark.parametrize("case", ["rmat12", "rmat12w", "rmat11wd", "rmat12f", "rmat12x", "multi", "multi_neg"])
 def test_binned_search_all_strategies(eng, oracle, case):
     if case.startswith("rmat"):
         sc = int(case[4:6])
         weighted, directed = "w" in case[6:], case.endswith("d")
         s, d, w = rmat_lines(oracle, sc, edge_factor=16, weighted=weighted)
+        if case.endswith("f"):      # arbitrary f32 mantissas in a narrow exponent range: the certificate holds
+            w = (0.5 + 1.5 * np.random.default_rng(4).random(len(s))).astype(np.float32)
+        if case.endswith("x"):      # exponents spread over 2^-20 .. 2^20: hub rows fail the certificate -> scan path
+            w = (2.0 ** np.random.default_rng(5).integers(-20, 21, len(s))).astype(np.float32)
     else:
         rng = np.random.default_rng(11)
         weighted, directed = True, False
@@ -616,7 +620,7 @@ def test_binned_search_all_strategies(eng, oracle, case):
         for tune in BINNED_TUNES:
             paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, binned_tune=tune)
             assert np.array_equal(lens, ref[1]) and np.array_equal(paths, ref[0]), (case, p, q, tune)
-            if tune:
+            if tune and not case.endswith("x"):
                 assert st["ent_reads"] > 0, "binned search was not exercised"
         paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, binned=False)
         assert np.array_equal(paths, ref[0])

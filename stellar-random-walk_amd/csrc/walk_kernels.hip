@@ -335,8 +335,10 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
           const float u2 = (float)(o[2] >> 8) * (1.0f / 16777216.0f);
           if (!(u2 < e.prob)) { e = load_al<NT>(g.al + rc.off + e.alias); ++reads; }
           if (biased) {
-            float bias = inv_q;
-            if (e.id == prev) bias = inv_p;
+            const float u3 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
+            const float thr = u3 * Q;
+            if (e.id == prev) accepted = thr < inv_p;
+            else if (thr < fminf(inv_q, 1.0f)) accepted = true;   // accepted whether or not x is in N(prev): no lookup
             else {
               // x in N(prev)?  On an undirected load this equals prev in N(x): probe the shorter sorted row
               bool in;
@@ -346,10 +348,9 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
                 in = sorted_contains(g.sids + e.noff, e.ndeg, (uint32_t)((int64_t)prev - g.vmin));
               else
                 in = sorted_contains(g.sids + rp.off, rp.deg, (uint32_t)((int64_t)e.id - g.vmin));
-              if (in) bias = 1.0f;
+              accepted = thr < (in ? 1.0f : inv_q);
             }
-            const float u3 = (float)(o[3] >> 8) * (1.0f / 16777216.0f);
-            accepted = (u3 * Q < bias) || (t + 1u >= 65536u);
+            accepted = accepted || (t + 1u >= 65536u);
           }
         }
       }

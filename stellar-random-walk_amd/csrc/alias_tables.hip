@@ -255,7 +255,7 @@ __global__ void k_ehash_build(const Row *__restrict__ rows, const Ent *__restric
       const Row r = rows[v];
       for (int32_t k = lane; k < r.deg; k += 64) {
         const uint64_t key = ((uint64_t)(uint32_t)v << 32) | (uint32_t)((int64_t)ent[r.off + k].id - vmin);
-        uint64_t s = edge_hash(key) & mask;
+        uint64_t s = edge_hash(key, mask);
         while (true) {
           const unsigned long long old = atomicCAS((unsigned long long *)&tab[s], 0xFFFFFFFFFFFFFFFFull, (unsigned long long)key);
           if (old == 0xFFFFFFFFFFFFFFFFull || old == key) break;

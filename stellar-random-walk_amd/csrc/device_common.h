@@ -129,13 +129,23 @@ __host__ __device__ inline int32_t owner_of(int32_t v, int32_t world) {
   return m < 0 ? m + world : m;
 }
 // Edge-existence test through the hash set (linear probing, EMPTY = all ones).
-__device__ inline uint64_t edge_hash(uint64_t k) {
-  k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull; k ^= k >> 27; k *= 0x94D049BB133111EBull; k ^= k >> 31;
-  return k;
+// 32-bit mixing only (a 64-bit multiply costs ~8 VALU instructions on CDNA): murmur3's finalizer over the two halves of
+// the key; tables above 2^32 slots take their high index bits from a second, independent mix.
+__device__ inline uint64_t edge_hash(uint64_t k, uint64_t mask) {
+  const uint32_t row = (uint32_t)(k >> 32), id = (uint32_t)k;
+  uint32_t a = (row * 0x9E3779B1u) ^ id;
+  a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;
+  uint64_t h = a;
+  if (mask >> 32) {
+    uint32_t b = id * 0x27D4EB2Fu + row;
+    b ^= b >> 15; b *= 0x2C1B3C6Du; b ^= b >> 12; b *= 0x297A2D39u; b ^= b >> 15;
+    h |= (uint64_t)b << 32;
+  }
+  return h & mask;
 }
 __device__ inline bool edge_exists(const uint64_t *tab, uint64_t mask, uint32_t row_slot, uint32_t id_slot) {
   const uint64_t key = ((uint64_t)row_slot << 32) | id_slot;
-  uint64_t s = edge_hash(key) & mask;
+  uint64_t s = edge_hash(key, mask);
   while (true) {
     const uint64_t v = tab[s];
     if (v == key) return true;

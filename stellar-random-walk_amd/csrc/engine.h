@@ -122,6 +122,7 @@ struct srw_handle {
   int n_cus = 256;
   srw::DevBuf<unsigned long long> shard_counts;  // [world] bucket counters / cursors for srw_shard_step
   srw::DevBuf<srw::Walker> shard_scratch;        // sampled records before bucketing (persistent)
+  srw::DevBuf<uint32_t> shard_blk;               // [blocks][world] per-block survivor counts, then write cursors
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // srw_walk_to_host: second stream + two staging buffers for compute/copy overlap
   hipStream_t copy_stream = nullptr;

@@ -549,11 +549,11 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
 //   P2  every candidate (input order, no permutation needed) is searched in N(prev) ~ |N(curr)| log |N(prev)| probes
 //   W   id-window bitmap: both sorted id lists are streamed once in chunks of 1024 ids (16-byte loads, 16 ids per
 //       lane, kept in registers until their last id is below the window end); the ids of N(prev) inside the current
-//       window of 49152 vertex ids set bits in LDS (one non-returning ds_or each), the candidates test them (one
+//       window of 40960 vertex ids set bits in LDS (one non-returning ds_or each), the candidates test them (one
 //       ds_read each).  The window starts at the smallest id both lists still have, so empty id ranges cost nothing.
 //       (A hash set per chunk was tried: 3x the LDS operations, slower.)
 constexpr int BIN_CAP = 512;                  // f64 bins: 4 KB of the wave's LDS
-constexpr int WIN_WORDS = 1536;               // id-window bitmap behind the bins: 6 KB (49152 vertex ids)
+constexpr int WIN_WORDS = 1280;               // id-window bitmap behind the bins: 5 KB (40960 vertex ids)
 constexpr int WIN_BITS = WIN_WORDS * 32;
 constexpr int NE = 8;                       // ids per lane and chunk
 constexpr int HCHUNK = 64 * NE;

@@ -388,117 +388,196 @@ __global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Vertex-sharded super-step.  mode 0: count survivors per destination owner; mode 1: emit them.
-// One wave per record keeps the sampler identical to k_walk_general (bit-identical paths for any world).
-__global__ __launch_bounds__(TPB) void k_shard_step(GraphView g, const Walker *__restrict__ in, int64_t n_in,
-                                                    int64_t n_verts_global, int32_t first_walk, int32_t step,
-                                                    RngSpec rng, float p, float q, int32_t world,
-                                                    Walker *__restrict__ out, unsigned long long *cursors,
-                                                    int32_t *__restrict__ paths, int64_t stride, DevCounters *ctr) {
-  __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
-  const int lane = lane_id();
-  const int64_t ri = (blockIdx.x * (int64_t)TPB + threadIdx.x) >> 6;
-  if (ri >= n_in) return;
-  Member mem; mem.mode = 0; mem.bm = bitmap[threadIdx.x >> 6]; mem.seg_base = 0;
-  Walker wk = in[ri];
-  const Row *rp = row_of(g, wk.curr);
-  Row r; r.off = 0; r.deg = 0; r.flags = 0;
-  if (rp) r = *rp;
-  if (r.deg == 0) {
-    if (lane == 0) { Walker dw = wk; dw.wid = -1; out[ri] = dw; if (step > 1) atomicAdd(&ctr->dead_ends, 1ull); }
-    return;
+// Vertex-sharded super-step (run_shard_step).  A fixed grid of SHARD_BLOCKS blocks, block b owns the contiguous slice
+// [b * per_block, (b + 1) * per_block) of the incoming records in all three kernels:
+//   k_shard_step / k_shard_step_fo : sample every record in place into `scratch` (dead ends get wid = -1), write the
+//       path slot, and count the block's survivors per destination owner in LDS -> blk[b][d]   (no global atomics
+//       besides three block-reduced statistics: a single counter word saturates at ~88 atomics/us on MI355X)
+//   k_shard_offsets : one wave per destination: exclusive scan of blk[.][d] over the blocks -> every block's write
+//       cursor per destination, and the per-destination totals (the all-to-all-v split sizes)
+//   k_shard_bucket  : re-reads the slice and writes the survivors grouped by destination (LDS cursors,
+//       wave-aggregated), in rank order, ready for all_to_all_single
+// The general kernel keeps one wave per record and the same samplers as k_walk_general (bit-identical paths for any
+// world).
+constexpr int SHARD_MAX_WORLD = 64;
+
+__device__ inline void block_flush_counters(DevCounters *ctr, unsigned long long *red, unsigned long long steps,
+                                            unsigned long long dead, unsigned long long degc, unsigned long long degp,
+                                            unsigned long long reads, unsigned long long fb) {
+  // red: 6 words of LDS, zeroed before the block's work; one global atomic per counter per BLOCK
+  steps = wave_sum_u64(steps); dead = wave_sum_u64(dead); degc = wave_sum_u64(degc);
+  degp = wave_sum_u64(degp); reads = wave_sum_u64(reads); fb = wave_sum_u64(fb);
+  if (lane_id() == 0) {
+    if (steps) atomicAdd(&red[0], steps);
+    if (dead) atomicAdd(&red[1], dead);
+    if (degc) atomicAdd(&red[2], degc);
+    if (degp) atomicAdd(&red[3], degp);
+    if (reads) atomicAdd(&red[4], reads);
+    if (fb) atomicAdd(&red[5], fb);
   }
-  const uint32_t iter = (uint32_t)(first_walk + (int64_t)wk.wid / n_verts_global);
-  Bias b = make_bias(g, p, q, wk.prev, step > 1);
-  float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
-  unsigned f = 0, sv = 0;
-  int32_t k = -1;                                  // same routing as k_walk_general
-  if (!b.need_member) k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
-  else k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem);
-  if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
-  int32_t next = g.ent[r.off + k].id;
-  if (lane == 0) {
-    paths[(int64_t)wk.wid * stride + step] = next;
-    Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
-    out[ri] = nw;                                   // in place; dead records carry wid = -1 (no cursor atomics)
-    atomicAdd(&ctr->steps, 1ull);
-    atomicAdd(&ctr->sum_deg_curr, (unsigned long long)r.deg);
-    if (b.need_member) atomicAdd(&ctr->sum_deg_prev, (unsigned long long)b.prev_deg);
-    if (f) atomicAdd(&ctr->fallbacks, 1ull);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (red[0]) atomicAdd(&ctr->steps, red[0]);
+    if (red[1]) atomicAdd(&ctr->dead_ends, red[1]);
+    if (red[2]) atomicAdd(&ctr->sum_deg_curr, red[2]);
+    if (red[3]) atomicAdd(&ctr->sum_deg_prev, red[3]);
+    if (red[4]) atomicAdd(&ctr->ent_reads, red[4]);
+    if (red[5]) atomicAdd(&ctr->fallbacks, red[5]);
   }
 }
 
-// First-order (p == q == 1) super-step: one record per LANE through the exact CDF + guide records of the local rows.
-__global__ __launch_bounds__(TPB) void k_shard_step_fo(GraphView g, const Walker *__restrict__ in, int64_t n_in,
-                                                       int64_t n_verts_global, int32_t first_walk, int32_t step,
-                                                       RngSpec rng, Walker *__restrict__ out,
-                                                       unsigned long long *cursor, int32_t *__restrict__ paths,
-                                                       int64_t stride, DevCounters *ctr) {
-  const int64_t ri = blockIdx.x * (int64_t)TPB + threadIdx.x;
-  unsigned long long steps = 0, dead = 0, reads = 0, fb = 0;
-  if (ri < n_in) {
+__global__ __launch_bounds__(TPB, 4) void k_shard_step(GraphView g, const Walker *__restrict__ in, int64_t n_in,
+                                                       int64_t per_block, int64_t n_verts_global, int32_t first_walk,
+                                                       int32_t step, RngSpec rng, float p, float q, int32_t world,
+                                                       Walker *__restrict__ out, uint32_t *__restrict__ blk,
+                                                       int32_t *__restrict__ paths, int64_t stride, DevCounters *ctr) {
+  __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
+  __shared__ uint32_t cnt[SHARD_MAX_WORLD];
+  __shared__ unsigned long long red[6];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  if (threadIdx.x < SHARD_MAX_WORLD) cnt[threadIdx.x] = 0u;
+  if (threadIdx.x < 6) red[threadIdx.x] = 0ull;
+  __syncthreads();
+  Member mem; mem.mode = 0; mem.bm = bitmap[wv]; mem.seg_base = 0;
+  unsigned long long steps = 0, dead = 0, degc = 0, degp = 0, fb = 0;
+  const int64_t lo = blockIdx.x * per_block, hi = min(n_in, lo + per_block);
+  for (int64_t ri = lo + wv; ri < hi; ri += TPB / 64) {     // one wave per record
     Walker wk = in[ri];
     const Row *rp = row_of(g, wk.curr);
     Row r; r.off = 0; r.deg = 0; r.flags = 0;
     if (rp) r = *rp;
     if (r.deg == 0) {
-      if (step > 1) dead = 1;
-      Walker dw = wk; dw.wid = -1; out[ri] = dw;
-    } else {
-      const uint32_t iter = (uint32_t)(first_walk + (int64_t)wk.wid / n_verts_global);
-      float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
-      int32_t next;
-      if (r.flags & ROW_IRREGULAR) {
-        Bias nb; nb.second_order = false; nb.need_member = false; nb.p = nb.q = 1.0f; nb.prev = 0;
-        nb.prev_sids = nullptr; nb.prev_deg = 0; nb.vmin = g.vmin;
-        next = g.ent[r.off + lane_pick_sequential(g.ent + r.off, r.deg, nb, u)].id; fb = 1;
-      } else {
-        unsigned rd; int32_t k;
-        FoEnt e = fo_pick<false>(g.fo + r.off, r.deg, u, k, rd); reads = rd;
-        next = e.id;
-      }
+      if (lane == 0) { Walker dw = wk; dw.wid = -1; out[ri] = dw; }
+      if (step > 1) dead += (lane == 0);
+      continue;
+    }
+    const uint32_t iter = (uint32_t)(first_walk + (int64_t)wk.wid / n_verts_global);
+    Bias b = make_bias(g, p, q, wk.prev, step > 1);
+    float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
+    unsigned f = 0, sv = 0;
+    int32_t k = -1;                                  // same routing as k_walk_general
+    if (!b.need_member) k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
+    else k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem);
+    if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
+    int32_t next = g.ent[r.off + k].id;
+    if (lane == 0) {
       paths[(int64_t)wk.wid * stride + step] = next;
       Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
-      out[ri] = nw;
-      steps = 1;
+      out[ri] = nw;                                   // in place; dead records carry wid = -1
+      atomicAdd(&cnt[owner_of_tab(next, world, g.owner_tab, g.vmin, g.n_slots)], 1u);
+      steps += 1; degc += (unsigned long long)r.deg; fb += f;
+      if (b.need_member) degp += (unsigned long long)b.prev_deg;
     }
   }
-  flush_counters(ctr, steps, dead, 0, 0, reads, fb);
+  block_flush_counters(ctr, red, steps, dead, degc, degp, 0, fb);   // contains the __syncthreads() cnt needs
+  if ((int)threadIdx.x < world) blk[(int64_t)blockIdx.x * world + threadIdx.x] = cnt[threadIdx.x];
 }
 
-// pre-pass of the super-step: where will each record go?  (needs the sampled vertex, so the step kernel runs
-// once into a scratch ordering and k_shard_bucket reorders — see run_shard_step)
-// A single counter word saturates at ~88 atomics/us on MI355X (MI355X_MICROARCH "dequeue"), so the per-destination
-// counters are bumped once per WAVE: ballot the lanes that go to destination d, one atomic for popcount(mask).
-__global__ void k_shard_count(GraphView g, const Walker *__restrict__ recs, int64_t n, int32_t world, unsigned long long *counts) {
-  const int lane = lane_id();
-  for (int64_t base = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) - lane; base < n; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = base + lane;
+// p = q = 1 on a shard: one record per lane through the precomputed CDF + guide table.
+__global__ __launch_bounds__(TPB) void k_shard_step_fo(GraphView g, const Walker *__restrict__ in, int64_t n_in,
+                                                       int64_t per_block, int64_t n_verts_global, int32_t first_walk,
+                                                       int32_t step, RngSpec rng, int32_t world,
+                                                       Walker *__restrict__ out, uint32_t *__restrict__ blk,
+                                                       int32_t *__restrict__ paths, int64_t stride, DevCounters *ctr) {
+  __shared__ uint32_t cnt[SHARD_MAX_WORLD];
+  __shared__ unsigned long long red[6];
+  if (threadIdx.x < SHARD_MAX_WORLD) cnt[threadIdx.x] = 0u;
+  if (threadIdx.x < 6) red[threadIdx.x] = 0ull;
+  __syncthreads();
+  unsigned long long steps = 0, dead = 0, reads = 0, fb = 0;
+  const int64_t lo = blockIdx.x * per_block, hi = min(n_in, lo + per_block);
+  for (int64_t base = lo; base < hi; base += TPB) {
+    const int64_t ri = base + threadIdx.x;
     int32_t o = -1;
-    if (i < n) { Walker w = recs[i]; if (w.wid >= 0) o = owner_of_tab(w.curr, world, g.owner_tab, g.vmin, g.n_slots); }
-    for (int32_t d = 0; d < world; ++d) {
+    if (ri < hi) {
+      Walker wk = in[ri];
+      const Row *rp = row_of(g, wk.curr);
+      Row r; r.off = 0; r.deg = 0; r.flags = 0;
+      if (rp) r = *rp;
+      if (r.deg == 0) {
+        if (step > 1) ++dead;
+        Walker dw = wk; dw.wid = -1; out[ri] = dw;
+      } else {
+        const uint32_t iter = (uint32_t)(first_walk + (int64_t)wk.wid / n_verts_global);
+        float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
+        int32_t next;
+        if (r.flags & ROW_IRREGULAR) {
+          Bias nb; nb.second_order = false; nb.need_member = false; nb.p = nb.q = 1.0f; nb.prev = 0;
+          nb.prev_sids = nullptr; nb.prev_deg = 0; nb.vmin = g.vmin;
+          next = g.ent[r.off + lane_pick_sequential(g.ent + r.off, r.deg, nb, u)].id; ++fb;
+        } else {
+          unsigned rd; int32_t k;
+          FoEnt e = fo_pick<false>(g.fo + r.off, r.deg, u, k, rd); reads += rd;
+          next = e.id;
+        }
+        paths[(int64_t)wk.wid * stride + step] = next;
+        Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
+        out[ri] = nw;
+        ++steps;
+        o = owner_of_tab(next, world, g.owner_tab, g.vmin, g.n_slots);
+      }
+    }
+    for (int32_t d = 0; d < world; ++d) {               // one LDS atomic per wave and destination
       const unsigned long long m = __ballot(o == d);
-      if (m && lane == 0) atomicAdd(&counts[d], (unsigned long long)__popcll(m));
+      if (m && lane_id() == 0) atomicAdd(&cnt[d], (uint32_t)__popcll(m));
+    }
+  }
+  block_flush_counters(ctr, red, steps, dead, 0, 0, reads, fb);
+  if ((int)threadIdx.x < world) blk[(int64_t)blockIdx.x * world + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// blk[b][d] (counts) -> blk[b][d] (write cursor of block b inside the output, destinations laid out in rank order);
+// totals[d] = records for destination d.  One block; wave w handles destinations w, w + nwaves, ...
+__global__ void k_shard_offsets(uint32_t *__restrict__ blk, int32_t n_blocks, int32_t world, unsigned long long *totals) {
+  __shared__ unsigned long long tot[SHARD_MAX_WORLD], basev[SHARD_MAX_WORLD];
+  const int lane = lane_id(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int per = (n_blocks + 63) / 64;
+  for (int d = wv; d < world; d += nw) {
+    unsigned long long s = 0;
+    for (int i = 0; i < per; ++i) { const int b = lane * per + i; if (b < n_blocks) s += blk[(int64_t)b * world + d]; }
+    s = wave_sum_u64(s);
+    if (lane == 0) tot[d] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long acc = 0;
+    for (int d = 0; d < world; ++d) { basev[d] = acc; acc += tot[d]; totals[d] = tot[d]; }
+  }
+  __syncthreads();
+  for (int d = wv; d < world; d += nw) {
+    unsigned long long loc = 0;
+    for (int i = 0; i < per; ++i) { const int b = lane * per + i; if (b < n_blocks) loc += blk[(int64_t)b * world + d]; }
+    unsigned long long incl = loc;
+    for (int o = 1; o < 64; o <<= 1) { unsigned long long t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    unsigned long long run = basev[d] + incl - loc;
+    for (int i = 0; i < per; ++i) {
+      const int b = lane * per + i;
+      if (b < n_blocks) { const uint32_t c = blk[(int64_t)b * world + d]; blk[(int64_t)b * world + d] = (uint32_t)run; run += c; }
     }
   }
 }
-__global__ void k_shard_bucket(GraphView g, const Walker *__restrict__ recs, int64_t n, int32_t world, unsigned long long *cursors,
-                               Walker *__restrict__ out) {
+
+__global__ __launch_bounds__(TPB) void k_shard_bucket(GraphView g, const Walker *__restrict__ recs, int64_t n,
+                                                      int64_t per_block, int32_t world, const uint32_t *__restrict__ blk,
+                                                      Walker *__restrict__ out) {
+  __shared__ uint32_t cur[SHARD_MAX_WORLD];
+  if ((int)threadIdx.x < world) cur[threadIdx.x] = blk[(int64_t)blockIdx.x * world + threadIdx.x];
+  __syncthreads();
   const int lane = lane_id();
-  for (int64_t base = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) - lane; base < n; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = base + lane;
+  const int64_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
+  for (int64_t base = lo; base < hi; base += TPB) {
+    const int64_t i = base + threadIdx.x;
     Walker w; w.wid = -1; w.src = 0; w.prev = 0; w.curr = 0;
     int32_t o = -1;
-    if (i < n) { w = recs[i]; if (w.wid >= 0) o = owner_of_tab(w.curr, world, g.owner_tab, g.vmin, g.n_slots); }
+    if (i < hi) { w = recs[i]; if (w.wid >= 0) o = owner_of_tab(w.curr, world, g.owner_tab, g.vmin, g.n_slots); }
     for (int32_t d = 0; d < world; ++d) {
       const unsigned long long m = __ballot(o == d);
       if (!m) continue;
-      unsigned long long b = 0;
+      uint32_t b0 = 0;
       const int leader = __ffsll((long long)m) - 1;
-      if (lane == leader) b = atomicAdd(&cursors[d], (unsigned long long)__popcll(m));
-      b = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), leader) << 32) |
-          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, leader);
-      if (o == d) out[b + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = w;
+      if (lane == leader) b0 = atomicAdd(&cur[d], (uint32_t)__popcll(m));
+      b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
+      if (o == d) out[(uint64_t)b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
     }
   }
 }
@@ -832,15 +911,15 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
   if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
   check_params(P);
   const int32_t world = h->cfg.world;
+  if (world > SHARD_MAX_WORLD) throw Error(SRW_ERR_INVALID, "world larger than 64 shards");
+  if (n_in >= ((int64_t)1 << 32)) throw Error(SRW_ERR_INVALID, "more than 2^32 records in one super-step");
   hipStream_t st = h->stream;
   h->counters.ensure(1);
-  h->shard_counts.ensure((size_t)world * 2);
+  h->shard_counts.ensure((size_t)world);
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
-  SRW_HIP(hipMemsetAsync(h->shard_counts.p, 0, sizeof(unsigned long long) * world * 2, st));
   std::vector<unsigned long long> counts((size_t)world, 0ull);
   srw_walk_stats local; srw_walk_stats *s = stats ? stats : &local; memset(s, 0, sizeof(*s));
   if (n_in > 0) {
-    // pass A: sample in place into the scratch buffer (record i -> scratch[i]; dead ends carry wid = -1)
     h->shard_scratch.ensure((size_t)n_in);
     Walker *scratch = h->shard_scratch.p;
     RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
@@ -851,32 +930,26 @@ void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32
       if (!(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX)) build_pq_tables(h, P.p, P.q);
       else h->g.has_pq = false;
     }
+    // fixed grid: every block owns one contiguous slice of the records in all three kernels
+    const int64_t unit = first_order ? TPB : TPB / 64;          // records one block handles per sweep
+    const int32_t n_blocks = (int32_t)std::min<int64_t>((n_in + unit - 1) / unit, (int64_t)h->n_cus * 4);
+    int64_t per_block = (n_in + n_blocks - 1) / n_blocks;
+    per_block = (per_block + TPB - 1) / TPB * TPB;
+    h->shard_blk.ensure((size_t)n_blocks * world);
     SRW_HIP(hipEventRecord(h->ev0, st));
-    if (first_order) {
-      int64_t blocks = (n_in + TPB - 1) / TPB;
-      hipLaunchKernelGGL(k_shard_step_fo, dim3((unsigned)blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, g.n_vertices,
-                         P.first_walk, step, rng, scratch, h->shard_counts.p + world, d_paths, stride, h->counters.p);
-    } else {
-      int64_t blocks = (n_in * 64 + TPB - 1) / TPB;
-      hipLaunchKernelGGL(k_shard_step, dim3((unsigned)blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, g.n_vertices,
-                         P.first_walk, step, rng, P.p, P.q, /*world=*/1, scratch, h->shard_counts.p + world, d_paths,
-                         stride, h->counters.p);
-    }
+    if (first_order)
+      hipLaunchKernelGGL(k_shard_step_fo, dim3((unsigned)n_blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, per_block, g.n_vertices,
+                         P.first_walk, step, rng, world, scratch, h->shard_blk.p, d_paths, stride, h->counters.p);
+    else
+      hipLaunchKernelGGL(k_shard_step, dim3((unsigned)n_blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, per_block, g.n_vertices,
+                         P.first_walk, step, rng, P.p, P.q, world, scratch, h->shard_blk.p, d_paths, stride, h->counters.p);
     SRW_HIP(hipEventRecord(h->ev1, st));
-    // pass B: bucket the survivors by owner(next): count -> exclusive offsets -> scatter
-    int gb = (int)std::min<int64_t>((n_in + TPB - 1) / TPB, 8192);
-    hipLaunchKernelGGL(k_shard_count, dim3(gb), dim3(TPB), 0, st, g.view(), scratch, n_in, world, h->shard_counts.p);
-    SRW_HIP(hipMemcpyAsync(counts.data(), h->shard_counts.p, 8 * world, hipMemcpyDeviceToHost, st));
-    SRW_HIP(hipStreamSynchronize(st));
-    std::vector<unsigned long long> cur((size_t)world, 0ull);
-    unsigned long long acc = 0;
-    for (int r = 0; r < world; ++r) { cur[r] = acc; acc += counts[r]; }
-    if (acc) {
-      SRW_HIP(hipMemcpyAsync(h->shard_counts.p, cur.data(), 8 * world, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_shard_bucket, dim3(gb), dim3(TPB), 0, st, g.view(), scratch, n_in, world, h->shard_counts.p, d_out);
-      SRW_HIP(hipStreamSynchronize(st));
-    }
+    hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(1024), 0, st, h->shard_blk.p, n_blocks, world, h->shard_counts.p);
+    hipLaunchKernelGGL(k_shard_bucket, dim3((unsigned)n_blocks), dim3(TPB), 0, st, g.view(), scratch, n_in, per_block, world,
+                       h->shard_blk.p, d_out);
     SRW_HIP(hipGetLastError());
+    SRW_HIP(hipMemcpyAsync(counts.data(), h->shard_counts.p, 8 * world, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));                          // the only host sync of the super-step
     float ms = 0.f; SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     s->kernel_ms = ms;
   }

@@ -178,7 +178,10 @@ class Engine:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: module globals may already be gone
+            pass
 
     def __enter__(self):
         return self

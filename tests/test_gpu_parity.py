@@ -462,7 +462,27 @@ def test_compact_lattice_records(eng, oracle):
     assert a[2]["record_bytes"] == 16 and np.array_equal(a[0], rp) and np.array_equal(a[1], rl)
     s, d, w = rmat_lines(oracle, 13, edge_factor=16, weighted=True)                     # escapes -> exact records
     eng.load_coo(s, d, w)
-    assert eng.walk(walk_length=5, seed=1)[2]["record_bytes"] == 32
+    gw = oracle.Graph.from_coo(s, d, w)
+    a = eng.walk(walk_length=12, seed=1)          # compact tried first, rejected, exact table from the slim temporaries
+    rp, rl, _ = gw.walk(walk_length=12, seed=1, threads=8)
+    assert a[2]["record_bytes"] == 32 and np.array_equal(a[0], rp) and np.array_equal(a[1], rl)
+    # table build orders: exact table first (constant-r call), compact derived from it on the next Philox call
+    s, d, _ = rmat_lines(oracle, 12, edge_factor=16)
+    g = oracle.Graph.from_coo(s, d, None)
+    eng.load_coo(s, d, None)
+    c = eng.walk(walk_length=9, rng="const", const_r=0.25)
+    rc = g.walk(walk_length=9, rng="const", const_r=0.25, threads=8)
+    assert c[2]["record_bytes"] == 32 and np.array_equal(c[0], rc[0])
+    a = eng.walk(walk_length=30, seed=3)
+    rp, rl, _ = g.walk(walk_length=30, seed=3, threads=8)
+    assert a[2]["record_bytes"] == 16 and np.array_equal(a[0], rp) and np.array_equal(a[1], rl)
+    # ... and compact first, exact table added by a later constant-r call
+    eng.load_coo(s, d, None)
+    a = eng.walk(walk_length=30, seed=3)
+    c = eng.walk(walk_length=9, rng="const", const_r=0.25)
+    b = eng.walk(walk_length=30, seed=3)
+    assert a[2]["record_bytes"] == 16 and c[2]["record_bytes"] == 32 and b[2]["record_bytes"] == 16
+    assert np.array_equal(a[0], rp) and np.array_equal(b[0], rp) and np.array_equal(c[0], rc[0])
 
 
 @pytest.mark.parametrize("p,q,sampler", [(1.0, 1.0, "reference"), (0.25, 4.0, "reference"), (0.25, 4.0, "alias")])

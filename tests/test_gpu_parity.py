@@ -673,3 +673,9 @@ def test_binned_search_two_giant_hubs(eng, oracle):
             paths, lens, st = eng.walk(p=p, q=q, walk_length=8, seed=29, binned_tune=tune)
             assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl), (p, q, tune)
             assert st["ent_reads"] > 0
+
+
+def test_randomized_differential_fuzz(eng):
+    # ~8 s of tests/fuzz_parity.py: random multigraphs / hub graphs / RMATs, every sampler variant vs the CPU oracle
+    import fuzz_parity
+    assert fuzz_parity.run(budget=8.0, seed=20260928, eng=eng)

@@ -4,11 +4,14 @@
 //   k_walk_first_order   p == q == 1: one walker per LANE, all walk_length+1 steps in one launch, O(1)
 //                        exact sampling through the CDF+guide records (16 B, one sector per probe), paths
 //                        staged in LDS and flushed as 64-byte runs.  HBM-latency/sector bound gather.
-//   k_walk_general       any p, q: one walker per WAVE; the wave streams N(curr) coalesced (8 B/lane),
-//                        applies the node2vec bias with a binary search in the sorted N(prev), and evaluates
-//                        the reference's sequential f64 CDF exactly (sampling.h).
-//   k_shard_step         one super-step of the vertex-sharded multi-GPU path: same samplers, one step,
-//                        output records bucketed by owner(next) for the RCCL all-to-all.
+//   k_walk_general       any p, q: one walker per WAVE, persistent waves taking walkers from a counter; per step the
+//                        first sampler that applies (sampling.h): search over exact prefix sums (specials binned by
+//                        position in LDS, sorted-row intersection by probes / edge hash / id-window bitmap),
+//                        certified parallel scan of the streamed row, or the reference's sequential f64 chain.
+//   k_walk_alias         Mode A: per-vertex alias tables + rejection, one walker per lane.
+//   k_shard_step(_fo)    one super-step of the vertex-sharded multi-GPU path: same samplers, one step per record,
+//                        survivors counted per destination in LDS, k_shard_offsets + k_shard_bucket group them by
+//                        owner(next) for the RCCL all-to-all.
 // No MFMA anywhere: integer/byte gather work bounded by HBM.
 #include <algorithm>
 #include <cstring>

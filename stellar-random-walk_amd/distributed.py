@@ -79,20 +79,28 @@ class ShardedWalker:
         self.engine.load_coo(src, dst, w, pid=pid, directed=directed)
         return self
 
-    # ---- one walk iteration = walk_length + 1 super-steps ----
+    # ---- walk_length + 1 super-steps over the walkers of `num_walks` consecutive walk iterations ----
     def walk_iteration(self, iteration=0, p=1.0, q=1.0, walk_length=80, num_walks=1, seed=42, rng="philox",
                        const_r=0.0, gather=False):
+        """Walk iterations iteration .. iteration + num_walks - 1 as ONE walker population (walker id =
+        iteration-in-call * nVertices + rank of the source vertex; the step kernels derive the RNG's iteration word
+        from it), so the per-super-step costs (launches, one host sync, two collectives) are paid once per batch."""
         world = self.world
         n_local, n_global = self.se.capacity()
+        if num_walks * n_global >= 2 ** 31:
+            raise SrwError(-1, "num_walks * nVertices must stay below 2^31 per batch")
         stride = walk_length + 2
         P = Engine.params(p=p, q=q, walk_length=walk_length, num_walks=1, first_walk=iteration, rng=rng,
                           const_r=const_r, seed=seed)
         dev = self.device
-        paths = torch.full((n_global, stride), UNWRITTEN, dtype=torch.int32, device=dev)
-        cap = max(n_global, 1)
+        n_walkers = num_walks * n_global
+        paths = torch.full((n_walkers, stride), UNWRITTEN, dtype=torch.int32, device=dev)
+        cap = max(n_walkers, 1)
         cur = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         out = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-        n = self.se.seed(0, cur, paths, stride)
+        n = 0
+        for b in range(num_walks):
+            n += self.se.seed(b, cur[n:], paths, stride)
         tot = {"n_steps": 0, "dead_ends": 0, "kernel_ms": 0.0, "sum_deg_curr": 0, "exchanged": 0}
         for step in range(1, walk_length + 2):
             counts, st = self.se.step(P, iteration, step, cur, n, out, paths, stride, world)
@@ -124,11 +132,17 @@ class ShardedWalker:
             return paths.cpu().numpy(), lens.cpu().numpy(), tot
         return tot
 
-    def walk(self, num_walks=1, first_walk=0, **kw):
-        """num_walks iterations; returns (paths [num_walks * nV, L + 2], lens, stats) on every rank."""
+    def walk(self, num_walks=1, first_walk=0, batch=None, **kw):
+        """num_walks iterations; returns (paths [num_walks * nV, L + 2], lens, stats) on every rank.  `batch` walk
+        iterations share their super-steps (default: as many as keep the path matrix under 8 GiB)."""
+        _, n_global = self.se.capacity()
+        stride = kw.get("walk_length", 80) + 2
+        if batch is None:
+            batch = max(1, min(num_walks, (8 << 30) // max(1, n_global * stride * 4), (2 ** 31 - 1) // max(1, n_global)))
         ps, ls, stats = [], [], []
-        for it in range(num_walks):
-            pth, ln, st = self.walk_iteration(iteration=first_walk + it, gather=True, **kw)
+        for it in range(0, num_walks, batch):
+            b = min(batch, num_walks - it)
+            pth, ln, st = self.walk_iteration(iteration=first_walk + it, num_walks=b, gather=True, **kw)
             ps.append(pth)
             ls.append(ln)
             stats.append(st)

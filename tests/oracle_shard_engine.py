@@ -41,7 +41,8 @@ class OracleShardEngine:
                 dead += step > 1
                 continue
             ids, w = nb
-            r = params.const_r if params.rng_mode == 0 else oracle_py.walk_uniform(params.seed, params.first_walk, src, step)
+            it = params.first_walk + wid // len(self.all_verts)      # batched iterations: the walker id names its iteration
+            r = params.const_r if params.rng_mode == 0 else oracle_py.walk_uniform(params.seed, it, src, step)
             if step == 1:
                 k = oracle_py.sample_index(w, r)
             else:

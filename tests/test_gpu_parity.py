@@ -383,7 +383,12 @@ def test_sharded_walker_world1_nccl(oracle):
         paths, lens, stats = drv.walk(num_walks=2, p=0.5, walk_length=20, seed=3)
         rp, rl, rs = g.walk(num_walks=2, p=0.5, walk_length=20, seed=3)
         assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
-        assert sum(s["n_steps_global"] for s in stats) == rs
+        assert sum(s["n_steps_global"] for s in stats) == rs and len(stats) == 1     # one batched population
+        for q, batch in ((4.0, 1), (0.5, 3)):                                       # q != 1, other batch sizes
+            paths, lens, stats = drv.walk(num_walks=3, first_walk=2, batch=batch, p=0.25, q=q, walk_length=15, seed=8)
+            rp, rl, rs = g.walk(num_walks=3, first_walk=2, p=0.25, q=q, walk_length=15, seed=8)
+            assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
+            assert sum(s["n_steps_global"] for s in stats) == rs
     finally:
         dist.destroy_process_group()
 

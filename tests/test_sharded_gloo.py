@@ -44,6 +44,9 @@ def _worker(rank, world, port, directed, p, q, L, rng, out_dir):
         g = oracle_py.Graph.load(KARATE, directed=directed)
         drv = sharded.ShardedWalker(rank=rank, world=world, step_engine=OracleShardEngine(g, rank, world))
         paths, lens, stats = drv.walk(num_walks=2, first_walk=3, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
+        # both iterations shared their super-steps (one population); one iteration per population must give the same
+        p1, l1, _ = drv.walk(num_walks=2, first_walk=3, batch=1, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
+        assert len(stats) == 1 and np.array_equal(p1, paths) and np.array_equal(l1, lens)
         np.save(os.path.join(out_dir, "paths_%d.npy" % rank), paths)
         np.save(os.path.join(out_dir, "lens_%d.npy" % rank), lens)
         np.save(os.path.join(out_dir, "steps_%d.npy" % rank), np.array([sum(s["n_steps_global"] for s in stats),

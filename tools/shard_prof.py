@@ -13,6 +13,11 @@ torch.cuda.synchronize(); t = time.perf_counter()
 st = sw.walk_iteration(iteration=1, walk_length=80)
 torch.cuda.synchronize(); dt = time.perf_counter() - t
 print("iteration %.1f ms, kernel sum %.1f ms, steps %d -> %.2f Gsteps/s" % (dt * 1e3, st["kernel_ms"], st["n_steps"], st["n_steps"] / dt / 1e9))
+for nb in (4, 10):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    st = sw.walk_iteration(iteration=3, walk_length=80, num_walks=nb)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print("%d iterations batched: %.1f ms, kernel sum %.1f ms, steps %d -> %.2f Gsteps/s" % (nb, dt * 1e3, st["kernel_ms"], st["n_steps"], st["n_steps"] / dt / 1e9))
 sys.exit(0) if os.environ.get("NOPROF") else None
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); sw.walk_iteration(iteration=2, walk_length=80); torch.cuda.synchronize(); pr.disable()

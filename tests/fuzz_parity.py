@@ -7,7 +7,7 @@ import numpy as np
 import _pkg
 import oracle_py as oracle
 pkg = _pkg.load()
-def run(budget=60.0, seed=1, eng=None):
+def run(budget=60.0, seed=1, eng=None, giant=False):
     rng = np.random.default_rng(seed)
     eng = eng or pkg.Engine(0)
     t0, n_graphs, n_walks = time.time(), 0, 0
@@ -20,6 +20,8 @@ def run(budget=60.0, seed=1, eng=None):
     ]
     while time.time() - t0 < budget:
         kind = rng.integers(0, 3)
+        if giant and rng.integers(0, 12) == 0:
+            kind = 3
         if kind == 0:      # small dense multigraph
             nv, nl = int(rng.integers(2, 40)), int(rng.integers(1, 400))
             s = rng.integers(-5, nv, nl).astype(np.int32); d = rng.integers(-5, nv, nl).astype(np.int32)
@@ -29,6 +31,11 @@ def run(budget=60.0, seed=1, eng=None):
             leaves = (100 + rng.integers(0, nleaf, nleaf * 2)).astype(np.int32)
             extra_s = rng.integers(0, nh, 8).astype(np.int32); extra_d = rng.integers(0, nh, 8).astype(np.int32)
             s = np.concatenate([hubs, extra_s]); d = np.concatenate([leaves, extra_d])
+        elif kind == 3:    # two or three giant hubs (rows beyond 65536 entries: wide chunks, multi-segment bitmaps)
+            nh, nleaf = int(rng.integers(2, 4)), int(rng.integers(70000, 160000))
+            s = np.concatenate([np.full(nleaf, h, np.int32) for h in range(nh)] + [np.arange(nh, dtype=np.int32)])
+            d = np.concatenate([(10 + rng.permutation(nleaf + nleaf // 2)[:nleaf]).astype(np.int32) for h in range(nh)]
+                               + [np.roll(np.arange(nh, dtype=np.int32), 1)])
         else:              # rmat
             sc = int(rng.integers(6, 12))
             s, d = oracle.rmat_edges(sc, int(rng.integers(4, 24)) << sc, seed=int(rng.integers(1, 1 << 30)))
@@ -41,31 +48,42 @@ def run(budget=60.0, seed=1, eng=None):
         for _ in range(4):
             p, q = [float(x) for x in rng.choice([0.25, 0.5, 1.0, 2.0, 4.0], 2)]
             L, nw, seed = int(rng.integers(0, 40)), int(rng.integers(1, 4)), int(rng.integers(0, 1 << 30))
+            if kind == 3:
+                L, nw = int(rng.integers(2, 7)), 1
             kw = dict(p=p, q=q, walk_length=L, num_walks=nw, seed=seed, first_walk=int(rng.integers(0, 5)))
             if rng.integers(0, 4) == 0:
                 kw.update(rng="const", const_r=float(rng.choice([0.0, 0.25, 0.5, 0.75, 0.99999994, float(rng.random())])))
-            ref = g.walk(threads=8, **kw)
+            sel = None
+            if kind == 3:          # the CPU oracle is O(deg) per step: compare the hubs and a sample of the leaves only
+                verts = eng.vertices()
+                src = np.unique(np.concatenate([np.arange(nh, dtype=np.int32), rng.choice(verts, 40).astype(np.int32)]))
+                sel = np.searchsorted(verts, src)
+                ref = g.walk(sources=src, threads=8, **kw)
+            else:
+                ref = g.walk(threads=8, **kw)
             variants = [dict(), dict(force_general=True), dict(binned_tune=4 | int(rng.integers(1, 4))), dict(binned=False),
                         dict(prefix=False), dict(compact=False)]
             for v in variants:
                 got = eng.walk(**kw, **v)
                 n_walks += 1
-                if not (np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2]["n_steps"] == ref[2]):
-                    bad = np.nonzero((got[0] != ref[0]).any(axis=1))[0]
+                gp, gl = (got[0], got[1]) if sel is None else (got[0][sel], got[1][sel])
+                if not (np.array_equal(gp, ref[0]) and np.array_equal(gl, ref[1]) and (sel is not None or got[2]["n_steps"] == ref[2])):
+                    bad = np.nonzero((gp != ref[0]).any(axis=1))[0]
                     print("MISMATCH", dict(kind=int(kind), directed=directed, weights=None if w is None else w[:8]), kw, v,
-                          "walker", bad[:3], got[0][bad[0]] if len(bad) else None, ref[0][bad[0]] if len(bad) else None)
+                          "walker", bad[:3], gp[bad[0]] if len(bad) else None, ref[0][bad[0]] if len(bad) else None)
                     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True); np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_fail.npz"), s=s, d=d, w=w if w is not None else np.zeros(0))
                     return False
             if "rng" not in kw:     # Mode A against its own oracle
                 a = eng.walk(sampler="alias", **kw)
-                r = g.walk(threads=8, sampler=1, **kw)
+                r = g.walk(threads=8, sampler=1, **kw) if sel is None else g.walk(sources=src, threads=8, sampler=1, **kw)
                 n_walks += 1
-                if not (np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1])):
+                ap, al = (a[0], a[1]) if sel is None else (a[0][sel], a[1][sel])
+                if not (np.array_equal(ap, r[0]) and np.array_equal(al, r[1])):
                     print("MODE-A MISMATCH", kw); return False
     print("fuzz ok: %d graphs, %d device walks in %.0f s" % (n_graphs, n_walks, time.time() - t0))
     return True
 
 
 if __name__ == "__main__":
-    ok = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    ok = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, giant=len(sys.argv) > 3)
     sys.exit(0 if ok else 1)

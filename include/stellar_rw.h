@@ -119,9 +119,11 @@ enum {
   SRW_WALK_NO_COMPACT = 16,   /* first-order kernel: do not use the 16-byte lattice records even when available */
   SRW_WALK_NO_PREFIX = 32,    /* general kernel: always stream N(curr); do not use the exact prefix-sum search */
   SRW_WALK_NO_EDGE_HASH = 64, /* Mode A: membership by binary search in the sorted rows instead of the edge hash set */
-  SRW_WALK_NO_BINNED = 128    /* Mode R, q != 1: never use the binned prefix-sum search (streaming scan instead) */
-  /* bits 12-13: test switch, force the binned search's intersection strategy (1 = P1, 2 = P2, 3 = id-window);
-     bit 14: test switch, use the binned search on rows of any degree (default: degree >= 128) */
+  SRW_WALK_NO_BINNED = 128,   /* Mode R, q != 1: never use the binned prefix-sum search (streaming scan instead) */
+  SRW_WALK_NO_HUB_BITMAPS = 65536 /* Mode R, q != 1: do not build / use the hub rows' neighbor-set bitmaps */
+  /* bits 12-14: test switch, force the binned search's membership strategy (1 = P1, 2 = P2, 3 = id-window,
+     4 = hub bitmap where there is one); bit 15: test switch, binned search and hub bitmaps on rows of any degree
+     (defaults: degree >= 128, hubs of degree >= 1024) */
 };
 
 typedef struct {

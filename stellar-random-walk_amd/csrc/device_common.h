@@ -19,7 +19,8 @@ struct alignas(16) Row {
   uint32_t flags;
 };
 enum : uint32_t { ROW_PRESENT = 1u, ROW_IRREGULAR = 2u, ROW_ALIAS_IRREGULAR = 4u,
-                  ROW_PQ_OK = 8u };   // certified for the prefix-sum samplers under the current call's (p, q); set by k_pq_*
+                  ROW_PQ_OK = 8u };
+constexpr int ROW_HUB_SHIFT = 8;   // Row::flags >> 8 = 1 + ordinal of the row's neighbor-set bitmap (0: none); world == 1 only   // certified for the prefix-sum samplers under the current call's (p, q); set by k_pq_*
 
 struct alignas(8) Ent {
   int32_t id;
@@ -86,6 +87,8 @@ struct GraphView {
   int32_t vmin;
   int64_t n_slots;
   const float *sw;      // weight of each sorted entry (same indexing as sids / sperm)
+  const uint32_t *hub_bm;   // neighbor-set bitmaps of the hub rows (ordinal in Row::flags >> ROW_HUB_SHIFT, 0 = none)
+  int64_t hub_words;        // 32-bit words per bitmap = ceil(n_slots / 32)
 };
 
 // Philox4x32-10 (Random123).  Same constants as oracle/srw_oracle.c:orc_philox4x32_10.

@@ -82,6 +82,8 @@ struct Graph {
   DevBuf<double> pq;              // [n_entries] per-(p,q) exact base prefix sums (general kernel fast path)
   DevBuf<uint8_t> pq_ok;          // [n_slots]
   bool has_pq = false; uint32_t pq_pbits = 0, pq_qbits = 0;
+  DevBuf<uint32_t> hub_bm;        // [n_hubs][hub_words] neighbor-set bitmaps of the highest-degree rows over the id slots
+  int64_t hub_words = 0; int64_t n_hubs = 0; int32_t hub_min_deg = 0; bool has_hub = false, use_hub = false;
   DevBuf<uint64_t> ehash;         // Mode A: edge hash set (optional, built lazily when q != 1)
   uint64_t ehash_mask = 0; bool has_ehash = false; bool use_ehash = false;   // built / used by the current call
   DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
@@ -91,7 +93,8 @@ struct Graph {
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
   GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_cfo ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
-                     symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p}; }
+                     symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
+                     (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words}; }
 };
 
 struct WalkResult {
@@ -172,6 +175,7 @@ void build_pq_tables(srw_handle *h, float p, float q);
 // ---- alias_tables.hip ----
 void build_alias_tables(srw_handle *h);
 void build_edge_hash(srw_handle *h);
+void build_hub_bitmaps(srw_handle *h, int32_t min_deg);   // graph_build.hip
 
 // ---- walk_kernels.hip ----
 void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats);

@@ -177,6 +177,7 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
   g.has_pq = false;
   g.pq.release();
   g.has_ehash = false;
+  g.has_hub = false; g.hub_bm.release(); g.n_hubs = 0;
   g.ehash.release();
 
   // 1. stable sort of the entry stream by owning vertex
@@ -399,6 +400,98 @@ void build_membership(srw_handle *h) {
     SRW_HIP(hipGetLastError());
   }
   g.has_member = true;
+}
+
+namespace {
+__global__ void k_hub_degrees(const Row *__restrict__ rows, int64_t n_slots, uint32_t *__restrict__ deg) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x)
+    deg[v] = (uint32_t)rows[v].deg;
+}
+// ordinals for the rows at or above the threshold (first come first served up to max_hubs), kept in Row::flags
+__global__ void k_hub_assign(Row *__restrict__ rows, int64_t n_slots, int32_t thr, unsigned long long max_hubs,
+                             unsigned long long *counter, uint32_t *__restrict__ hub_slot) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t f = rows[v].flags & ((1u << ROW_HUB_SHIFT) - 1u);
+    if (rows[v].deg >= thr && rows[v].deg > 0) {
+      const unsigned long long o = atomicAdd(counter, 1ull);
+      if (o < max_hubs) { f |= (uint32_t)(o + 1) << ROW_HUB_SHIFT; hub_slot[o] = (uint32_t)v; }
+    }
+    rows[v].flags = f;
+  }
+}
+__global__ void k_hub_fill(const Row *__restrict__ rows, const Ent *__restrict__ ent, const uint32_t *__restrict__ hub_slot,
+                           int64_t n_hubs, int32_t vmin, int64_t words, uint32_t *__restrict__ bm,
+                           unsigned long long *next_hub) {
+  const int lane = threadIdx.x & 63;
+  while (true) {
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(next_hub, 1ull);
+    grab = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab);
+    if ((int64_t)grab >= n_hubs) break;
+    const Row r = rows[hub_slot[grab]];
+    uint32_t *mine = bm + (int64_t)grab * words;
+    for (int32_t k = lane; k < r.deg; k += 64) {
+      const uint32_t x = (uint32_t)((int64_t)ent[r.off + k].id - vmin);
+      atomicOr(&mine[x >> 5], 1u << (x & 31));
+    }
+  }
+}
+}  // namespace
+
+// Neighbor-set bitmaps over the id slots for the highest-degree rows, as many as the memory budget allows: a step
+// whose PREVIOUS vertex is such a hub tests "x in N(prev)" with one L2-resident bit read per candidate instead of
+// intersecting two sorted rows (sampling.h, strategy P3).  Steps land on a vertex in proportion to its degree, so a
+// few thousand bitmaps cover most second-order steps of a power-law graph.
+void build_hub_bitmaps(srw_handle *h, int32_t min_deg) {
+  Graph &g = h->g;
+  if (g.has_hub && g.hub_min_deg == min_deg) return;
+  hipStream_t st = h->stream;
+  g.has_hub = false; g.n_hubs = 0;
+  const int64_t words = (g.n_slots + 31) / 32;
+  size_t free_b = 0, total_b = 0;
+  SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+  free_b += g.hub_bm.n * sizeof(uint32_t);                       // the previous set is released below
+  const size_t budget = std::min<size_t>((size_t)64 << 30, free_b > ((size_t)24 << 30) ? (free_b - ((size_t)24 << 30)) / 2 : 0);
+  int64_t max_hubs = (int64_t)(budget / ((size_t)words * 4));
+  max_hubs = std::min<int64_t>(max_hubs, ((int64_t)1 << (32 - ROW_HUB_SHIFT)) - 2);
+  // threshold = degree of the max_hubs-th largest row (device sort of the degrees), but never below min_deg
+  int32_t thr = min_deg;
+  if (max_hubs > 0 && g.n_slots > max_hubs) {
+    DevBuf<uint32_t> d_in, d_out; DevBuf<char> temp;
+    d_in.alloc((size_t)g.n_slots); d_out.alloc((size_t)g.n_slots);
+    hipLaunchKernelGGL(k_hub_degrees, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, g.rows.p, g.n_slots, d_in.p);
+    size_t tb = 0;
+    SRW_HIP(rocprim::radix_sort_keys_desc(nullptr, tb, d_in.p, d_out.p, (size_t)g.n_slots, 0u, 32u, st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::radix_sort_keys_desc((void *)temp.p, tb, d_in.p, d_out.p, (size_t)g.n_slots, 0u, 32u, st));
+    uint32_t kth = 0;
+    SRW_HIP(hipMemcpyAsync(&kth, d_out.p + (max_hubs - 1), 4, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    thr = std::max<int32_t>(min_deg, (int32_t)std::min<uint32_t>(kth, 0x7FFFFFFFu));
+  }
+  DevBuf<unsigned long long> counter; counter.alloc(1);
+  DevBuf<uint32_t> hub_slot; hub_slot.alloc((size_t)std::max<int64_t>(max_hubs, 1));
+  SRW_HIP(hipMemsetAsync(counter.p, 0, 8, st));
+  // max_hubs == 0 (no memory): the kernel still clears stale ordinals
+  hipLaunchKernelGGL(k_hub_assign, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, g.rows.p, g.n_slots, thr,
+                     (unsigned long long)std::max<int64_t>(max_hubs, 0), counter.p, hub_slot.p);
+  unsigned long long n = 0;
+  SRW_HIP(hipMemcpyAsync(&n, counter.p, 8, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  g.n_hubs = (int64_t)std::min<unsigned long long>(n, (unsigned long long)std::max<int64_t>(max_hubs, 0));
+  g.hub_words = words; g.hub_min_deg = min_deg;
+  g.hub_bm.release();
+  if (g.n_hubs > 0) {
+    g.hub_bm.alloc((size_t)g.n_hubs * words);
+    SRW_HIP(hipMemsetAsync(g.hub_bm.p, 0, (size_t)g.n_hubs * words * 4, st));
+    SRW_HIP(hipMemsetAsync(counter.p, 0, 8, st));
+    hipLaunchKernelGGL(k_hub_fill, dim3(256 * 8), dim3(TPB), 0, st, g.rows.p, g.ent.p, hub_slot.p, g.n_hubs, g.vmin, words,
+                       g.hub_bm.p, counter.p);
+    SRW_HIP(hipGetLastError());
+    SRW_HIP(hipStreamSynchronize(st));
+  }
+  g.has_hub = true;
 }
 
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,

@@ -312,24 +312,34 @@ __global__ void k_fo_from_slim(const Row *__restrict__ rows, const Ent *__restri
 }
 
 // ---- per-call exact prefix sums of the base weights fl(w / q) (general kernel, prefix-sum sampler) ---------------
-// A row qualifies when every variant a candidate can take — fl(w/q), w, fl(w/p) — is finite and >= 0 and the
-// exactness certificate holds over ALL of them: then every sum of any selection of variants, in any order, is exact.
+// A row qualifies when every variant a candidate can take — fl(w/q), w, fl(w/p) — is finite and >= 0 and NO sum the
+// samplers form can round: every variant is a multiple of g = 2^(emin - 23) (emin = smallest exponent of a nonzero
+// variant), and every quantity the samplers form — a prefix of base weights, a sum of corrections |w' - fl(w/q)| <=
+// max variant, their sum — is bounded in magnitude by 2 M with M = sum over the row of the LARGEST variant; so
+// 2 M <= 2^53 g makes all of them exactly representable, in any order.  M is accumulated in f64 (relative error
+// <= n 2^-53), hence one more bit of margin: M <= 2^51 g.  (The cruder bound n 2^(emax+1) for M turned hub rows away
+// four times earlier — at config 3 every row beyond 524 288 entries, which then took the streaming scan.)
 struct PqCert {
-  int emin, emax; bool bad;
-  __device__ PqCert() : emin(1 << 20), emax(-(1 << 20)), bad(false) {}
+  int emin; bool bad; double mass;
+  __device__ PqCert() : emin(1 << 20), bad(false), mass(0.0) {}
   __device__ inline void add(float x) {
     uint32_t b = __float_as_uint(x);
     int ex = (int)((b >> 23) & 0xFFu);
     if (ex == 255 || (b >> 31 && (b & 0x7FFFFFFFu))) { bad = true; return; }
     if ((b & 0x7FFFFFFFu) == 0u) return;
     int e = ex ? ex - 127 : -126;
-    emin = min(emin, e); emax = max(emax, e);
+    emin = min(emin, e);
+  }
+  __device__ inline void add_entry(float w, float p, float q) {
+    const float a = w / q, c = w / p;
+    add(w); add(a); add(c);
+    mass += (double)fmaxf(w, fmaxf(a, c));      // NaN-free once !bad
   }
 };
-__device__ inline bool pq_row_ok(int emin, int emax, bool bad, int32_t n) {
+__device__ inline bool pq_row_ok(int emin, bool bad, double mass) {
   if (bad) return false;
-  if (emax < emin) return false;                      // all-zero row: leave it to the literal sampler
-  return ceil_log2_i64(n) + 2 + emax - emin <= 29;    // +2: headroom for sums of differences of variants
+  if (emin > (1 << 19)) return false;                 // all-zero row: leave it to the literal sampler
+  return mass <= ldexp(1.0, 51 + emin - 23);
 }
 
 __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, double *__restrict__ pq,
@@ -340,8 +350,8 @@ __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, 
     if (r.flags & ROW_PQ_OK) rows[v].flags = r.flags & ~ROW_PQ_OK;   // the flag mirrors ok[v] (one load less per step)
     if (r.deg <= 0 || r.deg > SMALL_DEG) continue;
     PqCert c;
-    for (int32_t k = 0; k < r.deg; ++k) { float w = ent[r.off + k].w; c.add(w); c.add(w / q); c.add(w / p); }
-    if (!pq_row_ok(c.emin, c.emax, c.bad, r.deg)) continue;
+    for (int32_t k = 0; k < r.deg; ++k) c.add_entry(ent[r.off + k].w, p, q);
+    if (!pq_row_ok(c.emin, c.bad, c.mass)) continue;
     double acc = 0.0;
     for (int32_t k = 0; k < r.deg; ++k) { acc += (double)(ent[r.off + k].w / q); pq[r.off + k] = acc; }
     ok[v] = 1;
@@ -363,10 +373,11 @@ __global__ void k_pq_large(Row *__restrict__ rows, const Ent *__restrict__ ent, 
       if (r.deg <= SMALL_DEG) continue;
       const Ent *row = ent + r.off;
       PqCert c;
-      for (int32_t k = lane; k < r.deg; k += 64) { float w = row[k].w; c.add(w); c.add(w / q); c.add(w / p); }
-      int emin = wave_min_i32(c.emin), emax = wave_max_i32(c.emax);
-      bool bad = __any(c.bad);
-      if (!pq_row_ok(emin, emax, bad, r.deg)) continue;              // ok[v] stays 0 (set by k_pq_small)
+      for (int32_t k = lane; k < r.deg; k += 64) c.add_entry(row[k].w, p, q);
+      const int emin = wave_min_i32(c.emin);
+      const bool bad = __any(c.bad);
+      const double mass = wave_sum_f64(bad ? 0.0 : c.mass);
+      if (!pq_row_ok(emin, bad, mass)) continue;                     // ok[v] stays 0 (set by k_pq_small)
       double carry = 0.0;                                            // exact sums: any order gives the same bits
       for (int32_t base = 0; base < r.deg; base += 64) {
         int32_t k = base + lane;

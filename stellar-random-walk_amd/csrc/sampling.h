@@ -6,6 +6,7 @@ namespace srw {
 
 // ---- node2vec bias: RandomSample.computeSecondOrderWeights (:27-44) ------------------------------------
 struct Bias {
+  uint32_t prev_hub = 0;   // 1 + ordinal of N(prev)'s bitmap over the id slots, 0 = none (GraphView::hub_bm)
   float p, q;
   int32_t prev;             // previous vertex id
   bool second_order;        // false on the first step (initFirstStep samples the raw weights, RandomWalk.scala:57)
@@ -189,6 +190,7 @@ struct Member {
   uint32_t *bm;        // LDS, BM_WORDS words, private to the wave
   int32_t seg_base;    // first candidate position covered by the bitmap
   const uint64_t *ehash = nullptr; uint64_t ehash_mask = 0;   // edge hash set (whole-graph handles): mode 1 probes it
+  const uint32_t *hub = nullptr;   // this step's N(prev) bitmap over the id slots, if prev is a hub: mode 1 reads one bit
 #ifdef SRW_PHASE_TIMING
   unsigned long long t_fill = 0, t_pass1 = 0, t_pass2 = 0, t_prefix = 0, t_mark;
   unsigned long long t_a = 0, t_p1 = 0, t_p2 = 0, t_w = 0, t_fin = 0;
@@ -216,6 +218,7 @@ __device__ inline float biased_weight_m(const Bias &b, const Member &m, int32_t 
   if (m.mode == 0) return w / b.q;
   bool in;
   if (m.mode == 2) { uint32_t t = (uint32_t)(pos - m.seg_base); in = (m.bm[t >> 5] >> (t & 31)) & 1u; }
+  else if (m.hub) { const uint32_t x = (uint32_t)((int64_t)id - b.vmin); in = (m.hub[x >> 5] >> (x & 31)) & 1u; }
   else if (m.ehash) in = edge_exists(m.ehash, m.ehash_mask, (uint32_t)((int64_t)b.prev - b.vmin), (uint32_t)((int64_t)id - b.vmin));
   else in = sorted_contains(b.prev_sids, b.prev_deg, (uint32_t)((int64_t)id - b.vmin));
   return in ? w : w / b.q;
@@ -338,12 +341,13 @@ __device__ inline int32_t wave_pick_scan(const GraphView &g, const Row &rc, cons
   const uint32_t *csids = g.sids + rc.off, *csperm = g.sperm + rc.off;
   // membership strategy
   m.mode = 0;
+  m.hub = (b.need_member && b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
   if (b.need_member) {
     // cost model (in binary-search probes): per-candidate search twice (two passes) vs reverse marking per segment
     int lp = 32 - __clz(b.prev_deg | 1), lc = 32 - __clz(deg | 1);
     int64_t nseg = ((int64_t)deg + BM_BITS - 1) / BM_BITS;
     const int64_t probe = (int64_t)b.prev_deg * lc, merged = ((int64_t)deg + b.prev_deg) / 2;
-    int64_t direct = 2ll * deg * (m.ehash ? 2 : lp), reverse = 2ll * nseg * (probe < merged ? probe : merged) + deg / 16;
+    int64_t direct = 2ll * deg * (m.hub ? 1 : m.ehash ? 2 : lp), reverse = 2ll * nseg * (probe < merged ? probe : merged) + deg / 16;
     m.mode = reverse < direct ? 2 : 1;
   }
   const int32_t seg_cap = (m.mode == 2) ? BM_BITS : 0x7FFFFFFF;
@@ -619,7 +623,8 @@ __device__ inline void wave_lower_bound_multi(LowerBound (&s)[K]) {
   }
 }
 
-// tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W (tests force each one); force_small: no minimum degree
+// tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W, 4 = P3 if prev has a bitmap (tests force each one);
+// force_small: no minimum degree
 __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
                                            uint32_t *lds, float r, unsigned &fallback, unsigned &served, int tune,
                                            bool force_small, Member &tm) {
@@ -644,21 +649,43 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
   const float p_ = b.p, q_ = b.q;
   // strategy for (b) first, so that every wave-uniform lower bound this step needs is searched in one lockstep pass
   int strat = tune;
+  const uint32_t *hubbits = (b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
+  if (strat == 4 && !hubbits) strat = 0;               // forced P3 without a bitmap: automatic choice
   uint32_t lo_id = 1u, hi_id = 0u;
   if (m > 0 && (strat == 0 || strat == 3)) {
     lo_id = max(cs[0], B[0]); hi_id = min(cs[deg - 1], B[m - 1]);
     if (strat == 0) {
       const int lc = 32 - __clz(deg | 1), lp = 32 - __clz(m | 1);
       // rough wave-cycles: a dependent probe chain ~ 10 cycles per level per element (5 with two in lockstep)
-      const int64_t c1 = (int64_t)m * lc * 5, c2 = (int64_t)deg * (g.ehash ? 6 : lp) * 10;
+      // per candidate: P3 = one bit read (a random sector, like the hash probe, but no hashing and no probe loop)
+      const int64_t c1 = (int64_t)m * lc * 5, c2 = (int64_t)deg * (hubbits ? 3 : g.ehash ? 6 : lp) * 10;
       const int64_t span = lo_id > hi_id ? 0 : (int64_t)((hi_id - lo_id) / WIN_BITS) + 1;
       const int64_t nwin = span < ((int64_t)deg + m) / 8 ? span : ((int64_t)deg + m) / 8;
       const int64_t cw = ((int64_t)deg + m) * 2 + nwin * 1000 + 4000;
-      strat = (cw < c1 && cw < c2) ? 3 : (c1 <= c2 ? 1 : 2);
+      strat = (cw < c1 && cw < c2) ? 3 : (c1 <= c2 ? 1 : (hubbits ? 4 : 2));
     }
   }
-  int32_t ret_lo, pa = 0, pb = 0;
-  if (strat == 3 && lo_id <= hi_id) {
+  int32_t ret_lo = deg, pa = 0, pb = 0;
+  if (strat == 4 && m > 0) {
+    // P3: prev is a hub with a neighbor-set bitmap over the id slots.  One streaming pass over N(curr) in INPUT order
+    // (entries as they are, no sorted structure): a candidate is a member iff its bit is set — one L2-resident read
+    // each, four in flight per lane — and the return edges are recognised on the way.
+    for (int32_t k0 = 0; k0 < deg; k0 += 256) {
+      Ent e[4]; uint32_t wd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int32_t k = k0 + u * 64 + lane; e[u].id = b.prev; e[u].w = 0.0f; if (k < deg) e[u] = row[k]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const uint32_t x = (uint32_t)((int64_t)e[u].id - b.vmin); wd[u] = hubbits[x >> 5]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int32_t k = k0 + u * 64 + lane;
+        if (k >= deg) continue;
+        const uint32_t x = (uint32_t)((int64_t)e[u].id - b.vmin);
+        if (e[u].id == b.prev) atomicAdd(&bins[k >> csh], (double)(e[u].w / p_) - (double)(e[u].w / q_));
+        else if ((wd[u] >> (x & 31)) & 1u) atomicAdd(&bins[k >> csh], (double)e[u].w - (double)(e[u].w / q_));
+      }
+    }
+  } else if (strat == 3 && lo_id <= hi_id) {
     LowerBound lb[3] = {{cs, 0, deg, xprev, false}, {cs, 0, deg, lo_id, false}, {B, 0, m, lo_id, false}};
     wave_lower_bound_multi<3>(lb);
     ret_lo = lb[0].lo; pa = lb[1].lo; pb = lb[2].lo;
@@ -670,7 +697,7 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
     atomicAdd(&bins[cp[c] >> csh], (double)(csw[c] / p_) - (double)(csw[c] / q_));
   SRW_T1(tm, t_a); SRW_T0(tm);
   // (b) members of N(prev)
-  if (m > 0) {
+  if (m > 0 && strat != 4) {
 #ifdef SRW_PHASE_TIMING
     tm.n_binned += 1;
     if (strat == 1) { tm.n_p1 += 1; tm.n_p1_elems += m; }
@@ -879,7 +906,8 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
       else {
         const uint32_t xs = (uint32_t)((int64_t)e.id - b.vmin);
         // one probe of the edge hash set (prev -> x) instead of a log2|N(prev)|-deep dependent search
-        const bool in = g.ehash ? edge_exists(g.ehash, g.ehash_mask, xprev, xs) : sorted_contains(B, m, xs);
+        const bool in = hubbits ? ((hubbits[xs >> 5] >> (xs & 31)) & 1u) != 0u
+                        : g.ehash ? edge_exists(g.ehash, g.ehash_mask, xprev, xs) : sorted_contains(B, m, xs);
         if (in) corr = (double)e.w - (double)(e.w / q_);
       }
     }

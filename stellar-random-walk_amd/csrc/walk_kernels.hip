@@ -175,16 +175,16 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
       if (rp) r = *rp;
       if (r.deg == 0) { dead += s > 1; break; }
       Bias b = make_bias(g, p, q, prev, s > 1);     // need_member: N(prev) from the membership structure ...
-      if (b.need_member) { b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; }   // ... = last step's row here
+      if (b.need_member) { b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT; }   // ... = last step's row here
       float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
       unsigned f = 0, sv = 0;
       SRW_T0(mem);
       // search over exact prefix sums: a short list of specials (return edges only) when q == 1, position bins else
       int32_t k = -1;
-      if (!b.need_member || (tune & 8)) k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);
+      if (!b.need_member || (tune & 16)) k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);
       SRW_T1(mem, t_prefix);
-      if (k < 0 && !(tune & 8)) {
-        k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 3, (tune & 4) != 0, mem);
+      if (k < 0 && !(tune & 16)) {
+        k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 7, (tune & 8) != 0, mem);
         if (k >= 0) srch += (unsigned long long)r.deg;       // the sorted ids of N(curr) were read instead of its entries
       }
       if (k < 0) { k = wave_pick_scan(g, r, b, mem, u, f); degc += (unsigned long long)r.deg; }
@@ -712,7 +712,7 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
     SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_walk_general, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
                        P.walk_length, first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p,
-                       (int32_t)(((P.flags >> 12) & 7) | ((P.flags & SRW_WALK_NO_BINNED) ? 8 : 0)));
+                       (int32_t)(((P.flags >> 12) & 15) | ((P.flags & SRW_WALK_NO_BINNED) ? 16 : 0)));
   }
   SRW_HIP(hipGetLastError());
   LaunchInfo li;
@@ -733,6 +733,10 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool want_ehash = P.q != 1.0f && !(P.flags & SRW_WALK_NO_EDGE_HASH) && (alias || (general && h->cfg.world == 1));
   if (want_ehash) build_edge_hash(h);
   h->g.use_ehash = want_ehash;
+  // neighbor-set bitmaps of the hub rows: the general kernel's "x in N(prev)" for steps that come from a hub
+  const bool want_hub = general && P.q != 1.0f && h->cfg.world == 1 && !(P.flags & SRW_WALK_NO_HUB_BITMAPS);
+  if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024);
+  h->g.use_hub = want_hub;
   if (!alias && !first_order && !(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX))
     build_pq_tables(h, P.p, P.q);                    // optional: exact base prefix sums for the search sampler
   else if (!alias && !first_order) h->g.has_pq = false;

@@ -61,7 +61,7 @@ def run(budget=60.0, seed=1, eng=None, giant=False):
                 ref = g.walk(sources=src, threads=8, **kw)
             else:
                 ref = g.walk(threads=8, **kw)
-            variants = [dict(), dict(force_general=True), dict(binned_tune=4 | int(rng.integers(1, 4))), dict(binned=False),
+            variants = [dict(), dict(force_general=True), dict(binned_tune=8 | int(rng.integers(1, 5))), dict(hub_bitmaps=False), dict(binned=False),
                         dict(prefix=False), dict(compact=False)]
             for v in variants:
                 got = eng.walk(**kw, **v)

@@ -621,7 +621,7 @@ def test_empty_and_degenerate_inputs(eng, oracle, tmp_path):
 
 
 # ---- binned prefix-sum search (Mode R, q != 1): every intersection strategy, every row size ---------------------
-BINNED_TUNES = [0, 4 | 1, 4 | 2, 4 | 3]     # automatic; forced P1 / P2 / id-window on rows of ANY degree
+BINNED_TUNES = [0, 8 | 1, 8 | 2, 8 | 3, 8 | 4]     # automatic; forced P1 / P2 / id-window / hub bitmap on rows of ANY degree
 
 
 @pytest.mark.parametrize("case", ["rmat12", "rmat12w", "rmat11wd", "rmat12f", "rmat12x", "multi", "multi_neg"])
@@ -649,6 +649,8 @@ def test_binned_search_all_strategies(eng, oracle, case):
                 assert st["ent_reads"] > 0, "binned search was not exercised"
         paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, binned=False)
         assert np.array_equal(paths, ref[0])
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, hub_bitmaps=False)
+        assert np.array_equal(paths, ref[0])
         # draws exactly on CDF boundaries (constant r on the 2^-24 lattice)
         for r in (0.5, 0.25):
             refc = g.walk(p=p, q=q, walk_length=8, rng="const", const_r=r, threads=8)
@@ -674,7 +676,7 @@ def test_binned_search_two_giant_hubs(eng, oracle):
     idx = np.searchsorted(verts, src)
     for p, q in [(0.25, 4.0), (4.0, 0.5)]:
         rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=8, seed=29, threads=8)
-        for tune in (0, 3, 1):
+        for tune in (0, 3, 1, 4):
             paths, lens, st = eng.walk(p=p, q=q, walk_length=8, seed=29, binned_tune=tune)
             assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl), (p, q, tune)
             assert st["ent_reads"] > 0

@@ -551,16 +551,15 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
 // The members of N(prev) among the candidates are found by the cheapest of three strategies over the SORTED rows:
 //   P1  every distinct id of N(prev) is searched in N(curr)                    ~ |N(prev)| log |N(curr)| probes
 //   P2  every candidate (input order, no permutation needed) is searched in N(prev) ~ |N(curr)| log |N(prev)| probes
-//   W   id-window bitmap: both sorted id lists are streamed once in chunks of 1024 ids (16-byte loads, 16 ids per
-//       lane, kept in registers until their last id is below the window end); the ids of N(prev) inside the current
-//       window of 40960 vertex ids set bits in LDS (one non-returning ds_or each), the candidates test them (one
-//       ds_read each).  The window starts at the smallest id both lists still have, so empty id ranges cost nothing.
-//       (A hash set per chunk was tried: 3x the LDS operations, slower.)
+//   W   sorted-chunk intersection: 1024 ids of N(prev) at a time are staged in LDS in sorted order, the candidates
+//       come 256 at a time (16-byte loads; ids, positions and weights) and do a branch-free 10-level lower bound in
+//       LDS, four per lane in lockstep; whichever list ends first in id order advances.  At most
+//       |N(curr)| / 256 + |N(prev)| / 1024 rounds, independent of the id range.  (Tried before it: an id-window bitmap
+//       — 6 us per window, 300 windows per step at RMAT-24 — and an LDS hash set per chunk — 3x the LDS operations.)
 constexpr int BIN_CAP = 512;                  // f64 bins: 4 KB of the wave's LDS
 constexpr int WIN_WORDS = 1280;               // id-window bitmap behind the bins: 5 KB (40960 vertex ids)
 constexpr int WIN_BITS = WIN_WORDS * 32;
-constexpr int NE = 8;                       // ids per lane and chunk
-constexpr int HCHUNK = 64 * NE;
+constexpr int HCHUNK = 1024;                // ids of N(prev) staged in LDS per round
 constexpr uint32_t HEMPTY = 0xFFFFFFFFu;
 constexpr int BINNED_LDS_WORDS = 2 * BIN_CAP + WIN_WORDS;
 struct __attribute__((packed, aligned(4))) U32x4 { uint32_t a, b, c, d; };   // 16-byte load at 4-byte alignment
@@ -659,9 +658,7 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
       // rough wave-cycles: a dependent probe chain ~ 10 cycles per level per element (5 with two in lockstep)
       // per candidate: P3 = one bit read (a random sector, like the hash probe, but no hashing and no probe loop)
       const int64_t c1 = (int64_t)m * lc * 5, c2 = (int64_t)deg * (hubbits ? 3 : g.ehash ? 6 : lp) * 10;
-      const int64_t span = lo_id > hi_id ? 0 : (int64_t)((hi_id - lo_id) / WIN_BITS) + 1;
-      const int64_t nwin = span < ((int64_t)deg + m) / 8 ? span : ((int64_t)deg + m) / 8;
-      const int64_t cw = ((int64_t)deg + m) * 2 + nwin * 1000 + 4000;
+      const int64_t cw = (int64_t)deg * 2 + (int64_t)m / 2 + 3000;      // ~2000 cycles per round of 256 / 1024 ids
       strat = (cw < c1 && cw < c2) ? 3 : (c1 <= c2 ? 1 : (hubbits ? 4 : 2));
     }
   }
@@ -737,106 +734,92 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
       }
     } else {
       if (lo_id <= hi_id) {
-        uint32_t AI[NE], AC[NE], BI[NE];
-        float AW[NE];
-        // element e = 4 * u + j of a lane sits at list position pos + 256 * u + 4 * lane + j: sorted in (u, lane, j)
-        auto load_ids = [&](const uint32_t *a_, int32_t pos, int32_t n_, uint32_t v[NE]) {
+        // Sorted-chunk intersection.  1024 ids of N(prev) are staged in LDS in sorted order (16-byte loads, padded with
+        // 0xFFFFFFFF); the candidates come 256 at a time (4 per lane, with their input-order positions and weights)
+        // and every candidate not above the staged chunk's last id does a branch-free 10-level lower bound in LDS,
+        // four searches per lane in lockstep.  Whichever list ends first in id order advances: at most
+        // |N(curr)| / 256 + |N(prev)| / 1024 rounds, independent of the id range.
+        uint32_t *bch = win;                                 // 1024 words of the 1280-word region
+        uint32_t AI[4], AC[4], AIn[4], ACn[4];
+        float AW[4], AWn[4];
+        auto load_a = [&](int32_t pos, uint32_t v[4], uint32_t c[4], float w[4]) {   // lane holds 4 consecutive entries
+          const int32_t i0 = pos + 4 * lane;
+          if (i0 + 3 < deg) {
+            const U32x4 q = *reinterpret_cast<const U32x4 *>(cs + i0);
+            const U32x4 r4 = *reinterpret_cast<const U32x4 *>(cp + i0);
+            const F32x4 w4 = *reinterpret_cast<const F32x4 *>(csw + i0);
+            v[0] = q.a; v[1] = q.b; v[2] = q.c; v[3] = q.d;
+            c[0] = r4.a; c[1] = r4.b; c[2] = r4.c; c[3] = r4.d;
+            w[0] = w4.a; w[1] = w4.b; w[2] = w4.c; w[3] = w4.d;
+          } else {
 #pragma unroll
-          for (int u = 0; u < NE / 4; ++u) {
-            const int32_t i0 = pos + 256 * u + 4 * lane;
-            if (i0 + 3 < n_) {
-              const U32x4 q = *reinterpret_cast<const U32x4 *>(a_ + i0);
-              v[4 * u] = q.a; v[4 * u + 1] = q.b; v[4 * u + 2] = q.c; v[4 * u + 3] = q.d;
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[4 * u + j] = (i0 + j < n_) ? a_[i0 + j] : HEMPTY;
+            for (int j = 0; j < 4; ++j) {
+              const bool ok = i0 + j < deg;
+              v[j] = ok ? cs[i0 + j] : HEMPTY; c[j] = ok ? cp[i0 + j] : 0u; w[j] = ok ? csw[i0 + j] : 0.0f;
             }
           }
         };
-        auto load_w = [&](int32_t pos, float v[NE]) {
+        auto stage_b = [&](int32_t pos) {                       // B[pos .. pos + 1024) -> LDS, sorted, padded
 #pragma unroll
-          for (int u = 0; u < NE / 4; ++u) {
+          for (int u = 0; u < 4; ++u) {
             const int32_t i0 = pos + 256 * u + 4 * lane;
-            if (i0 + 3 < deg) {
-              const F32x4 q = *reinterpret_cast<const F32x4 *>(csw + i0);
-              v[4 * u] = q.a; v[4 * u + 1] = q.b; v[4 * u + 2] = q.c; v[4 * u + 3] = q.d;
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[4 * u + j] = (i0 + j < deg) ? csw[i0 + j] : 0.0f;
-            }
+            uint4 q;
+            if (i0 + 3 < m) { const U32x4 t = *reinterpret_cast<const U32x4 *>(B + i0); q = make_uint4(t.a, t.b, t.c, t.d); }
+            else q = make_uint4(i0 < m ? B[i0] : HEMPTY, i0 + 1 < m ? B[i0 + 1] : HEMPTY, i0 + 2 < m ? B[i0 + 2] : HEMPTY, HEMPTY);
+            reinterpret_cast<uint4 *>(bch)[64 * u + lane] = q;
           }
         };
-        auto chunk_max = [&](const uint32_t v[NE], int32_t pos, int32_t n_) {       // last (= largest) valid id
-          uint32_t l = 0;
-#pragma unroll
-          for (int e = 0; e < NE; ++e) if (pos + 256 * (e >> 2) + 4 * lane + (e & 3) < n_) l = max(l, v[e]);
-          return wave_max_u32(l);
-        };
-        auto chunk_next = [&](const uint32_t v[NE], int32_t pos, int32_t n_, uint64_t limit) {   // smallest id >= limit
-          uint32_t l = HEMPTY;
-#pragma unroll
-          for (int e = 0; e < NE; ++e)
-            if (pos + 256 * (e >> 2) + 4 * lane + (e & 3) < n_ && (uint64_t)v[e] >= limit) l = min(l, v[e]);
-          return wave_min_u32(l);
-        };
-        load_ids(B, pb, m, BI);
-        load_ids(cs, pa, deg, AI); load_ids(cp, pa, deg, AC); load_w(pa, AW);
-        uint32_t amax = chunk_max(AI, pa, deg), bmax = chunk_max(BI, pb, m);
-        uint32_t next_a = lo_id, next_b = lo_id;      // lower bounds of the smallest ids not consumed yet
-        bool dirty = true;
+        stage_b(pb);
+        load_a(pa, AI, AC, AW);
+        load_a(pa + 256, AIn, ACn, AWn);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t handled = 0; bool have_handled = false;     // candidates <= handled met every id of N(prev) they could equal
 #ifdef SRW_PHASE_TIMING
         tm.n_w += 1; tm.n_w_elems += (unsigned long long)(deg - pa) + (m - pb);
 #endif
         while (true) {
-          const uint32_t base = next_a > next_b ? next_a : next_b;
-          if (base > hi_id) break;
-          const uint64_t limit = (uint64_t)base + WIN_BITS;
 #ifdef SRW_PHASE_TIMING
           tm.n_w_windows += 1;
 #endif
-          if (dirty) {
+          const int32_t nb = (m - pb) < HCHUNK ? (m - pb) : HCHUNK;
+          const uint32_t bmax = bch[nb - 1];                   // uniform LDS read
+          // my four candidates against the staged chunk
+          bool want[4]; uint32_t pos[4];
 #pragma unroll
-            for (int t = 0; t < WIN_WORDS / 256; ++t) reinterpret_cast<uint4 *>(win)[lane + 64 * t] = make_uint4(0u, 0u, 0u, 0u);
+          for (int j = 0; j < 4; ++j) {
+            want[j] = AI[j] <= bmax && AI[j] != xprev && !(have_handled && AI[j] <= handled);   // padding never <= bmax
+            pos[j] = 0u;
+          }
+#pragma unroll
+          for (int step = HCHUNK / 2; step >= 1; step >>= 1) {
+            uint32_t probe[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) probe[j] = bch[pos[j] + step - 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (probe[j] < AI[j]) pos[j] += step;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (want[j] && bch[pos[j]] == AI[j]) atomicAdd(&bins[AC[j] >> csh], (double)AW[j] - (double)(AW[j] / q_));
+          // advance the list that ends first
+          const int32_t na = (deg - pa) < 256 ? (deg - pa) : 256;
+          const int jl = (na - 1) & 3;
+          const uint32_t alast = jl == 0 ? AI[0] : jl == 1 ? AI[1] : jl == 2 ? AI[2] : AI[3];
+          const uint32_t amax = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)alast, (na - 1) >> 2));
+          if (amax <= bmax) {
+            pa += 256;
+            if (pa >= deg) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { AI[j] = AIn[j]; AC[j] = ACn[j]; AW[j] = AWn[j]; }
+            load_a(pa + 256, AIn, ACn, AWn);
+          } else {
+            handled = bmax; have_handled = true;
+            pb += HCHUNK;
+            if (pb >= m || bmax >= hi_id) break;
+            __builtin_amdgcn_wave_barrier();
+            stage_b(pb);
             __builtin_amdgcn_wave_barrier();
           }
-          bool marked = false, a_done = false, b_done = false;
-          // v in [base, limit)  <=>  (uint32)(v - base) < width (unsigned wrap); padding ids (0xFFFFFFFF) never qualify
-          const uint32_t width = (uint32_t)((limit > 0xFFFFFFFFull ? 0xFFFFFFFFull : limit) - base);
-          while (true) {                                     // ids of N(prev) inside the window: set bits
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-              const uint32_t t = BI[e] - base;
-              if (t < width) { atomicOr(&win[t >> 5], 1u << (t & 31)); marked = true; }
-            }
-            if ((uint64_t)bmax >= limit) { next_b = chunk_next(BI, pb, m, limit); break; }
-            pb += HCHUNK;
-            if (pb >= m) { b_done = true; break; }
-            load_ids(B, pb, m, BI);
-            bmax = chunk_max(BI, pb, m);
-          }
-          {                                                  // prev itself is a return edge, not a member
-            const uint32_t t = xprev - base;
-            if (t < width && lane == 0) atomicAnd(&win[t >> 5], ~(1u << (t & 31)));
-          }
-          dirty = __any(marked);
-          __builtin_amdgcn_wave_barrier();
-          while (true) {                                     // candidates inside the window: test bits
-            if (dirty) {
-#pragma unroll
-              for (int e = 0; e < NE; ++e) {
-                const uint32_t t = AI[e] - base;
-                if (t < width && ((win[t >> 5] >> (t & 31)) & 1u))
-                  atomicAdd(&bins[AC[e] >> csh], (double)AW[e] - (double)(AW[e] / q_));
-              }
-            }
-            if ((uint64_t)amax >= limit) { next_a = chunk_next(AI, pa, deg, limit); break; }
-            pa += HCHUNK;
-            if (pa >= deg) { a_done = true; break; }
-            load_ids(cs, pa, deg, AI); load_ids(cp, pa, deg, AC); load_w(pa, AW);
-            amax = chunk_max(AI, pa, deg);
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (a_done || b_done) break;
         }
       }
     }

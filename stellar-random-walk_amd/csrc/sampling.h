@@ -626,7 +626,7 @@ __device__ inline void wave_lower_bound_multi(LowerBound (&s)[K]) {
 // force_small: no minimum degree
 __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
                                            uint32_t *lds, float r, unsigned &fallback, unsigned &served, int tune,
-                                           bool force_small, Member &tm) {
+                                           bool force_small, Member &tm, unsigned long long &alg_bytes) {
   if (!g.pq || !b.second_order || !b.need_member) return -1;
   const int32_t deg = rc.deg;
   if ((!force_small && deg < 128) || !(rc.flags & ROW_PQ_OK)) return -1;
@@ -667,6 +667,7 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
     // P3: prev is a hub with a neighbor-set bitmap over the id slots.  One streaming pass over N(curr) in INPUT order
     // (entries as they are, no sorted structure): a candidate is a member iff its bit is set — one L2-resident read
     // each, four in flight per lane — and the return edges are recognised on the way.
+    alg_bytes += 12ull * (unsigned long long)deg;        // 8-byte entries + one bitmap word per candidate
     for (int32_t k0 = 0; k0 < deg; k0 += 256) {
       Ent e[4]; uint32_t wd[4];
 #pragma unroll
@@ -699,6 +700,9 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
     tm.n_binned += 1;
     if (strat == 1) { tm.n_p1 += 1; tm.n_p1_elems += m; }
 #endif
+    if (strat == 1) alg_bytes += 4ull * (unsigned long long)m * (unsigned long long)(1 + (32 - __clz(deg | 1)));   // ids + probes
+    else if (strat == 2) alg_bytes += 16ull * (unsigned long long)deg;                                            // entries + hash slots
+    else alg_bytes += 12ull * (unsigned long long)(deg - pa) + 4ull * (unsigned long long)(m - pb);              // both sorted rows
     if (strat == 1) {
       // two searches per lane in lockstep: twice the loads in flight on the dependent probe chain
       for (int32_t t0 = lane; t0 < m; t0 += 128) {

@@ -181,17 +181,18 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
       SRW_T0(mem);
       // search over exact prefix sums: a short list of specials (return edges only) when q == 1, position bins else
       int32_t k = -1;
+      bool binned_served = false;
       if (!b.need_member || (tune & 16)) k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);
       SRW_T1(mem, t_prefix);
       if (k < 0 && !(tune & 16)) {
-        k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 7, (tune & 8) != 0, mem);
-        if (k >= 0) srch += (unsigned long long)r.deg;       // the sorted ids of N(curr) were read instead of its entries
+        k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 7, (tune & 8) != 0, mem, srch);
+        binned_served = k >= 0;                             // srch: bytes its membership strategy read (bench.py)
       }
       if (k < 0) { k = wave_pick_scan(g, r, b, mem, u, f); degc += (unsigned long long)r.deg; }
       else { fast += sv; }
       int32_t next = g.ent[r.off + k].id;
       fb += f;
-      if (b.need_member) degp += (unsigned long long)b.prev_deg;
+      if (b.need_member && !binned_served) degp += (unsigned long long)b.prev_deg;
       if (lane == 0) path[s] = next;
       prev = curr; curr = next; ++len; rprev = r;
     }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     if (degp) atomicAdd(&ctr->sum_deg_prev, degp);
     if (fb) atomicAdd(&ctr->fallbacks, fb);
     if (fast) atomicAdd(&ctr->ent_reads, fast);      // general kernel: steps served by the prefix-sum search
-    if (srch) atomicAdd(&ctr->trials, srch);         // ... and the sum of deg(curr) over the binned ones
+    if (srch) atomicAdd(&ctr->trials, srch);         // ... and the bytes the binned ones' membership strategies read
 #ifdef SRW_PHASE_TIMING
     const unsigned long long tv[10] = {wall_clock64() - t_begin, mem.t_prefix, mem.t_a, mem.t_p1, mem.t_p2, mem.t_w,
                                        mem.t_fin, mem.t_fill, mem.t_pass1, mem.t_pass2};
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(TPB, 4) void k_shard_step(GraphView g, const Walker
     unsigned f = 0, sv = 0;
     int32_t k = -1;                                  // same routing as k_walk_general
     if (!b.need_member) k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
-    else k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem);
+    else { unsigned long long ab = 0; k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem, ab); }
     if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
     int32_t next = g.ent[r.off + k].id;
     if (lane == 0) {

@@ -184,7 +184,7 @@ def main():
         else:
             # general kernel (SURVEY §8d Mode R): 16 + 8*deg(curr) + 4 per step (+ 16 + 4*deg(prev) when q != 1) for the
             # steps that stream N(curr); steps served by the binned prefix-sum search count what their membership strategy
-            # reads instead (P1: ids of N(prev) + probes; P2/P3: entries + hash slot / bitmap word; W: both sorted rows)
+            # reads instead (P1: ids of N(prev) + the entries they land on; P2/P3: entries + hash slot / bitmap word; W: both sorted rows)
             per_launch_steps = steps / max(K, 1)
             alg_bytes = (per_launch_steps * 20 + stats["sum_deg_curr"] * 8 + stats.get("sum_deg_prev", 0) * 4
                          + stats.get("trials", 0))

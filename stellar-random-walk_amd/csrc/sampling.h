@@ -700,7 +700,7 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
     tm.n_binned += 1;
     if (strat == 1) { tm.n_p1 += 1; tm.n_p1_elems += m; }
 #endif
-    if (strat == 1) alg_bytes += 4ull * (unsigned long long)m * (unsigned long long)(1 + (32 - __clz(deg | 1)));   // ids + probes
+    if (strat == 1) alg_bytes += 8ull * (unsigned long long)m;   // the ids looked up + the entry each one lands on (probes above it: cache)
     else if (strat == 2) alg_bytes += 16ull * (unsigned long long)deg;                                            // entries + hash slots
     else alg_bytes += 12ull * (unsigned long long)(deg - pa) + 4ull * (unsigned long long)(m - pb);              // both sorted rows
     if (strat == 1) {

@@ -547,18 +547,18 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
 //   A'_{end of chunk j} = PQ[end_j] + sum(bins[0..j])          (exact)
 // locates, by a 64-ary search over the chunk ends with the same certified tolerance, the ONE chunk that holds the
 // first not-certain-miss index; only that chunk (64 .. a few thousand candidates) is evaluated candidate by
-// candidate.  No pass over N(curr)'s entries at all: the step costs the sorted intersection plus O(chunk).
-// The members of N(prev) among the candidates are found by the cheapest of three strategies over the SORTED rows:
-//   P1  every distinct id of N(prev) is searched in N(curr)                    ~ |N(prev)| log |N(curr)| probes
-//   P2  every candidate (input order, no permutation needed) is searched in N(prev) ~ |N(curr)| log |N(prev)| probes
+// candidate.  No scan of N(curr): the step costs the membership work plus O(chunk).
+// The members of N(prev) among the candidates are found by the cheapest of four strategies:
+//   P1  every distinct id of N(prev) is searched in the sorted N(curr)         ~ |N(prev)| log |N(curr)| probes
+//   P2  every candidate (input order) is probed in the edge hash set            ~ |N(curr)| probes
+//   P3  prev is a hub with a neighbor-set bitmap over the id slots (GraphView::hub_bm): one bit read per candidate
 //   W   sorted-chunk intersection: 1024 ids of N(prev) at a time are staged in LDS in sorted order, the candidates
 //       come 256 at a time (16-byte loads; ids, positions and weights) and do a branch-free 10-level lower bound in
 //       LDS, four per lane in lockstep; whichever list ends first in id order advances.  At most
 //       |N(curr)| / 256 + |N(prev)| / 1024 rounds, independent of the id range.  (Tried before it: an id-window bitmap
 //       — 6 us per window, 300 windows per step at RMAT-24 — and an LDS hash set per chunk — 3x the LDS operations.)
 constexpr int BIN_CAP = 512;                  // f64 bins: 4 KB of the wave's LDS
-constexpr int WIN_WORDS = 1280;               // id-window bitmap behind the bins: 5 KB (40960 vertex ids)
-constexpr int WIN_BITS = WIN_WORDS * 32;
+constexpr int WIN_WORDS = 1280;               // scratch behind the bins: 5 KB (W stages 1024 sorted ids of N(prev) here)
 constexpr int HCHUNK = 1024;                // ids of N(prev) staged in LDS per round
 constexpr uint32_t HEMPTY = 0xFFFFFFFFu;
 constexpr int BINNED_LDS_WORDS = 2 * BIN_CAP + WIN_WORDS;

@@ -241,7 +241,7 @@ __device__ inline AEnt load_al(const AEnt *p) {
 }
 
 template <bool NT>
-__global__ __launch_bounds__(TPB) void k_walk_alias(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
+__global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
                                                     int64_t n_walkers, int32_t L, int32_t first_walk, uint32_t seed,
                                                     float p, float q, int32_t *__restrict__ paths,
                                                     int32_t *__restrict__ lens, DevCounters *ctr) {

@@ -120,6 +120,7 @@ enum {
   SRW_WALK_NO_PREFIX = 32,    /* general kernel: always stream N(curr); do not use the exact prefix-sum search */
   SRW_WALK_NO_EDGE_HASH = 64, /* Mode A: membership by binary search in the sorted rows instead of the edge hash set */
   SRW_WALK_NO_BINNED = 128,   /* Mode R, q != 1: never use the binned prefix-sum search (streaming scan instead) */
+  SRW_WALK_DEVICE_FORMAT = 131072, /* srw_walk_and_save: the GPU formats the path text (path_format.hip); the host only writes it */
   SRW_WALK_NO_HUB_BITMAPS = 65536 /* Mode R, q != 1: do not build / use the hub rows' neighbor-set bitmaps */
   /* bits 12-14: test switch, force the binned search's membership strategy (1 = P1, 2 = P2, 3 = id-window,
      4 = hub bitmap where there is one); bit 15: test switch, binned search and hub bitmaps on rows of any degree

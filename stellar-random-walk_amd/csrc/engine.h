@@ -133,6 +133,9 @@ struct srw_handle {
   hipEvent_t stage_done[2] = {nullptr, nullptr}, kernel_done[2] = {nullptr, nullptr};
   int32_t *pin_paths[2] = {nullptr, nullptr}, *pin_lens[2] = {nullptr, nullptr};  // pinned ring of srw_walk_and_save
   size_t pin_cap = 0;
+  // device-side formatter (SRW_WALK_DEVICE_FORMAT): per staging slot the text + line offsets, one pinned text buffer
+  srw::DevBuf<char> fmt_text[2]; srw::DevBuf<unsigned long long> fmt_len[2], fmt_off[2]; srw::DevBuf<char> fmt_temp;
+  char *pin_text = nullptr; unsigned long long *pin_off = nullptr; size_t pin_text_cap = 0, pin_off_cap = 0;
 };
 
 namespace srw {
@@ -153,11 +156,18 @@ class PathWriter {
   PathWriter(const char *output_dir, int n_parts, int64_t total_walkers, bool write_crc);  // throws SRW_ERR_EXISTS
   ~PathWriter();
   void append(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride);
+  // already formatted lines (device formatter): `off` has n + 1 byte offsets into `text`
+  void append_text(const char *text, const unsigned long long *off, int64_t n);
   void close();  // finishes the parts, writes _SUCCESS
  private:
   struct Impl;
   Impl *p_;
 };
+
+// ---- path_format.hip ----
+size_t format_capacity(int64_t n, int64_t stride);
+void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens, int64_t n, int64_t stride,
+                         unsigned long long *d_len_bytes, unsigned long long *d_off, char *d_text);
 
 // ---- graph_build.hip ----
 // Lines already on the device (d_src/d_dst/d_w; d_w may be null = 1.0f).  Builds rows/ent/sids/verts.

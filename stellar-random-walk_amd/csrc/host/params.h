@@ -44,6 +44,7 @@ struct Params {
   int device = 0;           // --device: HIP ordinal
   bool crc = false;         // --crc: also write Hadoop .crc side files
   bool alias = false;       // --sampler alias: Mode A (alias tables + rejection) instead of the reference-exact Mode R
+  bool deviceFormat = true;   // --deviceFormat: the GPU formats the path text (SRW_WALK_DEVICE_FORMAT); false = host threads
 };
 
 }  // namespace common

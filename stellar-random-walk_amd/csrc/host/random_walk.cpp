@@ -144,6 +144,7 @@ void RandomWalk::executeAndSave(int partitions, const std::string &output) {
   P.sampler = (config_.alias && !config_.hasConstR) ? SRW_SAMPLER_ALIAS : SRW_SAMPLER_REFERENCE;
   srw_walk_stats st{};
   std::vector<int64_t> dead((size_t)std::max(config_.numWalks, 1), 0);
+  if (config_.deviceFormat) P.flags |= SRW_WALK_DEVICE_FORMAT;
   int32_t rc = srw_walk_and_save(h_, &P, output.c_str(), partitions, config_.crc ? 1 : 0, &st, dead.data());
   if (rc == SRW_ERR_EXISTS)
     throw std::runtime_error("org.apache.hadoop.mapred.FileAlreadyExistsException: Output directory " + output + "/" +

@@ -1,0 +1,86 @@
+// path_format.hip — device-side text formatter of the path output.
+// Same bytes as writer.cpp / RandomWalk.save (M/algorithm/RandomWalk.scala:234-241): decimal ids joined by ONE TAB, no
+// trailing tab, '\n' per line, canonical walker order.  Two kernels, one wave per walker, one lane per path slot:
+//   k_fmt_len   : bytes of every line                      -> exclusive scan (rocPRIM) -> byte offset of every line
+//   k_fmt_write : every lane writes its own number (+ separator) at  line offset + wave-prefix of the lengths
+// The host then only copies the text out and pwrite()s it (run_walk_and_save with SRW_WALK_DEVICE_FORMAT).
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "engine.h"
+#include "wave_primitives.h"
+
+namespace srw {
+namespace {
+constexpr int FTPB = 256;
+
+__device__ inline int dec_len(int32_t v) {
+  uint32_t u = v < 0 ? (uint32_t)(-(int64_t)v) : (uint32_t)v;
+  int n = 1;
+  while (u >= 10u) { u /= 10u; ++n; }
+  return n + (v < 0 ? 1 : 0);
+}
+
+__global__ void k_fmt_len(const int32_t *__restrict__ paths, const int32_t *__restrict__ lens, int64_t n, int64_t stride,
+                          unsigned long long *__restrict__ out) {
+  const int lane = lane_id();
+  for (int64_t w = (blockIdx.x * (int64_t)FTPB + threadIdx.x) >> 6; w < n; w += (int64_t)gridDim.x * (FTPB / 64)) {
+    const int32_t len = lens[w];
+    unsigned long long b = 0;
+    for (int32_t t = lane; t < len; t += 64) b += (unsigned long long)(dec_len(paths[w * stride + t]) + 1);   // + TAB or '\n'
+    b = wave_sum_u64(b);
+    if (lane == 0) out[w] = b ? b : 1ull;                       // an empty path would still be an empty line
+  }
+}
+
+__global__ void k_fmt_write(const int32_t *__restrict__ paths, const int32_t *__restrict__ lens, int64_t n, int64_t stride,
+                            const unsigned long long *__restrict__ off, char *__restrict__ text) {
+  const int lane = lane_id();
+  for (int64_t w = (blockIdx.x * (int64_t)FTPB + threadIdx.x) >> 6; w < n; w += (int64_t)gridDim.x * (FTPB / 64)) {
+    const int32_t len = lens[w];
+    char *line = text + off[w];
+    if (len <= 0) { if (lane == 0) line[0] = '\n'; continue; }
+    unsigned carry = 0;
+    for (int32_t base = 0; base < len; base += 64) {
+      const int32_t t = base + lane;
+      const bool ok = t < len;
+      const int32_t v = ok ? paths[w * stride + t] : 0;
+      const unsigned mine = ok ? (unsigned)dec_len(v) + 1u : 0u;
+      unsigned incl = mine;
+      for (int o = 1; o < 64; o <<= 1) { unsigned x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+      if (ok) {
+        char *p = line + carry + (incl - mine);
+        uint32_t u = v < 0 ? (uint32_t)(-(int64_t)v) : (uint32_t)v;
+        const int nd = (int)mine - 1;                            // characters of the number, sign included
+        if (v < 0) p[0] = '-';
+        for (int i = nd - 1; i >= (v < 0 ? 1 : 0); --i) { p[i] = (char)('0' + u % 10u); u /= 10u; }
+        p[nd] = (t == len - 1) ? '\n' : '\t';
+      }
+      carry += (unsigned)__shfl((int)incl, 63);
+    }
+  }
+}
+}  // namespace
+
+// Formats walkers [0, n) of (d_paths, d_lens) into d_text; d_off[0..n] receives the byte offset of every line and the
+// total.  Returns the text capacity needed (callers size d_text with format_capacity first).  Stream-ordered.
+size_t format_capacity(int64_t n, int64_t stride) { return (size_t)n * (size_t)stride * 12 + 16; }
+
+void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens, int64_t n, int64_t stride,
+                         unsigned long long *d_len_bytes, unsigned long long *d_off, char *d_text) {
+  hipStream_t st = h->stream;
+  if (n <= 0) return;
+  const int blocks = (int)std::min<int64_t>((n * 64 + FTPB - 1) / FTPB, (int64_t)h->n_cus * 16);
+  hipLaunchKernelGGL(k_fmt_len, dim3(blocks), dim3(FTPB), 0, st, d_paths, d_lens, n, stride, d_len_bytes);
+  // exclusive scan over n + 1 items (the extra zero item yields the total in d_off[n])
+  SRW_HIP(hipMemsetAsync(d_len_bytes + n, 0, 8, st));
+  size_t tb = 0;
+  SRW_HIP(rocprim::exclusive_scan(nullptr, tb, d_len_bytes, d_off, 0ull, (size_t)n + 1, rocprim::plus<unsigned long long>(), st));
+  h->fmt_temp.ensure(tb);
+  SRW_HIP(rocprim::exclusive_scan((void *)h->fmt_temp.p, tb, d_len_bytes, d_off, 0ull, (size_t)n + 1,
+                                  rocprim::plus<unsigned long long>(), st));
+  hipLaunchKernelGGL(k_fmt_write, dim3(blocks), dim3(FTPB), 0, st, d_paths, d_lens, n, stride, d_off, d_text);
+  SRW_HIP(hipGetLastError());
+}
+
+}  // namespace srw

@@ -875,6 +875,57 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   SRW_HIP(hipEventRecord(h->ev0, st));
   LaunchInfo li{0, 0};
+  if (P.flags & SRW_WALK_DEVICE_FORMAT) {
+    // Device-side formatter (path_format.hip): the GPU turns iteration `it` into text while the host copies out and
+    // writes the text of iteration `it - 1`; the host never touches the ids.
+    const size_t cap = format_capacity(nv, stride);
+    for (int i = 0; i < 2; ++i) { h->fmt_text[i].ensure(cap); h->fmt_len[i].ensure((size_t)nv + 1); h->fmt_off[i].ensure((size_t)nv + 1); }
+    if (h->pin_off_cap < (size_t)nv + 1) {
+      if (h->pin_off) (void)hipHostFree(h->pin_off);
+      SRW_HIP(hipHostMalloc((void **)&h->pin_off, ((size_t)nv + 1) * 8, hipHostMallocDefault));
+      h->pin_off_cap = (size_t)nv + 1;
+    }
+    auto consume_text = [&](int32_t it) {
+      const int b = it & 1;
+      SRW_HIP(hipEventSynchronize(h->kernel_done[b]));                      // walk + format of iteration `it` done
+      SRW_HIP(hipMemcpyAsync(h->pin_off, h->fmt_off[b].p, ((size_t)nv + 1) * 8, hipMemcpyDeviceToHost, h->copy_stream));
+      SRW_HIP(hipMemcpyAsync(h->pin_lens[b], h->stage_lens[b].p, (size_t)nv * 4, hipMemcpyDeviceToHost, h->copy_stream));
+      SRW_HIP(hipStreamSynchronize(h->copy_stream));
+      const size_t bytes = (size_t)h->pin_off[nv];
+      if (h->pin_text_cap < bytes) {
+        if (h->pin_text) (void)hipHostFree(h->pin_text);
+        SRW_HIP(hipHostMalloc((void **)&h->pin_text, bytes + bytes / 8 + 4096, hipHostMallocDefault));
+        h->pin_text_cap = bytes + bytes / 8 + 4096;
+      }
+      SRW_HIP(hipMemcpyAsync(h->pin_text, h->fmt_text[b].p, bytes, hipMemcpyDeviceToHost, h->copy_stream));
+      SRW_HIP(hipStreamSynchronize(h->copy_stream));
+      if (dead_per_iter) {
+        int64_t dead = 0;
+        for (int64_t i = 0; i < nv; ++i) dead += (h->pin_lens[b][i] >= 2 && h->pin_lens[b][i] < stride);
+        dead_per_iter[it] = dead;
+      }
+      writer.append_text(h->pin_text, h->pin_off, nv);
+    };
+    for (int32_t it = 0; it < P.num_walks; ++it) {
+      const int b = it & 1;                            // slot b was consumed before iteration it - 1 was launched
+      li = launch_walk(h, P, 1, P.first_walk + it, h->stage_paths[b].p, h->stage_lens[b].p);
+      format_paths_device(h, h->stage_paths[b].p, h->stage_lens[b].p, nv, stride, h->fmt_len[b].p, h->fmt_off[b].p,
+                          h->fmt_text[b].p);
+      SRW_HIP(hipEventRecord(h->kernel_done[b], st));
+      if (it >= 1) consume_text(it - 1);
+    }
+    SRW_HIP(hipEventRecord(h->ev1, st));
+    consume_text(P.num_walks - 1);
+    writer.close();
+    srw_walk_stats local;
+    srw_walk_stats *s = stats ? stats : &local;
+    memset(s, 0, sizeof(*s));
+    read_counters(h, s);
+    float ms = 0.f;
+    SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    s->kernel_ms = ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
+    return;
+  }
   auto consume = [&](int32_t it) {      // host side of iteration `it`: wait for its slice, format + append
     const int b = it & 1;
     SRW_HIP(hipEventSynchronize(h->stage_done[b]));

@@ -207,6 +207,40 @@ void PathWriter::append(const int32_t *paths, const int32_t *lens, int64_t n, in
   }
 }
 
+// Lines formatted on the device: split at the part boundaries (by walker count, as append does) and write the bytes.
+void PathWriter::append_text(const char *text, const unsigned long long *off, int64_t n) {
+  int64_t done = 0;
+  while (done < n) {
+    const int64_t g = p_->next;
+    const int part = p_->per > 0 ? (int)std::min<int64_t>(g / p_->per, p_->n_parts - 1) : 0;
+    if (part != p_->cur_part) p_->open_part(part);
+    const int64_t part_end = std::min<int64_t>((int64_t)(part + 1) * p_->per, p_->total);
+    const int64_t take = std::min<int64_t>(n - done, std::max<int64_t>(part_end - g, 1));
+    const char *src = text + off[done];
+    const size_t bytes = (size_t)(off[done + take] - off[done]);
+    auto t0 = std::chrono::steady_clock::now();
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(p_->hw, bytes / ((size_t)8 << 20) + 1));
+    std::vector<std::string> errs((size_t)nt);
+    const std::string fn = p_->dir + "/" + p_->part_name(p_->cur_part);
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; ++t) {
+        const size_t b = bytes * (size_t)t / (size_t)nt, e = bytes * (size_t)(t + 1) / (size_t)nt;
+        th.emplace_back([&, t, b, e] {
+          try { pwrite_all(p_->fd, src + b, e - b, p_->file_off + (off_t)b, fn); }
+          catch (const Error &er) { errs[(size_t)t] = er.what(); }
+        });
+      }
+      for (auto &x : th) x.join();
+    }
+    for (auto &er : errs) if (!er.empty()) throw Error(SRW_ERR_IO, er);
+    p_->file_off += (off_t)bytes;
+    p_->crc_feed(src, bytes);
+    p_->t_write += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    done += take; p_->next += take;
+  }
+}
+
 void PathWriter::close() {
   if (p_->cur_part < 0 && p_->n_parts > 0) p_->open_part(0);   // zero paths: still an (empty) part-00000
   if (getenv("SRW_TIMING"))

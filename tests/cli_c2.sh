@@ -16,3 +16,7 @@ rm -rf /tmp/out_c2
 export SRW_TIMING=1
 ( time stellar-random-walk_amd/stellar-rw --cmd randomwalk --numWalks 10 --p 1 --q 1 --walkLength 80 --input /tmp/rmat20.txt --output /tmp/out_c2 ) 2>&1 | sort | uniq -c | sort -rn | head -20
 ls -la /tmp/out_c2/path | head; head -c 300 /tmp/out_c2/path/part-00000; echo; wc -l /tmp/out_c2/path/part-00000
+echo "--- same job with --deviceFormat false (host threads format) ---"
+rm -rf /tmp/out_c2d
+( time stellar-random-walk_amd/stellar-rw --cmd randomwalk --numWalks 10 --p 1 --q 1 --walkLength 80 --input /tmp/rmat20.txt --output /tmp/out_c2d --deviceFormat false ) 2>&1 | grep "timing\|real\|user\|sys"
+cmp /tmp/out_c2/path/part-00000 /tmp/out_c2d/path/part-00000 && echo "host-formatted output identical"

@@ -526,6 +526,34 @@ def test_walk_and_save_streamed(eng, oracle, tmp_path, n_parts, num_walks):
     with pytest.raises(pkg().SrwError) as ei:
         eng.walk_and_save(str(tmp_path / "gpu"), walk_length=5)
     assert ei.value.code == pkg().ERR_EXISTS
+    # device-side formatter (path_format.hip): the same bytes, .crc files and dead-end counts
+    st2, dead2 = eng.walk_and_save(str(tmp_path / "gpu_fmt"), n_parts=n_parts, write_crc=True, walk_length=15,
+                                   num_walks=num_walks, seed=9, device_format=True)
+    assert st2["n_steps"] == rs and dead2 == want_dead
+    for k in range(n_parts):
+        for name in ("part-%05d" % k, ".part-%05d.crc" % k):
+            assert (tmp_path / "gpu_fmt" / "path" / name).read_bytes() == (tmp_path / "gpu" / "path" / name).read_bytes()
+
+
+def test_device_formatter_negative_ids_and_long_paths(eng, oracle, tmp_path):
+    # negative ids (sign character), walkLength + 2 > 64 (two lane rounds per line), several iterations, odd part counts
+    rng = np.random.default_rng(12)
+    s, d, w = random_multigraph(rng, 300, 2500, True, id_lo=-150)
+    g = oracle.Graph.from_coo(s, d, w, directed=True)
+    eng.load_coo(s, d, w, directed=True)
+    for sampler, parts in (("reference", 3), ("alias", 1)):
+        eng.walk_and_save(str(tmp_path / ("h" + sampler)), n_parts=parts, walk_length=100, num_walks=3, seed=4, p=0.5, q=2.0,
+                          sampler=sampler)
+        eng.walk_and_save(str(tmp_path / ("d" + sampler)), n_parts=parts, walk_length=100, num_walks=3, seed=4, p=0.5, q=2.0,
+                          sampler=sampler, device_format=True)
+        for k in range(parts):
+            a = (tmp_path / ("h" + sampler) / "path" / ("part-%05d" % k)).read_bytes()
+            assert a == (tmp_path / ("d" + sampler) / "path" / ("part-%05d" % k)).read_bytes() and (len(a) > 0 or k > 0)
+    rp, rl, _ = g.walk(walk_length=100, num_walks=3, seed=4, p=0.5, q=2.0, threads=8)
+    assert oracle.write_paths(rp, rl, str(tmp_path / "ref"), 3) == 0
+    for k in range(3):
+        assert (tmp_path / "ref" / "path" / ("part-%05d" % k)).read_bytes() == \
+               (tmp_path / "dreference" / "path" / ("part-%05d" % k)).read_bytes()
 
 
 @pytest.mark.parametrize("world,p,q", [(2, 1.0, 1.0), (3, 0.5, 2.0)])

@@ -165,7 +165,7 @@ class PathWriter {
 };
 
 // ---- path_format.hip ----
-size_t format_capacity(int64_t n, int64_t stride);
+size_t format_capacity(int64_t n, int64_t stride, int32_t vmin, int32_t vmax);
 void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens, int64_t n, int64_t stride,
                          unsigned long long *d_len_bytes, unsigned long long *d_off, char *d_text);
 

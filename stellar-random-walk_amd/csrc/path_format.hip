@@ -64,7 +64,12 @@ __global__ void k_fmt_write(const int32_t *__restrict__ paths, const int32_t *__
 
 // Formats walkers [0, n) of (d_paths, d_lens) into d_text; d_off[0..n] receives the byte offset of every line and the
 // total.  Returns the text capacity needed (callers size d_text with format_capacity first).  Stream-ordered.
-size_t format_capacity(int64_t n, int64_t stride) { return (size_t)n * (size_t)stride * 12 + 16; }
+size_t format_capacity(int64_t n, int64_t stride, int32_t vmin, int32_t vmax) {
+  // every number takes at most (digits of the largest magnitude + sign) characters plus one separator
+  auto digits = [](int64_t v) { int d = 1; if (v < 0) v = -v; while (v >= 10) { v /= 10; ++d; } return d; };
+  const int per = std::max(digits(vmin) + (vmin < 0 ? 1 : 0), digits(vmax) + (vmax < 0 ? 1 : 0)) + 1;
+  return (size_t)n * (size_t)stride * (size_t)per + 16;
+}
 
 void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens, int64_t n, int64_t stride,
                          unsigned long long *d_len_bytes, unsigned long long *d_off, char *d_text) {

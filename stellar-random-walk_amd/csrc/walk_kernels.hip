@@ -875,10 +875,17 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   SRW_HIP(hipEventRecord(h->ev0, st));
   LaunchInfo li{0, 0};
-  if (P.flags & SRW_WALK_DEVICE_FORMAT) {
+  bool device_format = (P.flags & SRW_WALK_DEVICE_FORMAT) != 0;
+  const size_t cap = format_capacity(nv, stride, g.vmin, (int32_t)((int64_t)g.vmin + g.n_slots - 1));
+  if (device_format) {        // two text slots in HBM: fall back to the host formatter when they do not fit
+    size_t free_b = 0, total_b = 0;
+    SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t have = h->fmt_text[0].n + h->fmt_text[1].n;
+    if (2 * cap > have && free_b < 2 * cap - have + ((size_t)4 << 30)) device_format = false;
+  }
+  if (device_format) {
     // Device-side formatter (path_format.hip): the GPU turns iteration `it` into text while the host copies out and
     // writes the text of iteration `it - 1`; the host never touches the ids.
-    const size_t cap = format_capacity(nv, stride);
     for (int i = 0; i < 2; ++i) { h->fmt_text[i].ensure(cap); h->fmt_len[i].ensure((size_t)nv + 1); h->fmt_off[i].ensure((size_t)nv + 1); }
     if (h->pin_off_cap < (size_t)nv + 1) {
       if (h->pin_off) (void)hipHostFree(h->pin_off);

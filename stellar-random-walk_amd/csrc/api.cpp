@@ -1,6 +1,8 @@
 // api.cpp — the C ABI (include/stellar_rw.h).  Everything here is glue: argument checks, host<->device
 // staging, and translation of C++ exceptions into status codes + srw_last_error().
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -141,7 +143,9 @@ int32_t srw_load_edgelist(srw_handle *h, const char *path, int32_t directed, int
   return guarded(h, [&] {
     need(path != nullptr, "path is null");
     ParsedLines L;
+    const auto t0 = std::chrono::steady_clock::now();
     parse_edgelist_file(path, weighted != 0, partitioned != 0, L);
+    const auto t1 = std::chrono::steady_clock::now();
     if (partitioned) {
       // a missing / unparsable pId is Random.nextInt(rddPartitions) in the reference (VCutRandomWalk.scala:24-25,
       // unseeded); partition ids never change walk results, so a deterministic hash stands in.
@@ -151,6 +155,10 @@ int32_t srw_load_edgelist(srw_handle *h, const char *path, int32_t directed, int
     }
     load_lines(h, L.src.data(), L.dst.data(), L.w.data(), partitioned ? L.pid.data() : nullptr, (int64_t)L.src.size(),
                directed != 0);
+    if (getenv("SRW_TIMING"))
+      fprintf(stderr, "[timing] loadGraph: tokenizer %.1f ms (%zu lines), upload + device CSR build %.1f ms\n",
+              std::chrono::duration<double, std::milli>(t1 - t0).count(), L.src.size(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
   });
 }
 

@@ -199,13 +199,22 @@ void parse_edgelist_file(const char *path, bool weighted, bool partitioned, Pars
     lines_before += c.n_lines;
     total += c.src.size();
   }
-  out.src.reserve(total); out.dst.reserve(total); out.w.reserve(total); out.pid.reserve(total);
-  for (auto &c : chunks) {
-    out.src.insert(out.src.end(), c.src.begin(), c.src.end());
-    out.dst.insert(out.dst.end(), c.dst.begin(), c.dst.end());
-    out.w.insert(out.w.end(), c.w.begin(), c.w.end());
-    out.pid.insert(out.pid.end(), c.pid.begin(), c.pid.end());
-  }
+  // every thread copies its chunk to its final place (no zero-fill, no serial concatenation)
+  out.src.resize_uninit(total); out.dst.resize_uninit(total); out.w.resize_uninit(total); out.pid.resize_uninit(total);
+  std::vector<size_t> at(nthreads + 1, 0);
+  for (size_t t = 0; t < nthreads; ++t) at[t + 1] = at[t] + chunks[t].src.size();
+  th.clear();
+  for (size_t t = 0; t < nthreads; ++t)
+    th.emplace_back([&, t] {
+      const Chunk &c = chunks[t];
+      const size_t k = c.src.size();
+      if (!k) return;
+      memcpy(out.src.data() + at[t], c.src.data(), k * 4);
+      memcpy(out.dst.data() + at[t], c.dst.data(), k * 4);
+      memcpy(out.w.data() + at[t], c.w.data(), k * 4);
+      memcpy(out.pid.data() + at[t], c.pid.data(), k * 4);
+    });
+  for (auto &x : th) x.join();
 }
 
 }  // namespace srw

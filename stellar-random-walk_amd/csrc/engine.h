@@ -4,6 +4,8 @@
 #include <stdint.h>
 
 #include <stdexcept>
+#include <cstdlib>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -141,9 +143,30 @@ struct srw_handle {
 namespace srw {
 
 // ---- edgelist.cpp (host) ----
+// Uninitialised, non-copyable array: the tokenizer's threads fill it in place (a std::vector would zero 268 MB first
+// at config 2, on one thread).
+template <class T>
+struct RawVec {
+  T *p = nullptr; size_t n = 0;
+  RawVec() = default;
+  RawVec(const RawVec &) = delete;
+  RawVec &operator=(const RawVec &) = delete;
+  RawVec(RawVec &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  RawVec &operator=(RawVec &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  ~RawVec() { free(p); }
+  void resize_uninit(size_t k) {
+    free(p); p = nullptr; n = 0;
+    if (k) { p = (T *)malloc(k * sizeof(T)); if (!p) throw std::bad_alloc(); n = k; }
+  }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  size_t size() const { return n; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+};
 struct ParsedLines {
-  std::vector<int32_t> src, dst, pid;
-  std::vector<float> w;
+  RawVec<int32_t> src, dst, pid;
+  RawVec<float> w;
 };
 void parse_edgelist_file(const char *path, bool weighted, bool partitioned, ParsedLines &out);
 

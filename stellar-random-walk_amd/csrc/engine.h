@@ -134,7 +134,7 @@ struct srw_handle {
   srw::DevBuf<int32_t> stage_paths[2], stage_lens[2];
   hipEvent_t stage_done[2] = {nullptr, nullptr}, kernel_done[2] = {nullptr, nullptr};
   int32_t *pin_paths[2] = {nullptr, nullptr}, *pin_lens[2] = {nullptr, nullptr};  // pinned ring of srw_walk_and_save
-  size_t pin_cap = 0;
+  size_t pin_cap = 0, pin_lens_cap = 0;
   // device-side formatter (SRW_WALK_DEVICE_FORMAT): per staging slot the text + line offsets, one pinned text buffer
   srw::DevBuf<char> fmt_text[2]; srw::DevBuf<unsigned long long> fmt_len[2], fmt_off[2]; srw::DevBuf<char> fmt_temp;
   char *pin_text = nullptr; unsigned long long *pin_off = nullptr; size_t pin_text_cap = 0, pin_off_cap = 0;

@@ -78,6 +78,7 @@ std::pair<int32_t, float> RandomSample::secondOrderSample(float p, float q, int3
 RandomWalk::RandomWalk(const Params &config, std::ostream *log) : config_(config), log_(log) {
   srw_config c{};
   c.device = config.device; c.rank = 0; c.world = 1;
+  Phase ph("create (HIP runtime, context, code objects)");
   int32_t rc = srw_create(&c, &h_);
   if (rc != SRW_OK) throw std::runtime_error(std::string("srw_create: ") + srw_last_error(nullptr));
 }

@@ -856,33 +856,39 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   prepare_tables(h, P);
   if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   const size_t need = (size_t)nv * stride * 4;
-  for (int i = 0; i < 2; ++i) {
-    h->stage_paths[i].ensure((size_t)nv * stride);
-    h->stage_lens[i].ensure((size_t)nv);
-    if (!h->stage_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming));
-    if (!h->kernel_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->kernel_done[i], hipEventDisableTiming));
-    if (h->pin_cap < need) {
-      if (h->pin_paths[i]) (void)hipHostFree(h->pin_paths[i]);
-      if (h->pin_lens[i]) (void)hipHostFree(h->pin_lens[i]);
-      SRW_HIP(hipHostMalloc((void **)&h->pin_paths[i], need ? need : 4, hipHostMallocDefault));
-      SRW_HIP(hipHostMalloc((void **)&h->pin_lens[i], (size_t)nv * 4 + 4, hipHostMallocDefault));
-    }
-  }
-  h->pin_cap = std::max(h->pin_cap, need);
-  h->res.valid = false;
-  h->counters.ensure(1);
-  StreamDrain drain(h);
-  SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
-  SRW_HIP(hipEventRecord(h->ev0, st));
-  LaunchInfo li{0, 0};
   bool device_format = (P.flags & SRW_WALK_DEVICE_FORMAT) != 0;
   const size_t cap = format_capacity(nv, stride, g.vmin, (int32_t)((int64_t)g.vmin + g.n_slots - 1));
   if (device_format) {        // two text slots in HBM: fall back to the host formatter when they do not fit
     size_t free_b = 0, total_b = 0;
     SRW_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t have = h->fmt_text[0].n + h->fmt_text[1].n;
-    if (2 * cap > have && free_b < 2 * cap - have + ((size_t)4 << 30)) device_format = false;
+    if (2 * cap > have && free_b < 2 * cap - have + need * 2 + ((size_t)4 << 30)) device_format = false;
   }
+  for (int i = 0; i < 2; ++i) {
+    h->stage_paths[i].ensure((size_t)nv * stride);
+    h->stage_lens[i].ensure((size_t)nv);
+    if (!h->stage_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming));
+    if (!h->kernel_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->kernel_done[i], hipEventDisableTiming));
+    // pinned ring: the ids only travel to the host when the host formats them; the lengths always do (dead-end counts)
+    if (!device_format && h->pin_cap < need) {
+      if (h->pin_paths[i]) (void)hipHostFree(h->pin_paths[i]);
+      h->pin_paths[i] = nullptr;
+      SRW_HIP(hipHostMalloc((void **)&h->pin_paths[i], need ? need : 4, hipHostMallocDefault));
+    }
+    if (h->pin_lens_cap < (size_t)nv) {
+      if (h->pin_lens[i]) (void)hipHostFree(h->pin_lens[i]);
+      h->pin_lens[i] = nullptr;
+      SRW_HIP(hipHostMalloc((void **)&h->pin_lens[i], (size_t)nv * 4 + 4, hipHostMallocDefault));
+    }
+  }
+  if (!device_format) h->pin_cap = std::max(h->pin_cap, need);
+  h->pin_lens_cap = std::max(h->pin_lens_cap, (size_t)nv);
+  h->res.valid = false;
+  h->counters.ensure(1);
+  StreamDrain drain(h);
+  SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
+  SRW_HIP(hipEventRecord(h->ev0, st));
+  LaunchInfo li{0, 0};
   if (device_format) {
     // Device-side formatter (path_format.hip): the GPU turns iteration `it` into text while the host copies out and
     // writes the text of iteration `it - 1`; the host never touches the ids.

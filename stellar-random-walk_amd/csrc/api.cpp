@@ -116,8 +116,7 @@ void srw_destroy(srw_handle *h) {
   }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   for (int i = 0; i < 2; ++i) { if (h->pin_paths[i]) (void)hipHostFree(h->pin_paths[i]); if (h->pin_lens[i]) (void)hipHostFree(h->pin_lens[i]); }
-  if (h->pin_text) (void)hipHostFree(h->pin_text);
-  if (h->pin_off) (void)hipHostFree(h->pin_off);
+  for (int i = 0; i < 2; ++i) { if (h->pin_text[i]) (void)hipHostFree(h->pin_text[i]); if (h->pin_off[i]) (void)hipHostFree(h->pin_off[i]); }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

@@ -137,7 +137,8 @@ struct srw_handle {
   size_t pin_cap = 0, pin_lens_cap = 0;
   // device-side formatter (SRW_WALK_DEVICE_FORMAT): per staging slot the text + line offsets, one pinned text buffer
   srw::DevBuf<char> fmt_text[2]; srw::DevBuf<unsigned long long> fmt_len[2], fmt_off[2]; srw::DevBuf<char> fmt_temp;
-  char *pin_text = nullptr; unsigned long long *pin_off = nullptr; size_t pin_text_cap = 0, pin_off_cap = 0;
+  char *pin_text[2] = {nullptr, nullptr}; unsigned long long *pin_off[2] = {nullptr, nullptr};
+  size_t pin_text_cap[2] = {0, 0}, pin_off_cap = 0;
 };
 
 namespace srw {
@@ -179,8 +180,8 @@ class PathWriter {
   PathWriter(const char *output_dir, int n_parts, int64_t total_walkers, bool write_crc);  // throws SRW_ERR_EXISTS
   ~PathWriter();
   void append(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride);
-  // already formatted lines (device formatter): `off` has n + 1 byte offsets into `text`
-  void append_text(const char *text, const unsigned long long *off, int64_t n);
+  // already formatted lines (device formatter): off[0..n] are byte offsets, text[0] is the byte at offset `base`
+  void append_text(const char *text, const unsigned long long *off, int64_t n, unsigned long long base = 0);
   void close();  // finishes the parts, writes _SUCCESS
  private:
   struct Impl;

@@ -893,42 +893,67 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
     // Device-side formatter (path_format.hip): the GPU turns iteration `it` into text while the host copies out and
     // writes the text of iteration `it - 1`; the host never touches the ids.
     for (int i = 0; i < 2; ++i) { h->fmt_text[i].ensure(cap); h->fmt_len[i].ensure((size_t)nv + 1); h->fmt_off[i].ensure((size_t)nv + 1); }
-    if (h->pin_off_cap < (size_t)nv + 1) {
-      if (h->pin_off) (void)hipHostFree(h->pin_off);
-      SRW_HIP(hipHostMalloc((void **)&h->pin_off, ((size_t)nv + 1) * 8, hipHostMallocDefault));
-      h->pin_off_cap = (size_t)nv + 1;
-    }
-    auto consume_text = [&](int32_t it) {
+    for (int i = 0; i < 2; ++i)
+      if (h->pin_off_cap < (size_t)nv + 1) {
+        if (h->pin_off[i]) (void)hipHostFree(h->pin_off[i]);
+        h->pin_off[i] = nullptr;
+        SRW_HIP(hipHostMalloc((void **)&h->pin_off[i], ((size_t)nv + 1) * 8, hipHostMallocDefault));
+      }
+    h->pin_off_cap = std::max(h->pin_off_cap, (size_t)nv + 1);
+    const int32_t N = P.num_walks;
+    auto launch = [&](int32_t it) {
       const int b = it & 1;
-      SRW_HIP(hipEventSynchronize(h->kernel_done[b]));                      // walk + format of iteration `it` done
-      SRW_HIP(hipMemcpyAsync(h->pin_off, h->fmt_off[b].p, ((size_t)nv + 1) * 8, hipMemcpyDeviceToHost, h->copy_stream));
-      SRW_HIP(hipMemcpyAsync(h->pin_lens[b], h->stage_lens[b].p, (size_t)nv * 4, hipMemcpyDeviceToHost, h->copy_stream));
-      SRW_HIP(hipStreamSynchronize(h->copy_stream));
-      const size_t bytes = (size_t)h->pin_off[nv];
-      if (h->pin_text_cap < bytes) {
-        if (h->pin_text) (void)hipHostFree(h->pin_text);
-        SRW_HIP(hipHostMalloc((void **)&h->pin_text, bytes + bytes / 8 + 4096, hipHostMallocDefault));
-        h->pin_text_cap = bytes + bytes / 8 + 4096;
-      }
-      SRW_HIP(hipMemcpyAsync(h->pin_text, h->fmt_text[b].p, bytes, hipMemcpyDeviceToHost, h->copy_stream));
-      SRW_HIP(hipStreamSynchronize(h->copy_stream));
-      if (dead_per_iter) {
-        int64_t dead = 0;
-        for (int64_t i = 0; i < nv; ++i) dead += (h->pin_lens[b][i] >= 2 && h->pin_lens[b][i] < stride);
-        dead_per_iter[it] = dead;
-      }
-      writer.append_text(h->pin_text, h->pin_off, nv);
-    };
-    for (int32_t it = 0; it < P.num_walks; ++it) {
-      const int b = it & 1;                            // slot b was consumed before iteration it - 1 was launched
       li = launch_walk(h, P, 1, P.first_walk + it, h->stage_paths[b].p, h->stage_lens[b].p);
       format_paths_device(h, h->stage_paths[b].p, h->stage_lens[b].p, nv, stride, h->fmt_len[b].p, h->fmt_off[b].p,
                           h->fmt_text[b].p);
       SRW_HIP(hipEventRecord(h->kernel_done[b], st));
-      if (it >= 1) consume_text(it - 1);
+    };
+    // Pinned memory costs ~0.2 ms/MB to allocate and ~0.1 ms/MB to free on this stack, so the text leaves the device in
+    // slices of <= 64 MB of whole lines through two small pinned buffers: slice j + 1 is copied while slice j is written.
+    const size_t slice_cap = std::max<size_t>((size_t)64 << 20, (size_t)stride * 12 + 64);
+    for (int i = 0; i < 2; ++i)
+      if (h->pin_text_cap[i] < slice_cap) {
+        if (h->pin_text[i]) (void)hipHostFree(h->pin_text[i]);
+        h->pin_text[i] = nullptr;
+        SRW_HIP(hipHostMalloc((void **)&h->pin_text[i], slice_cap, hipHostMallocDefault));
+        h->pin_text_cap[i] = slice_cap;
+      }
+    launch(0);
+    if (N > 1) launch(1);
+    for (int32_t k = 0; k < N; ++k) {
+      const int b = k & 1;
+      SRW_HIP(hipEventSynchronize(h->kernel_done[b]));                      // walk + format of iteration k done
+      SRW_HIP(hipMemcpyAsync(h->pin_off[0], h->fmt_off[b].p, ((size_t)nv + 1) * 8, hipMemcpyDeviceToHost, h->copy_stream));
+      SRW_HIP(hipMemcpyAsync(h->pin_lens[b], h->stage_lens[b].p, (size_t)nv * 4, hipMemcpyDeviceToHost, h->copy_stream));
+      SRW_HIP(hipStreamSynchronize(h->copy_stream));
+      const unsigned long long *off = h->pin_off[0];
+      auto slice_end = [&](int64_t w0) {                       // largest w1 > w0 with off[w1] - off[w0] <= slice_cap
+        int64_t lo = w0 + 1, hi = nv;
+        while (lo < hi) { const int64_t mid = lo + (hi - lo + 1) / 2; if (off[mid] - off[w0] <= slice_cap) lo = mid; else hi = mid - 1; }
+        return lo;
+      };
+      auto copy_slice = [&](int64_t w0, int64_t w1, int buf) {
+        SRW_HIP(hipMemcpyAsync(h->pin_text[buf], h->fmt_text[b].p + off[w0], (size_t)(off[w1] - off[w0]), hipMemcpyDeviceToHost,
+                               h->copy_stream));
+      };
+      int64_t w0 = 0, w1 = slice_end(0);
+      int buf = 0;
+      copy_slice(w0, w1, buf);
+      while (w0 < nv) {
+        SRW_HIP(hipStreamSynchronize(h->copy_stream));        // slice [w0, w1) is in pin_text[buf]
+        const int64_t n0 = w1, n1 = n0 < nv ? slice_end(n0) : n0;
+        if (n0 < nv) copy_slice(n0, n1, buf ^ 1);
+        else if (k + 2 < N) launch(k + 2);                    // every byte of device slot b is out: reuse it
+        writer.append_text(h->pin_text[buf], off + w0, w1 - w0, off[w0]);
+        w0 = n0; w1 = n1; buf ^= 1;
+      }
+      if (dead_per_iter) {
+        int64_t dead = 0;
+        for (int64_t i = 0; i < nv; ++i) dead += (h->pin_lens[b][i] >= 2 && h->pin_lens[b][i] < stride);
+        dead_per_iter[k] = dead;
+      }
     }
     SRW_HIP(hipEventRecord(h->ev1, st));
-    consume_text(P.num_walks - 1);
     writer.close();
     srw_walk_stats local;
     srw_walk_stats *s = stats ? stats : &local;

@@ -208,7 +208,7 @@ void PathWriter::append(const int32_t *paths, const int32_t *lens, int64_t n, in
 }
 
 // Lines formatted on the device: split at the part boundaries (by walker count, as append does) and write the bytes.
-void PathWriter::append_text(const char *text, const unsigned long long *off, int64_t n) {
+void PathWriter::append_text(const char *text, const unsigned long long *off, int64_t n, unsigned long long base) {
   int64_t done = 0;
   while (done < n) {
     const int64_t g = p_->next;
@@ -216,10 +216,10 @@ void PathWriter::append_text(const char *text, const unsigned long long *off, in
     if (part != p_->cur_part) p_->open_part(part);
     const int64_t part_end = std::min<int64_t>((int64_t)(part + 1) * p_->per, p_->total);
     const int64_t take = std::min<int64_t>(n - done, std::max<int64_t>(part_end - g, 1));
-    const char *src = text + off[done];
+    const char *src = text + (off[done] - base);
     const size_t bytes = (size_t)(off[done + take] - off[done]);
     auto t0 = std::chrono::steady_clock::now();
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>(p_->hw, bytes / ((size_t)8 << 20) + 1));
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(p_->hw, bytes / ((size_t)2 << 20) + 1));
     std::vector<std::string> errs((size_t)nt);
     const std::string fn = p_->dir + "/" + p_->part_name(p_->cur_part);
     {

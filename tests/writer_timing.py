@@ -1,5 +1,5 @@
 import sys, time, os, shutil
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle")
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, _pkg
 pkg = _pkg.load()
 n, stride = 6458340, 82

@@ -1,0 +1,172 @@
+// edgelist_device.hip — device-side tokenizer for the common edge-list shape:
+// every line is exactly "<int><blanks><int>[blanks]" over the characters 0-9 + - space TAB, lines end in '\n'.
+// Same acceptance rules as the host tokenizer (edgelist.cpp) and UniformRandomWalk.loadGraph
+// (M/algorithm/UniformRandomWalk.scala:23-43) on that shape: Java split("\\s+") (leading blank => empty first token
+// => NumberFormatException), Integer.parseInt (optional single sign, >= 1 digit, int32 range).  ANYTHING else — a
+// third column (weights / partition ids), CR, other characters, an empty line, an overflow — makes the function
+// return false and the caller runs the host tokenizer, which parses it or raises the reference's error.
+//   k_nl_count : newline count per 4 KB block + character check      -> exclusive scan (rocPRIM)
+//   k_nl_pos   : byte position of every newline
+//   k_parse    : one thread per line -> src[], dst[], min / max id
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "engine.h"
+#include "wave_primitives.h"
+
+namespace srw {
+namespace {
+constexpr int TTPB = 256;
+constexpr int BYTES_PER_THREAD = 16;
+constexpr int64_t BLOCK_BYTES = (int64_t)TTPB * BYTES_PER_THREAD;
+
+__device__ inline bool tok_char_ok(unsigned char c) {
+  return (c >= '0' && c <= '9') || c == ' ' || c == '\t' || c == '\n' || c == '-' || c == '+';
+}
+
+__global__ __launch_bounds__(TTPB) void k_nl_count(const unsigned char *__restrict__ text, int64_t size,
+                                                   uint32_t *__restrict__ blk, uint32_t *err) {
+  __shared__ uint32_t cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const int64_t b0 = blockIdx.x * BLOCK_BYTES + (int64_t)threadIdx.x * BYTES_PER_THREAD;
+  uint32_t c = 0; bool bad = false;
+  for (int i = 0; i < BYTES_PER_THREAD; ++i) {
+    const int64_t p = b0 + i;
+    if (p < size) { const unsigned char ch = text[p]; c += ch == '\n'; bad |= !tok_char_ok(ch); }
+  }
+  c = (uint32_t)wave_sum_u64(c);
+  if (lane_id() == 0 && c) atomicAdd(&cnt, c);
+  if (__any(bad) && lane_id() == 0) atomicOr(err, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = cnt;
+}
+
+__global__ __launch_bounds__(TTPB) void k_nl_pos(const unsigned char *__restrict__ text, int64_t size,
+                                                 const uint32_t *__restrict__ blkoff, int64_t *__restrict__ nlpos) {
+  __shared__ uint32_t wsum[TTPB / 64];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const int64_t b0 = blockIdx.x * BLOCK_BYTES + (int64_t)threadIdx.x * BYTES_PER_THREAD;
+  uint32_t c = 0;
+  for (int i = 0; i < BYTES_PER_THREAD; ++i) { const int64_t p = b0 + i; if (p < size) c += text[p] == '\n'; }
+  uint32_t incl = c;
+  for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  uint32_t base = blkoff[blockIdx.x];
+  for (int w = 0; w < wv; ++w) base += wsum[w];
+  uint32_t r = base + incl - c;
+  for (int i = 0; i < BYTES_PER_THREAD; ++i) { const int64_t p = b0 + i; if (p < size && text[p] == '\n') nlpos[r++] = p; }
+}
+
+__device__ inline bool parse_int_token(const unsigned char *t, int64_t &p, int64_t end, int32_t &out) {
+  bool neg = false;
+  if (p < end && (t[p] == '-' || t[p] == '+')) { neg = t[p] == '-'; ++p; }
+  if (p >= end || t[p] < '0' || t[p] > '9') return false;          // "", "-", "+", "-x"
+  int64_t v = 0;
+  while (p < end && t[p] >= '0' && t[p] <= '9') {
+    v = v * 10 + (t[p] - '0');
+    if (v > 2147483648ll) return false;                              // beyond int32 either way
+    ++p;
+  }
+  if (neg) v = -v;
+  if (v > 2147483647ll) return false;
+  if (p < end && t[p] != ' ' && t[p] != '\t') return false;       // "12-3", "1+2": one token, not an int
+  out = (int32_t)v;
+  return true;
+}
+
+__global__ void k_parse(const unsigned char *__restrict__ text, int64_t size, const int64_t *__restrict__ nlpos,
+                        int64_t n_nl, int64_t n_lines, int32_t *__restrict__ src, int32_t *__restrict__ dst,
+                        int32_t *minmax, uint32_t *err) {
+  int32_t lo = 2147483647, hi = -2147483647 - 1;
+  bool bad = false;
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n_lines; j += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = j == 0 ? 0 : nlpos[j - 1] + 1;
+    const int64_t end = j < n_nl ? nlpos[j] : size;
+    int32_t a = 0, b = 0;
+    bool ok = parse_int_token(text, p, end, a);                      // a leading blank fails here, as in Java
+    if (ok) {
+      const int64_t q = p;
+      while (p < end && (text[p] == ' ' || text[p] == '\t')) ++p;
+      ok = p > q && parse_int_token(text, p, end, b);
+    }
+    if (ok) {
+      while (p < end && (text[p] == ' ' || text[p] == '\t')) ++p;    // trailing blanks are dropped by split
+      ok = p == end;                                                  // a third token: weights / partition ids -> host
+    }
+    if (!ok) { bad = true; continue; }
+    src[j] = a; dst[j] = b;
+    lo = min(lo, min(a, b)); hi = max(hi, max(a, b));
+  }
+  lo = wave_min_i32(lo); hi = wave_max_i32(hi);
+  if (lane_id() == 0) { atomicMin(&minmax[0], lo); atomicMax(&minmax[1], hi); }
+  if (__any(bad) && lane_id() == 0) atomicOr(err, 1u);
+}
+}  // namespace
+
+bool load_edgelist_device(srw_handle *h, const char *path, bool directed) {
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return false;                                           // the host path reports the error
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || sb.st_size <= 0 || (uint64_t)sb.st_size > ((uint64_t)8 << 30)) { close(fd); return false; }
+  const int64_t size = (int64_t)sb.st_size;
+  const unsigned char *data = (const unsigned char *)mmap(nullptr, (size_t)size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (data == MAP_FAILED) return false;
+  {   // cheap shape check on the first line: exactly two tokens, else do not even upload
+    int64_t e = 0; int tokens = 0; bool in_tok = false;
+    while (e < size && data[e] != '\n' && e < 4096) { const bool ws = data[e] == ' ' || data[e] == '\t'; if (!ws && !in_tok) ++tokens; in_tok = !ws; ++e; }
+    if (tokens != 2) { munmap((void *)data, (size_t)size); return false; }
+  }
+  hipStream_t st = h->stream;
+  DevBuf<unsigned char> d_text; d_text.alloc((size_t)size);
+  hipError_t ce = hipMemcpyAsync(d_text.p, data, (size_t)size, hipMemcpyHostToDevice, st);
+  if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+  munmap((void *)data, (size_t)size);
+  SRW_HIP(ce);
+  const int64_t n_blocks = (size + BLOCK_BYTES - 1) / BLOCK_BYTES;
+  DevBuf<uint32_t> blk, blkoff, flags; DevBuf<char> temp; DevBuf<int32_t> minmax;
+  blk.alloc((size_t)n_blocks + 1); blkoff.alloc((size_t)n_blocks + 1); flags.alloc(1); minmax.alloc(2);
+  SRW_HIP(hipMemsetAsync(flags.p, 0, 4, st));
+  SRW_HIP(hipMemsetAsync(blk.p + n_blocks, 0, 4, st));
+  hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_blocks), dim3(TTPB), 0, st, d_text.p, size, blk.p, flags.p);
+  size_t tb = 0;
+  SRW_HIP(rocprim::exclusive_scan(nullptr, tb, blk.p, blkoff.p, 0u, (size_t)n_blocks + 1, rocprim::plus<uint32_t>(), st));
+  temp.alloc(tb);
+  SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, blk.p, blkoff.p, 0u, (size_t)n_blocks + 1, rocprim::plus<uint32_t>(), st));
+  uint32_t n_nl32 = 0, bad = 0; unsigned char last = 0;
+  SRW_HIP(hipMemcpyAsync(&n_nl32, blkoff.p + n_blocks, 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipMemcpyAsync(&bad, flags.p, 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipMemcpyAsync(&last, d_text.p + (size - 1), 1, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  if (bad) return false;
+  const int64_t n_nl = n_nl32, n_lines = n_nl + (last != '\n' ? 1 : 0);
+  if (n_lines <= 0 || n_lines >= ((int64_t)1 << 31)) return false;
+  DevBuf<int64_t> nlpos; nlpos.alloc((size_t)std::max<int64_t>(n_nl, 1));
+  hipLaunchKernelGGL(k_nl_pos, dim3((unsigned)n_blocks), dim3(TTPB), 0, st, d_text.p, size, blkoff.p, nlpos.p);
+  DevBuf<int32_t> d_src, d_dst;
+  d_src.alloc((size_t)n_lines); d_dst.alloc((size_t)n_lines);
+  const int32_t init[2] = {2147483647, -2147483647 - 1};
+  SRW_HIP(hipMemcpyAsync(minmax.p, init, 8, hipMemcpyHostToDevice, st));
+  const int gp = (int)std::min<int64_t>((n_lines + TTPB - 1) / TTPB, (int64_t)h->n_cus * 16);
+  hipLaunchKernelGGL(k_parse, dim3(gp), dim3(TTPB), 0, st, d_text.p, size, nlpos.p, n_nl, n_lines, d_src.p, d_dst.p, minmax.p,
+                     flags.p);
+  int32_t mm[2];
+  SRW_HIP(hipMemcpyAsync(mm, minmax.p, 8, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipMemcpyAsync(&bad, flags.p, 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  SRW_HIP(hipGetLastError());
+  if (bad) return false;
+  d_text.release(); nlpos.release();
+  build_graph_from_device_lines(h, d_src.p, d_dst.p, nullptr, n_lines, directed, mm[0], mm[1], nullptr);
+  h->g.part_of.clear();
+  return true;
+}
+
+}  // namespace srw

@@ -188,6 +188,10 @@ class PathWriter {
   Impl *p_;
 };
 
+// ---- edgelist_device.hip ----
+// Device-side tokenizer for two-column integer edge lists; false = not that shape (or any doubt): use the host tokenizer.
+bool load_edgelist_device(srw_handle *h, const char *path, bool directed);
+
 // ---- path_format.hip ----
 size_t format_capacity(int64_t n, int64_t stride, int32_t vmin, int32_t vmax);
 void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens, int64_t n, int64_t stride,

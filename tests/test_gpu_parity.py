@@ -714,3 +714,95 @@ def test_randomized_differential_fuzz(eng):
     # ~8 s of tests/fuzz_parity.py: random multigraphs / hub graphs / RMATs, every sampler variant vs the CPU oracle
     import fuzz_parity
     assert fuzz_parity.run(budget=8.0, seed=20260928, eng=eng)
+
+
+def _graph_snapshot(eng):
+    verts = eng.vertices()
+    nb = [eng.neighbors(int(v)) for v in verts[:: max(1, len(verts) // 50)]]
+    return eng.stats(), verts.tolist(), [(a.tolist(), b.tolist()) for a, b in nb]
+
+
+def test_device_tokenizer_equals_host_tokenizer(eng, oracle, tmp_path, monkeypatch):
+    # two-column integer files go through the device tokenizer (edgelist_device.hip); everything else falls back to
+    # the host tokenizer.  Same graph either way, and the same errors for malformed input.
+    rng = np.random.default_rng(8)
+    n = 5000
+    a = rng.integers(-300, 900, n); b = rng.integers(-300, 900, n)
+    sep = rng.choice([" ", "\t", "  ", " \t "], n); tail = rng.choice(["", "", " ", "\t\t"], n)
+    sign = rng.choice(["", "", "+"], n)
+    body = "\n".join("%s%d%s%d%s" % (sg if x >= 0 else "", x, s_, y, t) for x, y, s_, t, sg in zip(a, b, sep, tail, sign))
+    cases = {
+        "plain": body + "\n",
+        "no_final_newline": body,
+        "one_line": "7 9",
+        "signs": "1000000 -1000000\n0 1\n-5 +5\n+0 -0\n",
+        "leading_zeros": "007 0012\n3 4\n",
+    }
+    for name, text in cases.items():
+        f = tmp_path / (name + ".txt")
+        f.write_text(text)
+        for directed in (False, True):
+            monkeypatch.delenv("SRW_HOST_TOKENIZER", raising=False)
+            eng.load_edgelist(str(f), directed=directed)
+            dev = _graph_snapshot(eng)
+            monkeypatch.setenv("SRW_HOST_TOKENIZER", "1")
+            eng.load_edgelist(str(f), directed=directed)
+            assert _graph_snapshot(eng) == dev, (name, directed)
+        g = oracle.Graph.load(str(f), directed=False)
+        monkeypatch.delenv("SRW_HOST_TOKENIZER", raising=False)
+        eng.load_edgelist(str(f), directed=False)
+        assert eng.stats() == (g.num_vertices, g.num_entries), name
+    # not the fast shape: host tokenizer decides (weights parsed, CRLF accepted, errors raised as before)
+    monkeypatch.delenv("SRW_HOST_TOKENIZER", raising=False)
+    ok_cases = {"weighted": "1 2 0.5\n2 3 1.5\n", "crlf": "1 2\r\n2 3\r\n", "three_ints": "1 2 3\n4 5 6\n"}
+    for name, text in ok_cases.items():
+        f = tmp_path / (name + ".txt")
+        f.write_text(text)
+        g = oracle.Graph.load(str(f), directed=False)
+        eng.load_edgelist(str(f), directed=False)
+        assert eng.stats() == (g.num_vertices, g.num_entries), name
+        nb = eng.neighbors(2)
+        onb = g.neighbors(2)
+        assert nb[0].tolist() == onb[0].tolist() and nb[1].tolist() == onb[1].tolist(), name
+    bad_cases = {"leading_blank": " 1 2\n", "empty_line": "1 2\n\n3 4\n", "overflow": "1 2147483648\n", "garbage": "1 x\n",
+                 "glued": "12-3 4\n", "lonely_sign": "- 4\n"}
+    for name, text in bad_cases.items():
+        f = tmp_path / (name + ".txt")
+        f.write_text(text)
+        with pytest.raises(pkg().SrwError) as ei:
+            eng.load_edgelist(str(f), directed=False)
+        assert ei.value.code == pkg().ERR_PARSE, name
+
+
+def test_device_tokenizer_fuzz(eng, tmp_path, monkeypatch):
+    # random files over an alphabet that mixes the fast shape with everything that must fall back or fail:
+    # the default loader (device tokenizer first) and the host tokenizer alone agree on graph or error, file by file
+    rng = np.random.default_rng(99)
+    toks = ["1", "2", "33", "-4", "+5", "007", "2147483647", "-2147483648", "2147483648", "-", "+", "1-2", "x", "1.5", "", "9"]
+    seps = [" ", "\t", "  ", " \t"]
+    ends = ["\n", "\n", "\n", "\r\n", " \n", "\n\n"]
+    def outcome():
+        try:
+            eng.load_edgelist(str(f), directed=bool(k & 1))
+            return ("ok",) + _graph_snapshot(eng)
+        except pkg().SrwError as e:
+            return ("err", e.code)
+    for k in range(80):
+        nl = int(rng.integers(1, 6))
+        lines = []
+        for _ in range(nl):
+            nt = int(rng.choice([2, 2, 2, 2, 3, 1]))
+            p_weird = 0.06
+            parts = [str(rng.choice(toks)) if rng.random() < p_weird else str(int(rng.integers(-50, 60))) for _ in range(nt)]
+            lead = " " if rng.random() < 0.03 else ""
+            lines.append(lead + str(rng.choice(seps)).join(parts) + str(rng.choice(ends)))
+        text = "".join(lines)
+        if rng.random() < 0.3:
+            text = text.rstrip("\n")
+        f = tmp_path / ("f%d.txt" % k)
+        f.write_text(text)
+        monkeypatch.delenv("SRW_HOST_TOKENIZER", raising=False)
+        a = outcome()
+        monkeypatch.setenv("SRW_HOST_TOKENIZER", "1")
+        b = outcome()
+        assert a == b, (k, text)

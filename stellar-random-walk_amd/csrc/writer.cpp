@@ -219,7 +219,10 @@ void PathWriter::append_text(const char *text, const unsigned long long *off, in
     const char *src = text + (off[done] - base);
     const size_t bytes = (size_t)(off[done + take] - off[done]);
     auto t0 = std::chrono::steady_clock::now();
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>(p_->hw, bytes / ((size_t)2 << 20) + 1));
+    // measured on the GPU box (3.3 GB into the page cache): reserving the extent first and writing 64 MB per thread
+    // (one or two threads per slice) takes ~295 ms; 2 MB per thread ~345 ms, 1 MB per thread ~585 ms (contention)
+    (void)posix_fallocate(p_->fd, p_->file_off, (off_t)bytes);
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(p_->hw, bytes / ((size_t)64 << 20) + 1));
     std::vector<std::string> errs((size_t)nt);
     const std::string fn = p_->dir + "/" + p_->part_name(p_->cur_part);
     {

@@ -1,6 +1,7 @@
 // main.cpp — `stellar-rw`: native stand-in for `spark-submit --class au.csiro.data61.randomwalk.Main`
 // (M/Main.scala:18-27,53-69,109-127) for the --cmd randomwalk path.  Same flags, same stdout lines, same
 // <output>/path layout.  --cmd node2vec / embedding (MLlib Word2Vec) are out of scope and rejected.
+#include <chrono>
 #include <cstdlib>
 #include <iostream>
 #include <memory>
@@ -26,6 +27,8 @@ static void doRandomWalk(const Params &param) {  // Main.scala:53-62
 }
 
 int main(int argc, char **argv) {
+  const auto t_main = std::chrono::steady_clock::now();
+  struct AtExit { std::chrono::steady_clock::time_point t0; ~AtExit() { if (getenv("SRW_TIMING")) std::cerr << "[timing] main() body: " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() << " ms\n"; } } at_exit{t_main};
   std::vector<std::string> args(argv + 1, argv + argc);
   for (auto &a : args)
     if (a == "--help") { std::cout << CommandParser::usage(); return 0; }

@@ -332,6 +332,8 @@ int32_t srw_write_paths(const srw_handle *ch, const char *output_dir, int32_t n_
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
     need(h->res.valid && output_dir, "no walk result / null output_dir");
+    // the result is in HBM: format it there (path_format.hip) unless told otherwise or memory is short
+    if (!getenv("SRW_HOST_FORMATTER") && write_result_device(h, output_dir, n_parts, write_crc != 0)) return;
     std::vector<int32_t> paths((size_t)h->res.n_walkers * h->res.stride + 1), lens((size_t)h->res.n_walkers + 1);
     if (h->res.n_walkers > 0) {
       SRW_HIP(hipMemcpy(paths.data(), h->res.paths.p, (size_t)h->res.n_walkers * h->res.stride * 4, hipMemcpyDeviceToHost));

@@ -194,6 +194,8 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed);
 
 // ---- path_format.hip ----
 size_t format_capacity(int64_t n, int64_t stride, int32_t vmin, int32_t vmax);
+void ensure_pinned_text(srw_handle *h, size_t slice_cap, size_t n_off);
+bool write_result_device(srw_handle *h, const char *output_dir, int n_parts, bool write_crc);
 void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens, int64_t n, int64_t stride,
                          unsigned long long *d_len_bytes, unsigned long long *d_off, char *d_text);
 

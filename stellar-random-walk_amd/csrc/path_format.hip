@@ -88,4 +88,73 @@ void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d
   SRW_HIP(hipGetLastError());
 }
 
+// Pinned staging of the device formatter's output: two text slices (+ the line offsets of one chunk).
+void ensure_pinned_text(srw_handle *h, size_t slice_cap, size_t n_off) {
+  for (int i = 0; i < 2; ++i)
+    if (h->pin_text_cap[i] < slice_cap) {
+      if (h->pin_text[i]) (void)hipHostFree(h->pin_text[i]);
+      h->pin_text[i] = nullptr;
+      SRW_HIP(hipHostMalloc((void **)&h->pin_text[i], slice_cap, hipHostMallocDefault));
+      h->pin_text_cap[i] = slice_cap;
+    }
+  if (h->pin_off_cap < n_off) {
+    for (int i = 0; i < 2; ++i) {
+      if (h->pin_off[i]) (void)hipHostFree(h->pin_off[i]);
+      h->pin_off[i] = nullptr;
+      SRW_HIP(hipHostMalloc((void **)&h->pin_off[i], n_off * 8, hipHostMallocDefault));
+    }
+    h->pin_off_cap = n_off;
+  }
+}
+
+// srw_write_paths on a device-resident result: formatted on the GPU chunk by chunk, copied out in slices of whole lines
+// through the two pinned buffers (slice j + 1 in flight while slice j is written).  false = not enough HBM for a chunk's
+// text: the caller formats on the host.
+bool write_result_device(srw_handle *h, const char *output_dir, int n_parts, bool write_crc) {
+  const int64_t n = h->res.n_walkers, stride = h->res.stride;
+  Graph &g = h->g;
+  const size_t per_walker = format_capacity(1, stride, g.vmin, (int32_t)((int64_t)g.vmin + g.n_slots - 1));
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(((size_t)1 << 30) / per_walker)));
+  const size_t cap = (size_t)chunk * per_walker + 16;
+  size_t free_b = 0, total_b = 0;
+  SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+  if (h->fmt_text[0].n < cap && free_b < cap + (size_t)chunk * 16 + ((size_t)2 << 30)) return false;
+  PathWriter writer(output_dir, n_parts, n, write_crc);
+  if (n == 0) { writer.close(); return true; }
+  hipStream_t st = h->stream;
+  if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  h->fmt_text[0].ensure(cap); h->fmt_len[0].ensure((size_t)chunk + 1); h->fmt_off[0].ensure((size_t)chunk + 1);
+  const size_t slice_cap = std::max<size_t>((size_t)64 << 20, (size_t)stride * 12 + 64);
+  ensure_pinned_text(h, slice_cap, (size_t)chunk + 1);
+  for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+    const int64_t m = std::min<int64_t>(chunk, n - c0);
+    format_paths_device(h, h->res.paths.p + c0 * stride, h->res.lens.p + c0, m, stride, h->fmt_len[0].p, h->fmt_off[0].p,
+                        h->fmt_text[0].p);
+    SRW_HIP(hipMemcpyAsync(h->pin_off[0], h->fmt_off[0].p, ((size_t)m + 1) * 8, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    const unsigned long long *off = h->pin_off[0];
+    auto slice_end = [&](int64_t w0) {
+      int64_t lo = w0 + 1, hi = m;
+      while (lo < hi) { const int64_t mid = lo + (hi - lo + 1) / 2; if (off[mid] - off[w0] <= slice_cap) lo = mid; else hi = mid - 1; }
+      return lo;
+    };
+    auto copy_slice = [&](int64_t w0, int64_t w1, int buf) {
+      SRW_HIP(hipMemcpyAsync(h->pin_text[buf], h->fmt_text[0].p + off[w0], (size_t)(off[w1] - off[w0]), hipMemcpyDeviceToHost,
+                             h->copy_stream));
+    };
+    int64_t w0 = 0, w1 = slice_end(0);
+    int buf = 0;
+    copy_slice(w0, w1, buf);
+    while (w0 < m) {
+      SRW_HIP(hipStreamSynchronize(h->copy_stream));
+      const int64_t n0 = w1, n1 = n0 < m ? slice_end(n0) : n0;
+      if (n0 < m) copy_slice(n0, n1, buf ^ 1);
+      writer.append_text(h->pin_text[buf], off + w0, w1 - w0, off[w0]);
+      w0 = n0; w1 = n1; buf ^= 1;
+    }
+  }
+  writer.close();
+  return true;
+}
+
 }  // namespace srw

@@ -893,13 +893,6 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
     // Device-side formatter (path_format.hip): the GPU turns iteration `it` into text while the host copies out and
     // writes the text of iteration `it - 1`; the host never touches the ids.
     for (int i = 0; i < 2; ++i) { h->fmt_text[i].ensure(cap); h->fmt_len[i].ensure((size_t)nv + 1); h->fmt_off[i].ensure((size_t)nv + 1); }
-    for (int i = 0; i < 2; ++i)
-      if (h->pin_off_cap < (size_t)nv + 1) {
-        if (h->pin_off[i]) (void)hipHostFree(h->pin_off[i]);
-        h->pin_off[i] = nullptr;
-        SRW_HIP(hipHostMalloc((void **)&h->pin_off[i], ((size_t)nv + 1) * 8, hipHostMallocDefault));
-      }
-    h->pin_off_cap = std::max(h->pin_off_cap, (size_t)nv + 1);
     const int32_t N = P.num_walks;
     auto launch = [&](int32_t it) {
       const int b = it & 1;
@@ -911,13 +904,7 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
     // Pinned memory costs ~0.2 ms/MB to allocate and ~0.1 ms/MB to free on this stack, so the text leaves the device in
     // slices of <= 64 MB of whole lines through two small pinned buffers: slice j + 1 is copied while slice j is written.
     const size_t slice_cap = std::max<size_t>((size_t)64 << 20, (size_t)stride * 12 + 64);
-    for (int i = 0; i < 2; ++i)
-      if (h->pin_text_cap[i] < slice_cap) {
-        if (h->pin_text[i]) (void)hipHostFree(h->pin_text[i]);
-        h->pin_text[i] = nullptr;
-        SRW_HIP(hipHostMalloc((void **)&h->pin_text[i], slice_cap, hipHostMallocDefault));
-        h->pin_text_cap[i] = slice_cap;
-      }
+    ensure_pinned_text(h, slice_cap, (size_t)nv + 1);
     launch(0);
     if (N > 1) launch(1);
     for (int32_t k = 0; k < N; ++k) {

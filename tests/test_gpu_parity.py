@@ -292,7 +292,15 @@ def test_high_degree_hub(eng, oracle):
 def test_writer_matches_oracle(eng, oracle, tmp_path):
     eng.load_edgelist(KARATE, directed=True)
     paths, lens, _ = eng.walk(walk_length=10, num_walks=2, seed=3)
-    eng.write_paths(str(tmp_path / "gpu"), n_parts=3)
+    eng.write_paths(str(tmp_path / "gpu"), n_parts=3)                 # formatted on the device (path_format.hip)
+    os.environ["SRW_HOST_FORMATTER"] = "1"
+    try:
+        eng.write_paths(str(tmp_path / "gpu_host"), n_parts=3)       # ... and by the host formatter
+    finally:
+        del os.environ["SRW_HOST_FORMATTER"]
+    for k in range(3):
+        assert (tmp_path / "gpu" / "path" / ("part-%05d" % k)).read_bytes() == \
+               (tmp_path / "gpu_host" / "path" / ("part-%05d" % k)).read_bytes()
     assert oracle.write_paths(paths, lens, str(tmp_path / "ref"), 3) == 0
     for name in ("part-00000", "part-00001", "part-00002", "_SUCCESS"):
         assert (tmp_path / "gpu" / "path" / name).read_bytes() == (tmp_path / "ref" / "path" / name).read_bytes()

@@ -143,7 +143,7 @@ int32_t srw_load_edgelist(srw_handle *h, const char *path, int32_t directed, int
     need(path != nullptr, "path is null");
     const auto t0 = std::chrono::steady_clock::now();
     // two integer columns and nothing unusual: tokenized on the device (edgelist_device.hip); anything else: below
-    if (!partitioned && !getenv("SRW_HOST_TOKENIZER") && load_edgelist_device(h, path, directed != 0)) {
+    if (!partitioned && !getenv("SRW_HOST_TOKENIZER") && load_edgelist_device(h, path, directed != 0, weighted != 0)) {
       if (getenv("SRW_TIMING"))
         fprintf(stderr, "[timing] loadGraph: device tokenizer + device CSR build %.1f ms\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

@@ -1,5 +1,10 @@
 // edgelist_device.hip — device-side tokenizer for the common edge-list shape:
-// every line is exactly "<int><blanks><int>[blanks]" over the characters 0-9 + - space TAB, lines end in '\n'.
+// every line is "<int><blanks><int>[blanks]" or, with `weighted`, "<int><blanks><int><blanks><simple decimal>[blanks]", over the
+// characters 0-9 + - . space TAB; lines end in '\n'.  A simple decimal is [sign] digits [. digits] with at most 7
+// significant digits and at most 10 fraction digits: then M / 10^k (M < 10^7 < 2^24, 10^k exact) evaluated in f64 and
+// rounded to f32 IS the correctly rounded binary32 value Float.parseFloat returns — a decimal this short is never
+// within 2^-48 (relative) of a binary32 rounding boundary unless it sits on it, so the f64 quotient cannot round
+// across one (argument in DESIGN.md §4.1; checked against strtof by the tests).
 // Same acceptance rules as the host tokenizer (edgelist.cpp) and UniformRandomWalk.loadGraph
 // (M/algorithm/UniformRandomWalk.scala:23-43) on that shape: Java split("\\s+") (leading blank => empty first token
 // => NumberFormatException), Integer.parseInt (optional single sign, >= 1 digit, int32 range).  ANYTHING else — a
@@ -26,7 +31,7 @@ constexpr int BYTES_PER_THREAD = 16;
 constexpr int64_t BLOCK_BYTES = (int64_t)TTPB * BYTES_PER_THREAD;
 
 __device__ inline bool tok_char_ok(unsigned char c) {
-  return (c >= '0' && c <= '9') || c == ' ' || c == '\t' || c == '\n' || c == '-' || c == '+';
+  return (c >= '0' && c <= '9') || c == ' ' || c == '\t' || c == '\n' || c == '-' || c == '+' || c == '.';
 }
 
 __global__ __launch_bounds__(TTPB) void k_nl_count(const unsigned char *__restrict__ text, int64_t size,
@@ -64,7 +69,9 @@ __global__ __launch_bounds__(TTPB) void k_nl_pos(const unsigned char *__restrict
   for (int i = 0; i < BYTES_PER_THREAD; ++i) { const int64_t p = b0 + i; if (p < size && text[p] == '\n') nlpos[r++] = p; }
 }
 
-__device__ inline bool parse_int_token(const unsigned char *t, int64_t &p, int64_t end, int32_t &out) {
+// (__noinline__ on purpose: with both token parsers inlined into k_parse, hipcc 7.2 -O3 produced a kernel that stored 0 for
+// the first column — same source, tests/test_gpu_parity.py::test_device_tokenizer_* catch it; as calls they are correct)
+__device__ __noinline__ bool parse_int_token(const unsigned char *t, int64_t &p, int64_t end, int32_t &out) {
   bool neg = false;
   if (p < end && (t[p] == '-' || t[p] == '+')) { neg = t[p] == '-'; ++p; }
   if (p >= end || t[p] < '0' || t[p] > '9') return false;          // "", "-", "+", "-x"
@@ -81,9 +88,35 @@ __device__ inline bool parse_int_token(const unsigned char *t, int64_t &p, int64
   return true;
 }
 
+// [sign] digits [. digits], <= 7 significant digits, <= 10 fraction digits, delimited by a blank or the line end
+__device__ __noinline__ bool parse_simple_decimal(const unsigned char *t, int64_t &p, int64_t end, float &out) {
+  bool neg = false;
+  if (p < end && (t[p] == '-' || t[p] == '+')) { neg = t[p] == '-'; ++p; }
+  int64_t M = 0; int sig = 0, frac = 0, ndig = 0;
+  bool seen_dot = false;
+  while (p < end) {
+    const unsigned char c = t[p];
+    if (c >= '0' && c <= '9') {
+      ++ndig;
+      if (sig > 0 || c != '0') ++sig;
+      if (sig > 7) return false;
+      M = M * 10 + (c - '0');
+      if (seen_dot && ++frac > 10) return false;
+    } else if (c == '.' && !seen_dot) seen_dot = true;
+    else break;
+    ++p;
+  }
+  if (ndig == 0) return false;                                         // ".", "-", "": unparsable -> host (1.0f there)
+  if (p < end && t[p] != ' ' && t[p] != '\t') return false;
+  const double pow10[11] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10};
+  const float v = (float)((double)M / pow10[frac]);
+  out = neg ? -v : v;
+  return true;
+}
+
 __global__ void k_parse(const unsigned char *__restrict__ text, int64_t size, const int64_t *__restrict__ nlpos,
                         int64_t n_nl, int64_t n_lines, int32_t *__restrict__ src, int32_t *__restrict__ dst,
-                        int32_t *minmax, uint32_t *err) {
+                        float *__restrict__ wout, int32_t *minmax, uint32_t *err) {
   int32_t lo = 2147483647, hi = -2147483647 - 1;
   bool bad = false;
   for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n_lines; j += (int64_t)gridDim.x * blockDim.x) {
@@ -96,12 +129,18 @@ __global__ void k_parse(const unsigned char *__restrict__ text, int64_t size, co
       while (p < end && (text[p] == ' ' || text[p] == '\t')) ++p;
       ok = p > q && parse_int_token(text, p, end, b);
     }
+    float w = 1.0f;                                                   // two columns: weight 1.0f (:29-32)
     if (ok) {
       while (p < end && (text[p] == ' ' || text[p] == '\t')) ++p;    // trailing blanks are dropped by split
-      ok = p == end;                                                  // a third token: weights / partition ids -> host
+      if (p < end && wout) {                                          // weighted: the third (= last) column
+        ok = parse_simple_decimal(text, p, end, w);
+        while (ok && p < end && (text[p] == ' ' || text[p] == '\t')) ++p;
+      }
+      ok = ok && p == end;                                            // anything further -> host tokenizer
     }
     if (!ok) { bad = true; continue; }
     src[j] = a; dst[j] = b;
+    if (wout) wout[j] = w;
     lo = min(lo, min(a, b)); hi = max(hi, max(a, b));
   }
   lo = wave_min_i32(lo); hi = wave_max_i32(hi);
@@ -110,7 +149,7 @@ __global__ void k_parse(const unsigned char *__restrict__ text, int64_t size, co
 }
 }  // namespace
 
-bool load_edgelist_device(srw_handle *h, const char *path, bool directed) {
+bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool weighted) {
   int fd = open(path, O_RDONLY);
   if (fd < 0) return false;                                           // the host path reports the error
   struct stat sb;
@@ -122,7 +161,7 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed) {
   {   // cheap shape check on the first line: exactly two tokens, else do not even upload
     int64_t e = 0; int tokens = 0; bool in_tok = false;
     while (e < size && data[e] != '\n' && e < 4096) { const bool ws = data[e] == ' ' || data[e] == '\t'; if (!ws && !in_tok) ++tokens; in_tok = !ws; ++e; }
-    if (tokens != 2) { munmap((void *)data, (size_t)size); return false; }
+    if (tokens != 2 && !(weighted && tokens == 3)) { munmap((void *)data, (size_t)size); return false; }
   }
   hipStream_t st = h->stream;
   DevBuf<unsigned char> d_text; d_text.alloc((size_t)size);
@@ -150,13 +189,14 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed) {
   if (n_lines <= 0 || n_lines >= ((int64_t)1 << 31)) return false;
   DevBuf<int64_t> nlpos; nlpos.alloc((size_t)std::max<int64_t>(n_nl, 1));
   hipLaunchKernelGGL(k_nl_pos, dim3((unsigned)n_blocks), dim3(TTPB), 0, st, d_text.p, size, blkoff.p, nlpos.p);
-  DevBuf<int32_t> d_src, d_dst;
+  DevBuf<int32_t> d_src, d_dst; DevBuf<float> d_w;
   d_src.alloc((size_t)n_lines); d_dst.alloc((size_t)n_lines);
+  if (weighted) d_w.alloc((size_t)n_lines);
   const int32_t init[2] = {2147483647, -2147483647 - 1};
   SRW_HIP(hipMemcpyAsync(minmax.p, init, 8, hipMemcpyHostToDevice, st));
   const int gp = (int)std::min<int64_t>((n_lines + TTPB - 1) / TTPB, (int64_t)h->n_cus * 16);
-  hipLaunchKernelGGL(k_parse, dim3(gp), dim3(TTPB), 0, st, d_text.p, size, nlpos.p, n_nl, n_lines, d_src.p, d_dst.p, minmax.p,
-                     flags.p);
+  hipLaunchKernelGGL(k_parse, dim3(gp), dim3(TTPB), 0, st, d_text.p, size, nlpos.p, n_nl, n_lines, d_src.p, d_dst.p,
+                     weighted ? d_w.p : nullptr, minmax.p, flags.p);
   int32_t mm[2];
   SRW_HIP(hipMemcpyAsync(mm, minmax.p, 8, hipMemcpyDeviceToHost, st));
   SRW_HIP(hipMemcpyAsync(&bad, flags.p, 4, hipMemcpyDeviceToHost, st));
@@ -164,7 +204,7 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed) {
   SRW_HIP(hipGetLastError());
   if (bad) return false;
   d_text.release(); nlpos.release();
-  build_graph_from_device_lines(h, d_src.p, d_dst.p, nullptr, n_lines, directed, mm[0], mm[1], nullptr);
+  build_graph_from_device_lines(h, d_src.p, d_dst.p, weighted ? d_w.p : nullptr, n_lines, directed, mm[0], mm[1], nullptr);
   h->g.part_of.clear();
   return true;
 }

@@ -189,8 +189,8 @@ class PathWriter {
 };
 
 // ---- edgelist_device.hip ----
-// Device-side tokenizer for two-column integer edge lists; false = not that shape (or any doubt): use the host tokenizer.
-bool load_edgelist_device(srw_handle *h, const char *path, bool directed);
+// Device-side tokenizer for two-column integer edge lists (+ a short decimal weight column); false = not that shape (or any doubt): use the host tokenizer.
+bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool weighted);
 
 // ---- path_format.hip ----
 size_t format_capacity(int64_t n, int64_t stride, int32_t vmin, int32_t vmax);

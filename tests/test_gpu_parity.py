@@ -760,9 +760,35 @@ def test_device_tokenizer_equals_host_tokenizer(eng, oracle, tmp_path, monkeypat
         monkeypatch.delenv("SRW_HOST_TOKENIZER", raising=False)
         eng.load_edgelist(str(f), directed=False)
         assert eng.stats() == (g.num_vertices, g.num_entries), name
+    # weighted files with short decimal weights are tokenized on the device too: bitwise the same weights as strtof
+    wrng = np.random.default_rng(21)
+    def wtoken(i):
+        kind = i % 6
+        if kind == 0: return str(int(wrng.integers(0, 9999999)))
+        if kind == 1: return "%.*f" % (int(wrng.integers(1, 7)), wrng.random() * 10 ** int(wrng.integers(0, 2)))
+        if kind == 2: return "0." + "0" * int(wrng.integers(0, 4)) + str(int(wrng.integers(1, 9999999)))[: 10 - 4]
+        if kind == 3: return ("-" if wrng.random() < 0.5 else "+") + "%.3f" % (wrng.random() * 100)
+        if kind == 4: return str(int(wrng.integers(0, 999))) + "."
+        return "." + str(int(wrng.integers(0, 9999999)))
+    wlines = ["%d %d %s" % (x, y, wtoken(i)) for i, (x, y) in enumerate(zip(a[:3000], b[:3000]))]
+    wlines[5] = "%d %d" % (a[5], b[5])                      # a two-column line in a weighted file: weight 1.0
+    fw = tmp_path / "weighted_simple.txt"
+    fw.write_text("\n".join(wlines) + "\n")
+    for directed in (False, True):
+        monkeypatch.delenv("SRW_HOST_TOKENIZER", raising=False)
+        eng.load_edgelist(str(fw), directed=directed, weighted=True)
+        dev = _graph_snapshot(eng)
+        devw = np.concatenate([eng.neighbors(int(v))[1] for v in eng.vertices()]).view(np.uint32)
+        monkeypatch.setenv("SRW_HOST_TOKENIZER", "1")
+        eng.load_edgelist(str(fw), directed=directed, weighted=True)
+        hostw = np.concatenate([eng.neighbors(int(v))[1] for v in eng.vertices()]).view(np.uint32)
+        assert _graph_snapshot(eng) == dev and np.array_equal(devw, hostw)
+    monkeypatch.delenv("SRW_HOST_TOKENIZER", raising=False)
     # not the fast shape: host tokenizer decides (weights parsed, CRLF accepted, errors raised as before)
     monkeypatch.delenv("SRW_HOST_TOKENIZER", raising=False)
-    ok_cases = {"weighted": "1 2 0.5\n2 3 1.5\n", "crlf": "1 2\r\n2 3\r\n", "three_ints": "1 2 3\n4 5 6\n"}
+    ok_cases = {"weighted": "1 2 0.5\n2 3 1.5\n", "crlf": "1 2\r\n2 3\r\n", "three_ints": "1 2 3\n4 5 6\n",
+                "exp_weights": "1 2 1e-3\n2 3 2.5E2\n", "long_weights": "1 2 0.123456789012\n2 3 16777217\n",
+                "odd_weights": "1 2 NaN\n2 3 0x1p3\n3 4 1.5f\n4 5 abc\n5 6 .\n", "four_cols": "1 2 9 0.25\n2 3 9 4\n"}
     for name, text in ok_cases.items():
         f = tmp_path / (name + ".txt")
         f.write_text(text)
@@ -771,7 +797,8 @@ def test_device_tokenizer_equals_host_tokenizer(eng, oracle, tmp_path, monkeypat
         assert eng.stats() == (g.num_vertices, g.num_entries), name
         nb = eng.neighbors(2)
         onb = g.neighbors(2)
-        assert nb[0].tolist() == onb[0].tolist() and nb[1].tolist() == onb[1].tolist(), name
+        assert nb[0].tolist() == onb[0].tolist(), name
+        assert np.array_equal(np.asarray(nb[1], np.float32).view(np.uint32), np.asarray(onb[1], np.float32).view(np.uint32)), name
     bad_cases = {"leading_blank": " 1 2\n", "empty_line": "1 2\n\n3 4\n", "overflow": "1 2147483648\n", "garbage": "1 x\n",
                  "glued": "12-3 4\n", "lonely_sign": "- 4\n"}
     for name, text in bad_cases.items():
@@ -786,7 +813,8 @@ def test_device_tokenizer_fuzz(eng, tmp_path, monkeypatch):
     # random files over an alphabet that mixes the fast shape with everything that must fall back or fail:
     # the default loader (device tokenizer first) and the host tokenizer alone agree on graph or error, file by file
     rng = np.random.default_rng(99)
-    toks = ["1", "2", "33", "-4", "+5", "007", "2147483647", "-2147483648", "2147483648", "-", "+", "1-2", "x", "1.5", "", "9"]
+    toks = ["1", "2", "33", "-4", "+5", "007", "2147483647", "-2147483648", "2147483648", "-", "+", "1-2", "x", "1.5", "", "9",
+            "0.25", ".5", "5.", "1e3", "12345678", "0.00000000001", "-0", "1..2", "3.1415927"]
     seps = [" ", "\t", "  ", " \t"]
     ends = ["\n", "\n", "\n", "\r\n", " \n", "\n\n"]
     def outcome():

@@ -30,6 +30,8 @@ constexpr int TTPB = 256;
 constexpr int BYTES_PER_THREAD = 16;
 constexpr int64_t BLOCK_BYTES = (int64_t)TTPB * BYTES_PER_THREAD;
 
+__constant__ double kPow10[11] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10};   // all exact in f64
+
 __device__ inline bool tok_char_ok(unsigned char c) {
   return (c >= '0' && c <= '9') || c == ' ' || c == '\t' || c == '\n' || c == '-' || c == '+' || c == '.';
 }
@@ -108,8 +110,7 @@ __device__ __noinline__ bool parse_simple_decimal(const unsigned char *t, int64_
   }
   if (ndig == 0) return false;                                         // ".", "-", "": unparsable -> host (1.0f there)
   if (p < end && t[p] != ' ' && t[p] != '\t') return false;
-  const double pow10[11] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10};
-  const float v = (float)((double)M / pow10[frac]);
+  const float v = (float)((double)M / kPow10[frac]);
   out = neg ? -v : v;
   return true;
 }

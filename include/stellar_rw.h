@@ -73,7 +73,9 @@ int32_t srw_set_stream(srw_handle *h, void *hip_stream);
 /* Replaces UniformRandomWalk.loadGraph (M/algorithm/UniformRandomWalk.scala:17-88) and, with
  * partitioned != 0, VCutRandomWalk.loadGraph (M/algorithm/VCutRandomWalk.scala:13-98): parses the
  * edge-list text with the reference's token rules, builds the adjacency in HBM as CSR with every
- * neighbor list in input-line order, multi-edges and self-loops kept. */
+ * neighbor list in input-line order, multi-edges and self-loops kept.  Files of two integer columns (plus, with
+ * weighted, a short decimal weight column) are tokenized on the GPU; every other shape and every malformed file
+ * goes through the host tokenizer, with identical results and errors (SRW_HOST_TOKENIZER=1 forces the host). */
 int32_t srw_load_edgelist(srw_handle *h, const char *path, int32_t directed, int32_t weighted,
                           int32_t partitioned, int32_t rdd_partitions);
 /* Same construction from already-parsed lines in file order (host pointers).  w may be NULL (1.0f),
@@ -156,6 +158,7 @@ int32_t srw_walk_to_host(srw_handle *h, const srw_walk_params *params, int32_t *
 /* Main.doRandomWalk fused (M/Main.scala:53-62: rw.execute() then rw.save(...)): walks num_walks iterations and
  * writes <output_dir>/path/part-* + _SUCCESS while streaming — iteration i's kernel and PCIe transfer overlap the host's
  * formatting of iteration i-1 (pinned ring of two slices); the paths are never held as a whole in host memory.
+ * With SRW_WALK_DEVICE_FORMAT in params->flags the GPU formats the text and the host only copies it out and writes it.
  * dead_ends_per_iteration (optional, [num_walks]) receives the reference's per-iteration "Zero Neighbors" count.
  * Fails with SRW_ERR_EXISTS before any work if <output_dir>/path exists. */
 int32_t srw_walk_and_save(srw_handle *h, const srw_walk_params *params, const char *output_dir, int32_t n_parts,
@@ -169,7 +172,8 @@ int32_t srw_fetch_paths(const srw_handle *h, int32_t *paths, int32_t *lens);
 int32_t srw_device_paths(const srw_handle *h, void **d_paths, void **d_lens, int64_t *n_walkers, int32_t *stride);
 /* Replaces RandomWalk.save (M/algorithm/RandomWalk.scala:234-241) + Property.pathSuffix: writes
  * <output_dir>/path/part-00000.. (TAB-joined ids, one '\n' per path) and _SUCCESS; canonical line
- * order (walk iteration major, source id ascending).  write_crc != 0 adds Hadoop .crc side files. */
+ * order (walk iteration major, source id ascending).  write_crc != 0 adds Hadoop .crc side files.
+ * The text is formatted on the GPU from the device-resident result (SRW_HOST_FORMATTER=1: on host threads). */
 int32_t srw_write_paths(const srw_handle *h, const char *output_dir, int32_t n_parts, int32_t write_crc);
 
 /* Mode A table of vertex v (build-defined exact-integer alias construction): prob/alias of each

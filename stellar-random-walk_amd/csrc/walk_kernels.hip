@@ -742,7 +742,11 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   else build_membership(h);                           // sorted rows: general and alias kernels only
   if (alias) build_alias_tables(h);
   const bool general = !alias && !first_order;
-  // the edge hash set answers "x in N(prev)?" in one probe: Mode A's rejection test, and the general kernel's
+  // optional accelerators, most valuable first (each one skips itself when HBM is short):
+  // exact base prefix sums for the search samplers ...
+  if (general && !(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX)) build_pq_tables(h, P.p, P.q);
+  else if (general) h->g.has_pq = false;
+  // ... the edge hash set answers "x in N(prev)?" in one probe: Mode A's rejection test, and the general kernel's
   // candidate-by-candidate membership (small rows, the located chunk of the binned search)
   const bool want_ehash = P.q != 1.0f && !(P.flags & SRW_WALK_NO_EDGE_HASH) && (alias || (general && h->cfg.world == 1));
   if (want_ehash) build_edge_hash(h);
@@ -751,9 +755,6 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool want_hub = general && P.q != 1.0f && h->cfg.world == 1 && !(P.flags & SRW_WALK_NO_HUB_BITMAPS);
   if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024);
   h->g.use_hub = want_hub;
-  if (!alias && !first_order && !(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX))
-    build_pq_tables(h, P.p, P.q);                    // optional: exact base prefix sums for the search sampler
-  else if (!alias && !first_order) h->g.has_pq = false;
 }
 }  // namespace
 

@@ -39,17 +39,26 @@ struct alignas(32) FoEnt {
 };
 
 // Compact first-order record for LATTICE draws (p = m * 2^-24, i.e. the Philox stream): cdf >= p  <=>
-// floor(cdf * 2^24) >= m, so 25 bits of the exact f64 CDF decide exactly like the f64 compare.  One 16-byte load.
-//   cg   : bits 0..24  c = min(floor(cdf * 2^24), 2^24)      bits 26..31  guide delta gd = j - guide[j] (0..62)
+// floor(cdf * 2^24) >= m, and since m <= 2^24 - 1, min(floor(cdf * 2^24), 2^24 - 1) decides exactly like the f64
+// compare: 24 bits.  One 16-byte load.
+//   cg   : bits 0..23  c = min(floor(cdf * 2^24), 2^24 - 1)     bits 24..31  low 8 bits of the guide delta
 //   id   : neighbor id
-//   link : bits 0..39 noff | bits 40..62 ndeg (< 2^23 - 1) | bit 63 next row needs the generic path
-// Built from the exact 32-byte table and used only if no entry needs an escape (sampler_tables.hip).
+//   link : bits 0..35 noff | bits 36..39 high 4 bits of the guide delta | bits 40..62 ndeg (< 2^23 - 1) |
+//          bit 63 next row needs the generic path
+// guide delta gd = j - guide[j] as a signed 12-bit number (-2047 .. 2047; weighted hub rows need both signs and
+// hundreds); CFO_GD_SAT marks an entry whose delta does not fit: the pick then searches the row's (monotone) c values.
 struct alignas(16) CfoEnt {
   uint32_t cg;
   int32_t id;
   uint64_t link;
 };
 constexpr uint32_t CFO_NDEG_MAX = (1u << 23) - 2u;
+constexpr int32_t CFO_GD_SAT = -2048;
+constexpr uint64_t CFO_NOFF_MASK = (1ull << 36) - 1ull;
+__host__ __device__ inline int32_t cfo_delta(uint32_t cg, uint64_t link) {
+  const uint32_t d = (cg >> 24) | ((uint32_t)((link >> 36) & 0xFull) << 8);
+  return (int32_t)(d << 20) >> 20;                     // sign-extend 12 bits
+}
 
 // Mode A record: alias slot of entry k of a row + the neighbor's id / weight / row descriptor (linked).
 struct alignas(32) AEnt {

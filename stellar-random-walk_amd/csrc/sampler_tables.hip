@@ -261,21 +261,20 @@ __device__ inline void cfo_write(const ST &st, const Row *__restrict__ rows, con
   const int64_t s = (int64_t)id - vmin;
   Row nr; nr.off = 0; nr.deg = 0; nr.flags = 0;
   if (s >= 0 && s < n_slots) nr = rows[s];
-  bool esc = nr.deg > (int32_t)CFO_NDEG_MAX || nr.off >= ((int64_t)1 << 40);
-  uint32_t cg = 0;
+  bool esc = nr.deg > (int32_t)CFO_NDEG_MAX || nr.off >= ((int64_t)1 << 36);
+  uint32_t cg = 0; uint32_t dbits = 0;
   if (regular) {
     const double sc = st.cdf(e) * 16777216.0;                     // exact scaling
-    const uint32_t c = sc >= 16777216.0 ? 16777216u : (uint32_t)sc;   // floor; cdf >= 0 on a regular row
+    const uint32_t c = sc >= 16777215.0 ? 16777215u : (uint32_t)sc;   // min(floor, 2^24 - 1); cdf >= 0 on a regular row
     const int32_t delta = j - st.guide(e);
-    // a start below guide[j] stays a valid lower bound, so a small negative delta could use 0; be strict instead
-    const bool desc = delta < 0 || delta > 62;
-    esc |= desc;
-    cg = c | ((uint32_t)(desc ? 63 : delta) << 26);
+    const int32_t d12 = (delta < -2047 || delta > 2047) ? CFO_GD_SAT : delta;   // saturated: the pick bisects the row
+    dbits = (uint32_t)d12 & 0xFFFu;
+    cg = c | ((dbits & 0xFFu) << 24);
   }
   CfoEnt o;
   o.cg = cg; o.id = id;
-  o.link = (uint64_t)nr.off | ((uint64_t)(uint32_t)min(nr.deg, (int32_t)CFO_NDEG_MAX) << 40) |
-           ((uint64_t)((nr.flags & ROW_IRREGULAR) != 0) << 63);
+  o.link = ((uint64_t)nr.off & CFO_NOFF_MASK) | ((uint64_t)(dbits >> 8) << 36) |
+           ((uint64_t)(uint32_t)min(nr.deg, (int32_t)CFO_NDEG_MAX) << 40) | ((uint64_t)((nr.flags & ROW_IRREGULAR) != 0) << 63);
   cfo[e] = o;
   if (esc) atomicAdd(escapes, 1ull);
 }

@@ -88,10 +88,22 @@ __device__ inline CfoEnt cfo_pick(const CfoEnt *row, int32_t deg, uint32_t m, un
   const uint32_t j = (uint32_t)(((uint64_t)m * (uint64_t)(uint32_t)deg) >> 24);
   CfoEnt e = load_cfo<NT>(row + j);
   reads = 1;
-  const uint32_t gd = e.cg >> 26;
-  int32_t k = (int32_t)j - (int32_t)gd;
+  const int32_t gd = cfo_delta(e.cg, e.link);
+  int32_t k;
+  if (gd == CFO_GD_SAT) {                       // delta beyond 12 bits: first k with c_k >= m by bisection (c is monotone)
+    int32_t lo = 0, hi = deg;
+    while (lo < hi) {
+      const int32_t mid = lo + ((hi - lo) >> 1);
+      const CfoEnt t = load_cfo<NT>(row + mid); ++reads;
+      if ((t.cg & 0xFFFFFFu) < m) lo = mid + 1; else hi = mid;
+    }
+    k = lo < deg ? lo : 0;                      // no crossing: edges.head (:24)
+    e = load_cfo<NT>(row + k); ++reads;
+    return e;
+  }
+  k = (int32_t)j - gd;
   if (gd) { e = load_cfo<NT>(row + k); ++reads; }
-  while ((e.cg & 0x3FFFFFFu) < m) {           // floor(cdf * 2^24) < m  <=>  cdf < p
+  while ((e.cg & 0xFFFFFFu) < m) {              // min(floor(cdf * 2^24), 2^24 - 1) < m  <=>  cdf < p
     ++k;
     if (k >= deg) { e = load_cfo<NT>(row); ++reads; break; }   // edges.head fallback (:24)
     e = load_cfo<NT>(row + k); ++reads;

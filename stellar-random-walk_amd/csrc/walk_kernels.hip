@@ -85,7 +85,7 @@ __global__ __launch_bounds__(TPB, MINW) void k_walk_first_order(GraphView g, con
           unsigned rd;
           const CfoEnt e = cfo_pick<NT>(g.cfo + r.off, r.deg, m, rd); reads += rd;
           val = e.id; ++len;
-          r.off = (int64_t)(e.link & 0xFFFFFFFFFFull); r.deg = (int32_t)((e.link >> 40) & 0x7FFFFFu);
+          r.off = (int64_t)(e.link & CFO_NOFF_MASK); r.deg = (int32_t)((e.link >> 40) & 0x7FFFFFu);
           r.flags = (e.link >> 63) ? ROW_IRREGULAR : 0u;
         } else {
           float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(TPB, MINW) void k_walk_first_order(GraphView g, con
             ++fb;
             if (COMPACT) {                                   // only the compact table exists: its links are valid for every row
               const CfoEnt ce = g.cfo[r.off + k];
-              e.id = ce.id; e.noff = (int64_t)(ce.link & 0xFFFFFFFFFFull); e.ndeg = (int32_t)((ce.link >> 40) & 0x7FFFFFu);
+              e.id = ce.id; e.noff = (int64_t)(ce.link & CFO_NOFF_MASK); e.ndeg = (int32_t)((ce.link >> 40) & 0x7FFFFFu);
               e.nflags = (ce.link >> 63) ? ROW_IRREGULAR : 0u;
             } else {
               e = g.fo[r.off + k];

@@ -473,12 +473,25 @@ def test_compact_lattice_records(eng, oracle):
     a = eng.walk(walk_length=20, num_walks=3, seed=5)
     rp, rl, _ = oracle.Graph.load(KARATE, directed=True).walk(walk_length=20, num_walks=3, seed=5)
     assert a[2]["record_bytes"] == 16 and np.array_equal(a[0], rp) and np.array_equal(a[1], rl)
-    s, d, w = rmat_lines(oracle, 13, edge_factor=16, weighted=True)                     # escapes -> exact records
+    # weighted rows: guide deltas of both signs, in the hundreds on hubs -> signed 12-bit deltas, still 16-byte records
+    s, d, w = rmat_lines(oracle, 13, edge_factor=16, weighted=True)
     eng.load_coo(s, d, w)
     gw = oracle.Graph.from_coo(s, d, w)
-    a = eng.walk(walk_length=12, seed=1)          # compact tried first, rejected, exact table from the slim temporaries
+    a = eng.walk(walk_length=12, seed=1)
     rp, rl, _ = gw.walk(walk_length=12, seed=1, threads=8)
-    assert a[2]["record_bytes"] == 32 and np.array_equal(a[0], rp) and np.array_equal(a[1], rl)
+    assert a[2]["record_bytes"] == 16 and np.array_equal(a[0], rp) and np.array_equal(a[1], rl)
+    b = eng.walk(walk_length=12, seed=1, compact=False)
+    assert b[2]["record_bytes"] == 32 and np.array_equal(b[0], rp)
+    # one hub whose weights make the guide delta overflow 12 bits (a long run of tiny weights, then heavy ones): the
+    # saturated entries are resolved by bisection
+    n = 30000
+    hs = np.zeros(n, np.int32); hd = np.arange(1, n + 1, dtype=np.int32)
+    hw = np.concatenate([np.full(n - 3000, 0.001, np.float32), np.full(3000, 50.0, np.float32)])
+    gh = oracle.Graph.from_coo(hs, hd, hw)
+    eng.load_coo(hs, hd, hw)
+    a = eng.walk(walk_length=6, num_walks=2, seed=3)
+    rp, rl, _ = gh.walk(walk_length=6, num_walks=2, seed=3, threads=8)
+    assert a[2]["record_bytes"] == 16 and np.array_equal(a[0], rp) and np.array_equal(a[1], rl)
     # table build orders: exact table first (constant-r call), compact derived from it on the next Philox call
     s, d, _ = rmat_lines(oracle, 12, edge_factor=16)
     g = oracle.Graph.from_coo(s, d, None)

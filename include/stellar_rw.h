@@ -123,7 +123,9 @@ enum {
   SRW_WALK_NO_EDGE_HASH = 64, /* Mode A: membership by binary search in the sorted rows instead of the edge hash set */
   SRW_WALK_NO_BINNED = 128,   /* Mode R, q != 1: never use the binned prefix-sum search (streaming scan instead) */
   SRW_WALK_DEVICE_FORMAT = 131072, /* srw_walk_and_save: the GPU formats the path text (path_format.hip); the host only writes it */
-  SRW_WALK_NO_HUB_BITMAPS = 65536 /* Mode R, q != 1: do not build / use the hub rows' neighbor-set bitmaps */
+  SRW_WALK_NO_HUB_BITMAPS = 65536, /* Mode R, q != 1: do not build / use the hub rows' neighbor-set bitmaps */
+  SRW_WALK_NO_EDGE_TABLES = 262144, /* Mode R, q != 1: do not build / use the per-edge bias tables */
+  SRW_WALK_EDGE_TABLES_ALL = 524288 /* test switch: a table for EVERY certified pair, chunks of 4 candidates */
   /* bits 12-14: test switch, force the binned search's membership strategy (1 = P1, 2 = P2, 3 = id-window,
      4 = hub bitmap where there is one); bit 15: test switch, binned search and hub bitmaps on rows of any degree
      (defaults: degree >= 128, hubs of degree >= 1024) */
@@ -141,7 +143,21 @@ typedef struct {
   double kernel_ms;     /* hipEvent time of the walk kernels of this call, on the handle's stream */
   int32_t kernel_kind;  /* 1 = first-order guide-table kernel, 2 = general second-order kernel, 3 = alias */
   int32_t record_bytes; /* bytes of one sampling-table record read by this kernel (16 compact / 32 / 0) */
+  int64_t strategy_steps[8]; /* general kernel: steps served by each sampler, indexed by SRW_STRAT_* */
+  int64_t edge_tables;       /* per-edge bias tables in use by this call (0: none built) */
+  int64_t edge_table_bytes;  /* HBM held by them */
+  double setup_ms;           /* host wall time this call spent building sampling tables before the first kernel */
 } srw_walk_stats;
+enum { /* srw_walk_stats.strategy_steps: which sampler of the general (second-order) kernel served a step */
+  SRW_STRAT_EDGE_TABLE = 0, /* precomputed per-edge bias table: search + one chunk */
+  SRW_STRAT_P1 = 1,         /* binned search, N(prev) looked up in the sorted N(curr) */
+  SRW_STRAT_P2 = 2,         /* binned search, candidates probed in the edge hash set / sorted N(prev) */
+  SRW_STRAT_W = 3,          /* binned search, sorted-chunk intersection */
+  SRW_STRAT_P3 = 4,         /* binned search, hub neighbor-set bitmap */
+  SRW_STRAT_SCAN = 5,       /* certified streaming scan (small rows, rows without a certificate, first steps) */
+  SRW_STRAT_PREFIX = 6,     /* q == 1: prefix-sum search with the return edges as a short list */
+  SRW_STRAT_CHAIN = 7       /* the reference's sequential f64 chain (irregular rows, draws on a CDF boundary) */
+};
 
 /* Replaces RandomWalk.randomWalk (M/algorithm/RandomWalk.scala:75-176) incl. initFirstStep (:51-66):
  * num_walks iterations, one walker per present vertex (ascending id), walker index =

@@ -27,6 +27,8 @@ WALK_NO_EDGE_HASH = 64
 WALK_NO_BINNED = 128
 WALK_NO_HUB_BITMAPS = 65536
 WALK_DEVICE_FORMAT = 131072
+WALK_NO_EDGE_TABLES = 262144
+WALK_EDGE_TABLES_ALL = 524288
 
 
 class SrwError(RuntimeError):
@@ -49,10 +51,16 @@ class WalkStats(C.Structure):
     _fields_ = [("n_walkers", C.c_int64), ("n_steps", C.c_int64), ("dead_ends", C.c_int64),
                 ("sum_deg_curr", C.c_int64), ("sum_deg_prev", C.c_int64), ("ent_reads", C.c_int64),
                 ("fallbacks", C.c_int64), ("trials", C.c_int64), ("kernel_ms", C.c_double), ("kernel_kind", C.c_int32),
-                ("record_bytes", C.c_int32)]
+                ("record_bytes", C.c_int32), ("strategy_steps", C.c_int64 * 8), ("edge_tables", C.c_int64),
+                ("edge_table_bytes", C.c_int64), ("setup_ms", C.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["strategy_steps"] = dict(zip(STRATEGIES, list(self.strategy_steps)))
+        return d
+
+
+STRATEGIES = ("edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain")   # SRW_STRAT_*
 
 
 # every symbol include/stellar_rw.h declares
@@ -296,14 +304,14 @@ class Engine:
     # ---- walk ----
     @staticmethod
     def params(p=1.0, q=1.0, walk_length=80, num_walks=1, first_walk=0, rng="philox", const_r=0.0, seed=42,
-               sampler=SAMPLER_REFERENCE, force_general=False, nt_loads=None, occ=0, compact=True, prefix=True, edge_hash=True, binned=True, binned_tune=0, hub_bitmaps=True, device_format=False):
+               sampler=SAMPLER_REFERENCE, force_general=False, nt_loads=None, occ=0, compact=True, prefix=True, edge_hash=True, binned=True, binned_tune=0, hub_bitmaps=True, device_format=False, edge_tables=True, edge_tables_all=False):
         if sampler == "alias":
             sampler = SAMPLER_ALIAS
         elif sampler == "reference":
             sampler = SAMPLER_REFERENCE
         return WalkParams(np.float32(p), np.float32(q), walk_length, num_walks, first_walk,
                           RNG_CONST if rng == "const" else RNG_PHILOX, np.float32(const_r), seed, sampler,
-                          (WALK_FORCE_GENERAL if force_general else 0) | (0 if nt_loads is None else WALK_NT_LOADS if nt_loads else WALK_CACHED_LOADS) | (occ << 8) | (0 if compact else WALK_NO_COMPACT) | (0 if prefix else WALK_NO_PREFIX) | (0 if edge_hash else WALK_NO_EDGE_HASH) | (0 if binned else WALK_NO_BINNED) | (0 if hub_bitmaps else WALK_NO_HUB_BITMAPS) | (WALK_DEVICE_FORMAT if device_format else 0) | (binned_tune << 12))
+                          (WALK_FORCE_GENERAL if force_general else 0) | (0 if nt_loads is None else WALK_NT_LOADS if nt_loads else WALK_CACHED_LOADS) | (occ << 8) | (0 if compact else WALK_NO_COMPACT) | (0 if prefix else WALK_NO_PREFIX) | (0 if edge_hash else WALK_NO_EDGE_HASH) | (0 if binned else WALK_NO_BINNED) | (0 if hub_bitmaps else WALK_NO_HUB_BITMAPS) | (WALK_DEVICE_FORMAT if device_format else 0) | (binned_tune << 12) | (0 if edge_tables else WALK_NO_EDGE_TABLES) | (WALK_EDGE_TABLES_ALL if edge_tables_all else 0))
 
     def walk(self, fetch=True, **kw):
         """Runs srw_walk.  Returns (paths [nWalkers, L+2] int32 (-1 tail), lens, stats dict) or just stats."""

@@ -49,6 +49,7 @@ void load_lines(srw_handle *h, const int32_t *src, const int32_t *dst, const flo
     vmin = std::min(vmin, std::min(src[i], dst[i]));
     vmax = std::max(vmax, std::max(src[i], dst[i]));
   }
+  check_id_range(vmin, vmax);                    // before any allocation that is proportional to the id range
   hipStream_t st = h->stream;
   DevBuf<int32_t> d_src, d_dst; DevBuf<float> d_w;
   d_src.alloc((size_t)n); d_dst.alloc((size_t)n);

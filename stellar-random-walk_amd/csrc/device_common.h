@@ -98,7 +98,13 @@ struct GraphView {
   const float *sw;      // weight of each sorted entry (same indexing as sids / sperm)
   const uint32_t *hub_bm;   // neighbor-set bitmaps of the hub rows (ordinal in Row::flags >> ROW_HUB_SHIFT, 0 = none)
   int64_t hub_words;        // 32-bit words per bitmap = ceil(n_slots / 32)
+  // per-edge bias tables of the current call's (p, q) (edge_tables.hip): entry e = (prev -> curr) owns
+  // eb_bins[eb_off[e] * 8 ..): exact chunk prefixes of the corrections of N(prev) ∩ N(curr) over curr's positions
+  const uint32_t *eb_off;   // [n_entries] offset in 64-byte units, EB_NONE = no table for this edge; null if not built
+  const double *eb_bins;
+  int32_t eb_min_sh;        // smallest chunk shift of a table (8: chunks of >= 256 candidates; tests use 2)
 };
+constexpr uint32_t EB_NONE = 0xFFFFFFFFu;
 
 // Philox4x32-10 (Random123).  Same constants as oracle/srw_oracle.c:orc_philox4x32_10.
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,

@@ -1,0 +1,279 @@
+// edge_tables.hip — per-edge bias tables for the second-order walk (gfx950).
+//
+// The reference recomputes computeSecondOrderWeights for every step (M/algorithm/RandomSample.scala:27-44): for the
+// step prev -> curr -> ? that is an intersection N(prev) ∩ N(curr), O(min(deg) log) at best, and on a power-law graph
+// the walk sits on hub -> hub pairs most of the time (≈40 K row elements per step at config 3).  The walk visits each
+// directed edge about numWalks * 1.3 times, so the intersection of a pair is worth computing ONCE per (p, q):
+//
+//   table(prev -> curr)[j] = sum over positions k < (j + 1) << csh of N(curr) of (w'_k - fl(w_k / q))       j < 64
+//
+// — the exact chunk prefixes of the corrections the binned search of sampling.h accumulates in LDS (same binned_fill,
+// same certificate: every such sum is exact in any order), at most 64 chunks per pair (one lane each in the search),
+// 512 B per pair.  A step over a pair with a table is then: 64 chunk ends compared in one wave instruction + ONE chunk
+// evaluated candidate by candidate (sampling.h:binned_resolve) — the same arithmetic, hence the same bits, as the
+// on-the-fly search.  Pairs are prioritised by the cost model of the on-the-fly strategies (binned_cost) and take what
+// HBM is left after every other structure; everything else keeps the on-the-fly path.
+//
+// This is north_star's "per-edge p/q-biased tables built by a CDNA4 kernel that stages neighbor lists in LDS" in the
+// only form that stays bit-identical to the reference's CDF inversion.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "engine.h"
+#include "sampling.h"
+
+namespace srw {
+namespace {
+
+constexpr int TPB = 256;
+constexpr int GRAB_SLOTS = 4;      // row slots per cursor grab of the selection passes
+constexpr int GRAB_ITEMS = 16;     // pairs per cursor grab of the build kernel (a single counter word saturates at ~88 atomics/us)
+
+struct EbSel {          // which pairs get a table
+  int32_t min_deg;      // of curr: shorter rows are cheap to evaluate whole
+  int64_t min_cost;     // wave-cycles by binned_cost: cheaper intersections stay on the fly
+  int32_t min_sh;       // smallest chunk shift
+  int32_t has_ehash, has_hub;
+};
+
+// 64-byte units of the table of pair (u -> v), 0 = no table.  cost_out: the model's cost of the pair (valid when the
+// pair qualifies on every other count).
+__device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s, int64_t &cost_out) {
+  cost_out = 0;
+  if (rv.deg < s.min_deg || !(rv.flags & ROW_PQ_OK) || ru.deg <= 0) return 0u;
+  const BinnedCost c = binned_cost(rv.deg, ru.deg, s.has_hub && (ru.flags >> ROW_HUB_SHIFT) != 0u, s.has_ehash != 0);
+  cost_out = c.c1 < c.c2 ? (c.c1 < c.cw ? c.c1 : c.cw) : (c.c2 < c.cw ? c.c2 : c.cw);
+  if (cost_out < s.min_cost) return 0u;
+  const BinGeom geo = bin_geometry(rv.deg, s.min_sh, EB_BINS);
+  return (uint32_t)((geo.n_bins + 7) >> 3);
+}
+
+__device__ inline int64_t grab_u64(unsigned long long *cursor, unsigned long long n) {
+  unsigned long long grab = 0;
+  if (lane_id() == 0) grab = atomicAdd(cursor, n);
+  return (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab));
+}
+
+// pass 1: table bytes per cost class (class = bit length of the cost), so that the host can fit a threshold to the budget
+__global__ __launch_bounds__(TPB) void k_eb_hist(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots,
+                                                 int32_t vmin, EbSel sel, unsigned long long *cursor,
+                                                 unsigned long long *hist /* [64][2]: units, pairs */) {
+  __shared__ unsigned long long lh[64][2];
+  if (threadIdx.x < 128) lh[threadIdx.x >> 1][threadIdx.x & 1] = 0ull;
+  __syncthreads();
+  const int lane = lane_id();
+  while (true) {
+    const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
+    if (v0 >= n_slots) break;
+    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < n_slots; ++u) {
+      const Row ru = rows[u];
+      for (int32_t k = lane; k < ru.deg; k += 64) {
+        const Row rv = rows[(int64_t)ent[ru.off + k].id - vmin];
+        int64_t cost;
+        const uint32_t un = eb_units(ru, rv, sel, cost);
+        if (un) {
+          const int cls = 64 - __clzll((unsigned long long)(cost | 1));   // 1 .. 63
+          atomicAdd(&lh[cls & 63][0], (unsigned long long)un);
+          atomicAdd(&lh[cls & 63][1], 1ull);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 128 && lh[threadIdx.x >> 1][threadIdx.x & 1])
+    atomicAdd(&hist[threadIdx.x], lh[threadIdx.x >> 1][threadIdx.x & 1]);
+}
+
+// pass 2: per row of prev, the units and the number of its pairs that get a table
+__global__ __launch_bounds__(TPB) void k_eb_rowsum(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots,
+                                                   int32_t vmin, EbSel sel, unsigned long long *cursor,
+                                                   unsigned long long *__restrict__ row_units,
+                                                   unsigned long long *__restrict__ row_pairs) {
+  const int lane = lane_id();
+  while (true) {
+    const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
+    if (v0 >= n_slots) break;
+    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < n_slots; ++u) {
+      const Row ru = rows[u];
+      unsigned long long un = 0, np = 0;
+      for (int32_t k = lane; k < ru.deg; k += 64) {
+        const Row rv = rows[(int64_t)ent[ru.off + k].id - vmin];
+        int64_t cost;
+        const uint32_t x = eb_units(ru, rv, sel, cost);
+        un += x; np += x ? 1u : 0u;
+      }
+      un = wave_sum_u64(un); np = wave_sum_u64(np);
+      if (lane == 0) { row_units[u] = un; row_pairs[u] = np; }
+    }
+  }
+}
+
+// pass 3: table offsets per entry + the work list (row slot of prev, position inside the row)
+__global__ __launch_bounds__(TPB) void k_eb_assign(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots,
+                                                   int32_t vmin, EbSel sel, unsigned long long *cursor,
+                                                   const unsigned long long *__restrict__ row_units,
+                                                   const unsigned long long *__restrict__ row_pairs,
+                                                   uint32_t *__restrict__ eb_off, uint2 *__restrict__ items) {
+  const int lane = lane_id();
+  while (true) {
+    const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
+    if (v0 >= n_slots) break;
+    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < n_slots; ++u) {
+      const Row ru = rows[u];
+      unsigned long long ubase = row_units[u], pbase = row_pairs[u];
+      for (int32_t base = 0; base < ru.deg; base += 64) {
+        const int32_t k = base + lane;
+        uint32_t x = 0;
+        if (k < ru.deg) {
+          const Row rv = rows[(int64_t)ent[ru.off + k].id - vmin];
+          int64_t cost;
+          x = eb_units(ru, rv, sel, cost);
+        }
+        uint32_t incl = x;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+        const unsigned long long has = __ballot(x != 0u);
+        if (k < ru.deg) eb_off[ru.off + k] = x ? (uint32_t)(ubase + incl - x) : EB_NONE;
+        if (x) items[pbase + (unsigned long long)__popcll(has & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)u, (uint32_t)k);
+        ubase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        pbase += (unsigned long long)__popcll(has);
+      }
+    }
+  }
+}
+
+// pass 4: the tables.  One wave per pair: binned_fill exactly as a walk step over that pair would run it, then the
+// prefix at every table chunk end goes to HBM.
+__global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
+                                                     float q, int32_t min_sh, const uint32_t *__restrict__ eb_off,
+                                                     double *__restrict__ eb_bins, unsigned long long *cursor,
+                                                     unsigned long long *strat_count /* [8] */) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][BINNED_LDS_WORDS];
+  const int lane = lane_id();
+  uint32_t *mine = lds[threadIdx.x >> 6];
+  Member tm; tm.mode = 0; tm.bm = mine; tm.seg_base = 0; tm.ehash = g.ehash; tm.ehash_mask = g.ehash_mask;
+  unsigned long long ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  while (true) {
+    const int64_t i0 = grab_u64(cursor, GRAB_ITEMS);
+    if (i0 >= n_items) break;
+    for (int64_t i = i0; i < i0 + GRAB_ITEMS && i < n_items; ++i) {
+      const uint2 it = items[i];
+      const Row ru = g.rows[it.x];
+      const int64_t e = ru.off + it.y;
+      const int32_t v = g.ent[e].id;
+      const Row rv = g.rows[(int64_t)v - g.vmin];
+      Bias b;
+      b.p = p; b.q = q; b.prev = (int32_t)((int64_t)it.x + g.vmin); b.second_order = true; b.need_member = true;
+      b.prev_sids = g.sids + ru.off; b.prev_deg = ru.deg; b.vmin = g.vmin; b.prev_hub = ru.flags >> ROW_HUB_SHIFT;
+      const BinGeom gc = bin_geometry(rv.deg, min_sh, EB_BINS);
+      const BinGeom gf = gc.csh < 6 ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
+      unsigned long long ab = 0; unsigned su = 0;
+      binned_fill(g, rv, b, mine, 0, gf, tm, ab, su);
+      ns[su & 7] += 1;
+      const double *bins = reinterpret_cast<const double *>(mine);
+      double *out = eb_bins + (size_t)eb_off[e] * 8;
+      const int up = gc.csh - gf.csh;
+      for (int32_t j = lane; j < gc.n_bins; j += 64) {
+        const int64_t fi = (((int64_t)j + 1) << up) - 1;
+        out[j] = bins[fi < gf.n_bins ? fi : gf.n_bins - 1];
+      }
+      __builtin_amdgcn_wave_barrier();          // the next fill clears the bins
+    }
+  }
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) if (ns[i]) atomicAdd(&strat_count[i], ns[i]);
+}
+
+size_t env_gb(const char *name, size_t dflt_gb) {
+  const char *e = getenv(name);
+  if (!e || !*e) return dflt_gb << 30;
+  return (size_t)(atof(e) * (double)((size_t)1 << 30));
+}
+
+}  // namespace
+
+void build_edge_tables(srw_handle *h, float p, float q, int mode) {
+  Graph &g = h->g;
+  uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);
+  if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode) return;
+  hipStream_t st = h->stream;
+  g.has_eb = false; g.eb_tables = 0; g.eb_bytes = 0; g.eb_build_ms = 0.0;
+  g.eb_bins.release();
+  if (!g.has_pq || !g.has_member || g.n_entries <= 0) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  EbSel sel;
+  sel.min_deg = mode ? 1 : 512; sel.min_sh = mode ? 2 : 8;
+  { const char *e = getenv("SRW_EB_MIN_COST"); sel.min_cost = mode ? 0 : (e && *e ? atoll(e) : 4096); }
+  sel.has_ehash = (g.has_ehash && g.use_ehash) ? 1 : 0; sel.has_hub = (g.has_hub && g.use_hub) ? 1 : 0;
+  g.eb_min_sh = sel.min_sh;
+  // budget: what is free now minus the offsets, the work list and a reserve for the walk's own buffers
+  size_t free_b = 0, total_b = 0;
+  SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+  free_b += g.eb_off.n * sizeof(uint32_t);
+  const size_t fixed = (size_t)g.n_entries * 4 + (size_t)g.n_slots * 16 + env_gb("SRW_EB_RESERVE_GB", 24);
+  if (free_b < fixed + ((size_t)64 << 20)) return;
+  size_t budget = std::min(env_gb("SRW_EB_BUDGET_GB", 128), (free_b - fixed) * 8 / 9);   // 1/9 of a table's bytes: its work-list item
+  const int blocks = h->n_cus * 8;
+  DevBuf<unsigned long long> cursor, hist, row_units, row_pairs;
+  cursor.alloc(1); hist.alloc(128);
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  SRW_HIP(hipMemsetAsync(hist.p, 0, 128 * 8, st));
+  hipLaunchKernelGGL(k_eb_hist, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p, hist.p);
+  SRW_HIP(hipGetLastError());
+  unsigned long long hh[128];
+  SRW_HIP(hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  // most expensive classes first while they fit (class c = costs in [2^(c-1), 2^c))
+  unsigned long long units = 0, pairs = 0;
+  int cls = 64;
+  while (cls > 1) {
+    const unsigned long long nu = units + hh[(cls - 1) * 2], np = pairs + hh[(cls - 1) * 2 + 1];
+    if (nu * 64 + np * 8 > budget || nu >= 0xFFFFFFF0ull) break;
+    units = nu; pairs = np; --cls;
+  }
+  if (pairs == 0) return;
+  if (cls > 1) sel.min_cost = std::max<int64_t>(sel.min_cost, (int64_t)1 << (cls - 1));
+  row_units.alloc((size_t)g.n_slots + 1); row_pairs.alloc((size_t)g.n_slots + 1);
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  hipLaunchKernelGGL(k_eb_rowsum, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p,
+                     row_units.p, row_pairs.p);
+  SRW_HIP(hipGetLastError());
+  {
+    size_t tb = 0;
+    SRW_HIP(rocprim::exclusive_scan(nullptr, tb, row_units.p, row_units.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
+    DevBuf<char> temp; temp.alloc(tb);
+    SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_units.p, row_units.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
+    SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_pairs.p, row_pairs.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
+    SRW_HIP(hipStreamSynchronize(st));
+  }
+  g.eb_off.ensure((size_t)g.n_entries);
+  g.eb_bins.alloc((size_t)units * 8);
+  DevBuf<uint2> items; items.alloc((size_t)pairs);
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  hipLaunchKernelGGL(k_eb_assign, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p,
+                     row_units.p, row_pairs.p, g.eb_off.p, items.p);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
+  g.has_eb = true; g.use_eb = true;             // the view the build kernel gets must not carry half-built tables: ...
+  GraphView gv = g.view();
+  gv.eb_off = nullptr;                          // ... binned_fill never reads them, and nothing else runs here
+  hipLaunchKernelGGL(k_eb_build, dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)pairs, p, q, sel.min_sh, g.eb_off.p,
+                     g.eb_bins.p, cursor.p, hist.p);
+  SRW_HIP(hipGetLastError());
+  unsigned long long sc[8];
+  SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  g.eb_pbits = pb; g.eb_qbits = qb; g.eb_mode = mode;
+  g.eb_tables = (int64_t)pairs; g.eb_bytes = (int64_t)(units * 64 + (unsigned long long)g.n_entries * 4);
+  g.eb_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (getenv("SRW_TIMING"))
+    fprintf(stderr, "[edge tables] %llu pairs, %.2f GB, min cost %lld, built in %.0f ms (P1 %llu, P2 %llu, W %llu, P3 %llu)\n", pairs,
+            (double)g.eb_bytes / 1e9, (long long)sel.min_cost, g.eb_build_ms, sc[1], sc[2], sc[3], sc[4]);
+}
+
+}  // namespace srw

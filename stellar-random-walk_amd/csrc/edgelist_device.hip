@@ -165,10 +165,13 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool w
     if (tokens != 2 && !(weighted && tokens == 3)) { munmap((void *)data, (size_t)size); return false; }
   }
   hipStream_t st = h->stream;
-  DevBuf<unsigned char> d_text; d_text.alloc((size_t)size);
+  struct Unmap { const unsigned char *p; size_t n; ~Unmap() { if (p) munmap((void *)p, n); } } unmap{data, (size_t)size};
+  DevBuf<unsigned char> d_text;
+  try { d_text.alloc((size_t)size); }
+  catch (const Error &) { return false; }        // no room for the text in HBM: the host tokenizer streams it instead
   hipError_t ce = hipMemcpyAsync(d_text.p, data, (size_t)size, hipMemcpyHostToDevice, st);
   if (ce == hipSuccess) ce = hipStreamSynchronize(st);
-  munmap((void *)data, (size_t)size);
+  munmap((void *)data, (size_t)size); unmap.p = nullptr;
   SRW_HIP(ce);
   const int64_t n_blocks = (size + BLOCK_BYTES - 1) / BLOCK_BYTES;
   DevBuf<uint32_t> blk, blkoff, flags; DevBuf<char> temp; DevBuf<int32_t> minmax;

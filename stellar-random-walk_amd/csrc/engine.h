@@ -88,6 +88,10 @@ struct Graph {
   int64_t hub_words = 0; int64_t n_hubs = 0; int32_t hub_min_deg = 0; bool has_hub = false, use_hub = false;
   DevBuf<uint64_t> ehash;         // Mode A: edge hash set (optional, built lazily when q != 1)
   uint64_t ehash_mask = 0; bool has_ehash = false; bool use_ehash = false;   // built / used by the current call
+  DevBuf<uint32_t> eb_off;        // [n_entries] per-edge bias tables (edge_tables.hip): offset of entry e's table, 64-B units
+  DevBuf<double> eb_bins;         // the tables
+  bool has_eb = false, use_eb = false; uint32_t eb_pbits = 0, eb_qbits = 0; int32_t eb_min_sh = 8, eb_mode = 0;
+  int64_t eb_tables = 0, eb_bytes = 0; double eb_build_ms = 0.0;
   DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
   bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
@@ -96,7 +100,8 @@ struct Graph {
   GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_cfo ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
-                     (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words}; }
+                     (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
+                     (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh}; }
 };
 
 struct WalkResult {
@@ -108,6 +113,7 @@ struct WalkResult {
 
 struct DevCounters {  // device-side accumulators, one 64-bit word each
   unsigned long long steps, dead_ends, sum_deg_curr, sum_deg_prev, ent_reads, fallbacks, owned_entries, trials;
+  unsigned long long strat[8];    // general kernel, steps per sampler: SRW_STRAT_* (include/stellar_rw.h)
 #ifdef SRW_PHASE_TIMING
   unsigned long long dbg[24];   // wave-time per phase of the general kernel, 100 MHz ticks >> 10 (tools/phase_timing.py)
 #endif
@@ -200,6 +206,7 @@ void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d
                          unsigned long long *d_len_bytes, unsigned long long *d_off, char *d_text);
 
 // ---- graph_build.hip ----
+void check_id_range(int32_t vmin, int32_t vmax);   // throws SRW_ERR_NOMEM when the dense slot tables cannot hold [vmin, vmax]
 // Lines already on the device (d_src/d_dst/d_w; d_w may be null = 1.0f).  Builds rows/ent/sids/verts.
 void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
                                    int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
@@ -216,6 +223,11 @@ void build_pq_tables(srw_handle *h, float p, float q);
 void build_alias_tables(srw_handle *h);
 void build_edge_hash(srw_handle *h);
 void build_hub_bitmaps(srw_handle *h, int32_t min_deg);   // graph_build.hip
+
+// ---- edge_tables.hip ----
+// Per-edge bias tables for the general kernel under (p, q): mode 0 = automatic (most expensive pairs first, within the
+// HBM budget), 1 = every certified pair (tests: tiny chunks, no cost threshold).  Needs build_pq_tables first.
+void build_edge_tables(srw_handle *h, float p, float q, int mode);
 
 // ---- walk_kernels.hip ----
 void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats);

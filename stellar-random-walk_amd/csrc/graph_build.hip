@@ -256,12 +256,33 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
 
 }  // namespace
 
+// Every per-vertex structure is dense over slot = id - vmin: the row table, the presence scan, the
+// optional owner table, hub bitmaps.  The reference keys vertices in a HashMap and takes any int32 ids; here a sparse id
+// space (two ids 2^31 apart) would need tens of GB for nothing, so it is refused up front with a clear message instead of
+// failing somewhere inside an allocation (documented deviation).
+void check_id_range(int32_t vmin, int32_t vmax) {
+  const int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
+  if (n_slots <= 0) throw Error(SRW_ERR_INVALID, "empty vertex id range");
+  size_t free_b = 0, total_b = 0;
+  const double per_slot = 48.0;                 // rows 16 B + presence/scan/sort temporaries + host mirrors
+  const double need = (double)n_slots * per_slot;
+  const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+  if (n_slots >= (int64_t)0xFFFFFFFEll || (have && need > 0.5 * (double)free_b)) {
+    char msg[320];
+    snprintf(msg, sizeof msg,
+             "vertex ids span [%d, %d] = %lld slots: the dense per-vertex tables would need %.1f GB (%.1f GB of HBM free). "
+             "This engine indexes vertices by id - min(id); renumber the ids compactly (the reference's HashMap-keyed GraphMap "
+             "has no such limit)", vmin, vmax, (long long)n_slots, need / 1e9, (double)free_b / 1e9);
+    throw Error(SRW_ERR_NOMEM, msg);
+  }
+}
+
 void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
                                    int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
                                    const int32_t *host_owner_tab) {
   if (n_lines <= 0) throw Error(SRW_ERR_INVALID, "empty edge list");
   int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
-  if (n_slots <= 0 || n_slots >= (int64_t)0xFFFFFFFEll) throw Error(SRW_ERR_INVALID, "vertex id range too large");
+  check_id_range(vmin, vmax);
   hipStream_t st = h->stream;
   Graph &g = h->g;
   g = Graph();
@@ -321,7 +342,7 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
   for (int64_t i = 0; i < n_rows; ++i) { vmin = std::min(vmin, vids[i]); vmax = std::max(vmax, vids[i]); }
   for (int64_t e = 0; e < n_ent_in; ++e) { vmin = std::min(vmin, ids[e]); vmax = std::max(vmax, ids[e]); }
   int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
-  if (n_slots >= (int64_t)0xFFFFFFFEll) throw Error(SRW_ERR_INVALID, "vertex id range too large");
+  check_id_range(vmin, vmax);
   std::vector<uint32_t> hkeys; std::vector<uint64_t> hvals; std::vector<uint32_t> hpresent((size_t)n_slots, 0u);
   hkeys.reserve((size_t)n_ent_in); hvals.reserve((size_t)n_ent_in);
   for (int64_t i = 0; i < n_rows; ++i) {

@@ -634,21 +634,41 @@ __device__ inline void wave_lower_bound_multi(LowerBound (&s)[K]) {
   }
 }
 
-// tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W, 4 = P3 if prev has a bitmap (tests force each one);
-// force_small: no minimum degree
-__device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
-                                           uint32_t *lds, float r, unsigned &fallback, unsigned &served, int tune,
-                                           bool force_small, Member &tm, unsigned long long &alg_bytes) {
-  if (!g.pq || !b.second_order || !b.need_member) return -1;
+// Chunking of a row's candidate positions: chunk j = positions [j << csh, (j + 1) << csh), at most `cap` chunks.
+struct BinGeom { int csh; int32_t n_bins; };
+__host__ __device__ inline BinGeom bin_geometry(int32_t deg, int min_sh, int cap) {
+  BinGeom g; g.csh = min_sh;
+  while ((((int64_t)deg + ((int64_t)1 << g.csh) - 1) >> g.csh) > cap) ++g.csh;
+  g.n_bins = (int32_t)(((int64_t)deg + ((int64_t)1 << g.csh) - 1) >> g.csh);
+  return g;
+}
+
+// Rough cost (wave-cycles) of finding N(prev) ∩ N(curr) with the cheapest membership strategy — the model the binned
+// search chooses its strategy with, and the one the per-edge tables (edge_tables.hip) are prioritised by.
+struct BinnedCost { int64_t c1, c2, cw; };
+__host__ __device__ inline int bit_length_i32(int32_t x) { int l = 0; while (l < 31 && ((int32_t)1 << l) <= x) ++l; return l; }   // 32 - clz(x | 1)
+__host__ __device__ inline BinnedCost binned_cost(int32_t deg, int32_t m, bool hubbits, bool ehash) {
+  const int lc = bit_length_i32(deg | 1), lp = bit_length_i32(m | 1);
+  BinnedCost c;
+  // a dependent probe chain ~ 10 cycles per level per element (5 with two in lockstep)
+  // per candidate: P3 = one bit read (a random sector, like the hash probe, but no hashing and no probe loop)
+  c.c1 = (int64_t)m * lc * 5; c.c2 = (int64_t)deg * (hubbits ? 3 : ehash ? 6 : lp) * 10;
+  c.cw = (int64_t)deg * 2 + (int64_t)m / 2 + 3000;      // ~2000 cycles per round of 256 / 1024 ids
+  return c;
+}
+
+// Fills the wave's LDS bins with the EXACT inclusive prefix, by chunk, of the corrections of the specials of this
+// (prev, curr) pair: bins[j] = sum over positions k < ((j + 1) << csh) of (w'_k - fl(w_k / q)).
+// tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W, 4 = P3 if prev has a bitmap (tests force each one)
+__device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias &b, uint32_t *lds, int tune,
+                                   const BinGeom geo, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used) {
   const int32_t deg = rc.deg;
-  if ((!force_small && deg < 128) || !(rc.flags & ROW_PQ_OK)) return -1;
   const int lane = lane_id();
   double *bins = reinterpret_cast<double *>(lds);
   uint32_t *win = lds + 2 * BIN_CAP;
   SRW_T0(tm);
-  int csh = 6;
-  while ((((int64_t)deg + ((int64_t)1 << csh) - 1) >> csh) > BIN_CAP) ++csh;
-  const int32_t n_bins = (int32_t)(((int64_t)deg + ((int64_t)1 << csh) - 1) >> csh);
+  const int csh = geo.csh;
+  const int32_t n_bins = geo.n_bins;
   for (int t = lane; t < n_bins; t += 64) bins[t] = 0.0;
   __builtin_amdgcn_wave_barrier();
   const Ent *row = g.ent + rc.off;
@@ -666,12 +686,8 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
   if (m > 0 && (strat == 0 || strat == 3)) {
     lo_id = max(cs[0], B[0]); hi_id = min(cs[deg - 1], B[m - 1]);
     if (strat == 0) {
-      const int lc = 32 - __clz(deg | 1), lp = 32 - __clz(m | 1);
-      // rough wave-cycles: a dependent probe chain ~ 10 cycles per level per element (5 with two in lockstep)
-      // per candidate: P3 = one bit read (a random sector, like the hash probe, but no hashing and no probe loop)
-      const int64_t c1 = (int64_t)m * lc * 5, c2 = (int64_t)deg * (hubbits ? 3 : g.ehash ? 6 : lp) * 10;
-      const int64_t cw = (int64_t)deg * 2 + (int64_t)m / 2 + 3000;      // ~2000 cycles per round of 256 / 1024 ids
-      strat = (cw < c1 && cw < c2) ? 3 : (c1 <= c2 ? 1 : (hubbits ? 4 : 2));
+      const BinnedCost bc = binned_cost(deg, m, hubbits != nullptr, g.ehash != nullptr);
+      strat = (bc.cw < bc.c1 && bc.cw < bc.c2) ? 3 : (bc.c1 <= bc.c2 ? 1 : (hubbits ? 4 : 2));
     }
   }
   int32_t ret_lo = deg, pa = 0, pb = 0;
@@ -745,7 +761,8 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
       for (int32_t k = lane; k < deg; k += 64) {
         const Ent e = row[k];
         if (e.id == b.prev) continue;
-        if (sorted_contains(B, m, (uint32_t)((int64_t)e.id - b.vmin)))
+        const uint32_t xs = (uint32_t)((int64_t)e.id - b.vmin);
+        if (g.ehash ? edge_exists(g.ehash, g.ehash_mask, xprev, xs) : sorted_contains(B, m, xs))
           atomicAdd(&bins[k >> csh], (double)e.w - (double)(e.w / q_));
       }
     } else {
@@ -860,6 +877,24 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
     for (int i = 0; i < PER; ++i) { const int j = lane * PER + i; if (j < n_bins) bins[j] = excl + loc[i]; }
     __builtin_amdgcn_wave_barrier();
   }
+  strat_used = (unsigned)strat;
+}
+
+// Given the exact inclusive chunk prefixes of the corrections (`bins`: the wave's LDS right after binned_fill, or the
+// (prev -> curr) edge's precomputed table in HBM, edge_tables.hip): 64-ary search over the chunk ends for the ONE chunk
+// holding the first not-certain-miss index, then that chunk candidate by candidate.  -1: not applicable.
+__device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, const Bias &b, const double *bins,
+                                         const BinGeom geo, float r, unsigned &fallback, unsigned &served, Member &tm) {
+  const int lane = lane_id();
+  const int32_t deg = rc.deg;
+  const int csh = geo.csh;
+  const int32_t n_bins = geo.n_bins;
+  const Ent *row = g.ent + rc.off;
+  const uint32_t *B = b.prev_sids;
+  const int32_t m = b.prev_deg;
+  const uint32_t xprev = (uint32_t)((int64_t)b.prev - b.vmin);
+  const float p_ = b.p, q_ = b.q;
+  const uint32_t *hubbits = (b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
   const double *PQ = g.pq + rc.off;
   const double S = PQ[deg - 1] + bins[n_bins - 1];
   if (!(S > 0.0)) return -1;
@@ -926,6 +961,28 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
   }
   fallback = 1;
   return wave_chain_pick(row, deg, b, r, S);
+}
+
+// force_small: no minimum degree.  strat_used: 1 = P1, 2 = P2, 3 = W, 4 = P3 (0 when the search does not apply).
+__device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
+                                           uint32_t *lds, float r, unsigned &fallback, unsigned &served, int tune,
+                                           bool force_small, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used) {
+  strat_used = 0;
+  if (!g.pq || !b.second_order || !b.need_member) return -1;
+  const int32_t deg = rc.deg;
+  if ((!force_small && deg < 128) || !(rc.flags & ROW_PQ_OK)) return -1;
+  const BinGeom geo = bin_geometry(deg, 6, BIN_CAP);
+  binned_fill(g, rc, b, lds, tune, geo, tm, alg_bytes, strat_used);
+  return binned_resolve(g, rc, b, reinterpret_cast<const double *>(lds), geo, r, fallback, served, tm);
+}
+
+// Per-edge bias table (edge_tables.hip): the chunk prefixes of this (prev -> curr) pair were computed once per (p, q)
+// by k_eb_build with the same binned_fill; the step is the search + one chunk, no intersection of the two rows.
+constexpr int EB_BINS = 64;                    // chunks per table: one lane each in the search
+__device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc, const Bias &b, const double *table,
+                                               float r, unsigned &fallback, unsigned &served, Member &tm) {
+  const BinGeom geo = bin_geometry(rc.deg, g.eb_min_sh, EB_BINS);
+  return binned_resolve(g, rc, b, table, geo, r, fallback, served, tm);
 }
 
 }  // namespace srw

@@ -14,6 +14,7 @@
 //                        owner(next) for the RCCL all-to-all.
 // No MFMA anywhere: integer/byte gather work bounded by HBM.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 
 #include "engine.h"
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
 #endif
   const int64_t stride = (int64_t)L + 2;
   unsigned long long steps = 0, degc = 0, degp = 0, fb = 0, dead = 0, fast = 0, srch = 0;
+  unsigned long long n_strat[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SRW_STRAT_*
   // Persistent waves: a walker costs anything from a few to millions of entry reads, and a block's LDS is only
   // released when its slowest wave ends — so every wave takes the next walker from a counter instead of owning one.
   while (true) {
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     if (lane == 0) path[0] = src;
     int32_t prev = src, curr = src, len = 1;
     Row rprev; rprev.off = 0; rprev.deg = 0; rprev.flags = 0;
+    int64_t eprev = 0;                               // entry index of the edge (prev -> curr) the walker arrived by
     for (int32_t s = 1; s <= L + 1; ++s) {
       const Row *rp = row_of(g, curr);
       Row r; r.off = 0; r.deg = 0; r.flags = 0;
@@ -182,19 +185,34 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
       // search over exact prefix sums: a short list of specials (return edges only) when q == 1, position bins else
       int32_t k = -1;
       bool binned_served = false;
-      if (!b.need_member || (tune & 16)) k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);
+      unsigned which = SRW_STRAT_SCAN;
+      // per-edge bias table of (prev -> curr), if this pair has one: search + one chunk, no intersection
+      if (g.eb_off && b.need_member && (r.flags & ROW_PQ_OK) && !(tune & 16)) {
+        const uint32_t eo = g.eb_off[eprev];
+        if (eo != EB_NONE) {
+          k = wave_pick_edge_table(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem);
+          if (k >= 0) { binned_served = true; which = SRW_STRAT_EDGE_TABLE; srch += 8ull * EB_BINS; }
+        }
+      }
+      if (k < 0 && (!b.need_member || (tune & 16))) {
+        k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);
+        if (k >= 0) which = SRW_STRAT_PREFIX;
+      }
       SRW_T1(mem, t_prefix);
       if (k < 0 && !(tune & 16)) {
-        k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 7, (tune & 8) != 0, mem, srch);
+        unsigned su = 0;
+        k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 7, (tune & 8) != 0, mem, srch, su);
         binned_served = k >= 0;                             // srch: bytes its membership strategy read (bench.py)
+        if (k >= 0) which = su == 1 ? SRW_STRAT_P1 : su == 2 ? SRW_STRAT_P2 : su == 4 ? SRW_STRAT_P3 : SRW_STRAT_W;
       }
       if (k < 0) { k = wave_pick_scan(g, r, b, mem, u, f); degc += (unsigned long long)r.deg; }
       else { fast += sv; }
+      n_strat[which] += 1; n_strat[SRW_STRAT_CHAIN] += f;
       int32_t next = g.ent[r.off + k].id;
       fb += f;
       if (b.need_member && !binned_served) degp += (unsigned long long)b.prev_deg;
       if (lane == 0) path[s] = next;
-      prev = curr; curr = next; ++len; rprev = r;
+      prev = curr; curr = next; ++len; rprev = r; eprev = r.off + k;
     }
     for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
     if (lane == 0) lens[wi] = len;
@@ -208,6 +226,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     if (fb) atomicAdd(&ctr->fallbacks, fb);
     if (fast) atomicAdd(&ctr->ent_reads, fast);      // general kernel: steps served by the prefix-sum search
     if (srch) atomicAdd(&ctr->trials, srch);         // ... and the bytes the binned ones' membership strategies read
+    for (int i = 0; i < 8; ++i) if (n_strat[i]) atomicAdd(&ctr->strat[i], n_strat[i]);
 #ifdef SRW_PHASE_TIMING
     const unsigned long long tv[10] = {wall_clock64() - t_begin, mem.t_prefix, mem.t_a, mem.t_p1, mem.t_p2, mem.t_w,
                                        mem.t_fin, mem.t_fill, mem.t_pass1, mem.t_pass2};
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(TPB, 4) void k_shard_step(GraphView g, const Walker
     unsigned f = 0, sv = 0;
     int32_t k = -1;                                  // same routing as k_walk_general
     if (!b.need_member) k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
-    else { unsigned long long ab = 0; k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem, ab); }
+    else { unsigned long long ab = 0; unsigned su = 0; k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem, ab, su); }
     if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
     int32_t next = g.ent[r.off + k].id;
     if (lane == 0) {
@@ -646,11 +665,15 @@ void read_counters(srw_handle *h, srw_walk_stats *stats) {
   stats->n_steps = (int64_t)c.steps; stats->dead_ends = (int64_t)c.dead_ends;
   stats->sum_deg_curr = (int64_t)c.sum_deg_curr; stats->sum_deg_prev = (int64_t)c.sum_deg_prev;
   stats->ent_reads = (int64_t)c.ent_reads; stats->fallbacks = (int64_t)c.fallbacks; stats->trials = (int64_t)c.trials;
+  for (int i = 0; i < 8; ++i) stats->strategy_steps[i] = (int64_t)c.strat[i];
+  stats->edge_tables = (h->g.has_eb && h->g.use_eb) ? h->g.eb_tables : 0;
+  stats->edge_table_bytes = (h->g.has_eb && h->g.use_eb) ? h->g.eb_bytes : 0;
 }
 
 void check_params(const srw_walk_params &P) {
   if (P.walk_length < 0) throw Error(SRW_ERR_INVALID, "walk_length must be >= 0");
-  if (P.num_walks < 1) throw Error(SRW_ERR_INVALID, "num_walks must be >= 1");
+  // --numWalks 0: the reference's `0 until numWalks` loop runs zero times and still writes an empty path/ + _SUCCESS
+  if (P.num_walks < 0) throw Error(SRW_ERR_INVALID, "num_walks must be >= 0");
   if (P.rng_mode != SRW_RNG_CONST && P.rng_mode != SRW_RNG_PHILOX) throw Error(SRW_ERR_INVALID, "bad rng_mode");
   if (P.sampler != SRW_SAMPLER_REFERENCE && P.sampler != SRW_SAMPLER_ALIAS) throw Error(SRW_ERR_INVALID, "bad sampler");
   if (P.sampler == SRW_SAMPLER_ALIAS && P.rng_mode != SRW_RNG_PHILOX)
@@ -755,6 +778,18 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool want_hub = general && P.q != 1.0f && h->cfg.world == 1 && !(P.flags & SRW_WALK_NO_HUB_BITMAPS);
   if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024);
   h->g.use_hub = want_hub;
+  // ... and, last (they take what HBM is left), the per-edge bias tables: the most expensive (prev, curr) pairs get
+  // their N(prev) ∩ N(curr) corrections precomputed once per (p, q) instead of once per visit
+  const bool want_eb = general && P.q != 1.0f && h->cfg.world == 1 && h->g.has_pq && !(P.flags & SRW_WALK_NO_EDGE_TABLES) &&
+                       !(P.flags & SRW_WALK_NO_BINNED);
+  if (want_eb) build_edge_tables(h, P.p, P.q, (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0);
+  h->g.use_eb = want_eb;
+}
+double timed_prepare_tables(srw_handle *h, const srw_walk_params &P) {   // builders synchronise the stream themselves
+  const auto t0 = std::chrono::steady_clock::now();
+  prepare_tables(h, P);
+  SRW_HIP(hipStreamSynchronize(h->stream));
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 }  // namespace
 
@@ -767,12 +802,12 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   const int64_t n_walkers = (int64_t)P.num_walks * g.n_vertices;
   if (n_walkers >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "more than 2^31 walkers in one call: lower num_walks");
   const int32_t stride = P.walk_length + 2;
-  if (n_walkers == 0) {   // empty graph: nothing to walk
+  if (n_walkers == 0) {   // empty graph or num_walks == 0: nothing to walk
     h->res.n_walkers = 0; h->res.stride = stride; h->res.valid = true;
     if (stats) { memset(stats, 0, sizeof(*stats)); }
     return;
   }
-  prepare_tables(h, P);
+  const double setup_ms = timed_prepare_tables(h, P);
   h->res.valid = false;
   h->res.paths.ensure((size_t)n_walkers * stride);
   h->res.lens.ensure((size_t)n_walkers);
@@ -788,7 +823,7 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats) {
   read_counters(h, s);
   float ms = 0.f;
   SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  s->kernel_ms = ms; s->n_walkers = n_walkers; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
+  s->kernel_ms = ms; s->setup_ms = setup_ms; s->n_walkers = n_walkers; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
   h->res.valid = true;
 }
 
@@ -803,8 +838,8 @@ void run_walk_to_host(srw_handle *h, const srw_walk_params &P, int32_t *paths, i
   const int64_t nv = g.n_vertices;
   if (nv >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "too many vertices");
   const int32_t stride = P.walk_length + 2;
-  if (nv == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return; }
-  prepare_tables(h, P);
+  if (nv == 0 || P.num_walks == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return; }
+  const double setup_ms = timed_prepare_tables(h, P);
   if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   for (int i = 0; i < 2; ++i) {
     h->stage_paths[i].ensure((size_t)nv * stride);
@@ -837,7 +872,7 @@ void run_walk_to_host(srw_handle *h, const srw_walk_params &P, int32_t *paths, i
   read_counters(h, s);
   float ms = 0.f;
   SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  s->kernel_ms = ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
+  s->kernel_ms = ms; s->setup_ms = setup_ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
 }
 
 // randomWalk + save fused and streamed (Main.doRandomWalk, M/Main.scala:53-62): the paths never exist as a whole on
@@ -853,8 +888,8 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   const int64_t nv = g.n_vertices;
   const int32_t stride = P.walk_length + 2;
   PathWriter writer(output_dir, n_parts, (int64_t)P.num_walks * nv, write_crc);   // fails first if <output>/path exists
-  if (nv == 0) { writer.close(); if (stats) memset(stats, 0, sizeof(*stats)); return; }
-  prepare_tables(h, P);
+  if (nv == 0 || P.num_walks == 0) { writer.close(); if (stats) memset(stats, 0, sizeof(*stats)); return; }   // empty part-00000 + _SUCCESS
+  const double setup_ms = timed_prepare_tables(h, P);
   if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   const size_t need = (size_t)nv * stride * 4;
   bool device_format = (P.flags & SRW_WALK_DEVICE_FORMAT) != 0;
@@ -949,7 +984,7 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
     read_counters(h, s);
     float ms = 0.f;
     SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    s->kernel_ms = ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
+    s->kernel_ms = ms; s->setup_ms = setup_ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
     return;
   }
   auto consume = [&](int32_t it) {      // host side of iteration `it`: wait for its slice, format + append
@@ -983,7 +1018,7 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   read_counters(h, s);
   float ms = 0.f;
   SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  s->kernel_ms = ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
+  s->kernel_ms = ms; s->setup_ms = setup_ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
 }
 
 void run_shard_seed(srw_handle *h, int32_t iter_in_call, Walker *d_out, int64_t *n_out, int32_t *d_paths,

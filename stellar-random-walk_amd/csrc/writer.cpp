@@ -186,9 +186,11 @@ PathWriter::PathWriter(const char *output_dir, int n_parts, int64_t total_walker
   mkdir(out.c_str(), 0777);  // the output root may exist
   p_->dir = out + "/path";
   if (mkdir(p_->dir.c_str(), 0777) != 0) {
+    const int err = errno;                       // before anything that may call malloc/free and clobber it
     std::string d = p_->dir;
     delete p_; p_ = nullptr;
-    if (errno == EEXIST) throw Error(SRW_ERR_EXISTS, "Output directory " + d + " already exists");
+    errno = err;
+    if (err == EEXIST) throw Error(SRW_ERR_EXISTS, "Output directory " + d + " already exists");
     throw Error(SRW_ERR_IO, "cannot create " + d + ": " + strerror(errno));
   }
 }

@@ -39,3 +39,15 @@ def random_multigraph(rng, n_vertices, n_lines, weighted, id_lo=0):
     if weighted:
         w = rng.choice(np.array([0.5, 1.0, 1.5, 2.0, 3.25, 7.0, 0.001, 1000.0], dtype=np.float32), size=n_lines)
     return ids[:, 0].copy(), ids[:, 1].copy(), w
+
+
+def rmat_weights_np(s, d, seed=42):
+    """Vectorised oracle.rmat_weight (oracle/srw_oracle.c:orc_rmat_weight): w = 1 + (mix32(min, max, seed) & 15)."""
+    a = np.minimum(s, d).astype(np.uint32)
+    b = np.maximum(s, d).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x = b * np.uint32(0x85EBCA77)
+        h = np.uint32(seed) ^ (a * np.uint32(0x9E3779B1)) ^ ((x << np.uint32(13)) | (x >> np.uint32(19)))
+        h ^= h >> np.uint32(16); h *= np.uint32(0x85EBCA6B); h ^= h >> np.uint32(13)
+        h *= np.uint32(0xC2B2AE35); h ^= h >> np.uint32(16)
+    return (np.uint32(1) + (h & np.uint32(15))).astype(np.float32)

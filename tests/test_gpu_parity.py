@@ -731,6 +731,89 @@ def test_binned_search_two_giant_hubs(eng, oracle):
             assert st["ent_reads"] > 0
 
 
+# ---- per-edge bias tables (edge_tables.hip): a (prev -> curr) pair's N(prev) ∩ N(curr) corrections precomputed --------
+@pytest.mark.parametrize("case", ["rmat12", "rmat12w", "rmat11wd", "rmat12f", "rmat12x", "multi", "multi_neg"])
+def test_edge_tables_every_pair(eng, oracle, case):
+    """Test switch edge_tables_all: a table for EVERY certified pair, chunks of 4 candidates — every second-order step of
+    a certified row goes through the table search; must equal the oracle (and the on-the-fly search) bit for bit."""
+    if case.startswith("rmat"):
+        sc = int(case[4:6])
+        weighted, directed = "w" in case[6:], case.endswith("d")
+        s, d, w = rmat_lines(oracle, sc, edge_factor=16, weighted=weighted)
+        if case.endswith("f"):
+            w = (0.5 + 1.5 * np.random.default_rng(4).random(len(s))).astype(np.float32)
+        if case.endswith("x"):      # hub rows fail the certificate: no tables for pairs that lead to them
+            w = (2.0 ** np.random.default_rng(5).integers(-20, 21, len(s))).astype(np.float32)
+    else:
+        rng = np.random.default_rng(11)
+        weighted, directed = True, False
+        s, d, w = random_multigraph(rng, 80, 900, True, id_lo=-30 if case == "multi_neg" else 3)
+    g = oracle.Graph.from_coo(s, d, w, directed=directed)
+    eng.load_coo(s, d, w, directed=directed)
+    for p, q in [(0.25, 4.0), (4.0, 0.5), (2.0, 2.0)]:
+        ref = g.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, threads=8)
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, edge_tables_all=True)
+        assert np.array_equal(lens, ref[1]) and np.array_equal(paths, ref[0]), (case, p, q)
+        assert st["edge_tables"] > 0 and st["strategy_steps"]["edge_table"] > 0, st
+        if not case.endswith("x"):   # nearly every second-order step of a certified row is a table step
+            assert st["strategy_steps"]["edge_table"] > 0.5 * st["n_steps"], st
+        off, _, st0 = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, edge_tables=False)
+        assert st0["edge_tables"] == 0 and st0["strategy_steps"]["edge_table"] == 0 and np.array_equal(off, ref[0])
+        for r in (0.5, 0.25, 0.999999):      # draws exactly on CDF boundaries
+            refc = g.walk(p=p, q=q, walk_length=8, rng="const", const_r=r, threads=8)
+            pc, lc, _ = eng.walk(p=p, q=q, walk_length=8, rng="const", const_r=r, edge_tables_all=True)
+            assert np.array_equal(pc, refc[0]) and np.array_equal(lc, refc[1]), (case, p, q, r)
+
+
+def test_edge_tables_selected_by_cost(eng, oracle):
+    """Default selection: only pairs whose intersection is expensive get a table — here the hub <-> hub double edge of
+    two 100 000-entry hubs sharing half of their leaves (chunks of 2048 candidates), not the hub <-> leaf pairs."""
+    n = 100000
+    leaves0 = np.arange(10, 10 + n, dtype=np.int32)
+    leaves1 = np.arange(10 + n // 2, 10 + n // 2 + n, dtype=np.int32)
+    s = np.concatenate([np.zeros(n, np.int32), np.ones(n, np.int32), [0, 0]]).astype(np.int32)
+    d = np.concatenate([leaves0, leaves1, [1, 1]]).astype(np.int32)
+    w = np.random.default_rng(3).integers(1, 9, len(s)).astype(np.float32)
+    g = oracle.Graph.from_coo(s, d, w)
+    eng.load_coo(s, d, w)
+    src = np.concatenate([[0, 1], leaves0[::7919], leaves1[::7877]]).astype(np.int32)
+    idx = np.searchsorted(eng.vertices(), src)
+    for p, q in [(0.25, 4.0), (4.0, 0.5)]:
+        rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=8, seed=29, threads=8)
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=8, seed=29)
+        assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl), (p, q)
+        assert st["edge_tables"] == 4, st             # 0 -> 1 twice, 1 -> 0 twice
+        assert st["strategy_steps"]["edge_table"] > 0, st
+        again, _, st2 = eng.walk(p=p, q=q, walk_length=8, seed=29)      # tables are reused, not rebuilt
+        assert np.array_equal(again, paths) and st2["setup_ms"] < st["setup_ms"] + 50.0
+    # a different (p, q) rebuilds them
+    rp, rl, _ = g.walk(sources=src, p=0.5, q=2.0, walk_length=8, seed=31, threads=8)
+    paths, lens, st = eng.walk(p=0.5, q=2.0, walk_length=8, seed=31)
+    assert np.array_equal(paths[idx], rp) and st["edge_tables"] == 4
+
+
+def test_giant_row_mass_certificate(eng, oracle):
+    """A row beyond 524 288 entries (the bound n * 2^(emax+1) would refuse it; the mass-based certificate accepts it):
+    hub 0 with 600 000 leaves + hub 1 sharing 50 000 of them; the searches must serve the hub steps."""
+    n0, n1 = 600000, 60000
+    leaves0 = np.arange(10, 10 + n0, dtype=np.int32)
+    leaves1 = np.arange(10 + n0 - 50000, 10 + n0 - 50000 + n1, dtype=np.int32)
+    s = np.concatenate([np.zeros(n0, np.int32), np.ones(n1, np.int32), [0]]).astype(np.int32)
+    d = np.concatenate([leaves0, leaves1, [1]]).astype(np.int32)
+    w = np.random.default_rng(8).integers(1, 17, len(s)).astype(np.float32)
+    g = oracle.Graph.from_coo(s, d, w)
+    eng.load_coo(s, d, w)
+    src = np.concatenate([[0, 1], leaves0[::59999], leaves1[::5999]]).astype(np.int32)
+    idx = np.searchsorted(eng.vertices(), src)
+    for p, q in [(0.25, 4.0), (4.0, 0.5)]:
+        rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=6, seed=77, threads=8)
+        for kw in ({}, {"edge_tables": False}, {"edge_tables": False, "hub_bitmaps": False}):
+            paths, lens, st = eng.walk(p=p, q=q, walk_length=6, seed=77, **kw)
+            assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl), (p, q, kw)
+            served = sum(st["strategy_steps"][k] for k in ("edge_table", "p1", "p2", "w", "p3"))
+            assert served > 0.4 * st["n_steps"], st     # every step that lands on a hub is served by a search, not the scan
+
+
 def test_randomized_differential_fuzz(eng):
     # ~8 s of tests/fuzz_parity.py: random multigraphs / hub graphs / RMATs, every sampler variant vs the CPU oracle
     import fuzz_parity

@@ -1,0 +1,80 @@
+"""GPU parity AT SCALE (GPU == oracle on RMAT-10..16 and beyond): weighted RMAT-16 and RMAT-20 generated on
+the device, the same graph rebuilt in the CPU oracle from the same (seed, edge index) stream, ~2 000 sampled walkers
+including the 20 highest-degree hubs compared BIT FOR BIT for the biased configs of BASELINE.json, with the DEFAULT
+strategy selection — hub bitmaps, the edge hash set, the per-edge bias tables and the on-the-fly searches must fire on
+their own (asserted through srw_walk_stats.strategy_steps)."""
+import numpy as np
+import pytest
+
+from helpers import pkg, rmat_weights_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = pkg().Engine(device=0)
+    yield e
+    e.close()
+
+
+def _sources(g, verts, n_sample, seed):
+    deg = np.array([g.degree(int(v)) for v in verts[:: max(1, len(verts) // 200000)]])   # sampled degrees are enough to find hubs
+    sub = verts[:: max(1, len(verts) // 200000)]
+    hubs = sub[np.argsort(-deg)[:20]]
+    rng = np.random.default_rng(seed)
+    rest = rng.choice(verts, size=n_sample, replace=False)
+    return np.unique(np.concatenate([hubs, rest])).astype(np.int32)
+
+
+@pytest.mark.parametrize("scale,n_sample,L", [(16, 2000, 40), (20, 1500, 24)])
+def test_weighted_rmat_biased_walks_equal_oracle(eng, oracle, scale, n_sample, L):
+    n_edges = 16 << scale
+    s, d = oracle.rmat_edges(scale, n_edges, seed=42)
+    w = rmat_weights_np(s, d, 42)
+    assert np.array_equal(w[:256], np.array([oracle.rmat_weight(a, b, 42) for a, b in zip(s[:256], d[:256])], dtype=np.float32))
+    g = oracle.Graph.from_coo(s, d, w, directed=False)
+    eng.generate_rmat(scale, n_edges, seed=42, weighted=True)          # same stream, generated on the device
+    assert eng.stats() == (g.num_vertices, g.num_entries)
+    verts = eng.vertices()
+    src = _sources(g, verts, n_sample, scale)
+    idx = np.searchsorted(verts, src)
+    hub = int(src[np.argmax([g.degree(int(v)) for v in src])])
+    ids, ws = eng.neighbors(hub)
+    oi, ow = g.neighbors(hub)
+    assert np.array_equal(ids, oi) and np.array_equal(ws, ow)            # neighbor order of the biggest row
+    for p, q in [(0.25, 4.0), (4.0, 0.5), (0.5, 1.0)]:
+        rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=L, seed=1234, threads=8)
+        # default strategy selection (per-edge tables on)
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=L, seed=1234)
+        assert np.array_equal(lens[idx], rl), (scale, p, q)
+        bad = np.nonzero((paths[idx] != rp).any(axis=1))[0]
+        assert bad.size == 0, (scale, p, q, int(src[bad[0]]), paths[idx][bad[0]], rp[bad[0]])
+        ss = st["strategy_steps"]
+        if q != 1.0:
+            assert st["edge_tables"] > 0 and ss["edge_table"] > 0, st
+            # without the tables the on-the-fly strategies carry the hub steps: they must fire on their own
+            paths2, lens2, st2 = eng.walk(p=p, q=q, walk_length=L, seed=1234, edge_tables=False)
+            assert np.array_equal(paths2, paths) and np.array_equal(lens2, lens)
+            s2 = st2["strategy_steps"]
+            assert s2["edge_table"] == 0 and s2["p1"] > 0 and (s2["p3"] > 0 or scale < 20) and s2["scan"] > 0, st2
+            if scale >= 20:
+                assert s2["w"] + s2["p2"] + s2["p3"] > 0, st2
+        else:
+            assert ss["prefix"] > 0 and st["edge_tables"] == 0, st
+
+
+def test_directed_rmat_biased_walk_equals_oracle(eng, oracle):
+    """Config 5's shape (directed, p = 4, q = .5) at RMAT-18 ef 27."""
+    scale, n_edges = 18, 27 << 18
+    s, d = oracle.rmat_edges(scale, n_edges, seed=7)
+    g = oracle.Graph.from_coo(s, d, None, directed=True)
+    eng.generate_rmat(scale, n_edges, seed=7, weighted=False, directed=True)
+    assert eng.stats() == (g.num_vertices, g.num_entries)
+    verts = eng.vertices()
+    src = _sources(g, verts, 1500, 5)
+    idx = np.searchsorted(verts, src)
+    rp, rl, _ = g.walk(sources=src, p=4.0, q=0.5, walk_length=40, seed=99, threads=8)
+    paths, lens, st = eng.walk(p=4.0, q=0.5, walk_length=40, seed=99)
+    assert np.array_equal(lens[idx], rl) and np.array_equal(paths[idx], rp)
+    assert st["edge_tables"] > 0 and st["strategy_steps"]["edge_table"] > 0, st

@@ -143,7 +143,7 @@ typedef struct {
   double kernel_ms;     /* hipEvent time of the walk kernels of this call, on the handle's stream */
   int32_t kernel_kind;  /* 1 = first-order guide-table kernel, 2 = general second-order kernel, 3 = alias */
   int32_t record_bytes; /* bytes of one sampling-table record read by this kernel (16 compact / 32 / 0) */
-  int64_t strategy_steps[8]; /* general kernel: steps served by each sampler, indexed by SRW_STRAT_* */
+  int64_t strategy_steps[12]; /* general kernel: steps served by each sampler, indexed by SRW_STRAT_* */
   int64_t edge_tables;       /* per-edge bias tables in use by this call (0: none built) */
   int64_t edge_table_bytes;  /* HBM held by them */
   double setup_ms;           /* host wall time this call spent building sampling tables before the first kernel */
@@ -156,7 +156,8 @@ enum { /* srw_walk_stats.strategy_steps: which sampler of the general (second-or
   SRW_STRAT_P3 = 4,         /* binned search, hub neighbor-set bitmap */
   SRW_STRAT_SCAN = 5,       /* certified streaming scan (small rows, rows without a certificate, first steps) */
   SRW_STRAT_PREFIX = 6,     /* q == 1: prefix-sum search with the return edges as a short list */
-  SRW_STRAT_CHAIN = 7       /* the reference's sequential f64 chain (irregular rows, draws on a CDF boundary) */
+  SRW_STRAT_CHAIN = 7,      /* the reference's sequential f64 chain (irregular rows, draws on a CDF boundary) */
+  SRW_STRAT_EDGE_MASK = 8   /* precomputed per-edge membership mask (rows up to 511 candidates): no lookup at all */
 };
 
 /* Replaces RandomWalk.randomWalk (M/algorithm/RandomWalk.scala:75-176) incl. initFirstStep (:51-66):

@@ -1,0 +1,167 @@
+/*
+ * stellar_rw_jni.c — JNI shim between the Scala host class au.csiro.data61.randomwalk.algorithm.HipRandomWalk
+ * (jni/HipRandomWalk.scala) and the C ABI of libstellar_rw.so (include/stellar_rw.h).
+ *
+ * Replaces, for `--cmd randomwalk`, the JVM-side implementations behind Main.doRandomWalk
+ * (randomwalk/src/main/scala/au/csiro/data61/randomwalk/Main.scala:53-62): UniformRandomWalk / VCutRandomWalk
+ * .loadGraph, RandomWalk.randomWalk (algorithm/RandomWalk.scala:75-176) and RandomWalk.save (:234-241).
+ *
+ * Build (needs a JDK; this image has none, so the file is only syntax-checked here against tests/jni_stub/jni.h):
+ *   make -C jni JAVA_HOME=/path/to/jdk
+ * Every C status other than SRW_OK becomes a Java exception whose class mirrors what the reference job would throw
+ * (INTEGRATION.md §5); no exception ever crosses the boundary in the other direction.
+ */
+#include <jni.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "stellar_rw.h"
+
+#define FN(name) Java_au_csiro_data61_randomwalk_algorithm_HipRandomWalk_##name
+
+static srw_handle *H(jlong h) { return (srw_handle *)(intptr_t)h; }
+
+/* status -> exception class of the reference's failure mode */
+static void throw_status(JNIEnv *env, int32_t rc, const srw_handle *h) {
+  const char *cls = "java/lang/RuntimeException";
+  switch (rc) {
+    case SRW_ERR_PARSE:   cls = "java/lang/NumberFormatException"; break;                         /* parts(0).toInt */
+    case SRW_ERR_EXISTS:  cls = "org/apache/hadoop/mapred/FileAlreadyExistsException"; break;     /* saveAsTextFile */
+    case SRW_ERR_IO:      cls = "java/io/IOException"; break;
+    case SRW_ERR_INVALID: cls = "java/lang/IllegalArgumentException"; break;
+    case SRW_ERR_NOMEM:   cls = "java/lang/OutOfMemoryError"; break;
+    default: break;                                                                               /* SRW_ERR_HIP */
+  }
+  jclass c = (*env)->FindClass(env, cls);
+  if (!c) { (*env)->ExceptionClear(env); c = (*env)->FindClass(env, "java/lang/RuntimeException"); }
+  if (c) (*env)->ThrowNew(env, c, srw_last_error(h));
+}
+
+static void fill_params(srw_walk_params *P, jfloat p, jfloat q, jint walkLength, jint numWalks, jint firstWalk,
+                        jboolean useConst, jfloat constR, jint seed, jint flags) {
+  memset(P, 0, sizeof *P);
+  P->p = p; P->q = q; P->walk_length = walkLength; P->num_walks = numWalks; P->first_walk = firstWalk;
+  P->rng_mode = useConst ? SRW_RNG_CONST : SRW_RNG_PHILOX; P->const_r = constR; P->seed = (uint32_t)seed;
+  P->sampler = SRW_SAMPLER_REFERENCE; P->flags = flags;
+}
+
+JNIEXPORT jlong JNICALL FN(create)(JNIEnv *env, jobject self, jint device) {
+  (void)self;
+  srw_config c; memset(&c, 0, sizeof c);
+  c.device = device; c.rank = 0; c.world = 1;
+  srw_handle *h = NULL;
+  const int32_t rc = srw_create(&c, &h);
+  if (rc != SRW_OK) { throw_status(env, rc, NULL); return 0; }
+  return (jlong)(intptr_t)h;
+}
+
+JNIEXPORT void JNICALL FN(destroy)(JNIEnv *env, jobject self, jlong h) {
+  (void)env; (void)self;
+  srw_destroy(H(h));
+}
+
+/* loadGraph(): returns (nVertices, nEdges) as the reference prints them (UniformRandomWalk.scala:69-72) */
+JNIEXPORT jlongArray JNICALL FN(loadEdgeList)(JNIEnv *env, jobject self, jlong hh, jstring path, jboolean directed,
+                                              jboolean weighted, jboolean partitioned, jint rddPartitions) {
+  (void)self;
+  const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+  if (!p) return NULL;
+  const int32_t rc = srw_load_edgelist(H(hh), p, directed, weighted, partitioned, rddPartitions);
+  (*env)->ReleaseStringUTFChars(env, path, p);
+  if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return NULL; }
+  int64_t nv = 0, ne = 0;
+  srw_graph_stats(H(hh), &nv, &ne);
+  jlong out[2]; out[0] = (jlong)nv; out[1] = (jlong)ne;
+  jlongArray a = (*env)->NewLongArray(env, 2);
+  if (a) (*env)->SetLongArrayRegion(env, a, 0, 2, out);
+  return a;
+}
+
+/* one walk iteration kept in HBM (RandomWalk.randomWalk's body for iteration `iteration`); returns the walk-steps */
+JNIEXPORT jlong JNICALL FN(walk)(JNIEnv *env, jobject self, jlong hh, jfloat p, jfloat q, jint walkLength,
+                                 jint iteration, jfloat constR, jboolean useConst, jint seed) {
+  (void)self;
+  srw_walk_params P; fill_params(&P, p, q, walkLength, 1, iteration, useConst, constR, seed, 0);
+  srw_walk_stats st;
+  const int32_t rc = srw_walk(H(hh), &P, &st);
+  if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return 0; }
+  return (jlong)st.n_steps;
+}
+
+/* RandomWalk.save of the last walk: <output>/path/part-* + _SUCCESS + Hadoop .crc side files */
+JNIEXPORT void JNICALL FN(writePaths)(JNIEnv *env, jobject self, jlong hh, jstring out, jint parts) {
+  (void)self;
+  const char *o = (*env)->GetStringUTFChars(env, out, NULL);
+  if (!o) return;
+  const int32_t rc = srw_write_paths(H(hh), o, parts, /*write_crc=*/1);
+  (*env)->ReleaseStringUTFChars(env, out, o);
+  if (rc != SRW_OK) throw_status(env, rc, H(hh));
+}
+
+/* Main.doRandomWalk fused and streamed (srw_walk_and_save, device-side formatter): returns the per-iteration
+ * "Zero Neighbors" counts (RandomWalk.scala:117,157) */
+JNIEXPORT jlongArray JNICALL FN(walkAndSave)(JNIEnv *env, jobject self, jlong hh, jfloat p, jfloat q, jint walkLength,
+                                             jint numWalks, jfloat constR, jboolean useConst, jint seed, jstring out,
+                                             jint parts) {
+  (void)self;
+  srw_walk_params P; fill_params(&P, p, q, walkLength, numWalks, 0, useConst, constR, seed, SRW_WALK_DEVICE_FORMAT);
+  const size_t n = numWalks > 0 ? (size_t)numWalks : 1;
+  int64_t *dead = (int64_t *)calloc(n, sizeof(int64_t));
+  if (!dead) { throw_status(env, SRW_ERR_NOMEM, NULL); return NULL; }
+  const char *o = (*env)->GetStringUTFChars(env, out, NULL);
+  if (!o) { free(dead); return NULL; }
+  const int32_t rc = srw_walk_and_save(H(hh), &P, o, parts, /*write_crc=*/1, NULL, dead);
+  (*env)->ReleaseStringUTFChars(env, out, o);
+  jlongArray a = NULL;
+  if (rc != SRW_OK) throw_status(env, rc, H(hh));
+  else {
+    a = (*env)->NewLongArray(env, numWalks > 0 ? numWalks : 0);
+    if (a && numWalks > 0) {
+      jlong *tmp = (jlong *)malloc(n * sizeof(jlong));
+      if (tmp) { for (size_t i = 0; i < n; ++i) tmp[i] = (jlong)dead[i]; (*env)->SetLongArrayRegion(env, a, 0, numWalks, tmp); free(tmp); }
+    }
+  }
+  free(dead);
+  return a;
+}
+
+/* paths of the last walk as a flat int[] of nWalkers * (walkLength + 2) ids (-1 padded) for callers that feed the
+ * embedding stage in-process; lens = path lengths */
+JNIEXPORT jintArray JNICALL FN(fetchPaths)(JNIEnv *env, jobject self, jlong hh, jintArray lensOut) {
+  (void)self;
+  int64_t nw = 0; int32_t stride = 0; void *dp = NULL, *dl = NULL;
+  int32_t rc = srw_device_paths(H(hh), &dp, &dl, &nw, &stride);
+  if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return NULL; }
+  if (nw * (int64_t)stride > 0x7FFFFFF0ll) { throw_status(env, SRW_ERR_NOMEM, H(hh)); return NULL; }
+  jintArray a = (*env)->NewIntArray(env, (jsize)(nw * stride));
+  if (!a) return NULL;
+  jint *paths = (jint *)(*env)->GetPrimitiveArrayCritical(env, a, NULL);
+  jint *lens = lensOut ? (jint *)(*env)->GetPrimitiveArrayCritical(env, lensOut, NULL) : NULL;
+  rc = paths ? srw_fetch_paths(H(hh), (int32_t *)paths, (int32_t *)lens) : SRW_ERR_NOMEM;
+  if (lens) (*env)->ReleasePrimitiveArrayCritical(env, lensOut, lens, 0);
+  if (paths) (*env)->ReleasePrimitiveArrayCritical(env, a, paths, 0);
+  if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return NULL; }
+  return a;
+}
+
+/* GraphMap.getNeighbors (algorithm/GraphMap.scala:109-120): null for an unknown vertex, else the ids in input order */
+JNIEXPORT jintArray JNICALL FN(neighbors)(JNIEnv *env, jobject self, jlong hh, jint v) {
+  (void)self;
+  int64_t n = 0;
+  int32_t rc = srw_graph_neighbors(H(hh), v, NULL, NULL, 0, &n);
+  if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return NULL; }
+  if (n < 0) return NULL;
+  jintArray a = (*env)->NewIntArray(env, (jsize)n);
+  if (!a || n == 0) return a;
+  jint *ids = (jint *)(*env)->GetPrimitiveArrayCritical(env, a, NULL);
+  rc = ids ? srw_graph_neighbors(H(hh), v, (int32_t *)ids, NULL, n, &n) : SRW_ERR_NOMEM;
+  if (ids) (*env)->ReleasePrimitiveArrayCritical(env, a, ids, 0);
+  if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return NULL; }
+  return a;
+}
+
+JNIEXPORT jstring JNICALL FN(version)(JNIEnv *env, jclass cls) {
+  (void)cls;
+  return (*env)->NewStringUTF(env, srw_version());
+}

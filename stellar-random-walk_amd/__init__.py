@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libstellar_rw.so")
+LIB_PATH = os.environ.get("SRW_LIB") or os.path.join(_DIR, "libstellar_rw.so")   # SRW_LIB: an instrumented build (tools/)
 CLI_PATH = os.path.join(_DIR, "stellar-rw")
 
 OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_HIP, ERR_EXISTS, ERR_NOMEM = range(7)
@@ -51,7 +51,7 @@ class WalkStats(C.Structure):
     _fields_ = [("n_walkers", C.c_int64), ("n_steps", C.c_int64), ("dead_ends", C.c_int64),
                 ("sum_deg_curr", C.c_int64), ("sum_deg_prev", C.c_int64), ("ent_reads", C.c_int64),
                 ("fallbacks", C.c_int64), ("trials", C.c_int64), ("kernel_ms", C.c_double), ("kernel_kind", C.c_int32),
-                ("record_bytes", C.c_int32), ("strategy_steps", C.c_int64 * 8), ("edge_tables", C.c_int64),
+                ("record_bytes", C.c_int32), ("strategy_steps", C.c_int64 * 12), ("edge_tables", C.c_int64),
                 ("edge_table_bytes", C.c_int64), ("setup_ms", C.c_double)]
 
     def as_dict(self):
@@ -60,7 +60,7 @@ class WalkStats(C.Structure):
         return d
 
 
-STRATEGIES = ("edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain")   # SRW_STRAT_*
+STRATEGIES = ("edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain", "edge_mask", "_9", "_10", "_11")   # SRW_STRAT_*
 
 
 # every symbol include/stellar_rw.h declares

@@ -103,6 +103,10 @@ struct GraphView {
   const uint32_t *eb_off;   // [n_entries] offset in 64-byte units, EB_NONE = no table for this edge; null if not built
   const double *eb_bins;
   int32_t eb_min_sh;        // smallest chunk shift of a table (8: chunks of >= 256 candidates; tests use 2)
+  // rows of curr with at most eb_mask_max candidates: eb_off[e] is the pair's membership mask itself (<= 32 candidates)
+  // or the offset, in 16-byte units, of its mask words in em_bits (bit k = candidate k of N(curr) is in N(prev))
+  const uint32_t *em_bits;
+  int32_t eb_mask_max;
 };
 constexpr uint32_t EB_NONE = 0xFFFFFFFFu;
 

@@ -5,7 +5,8 @@
 // the walk sits on hub -> hub pairs most of the time (≈40 K row elements per step at config 3).  The walk visits each
 // directed edge about numWalks * 1.3 times, so the intersection of a pair is worth computing ONCE per (p, q):
 //
-//   table(prev -> curr)[j] = sum over positions k < (j + 1) << csh of N(curr) of (w'_k - fl(w_k / q))       j < 64
+//   table(prev -> curr)[j] = A'_end(j) = sum over positions k < (j + 1) << csh of N(curr) of w'_k               j < 64
+//                          = PQ[end_j] + sum of (w'_k - fl(w_k / q))   (PQ: the row's exact prefix sums of fl(w / q))
 //
 // — the exact chunk prefixes of the corrections the binned search of sampling.h accumulates in LDS (same binned_fill,
 // same certificate: every such sum is exact in any order), at most 64 chunks per pair (one lane each in the search),
@@ -13,6 +14,11 @@
 // evaluated candidate by candidate (sampling.h:binned_resolve) — the same arithmetic, hence the same bits, as the
 // on-the-fly search.  Pairs are prioritised by the cost model of the on-the-fly strategies (binned_cost) and take what
 // HBM is left after every other structure; everything else keeps the on-the-fly path.
+//
+// Rows of at most 512 candidates get a second, smaller kind of table instead: the membership MASK of the pair (bit k =
+// "candidate k of N(curr) is in N(prev)", 4 .. 64 bytes; rows of at most 32 candidates keep it inline in the per-entry
+// offset word).  The step then needs no membership lookup at all (sampling.h:wave_pick_masked) — q-independent, but
+// rebuilt with the rest for simplicity.
 //
 // This is north_star's "per-edge p/q-biased tables built by a CDNA4 kernel that stages neighbor lists in LDS" in the
 // only form that stays bit-identical to the reference's CDF inversion.
@@ -34,21 +40,30 @@ constexpr int GRAB_SLOTS = 4;      // row slots per cursor grab of the selection
 constexpr int GRAB_ITEMS = 16;     // pairs per cursor grab of the build kernel (a single counter word saturates at ~88 atomics/us)
 
 struct EbSel {          // which pairs get a table
-  int32_t min_deg;      // of curr: shorter rows are cheap to evaluate whole
-  int64_t min_cost;     // wave-cycles by binned_cost: cheaper intersections stay on the fly
-  int32_t min_sh;       // smallest chunk shift
+  int32_t mask_max;     // rows of curr up to this many candidates: membership mask (0: none)
+  int32_t min_deg;      // bins tables: shortest row of curr
+  int64_t min_cost;     // bins tables: wave-cycles by binned_cost, cheaper intersections stay on the fly
+  int32_t min_sh;       // bins tables: smallest chunk shift
   int32_t has_ehash, has_hub;
 };
+constexpr int INLINE_MAX_DEG = 32;   // masks of rows up to 32 candidates live in eb_off[e] itself
 
-// 64-byte units of the table of pair (u -> v), 0 = no table.  cost_out: the model's cost of the pair (valid when the
-// pair qualifies on every other count).
-__device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s, int64_t &cost_out) {
-  cost_out = 0;
-  if (rv.deg < s.min_deg || !(rv.flags & ROW_PQ_OK) || ru.deg <= 0) return 0u;
+// Table of pair (u -> v): kind 0 = none, 1 = bins (64-byte units), 2 = mask (16-byte units), 3 = inline mask.
+// cost_out: the model's cost of the pair (bins tables: the priority under the HBM budget).
+__device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s, int64_t &cost_out, int &kind) {
+  cost_out = 0; kind = 0;
+  if (ru.deg <= 0 || rv.deg <= 0) return 0u;
+  if (rv.deg <= s.mask_max) {
+    if (rv.deg <= INLINE_MAX_DEG) { kind = 3; return 0u; }
+    kind = 2;
+    return (uint32_t)((((rv.deg + 31) >> 5) + 3) >> 2);
+  }
+  if (rv.deg < s.min_deg || !(rv.flags & ROW_PQ_OK)) return 0u;
   const BinnedCost c = binned_cost(rv.deg, ru.deg, s.has_hub && (ru.flags >> ROW_HUB_SHIFT) != 0u, s.has_ehash != 0);
   cost_out = c.c1 < c.c2 ? (c.c1 < c.cw ? c.c1 : c.cw) : (c.c2 < c.cw ? c.c2 : c.cw);
   if (cost_out < s.min_cost) return 0u;
   const BinGeom geo = bin_geometry(rv.deg, s.min_sh, EB_BINS);
+  kind = 1;
   return (uint32_t)((geo.n_bins + 7) >> 3);
 }
 
@@ -74,12 +89,15 @@ __global__ __launch_bounds__(TPB) void k_eb_hist(const Row *__restrict__ rows, c
       const Row ru = rows[u];
       for (int32_t k = lane; k < ru.deg; k += 64) {
         const Row rv = rows[(int64_t)ent[ru.off + k].id - vmin];
-        int64_t cost;
-        const uint32_t un = eb_units(ru, rv, sel, cost);
-        if (un) {
-          const int cls = 64 - __clzll((unsigned long long)(cost | 1));   // 1 .. 63
-          atomicAdd(&lh[cls & 63][0], (unsigned long long)un);
-          atomicAdd(&lh[cls & 63][1], 1ull);
+        int64_t cost; int kind;
+        const uint32_t un = eb_units(ru, rv, sel, cost, kind);
+        if (kind == 1) {
+          const int cls = 64 - __clzll((unsigned long long)(cost | 1));   // 1 .. 62
+          atomicAdd(&lh[cls < 62 ? cls : 62][0], (unsigned long long)un);
+          atomicAdd(&lh[cls < 62 ? cls : 62][1], 1ull);
+        } else if (kind == 2) {                                            // slot 63: the masks (all or nothing)
+          atomicAdd(&lh[63][0], (unsigned long long)un);
+          atomicAdd(&lh[63][1], 1ull);
         }
       }
     }
@@ -89,10 +107,11 @@ __global__ __launch_bounds__(TPB) void k_eb_hist(const Row *__restrict__ rows, c
     atomicAdd(&hist[threadIdx.x], lh[threadIdx.x >> 1][threadIdx.x & 1]);
 }
 
-// pass 2: per row of prev, the units and the number of its pairs that get a table
+// pass 2: per row of prev, the units (bins: 64 B, masks: 16 B) and the number of its pairs that get a table in HBM
 __global__ __launch_bounds__(TPB) void k_eb_rowsum(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots,
                                                    int32_t vmin, EbSel sel, unsigned long long *cursor,
                                                    unsigned long long *__restrict__ row_units,
+                                                   unsigned long long *__restrict__ row_munits,
                                                    unsigned long long *__restrict__ row_pairs) {
   const int lane = lane_id();
   while (true) {
@@ -100,23 +119,26 @@ __global__ __launch_bounds__(TPB) void k_eb_rowsum(const Row *__restrict__ rows,
     if (v0 >= n_slots) break;
     for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < n_slots; ++u) {
       const Row ru = rows[u];
-      unsigned long long un = 0, np = 0;
+      unsigned long long un = 0, mu = 0, np = 0;
       for (int32_t k = lane; k < ru.deg; k += 64) {
         const Row rv = rows[(int64_t)ent[ru.off + k].id - vmin];
-        int64_t cost;
-        const uint32_t x = eb_units(ru, rv, sel, cost);
-        un += x; np += x ? 1u : 0u;
+        int64_t cost; int kind;
+        const uint32_t x = eb_units(ru, rv, sel, cost, kind);
+        if (kind == 1) un += x; else if (kind == 2) mu += x;
+        np += (kind == 1 || kind == 2) ? 1u : 0u;
       }
-      un = wave_sum_u64(un); np = wave_sum_u64(np);
-      if (lane == 0) { row_units[u] = un; row_pairs[u] = np; }
+      un = wave_sum_u64(un); mu = wave_sum_u64(mu); np = wave_sum_u64(np);
+      if (lane == 0) { row_units[u] = un; row_munits[u] = mu; row_pairs[u] = np; }
     }
   }
 }
 
-// pass 3: table offsets per entry + the work list (row slot of prev, position inside the row)
+// pass 3: table offsets per entry + the work list (row slot of prev, position inside the row).  Rows of curr up to 32
+// candidates are not listed: k_eb_inline writes their masks into eb_off itself.
 __global__ __launch_bounds__(TPB) void k_eb_assign(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots,
                                                    int32_t vmin, EbSel sel, unsigned long long *cursor,
                                                    const unsigned long long *__restrict__ row_units,
+                                                   const unsigned long long *__restrict__ row_munits,
                                                    const unsigned long long *__restrict__ row_pairs,
                                                    uint32_t *__restrict__ eb_off, uint2 *__restrict__ items) {
   const int lane = lane_id();
@@ -125,22 +147,56 @@ __global__ __launch_bounds__(TPB) void k_eb_assign(const Row *__restrict__ rows,
     if (v0 >= n_slots) break;
     for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < n_slots; ++u) {
       const Row ru = rows[u];
-      unsigned long long ubase = row_units[u], pbase = row_pairs[u];
+      unsigned long long ubase = row_units[u], mbase = row_munits[u], pbase = row_pairs[u];
       for (int32_t base = 0; base < ru.deg; base += 64) {
         const int32_t k = base + lane;
-        uint32_t x = 0;
+        uint32_t x = 0; int kind = 0;
         if (k < ru.deg) {
           const Row rv = rows[(int64_t)ent[ru.off + k].id - vmin];
           int64_t cost;
-          x = eb_units(ru, rv, sel, cost);
+          x = eb_units(ru, rv, sel, cost, kind);
         }
-        uint32_t incl = x;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
-        const unsigned long long has = __ballot(x != 0u);
-        if (k < ru.deg) eb_off[ru.off + k] = x ? (uint32_t)(ubase + incl - x) : EB_NONE;
-        if (x) items[pbase + (unsigned long long)__popcll(has & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)u, (uint32_t)k);
-        ubase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t xb = kind == 1 ? x : 0u, xm = kind == 2 ? x : 0u, ib = xb, im = xm;
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t tb = (uint32_t)__shfl_up((int)ib, o), tm = (uint32_t)__shfl_up((int)im, o);
+          if (lane >= o) { ib += tb; im += tm; }
+        }
+        const bool listed = kind == 1 || kind == 2;
+        const unsigned long long has = __ballot(listed);
+        if (k < ru.deg && kind != 3)
+          eb_off[ru.off + k] = kind == 1 ? (uint32_t)(ubase + ib - xb) : kind == 2 ? (uint32_t)(mbase + im - xm) : EB_NONE;
+        if (listed) items[pbase + (unsigned long long)__popcll(has & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)u, (uint32_t)k);
+        ubase += (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+        mbase += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         pbase += (unsigned long long)__popcll(has);
+      }
+    }
+  }
+}
+
+// "x in N(u)?" for the mask builders: the hub bitmap of u, the edge hash set, or u's sorted row
+__device__ inline bool eb_member(const GraphView &g, const Row &ru, uint32_t uslot, uint32_t xs) {
+  const uint32_t hub = ru.flags >> ROW_HUB_SHIFT;
+  if (hub && g.hub_bm) return (g.hub_bm[(int64_t)(hub - 1) * g.hub_words + (xs >> 5)] >> (xs & 31)) & 1u;
+  if (g.ehash) return edge_exists(g.ehash, g.ehash_mask, uslot, xs);
+  return sorted_contains(g.sids + ru.off, ru.deg, xs);
+}
+
+// inline masks: one LANE per pair (u -> v) with deg(v) <= 32
+__global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, EbSel sel, unsigned long long *cursor, uint32_t *__restrict__ eb_off) {
+  const int lane = lane_id();
+  while (true) {
+    const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
+    if (v0 >= g.n_slots) break;
+    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < g.n_slots; ++u) {
+      const Row ru = g.rows[u];
+      for (int32_t k = lane; k < ru.deg; k += 64) {
+        const Row rv = g.rows[(int64_t)g.ent[ru.off + k].id - g.vmin];
+        if (rv.deg <= 0 || rv.deg > sel.mask_max || rv.deg > INLINE_MAX_DEG) continue;
+        uint32_t mask = 0u;
+        for (int32_t c = 0; c < rv.deg; ++c)
+          if (eb_member(g, ru, (uint32_t)u, (uint32_t)((int64_t)g.ent[rv.off + c].id - g.vmin))) mask |= 1u << c;
+        eb_off[ru.off + k] = mask;
       }
     }
   }
@@ -149,8 +205,8 @@ __global__ __launch_bounds__(TPB) void k_eb_assign(const Row *__restrict__ rows,
 // pass 4: the tables.  One wave per pair: binned_fill exactly as a walk step over that pair would run it, then the
 // prefix at every table chunk end goes to HBM.
 __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
-                                                     float q, int32_t min_sh, const uint32_t *__restrict__ eb_off,
-                                                     double *__restrict__ eb_bins, unsigned long long *cursor,
+                                                     float q, int32_t min_sh, int32_t mask_max, const uint32_t *__restrict__ eb_off,
+                                                     double *__restrict__ eb_bins, uint32_t *__restrict__ em_bits, unsigned long long *cursor,
                                                      unsigned long long *strat_count /* [8] */) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][BINNED_LDS_WORDS];
   const int lane = lane_id();
@@ -169,6 +225,18 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
       Bias b;
       b.p = p; b.q = q; b.prev = (int32_t)((int64_t)it.x + g.vmin); b.second_order = true; b.need_member = true;
       b.prev_sids = g.sids + ru.off; b.prev_deg = ru.deg; b.vmin = g.vmin; b.prev_hub = ru.flags >> ROW_HUB_SHIFT;
+      if (rv.deg <= mask_max) {                   // membership mask: 64 candidates per round, one probe each
+        uint32_t *out = em_bits + (size_t)eb_off[e] * 4;
+        const int32_t n_words = ((((rv.deg + 31) >> 5) + 3) >> 2) << 2;
+        for (int32_t c0 = 0; c0 < n_words * 32; c0 += 64) {
+          const int32_t c = c0 + lane;
+          const bool in = c < rv.deg && eb_member(g, ru, it.x, (uint32_t)((int64_t)g.ent[rv.off + c].id - g.vmin));
+          const unsigned long long mm = __ballot(in);
+          if (lane == 0) { out[c0 >> 5] = (uint32_t)mm; if ((c0 >> 5) + 1 < n_words) out[(c0 >> 5) + 1] = (uint32_t)(mm >> 32); }
+        }
+        ns[0] += 1;
+        continue;
+      }
       const BinGeom gc = bin_geometry(rv.deg, min_sh, EB_BINS);
       const BinGeom gf = gc.csh < 6 ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
       unsigned long long ab = 0; unsigned su = 0;
@@ -177,9 +245,11 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
       const double *bins = reinterpret_cast<const double *>(mine);
       double *out = eb_bins + (size_t)eb_off[e] * 8;
       const int up = gc.csh - gf.csh;
+      const double *PQ = g.pq + rv.off;            // the table keeps the complete numerator A'_end(j) = PQ[end_j] + corrections
       for (int32_t j = lane; j < gc.n_bins; j += 64) {
         const int64_t fi = (((int64_t)j + 1) << up) - 1;
-        out[j] = bins[fi < gf.n_bins ? fi : gf.n_bins - 1];
+        const int64_t ke = (((int64_t)j + 1) << gc.csh) - 1;
+        out[j] = PQ[ke < rv.deg ? ke : rv.deg - 1] + bins[fi < gf.n_bins ? fi : gf.n_bins - 1];
       }
       __builtin_amdgcn_wave_barrier();          // the next fill clears the bins
     }
@@ -202,23 +272,26 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode) return;
   hipStream_t st = h->stream;
   g.has_eb = false; g.eb_tables = 0; g.eb_bytes = 0; g.eb_build_ms = 0.0;
-  g.eb_bins.release();
+  g.eb_bins.release(); g.em_bits.release();
   if (!g.has_pq || !g.has_member || g.n_entries <= 0) return;
   const auto t0 = std::chrono::steady_clock::now();
   EbSel sel;
-  sel.min_deg = mode ? 1 : 512; sel.min_sh = mode ? 2 : 8;
-  { const char *e = getenv("SRW_EB_MIN_COST"); sel.min_cost = mode ? 0 : (e && *e ? atoll(e) : 4096); }
+  // mode 1 (tests): bins tables for every certified row, chunks of 4 candidates, no masks
+  sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
+  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : 8;
+  { const char *e = getenv("SRW_EB_MIN_COST"); sel.min_cost = (!mode && e && *e) ? atoll(e) : 0; }
+  { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
   sel.has_ehash = (g.has_ehash && g.use_ehash) ? 1 : 0; sel.has_hub = (g.has_hub && g.use_hub) ? 1 : 0;
   g.eb_min_sh = sel.min_sh;
-  // budget: what is free now minus the offsets, the work list and a reserve for the walk's own buffers
+  // budget: what is free now minus the offsets and a reserve for the walk's own buffers
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));
   free_b += g.eb_off.n * sizeof(uint32_t);
-  const size_t fixed = (size_t)g.n_entries * 4 + (size_t)g.n_slots * 16 + env_gb("SRW_EB_RESERVE_GB", 24);
+  const size_t fixed = (size_t)g.n_entries * 4 + (size_t)g.n_slots * 24 + env_gb("SRW_EB_RESERVE_GB", 24);
   if (free_b < fixed + ((size_t)64 << 20)) return;
-  size_t budget = std::min(env_gb("SRW_EB_BUDGET_GB", 128), (free_b - fixed) * 8 / 9);   // 1/9 of a table's bytes: its work-list item
+  size_t budget = std::min(env_gb("SRW_EB_BUDGET_GB", 128), free_b - fixed);
   const int blocks = h->n_cus * 8;
-  DevBuf<unsigned long long> cursor, hist, row_units, row_pairs;
+  DevBuf<unsigned long long> cursor, hist, row_units, row_munits, row_pairs;
   cursor.alloc(1); hist.alloc(128);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
   SRW_HIP(hipMemsetAsync(hist.p, 0, 128 * 8, st));
@@ -227,53 +300,70 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   unsigned long long hh[128];
   SRW_HIP(hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, st));
   SRW_HIP(hipStreamSynchronize(st));
-  // most expensive classes first while they fit (class c = costs in [2^(c-1), 2^c))
+  // the masks first (16 B units + 8 B per work-list item): cheap, and they serve every step into a short row
+  unsigned long long munits = hh[126], mpairs = hh[127];
+  if (munits * 16 + mpairs * 8 > budget || munits >= 0xFFFFFFF0ull) { sel.mask_max = 0; munits = 0; mpairs = 0; }
+  else budget -= munits * 16 + mpairs * 8;
+  // then the bins tables, most expensive classes first while they fit (class c = costs in [2^(c-1), 2^c))
   unsigned long long units = 0, pairs = 0;
-  int cls = 64;
+  int cls = 63;
   while (cls > 1) {
     const unsigned long long nu = units + hh[(cls - 1) * 2], np = pairs + hh[(cls - 1) * 2 + 1];
     if (nu * 64 + np * 8 > budget || nu >= 0xFFFFFFF0ull) break;
     units = nu; pairs = np; --cls;
   }
-  if (pairs == 0) return;
   if (cls > 1) sel.min_cost = std::max<int64_t>(sel.min_cost, (int64_t)1 << (cls - 1));
-  row_units.alloc((size_t)g.n_slots + 1); row_pairs.alloc((size_t)g.n_slots + 1);
+  if (pairs == 0) sel.min_deg = 0x7FFFFFFF;      // no bins tables at all
+  if (pairs + mpairs == 0 && sel.mask_max == 0) return;
+  row_units.alloc((size_t)g.n_slots + 1); row_munits.alloc((size_t)g.n_slots + 1); row_pairs.alloc((size_t)g.n_slots + 1);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
   hipLaunchKernelGGL(k_eb_rowsum, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p,
-                     row_units.p, row_pairs.p);
+                     row_units.p, row_munits.p, row_pairs.p);
   SRW_HIP(hipGetLastError());
   {
     size_t tb = 0;
     SRW_HIP(rocprim::exclusive_scan(nullptr, tb, row_units.p, row_units.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
     DevBuf<char> temp; temp.alloc(tb);
     SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_units.p, row_units.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
+    SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_munits.p, row_munits.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
     SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_pairs.p, row_pairs.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
     SRW_HIP(hipStreamSynchronize(st));
   }
+  const unsigned long long all_pairs = pairs + mpairs;
   g.eb_off.ensure((size_t)g.n_entries);
   g.eb_bins.alloc((size_t)units * 8);
-  DevBuf<uint2> items; items.alloc((size_t)pairs);
+  g.em_bits.alloc((size_t)munits * 4);
+  DevBuf<uint2> items; items.alloc((size_t)all_pairs);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
   hipLaunchKernelGGL(k_eb_assign, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p,
-                     row_units.p, row_pairs.p, g.eb_off.p, items.p);
+                     row_units.p, row_munits.p, row_pairs.p, g.eb_off.p, items.p);
   SRW_HIP(hipGetLastError());
-  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
-  SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
-  g.has_eb = true; g.use_eb = true;             // the view the build kernel gets must not carry half-built tables: ...
+  g.has_eb = true; g.use_eb = true; g.eb_mask_max = sel.mask_max;
   GraphView gv = g.view();
-  gv.eb_off = nullptr;                          // ... binned_fill never reads them, and nothing else runs here
-  hipLaunchKernelGGL(k_eb_build, dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)pairs, p, q, sel.min_sh, g.eb_off.p,
-                     g.eb_bins.p, cursor.p, hist.p);
-  SRW_HIP(hipGetLastError());
-  unsigned long long sc[8];
-  SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
+  gv.eb_off = nullptr;                          // the builders never read the tables they are writing
+  if (sel.mask_max > 0) {
+    SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+    hipLaunchKernelGGL(k_eb_inline, dim3(blocks), dim3(TPB), 0, st, gv, sel, cursor.p, g.eb_off.p);
+    SRW_HIP(hipGetLastError());
+  }
+  unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (all_pairs) {
+    SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+    SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
+    hipLaunchKernelGGL(k_eb_build, dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
+                       g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p);
+    SRW_HIP(hipGetLastError());
+    SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
+  }
   SRW_HIP(hipStreamSynchronize(st));
   g.eb_pbits = pb; g.eb_qbits = qb; g.eb_mode = mode;
-  g.eb_tables = (int64_t)pairs; g.eb_bytes = (int64_t)(units * 64 + (unsigned long long)g.n_entries * 4);
+  g.eb_tables = (int64_t)all_pairs;
+  g.eb_bytes = (int64_t)(units * 64 + munits * 16 + (unsigned long long)g.n_entries * 4);
   g.eb_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("SRW_TIMING"))
-    fprintf(stderr, "[edge tables] %llu pairs, %.2f GB, min cost %lld, built in %.0f ms (P1 %llu, P2 %llu, W %llu, P3 %llu)\n", pairs,
-            (double)g.eb_bytes / 1e9, (long long)sel.min_cost, g.eb_build_ms, sc[1], sc[2], sc[3], sc[4]);
+    fprintf(stderr, "[edge tables] %llu bins tables (%.2f GB, min cost %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
+            "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
+            sc[3], sc[4], mpairs, (double)munits * 16 / 1e9, (double)g.n_entries * 4 / 1e9, g.eb_build_ms);
 }
 
 }  // namespace srw

@@ -85,11 +85,13 @@ struct Graph {
   DevBuf<uint8_t> pq_ok;          // [n_slots]
   bool has_pq = false; uint32_t pq_pbits = 0, pq_qbits = 0;
   DevBuf<uint32_t> hub_bm;        // [n_hubs][hub_words] neighbor-set bitmaps of the highest-degree rows over the id slots
-  int64_t hub_words = 0; int64_t n_hubs = 0; int32_t hub_min_deg = 0; bool has_hub = false, use_hub = false;
+  int64_t hub_words = 0; int64_t n_hubs = 0; int32_t hub_min_deg = 0; size_t hub_budget_cap = 0; bool has_hub = false, use_hub = false;
   DevBuf<uint64_t> ehash;         // Mode A: edge hash set (optional, built lazily when q != 1)
   uint64_t ehash_mask = 0; bool has_ehash = false; bool use_ehash = false;   // built / used by the current call
   DevBuf<uint32_t> eb_off;        // [n_entries] per-edge bias tables (edge_tables.hip): offset of entry e's table, 64-B units
   DevBuf<double> eb_bins;         // the tables
+  DevBuf<uint32_t> em_bits;       // membership masks of the pairs whose curr row has 33 .. eb_mask_max candidates
+  int32_t eb_mask_max = 0;
   bool has_eb = false, use_eb = false; uint32_t eb_pbits = 0, eb_qbits = 0; int32_t eb_min_sh = 8, eb_mode = 0;
   int64_t eb_tables = 0, eb_bytes = 0; double eb_build_ms = 0.0;
   DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
@@ -101,7 +103,7 @@ struct Graph {
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
-                     (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh}; }
+                     (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max}; }
 };
 
 struct WalkResult {
@@ -113,9 +115,9 @@ struct WalkResult {
 
 struct DevCounters {  // device-side accumulators, one 64-bit word each
   unsigned long long steps, dead_ends, sum_deg_curr, sum_deg_prev, ent_reads, fallbacks, owned_entries, trials;
-  unsigned long long strat[8];    // general kernel, steps per sampler: SRW_STRAT_* (include/stellar_rw.h)
+  unsigned long long strat[12];   // general kernel, steps per sampler: SRW_STRAT_* (include/stellar_rw.h)
 #ifdef SRW_PHASE_TIMING
-  unsigned long long dbg[24];   // wave-time per phase of the general kernel, 100 MHz ticks >> 10 (tools/phase_timing.py)
+  unsigned long long dbg[40];   // wave-time per phase of the general kernel, 100 MHz ticks >> 10 (tools/phase_timing.py)
 #endif
 };
 
@@ -222,7 +224,7 @@ void build_pq_tables(srw_handle *h, float p, float q);
 // ---- alias_tables.hip ----
 void build_alias_tables(srw_handle *h);
 void build_edge_hash(srw_handle *h);
-void build_hub_bitmaps(srw_handle *h, int32_t min_deg);   // graph_build.hip
+void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap);   // graph_build.hip
 
 // ---- edge_tables.hip ----
 // Per-edge bias tables for the general kernel under (p, q): mode 0 = automatic (most expensive pairs first, within the

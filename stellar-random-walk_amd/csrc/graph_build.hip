@@ -464,16 +464,16 @@ __global__ void k_hub_fill(const Row *__restrict__ rows, const Ent *__restrict__
 // whose PREVIOUS vertex is such a hub tests "x in N(prev)" with one L2-resident bit read per candidate instead of
 // intersecting two sorted rows (sampling.h, strategy P3).  Steps land on a vertex in proportion to its degree, so a
 // few thousand bitmaps cover most second-order steps of a power-law graph.
-void build_hub_bitmaps(srw_handle *h, int32_t min_deg) {
+void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap) {
   Graph &g = h->g;
-  if (g.has_hub && g.hub_min_deg == min_deg) return;
+  if (g.has_hub && g.hub_min_deg == min_deg && g.hub_budget_cap == budget_cap) return;
   hipStream_t st = h->stream;
   g.has_hub = false; g.n_hubs = 0;
   const int64_t words = (g.n_slots + 31) / 32;
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));
   free_b += g.hub_bm.n * sizeof(uint32_t);                       // the previous set is released below
-  const size_t budget = std::min<size_t>((size_t)64 << 30, free_b > ((size_t)24 << 30) ? (free_b - ((size_t)24 << 30)) / 2 : 0);
+  const size_t budget = std::min<size_t>(budget_cap, free_b > ((size_t)24 << 30) ? (free_b - ((size_t)24 << 30)) / 2 : 0);
   int64_t max_hubs = (int64_t)(budget / ((size_t)words * 4));
   max_hubs = std::min<int64_t>(max_hubs, ((int64_t)1 << (32 - ROW_HUB_SHIFT)) - 2);
   // threshold = degree of the max_hubs-th largest row (device sort of the degrees), but never below min_deg
@@ -501,7 +501,7 @@ void build_hub_bitmaps(srw_handle *h, int32_t min_deg) {
   SRW_HIP(hipMemcpyAsync(&n, counter.p, 8, hipMemcpyDeviceToHost, st));
   SRW_HIP(hipStreamSynchronize(st));
   g.n_hubs = (int64_t)std::min<unsigned long long>(n, (unsigned long long)std::max<int64_t>(max_hubs, 0));
-  g.hub_words = words; g.hub_min_deg = min_deg;
+  g.hub_words = words; g.hub_min_deg = min_deg; g.hub_budget_cap = budget_cap;
   g.hub_bm.release();
   if (g.n_hubs > 0) {
     g.hub_bm.alloc((size_t)g.n_hubs * words);

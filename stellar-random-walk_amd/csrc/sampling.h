@@ -208,6 +208,7 @@ struct Member {
   unsigned long long t_a = 0, t_p1 = 0, t_p2 = 0, t_w = 0, t_fin = 0;
   unsigned long long t_w_lb = 0, t_w_ins = 0, t_w_la = 0, t_w_probe = 0, t_mark2;
   unsigned long long n_w = 0, n_w_elems = 0, n_w_windows = 0, n_p1 = 0, n_p1_elems = 0, n_binned = 0;
+  unsigned long long t_strat[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_step0 = 0;   // wave time per SRW_STRAT_* (whole step)
 #endif
 };
 #ifdef SRW_PHASE_TIMING
@@ -880,11 +881,48 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
   strat_used = (unsigned)strat;
 }
 
-// Given the exact inclusive chunk prefixes of the corrections (`bins`: the wave's LDS right after binned_fill, or the
-// (prev -> curr) edge's precomputed table in HBM, edge_tables.hip): 64-ary search over the chunk ends for the ONE chunk
+// Four edge-hash probes per lane in lockstep: the probe loads of one round are independent, so four candidates cost the
+// round trips of one.
+__device__ inline void edge_exists4(const uint64_t *tab, uint64_t mask, uint32_t row_slot, const uint32_t id_slot[4],
+                                    const bool want[4], bool out[4]) {
+  uint64_t key[4], s[4]; bool act[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    key[u] = ((uint64_t)row_slot << 32) | id_slot[u];
+    s[u] = edge_hash(key[u], mask); act[u] = want[u]; out[u] = false;
+  }
+  while (act[0] | act[1] | act[2] | act[3]) {
+    uint64_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = act[u] ? tab[s[u]] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (act[u]) {
+        if (v[u] == key[u]) { out[u] = true; act[u] = false; }
+        else if (v[u] == 0xFFFFFFFFFFFFFFFFull) act[u] = false;
+        else s[u] = (s[u] + 1) & mask;
+      }
+  }
+}
+
+// Given the exact inclusive chunk prefixes of the corrections: 64-ary search over the chunk ends for the ONE chunk
 // holding the first not-certain-miss index, then that chunk candidate by candidate.  -1: not applicable.
+//   ABS = false: `bins` is the wave's LDS right after binned_fill, bins[j] = corrections up to the end of chunk j
+//   ABS = true : `bins` is the (prev -> curr) edge's precomputed table in HBM (edge_tables.hip), which stores the
+//                complete numerator A'_end(j) = PQ[end_j] + corrections — the search then touches nothing but the
+//                table's 4 lines (64 scattered PQ reads otherwise), and inside the chunk
+//                A'_k = A'_end(jc-1) + (PQ[k] - PQ[k0-1]) + corrections of [k0, k]  (all exact under the certificate).
+// The table steps are bound by the number of memory requests they issue, so the membership probes of the chunk's
+// candidates — one random sector each — are avoided whenever the data allows it: a chunk whose corrections sum to
+// exactly zero holds neither a member nor a return edge (q > 1: all corrections are >= 0 ... the general case checks
+// |sum| only when all corrections of the pair have one sign, see `one_sign`), and a short N(prev) (<= 1024 ids) is
+// staged once in LDS and searched there.  Loads are batched: (1) S + the first search round, (2) 256 candidates'
+// entries and prefix sums (4 per lane), (3) their probes; the chosen candidate's id comes from the registers of the
+// lane that held it (id_out).
+template <bool ABS>
 __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, const Bias &b, const double *bins,
-                                         const BinGeom geo, float r, unsigned &fallback, unsigned &served, Member &tm) {
+                                         const BinGeom geo, float r, unsigned &fallback, unsigned &served, Member &tm,
+                                         int32_t &id_out, uint32_t *stage) {
   const int lane = lane_id();
   const int32_t deg = rc.deg;
   const int csh = geo.csh;
@@ -896,93 +934,233 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   const float p_ = b.p, q_ = b.q;
   const uint32_t *hubbits = (b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
   const double *PQ = g.pq + rc.off;
-  const double S = PQ[deg - 1] + bins[n_bins - 1];
+  auto chunk_end = [&](int32_t j) { const int64_t e = (((int64_t)j + 1) << csh) - 1; return (int32_t)(e < deg ? e : deg - 1); };
+  // round trip 1: everything the search needs first
+  int32_t lo = 0, hi = n_bins - 1;                 // the chunk of the first not-certain-miss index lies in [lo, hi]
+  int32_t j1 = hi >= 64 ? (int32_t)(((int64_t)hi * (lane + 1)) >> 6) : (lane <= hi ? lane : hi);   // lane 63 probes hi
+  const double b_last = bins[n_bins - 1];
+  double pq_last = 0.0, pq_j = 0.0, b_j = bins[j1];
+  if (!ABS) { pq_last = PQ[deg - 1]; pq_j = PQ[chunk_end(j1)]; }
+  const double S = pq_last + b_last;
   if (!(S > 0.0)) return -1;
   const double p = (double)r;
-  auto chunk_end = [&](int32_t j) { const int64_t e = (((int64_t)j + 1) << csh) - 1; return (int32_t)(e < deg ? e : deg - 1); };
-  auto not_miss_end = [&](int32_t j) {
-    const int32_t k = chunk_end(j);
-    const double X = (PQ[k] + bins[j]) / S;
+  auto not_miss = [&](int32_t k, double num) {
+    const double X = num / S;
     const double tol = (double)(k + 8) * 0x1p-51 * X;
     return !(X + tol < p);
   };
-  int32_t lo = 0, hi = n_bins - 1;                 // the chunk of the first not-certain-miss index lies in [lo, hi]
   while (hi - lo >= 64) {
-    const int64_t span = (int64_t)hi - lo;
-    const int32_t j = lo + (int32_t)((span * (lane + 1)) >> 6);          // lane 63 probes hi
-    const unsigned long long mm = __ballot(not_miss_end(j));
-    if (!mm) return 0;                              // even the last candidate is a certain miss -> edges.head
+    const unsigned long long mm = __ballot(not_miss(chunk_end(j1), pq_j + b_j));
+    if (!mm) { id_out = row[0].id; return 0; }      // even the last candidate is a certain miss -> edges.head
     const int f = __ffsll((long long)mm) - 1;
-    const int32_t jf = __builtin_amdgcn_readlane(j, f);
-    const int32_t jprev = f ? __builtin_amdgcn_readlane(j, f - 1) : lo - 1;
+    const int32_t jf = __builtin_amdgcn_readlane(j1, f);
+    const int32_t jprev = f ? __builtin_amdgcn_readlane(j1, f - 1) : lo - 1;
     hi = jf; lo = jprev + 1;
+    const int64_t span = (int64_t)hi - lo;
+    j1 = span >= 64 ? lo + (int32_t)((span * (lane + 1)) >> 6) : (lo + lane <= hi ? lo + lane : hi);
+    b_j = bins[j1];
+    if (!ABS) pq_j = PQ[chunk_end(j1)];
   }
   int32_t jc;
   {
-    const int32_t j = lo + lane;
-    const bool nm = j <= hi && not_miss_end(j);
+    const bool nm = lo + lane <= hi && not_miss(chunk_end(j1), pq_j + b_j);
     const unsigned long long mm = __ballot(nm);
-    if (!mm) return 0;
+    if (!mm) { id_out = row[0].id; return 0; }
     jc = lo + (__ffsll((long long)mm) - 1);
   }
-  // candidate-by-candidate evaluation of chunk jc
+  // candidate-by-candidate evaluation of chunk jc, 256 candidates per round
   const int32_t k0 = (int32_t)((int64_t)jc << csh), k1 = chunk_end(jc);
-  double carry = jc ? bins[jc - 1] : 0.0;
+  const double b_prev = jc ? bins[jc - 1] : 0.0, b_this = bins[jc];
+  // exact value of the numerator just before the chunk, and the exact sum of the chunk's corrections
+  double carry, pq_base = 0.0, chunk_corr;
+  if (ABS) {
+    pq_base = k0 ? PQ[k0 - 1] : 0.0;
+    carry = b_prev;                                          // A'_{k0-1}
+    chunk_corr = (b_this - b_prev) - (PQ[k1] - pq_base);
+  } else {
+    carry = b_prev;                                          // corrections before the chunk
+    chunk_corr = b_this - b_prev;
+  }
+  // q > 1 and p <= q: every correction (w - w/q for a member, w/p - w/q for a return edge) is >= 0; q < 1 and p >= q:
+  // every one is <= 0.  Then "the chunk's corrections sum to exactly 0" means "no special in the chunk".
+  const bool one_sign = (q_ > 1.0f && p_ <= q_) || (q_ < 1.0f && p_ >= q_);
+  const bool no_specials = one_sign && chunk_corr == 0.0;
+  // a short N(prev): staged in LDS once (sorted, padded to a power of two), searched there
+  int stage_levels = 0;
+  if (!no_specials && stage && !hubbits && m > 0 && m <= 1024) {
+    int P2 = 1; while (P2 < m) { P2 <<= 1; ++stage_levels; }
+    for (int32_t t = lane; t < P2; t += 64) stage[t] = t < m ? B[t] : 0xFFFFFFFFu;
+    if (stage_levels == 0) stage_levels = -1;               // m == 1: one compare, no search level
+    __builtin_amdgcn_wave_barrier();
+  }
   served = 1;
-  for (int32_t base = k0; base <= k1; base += 64) {
-    const int32_t k = base + lane;
-    const bool valid = k <= k1;
-    double corr = 0.0, pqk = 0.0;
-    if (valid) {
-      const Ent e = row[k];
-      pqk = PQ[k];
-      if (e.id == b.prev) corr = (double)(e.w / p_) - (double)(e.w / q_);
-      else {
-        const uint32_t xs = (uint32_t)((int64_t)e.id - b.vmin);
-        // one probe of the edge hash set (prev -> x) instead of a log2|N(prev)|-deep dependent search
-        const bool in = hubbits ? ((hubbits[xs >> 5] >> (xs & 31)) & 1u) != 0u
-                        : g.ehash ? edge_exists(g.ehash, g.ehash_mask, xprev, xs) : sorted_contains(B, m, xs);
-        if (in) corr = (double)e.w - (double)(e.w / q_);
-      }
+  for (int32_t base = k0; base <= k1; base += 256) {
+    Ent e[4]; double pqk[4]; bool valid[4], in[4], want[4]; uint32_t xs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int32_t k = base + u * 64 + lane;
+      valid[u] = k <= k1;
+      e[u].id = b.prev; e[u].w = 0.0f; pqk[u] = 0.0;
+      if (valid[u]) { e[u] = row[k]; pqk[u] = PQ[k]; }
     }
-    const double incl = wave_incl_scan_f64(corr);
-    const double X = (pqk + carry + incl) / S;
-    const double tol = (double)(k + 8) * 0x1p-51 * X;
-    const bool nm = valid && !(X + tol < p);
-    const bool hit = X - tol >= p;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xs[u] = (uint32_t)((int64_t)e[u].id - b.vmin); in[u] = false;
+      want[u] = !no_specials && valid[u] && e[u].id != b.prev;
+    }
+    if (no_specials) {
+    } else if (stage_levels) {
+      uint32_t pos[4] = {0u, 0u, 0u, 0u};
+      for (int st = stage_levels > 0 ? (1 << (stage_levels - 1)) : 0; st >= 1; st >>= 1) {
+        uint32_t probe[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) probe[u] = stage[pos[u] + st - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (probe[u] < xs[u]) pos[u] += st;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) in[u] = want[u] && stage[pos[u]] == xs[u];
+    } else if (hubbits) {
+      uint32_t wd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wd[u] = want[u] ? hubbits[xs[u] >> 5] : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) in[u] = (wd[u] >> (xs[u] & 31)) & 1u;
+    } else if (g.ehash) {
+      edge_exists4(g.ehash, g.ehash_mask, xprev, xs, want, in);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) in[u] = want[u] && sorted_contains(B, m, xs[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int32_t k = base + u * 64 + lane;
+      if (base + u * 64 > k1) break;                 // wave-uniform
+      double corr = 0.0;
+      if (valid[u] && !no_specials) {
+        if (e[u].id == b.prev) corr = (double)(e[u].w / p_) - (double)(e[u].w / q_);
+        else if (in[u]) corr = (double)e[u].w - (double)(e[u].w / q_);
+      }
+      const double incl = wave_incl_scan_f64(corr);
+      const double X = ((pqk[u] - pq_base) + carry + incl) / S;
+      const double tol = (double)(k + 8) * 0x1p-51 * X;
+      const bool nm = valid[u] && !(X + tol < p);
+      const bool hit = X - tol >= p;
+      const unsigned long long mm = __ballot(nm);
+      if (mm) {
+        const int f = __ffsll((long long)mm) - 1;
+        SRW_T1(tm, t_fin);
+        if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(e[u].id, f); return base + u * 64 + f; }
+        fallback = 1;
+        const int32_t kk = wave_chain_pick(row, deg, b, r, S);
+        id_out = row[kk].id;
+        return kk;
+      }
+      carry += readlane_f64(incl, 63);
+    }
+  }
+  fallback = 1;
+  const int32_t kk = wave_chain_pick(row, deg, b, r, S);
+  id_out = row[kk].id;
+  return kk;
+}
+
+// ---- rows of at most 512 candidates with a precomputed membership MASK of the (prev -> curr) pair ---------------------
+// (edge_tables.hip: bit k = "candidate k of N(curr) is in N(prev)".)  The whole row sits in registers (8 candidates per
+// lane), so the step is: one round trip for the mask + the row, then RandomSample.sample's certified evaluation — the
+// same arithmetic as wave_pick_scan (certified-exact parallel S, any-order scan of the quotients with the certain-miss
+// / certain-hit tolerance, the sequential chain otherwise) without a single membership lookup.
+constexpr int MASK_MAX_DEG = 512;
+__device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, const Bias &b, uint32_t inline_mask,
+                                           const uint32_t *words, float r, unsigned &fallback, int32_t &id_out) {
+  const int lane = lane_id();
+  const Ent *row = g.ent + rc.off;
+  const int32_t deg = rc.deg;
+  const int ni = (deg + 63) >> 6;                  // <= 8
+  float wv[8]; int32_t idv[8]; uint32_t mw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    mw[i] = 0u;
+    if (i < ni) mw[i] = words ? words[2 * i + (lane >> 5)] : ((i == 0 && lane < 32) ? inline_mask : 0u);
+  }
+  double part = 0.0;
+  SumCert cert;
+  bool neg = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int32_t k = i * 64 + lane;
+    wv[i] = 0.0f; idv[i] = 0;
+    if (i < ni && k < deg) {
+      const Ent e = row[k];
+      float w;
+      if (e.id == b.prev) w = e.w / b.p;
+      else if ((mw[i] >> (lane & 31)) & 1u) w = e.w;
+      else w = e.w / b.q;
+      wv[i] = w; idv[i] = e.id;
+      part += (double)w; cert.add(w); neg |= !(w >= 0.0f);
+    }
+  }
+  const int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
+  const bool bad = __any(cert.bad) || __any(neg);
+  if (bad || !sum_is_exact(emin, emax, false, deg)) {
+    unsigned f = 0;
+    const double Sc = wave_sum_exact_or_chain(row, deg, b, f);
+    fallback = 1;
+    const int32_t kk = wave_chain_pick(row, deg, b, r, Sc);
+    id_out = row[kk].id;
+    return kk;
+  }
+  const double S = wave_sum_f64(part);
+  const double p = (double)r;
+  double carry = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i >= ni) break;
+    const int32_t k = i * 64 + lane;
+    const bool valid = k < deg;
+    const double d = valid ? (double)wv[i] / S : 0.0;
+    const double incl = wave_incl_scan_f64(d);
+    const double acc = carry + incl;
+    const double tol = (double)(k + 1) * 0x1p-51 * acc;
+    const bool nm = valid && !(acc + tol < p);
+    const bool hit = acc - tol >= p;
     const unsigned long long mm = __ballot(nm);
     if (mm) {
       const int f = __ffsll((long long)mm) - 1;
-      SRW_T1(tm, t_fin);
-      if (__builtin_amdgcn_readlane((int)hit, f)) return base + f;
-      break;
+      if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(idv[i], f); return i * 64 + f; }
+      fallback = 1;                                 // within rounding distance of a boundary: exact chain
+      const int32_t kk = wave_chain_pick(row, deg, b, r, S);
+      id_out = row[kk].id;
+      return kk;
     }
     carry += readlane_f64(incl, 63);
   }
-  fallback = 1;
-  return wave_chain_pick(row, deg, b, r, S);
+  id_out = __builtin_amdgcn_readlane(idv[0], 0);   // edges.head (:24)
+  return 0;
 }
 
 // force_small: no minimum degree.  strat_used: 1 = P1, 2 = P2, 3 = W, 4 = P3 (0 when the search does not apply).
 __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
                                            uint32_t *lds, float r, unsigned &fallback, unsigned &served, int tune,
-                                           bool force_small, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used) {
+                                           bool force_small, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used,
+                                           int32_t &id_out) {
   strat_used = 0;
   if (!g.pq || !b.second_order || !b.need_member) return -1;
   const int32_t deg = rc.deg;
   if ((!force_small && deg < 128) || !(rc.flags & ROW_PQ_OK)) return -1;
   const BinGeom geo = bin_geometry(deg, 6, BIN_CAP);
   binned_fill(g, rc, b, lds, tune, geo, tm, alg_bytes, strat_used);
-  return binned_resolve(g, rc, b, reinterpret_cast<const double *>(lds), geo, r, fallback, served, tm);
+  return binned_resolve<false>(g, rc, b, reinterpret_cast<const double *>(lds), geo, r, fallback, served, tm, id_out, lds + 2 * BIN_CAP);
 }
 
 // Per-edge bias table (edge_tables.hip): the chunk prefixes of this (prev -> curr) pair were computed once per (p, q)
 // by k_eb_build with the same binned_fill; the step is the search + one chunk, no intersection of the two rows.
 constexpr int EB_BINS = 64;                    // chunks per table: one lane each in the search
 __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc, const Bias &b, const double *table,
-                                               float r, unsigned &fallback, unsigned &served, Member &tm) {
+                                               float r, unsigned &fallback, unsigned &served, Member &tm, int32_t &id_out,
+                                               uint32_t *lds) {
   const BinGeom geo = bin_geometry(rc.deg, g.eb_min_sh, EB_BINS);
-  return binned_resolve(g, rc, b, table, geo, r, fallback, served, tm);
+  return binned_resolve<true>(g, rc, b, table, geo, r, fallback, served, tm, id_out, lds + 2 * BIN_CAP);
 }
 
 }  // namespace srw

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
 #endif
   const int64_t stride = (int64_t)L + 2;
   unsigned long long steps = 0, degc = 0, degp = 0, fb = 0, dead = 0, fast = 0, srch = 0;
-  unsigned long long n_strat[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SRW_STRAT_*
+  unsigned long long n_strat[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // SRW_STRAT_*
   // Persistent waves: a walker costs anything from a few to millions of entry reads, and a block's LDS is only
   // released when its slowest wave ends — so every wave takes the next walker from a counter instead of owning one.
   while (true) {
@@ -173,42 +173,61 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     Row rprev; rprev.off = 0; rprev.deg = 0; rprev.flags = 0;
     int64_t eprev = 0;                               // entry index of the edge (prev -> curr) the walker arrived by
     for (int32_t s = 1; s <= L + 1; ++s) {
-      const Row *rp = row_of(g, curr);
-      Row r; r.off = 0; r.deg = 0; r.flags = 0;
-      if (rp) r = *rp;
+      // the step's first round trip: the row of curr and the (prev -> curr) pair's table word, issued together
+      const bool second = s > 1;
+      const int64_t cslot = (int64_t)curr - g.vmin;
+      const bool in_range = cslot >= 0 && cslot < g.n_slots;
+      const bool want_tab = g.eb_off && second && q != 1.0f && !(tune & 16);
+      Row r = g.rows[in_range ? cslot : 0];
+      uint32_t eo = EB_NONE;
+      if (want_tab) eo = g.eb_off[eprev];
+      if (!in_range) { r.off = 0; r.deg = 0; r.flags = 0; }
       if (r.deg == 0) { dead += s > 1; break; }
-      Bias b = make_bias(g, p, q, prev, s > 1);     // need_member: N(prev) from the membership structure ...
-      if (b.need_member) { b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT; }   // ... = last step's row here
+      Bias b;                                          // N(prev) = last step's row (whole-graph handle)
+      b.p = p; b.q = q; b.prev = prev; b.second_order = second; b.need_member = second && (q != 1.0f); b.vmin = g.vmin;
+      b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT;
       float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
       unsigned f = 0, sv = 0;
+#ifdef SRW_PHASE_TIMING
+      mem.t_step0 = wall_clock64();
+#endif
       SRW_T0(mem);
-      // search over exact prefix sums: a short list of specials (return edges only) when q == 1, position bins else
-      int32_t k = -1;
-      bool binned_served = false;
+      int32_t k = -1, next = 0;
+      bool binned_served = false, have_next = false;
       unsigned which = SRW_STRAT_SCAN;
-      // per-edge bias table of (prev -> curr), if this pair has one: search + one chunk, no intersection
-      if (g.eb_off && b.need_member && (r.flags & ROW_PQ_OK) && !(tune & 16)) {
-        const uint32_t eo = g.eb_off[eprev];
-        if (eo != EB_NONE) {
-          k = wave_pick_edge_table(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem);
-          if (k >= 0) { binned_served = true; which = SRW_STRAT_EDGE_TABLE; srch += 8ull * EB_BINS; }
+      if (want_tab) {
+        if (r.deg <= g.eb_mask_max) {
+          // membership mask of the pair (inline for rows up to 32 candidates): no lookup, the row sits in registers
+          if (r.deg <= 32 || eo != EB_NONE) {
+            k = wave_pick_masked(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
+            have_next = true; binned_served = true; which = SRW_STRAT_EDGE_MASK;
+            srch += 8ull * (unsigned long long)r.deg + 4ull * (unsigned long long)((r.deg + 31) >> 5);
+          }
+        } else if (eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
+          // chunk prefixes of the pair's corrections: search + one chunk, no intersection
+          k = wave_pick_edge_table(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, mem.bm);
+          if (k >= 0) { have_next = true; binned_served = true; which = SRW_STRAT_EDGE_TABLE; srch += 8ull * EB_BINS; }
         }
       }
+      // search over exact prefix sums: a short list of specials (return edges only) when q == 1, position bins else
       if (k < 0 && (!b.need_member || (tune & 16))) {
-        k = wave_pick_prefix(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv);
+        k = wave_pick_prefix(g, r, cslot, b, mem.bm, u, f, sv);
         if (k >= 0) which = SRW_STRAT_PREFIX;
       }
       SRW_T1(mem, t_prefix);
       if (k < 0 && !(tune & 16)) {
         unsigned su = 0;
-        k = wave_pick_binned(g, r, (int64_t)curr - g.vmin, b, mem.bm, u, f, sv, tune & 7, (tune & 8) != 0, mem, srch, su);
+        k = wave_pick_binned(g, r, cslot, b, mem.bm, u, f, sv, tune & 7, (tune & 8) != 0, mem, srch, su, next);
         binned_served = k >= 0;                             // srch: bytes its membership strategy read (bench.py)
-        if (k >= 0) which = su == 1 ? SRW_STRAT_P1 : su == 2 ? SRW_STRAT_P2 : su == 4 ? SRW_STRAT_P3 : SRW_STRAT_W;
+        if (k >= 0) { have_next = true; which = su == 1 ? SRW_STRAT_P1 : su == 2 ? SRW_STRAT_P2 : su == 4 ? SRW_STRAT_P3 : SRW_STRAT_W; }
       }
       if (k < 0) { k = wave_pick_scan(g, r, b, mem, u, f); degc += (unsigned long long)r.deg; }
       else { fast += sv; }
       n_strat[which] += 1; n_strat[SRW_STRAT_CHAIN] += f;
-      int32_t next = g.ent[r.off + k].id;
+      if (!have_next) next = g.ent[r.off + k].id;
+#ifdef SRW_PHASE_TIMING
+      mem.t_strat[which] += wall_clock64() - mem.t_step0 + (unsigned long long)(next & 0);   // (next: the id load is part of the step)
+#endif
       fb += f;
       if (b.need_member && !binned_served) degp += (unsigned long long)b.prev_deg;
       if (lane == 0) path[s] = next;
@@ -226,13 +245,14 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     if (fb) atomicAdd(&ctr->fallbacks, fb);
     if (fast) atomicAdd(&ctr->ent_reads, fast);      // general kernel: steps served by the prefix-sum search
     if (srch) atomicAdd(&ctr->trials, srch);         // ... and the bytes the binned ones' membership strategies read
-    for (int i = 0; i < 8; ++i) if (n_strat[i]) atomicAdd(&ctr->strat[i], n_strat[i]);
+    for (int i = 0; i < 12; ++i) if (n_strat[i]) atomicAdd(&ctr->strat[i], n_strat[i]);
 #ifdef SRW_PHASE_TIMING
     const unsigned long long tv[10] = {wall_clock64() - t_begin, mem.t_prefix, mem.t_a, mem.t_p1, mem.t_p2, mem.t_w,
                                        mem.t_fin, mem.t_fill, mem.t_pass1, mem.t_pass2};
     for (int i = 0; i < 10; ++i) atomicAdd(&ctr->dbg[i], tv[i] >> 10);
     atomicAdd(&ctr->dbg[10], mem.n_w); atomicAdd(&ctr->dbg[11], mem.n_w_elems); atomicAdd(&ctr->dbg[12], mem.n_w_windows);
     atomicAdd(&ctr->dbg[13], mem.n_p1); atomicAdd(&ctr->dbg[14], mem.n_p1_elems); atomicAdd(&ctr->dbg[15], mem.n_binned);
+    for (int i = 0; i < 12; ++i) atomicAdd(&ctr->dbg[24 + i], mem.t_strat[i] >> 10);
     atomicAdd(&ctr->dbg[16], mem.t_w_lb >> 10); atomicAdd(&ctr->dbg[17], mem.t_w_ins >> 10); atomicAdd(&ctr->dbg[18], mem.t_w_la >> 10); atomicAdd(&ctr->dbg[19], mem.t_w_probe >> 10);
 #endif
   }
@@ -490,7 +510,7 @@ __global__ __launch_bounds__(TPB, 4) void k_shard_step(GraphView g, const Walker
     unsigned f = 0, sv = 0;
     int32_t k = -1;                                  // same routing as k_walk_general
     if (!b.need_member) k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
-    else { unsigned long long ab = 0; unsigned su = 0; k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem, ab, su); }
+    else { unsigned long long ab = 0; unsigned su = 0; int32_t nid = 0; k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem, ab, su, nid); }
     if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
     int32_t next = g.ent[r.off + k].id;
     if (lane == 0) {
@@ -657,6 +677,14 @@ void read_counters(srw_handle *h, srw_walk_stats *stats) {
     for (int i = 0; i < 10; ++i) fprintf(stderr, " %s %.0f", nm[i], (double)c.dbg[i] * 1024.0 / 100e3);
     fprintf(stderr, "\n[phase] W calls %llu elems %llu windows %llu | P1 calls %llu elems %llu | binned steps %llu\n", c.dbg[10], c.dbg[11],
             c.dbg[12], c.dbg[13], c.dbg[14], c.dbg[15]);
+    {
+      static const char *sn[12] = {"edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain", "edge_mask", "-", "-", "-"};
+      fprintf(stderr, "[phase] per-strategy wave-ms (whole step) / steps / us per step:");
+      for (int i = 0; i < 12; ++i)
+        if (c.strat[i]) fprintf(stderr, " %s %.0f / %llu / %.2f", sn[i], (double)c.dbg[24 + i] * 1024.0 / 100e3, c.strat[i],
+                                (double)c.dbg[24 + i] * 1024.0 / 100.0 / (double)c.strat[i]);
+      fprintf(stderr, "\n");
+    }
     fprintf(stderr, "[phase] W detail wave-ms: wait-B %.0f clear+insert %.0f wait-A %.0f probe %.0f\n", (double)c.dbg[16] * 1024.0 / 100e3,
             (double)c.dbg[17] * 1024.0 / 100e3, (double)c.dbg[18] * 1024.0 / 100e3, (double)c.dbg[19] * 1024.0 / 100e3);
   }
@@ -665,7 +693,7 @@ void read_counters(srw_handle *h, srw_walk_stats *stats) {
   stats->n_steps = (int64_t)c.steps; stats->dead_ends = (int64_t)c.dead_ends;
   stats->sum_deg_curr = (int64_t)c.sum_deg_curr; stats->sum_deg_prev = (int64_t)c.sum_deg_prev;
   stats->ent_reads = (int64_t)c.ent_reads; stats->fallbacks = (int64_t)c.fallbacks; stats->trials = (int64_t)c.trials;
-  for (int i = 0; i < 8; ++i) stats->strategy_steps[i] = (int64_t)c.strat[i];
+  for (int i = 0; i < 12; ++i) stats->strategy_steps[i] = (int64_t)c.strat[i];
   stats->edge_tables = (h->g.has_eb && h->g.use_eb) ? h->g.eb_tables : 0;
   stats->edge_table_bytes = (h->g.has_eb && h->g.use_eb) ? h->g.eb_bytes : 0;
 }
@@ -776,12 +804,14 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   h->g.use_ehash = want_ehash;
   // neighbor-set bitmaps of the hub rows: the general kernel's "x in N(prev)" for steps that come from a hub
   const bool want_hub = general && P.q != 1.0f && h->cfg.world == 1 && !(P.flags & SRW_WALK_NO_HUB_BITMAPS);
-  if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024);
+  const bool want_eb = general && P.q != 1.0f && h->cfg.world == 1 && h->g.has_pq && !(P.flags & SRW_WALK_NO_EDGE_TABLES) &&
+                       !(P.flags & SRW_WALK_NO_BINNED);
+  // with per-edge tables the bitmaps only serve the tables' own construction and the probes of a located chunk: a
+  // quarter of the budget is plenty, the rest goes to the tables
+  if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, want_eb ? (size_t)16 << 30 : (size_t)64 << 30);
   h->g.use_hub = want_hub;
   // ... and, last (they take what HBM is left), the per-edge bias tables: the most expensive (prev, curr) pairs get
   // their N(prev) ∩ N(curr) corrections precomputed once per (p, q) instead of once per visit
-  const bool want_eb = general && P.q != 1.0f && h->cfg.world == 1 && h->g.has_pq && !(P.flags & SRW_WALK_NO_EDGE_TABLES) &&
-                       !(P.flags & SRW_WALK_NO_BINNED);
   if (want_eb) build_edge_tables(h, P.p, P.q, (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0);
   h->g.use_eb = want_eb;
 }

@@ -61,8 +61,11 @@ def run(budget=60.0, seed=1, eng=None, giant=False):
                 ref = g.walk(sources=src, threads=8, **kw)
             else:
                 ref = g.walk(threads=8, **kw)
-            variants = [dict(), dict(force_general=True), dict(binned_tune=8 | int(rng.integers(1, 5))), dict(hub_bitmaps=False), dict(binned=False),
-                        dict(prefix=False), dict(compact=False)]
+            # default = per-edge tables (masks for short rows, chunk prefixes for long ones); the on-the-fly strategies
+            # only run with the tables off
+            variants = [dict(), dict(force_general=True), dict(edge_tables_all=True), dict(edge_tables=False),
+                        dict(binned_tune=8 | int(rng.integers(1, 5)), edge_tables=False), dict(hub_bitmaps=False, edge_tables=False),
+                        dict(binned=False), dict(prefix=False), dict(compact=False)]
             for v in variants:
                 got = eng.walk(**kw, **v)
                 n_walks += 1

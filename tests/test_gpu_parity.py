@@ -691,21 +691,27 @@ def test_binned_search_all_strategies(eng, oracle, case):
     eng.load_coo(s, d, w, directed=directed)
     for p, q in [(0.25, 4.0), (4.0, 0.5), (2.0, 2.0)]:
         ref = g.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, threads=8)
-        for tune in BINNED_TUNES:
-            paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, binned_tune=tune)
+        for tune in BINNED_TUNES:      # the on-the-fly strategies: per-edge tables off
+            paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, binned_tune=tune, edge_tables=False)
             assert np.array_equal(lens, ref[1]) and np.array_equal(paths, ref[0]), (case, p, q, tune)
             if tune and not case.endswith("x"):
                 assert st["ent_reads"] > 0, "binned search was not exercised"
+                key = {1: "p1", 2: "p2", 3: "w", 4: "p3"}[tune & 7]
+                assert st["strategy_steps"][key] > 0 or (key == "p3" and st["strategy_steps"]["w"] + st["strategy_steps"]["p1"] > 0), st
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21)          # default: per-edge tables
+        assert np.array_equal(paths, ref[0]) and st["strategy_steps"]["edge_mask"] > 0, st
         paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, binned=False)
         assert np.array_equal(paths, ref[0])
-        paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, hub_bitmaps=False)
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=24, num_walks=2, seed=21, hub_bitmaps=False, edge_tables=False)
         assert np.array_equal(paths, ref[0])
         # draws exactly on CDF boundaries (constant r on the 2^-24 lattice)
         for r in (0.5, 0.25):
             refc = g.walk(p=p, q=q, walk_length=8, rng="const", const_r=r, threads=8)
             for tune in BINNED_TUNES:
-                pc, lc, _ = eng.walk(p=p, q=q, walk_length=8, rng="const", const_r=r, binned_tune=tune)
+                pc, lc, _ = eng.walk(p=p, q=q, walk_length=8, rng="const", const_r=r, binned_tune=tune, edge_tables=False)
                 assert np.array_equal(pc, refc[0]) and np.array_equal(lc, refc[1]), (case, p, q, tune, r)
+            pc, lc, _ = eng.walk(p=p, q=q, walk_length=8, rng="const", const_r=r)
+            assert np.array_equal(pc, refc[0]) and np.array_equal(lc, refc[1]), (case, p, q, "tables", r)
 
 
 def test_binned_search_two_giant_hubs(eng, oracle):
@@ -726,7 +732,7 @@ def test_binned_search_two_giant_hubs(eng, oracle):
     for p, q in [(0.25, 4.0), (4.0, 0.5)]:
         rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=8, seed=29, threads=8)
         for tune in (0, 3, 1, 4):
-            paths, lens, st = eng.walk(p=p, q=q, walk_length=8, seed=29, binned_tune=tune)
+            paths, lens, st = eng.walk(p=p, q=q, walk_length=8, seed=29, binned_tune=tune, edge_tables=False)
             assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl), (p, q, tune)
             assert st["ent_reads"] > 0
 
@@ -765,9 +771,10 @@ def test_edge_tables_every_pair(eng, oracle, case):
             assert np.array_equal(pc, refc[0]) and np.array_equal(lc, refc[1]), (case, p, q, r)
 
 
-def test_edge_tables_selected_by_cost(eng, oracle):
-    """Default selection: only pairs whose intersection is expensive get a table — here the hub <-> hub double edge of
-    two 100 000-entry hubs sharing half of their leaves (chunks of 2048 candidates), not the hub <-> leaf pairs."""
+def test_edge_tables_hubs_and_leaves(eng, oracle):
+    """Default selection on two 100 000-entry hubs sharing half of their leaves, joined by a double edge: every pair that
+    leads INTO a hub (leaf -> hub, hub -> hub) gets chunk prefixes (chunks of 2048 candidates), every pair that leads into
+    a leaf (1 .. 2 candidates) an inline membership mask."""
     n = 100000
     leaves0 = np.arange(10, 10 + n, dtype=np.int32)
     leaves1 = np.arange(10 + n // 2, 10 + n // 2 + n, dtype=np.int32)
@@ -782,14 +789,16 @@ def test_edge_tables_selected_by_cost(eng, oracle):
         rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=8, seed=29, threads=8)
         paths, lens, st = eng.walk(p=p, q=q, walk_length=8, seed=29)
         assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl), (p, q)
-        assert st["edge_tables"] == 4, st             # 0 -> 1 twice, 1 -> 0 twice
-        assert st["strategy_steps"]["edge_table"] > 0, st
+        assert st["edge_tables"] == 2 * n + 4, st     # every leaf -> hub entry, 0 -> 1 twice, 1 -> 0 twice
+        assert st["strategy_steps"]["edge_table"] > 0 and st["strategy_steps"]["edge_mask"] > 0, st
+        served = sum(st["strategy_steps"][k] for k in ("p1", "p2", "w", "p3"))
+        assert served == 0, st                         # nothing is left to the on-the-fly intersections
         again, _, st2 = eng.walk(p=p, q=q, walk_length=8, seed=29)      # tables are reused, not rebuilt
         assert np.array_equal(again, paths) and st2["setup_ms"] < st["setup_ms"] + 50.0
     # a different (p, q) rebuilds them
     rp, rl, _ = g.walk(sources=src, p=0.5, q=2.0, walk_length=8, seed=31, threads=8)
     paths, lens, st = eng.walk(p=0.5, q=2.0, walk_length=8, seed=31)
-    assert np.array_equal(paths[idx], rp) and st["edge_tables"] == 4
+    assert np.array_equal(paths[idx], rp) and st["edge_tables"] == 2 * n + 4
 
 
 def test_giant_row_mass_certificate(eng, oracle):

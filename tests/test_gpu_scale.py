@@ -52,7 +52,7 @@ def test_weighted_rmat_biased_walks_equal_oracle(eng, oracle, scale, n_sample, L
         assert bad.size == 0, (scale, p, q, int(src[bad[0]]), paths[idx][bad[0]], rp[bad[0]])
         ss = st["strategy_steps"]
         if q != 1.0:
-            assert st["edge_tables"] > 0 and ss["edge_table"] > 0, st
+            assert st["edge_tables"] > 0 and ss["edge_table"] > 0 and ss["edge_mask"] > 0, st
             # without the tables the on-the-fly strategies carry the hub steps: they must fire on their own
             paths2, lens2, st2 = eng.walk(p=p, q=q, walk_length=L, seed=1234, edge_tables=False)
             assert np.array_equal(paths2, paths) and np.array_equal(lens2, lens)

@@ -266,3 +266,23 @@ def test_tokenizer_fuzz_against_oracle(oracle, tmp_path):
             assert got[2].view(np.uint32).tolist() == want[2].view(np.uint32).tolist(), text
             assert got[3].tolist() == want[3].tolist(), text
     assert n_accept > 100 and n_reject > 100
+
+
+def test_jni_shim_syntax():
+    """jni/stellar_rw_jni.c (the binding the Scala host class jni/HipRandomWalk.scala loads) compiles cleanly against
+    include/stellar_rw.h and a hand-declared JNI subset (no JDK in this image); and every native
+    method the Scala class declares has its Java_..._HipRandomWalk_<name> definition in the shim."""
+    import re
+    import subprocess
+    jni = os.path.join(ROOT, "jni")
+    r = subprocess.run(["make", "-C", jni, "check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    scala = open(os.path.join(jni, "HipRandomWalk.scala")).read()
+    shim = open(os.path.join(jni, "stellar_rw_jni.c")).read()
+    natives = set(re.findall(r"@native\s+(?:private\s+)?def\s+(\w+)", scala))
+    defined = set(re.findall(r"FN\((\w+)\)\(JNIEnv", shim))
+    assert natives and natives <= defined, (natives - defined)
+    # every C-ABI function the shim calls is declared in the header
+    header = open(os.path.join(ROOT, "include", "stellar_rw.h")).read()
+    for fn in set(re.findall(r"\b(srw_\w+)\(", shim)):
+        assert re.search(r"\b%s\(" % fn, header), fn

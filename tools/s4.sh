@@ -1,0 +1,10 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/s4
+timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scale.py tests/test_mode_a.py -x -q -m gpu > gpurun_out/s4/pytest.txt 2>&1; tail -25 gpurun_out/s4/pytest.txt
+T=$GRAFT_REPO_ROOT/stellar-random-walk_amd/libstellar_rw_timing.so
+SRW_LIB=$T timeout 900 python tools/explore_edge_tables.py 24w 0.25 4 16 skip > gpurun_out/s4/t24w.txt 2>&1; cat gpurun_out/s4/t24w.txt
+timeout 900 python tools/explore_edge_tables.py 24w 0.25 4 16 skip > gpurun_out/s4/24w.txt 2>&1; cat gpurun_out/s4/24w.txt
+timeout 900 python tools/explore_edge_tables.py 24w 4 0.5 16 skip > gpurun_out/s4/24w_4_05.txt 2>&1; cat gpurun_out/s4/24w_4_05.txt
+timeout 600 python tools/explore_edge_tables.py 20 0.25 4 > gpurun_out/s4/20.txt 2>&1; cat gpurun_out/s4/20.txt
+timeout 1500 python tools/explore_edge_tables.py 26d 4 0.5 27 skip > gpurun_out/s4/c5.txt 2>&1; cat gpurun_out/s4/c5.txt

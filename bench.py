@@ -3,29 +3,38 @@
 
   python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
-Workload (BASELINE.json metric: "walk-steps/sec ... on 1B-edge RMAT"): RMAT scale-26, edge factor 16
+Headline workload (BASELINE.json metric: "walk-steps/sec ... on 1B-edge RMAT"): RMAT scale-26, edge factor 16
 (1.07 B edge lines -> 2.15 B adjacency entries, 32.8 M present vertices), undirected, p = q = 1,
 walkLength = 80, generated and built into CSR on the device (synthetic, seed 42).  One bench "step" = one walk
 iteration (numWalks = 1): one walker per present vertex, 81 walk-steps each = 2.66e9 walk-steps.
-Multi-GPU: the graph (≈72 GB with sampling tables) fits one 288 GB GPU, so it is replicated and the walk
-iterations are sharded across ranks with NO data-path collective (walkers are independent; the keyed Philox
-stream makes every path independent of which GPU computes it) -> "scaling": "weak" (each rank runs K
-iterations).  `--shard vertex` instead runs the vertex-sharded path with the per-super-step walker
-all-to-all (RCCL) that graphs beyond one GPU need.
+Timed region: K walk iterations, inputs (graph + sampling tables) resident in HBM, outputs (paths) left in HBM;
+barrier + torch.cuda.synchronize() on both sides; max over ranks.  Everything the timed region excludes is reported next
+to it: `setup_s` (graph generation + CSR build + sampling tables) and `end_to_end` (one iteration through
+srw_walk_and_save: walk + device formatter + PCIe + part files, text bytes per second).
 
-Timed region: K walk iterations, inputs resident in HBM, outputs (paths) left in HBM; barrier +
-torch.cuda.synchronize() on both sides; max over ranks.
+After the headline, with one GPU, `configs` carries the other BASELINE.json configurations that fit one GPU — C2
+(RMAT-20, p = q = 1), C3 (weighted RMAT-24, p = .25 q = 4; Mode R = bit-exact reference sampler, and Mode A = alias tables
++ rejection), C5's stand-in (directed RMAT-26 ef 27, p = 4 q = .5; Mode R and Mode A) — each with its own value, kernel
+time, setup and roofline.
+
+Multi-GPU (`--gpus N` under torch.distributed.run): `value` is the replicated mode (the graph fits one 288 GB GPU, so
+it is replicated and the walk iterations are sharded across ranks with NO data-path collective; "scaling": "weak"),
+and `vertex_sharded` reports north_star's split next to it (graph sharded by source vertex, walkers exchanged by an
+RCCL all-to-all per super-step, paths kept on the home GPU; stellar-random-walk_amd/distributed.py).
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+REQUEST_CEILING = 50.0e9       # profiles/r02_translation_and_request_rate.md: L2-miss requests/s, any request size
 
 
 def cpu_baseline(args):
@@ -55,6 +64,111 @@ def cpu_baseline(args):
                       % (scale, args.p, args.q, n_src, args.cpu_walk_length + 1, cores, dt, t_build)}
 
 
+def roofline_of(stats, steps_per_launch, avg_ms, scale=None):
+    """Algorithmic bytes per launch / average kernel time of the dominant kernel."""
+    kind = stats["kernel_kind"]
+    if kind == 1:
+        # first-order guide-table kernel (§4.3): linked CDF/guide records actually read (counted by the kernel; 16 B compact
+        # or 32 B exact) + 4 B path store per step; per walker 4 B seed + 16 B row + 4 B len
+        alg = steps_per_launch * 4 + stats["ent_reads"] * stats["record_bytes"] + stats["n_walkers"] * 24
+        name = "k_walk_first_order"
+        formula = "records_read*record_bytes + 4 B path/step + 24 B/walker (the O(deg) scan of SURVEY §8d is replaced by an exact precomputed CDF + guide table: its 16+8*deg+4 B/step are never issued)"
+    elif kind == 3:
+        # Mode A (§4.6): 32-B alias records read (counted) + 4 B path store per step (membership probes not counted)
+        alg = steps_per_launch * 4 + stats["ent_reads"] * 32 + stats["n_walkers"] * 24
+        name = "k_walk_alias"
+        formula = "alias records read*32 + 4 B path/step + 24 B/walker (probes of the rejection test not counted: lower bound)"
+    else:
+        # general kernel (§4.4, SURVEY §8d Mode R): 16 B row + 4 B path per step; + what the step's sampler reads:
+        # streamed rows 8*deg(curr) (+ 4*deg(prev) of membership), searches their strategy's bytes, per-edge tables
+        # 512 B + 16 B per evaluated candidate, membership masks 8*deg + mask words (all counted by the kernel)
+        alg = steps_per_launch * 20 + stats["sum_deg_curr"] * 8 + stats.get("sum_deg_prev", 0) * 4 + stats.get("trials", 0)
+        name = "k_walk_general"
+        formula = "20 B/step + 8*deg(curr) (+4*deg(prev)) for streamed rows + bytes read by the searches / per-edge tables / masks (kernel counters)"
+    achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": None, "kernel": name, "kernel_ms_avg": avg_ms, "algorithmic_bytes_per_launch": int(alg),
+         "algorithmic_bytes_formula": formula, "record_bytes": stats.get("record_bytes", 0)}
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc) and scale is not None:
+        try:
+            js = json.load(open(pmc))
+            for j in (js if isinstance(js, list) else [js]):
+                if j.get("kernel") == name and j.get("scale") == scale:
+                    r["traffic"] = j.get("hbm_bytes_per_launch")
+                    r["traffic_source"] = ("profiles/pmc_latest.json <- %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by the "
+                                           "builder on the same command; NOT measured in this run" % j.get("source", "profiles/"))
+                    if r["traffic"]:
+                        r["physical_traffic_frac"] = r["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        except Exception:
+            pass
+    if kind == 1 and stats["ent_reads"]:
+        # the kernel's bound is the L2-miss REQUEST rate (one request per record whatever its size, + 1/16 path-store sector
+        # per step), not bytes: profiles/r02_translation_and_request_rate.md
+        req = (stats["ent_reads"] + steps_per_launch / 16.0) / (avg_ms * 1e-3)
+        r["requests_per_s"] = req
+        r["request_rate_ceiling"] = REQUEST_CEILING
+        r["request_rate_frac"] = req / REQUEST_CEILING
+        r["request_rate_source"] = "profiles/r02_translation_and_request_rate.md (builder's microbenchmark: ~50 G L2-miss requests/s for 16 B, 64 B and 128 B requests alike; a constant here, NOT measured in this run)"
+    return r
+
+
+def measure(eng, walk_kw, K, W, first_walk=0):
+    """W + K walk iterations of one walker per vertex; returns (steps, wall seconds of the K, kernel_ms list, last stats,
+    setup seconds spent inside the calls)."""
+    import torch
+    setup_ms = 0.0
+    for it in range(W):
+        st = eng.walk(fetch=False, first_walk=first_walk + it, **walk_kw)
+        setup_ms += st["setup_ms"]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps, kernel_ms, stats, inner_setup = 0, [], None, 0.0
+    for it in range(W, W + K):
+        st = eng.walk(fetch=False, first_walk=first_walk + it, **walk_kw)  # srw_walk: launch + hipEvents on its stream
+        steps += st["n_steps"]
+        kernel_ms.append(st["kernel_ms"])
+        inner_setup += st["setup_ms"]
+        stats = st
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0 - inner_setup * 1e-3
+    return steps, dt, kernel_ms, stats, (setup_ms + inner_setup) * 1e-3
+
+
+def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L=80):
+    """One BASELINE configuration on one GPU: graph generated on the device, W + K walk iterations."""
+    t0 = time.perf_counter()
+    eng = pkg.Engine(device=device)
+    try:
+        eng.generate_rmat(scale, ef << scale, seed=42, weighted=weighted, directed=directed)
+        nv, ne = eng.stats()
+        t_graph = time.perf_counter() - t0
+        kw = dict(p=p, q=q, walk_length=L, num_walks=1, seed=42)
+        if sampler == "alias":
+            kw["sampler"] = "alias"
+        steps, dt, kms, st, t_tables = measure(eng, kw, K, W)
+        avg_ms = sum(kms) / max(len(kms), 1)
+        out = {"name": name,
+               "workload": "RMAT scale-%d ef%d %s %s p=%g q=%g walkLength=%d, %s" % (
+                   scale, ef, "directed" if directed else "undirected", "weighted" if weighted else "unweighted", p, q, L,
+                   "Mode A (alias + rejection)" if sampler == "alias" else "Mode R (reference-exact)"),
+               "vertices": nv, "adjacency_entries": ne, "value": steps / dt, "unit": "walk-steps/s",
+               "steps": K, "warmup": W, "ms_per_step": dt / max(K, 1) * 1e3, "kernel_ms": avg_ms,
+               "walk_steps_per_bench_step": int(steps / max(K, 1)),
+               "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables},
+               "roofline": roofline_of(st, steps / max(K, 1), avg_ms)}
+        if st["kernel_kind"] == 2:
+            out["strategy_steps"] = {k: v for k, v in st["strategy_steps"].items() if v}
+            out["edge_tables"] = {"count": st["edge_tables"], "bytes": st["edge_table_bytes"]}
+            # the whole job of the config's numWalks = 10 from a cold start: tables once + 10 iterations
+            out["job_numWalks10_steps_per_s"] = 10 * steps / max(K, 1) / (t_tables + 10 * dt / max(K, 1))
+        if st["kernel_kind"] == 3:
+            out["trials_per_step"] = st["trials"] / max(st["n_steps"], 1)
+        return out
+    finally:
+        eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,9 +182,12 @@ def main():
     ap.add_argument("--weighted", type=int, default=0)
     ap.add_argument("--directed", type=int, default=0)
     ap.add_argument("--sampler", choices=["reference", "alias"], default="reference")
-    ap.add_argument("--shard", choices=["replicate", "vertex"], default="replicate")
+    ap.add_argument("--shard", choices=["both", "replicate", "vertex"], default="both",
+                    help="N > 1: which multi-GPU mode(s) to run; `value` is always the replicated mode when it runs")
     ap.add_argument("--nt-loads", type=int, default=-1, help="-1 auto, 0 cached, 1 nontemporal record loads")
     ap.add_argument("--compact", type=int, default=1, help="0: do not use the 16-byte lattice records")
+    ap.add_argument("--configs", type=int, default=1, help="1 GPU: also run BASELINE configs C2, C3 (Mode R / A), C5 stand-in")
+    ap.add_argument("--end-to-end", type=int, default=1, help="1 GPU: also time one iteration through srw_walk_and_save")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-scale", type=int, default=20)
     ap.add_argument("--cpu-sources", type=int, default=0, help="0 = max(64, 3 per host core)")
@@ -90,6 +207,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
+    torch.zeros(1, device="cuda")          # torch's device context first (it ships its own HIP runtime)
     dist = None
     if "RANK" in os.environ:  # launched by torch.distributed.run (any world size, including 1)
         import torch.distributed as dist
@@ -105,6 +223,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def allreduce(x, op):
+        if dist is None:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
     n_edges = args.edge_factor << args.scale
     K, W = args.steps, args.warmup
     walk_kw = dict(p=args.p, q=args.q, walk_length=args.walk_length, num_walks=1, seed=42)
@@ -115,34 +240,21 @@ def main():
     if not args.compact:
         walk_kw["compact"] = False
 
-    if args.shard == "vertex" and dist is not None:
-        from importlib import import_module
-        sharded = import_module("stellar_random_walk_amd.distributed")
-        drv = sharded.ShardedWalker(device=local_rank, rank=rank, world=world)
-        drv.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
-        nv, ne = drv.engine.stats()
-        for it in range(W):
-            drv.walk_iteration(iteration=it, **walk_kw)
-        barrier_sync()
+    out = None
+    nv = ne = 0
+    # ---- replicated mode (N = 1: the single-GPU headline) -----------------------------------------------------------
+    if args.shard in ("both", "replicate") or dist is None:
         t0 = time.perf_counter()
-        steps = 0
-        kernel_ms = []
-        for it in range(W, W + K):
-            st = drv.walk_iteration(iteration=it, **walk_kw)
-            steps += st["n_steps"]
-            kernel_ms.append(st["kernel_ms"])
-        barrier_sync()
-        dt = time.perf_counter() - t0
-        stats = {"ent_reads": 0, "n_walkers": 0, "kernel_kind": 2, "sum_deg_curr": st.get("sum_deg_curr", 0)}
-        parallelism = "vertex-sharded x%d, RCCL all-to-all per super-step" % world
-        scaling = "strong"
-    else:
         eng = pkg.Engine(device=local_rank)
         eng.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
         nv, ne = eng.stats()
+        t_graph = time.perf_counter() - t0
         base = rank * (W + K)  # disjoint walk-iteration indices per rank: numWalks = world * K in total
+        t_tables = 0.0
         for it in range(W):
-            eng.walk(fetch=False, first_walk=base + it, **walk_kw)
+            t_tables += eng.walk(fetch=False, first_walk=base + it, **walk_kw)["setup_ms"] * 1e-3
+        if W == 0:                                    # tables must not be built inside the timed region
+            t_tables += eng.walk(fetch=False, first_walk=base, **dict(walk_kw, walk_length=1))["setup_ms"] * 1e-3
         barrier_sync()
         t0 = time.perf_counter()
         steps = 0
@@ -155,70 +267,84 @@ def main():
             stats = st
         barrier_sync()
         dt = time.perf_counter() - t0
-        parallelism = "graph replicated, walk iterations sharded x%d, no collective" % world if world > 1 else "1 GPU"
-        scaling = "weak"
+        total_steps = int(allreduce(steps, dist.ReduceOp.SUM)) if dist is not None else steps
+        max_dt = allreduce(dt, dist.ReduceOp.MAX) if dist is not None else dt
+        if rank == 0:
+            avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+            out = {
+                "metric": "walk-steps/sec", "value": total_steps / max_dt, "unit": "walk-steps/s", "n_gpus": world,
+                "steps": K, "warmup": W, "ms_per_step": max_dt / max(K, 1) * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None,
+                "dtype": "f64 CDF tables (u32 lattice compares in the walk), int32 ids", "data": "synthetic",
+                "config": {"workload": "RMAT scale-%d ef%d (%d edge lines, %d adjacency entries, %d vertices) %s "
+                                       "%s p=%g q=%g walkLength=%d, 1 walk iteration per step, %s"
+                                       % (args.scale, args.edge_factor, n_edges, ne, nv,
+                                          "directed" if args.directed else "undirected",
+                                          "weighted" if args.weighted else "unweighted", args.p, args.q, args.walk_length,
+                                          "Mode A (alias + rejection)" if args.sampler == "alias" else "Mode R (reference-exact)"),
+                           "walk_steps_per_bench_step": int(steps / max(K, 1)),
+                           "parallelism": ("graph replicated, walk iterations sharded x%d, no collective" % world) if world > 1 else "1 GPU",
+                           "rng": "Philox4x32-10 keyed (iteration, source, step)"},
+                "roofline": roofline_of(stats, steps / max(K, 1), avg_ms, scale=args.scale),
+                "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables,
+                            "note": "outside the timed region; one-off per graph / per (p, q)"},
+            }
+        # ---- end to end: the reference's contract is path FILES --------------------------------------------------------
+        if rank == 0 and world == 1 and args.end_to_end:
+            e2e = {"what": "srw_walk_and_save, 1 walk iteration: walk kernel + device-side formatter + PCIe + part-00000 on local disk"}
+            tmp_root = os.environ.get("TMPDIR", "/tmp")
+            need = nv * (args.walk_length + 2) * 8          # generous bound on the text size
+            try:
+                free = shutil.disk_usage(tmp_root).free
+                if free < need * 1.2:
+                    e2e["skipped"] = "needs ~%.0f GB under %s, %.0f GB free" % (need / 1e9, tmp_root, free / 1e9)
+                else:
+                    d = tempfile.mkdtemp(prefix="srw_bench_", dir=tmp_root)
+                    try:
+                        t0 = time.perf_counter()
+                        st, _ = eng.walk_and_save(os.path.join(d, "out"), n_parts=1, first_walk=base + W + K, device_format=True, **walk_kw)
+                        dt_e = time.perf_counter() - t0
+                        nbytes = sum(os.path.getsize(os.path.join(d, "out", "path", f)) for f in os.listdir(os.path.join(d, "out", "path")))
+                        e2e.update({"seconds": dt_e, "walk_steps_per_s": st["n_steps"] / dt_e, "text_bytes": nbytes,
+                                    "text_GB_per_s": nbytes / dt_e / 1e9, "kernel_ms": st["kernel_ms"]})
+                    finally:
+                        shutil.rmtree(d, ignore_errors=True)
+            except Exception as ex:  # the headline must survive a full disk
+                e2e["error"] = str(ex)[:200]
+            out["end_to_end"] = e2e
+        eng.close()
+        del eng
 
-    total_steps, max_dt = steps, dt
-    if dist is not None:
-        t = torch.tensor([float(steps)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_steps = int(t.item())
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        max_dt = float(t.item())
+    # ---- vertex-sharded mode (north_star's split) --------------------------------------------------------------------
+    if dist is not None and args.shard in ("both", "vertex"):
+        from importlib import import_module
+        sharded = import_module("stellar_random_walk_amd.distributed")
+        if not hasattr(sharded, "bench_vertex_sharded"):
+            raise SystemExit("vertex-sharded bench entry missing")
+        vs = sharded.bench_vertex_sharded(dist, local_rank, rank, world, args.scale, n_edges, bool(args.weighted),
+                                          bool(args.directed), walk_kw, K, W, barrier_sync)
+        if rank == 0:
+            if out is None:
+                out = {"metric": "walk-steps/sec", "value": vs["value"], "unit": "walk-steps/s", "n_gpus": world, "steps": K,
+                       "warmup": W, "ms_per_step": vs["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                       "vs_baseline": None, "dtype": "f64 CDF tables, int32 ids", "data": "synthetic",
+                       "config": {"workload": vs["workload"], "parallelism": vs["parallelism"]}}
+            out["vertex_sharded"] = vs
 
     if rank == 0:
-        avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        if stats["kernel_kind"] == 1:
-            # first-order guide-table kernel, per launch: the linked CDF/guide records actually read
-            # (counted by the kernel; 16 B compact lattice records or 32 B exact records) + 4 B path store per step; per walker 4 B seed + 16 B row + 4 B len
-            per_launch_steps = steps / max(K, 1)
-            alg_bytes = per_launch_steps * 4 + stats["ent_reads"] * stats["record_bytes"] + stats["n_walkers"] * 24
-            kernel_name = "k_walk_first_order"
-        elif stats["kernel_kind"] == 3:
-            # Mode A: 32-B alias records read (counted) + 4 B path store per step; membership probes of
-            # rejected/accepted candidates are not counted (lower bound)
-            per_launch_steps = steps / max(K, 1)
-            alg_bytes = per_launch_steps * 4 + stats["ent_reads"] * 32 + stats["n_walkers"] * 24
-            kernel_name = "k_walk_alias"
-        else:
-            # general kernel (SURVEY §8d Mode R): 16 + 8*deg(curr) + 4 per step (+ 16 + 4*deg(prev) when q != 1) for the
-            # steps that stream N(curr); steps served by the binned prefix-sum search count what their membership strategy
-            # reads instead (P1: ids of N(prev) + the entries they land on; P2/P3: entries + hash slot / bitmap word; W: both sorted rows)
-            per_launch_steps = steps / max(K, 1)
-            alg_bytes = (per_launch_steps * 20 + stats["sum_deg_curr"] * 8 + stats.get("sum_deg_prev", 0) * 4
-                         + stats.get("trials", 0))
-            kernel_name = "k_walk_general"
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                if j.get("kernel") == kernel_name and j.get("scale") == args.scale:
-                    traffic = j.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "walk-steps/sec", "value": total_steps / max_dt, "unit": "walk-steps/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": max_dt / max(K, 1) * 1e3, "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "f64 CDF tables (u32 lattice compares in the walk), int32 ids", "data": "synthetic",
-            "config": {"workload": "RMAT scale-%d ef%d (%d edge lines, %d adjacency entries, %d vertices) %s "
-                                   "%s p=%g q=%g walkLength=%d, 1 walk iteration per step, %s"
-                                   % (args.scale, args.edge_factor, n_edges, ne, nv,
-                                      "directed" if args.directed else "undirected",
-                                      "weighted" if args.weighted else "unweighted", args.p, args.q, args.walk_length,
-                                      "Mode A (alias + rejection)" if args.sampler == "alias" else "Mode R (reference-exact)"),
-                       "walk_steps_per_bench_step": int(steps / max(K, 1)), "parallelism": parallelism,
-                       "rng": "Philox4x32-10 keyed (iteration, source, step)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
-                         "kernel_ms_avg": avg_ms, "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "record_bytes": stats.get("record_bytes", 0),
-                         # context (profiles/r01_microbench_random_gather.txt): measured MI355X ceiling of dependent random
-                         # reads, the access pattern of this kernel: 51.2e9 16-B records/s, 40.3e9 32-B records/s
-                         "random_gather_ceiling_records_per_s": {16: 51.2e9, 32: 40.3e9}.get(stats.get("record_bytes", 0))},
-        }
+        if world == 1 and args.configs:
+            cfgs = []
+            plan = [("C2", 20, 16, False, False, 1.0, 1.0, "reference", 10, 1),
+                    ("C3 Mode R", 24, 16, True, False, 0.25, 4.0, "reference", 2, 1),
+                    ("C3 Mode A", 24, 16, True, False, 0.25, 4.0, "alias", 3, 1),
+                    ("C5 stand-in Mode R", 26, 27, False, True, 4.0, 0.5, "reference", 1, 1),
+                    ("C5 stand-in Mode A", 26, 27, False, True, 4.0, 0.5, "alias", 2, 1)]
+            for (name, sc, ef, wt, dr, p, q, smp, k, w) in plan:
+                try:
+                    cfgs.append(run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w))
+                except Exception as ex:
+                    cfgs.append({"name": name, "error": str(ex)[:300]})
+            out["configs"] = cfgs
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -199,18 +199,65 @@ int32_t srw_write_paths(const srw_handle *h, const char *output_dir, int32_t n_p
 int32_t srw_alias_row(srw_handle *h, int32_t v, float *prob, int32_t *alias, int64_t cap, int64_t *n, int32_t *regular);
 
 /* ---- vertex-sharded multi-GPU path (one handle per GPU, world > 1) -------------------------- */
-typedef struct { int32_t wid, src, prev, curr; } srw_walker; /* 16-byte record exchanged over xGMI */
-/* Seeds for this rank's vertices, replaces initWalkersToTheirPartitions / the walker seeds
- * (UniformRandomWalk.scala:81-87).  d_out (device) must hold srw_shard_capacity records. */
+/* Replaces the Spark shuffle of the super-step loop: prepareWalkersToTransfer (UniformRandomWalk.scala:103-112,
+ * VCutRandomWalk.scala:121-134) + transferWalkersToTheirPartitions (RandomWalk.scala:186-192) + the loop itself
+ * (RandomWalk.scala:91-162).  The graph is sharded by source vertex (srw_config.rank / world); a walker standing on v is
+ * processed by owner(v); its PATH stays on its home rank = owner(source).  Each super-step every rank consumes one
+ * receive buffer of `world` fixed-capacity chunks (one per sender) and fills `world` destination chunks:
+ *     chunk = { uint32 n_walkers, n_rets, 0, 0 } | srw_walker[cap_walkers] | srw_path_ret[cap_rets]
+ * The caller moves chunk (me -> d) to rank d's receive buffer slot `me`: one equal-split all-to-all of chunk_bytes per
+ * peer (RCCL over xGMI; stellar-random-walk_amd/distributed.py), or — one process, several devices — the kernels store
+ * straight into the peers' receive buffers (srw_cluster_*, below).  No host synchronisation per super-step: counts live
+ * in the chunk headers; an overflowing chunk drops its surplus and srw_shard_finish reports it (retry with more slack).
+ * The keyed RNG makes the paths bit-identical for any world size (tests assert it against the oracle). */
+typedef struct { int32_t lw, src, prev, curr; } srw_walker;   /* lw = local vertex index on the home rank * batch + iteration in batch */
+typedef struct { int32_t lw, v; } srw_path_ret;               /* vertex sampled for walker lw, returned to its home rank */
+typedef struct { int64_t cap_walkers, cap_rets, chunk_bytes; } srw_shard_layout;
+/* vertices owned by this handle / present in the whole graph (the walker seeds, UniformRandomWalk.scala:81-87) */
 int32_t srw_shard_capacity(const srw_handle *h, int64_t *n_local_vertices, int64_t *n_global_vertices);
-int32_t srw_shard_seed(srw_handle *h, int32_t iter_in_call, void *d_out, int64_t *n_out, void *d_paths,
-                       int64_t stride); /* also writes path slot 0 of the seeded walkers into d_paths */
-/* One super-step (RandomWalk.scala:92-139 with exactly one step per walker): samples the next vertex
- * of the n_in records in d_in (all at path slot `step`), writes it to d_paths[wid * stride + step],
- * and emits the surviving walkers into d_out grouped by owner(next); counts_out[world] (host). */
-int32_t srw_shard_step(srw_handle *h, const srw_walk_params *params, int32_t iter, int32_t step,
-                       const void *d_in, int64_t n_in, void *d_out, int64_t *counts_out,
-                       void *d_paths, int64_t stride, srw_walk_stats *stats);
+/* global rank (position among all present vertices, ascending id) of each local vertex: path row lw of a batch of B
+ * iterations is canonical walker (first_walk + lw % B) * nVertices + ranks[lw / B].  out[n_local_vertices] (host). */
+int32_t srw_shard_vertex_ranks(const srw_handle *h, int32_t *out);
+/* Chunk capacities for `batch` walk iterations sharing their super-steps: slack * batch * nVertices / world^2 + 4096. */
+int32_t srw_shard_layout_for(const srw_handle *h, int32_t batch, double slack, srw_shard_layout *out);
+/* Seeds this rank's batch * n_local walkers into its own receive buffer d_recv (world * chunk_bytes, device), writes
+ * path slot 0 / lens into d_paths [batch * n_local][walk_length + 2] / d_lens (device), clears the counters. */
+int32_t srw_shard_begin(srw_handle *h, const srw_walk_params *params, int32_t batch, const srw_shard_layout *layout,
+                        void *d_recv, void *d_paths, void *d_lens);
+/* Super-step `step` (1 .. walk_length + 1), enqueued on the handle's stream: applies the path returns found in d_recv,
+ * samples every walker in d_recv once, writes chunk (me -> d) to dst_chunks[d] (device or peer pointers, d < world). */
+int32_t srw_shard_superstep(srw_handle *h, const srw_walk_params *params, int32_t batch, int32_t step,
+                            const srw_shard_layout *layout, const void *d_recv, void *const *dst_chunks, void *d_paths,
+                            void *d_lens);
+/* After the exchange that follows super-step walk_length + 1: applies its path returns. */
+int32_t srw_shard_flush(srw_handle *h, const srw_walk_params *params, int32_t batch, const srw_shard_layout *layout,
+                        const void *d_recv, void *d_paths, void *d_lens);
+/* Synchronises the stream; steps / dead ends since srw_shard_begin; *overflow != 0: a chunk was too small. */
+int32_t srw_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow);
+
+/* ---- the same walk inside ONE process over several devices (CLI --gpus N, the JNI host) ------------------------------ */
+/* One sharded handle per device, peer access enabled; the bucket kernels store every chunk directly into the receiving
+ * device's buffer over xGMI and the super-steps are ordered by events — no collective library, no host sync per step.
+ * devices may repeat an ordinal (several shards on one GPU: how the protocol is tested on a single-GPU box). */
+typedef struct srw_cluster srw_cluster;
+int32_t srw_cluster_create(const int32_t *devices, int32_t n_devices, int32_t flags, srw_cluster **out);
+void srw_cluster_destroy(srw_cluster *c);
+const char *srw_cluster_last_error(const srw_cluster *c);
+srw_handle *srw_cluster_shard(srw_cluster *c, int32_t rank);   /* the rank's handle (graph queries, tests) */
+int32_t srw_cluster_load_edgelist(srw_cluster *c, const char *path, int32_t directed, int32_t weighted, int32_t partitioned,
+                                  int32_t rdd_partitions);
+int32_t srw_cluster_load_coo(srw_cluster *c, const int32_t *src, const int32_t *dst, const float *w, const int32_t *pid,
+                             int64_t n_lines, int32_t directed);
+int32_t srw_cluster_generate_rmat(srw_cluster *c, int32_t scale, int64_t n_edges, uint32_t seed, int32_t weighted, int32_t directed);
+int32_t srw_cluster_graph_stats(const srw_cluster *c, int64_t *n_vertices, int64_t *n_entries);
+/* params->num_walks iterations starting at first_walk, `batch` of them per population (0 = automatic); paths stay on
+ * their home devices.  stats: n_steps / dead_ends summed over the shards, kernel_ms = wall time of the super-steps. */
+int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t batch, srw_walk_stats *stats);
+/* The last walk in canonical order (iteration major, source id ascending): paths [num_walks * nVertices][walk_length + 2]. */
+int32_t srw_cluster_fetch_paths(srw_cluster *c, int32_t *paths, int32_t *lens);
+/* walk + RandomWalk.save (RandomWalk.scala:234-241) over the cluster: <output_dir>/path/part-* + _SUCCESS. */
+int32_t srw_cluster_walk_and_save(srw_cluster *c, const srw_walk_params *params, const char *output_dir, int32_t n_parts,
+                                  int32_t write_crc, srw_walk_stats *stats);
 
 /* ---- unit hooks (device arithmetic of RandomSample, for parity tests) ----------------------- */
 /* RandomSample.sample (M/algorithm/RandomSample.scala:12-25) on the GPU; *index = chosen position. */

@@ -60,6 +60,10 @@ class WalkStats(C.Structure):
         return d
 
 
+class ShardLayout(C.Structure):
+    _fields_ = [("cap_walkers", C.c_int64), ("cap_rets", C.c_int64), ("chunk_bytes", C.c_int64)]
+
+
 STRATEGIES = ("edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain", "edge_mask", "_9", "_10", "_11")   # SRW_STRAT_*
 
 
@@ -68,7 +72,11 @@ EXPORTS = [
     "srw_create", "srw_destroy", "srw_last_error", "srw_set_stream", "srw_load_edgelist", "srw_load_coo",
     "srw_load_adjacency", "srw_generate_rmat", "srw_graph_stats", "srw_graph_vertices", "srw_graph_neighbors",
     "srw_graph_partition", "srw_alias_row", "srw_walk", "srw_walk_to_host", "srw_walk_and_save", "srw_host_alloc", "srw_host_free", "srw_fetch_paths", "srw_device_paths", "srw_write_paths",
-    "srw_shard_capacity", "srw_shard_seed", "srw_shard_step", "srw_sample", "srw_second_order_weights",
+    "srw_shard_capacity", "srw_shard_vertex_ranks", "srw_shard_layout_for", "srw_shard_begin", "srw_shard_superstep",
+    "srw_shard_flush", "srw_shard_finish", "srw_cluster_create", "srw_cluster_destroy", "srw_cluster_last_error",
+    "srw_cluster_shard", "srw_cluster_load_edgelist", "srw_cluster_load_coo", "srw_cluster_generate_rmat",
+    "srw_cluster_graph_stats", "srw_cluster_walk", "srw_cluster_fetch_paths", "srw_cluster_walk_and_save",
+    "srw_sample", "srw_second_order_weights",
     "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_version",
 ]
 
@@ -111,9 +119,27 @@ def lib():
     L.srw_device_paths.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i64p, i32p]
     L.srw_write_paths.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
     L.srw_shard_capacity.argtypes = [vp, i64p, i64p]
-    L.srw_shard_seed.argtypes = [vp, C.c_int32, vp, i64p, vp, C.c_int64]
-    L.srw_shard_step.argtypes = [vp, C.POINTER(WalkParams), C.c_int32, C.c_int32, vp, C.c_int64, vp, i64p, vp,
-                                 C.c_int64, C.POINTER(WalkStats)]
+    L.srw_shard_vertex_ranks.argtypes = [vp, i32p]
+    L.srw_shard_layout_for.argtypes = [vp, C.c_int32, C.c_double, C.POINTER(ShardLayout)]
+    L.srw_shard_begin.argtypes = [vp, C.POINTER(WalkParams), C.c_int32, C.POINTER(ShardLayout), vp, vp, vp]
+    L.srw_shard_superstep.argtypes = [vp, C.POINTER(WalkParams), C.c_int32, C.c_int32, C.POINTER(ShardLayout), vp,
+                                      C.POINTER(vp), vp, vp]
+    L.srw_shard_flush.argtypes = [vp, C.POINTER(WalkParams), C.c_int32, C.POINTER(ShardLayout), vp, vp, vp]
+    L.srw_shard_finish.argtypes = [vp, C.POINTER(WalkStats), i32p]
+    L.srw_cluster_create.argtypes = [i32p, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.srw_cluster_destroy.argtypes = [vp]
+    L.srw_cluster_destroy.restype = None
+    L.srw_cluster_last_error.argtypes = [vp]
+    L.srw_cluster_last_error.restype = C.c_char_p
+    L.srw_cluster_shard.argtypes = [vp, C.c_int32]
+    L.srw_cluster_shard.restype = vp
+    L.srw_cluster_load_edgelist.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.srw_cluster_load_coo.argtypes = [vp, i32p, i32p, f32p, i32p, C.c_int64, C.c_int32]
+    L.srw_cluster_generate_rmat.argtypes = [vp, C.c_int32, C.c_int64, C.c_uint32, C.c_int32, C.c_int32]
+    L.srw_cluster_graph_stats.argtypes = [vp, i64p, i64p]
+    L.srw_cluster_walk.argtypes = [vp, C.POINTER(WalkParams), C.c_int32, C.POINTER(WalkStats)]
+    L.srw_cluster_fetch_paths.argtypes = [vp, i32p, i32p]
+    L.srw_cluster_walk_and_save.argtypes = [vp, C.POINTER(WalkParams), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(WalkStats)]
     L.srw_sample.argtypes = [vp, f32p, C.c_int64, C.c_float, i64p]
     L.srw_second_order_weights.argtypes = [vp, C.c_float, C.c_float, C.c_int32, i32p, C.c_int64, i32p, f32p,
                                            C.c_int64, f32p]
@@ -402,3 +428,75 @@ class Engine:
         self._ck(lib().srw_rng_uniform(self.h, seed, it.ctypes.data_as(u32p), src.ctypes.data_as(u32p),
                                        step.ctypes.data_as(u32p), len(it), _f32(out)))
         return out
+
+
+class Cluster:
+    """srw_cluster_*: the vertex-sharded walk inside one process over several devices (peer stores over xGMI, no
+    collective).  `devices` may repeat an ordinal: several shards on one GPU (how single-GPU boxes test the protocol)."""
+
+    def __init__(self, devices, owner_from_partitions=False):
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        self.h = C.c_void_p()
+        rc = lib().srw_cluster_create(_i32(devs), len(devs), CFG_OWNER_FROM_PARTITIONS if owner_from_partitions else 0,
+                                      C.byref(self.h))
+        if rc != OK:
+            raise SrwError(rc, lib().srw_last_error(None).decode())
+        self.world = len(devs)
+
+    def close(self):
+        if self.h:
+            lib().srw_cluster_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise SrwError(rc, lib().srw_cluster_last_error(self.h).decode())
+
+    def load_edgelist(self, path, directed=False, weighted=True, partitioned=False, rdd_partitions=200):
+        self._ck(lib().srw_cluster_load_edgelist(self.h, os.fsencode(path), int(directed), int(weighted), int(partitioned),
+                                                 rdd_partitions))
+        return self
+
+    def load_coo(self, src, dst, w=None, pid=None, directed=False):
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        dst = np.ascontiguousarray(dst, dtype=np.int32)
+        w = None if w is None else np.ascontiguousarray(w, dtype=np.float32)
+        pid = None if pid is None else np.ascontiguousarray(pid, dtype=np.int32)
+        self._ck(lib().srw_cluster_load_coo(self.h, _i32(src), _i32(dst), None if w is None else _f32(w),
+                                            None if pid is None else _i32(pid), len(src), int(directed)))
+        return self
+
+    def generate_rmat(self, scale, n_edges=None, seed=42, weighted=False, directed=False):
+        self._ck(lib().srw_cluster_generate_rmat(self.h, scale, (16 << scale) if n_edges is None else n_edges, seed,
+                                                 int(weighted), int(directed)))
+        return self
+
+    def stats(self):
+        v, e = C.c_int64(0), C.c_int64(0)
+        self._ck(lib().srw_cluster_graph_stats(self.h, C.byref(v), C.byref(e)))
+        return v.value, e.value
+
+    def walk(self, fetch=True, batch=0, **kw):
+        P = Engine.params(**kw)
+        st = WalkStats()
+        self._ck(lib().srw_cluster_walk(self.h, C.byref(P), batch, C.byref(st)))
+        if not fetch:
+            return st.as_dict()
+        nv = self.stats()[0]
+        n = P.num_walks * nv
+        paths = np.empty((max(n, 1), P.walk_length + 2), dtype=np.int32)
+        lens = np.empty(max(n, 1), dtype=np.int32)
+        self._ck(lib().srw_cluster_fetch_paths(self.h, _i32(paths), _i32(lens)))
+        return paths[:n], lens[:n], st.as_dict()
+
+    def walk_and_save(self, output_dir, n_parts=1, write_crc=False, **kw):
+        P = Engine.params(**kw)
+        st = WalkStats()
+        self._ck(lib().srw_cluster_walk_and_save(self.h, C.byref(P), os.fsencode(output_dir), n_parts, int(write_crc), C.byref(st)))
+        return st.as_dict()

@@ -351,23 +351,54 @@ int32_t srw_shard_capacity(const srw_handle *h, int64_t *n_local_vertices, int64
   return SRW_OK;
 }
 
-int32_t srw_shard_seed(srw_handle *h, int32_t iter_in_call, void *d_out, int64_t *n_out, void *d_paths, int64_t stride) {
-  if (!h) return SRW_ERR_INVALID;
-  return guarded(h, [&] {
-    need(d_out && n_out, "null argument");
-    run_shard_seed(h, iter_in_call, (Walker *)d_out, n_out, (int32_t *)d_paths, stride);
+int32_t srw_shard_vertex_ranks(const srw_handle *h, int32_t *out) {
+  if (!h || !h->g.loaded || !out) return SRW_ERR_INVALID;
+  return guarded(const_cast<srw_handle *>(h), [&] {
+    if (h->g.n_local_vertices > 0)
+      SRW_HIP(hipMemcpy(out, h->g.vrank.p, (size_t)h->g.n_local_vertices * 4, hipMemcpyDeviceToHost));
   });
 }
 
-int32_t srw_shard_step(srw_handle *h, const srw_walk_params *params, int32_t iter, int32_t step, const void *d_in,
-                       int64_t n_in, void *d_out, int64_t *counts_out, void *d_paths, int64_t stride,
-                       srw_walk_stats *stats) {
+int32_t srw_shard_layout_for(const srw_handle *h, int32_t batch, double slack, srw_shard_layout *out) {
+  if (!h || !out) return SRW_ERR_INVALID;
+  return guarded(const_cast<srw_handle *>(h), [&] {
+    need(h->g.loaded, "no graph loaded");
+    shard_layout(h, batch, slack, out);
+  });
+}
+
+int32_t srw_shard_begin(srw_handle *h, const srw_walk_params *params, int32_t batch, const srw_shard_layout *layout,
+                        void *d_recv, void *d_paths, void *d_lens) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
-    need(params && counts_out && d_paths && (n_in == 0 || (d_in && d_out)), "null argument");
-    run_shard_step(h, *params, iter, step, (const Walker *)d_in, n_in, (Walker *)d_out, counts_out, (int32_t *)d_paths,
-                   stride, stats);
+    need(params && layout && d_recv && d_paths && d_lens, "null argument");
+    run_shard_begin(h, batch, *layout, d_recv, (int32_t *)d_paths, (int32_t *)d_lens, (int64_t)params->walk_length + 2);
   });
+}
+
+int32_t srw_shard_superstep(srw_handle *h, const srw_walk_params *params, int32_t batch, int32_t step,
+                            const srw_shard_layout *layout, const void *d_recv, void *const *dst_chunks, void *d_paths,
+                            void *d_lens) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(params && layout && d_recv && dst_chunks && d_paths && d_lens, "null argument");
+    run_shard_superstep(h, *params, batch, step, *layout, d_recv, dst_chunks, (int32_t *)d_paths, (int32_t *)d_lens,
+                        (int64_t)params->walk_length + 2);
+  });
+}
+
+int32_t srw_shard_flush(srw_handle *h, const srw_walk_params *params, int32_t batch, const srw_shard_layout *layout,
+                        const void *d_recv, void *d_paths, void *d_lens) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(params && layout && d_recv && d_paths && d_lens, "null argument");
+    run_shard_flush(h, *params, batch, *layout, d_recv, (int32_t *)d_paths, (int32_t *)d_lens, (int64_t)params->walk_length + 2);
+  });
+}
+
+int32_t srw_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { run_shard_finish(h, stats, overflow); });
 }
 
 int32_t srw_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index) {

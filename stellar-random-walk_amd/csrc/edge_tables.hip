@@ -42,14 +42,14 @@ constexpr int GRAB_ITEMS = 16;     // pairs per cursor grab of the build kernel 
 struct EbSel {          // which pairs get a table
   int32_t mask_max;     // rows of curr up to this many candidates: membership mask (0: none)
   int32_t min_deg;      // bins tables: shortest row of curr
-  int64_t min_cost;     // bins tables: wave-cycles by binned_cost, cheaper intersections stay on the fly
+  int64_t min_cost;     // bins tables: smallest priority (saved wave-cycles per 64 B of table, see eb_units) that still fits the budget
   int32_t min_sh;       // bins tables: smallest chunk shift
   int32_t has_ehash, has_hub;
 };
 constexpr int INLINE_MAX_DEG = 32;   // masks of rows up to 32 candidates live in eb_off[e] itself
 
 // Table of pair (u -> v): kind 0 = none, 1 = bins (64-byte units), 2 = mask (16-byte units), 3 = inline mask.
-// cost_out: the model's cost of the pair (bins tables: the priority under the HBM budget).
+// cost_out: the pair's priority under the HBM budget (bins tables).
 __device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s, int64_t &cost_out, int &kind) {
   cost_out = 0; kind = 0;
   if (ru.deg <= 0 || rv.deg <= 0) return 0u;
@@ -60,11 +60,28 @@ __device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s
   }
   if (rv.deg < s.min_deg || !(rv.flags & ROW_PQ_OK)) return 0u;
   const BinnedCost c = binned_cost(rv.deg, ru.deg, s.has_hub && (ru.flags >> ROW_HUB_SHIFT) != 0u, s.has_ehash != 0);
-  cost_out = c.c1 < c.c2 ? (c.c1 < c.cw ? c.c1 : c.cw) : (c.c2 < c.cw ? c.c2 : c.cw);
-  if (cost_out < s.min_cost) return 0u;
+  const int64_t cost = c.c1 < c.c2 ? (c.c1 < c.cw ? c.c1 : c.cw) : (c.c2 < c.cw ? c.c2 : c.cw);
   const BinGeom geo = bin_geometry(rv.deg, s.min_sh, EB_BINS);
+  const uint32_t units = (uint32_t)((geo.n_bins + 7) >> 3);
+  // priority = wave-cycles a table saves per visit, per 64 bytes of table: an on-the-fly step costs its intersection
+  // work plus ~20 us of dependent round trips whatever its size (measured: 38 .. 43 us per P1 / W step at config 3
+  // against 10 .. 25 us per table step), so short cheap tables are worth as much per byte as the hub <-> hub ones
+  cost_out = (cost + 49152) / (int64_t)units;
+  if (cost_out < s.min_cost) return 0u;
   kind = 1;
-  return (uint32_t)((geo.n_bins + 7) >> 3);
+  return units;
+}
+
+// Priority classes for the budget fit: 4 per octave from 2^11 up (class 1 .. 62; 0 unused, 63 = the masks).
+__host__ __device__ inline int prio_class(int64_t x) {
+  if (x < 2048) return 1;
+  int e = 0; while ((x >> (e + 1)) != 0) ++e;          // floor(log2 x) >= 11
+  const int c = (e - 11) * 4 + (int)((x >> (e - 2)) & 3) + 1;
+  return c > 62 ? 62 : c;
+}
+__host__ __device__ inline int64_t prio_class_floor(int c) {   // smallest priority in class c (c >= 2)
+  const int e = (c - 1) / 4 + 11, sub = (c - 1) & 3;
+  return (int64_t)(4 + sub) << (e - 2);
 }
 
 __device__ inline int64_t grab_u64(unsigned long long *cursor, unsigned long long n) {
@@ -92,9 +109,9 @@ __global__ __launch_bounds__(TPB) void k_eb_hist(const Row *__restrict__ rows, c
         int64_t cost; int kind;
         const uint32_t un = eb_units(ru, rv, sel, cost, kind);
         if (kind == 1) {
-          const int cls = 64 - __clzll((unsigned long long)(cost | 1));   // 1 .. 62
-          atomicAdd(&lh[cls < 62 ? cls : 62][0], (unsigned long long)un);
-          atomicAdd(&lh[cls < 62 ? cls : 62][1], 1ull);
+          const int cls = prio_class(cost);                                  // 1 .. 62
+          atomicAdd(&lh[cls][0], (unsigned long long)un);
+          atomicAdd(&lh[cls][1], 1ull);
         } else if (kind == 2) {                                            // slot 63: the masks (all or nothing)
           atomicAdd(&lh[63][0], (unsigned long long)un);
           atomicAdd(&lh[63][1], 1ull);
@@ -289,7 +306,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   free_b += g.eb_off.n * sizeof(uint32_t);
   const size_t fixed = (size_t)g.n_entries * 4 + (size_t)g.n_slots * 24 + env_gb("SRW_EB_RESERVE_GB", 24);
   if (free_b < fixed + ((size_t)64 << 20)) return;
-  size_t budget = std::min(env_gb("SRW_EB_BUDGET_GB", 128), free_b - fixed);
+  size_t budget = std::min(env_gb("SRW_EB_BUDGET_GB", 160), free_b - fixed);
   const int blocks = h->n_cus * 8;
   DevBuf<unsigned long long> cursor, hist, row_units, row_munits, row_pairs;
   cursor.alloc(1); hist.alloc(128);
@@ -304,7 +321,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   unsigned long long munits = hh[126], mpairs = hh[127];
   if (munits * 16 + mpairs * 8 > budget || munits >= 0xFFFFFFF0ull) { sel.mask_max = 0; munits = 0; mpairs = 0; }
   else budget -= munits * 16 + mpairs * 8;
-  // then the bins tables, most expensive classes first while they fit (class c = costs in [2^(c-1), 2^c))
+  // then the bins tables, highest priority classes first while they fit
   unsigned long long units = 0, pairs = 0;
   int cls = 63;
   while (cls > 1) {
@@ -312,7 +329,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
     if (nu * 64 + np * 8 > budget || nu >= 0xFFFFFFF0ull) break;
     units = nu; pairs = np; --cls;
   }
-  if (cls > 1) sel.min_cost = std::max<int64_t>(sel.min_cost, (int64_t)1 << (cls - 1));
+  if (cls > 1) sel.min_cost = std::max<int64_t>(sel.min_cost, prio_class_floor(cls));
   if (pairs == 0) sel.min_deg = 0x7FFFFFFF;      // no bins tables at all
   if (pairs + mpairs == 0 && sel.mask_max == 0) return;
   row_units.alloc((size_t)g.n_slots + 1); row_munits.alloc((size_t)g.n_slots + 1); row_pairs.alloc((size_t)g.n_slots + 1);
@@ -361,7 +378,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   g.eb_bytes = (int64_t)(units * 64 + munits * 16 + (unsigned long long)g.n_entries * 4);
   g.eb_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("SRW_TIMING"))
-    fprintf(stderr, "[edge tables] %llu bins tables (%.2f GB, min cost %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
+    fprintf(stderr, "[edge tables] %llu bins tables (%.2f GB, min priority %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
             "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
             sc[3], sc[4], mpairs, (double)munits * 16 / 1e9, (double)g.n_entries * 4 / 1e9, g.eb_build_ms);
 }

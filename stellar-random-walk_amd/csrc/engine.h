@@ -133,9 +133,9 @@ struct srw_handle {
   srw::DevBuf<srw::DevCounters> counters;
   srw::DevBuf<unsigned long long> walk_cursor;   // next walker of the persistent general kernel
   int n_cus = 256;
-  srw::DevBuf<unsigned long long> shard_counts;  // [world] bucket counters / cursors for srw_shard_step
   srw::DevBuf<srw::Walker> shard_scratch;        // sampled records before bucketing (persistent)
-  srw::DevBuf<uint32_t> shard_blk;               // [blocks][world] per-block survivor counts, then write cursors
+  srw::DevBuf<uint32_t> shard_blk;               // [blocks][2 * world] per-block survivor / return counts, then write cursors
+  srw::DevBuf<uint32_t> shard_flag;              // chunk overflow flag of the sharded walk
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // srw_walk_to_host: second stream + two staging buffers for compute/copy overlap
   hipStream_t copy_stream = nullptr;
@@ -236,11 +236,14 @@ void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats);
 void run_walk_to_host(srw_handle *h, const srw_walk_params &P, int32_t *paths, int32_t *lens, srw_walk_stats *stats);
 void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *output_dir, int n_parts, bool write_crc,
                        srw_walk_stats *stats, int64_t *dead_per_iter);
-void run_shard_seed(srw_handle *h, int32_t iter_in_call, Walker *d_out, int64_t *n_out, int32_t *d_paths,
-                    int64_t stride);
-void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32_t step, const Walker *d_in,
-                    int64_t n_in, Walker *d_out, int64_t *counts_out, int32_t *d_paths, int64_t stride,
-                    srw_walk_stats *stats);
+void shard_layout(const srw_handle *h, int32_t batch, double slack, srw_shard_layout *out);
+void run_shard_begin(srw_handle *h, int32_t batch, const srw_shard_layout &lay, void *d_recv, int32_t *d_paths, int32_t *d_lens,
+                     int64_t stride);
+void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch, int32_t step, const srw_shard_layout &lay,
+                         const void *d_recv, void *const *dst, int32_t *d_paths, int32_t *d_lens, int64_t stride);
+void run_shard_flush(srw_handle *h, const srw_walk_params &P, int32_t batch, const srw_shard_layout &lay, const void *d_recv,
+                     int32_t *d_paths, int32_t *d_lens, int64_t stride);
+void run_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow);
 void hook_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index);
 void hook_second_order(srw_handle *h, float p, float q, int32_t prev_id, const int32_t *prev_ids, int64_t n_prev,
                        const int32_t *curr_ids, const float *curr_w, int64_t n, float r, float *out_w,

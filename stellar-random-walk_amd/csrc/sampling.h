@@ -203,6 +203,7 @@ struct Member {
   int32_t seg_base;    // first candidate position covered by the bitmap
   const uint64_t *ehash = nullptr; uint64_t ehash_mask = 0;   // edge hash set (whole-graph handles): mode 1 probes it
   const uint32_t *hub = nullptr;   // this step's N(prev) bitmap over the id slots, if prev is a hub: mode 1 reads one bit
+  unsigned long long res_bytes = 0;   // binned_resolve: bytes of the candidates it evaluated (entries + prefix sums), bench.py
 #ifdef SRW_PHASE_TIMING
   unsigned long long t_fill = 0, t_pass1 = 0, t_pass2 = 0, t_prefix = 0, t_mark;
   unsigned long long t_a = 0, t_p1 = 0, t_p2 = 0, t_w = 0, t_fin = 0;
@@ -996,6 +997,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   served = 1;
   for (int32_t base = k0; base <= k1; base += 256) {
     Ent e[4]; double pqk[4]; bool valid[4], in[4], want[4]; uint32_t xs[4];
+    tm.res_bytes += 16ull * (unsigned long long)((k1 - base + 1) < 256 ? (k1 - base + 1) : 256);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int32_t k = base + u * 64 + lane;

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     if (degp) atomicAdd(&ctr->sum_deg_prev, degp);
     if (fb) atomicAdd(&ctr->fallbacks, fb);
     if (fast) atomicAdd(&ctr->ent_reads, fast);      // general kernel: steps served by the prefix-sum search
+    srch += mem.res_bytes;
     if (srch) atomicAdd(&ctr->trials, srch);         // ... and the bytes the binned ones' membership strategies read
     for (int i = 0; i < 12; ++i) if (n_strat[i]) atomicAdd(&ctr->strat[i], n_strat[i]);
 #ifdef SRW_PHASE_TIMING
@@ -441,18 +442,39 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Vertex-sharded super-step (run_shard_step).  A fixed grid of SHARD_BLOCKS blocks, block b owns the contiguous slice
-// [b * per_block, (b + 1) * per_block) of the incoming records in all three kernels:
-//   k_shard_step / k_shard_step_fo : sample every record in place into `scratch` (dead ends get wid = -1), write the
-//       path slot, and count the block's survivors per destination owner in LDS -> blk[b][d]   (no global atomics
-//       besides three block-reduced statistics: a single counter word saturates at ~88 atomics/us on MI355X)
-//   k_shard_offsets : one wave per destination: exclusive scan of blk[.][d] over the blocks -> every block's write
-//       cursor per destination, and the per-destination totals (the all-to-all-v split sizes)
-//   k_shard_bucket  : re-reads the slice and writes the survivors grouped by destination (LDS cursors,
-//       wave-aggregated), in rank order, ready for all_to_all_single
+// Vertex-sharded walk (SURVEY §8e option 2; replaces transferWalkersToTheirPartitions, RandomWalk.scala:92-93,186-192,
+// and UniformRandomWalk.prepareWalkersToTransfer, UniformRandomWalk.scala:103-112).
+//
+// A walker standing on v is processed by owner(v); its PATH lives on its home rank = owner(source).  What moves between
+// ranks each super-step is fixed-size records in fixed-capacity CHUNKS, one chunk per (sender, receiver) pair:
+//     chunk = { u32 n_walkers, n_rets, overflow, pad } | Walker[cap_w] {lw, src, prev, curr} | PathRet[cap_r] {lw, v}
+// lw = (local index of the source vertex on its home rank) * batch + (walk iteration inside the batch): the home rank's
+// path row, and lw % batch is the RNG's iteration word.  A rank's receive buffer is `world` chunks (one per sender),
+// its send side is `world` destination pointers — the local send buffer (one equal-split all_to_all_single moves it,
+// distributed.py) or, inside one process, the peers' receive buffers themselves (xGMI peer stores, cluster.cpp).
+// Everything is sized and counted on the device: NO host synchronisation per super-step; an overflowing chunk drops
+// its surplus and raises a flag the host reads once per walk call (it then retries with more slack).
+//   k_sh_seed    : the rank's own walkers, spread over the chunks of its receive buffer; path slot 0, lens = 1
+//   k_sh_apply   : path returns of the previous super-step -> paths[lw][step - 1], lens[lw] = step
+//   k_sh_step(_fo): sample every incoming walker in place into `scratch` (dead ends: lw = -1), count the block's
+//                  survivors per destination owner and the returns per home rank in LDS -> blk[b][2 * world]
+//   k_sh_offsets : one block: scan of blk over the blocks -> every block's write cursors; chunk headers
+//   k_sh_bucket  : re-reads the slice, writes walkers to chunk[owner(next)] and {lw, next} to chunk[home(src)]
 // The general kernel keeps one wave per record and the same samplers as k_walk_general (bit-identical paths for any
-// world).
+// world, asserted against the oracle).
 constexpr int SHARD_MAX_WORLD = 64;
+struct alignas(8) PathRet { int32_t lw, v; };
+struct ShardIO {
+  const char *recv;        // world chunks, one per sender
+  int64_t chunk_bytes;
+  int32_t cap_w, cap_r, world, rank, batch;
+};
+struct ShardDst { char *p[SHARD_MAX_WORLD]; };   // where chunk (me -> d) is written
+__device__ inline const uint32_t *chunk_hdr(const char *base, int64_t cb, int c) { return reinterpret_cast<const uint32_t *>(base + c * cb); }
+__device__ inline const Walker *chunk_walkers(const char *base, int64_t cb, int c) { return reinterpret_cast<const Walker *>(base + c * cb + 16); }
+__device__ inline const PathRet *chunk_rets(const char *base, int64_t cb, int32_t cap_w, int c) {
+  return reinterpret_cast<const PathRet *>(base + c * cb + 16 + (int64_t)cap_w * 16);
+}
 
 __device__ inline void block_flush_counters(DevCounters *ctr, unsigned long long *red, unsigned long long steps,
                                             unsigned long long dead, unsigned long long degc, unsigned long long degp,
@@ -479,79 +501,134 @@ __device__ inline void block_flush_counters(DevCounters *ctr, unsigned long long
   }
 }
 
-__global__ __launch_bounds__(TPB, 4) void k_shard_step(GraphView g, const Walker *__restrict__ in, int64_t n_in,
-                                                       int64_t per_block, int64_t n_verts_global, int32_t first_walk,
-                                                       int32_t step, RngSpec rng, float p, float q, int32_t world,
-                                                       Walker *__restrict__ out, uint32_t *__restrict__ blk,
-                                                       int32_t *__restrict__ paths, int64_t stride, DevCounters *ctr) {
+// prefix of the incoming walkers per chunk -> LDS pre[0 .. world]; returns the total
+__device__ inline uint32_t shard_in_prefix(const ShardIO &io, uint32_t *pre) {
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int c = 0; c < io.world; ++c) { pre[c] = acc; acc += min(chunk_hdr(io.recv, io.chunk_bytes, c)[0], (uint32_t)io.cap_w); }
+    pre[io.world] = acc;
+  }
+  __syncthreads();
+  return pre[io.world];
+}
+__device__ inline Walker shard_in_record(const ShardIO &io, const uint32_t *pre, uint32_t i) {
+  int c = 0;
+  while (c + 1 < io.world && i >= pre[c + 1]) ++c;
+  return chunk_walkers(io.recv, io.chunk_bytes, c)[i - pre[c]];
+}
+// per-block slice of n records in units of `unit` records (TPB for the per-lane kernels, TPB / 64 for one wave per record)
+__device__ inline void shard_slice(uint32_t n, uint32_t unit, uint32_t &lo, uint32_t &hi) {
+  uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  per = (per + unit - 1) / unit * unit;
+  const uint64_t l = (uint64_t)blockIdx.x * per, h = l + per;
+  lo = (uint32_t)(l < n ? l : n); hi = (uint32_t)(h < n ? h : n);
+}
+
+__global__ void k_sh_seed(const int32_t *__restrict__ verts, int64_t n_local, ShardIO io, char *recv_w,
+                          int32_t *__restrict__ paths, int32_t *__restrict__ lens, int64_t stride) {
+  const int64_t n = n_local * io.batch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t src = verts[i / io.batch];
+    Walker w; w.wid = (int32_t)i; w.src = src; w.prev = src; w.curr = src;
+    const int c = (int)(i % io.world);
+    reinterpret_cast<Walker *>(recv_w + c * io.chunk_bytes + 16)[i / io.world] = w;
+    paths[i * stride] = src;
+    lens[i] = 1;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < io.world) {
+    const int c = (int)threadIdx.x;
+    uint32_t *h = reinterpret_cast<uint32_t *>(recv_w + c * io.chunk_bytes);
+    h[0] = (uint32_t)((n - c + io.world - 1) / io.world); h[1] = 0u; h[2] = 0u; h[3] = 0u;
+  }
+}
+
+// returns produced in super-step `slot` (the vertex sampled for path position `slot`) arrive one exchange later
+__global__ void k_sh_apply(ShardIO io, int32_t slot, int32_t *__restrict__ paths, int32_t *__restrict__ lens, int64_t stride) {
+  for (int c = 0; c < io.world; ++c) {
+    const uint32_t n = min(chunk_hdr(io.recv, io.chunk_bytes, c)[1], (uint32_t)io.cap_r);
+    const PathRet *r = chunk_rets(io.recv, io.chunk_bytes, io.cap_w, c);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const PathRet x = r[i];
+      paths[(int64_t)x.lw * stride + slot] = x.v;
+      lens[x.lw] = slot + 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
+                                                    RngSpec rng, float p, float q, Walker *__restrict__ scratch,
+                                                    uint32_t *__restrict__ blk, DevCounters *ctr) {
   __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
-  __shared__ uint32_t cnt[SHARD_MAX_WORLD];
+  __shared__ uint32_t cnt[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
   __shared__ unsigned long long red[6];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
-  if (threadIdx.x < SHARD_MAX_WORLD) cnt[threadIdx.x] = 0u;
+  if (threadIdx.x < 2 * SHARD_MAX_WORLD) cnt[threadIdx.x] = 0u;
   if (threadIdx.x < 6) red[threadIdx.x] = 0ull;
-  __syncthreads();
+  const uint32_t n_in = shard_in_prefix(io, pre);          // contains the __syncthreads() cnt / red need
   Member mem; mem.mode = 0; mem.bm = bitmap[wv]; mem.seg_base = 0;
   unsigned long long steps = 0, dead = 0, degc = 0, degp = 0, fb = 0;
-  const int64_t lo = blockIdx.x * per_block, hi = min(n_in, lo + per_block);
-  for (int64_t ri = lo + wv; ri < hi; ri += TPB / 64) {     // one wave per record
-    Walker wk = in[ri];
+  uint32_t lo, hi;
+  shard_slice(n_in, TPB / 64, lo, hi);
+  for (uint32_t ri = lo + wv; ri < hi; ri += TPB / 64) {     // one wave per record
+    Walker wk = shard_in_record(io, pre, ri);
     const Row *rp = row_of(g, wk.curr);
     Row r; r.off = 0; r.deg = 0; r.flags = 0;
     if (rp) r = *rp;
     if (r.deg == 0) {
-      if (lane == 0) { Walker dw = wk; dw.wid = -1; out[ri] = dw; }
+      if (lane == 0) { Walker dw = wk; dw.wid = -1; scratch[ri] = dw; }
       if (step > 1) dead += (lane == 0);
       continue;
     }
-    const uint32_t iter = (uint32_t)(first_walk + (int64_t)wk.wid / n_verts_global);
+    const uint32_t iter = (uint32_t)(first_walk + wk.wid % io.batch);
     Bias b = make_bias(g, p, q, wk.prev, step > 1);
     float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
     unsigned f = 0, sv = 0;
-    int32_t k = -1;                                  // same routing as k_walk_general
+    int32_t k = -1, nid = 0;                         // same routing as k_walk_general (no per-edge tables on a shard)
     if (!b.need_member) k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
-    else { unsigned long long ab = 0; unsigned su = 0; int32_t nid = 0; k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem, ab, su, nid); }
+    else { unsigned long long ab = 0; unsigned su = 0; k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem, ab, su, nid); }
     if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
-    int32_t next = g.ent[r.off + k].id;
+    const int32_t next = g.ent[r.off + k].id;
     if (lane == 0) {
-      paths[(int64_t)wk.wid * stride + step] = next;
       Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
-      out[ri] = nw;                                   // in place; dead records carry wid = -1
-      atomicAdd(&cnt[owner_of_tab(next, world, g.owner_tab, g.vmin, g.n_slots)], 1u);
+      scratch[ri] = nw;                                // in place; dead records carry lw = -1
+      if (!last) atomicAdd(&cnt[owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
+      atomicAdd(&cnt[SHARD_MAX_WORLD + owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
       steps += 1; degc += (unsigned long long)r.deg; fb += f;
       if (b.need_member) degp += (unsigned long long)b.prev_deg;
     }
   }
   block_flush_counters(ctr, red, steps, dead, degc, degp, 0, fb);   // contains the __syncthreads() cnt needs
-  if ((int)threadIdx.x < world) blk[(int64_t)blockIdx.x * world + threadIdx.x] = cnt[threadIdx.x];
+  if ((int)threadIdx.x < io.world) {
+    blk[(int64_t)blockIdx.x * 2 * io.world + threadIdx.x] = cnt[threadIdx.x];
+    blk[(int64_t)blockIdx.x * 2 * io.world + io.world + threadIdx.x] = cnt[SHARD_MAX_WORLD + threadIdx.x];
+  }
 }
 
 // p = q = 1 on a shard: one record per lane through the precomputed CDF + guide table.
-__global__ __launch_bounds__(TPB) void k_shard_step_fo(GraphView g, const Walker *__restrict__ in, int64_t n_in,
-                                                       int64_t per_block, int64_t n_verts_global, int32_t first_walk,
-                                                       int32_t step, RngSpec rng, int32_t world,
-                                                       Walker *__restrict__ out, uint32_t *__restrict__ blk,
-                                                       int32_t *__restrict__ paths, int64_t stride, DevCounters *ctr) {
-  __shared__ uint32_t cnt[SHARD_MAX_WORLD];
+__global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
+                                                    RngSpec rng, Walker *__restrict__ scratch, uint32_t *__restrict__ blk,
+                                                    DevCounters *ctr) {
+  __shared__ uint32_t cnt[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
   __shared__ unsigned long long red[6];
-  if (threadIdx.x < SHARD_MAX_WORLD) cnt[threadIdx.x] = 0u;
+  if (threadIdx.x < 2 * SHARD_MAX_WORLD) cnt[threadIdx.x] = 0u;
   if (threadIdx.x < 6) red[threadIdx.x] = 0ull;
-  __syncthreads();
+  const uint32_t n_in = shard_in_prefix(io, pre);
   unsigned long long steps = 0, dead = 0, reads = 0, fb = 0;
-  const int64_t lo = blockIdx.x * per_block, hi = min(n_in, lo + per_block);
-  for (int64_t base = lo; base < hi; base += TPB) {
-    const int64_t ri = base + threadIdx.x;
-    int32_t o = -1;
+  uint32_t lo, hi;
+  shard_slice(n_in, TPB, lo, hi);
+  for (uint32_t base = lo; base < hi; base += TPB) {
+    const uint32_t ri = base + threadIdx.x;
+    int32_t o = -1, hm = -1;
     if (ri < hi) {
-      Walker wk = in[ri];
+      Walker wk = shard_in_record(io, pre, ri);
       const Row *rp = row_of(g, wk.curr);
       Row r; r.off = 0; r.deg = 0; r.flags = 0;
       if (rp) r = *rp;
       if (r.deg == 0) {
         if (step > 1) ++dead;
-        Walker dw = wk; dw.wid = -1; out[ri] = dw;
+        Walker dw = wk; dw.wid = -1; scratch[ri] = dw;
       } else {
-        const uint32_t iter = (uint32_t)(first_walk + (int64_t)wk.wid / n_verts_global);
+        const uint32_t iter = (uint32_t)(first_walk + wk.wid % io.batch);
         float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
         int32_t next;
         if (r.flags & ROW_IRREGULAR) {
@@ -563,87 +640,101 @@ __global__ __launch_bounds__(TPB) void k_shard_step_fo(GraphView g, const Walker
           FoEnt e = fo_pick<false>(g.fo + r.off, r.deg, u, k, rd); reads += rd;
           next = e.id;
         }
-        paths[(int64_t)wk.wid * stride + step] = next;
         Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
-        out[ri] = nw;
+        scratch[ri] = nw;
         ++steps;
-        o = owner_of_tab(next, world, g.owner_tab, g.vmin, g.n_slots);
+        if (!last) o = owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots);
+        hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
       }
     }
-    for (int32_t d = 0; d < world; ++d) {               // one LDS atomic per wave and destination
-      const unsigned long long m = __ballot(o == d);
-      if (m && lane_id() == 0) atomicAdd(&cnt[d], (uint32_t)__popcll(m));
+    for (int32_t d = 0; d < io.world; ++d) {               // one LDS atomic per wave, destination and kind
+      const unsigned long long m = __ballot(o == d), mh = __ballot(hm == d);
+      if (lane_id() == 0) {
+        if (m) atomicAdd(&cnt[d], (uint32_t)__popcll(m));
+        if (mh) atomicAdd(&cnt[SHARD_MAX_WORLD + d], (uint32_t)__popcll(mh));
+      }
     }
   }
   block_flush_counters(ctr, red, steps, dead, 0, 0, reads, fb);
-  if ((int)threadIdx.x < world) blk[(int64_t)blockIdx.x * world + threadIdx.x] = cnt[threadIdx.x];
+  if ((int)threadIdx.x < io.world) {
+    blk[(int64_t)blockIdx.x * 2 * io.world + threadIdx.x] = cnt[threadIdx.x];
+    blk[(int64_t)blockIdx.x * 2 * io.world + io.world + threadIdx.x] = cnt[SHARD_MAX_WORLD + threadIdx.x];
+  }
 }
 
-// blk[b][d] (counts) -> blk[b][d] (write cursor of block b inside the output, destinations laid out in rank order);
-// totals[d] = records for destination d.  One block; wave w handles destinations w, w + nwaves, ...
-__global__ void k_shard_offsets(uint32_t *__restrict__ blk, int32_t n_blocks, int32_t world, unsigned long long *totals) {
-  __shared__ unsigned long long tot[SHARD_MAX_WORLD], basev[SHARD_MAX_WORLD];
+// blk[b][col] (counts) -> blk[b][col] (write cursor of block b inside chunk col's record array); the chunk headers get
+// the totals (clamped to the capacity, overflow flagged).  One block; wave w handles columns w, w + nwaves, ...
+__global__ void k_sh_offsets(uint32_t *__restrict__ blk, int32_t n_blocks, ShardIO io, ShardDst dst, uint32_t *overflow) {
   const int lane = lane_id(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int per = (n_blocks + 63) / 64;
-  for (int d = wv; d < world; d += nw) {
-    unsigned long long s = 0;
-    for (int i = 0; i < per; ++i) { const int b = lane * per + i; if (b < n_blocks) s += blk[(int64_t)b * world + d]; }
-    s = wave_sum_u64(s);
-    if (lane == 0) tot[d] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long acc = 0;
-    for (int d = 0; d < world; ++d) { basev[d] = acc; acc += tot[d]; totals[d] = tot[d]; }
-  }
-  __syncthreads();
-  for (int d = wv; d < world; d += nw) {
+  const int per = (n_blocks + 63) / 64, cols = 2 * io.world;
+  for (int col = wv; col < cols; col += nw) {
     unsigned long long loc = 0;
-    for (int i = 0; i < per; ++i) { const int b = lane * per + i; if (b < n_blocks) loc += blk[(int64_t)b * world + d]; }
+    for (int i = 0; i < per; ++i) { const int b = lane * per + i; if (b < n_blocks) loc += blk[(int64_t)b * cols + col]; }
     unsigned long long incl = loc;
     for (int o = 1; o < 64; o <<= 1) { unsigned long long t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    unsigned long long run = basev[d] + incl - loc;
+    unsigned long long run = incl - loc;
     for (int i = 0; i < per; ++i) {
       const int b = lane * per + i;
-      if (b < n_blocks) { const uint32_t c = blk[(int64_t)b * world + d]; blk[(int64_t)b * world + d] = (uint32_t)run; run += c; }
+      if (b < n_blocks) { const uint32_t c = blk[(int64_t)b * cols + col]; blk[(int64_t)b * cols + col] = (uint32_t)run; run += c; }
+    }
+    const unsigned long long total = (unsigned long long)__shfl((long long)incl, 63);
+    if (lane == 0) {
+      const bool rets = col >= io.world;
+      const int d = rets ? col - io.world : col;
+      const uint32_t cap = (uint32_t)(rets ? io.cap_r : io.cap_w);
+      uint32_t *h = reinterpret_cast<uint32_t *>(dst.p[d]);
+      h[rets ? 1 : 0] = (uint32_t)(total < cap ? total : cap);
+      if (total > cap) atomicOr(overflow, 1u);
     }
   }
 }
 
-__global__ __launch_bounds__(TPB) void k_shard_bucket(GraphView g, const Walker *__restrict__ recs, int64_t n,
-                                                      int64_t per_block, int32_t world, const uint32_t *__restrict__ blk,
-                                                      Walker *__restrict__ out) {
-  __shared__ uint32_t cur[SHARD_MAX_WORLD];
-  if ((int)threadIdx.x < world) cur[threadIdx.x] = blk[(int64_t)blockIdx.x * world + threadIdx.x];
+__global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int32_t unit, int32_t last,
+                                                   const Walker *__restrict__ recs, const uint32_t *__restrict__ blk, ShardDst dst) {
+  __shared__ uint32_t cur[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
+  const uint32_t n_in = shard_in_prefix(io, pre);
+  if ((int)threadIdx.x < io.world) {
+    cur[threadIdx.x] = blk[(int64_t)blockIdx.x * 2 * io.world + threadIdx.x];
+    cur[SHARD_MAX_WORLD + threadIdx.x] = blk[(int64_t)blockIdx.x * 2 * io.world + io.world + threadIdx.x];
+  }
   __syncthreads();
   const int lane = lane_id();
-  const int64_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
-  for (int64_t base = lo; base < hi; base += TPB) {
-    const int64_t i = base + threadIdx.x;
+  uint32_t lo, hi;
+  shard_slice(n_in, (uint32_t)unit, lo, hi);
+  for (uint32_t base = lo; base < hi; base += TPB) {
+    const uint32_t i = base + threadIdx.x;
     Walker w; w.wid = -1; w.src = 0; w.prev = 0; w.curr = 0;
-    int32_t o = -1;
-    if (i < hi) { w = recs[i]; if (w.wid >= 0) o = owner_of_tab(w.curr, world, g.owner_tab, g.vmin, g.n_slots); }
-    for (int32_t d = 0; d < world; ++d) {
-      const unsigned long long m = __ballot(o == d);
-      if (!m) continue;
-      uint32_t b0 = 0;
-      const int leader = __ffsll((long long)m) - 1;
-      if (lane == leader) b0 = atomicAdd(&cur[d], (uint32_t)__popcll(m));
-      b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
-      if (o == d) out[(uint64_t)b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
+    int32_t o = -1, hm = -1;
+    if (i < hi) {
+      w = recs[i];
+      if (w.wid >= 0) {
+        if (!last) o = owner_of_tab(w.curr, io.world, g.owner_tab, g.vmin, g.n_slots);
+        hm = owner_of_tab(w.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+      }
     }
-  }
-}
-
-__global__ void k_shard_seed(const int32_t *__restrict__ verts, const int32_t *__restrict__ vrank, int64_t n_local,
-                             int64_t n_verts_global, int32_t iter_in_call, Walker *__restrict__ out,
-                             int32_t *__restrict__ paths, int64_t stride) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_local; i += (int64_t)gridDim.x * blockDim.x) {
-    Walker w;
-    w.wid = (int32_t)((int64_t)iter_in_call * n_verts_global + vrank[i]);
-    w.src = verts[i]; w.prev = verts[i]; w.curr = verts[i];
-    out[i] = w;
-    if (paths) paths[(int64_t)w.wid * stride] = w.src;
+    for (int32_t d = 0; d < io.world; ++d) {
+      const unsigned long long m = __ballot(o == d);
+      if (m) {
+        uint32_t b0 = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) b0 = atomicAdd(&cur[d], (uint32_t)__popcll(m));
+        b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
+        const uint32_t pos = b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (o == d && pos < (uint32_t)io.cap_w) reinterpret_cast<Walker *>(dst.p[d] + 16)[pos] = w;
+      }
+      const unsigned long long mh = __ballot(hm == d);
+      if (mh) {
+        uint32_t b0 = 0;
+        const int leader = __ffsll((long long)mh) - 1;
+        if (lane == leader) b0 = atomicAdd(&cur[SHARD_MAX_WORLD + d], (uint32_t)__popcll(mh));
+        b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
+        const uint32_t pos = b0 + (uint32_t)__popcll(mh & ((1ull << lane) - 1ull));
+        if (hm == d && pos < (uint32_t)io.cap_r) {
+          PathRet r; r.lw = w.wid; r.v = w.curr;
+          reinterpret_cast<PathRet *>(dst.p[d] + 16 + (int64_t)io.cap_w * 16)[pos] = r;
+        }
+      }
+    }
   }
 }
 
@@ -1051,74 +1142,110 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   s->kernel_ms = ms; s->setup_ms = setup_ms; s->n_walkers = (int64_t)P.num_walks * nv; s->kernel_kind = li.kind; s->record_bytes = li.record_bytes;
 }
 
-void run_shard_seed(srw_handle *h, int32_t iter_in_call, Walker *d_out, int64_t *n_out, int32_t *d_paths,
-                    int64_t stride) {
-  Graph &g = h->g;
-  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
-  int64_t n = g.n_local_vertices;
-  if (n > 0) {
-    int blocks = (int)std::min<int64_t>((n + TPB - 1) / TPB, 8192);
-    hipLaunchKernelGGL(k_shard_seed, dim3(blocks), dim3(TPB), 0, h->stream, g.verts.p, g.vrank.p, n, g.n_vertices,
-                       iter_in_call, d_out, d_paths, stride);
-    SRW_HIP(hipGetLastError());
-  }
-  SRW_HIP(hipStreamSynchronize(h->stream));
-  *n_out = n;
+// ---- vertex-sharded walk: host side of one rank (see the kernels above) -------------------------------------------
+void shard_layout(const srw_handle *h, int32_t batch, double slack, srw_shard_layout *out) {
+  const int64_t world = h->cfg.world;
+  if (batch < 1) throw Error(SRW_ERR_INVALID, "batch must be >= 1");
+  if (!(slack >= 1.0)) slack = 1.25;
+  // walkers alive at any time <= batch * nVertices, spread over world^2 (sender, receiver) pairs; owner = id mod world
+  // (or the recorded partition) mixes hubs and leaves, so the pairs are even up to sampling noise
+  const double per_pair = (double)batch * (double)h->g.n_vertices / (double)(world * world);
+  const int64_t cap = (int64_t)(per_pair * slack) + 4096;
+  if (cap >= ((int64_t)1 << 31) / 16) throw Error(SRW_ERR_INVALID, "shard chunk too large: lower the batch");
+  out->cap_walkers = cap; out->cap_rets = cap;
+  out->chunk_bytes = 16 + cap * 16 + cap * 8;
 }
 
-void run_shard_step(srw_handle *h, const srw_walk_params &P, int32_t iter, int32_t step, const Walker *d_in,
-                    int64_t n_in, Walker *d_out, int64_t *counts_out, int32_t *d_paths, int64_t stride,
-                    srw_walk_stats *stats) {
-  (void)iter;
+namespace {
+ShardIO make_io(const srw_handle *h, int32_t batch, const srw_shard_layout &lay, const void *d_recv) {
+  ShardIO io;
+  io.recv = (const char *)d_recv; io.chunk_bytes = lay.chunk_bytes; io.cap_w = (int32_t)lay.cap_walkers; io.cap_r = (int32_t)lay.cap_rets;
+  io.world = h->cfg.world; io.rank = h->cfg.rank; io.batch = batch;
+  return io;
+}
+void check_shard(const srw_handle *h, int32_t batch, const srw_shard_layout &lay) {
+  if (!h->g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
+  if (h->cfg.world > SHARD_MAX_WORLD) throw Error(SRW_ERR_INVALID, "world larger than 64 shards");
+  if (batch < 1 || lay.cap_walkers < 1 || lay.cap_rets < 1 || lay.chunk_bytes != 16 + lay.cap_walkers * 16 + lay.cap_rets * 8)
+    throw Error(SRW_ERR_INVALID, "bad shard layout");
+  if ((int64_t)batch * h->g.n_local_vertices >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "batch * local vertices must stay below 2^31");
+}
+}  // namespace
+
+// Seeds this rank's batch * n_local walkers into its receive buffer, path slot 0 and lens; clears the counters.
+void run_shard_begin(srw_handle *h, int32_t batch, const srw_shard_layout &lay, void *d_recv, int32_t *d_paths, int32_t *d_lens,
+                     int64_t stride) {
+  check_shard(h, batch, lay);
   Graph &g = h->g;
-  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
-  check_params(P);
-  const int32_t world = h->cfg.world;
-  if (world > SHARD_MAX_WORLD) throw Error(SRW_ERR_INVALID, "world larger than 64 shards");
-  if (n_in >= ((int64_t)1 << 32)) throw Error(SRW_ERR_INVALID, "more than 2^32 records in one super-step");
   hipStream_t st = h->stream;
+  const int64_t n = g.n_local_vertices * batch;
   h->counters.ensure(1);
-  h->shard_counts.ensure((size_t)world);
+  h->shard_flag.ensure(1);
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
-  std::vector<unsigned long long> counts((size_t)world, 0ull);
-  srw_walk_stats local; srw_walk_stats *s = stats ? stats : &local; memset(s, 0, sizeof(*s));
-  if (n_in > 0) {
-    h->shard_scratch.ensure((size_t)n_in);
-    Walker *scratch = h->shard_scratch.p;
-    RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
-    const bool first_order = P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL);
-    if (first_order) build_first_order_tables(h, true);
-    else {
-      build_membership(h);
-      if (!(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX)) build_pq_tables(h, P.p, P.q);
-      else h->g.has_pq = false;
-    }
-    // fixed grid: every block owns one contiguous slice of the records in all three kernels
-    const int64_t unit = first_order ? TPB : TPB / 64;          // records one block handles per sweep
-    const int32_t n_blocks = (int32_t)std::min<int64_t>((n_in + unit - 1) / unit, (int64_t)h->n_cus * 4);
-    int64_t per_block = (n_in + n_blocks - 1) / n_blocks;
-    per_block = (per_block + TPB - 1) / TPB * TPB;
-    h->shard_blk.ensure((size_t)n_blocks * world);
-    SRW_HIP(hipEventRecord(h->ev0, st));
-    if (first_order)
-      hipLaunchKernelGGL(k_shard_step_fo, dim3((unsigned)n_blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, per_block, g.n_vertices,
-                         P.first_walk, step, rng, world, scratch, h->shard_blk.p, d_paths, stride, h->counters.p);
-    else
-      hipLaunchKernelGGL(k_shard_step, dim3((unsigned)n_blocks), dim3(TPB), 0, st, g.view(), d_in, n_in, per_block, g.n_vertices,
-                         P.first_walk, step, rng, P.p, P.q, world, scratch, h->shard_blk.p, d_paths, stride, h->counters.p);
-    SRW_HIP(hipEventRecord(h->ev1, st));
-    hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(1024), 0, st, h->shard_blk.p, n_blocks, world, h->shard_counts.p);
-    hipLaunchKernelGGL(k_shard_bucket, dim3((unsigned)n_blocks), dim3(TPB), 0, st, g.view(), scratch, n_in, per_block, world,
-                       h->shard_blk.p, d_out);
-    SRW_HIP(hipGetLastError());
-    SRW_HIP(hipMemcpyAsync(counts.data(), h->shard_counts.p, 8 * world, hipMemcpyDeviceToHost, st));
-    SRW_HIP(hipStreamSynchronize(st));                          // the only host sync of the super-step
-    float ms = 0.f; SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    s->kernel_ms = ms;
+  SRW_HIP(hipMemsetAsync(h->shard_flag.p, 0, 4, st));
+  if (n > 0) SRW_HIP(hipMemsetAsync(d_paths, 0xFF, (size_t)n * stride * 4, st));     // -1: unused tail
+  const ShardIO io = make_io(h, batch, lay, d_recv);
+  const int blocks = (int)std::min<int64_t>(std::max<int64_t>((n + TPB - 1) / TPB, 1), 8192);
+  hipLaunchKernelGGL(k_sh_seed, dim3(blocks), dim3(TPB), 0, st, g.verts.p, g.n_local_vertices, io, (char *)d_recv, d_paths, d_lens, stride);
+  SRW_HIP(hipGetLastError());
+}
+
+// One super-step, enqueued on the handle's stream without any host synchronisation: returns of the previous
+// super-step applied, every incoming walker sampled once, walkers and path returns bucketed into dst[0 .. world).
+void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch, int32_t step, const srw_shard_layout &lay,
+                         const void *d_recv, void *const *dst, int32_t *d_paths, int32_t *d_lens, int64_t stride) {
+  check_shard(h, batch, lay);
+  check_params(P);
+  if (step < 1 || step > P.walk_length + 1) throw Error(SRW_ERR_INVALID, "step out of range");
+  Graph &g = h->g;
+  hipStream_t st = h->stream;
+  const int32_t world = h->cfg.world;
+  const bool first_order = P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL);
+  if (first_order) build_first_order_tables(h, true);
+  else {
+    build_membership(h);
+    if (!(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX)) build_pq_tables(h, P.p, P.q);
+    else g.has_pq = false;
   }
-  read_counters(h, s);
-  s->kernel_kind = (P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL)) ? 1 : 2; s->n_walkers = n_in;
-  for (int r = 0; r < world; ++r) counts_out[r] = (int64_t)counts[r];
+  const ShardIO io = make_io(h, batch, lay, d_recv);
+  ShardDst sd;
+  for (int d = 0; d < SHARD_MAX_WORLD; ++d) sd.p[d] = d < world ? (char *)dst[d] : nullptr;
+  const int n_blocks = h->n_cus * 4;
+  h->shard_scratch.ensure((size_t)world * (size_t)lay.cap_walkers);
+  h->shard_blk.ensure((size_t)n_blocks * 2 * world);
+  h->shard_flag.ensure(1);
+  RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
+  const int32_t last = step == P.walk_length + 1 ? 1 : 0;
+  if (step > 1) hipLaunchKernelGGL(k_sh_apply, dim3(n_blocks), dim3(TPB), 0, st, io, step - 1, d_paths, d_lens, stride);
+  if (first_order)
+    hipLaunchKernelGGL(k_sh_step_fo, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng, h->shard_scratch.p,
+                       h->shard_blk.p, h->counters.p);
+  else
+    hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng, P.p, P.q,
+                       h->shard_scratch.p, h->shard_blk.p, h->counters.p);
+  hipLaunchKernelGGL(k_sh_offsets, dim3(1), dim3(1024), 0, st, h->shard_blk.p, n_blocks, io, sd, h->shard_flag.p);
+  hipLaunchKernelGGL(k_sh_bucket, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, first_order ? TPB : TPB / 64, last,
+                     h->shard_scratch.p, h->shard_blk.p, sd);
+  SRW_HIP(hipGetLastError());
+}
+
+// After the exchange that follows the last super-step: its path returns.
+void run_shard_flush(srw_handle *h, const srw_walk_params &P, int32_t batch, const srw_shard_layout &lay, const void *d_recv,
+                     int32_t *d_paths, int32_t *d_lens, int64_t stride) {
+  check_shard(h, batch, lay);
+  const ShardIO io = make_io(h, batch, lay, d_recv);
+  hipLaunchKernelGGL(k_sh_apply, dim3(h->n_cus * 4), dim3(TPB), 0, h->stream, io, P.walk_length + 1, d_paths, d_lens, stride);
+  SRW_HIP(hipGetLastError());
+}
+
+// Synchronises the handle's stream; counters accumulated since run_shard_begin and the overflow flag.
+void run_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow) {
+  srw_walk_stats local; srw_walk_stats *s = stats ? stats : &local; memset(s, 0, sizeof(*s));
+  uint32_t flag = 0;
+  h->shard_flag.ensure(1);
+  SRW_HIP(hipMemcpyAsync(&flag, h->shard_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
+  read_counters(h, s);                                  // synchronises
+  if (overflow) *overflow = (int32_t)flag;
 }
 
 void hook_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index) {

@@ -1,59 +1,80 @@
-"""Vertex-sharded multi-GPU walk: one process per GPU, walkers exchanged by all-to-all each super-step.
+"""Vertex-sharded multi-GPU walk, one process per GPU: walkers exchanged by ONE all-to-all per super-step.
 
 Replaces the Spark shuffle of the reference's super-step loop
 (M/algorithm/RandomWalk.scala:91-162: prepareWalkersToTransfer -> partitionBy(HashPartitioner) -> zipPartitions,
 UniformRandomWalk.scala:103-112): the graph is sharded by source vertex, owner(v) = nonNegativeMod(v, world)
-(RandomWalk.scala:16), and a walker standing on v is processed by owner(v).
+(RandomWalk.scala:16) or the VCut partition ids, and a walker standing on v is processed by owner(v).
 
-What moves (xGMI, RCCL `all_to_all_single`): fixed 16-byte records {wid, src, prev, curr} — not the path and
-not N(prev) as in the reference (RandomWalk.scala:135).  Every rank writes the vertices it samples into its own
-copy of the path matrix (slot (wid, step) is written by exactly one rank); one MAX all-reduce per walk
-iteration assembles the paths.  Because the RNG is keyed by (iteration, source vertex, step), the result is
-bit-identical to the single-GPU walk for any world size — tests assert exactly that.
+What moves (xGMI, RCCL `all_to_all_single`, equal splits): per (sender, receiver) pair one fixed-capacity chunk
+    { n_walkers, n_rets, 0, 0 } | {lw, src, prev, curr}[cap] | {lw, vertex}[cap]
+— 16-byte walker records (not the path and not N(prev) as in the reference, RandomWalk.scala:135) and 8-byte path returns
+to the walker's HOME rank, which alone stores its path: memory per rank is 1/world of the paths plus 30 B per resident
+walker of chunk buffers.  The counts travel in the chunk headers, so a super-step is: kernels -> one collective -> kernels,
+with no host synchronisation; an overflowing chunk raises a flag that is read once per batch (retry with more slack).
+Because the RNG is keyed by (iteration, source vertex, step), the result is bit-identical to the single-GPU walk for any
+world size — tests assert exactly that.
 
 q != 1 needs N(prev), which lives on owner(prev): every shard therefore also keeps a replicated *membership
 structure* of the whole graph (row boundaries + sorted neighbor ids, 4 B/entry; graph_build.hip), so the p/q bias is
 evaluated locally and the exchanged record stays 16 bytes — see DESIGN.md §6.
 
-The step engine is injectable so that the exchange protocol can be tested with the gloo backend on CPU (the
-tests plug the CPU oracle in; the product default is the HIP engine, which needs a GPU).
+The same kernels serve the single-process form (csrc/cluster.cpp: peer stores instead of the collective).  The step
+engine is injectable so that this driver's protocol can be tested with the gloo backend on CPU (the tests plug the CPU
+oracle in; the product default is the HIP engine, which needs a GPU).
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import Engine, WalkStats, lib, OK, SrwError
-
-UNWRITTEN = -(2 ** 31)  # path-slot filler for the MAX-combine (every real id is larger)
+from . import Engine, ShardLayout, WalkStats, lib
 
 
 class HipShardEngine:
     """Thin adapter: srw_shard_* on torch CUDA tensors (device pointers), kernels on torch's current stream."""
 
     def __init__(self, device, rank, world, owner_from_partitions=False):
-        self.engine = Engine(device=device, rank=rank, world=world, owner_from_partitions=owner_from_partitions)
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
+        torch.zeros(1, device=self.device)       # torch's device context first (it ships its own HIP runtime)
+        self.engine = Engine(device=device, rank=rank, world=world, owner_from_partitions=owner_from_partitions)
         self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.world = world
 
     def capacity(self):
         return self.engine.shard_capacity()
 
-    def seed(self, iter_in_call, out, paths, stride):
-        n = C.c_int64(0)
-        self.engine._ck(lib().srw_shard_seed(self.engine.h, iter_in_call, C.c_void_p(out.data_ptr()), C.byref(n),
-                                             C.c_void_p(paths.data_ptr()), stride))
-        return n.value
+    def vertex_ranks(self):
+        n = self.capacity()[0]
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        self.engine._ck(lib().srw_shard_vertex_ranks(self.engine.h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out[:n]
 
-    def step(self, params, iteration, step, recs_in, n_in, recs_out, paths, stride, world):
-        counts = (C.c_int64 * world)()
-        st = WalkStats()
-        self.engine._ck(lib().srw_shard_step(self.engine.h, C.byref(params), iteration, step,
-                                             C.c_void_p(recs_in.data_ptr()), n_in, C.c_void_p(recs_out.data_ptr()),
-                                             counts, C.c_void_p(paths.data_ptr()), stride, C.byref(st)))
-        return list(counts), st.as_dict()
+    def layout(self, batch, slack):
+        lay = ShardLayout()
+        self.engine._ck(lib().srw_shard_layout_for(self.engine.h, batch, float(slack), C.byref(lay)))
+        return lay
+
+    def begin(self, P, batch, lay, recv, paths, lens):
+        self.engine._ck(lib().srw_shard_begin(self.engine.h, C.byref(P), batch, C.byref(lay), C.c_void_p(recv.data_ptr()),
+                                              C.c_void_p(paths.data_ptr()), C.c_void_p(lens.data_ptr())))
+
+    def superstep(self, P, batch, step, lay, recv, send, paths, lens):
+        dst = (C.c_void_p * self.world)(*[C.c_void_p(send.data_ptr() + d * lay.chunk_bytes) for d in range(self.world)])
+        self.engine._ck(lib().srw_shard_superstep(self.engine.h, C.byref(P), batch, step, C.byref(lay),
+                                                  C.c_void_p(recv.data_ptr()), dst, C.c_void_p(paths.data_ptr()),
+                                                  C.c_void_p(lens.data_ptr())))
+
+    def flush(self, P, batch, lay, recv, paths, lens):
+        self.engine._ck(lib().srw_shard_flush(self.engine.h, C.byref(P), batch, C.byref(lay), C.c_void_p(recv.data_ptr()),
+                                              C.c_void_p(paths.data_ptr()), C.c_void_p(lens.data_ptr())))
+
+    def finish(self):
+        st, of = WalkStats(), C.c_int32(0)
+        self.engine._ck(lib().srw_shard_finish(self.engine.h, C.byref(st), C.byref(of)))
+        return st.as_dict(), of.value
 
 
 class ShardedWalker:
@@ -65,6 +86,7 @@ class ShardedWalker:
                                                                             owner_from_partitions)
         self.engine = getattr(self.se, "engine", None)
         self.device = self.se.device
+        self._bufs = {}
 
     # ---- graph (each rank keeps only the rows it owns) ----
     def generate_rmat(self, scale, n_edges=None, seed=42, weighted=False, directed=False):
@@ -79,71 +101,107 @@ class ShardedWalker:
         self.engine.load_coo(src, dst, w, pid=pid, directed=directed)
         return self
 
+    def _buffers(self, nbytes):
+        b = self._bufs.get("x")
+        if b is None or b[0].numel() < nbytes:
+            b = (torch.empty(nbytes, dtype=torch.uint8, device=self.device), torch.empty(nbytes, dtype=torch.uint8, device=self.device))
+            self._bufs["x"] = b
+        return b[0][:nbytes], b[1][:nbytes]
+
     # ---- walk_length + 1 super-steps over the walkers of `num_walks` consecutive walk iterations ----
-    def walk_iteration(self, iteration=0, p=1.0, q=1.0, walk_length=80, num_walks=1, seed=42, rng="philox",
-                       const_r=0.0, gather=False):
-        """Walk iterations iteration .. iteration + num_walks - 1 as ONE walker population (walker id =
-        iteration-in-call * nVertices + rank of the source vertex; the step kernels derive the RNG's iteration word
-        from it), so the per-super-step costs (launches, one host sync, two collectives) are paid once per batch."""
-        world = self.world
+    def walk_batch(self, iteration=0, p=1.0, q=1.0, walk_length=80, num_walks=1, seed=42, rng="philox", const_r=0.0,
+                   slack=1.25):
+        """Walk iterations iteration .. iteration + num_walks - 1 as ONE walker population: they share their super-steps,
+        so the per-super-step costs (kernel launches, one collective) are paid once per batch.  Returns (paths, lens, stats)
+        of THIS rank's walkers (device tensors; row lw = local vertex lw // num_walks, iteration lw % num_walks)."""
+        world, B = self.world, num_walks
         n_local, n_global = self.se.capacity()
-        if num_walks * n_global >= 2 ** 31:
-            raise SrwError(-1, "num_walks * nVertices must stay below 2^31 per batch")
         stride = walk_length + 2
-        P = Engine.params(p=p, q=q, walk_length=walk_length, num_walks=1, first_walk=iteration, rng=rng,
-                          const_r=const_r, seed=seed)
+        P = Engine.params(p=p, q=q, walk_length=walk_length, num_walks=B, first_walk=iteration, rng=rng, const_r=const_r, seed=seed)
         dev = self.device
-        n_walkers = num_walks * n_global
-        paths = torch.full((n_walkers, stride), UNWRITTEN, dtype=torch.int32, device=dev)
-        cap = max(n_walkers, 1)
-        cur = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-        out = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-        n = 0
-        for b in range(num_walks):
-            n += self.se.seed(b, cur[n:], paths, stride)
-        tot = {"n_steps": 0, "dead_ends": 0, "kernel_ms": 0.0, "sum_deg_curr": 0, "exchanged": 0}
-        for step in range(1, walk_length + 2):
-            counts, st = self.se.step(P, iteration, step, cur, n, out, paths, stride, world)
-            tot["n_steps"] += st["n_steps"]
-            tot["dead_ends"] += st["dead_ends"]
-            tot["kernel_ms"] += st["kernel_ms"]
-            tot["sum_deg_curr"] += st["sum_deg_curr"]
-            # 1) counts: who sends how many records to whom
-            send = torch.tensor(counts, dtype=torch.int64, device=dev)
-            recv = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_to_all_single(recv, send, group=self.group)
-            recv_counts = recv.tolist()
-            n_next = int(sum(recv_counts))
-            tot["exchanged"] += int(sum(counts)) - counts[self.rank]
-            # 2) records: all-to-all-v of 16-byte rows (out is grouped by owner(next) in rank order)
-            n_send = int(sum(counts))
-            dist.all_to_all_single(cur[:n_next], out[:n_send], output_split_sizes=recv_counts,
-                                   input_split_sizes=counts, group=self.group)
-            n = n_next
-        # assemble: slot (wid, step) was written by exactly one rank
-        dist.all_reduce(paths, op=dist.ReduceOp.MAX, group=self.group)
-        t = torch.tensor([tot["n_steps"], tot["dead_ends"]], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, group=self.group)
-        tot["n_steps_global"], tot["dead_ends_global"] = int(t[0]), int(t[1])
-        if gather:
-            written = paths != UNWRITTEN
-            lens = written.sum(dim=1).to(torch.int32)
-            paths = torch.where(written, paths, torch.full_like(paths, -1))
-            return paths.cpu().numpy(), lens.cpu().numpy(), tot
-        return tot
+        paths = torch.empty((max(B * n_local, 1), stride), dtype=torch.int32, device=dev)
+        lens = torch.empty(max(B * n_local, 1), dtype=torch.int32, device=dev)
+        while True:
+            lay = self.se.layout(B, slack)
+            recv, send = self._buffers(world * lay.chunk_bytes)
+            self.se.begin(P, B, lay, recv, paths, lens)
+            for step in range(1, walk_length + 2):
+                self.se.superstep(P, B, step, lay, recv, send, paths, lens)
+                dist.all_to_all_single(recv, send, group=self.group)       # chunk (me -> d) -> rank d's slot `me`
+            self.se.flush(P, B, lay, recv, paths, lens)
+            st, overflow = self.se.finish()
+            t = torch.tensor([st["n_steps"], st["dead_ends"], overflow], dtype=torch.int64, device=dev)
+            tot = t.clone()
+            dist.all_reduce(tot, group=self.group)
+            if int(tot[2]) == 0:
+                break
+            slack *= 2.0                                  # a chunk was too small somewhere: every rank retries together
+            if slack > 64:
+                raise RuntimeError("vertex-sharded walk: chunk overflow persists at 64x slack")
+        st["n_steps_global"], st["dead_ends_global"] = int(tot[0]), int(tot[1])
+        st["exchange_bytes_per_superstep"] = world * lay.chunk_bytes
+        return paths[:B * n_local], lens[:B * n_local], st
 
     def walk(self, num_walks=1, first_walk=0, batch=None, **kw):
-        """num_walks iterations; returns (paths [num_walks * nV, L + 2], lens, stats) on every rank.  `batch` walk
-        iterations share their super-steps (default: as many as keep the path matrix under 8 GiB)."""
-        _, n_global = self.se.capacity()
+        """num_walks iterations; returns (paths [num_walks * nV, L + 2], lens, stats) in canonical order on every rank
+        (all-gathered: tests and small graphs; production keeps the paths on their home ranks, see walk_batch)."""
+        n_local, n_global = self.se.capacity()
         stride = kw.get("walk_length", 80) + 2
         if batch is None:
-            batch = max(1, min(num_walks, (8 << 30) // max(1, n_global * stride * 4), (2 ** 31 - 1) // max(1, n_global)))
-        ps, ls, stats = [], [], []
+            batch = max(1, min(num_walks, (1 << 30) // max(1, (n_global // self.world + 1) * 30)))
+        vr = torch.as_tensor(self.se.vertex_ranks().astype(np.int64), device=self.device)
+        out_p = torch.full((num_walks * n_global, stride), -1, dtype=torch.int32, device=self.device)
+        out_l = torch.zeros(num_walks * n_global, dtype=torch.int32, device=self.device)
+        stats = []
         for it in range(0, num_walks, batch):
             b = min(batch, num_walks - it)
-            pth, ln, st = self.walk_iteration(iteration=first_walk + it, num_walks=b, gather=True, **kw)
-            ps.append(pth)
-            ls.append(ln)
+            pth, ln, st = self.walk_batch(iteration=first_walk + it, num_walks=b, **kw)
+            lw = torch.arange(b * n_local, device=self.device, dtype=torch.int64)
+            canon = (it + lw % b) * n_global + vr[lw // b] if n_local else lw
+            out_p[canon] = pth
+            out_l[canon] = ln
             stats.append(st)
-        return np.concatenate(ps), np.concatenate(ls), stats
+        # every canonical row is owned by exactly one rank; rows of other ranks are (-1.., 0) here
+        dist.all_reduce(out_l, op=dist.ReduceOp.SUM, group=self.group)
+        out_p += 1                                        # -1 filler -> 0, ids shifted by one: SUM assembles, no sentinel id
+        wide = out_p.to(torch.int64)
+        dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=self.group)
+        # rows owned by nobody else contributed 0 = (-1 + 1) from the other ranks
+        paths = (wide - 1).to(torch.int32)
+        return paths.cpu().numpy(), out_l.cpu().numpy(), stats
+
+
+def bench_vertex_sharded(dist_mod, local_rank, rank, world, scale, n_edges, weighted, directed, walk_kw, K, W, barrier_sync):
+    """bench.py's vertex-sharded leg: K walk iterations (strong scaling: every rank works on every iteration)."""
+    drv = ShardedWalker(device=local_rank, rank=rank, world=world)
+    t0 = time.perf_counter()
+    drv.generate_rmat(scale, n_edges, seed=42, weighted=weighted, directed=directed)
+    nv, ne = drv.engine.stats()
+    n_local, _ = drv.se.capacity()
+    t_graph = time.perf_counter() - t0
+    kw = {k: v for k, v in walk_kw.items() if k in ("p", "q", "walk_length", "seed")}
+    B = max(1, min(K, 4))
+    for it in range(0, W, B):
+        drv.walk_batch(iteration=it, num_walks=min(B, W - it), **kw)
+    if W == 0:
+        drv.walk_batch(iteration=0, num_walks=1, **dict(kw, walk_length=1))     # tables outside the timed region
+    barrier_sync()
+    t0 = time.perf_counter()
+    steps = 0
+    st = None
+    for it in range(W, W + K, B):
+        _, _, st = drv.walk_batch(iteration=it, num_walks=min(B, W + K - it), **kw)
+        steps += st["n_steps_global"]
+    barrier_sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+    max_dt = float(t.item())
+    return {"value": steps / max_dt, "unit": "walk-steps/s", "ms_per_step": max_dt / max(K, 1) * 1e3, "scaling": "strong",
+            "steps": K, "warmup": W, "iterations_per_population": B,
+            "workload": "RMAT scale-%d (%d edge lines, %d adjacency entries, %d vertices), p=%g q=%g walkLength=%d" % (
+                scale, n_edges, ne, nv, kw.get("p", 1.0), kw.get("q", 1.0), kw.get("walk_length", 80)),
+            "parallelism": "graph sharded by source vertex x%d (owner = id mod world), 1 RCCL all_to_all_single per super-step, "
+                           "paths on the home GPU" % world,
+            "local_vertices_rank0": n_local, "exchange_bytes_per_superstep_per_rank": st["exchange_bytes_per_superstep"] if st else 0,
+            "setup_s": {"graph_generate_and_csr": t_graph}}

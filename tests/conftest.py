@@ -22,3 +22,18 @@ def oracle():
     import oracle_py
     oracle_py.lib()
     return oracle_py
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_cuda_first():
+    """torch ships its own HIP runtime next to the system one libstellar_rw.so links; initialise torch's device
+    context BEFORE the product library launches its first kernel (the order bench.py uses), otherwise a later
+    torch.cuda init in the same process can report "No HIP GPUs are available" (seen on the round-2 GPU boxes)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+    yield

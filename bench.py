@@ -137,11 +137,14 @@ def measure(eng, walk_kw, K, W, first_walk=0):
 
 def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L=80):
     """One BASELINE configuration on one GPU: graph generated on the device, W + K walk iterations."""
+    import torch
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng = pkg.Engine(device=device)
     try:
         eng.generate_rmat(scale, ef << scale, seed=42, weighted=weighted, directed=directed)
         nv, ne = eng.stats()
+        torch.cuda.synchronize()                   # device-wide: the build runs on the engine's own stream
         t_graph = time.perf_counter() - t0
         kw = dict(p=p, q=q, walk_length=L, num_walks=1, seed=42)
         if sampler == "alias":
@@ -248,6 +251,7 @@ def main():
         eng = pkg.Engine(device=local_rank)
         eng.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
         nv, ne = eng.stats()
+        torch.cuda.synchronize()
         t_graph = time.perf_counter() - t0
         base = rank * (W + K)  # disjoint walk-iteration indices per rank: numWalks = world * K in total
         t_tables = 0.0

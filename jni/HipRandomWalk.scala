@@ -29,6 +29,10 @@ class HipRandomWalk(config: Params, seed: Int = 42, constR: Option[Float] = None
   @native private def walkAndSave(h: Long, p: Float, q: Float, walkLength: Int, numWalks: Int,
                                   constR: Float, useConst: Boolean, seed: Int, output: String,
                                   parts: Int): Array[Long]
+  @native private def walkAndSaveSharded(devices: Array[Int], input: String, directed: Boolean, weighted: Boolean,
+                                         partitioned: Boolean, rddPartitions: Int, p: Float, q: Float,
+                                         walkLength: Int, numWalks: Int, constR: Float, useConst: Boolean,
+                                         seed: Int, output: String, parts: Int): Array[Long]
   @native private def fetchPaths(h: Long, lens: Array[Int]): Array[Int]
   @native private def neighbors(h: Long, v: Int): Array[Int]
 
@@ -52,6 +56,24 @@ class HipRandomWalk(config: Params, seed: Int = 42, constR: Option[Float] = None
         if (dead(i) > 0) println(s"Zero Neighbors: ${dead(i)}")
       }
     } finally destroy(h)
+  }
+
+  /**
+    * The same job with the graph sharded by source vertex over several GPUs of this node — owner(v) =
+    * nonNegativeMod(v, #GPUs) as HashPartitioner (RandomWalk.scala:16), or the VCut partition ids when
+    * config.partitioned — and the walkers crossing shards every super-step over xGMI: what replaces
+    * transferWalkersToTheirPartitions (RandomWalk.scala:186-192).  Same files as execute().
+    */
+  def executeSharded(output: String, partitions: Int, devices: Seq[Int]): Unit = {
+    val Array(v, e, _, dead) = walkAndSaveSharded((devices :+ -1).toArray, config.input, config.directed, config.weighted,
+      config.partitioned, config.rddPartitions, config.p.toFloat, config.q.toFloat, config.walkLength,
+      config.numWalks, constR.getOrElse(0f), constR.isDefined, seed, output, partitions)
+    nVertices = v
+    nEdges = e
+    println(s"edges: $nEdges")
+    println(s"vertices: $nVertices")
+    for (_ <- 0 until config.numWalks) println("Unfinished Walkers: 0")
+    if (dead > 0) println(s"Zero Neighbors: $dead")
   }
 
   /** randomWalk() with the paths returned to the JVM (e.g. to feed `--cmd node2vec`), one iteration at a time. */

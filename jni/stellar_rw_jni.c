@@ -126,6 +126,52 @@ JNIEXPORT jlongArray JNICALL FN(walkAndSave)(JNIEnv *env, jobject self, jlong hh
   return a;
 }
 
+/* The same job with the graph sharded by source vertex over `devices` GPUs of this node (srw_cluster_*: replaces
+ * transferWalkersToTheirPartitions, RandomWalk.scala:186-192).  Returns (nVertices, nEdges, steps, zeroNeighbors). */
+JNIEXPORT jlongArray JNICALL FN(walkAndSaveSharded)(JNIEnv *env, jobject self, jintArray devices, jstring input, jboolean directed,
+                                                    jboolean weighted, jboolean partitioned, jint rddPartitions, jfloat p, jfloat q,
+                                                    jint walkLength, jint numWalks, jfloat constR, jboolean useConst, jint seed,
+                                                    jstring out, jint parts) {
+  (void)self;
+  jint devs[64];
+  jint n = 0;
+  {
+    jint *d = (jint *)(*env)->GetPrimitiveArrayCritical(env, devices, NULL);
+    if (!d) return NULL;
+    /* the array length is not needed from the JVM: the Scala side passes at most 64 ordinals, terminated by -1 */
+    while (n < 64 && d[n] >= 0) { devs[n] = d[n]; ++n; }
+    (*env)->ReleasePrimitiveArrayCritical(env, devices, d, 0);
+  }
+  srw_cluster *c = NULL;
+  int32_t rc = srw_cluster_create((const int32_t *)devs, n, partitioned ? SRW_CFG_OWNER_FROM_PARTITIONS : 0, &c);
+  if (rc != SRW_OK) { throw_status(env, rc, NULL); return NULL; }
+  jlongArray a = NULL;
+  const char *in = (*env)->GetStringUTFChars(env, input, NULL);
+  const char *o = in ? (*env)->GetStringUTFChars(env, out, NULL) : NULL;
+  if (in && o) {
+    srw_walk_params P; fill_params(&P, p, q, walkLength, numWalks, 0, useConst, constR, seed, 0);
+    srw_walk_stats st; memset(&st, 0, sizeof st);
+    int64_t nv = 0, ne = 0;
+    rc = srw_cluster_load_edgelist(c, in, directed, weighted, partitioned, rddPartitions);
+    if (rc == SRW_OK) rc = srw_cluster_graph_stats(c, &nv, &ne);
+    if (rc == SRW_OK) rc = srw_cluster_walk_and_save(c, &P, o, parts, /*write_crc=*/1, &st);
+    if (rc != SRW_OK) {
+      jclass cls = (*env)->FindClass(env, rc == SRW_ERR_EXISTS ? "org/apache/hadoop/mapred/FileAlreadyExistsException"
+                                          : rc == SRW_ERR_PARSE ? "java/lang/NumberFormatException" : "java/lang/RuntimeException");
+      if (!cls) { (*env)->ExceptionClear(env); cls = (*env)->FindClass(env, "java/lang/RuntimeException"); }
+      if (cls) (*env)->ThrowNew(env, cls, srw_cluster_last_error(c));
+    } else {
+      jlong res[4]; res[0] = (jlong)nv; res[1] = (jlong)ne; res[2] = (jlong)st.n_steps; res[3] = (jlong)st.dead_ends;
+      a = (*env)->NewLongArray(env, 4);
+      if (a) (*env)->SetLongArrayRegion(env, a, 0, 4, res);
+    }
+  }
+  if (o) (*env)->ReleaseStringUTFChars(env, out, o);
+  if (in) (*env)->ReleaseStringUTFChars(env, input, in);
+  srw_cluster_destroy(c);
+  return a;
+}
+
 /* paths of the last walk as a flat int[] of nWalkers * (walkLength + 2) ids (-1 padded) for callers that feed the
  * embedding stage in-process; lens = path lengths */
 JNIEXPORT jintArray JNICALL FN(fetchPaths)(JNIEnv *env, jobject self, jlong hh, jintArray lensOut) {

@@ -210,7 +210,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().srw_destroy(self.h)
+            if getattr(self, "_owned", True):
+                lib().srw_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -481,6 +482,14 @@ class Cluster:
         v, e = C.c_int64(0), C.c_int64(0)
         self._ck(lib().srw_cluster_graph_stats(self.h, C.byref(v), C.byref(e)))
         return v.value, e.value
+
+    def shard(self, rank):
+        """Non-owning Engine view of one shard's handle (graph queries, tests)."""
+        e = Engine.__new__(Engine)
+        e.h = C.c_void_p(lib().srw_cluster_shard(self.h, rank))
+        e._owned = False
+        e.rank, e.world = rank, self.world
+        return e
 
     def walk(self, fetch=True, batch=0, **kw):
         P = Engine.params(**kw)

@@ -74,6 +74,7 @@ std::string CommandParser::usage() {
     << "  --seed <value>           Philox seed of the walk RNG: 42\n"
     << "  --constR <value>         inject a constant nextFloat (test hook of the reference)\n"
     << "  --device <value>         HIP device ordinal: 0\n"
+    << "  --gpus <value>           GPUs of this node to shard the graph over (by source vertex; 1 = whole graph on one GPU): 1\n"
     << "  --crc <value>            also write Hadoop .crc side files: false\n"
     << "  --sampler <value>        reference (bit-identical CDF inversion) | alias (alias tables + rejection): reference\n"
     << "  --deviceFormat <value>   format the path text on the GPU (false: on host threads): true\n";
@@ -94,7 +95,7 @@ std::optional<Params> CommandParser::parse(const std::vector<std::string> &args,
     if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); inline_val = true; }
     static const char *known[] = {WALK_LENGTH, NUM_WALKS, P, Q, RDD_PARTITIONS, WEIGHTED, DIRECTED, SINGLE_OUTPUT,
                                   W2V_PARTITIONS, INPUT, OUTPUT, CMD, PARTITIONED, LEARNING_RATE, ITERATION, DIMENSION,
-                                  WINDOW, "seed", "constR", "device", "crc", "sampler", "deviceFormat"};
+                                  WINDOW, "seed", "constR", "device", "gpus", "crc", "sampler", "deviceFormat"};
     if (std::find_if(std::begin(known), std::end(known), [&](const char *k) { return name == k; }) == std::end(known)) {
       fail("Unknown option " + a);
       continue;
@@ -132,6 +133,7 @@ std::optional<Params> CommandParser::parse(const std::vector<std::string> &args,
     else if (name == "seed") { if (!readLong(val, c.seed)) fail("Option --seed failed when given '" + val + "'"); }
     else if (name == "constR") { double d; if (readDouble(val, d)) { c.constR = (float)d; c.hasConstR = true; } else fail("Option --constR failed when given '" + val + "'"); }
     else if (name == "device") asInt(c.device);
+    else if (name == "gpus") { asInt(c.gpus); if (c.gpus < 1 || c.gpus > 64) fail("Option --gpus must be in 1 .. 64"); }
     else if (name == "crc") asBool(c.crc);
     else if (name == "deviceFormat") asBool(c.deviceFormat);
     else if (name == "sampler") {

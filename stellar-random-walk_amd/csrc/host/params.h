@@ -41,7 +41,8 @@ struct Params {
   int64_t seed = 42;        // --seed: Philox key (the reference's RNG is clock-seeded and not reproducible)
   bool hasConstR = false;   // --constR: inject nextFloat = () => constR, as the reference's tests do
   float constR = 0.0f;
-  int device = 0;           // --device: HIP ordinal
+  int device = 0;           // --device: HIP ordinal (first of --gpus consecutive ordinals)
+  int gpus = 1;             // --gpus: > 1 = graph sharded by source vertex over that many GPUs of this node (srw_cluster_*)
   bool crc = false;         // --crc: also write Hadoop .crc side files
   bool alias = false;       // --sampler alias: Mode A (alias tables + rejection) instead of the reference-exact Mode R
   bool deviceFormat = true;   // --deviceFormat: the GPU formats the path text (SRW_WALK_DEVICE_FORMAT); false = host threads

@@ -135,7 +135,45 @@ Paths RandomWalk::walkImpl(bool useConst, float constR) {
   }
   return out;
 }
+// --gpus N: the graph is sharded by source vertex over N devices of this node and the walkers cross shards every
+// super-step (srw_cluster_*: what replaces transferWalkersToTheirPartitions, RandomWalk.scala:186-192); same files.
+void RandomWalk::executeAndSaveSharded(int partitions, const std::string &output) {
+  std::vector<int32_t> devs;
+  for (int i = 0; i < config_.gpus; ++i) devs.push_back(config_.device + i);
+  srw_cluster *cl = nullptr;
+  if (srw_cluster_create(devs.data(), (int32_t)devs.size(), config_.partitioned ? SRW_CFG_OWNER_FROM_PARTITIONS : 0, &cl) != SRW_OK)
+    throw std::runtime_error(std::string("srw_cluster_create: ") + srw_last_error(nullptr));
+  struct Guard { srw_cluster *c; ~Guard() { srw_cluster_destroy(c); } } guard{cl};
+  auto ckc = [&](int32_t rc, const char *what) {
+    if (rc == SRW_ERR_EXISTS)
+      throw std::runtime_error("org.apache.hadoop.mapred.FileAlreadyExistsException: Output directory " + output + "/" +
+                               common::Property::pathSuffix + " already exists");
+    if (rc != SRW_OK) throw std::runtime_error(std::string(what) + ": " + srw_cluster_last_error(cl));
+  };
+  {
+    Phase ph("loadGraph (parse + upload + device CSR build, one shard per GPU)");
+    ckc(srw_cluster_load_edgelist(cl, config_.input.c_str(), config_.directed, config_.weighted, config_.partitioned ? 1 : 0,
+                                  config_.rddPartitions), "loadGraph");
+    ckc(srw_cluster_graph_stats(cl, &nVertices, &nEdges), "graph stats");
+    if (log_)
+      *log_ << "edges: " << nEdges << "\n" << "vertices: " << nVertices << "\n" << "E Partitions: " << nEdges << "\n"
+            << "V Partitions: " << nVertices << "\n";
+  }
+  Phase ph("randomWalk + save (vertex-sharded super-steps over xGMI, then format + write)");
+  srw_walk_params P{};
+  P.p = (float)config_.p; P.q = (float)config_.q;
+  P.walk_length = config_.walkLength; P.num_walks = config_.numWalks; P.first_walk = 0;
+  P.rng_mode = config_.hasConstR ? SRW_RNG_CONST : SRW_RNG_PHILOX; P.const_r = config_.constR; P.seed = (uint32_t)config_.seed;
+  P.sampler = SRW_SAMPLER_REFERENCE;
+  srw_walk_stats st{};
+  ckc(srw_cluster_walk_and_save(cl, &P, output.c_str(), partitions, config_.crc ? 1 : 0, &st), "randomWalk");
+  if (log_)
+    for (int it = 0; it < config_.numWalks; ++it) *log_ << "Unfinished Walkers: 0\n";
+  if (log_ && st.dead_ends) *log_ << "Wrong Transports: 0\n" << "Zero Neighbors: " << st.dead_ends << "\n";
+}
+
 void RandomWalk::executeAndSave(int partitions, const std::string &output) {
+  if (config_.gpus > 1) { executeAndSaveSharded(partitions, output); return; }
   loadGraph();
   Phase ph("randomWalk + save (kernel / PCIe / format+write pipelined)");
   srw_walk_params P{};

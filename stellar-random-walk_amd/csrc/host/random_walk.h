@@ -84,6 +84,7 @@ class RandomWalk {  // trait RandomWalk
   // loadGraph + randomWalk + save fused and streamed (what Main.doRandomWalk does, M/Main.scala:53-62), without
   // materialising the paths on the host
   void executeAndSave(int partitions, const std::string &output);
+  void executeAndSaveSharded(int partitions, const std::string &output);   // --gpus N > 1 (srw_cluster_*)
   GraphMap graphMap() const { return GraphMap(h_); }
   srw_handle *handle() const { return h_; }
 

@@ -449,13 +449,14 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
 // ranks each super-step is fixed-size records in fixed-capacity CHUNKS, one chunk per (sender, receiver) pair:
 //     chunk = { u32 n_walkers, n_rets, overflow, pad } | Walker[cap_w] {lw, src, prev, curr} | PathRet[cap_r] {lw, v}
 // lw = (local index of the source vertex on its home rank) * batch + (walk iteration inside the batch): the home rank's
-// path row, and lw % batch is the RNG's iteration word.  A rank's receive buffer is `world` chunks (one per sender),
+// path row, and lw % batch is the RNG's iteration word.  A return with the top bit of lw set is a death notice
+// {lw, path length}: lens start at walk_length + 2 and only walkers that stop early are corrected.  A rank's receive buffer is `world` chunks (one per sender),
 // its send side is `world` destination pointers — the local send buffer (one equal-split all_to_all_single moves it,
 // distributed.py) or, inside one process, the peers' receive buffers themselves (xGMI peer stores, cluster.cpp).
 // Everything is sized and counted on the device: NO host synchronisation per super-step; an overflowing chunk drops
 // its surplus and raises a flag the host reads once per walk call (it then retries with more slack).
-//   k_sh_seed    : the rank's own walkers, spread over the chunks of its receive buffer; path slot 0, lens = 1
-//   k_sh_apply   : path returns of the previous super-step -> paths[lw][step - 1], lens[lw] = step
+//   k_sh_seed    : the rank's own walkers, spread over the chunks of its receive buffer; path slot 0, lens = L + 2
+//   k_sh_apply   : path returns of the previous super-step -> paths[lw][step - 1]; death notices -> lens[lw]
 //   k_sh_step(_fo): sample every incoming walker in place into `scratch` (dead ends: lw = -1), count the block's
 //                  survivors per destination owner and the returns per home rank in LDS -> blk[b][2 * world]
 //   k_sh_offsets : one block: scan of blk over the blocks -> every block's write cursors; chunk headers
@@ -533,7 +534,7 @@ __global__ void k_sh_seed(const int32_t *__restrict__ verts, int64_t n_local, Sh
     const int c = (int)(i % io.world);
     reinterpret_cast<Walker *>(recv_w + c * io.chunk_bytes + 16)[i / io.world] = w;
     paths[i * stride] = src;
-    lens[i] = 1;
+    lens[i] = (int32_t)stride;        // full length unless a death notice says otherwise (k_sh_apply)
   }
   if (blockIdx.x == 0 && (int)threadIdx.x < io.world) {
     const int c = (int)threadIdx.x;
@@ -549,8 +550,8 @@ __global__ void k_sh_apply(ShardIO io, int32_t slot, int32_t *__restrict__ paths
     const PathRet *r = chunk_rets(io.recv, io.chunk_bytes, io.cap_w, c);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
       const PathRet x = r[i];
-      paths[(int64_t)x.lw * stride + slot] = x.v;
-      lens[x.lw] = slot + 1;
+      if (x.lw < 0) lens[x.lw & 0x7FFFFFFF] = x.v;             // death notice: the walker stopped with x.v path entries
+      else paths[(int64_t)x.lw * stride + slot] = x.v;
     }
   }
 }
@@ -574,8 +575,11 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
     const Row *rp = row_of(g, wk.curr);
     Row r; r.off = 0; r.deg = 0; r.flags = 0;
     if (rp) r = *rp;
-    if (r.deg == 0) {
-      if (lane == 0) { Walker dw = wk; dw.wid = -1; scratch[ri] = dw; }
+    if (r.deg == 0) {                                  // dead end (or a source without neighbors): tell the home rank the length
+      if (lane == 0) {
+        Walker dw = wk; dw.wid = (int32_t)((uint32_t)wk.wid | 0x80000000u); dw.curr = step; scratch[ri] = dw;
+        atomicAdd(&cnt[SHARD_MAX_WORLD + owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
+      }
       if (step > 1) dead += (lane == 0);
       continue;
     }
@@ -626,7 +630,8 @@ __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int
       if (rp) r = *rp;
       if (r.deg == 0) {
         if (step > 1) ++dead;
-        Walker dw = wk; dw.wid = -1; scratch[ri] = dw;
+        Walker dw = wk; dw.wid = (int32_t)((uint32_t)wk.wid | 0x80000000u); dw.curr = step; scratch[ri] = dw;
+        hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);     // death notice to the home rank
       } else {
         const uint32_t iter = (uint32_t)(first_walk + wk.wid % io.batch);
         float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
@@ -703,14 +708,12 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
   shard_slice(n_in, (uint32_t)unit, lo, hi);
   for (uint32_t base = lo; base < hi; base += TPB) {
     const uint32_t i = base + threadIdx.x;
-    Walker w; w.wid = -1; w.src = 0; w.prev = 0; w.curr = 0;
+    Walker w; w.wid = 0; w.src = 0; w.prev = 0; w.curr = 0;
     int32_t o = -1, hm = -1;
     if (i < hi) {
       w = recs[i];
-      if (w.wid >= 0) {
-        if (!last) o = owner_of_tab(w.curr, io.world, g.owner_tab, g.vmin, g.n_slots);
-        hm = owner_of_tab(w.src, io.world, g.owner_tab, g.vmin, g.n_slots);
-      }
+      if (w.wid >= 0 && !last) o = owner_of_tab(w.curr, io.world, g.owner_tab, g.vmin, g.n_slots);
+      hm = owner_of_tab(w.src, io.world, g.owner_tab, g.vmin, g.n_slots);   // sampled vertex, or (wid < 0) the death notice
     }
     for (int32_t d = 0; d < io.world; ++d) {
       const unsigned long long m = __ballot(o == d);

@@ -328,52 +328,48 @@ def test_cli_end_to_end(oracle, tmp_path):
     assert r2.returncode == 1 and "already exists" in r2.stderr
 
 
-# ---- vertex-sharded path: two shard handles on one GPU, exchange done by hand ---------------------------
-@pytest.mark.parametrize("world,p,q,directed", [(2, 1.0, 1.0, False), (2, 0.5, 1.0, True), (3, 4.0, 1.0, False),
-                                                 (2, 0.25, 4.0, False), (3, 4.0, 0.5, True)])
-def test_sharded_kernels_inprocess_exchange(oracle, world, p, q, directed):
-    import torch
-    from importlib import import_module
-    pkg()
-    sharded = import_module("stellar_random_walk_amd.distributed")
+# ---- vertex-sharded path: several shards on one GPU, the in-process cluster (peer stores + events) -----------------
+@pytest.mark.parametrize("world,p,q,directed", [(1, 1.0, 1.0, False), (2, 1.0, 1.0, False), (2, 0.5, 1.0, True), (3, 4.0, 1.0, False),
+                                                 (2, 0.25, 4.0, False), (3, 4.0, 0.5, True), (8, 1.0, 1.0, True)])
+def test_cluster_inprocess_shards(oracle, world, p, q, directed):
+    """srw_cluster_*: `world` sharded handles on device 0, chunks stored straight into the receiving shard's buffer,
+    super-steps ordered by events, paths kept by the home shard.  Must equal the single-process oracle for every world
+    and every batching of the walk iterations."""
     s, d, w = rmat_lines(oracle, 10, edge_factor=8, weighted=True)
     g = oracle.Graph.from_coo(s, d, w, directed=directed)
-    ses = [sharded.HipShardEngine(0, r, world) for r in range(world)]
-    for se in ses:
-        se.engine.load_coo(s, d, w, directed=directed)
-        assert se.engine.stats() == (g.num_vertices, g.num_entries)      # global counts on every shard
-    assert sum(se.capacity()[0] for se in ses) == g.num_vertices
-    L, it = 9, 4
-    stride, nv = L + 2, g.num_vertices
-    P = pkg().Engine.params(p=p, q=q, walk_length=L, first_walk=it, seed=21)
-    dev = ses[0].device
-    paths = [torch.full((nv, stride), sharded.UNWRITTEN, dtype=torch.int32, device=dev) for _ in range(world)]
-    cur = [torch.empty((nv, 4), dtype=torch.int32, device=dev) for _ in range(world)]
-    out = [torch.empty((nv, 4), dtype=torch.int32, device=dev) for _ in range(world)]
-    n = [ses[r].seed(0, cur[r], paths[r], stride) for r in range(world)]
-    steps = 0
-    for step in range(1, L + 2):
-        res = [ses[r].step(P, it, step, cur[r], n[r], out[r], paths[r], stride, world) for r in range(world)]
-        steps += sum(st["n_steps"] for _, st in res)
-        torch.cuda.synchronize()
-        newn = [0] * world
-        for r in range(world):                       # the all-to-all-v, by hand
-            counts, off = res[r][0], 0
-            for dst in range(world):
-                c = counts[dst]
-                cur[dst][newn[dst]:newn[dst] + c] = out[r][off:off + c]
-                newn[dst] += c
-                off += c
-        torch.cuda.synchronize()
-        n = newn
-    full = torch.stack(paths).max(dim=0).values
-    written = full != sharded.UNWRITTEN
-    lens = written.sum(dim=1).cpu().numpy().astype(np.int32)
-    got = torch.where(written, full, torch.full_like(full, -1)).cpu().numpy()
-    rp, rl, rs = g.walk(p=p, q=q, walk_length=L, first_walk=it, seed=21, threads=8)
-    assert np.array_equal(lens, rl) and np.array_equal(got, rp) and steps == rs
-    for se in ses:
-        se.engine.close()
+    with pkg().Cluster([0] * world) as cl:
+        cl.load_coo(s, d, w, directed=directed)
+        assert cl.stats() == (g.num_vertices, g.num_entries)
+        rp, rl, rs = g.walk(p=p, q=q, walk_length=9, num_walks=3, first_walk=4, seed=21, threads=8)
+        for batch in (0, 1, 2):
+            paths, lens, st = cl.walk(p=p, q=q, walk_length=9, num_walks=3, first_walk=4, seed=21, batch=batch)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (world, batch)
+            assert st["n_steps"] == rs
+        # constant r (the reference tests' injection), L = 0 .. 1
+        for L in (0, 1):
+            rp, rl, rs = g.walk(p=p, q=q, walk_length=L, rng="const", const_r=0.4, threads=8)
+            paths, lens, st = cl.walk(p=p, q=q, walk_length=L, rng="const", const_r=0.4)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs
+
+
+def test_cluster_walk_and_save_and_hub(oracle, tmp_path):
+    """A hub every walker runs into (chunk skew: the overflow retry must kick in or the slack must hold) + the
+    cluster's RandomWalk.save."""
+    n = 20000
+    s = np.concatenate([np.zeros(n, np.int32), np.arange(1, n + 1, dtype=np.int32)])
+    d = np.concatenate([np.arange(1, n + 1, dtype=np.int32), np.roll(np.arange(1, n + 1, dtype=np.int32), 1)])
+    g = oracle.Graph.from_coo(s, d, None, directed=True)                 # leaves point at each other in a ring, 0 -> all
+    with pkg().Cluster([0, 0, 0, 0]) as cl:
+        cl.load_coo(s, d, None, directed=True)
+        rp, rl, rs = g.walk(walk_length=6, num_walks=2, seed=5, threads=8)
+        paths, lens, st = cl.walk(walk_length=6, num_walks=2, seed=5)
+        assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs
+        out = tmp_path / "out"
+        cl.walk_and_save(str(out), n_parts=3, walk_length=6, num_walks=2, seed=5)
+        ref = tmp_path / "ref"
+        oracle.write_paths(rp, rl, str(ref), n_parts=3)
+        for f in sorted(os.listdir(ref / "path")):
+            assert (out / "path" / f).read_bytes() == (ref / "path" / f).read_bytes(), f
 
 
 def test_sharded_walker_world1_nccl(oracle):
@@ -581,53 +577,25 @@ def test_device_formatter_negative_ids_and_long_paths(eng, oracle, tmp_path):
 def test_sharded_by_user_partitions(oracle, tmp_path, world, p, q):
     # VCut input (src dst pId [w]): shards own the vertices of "their" partition (SRW_CFG_OWNER_FROM_PARTITIONS);
     # the walk result must not depend on the partitioning (what T/VCutRandomWalkTest asserts for the reference)
-    import torch
-    from importlib import import_module
-    pkg()
-    sharded = import_module("stellar_random_walk_amd.distributed")
     rng = np.random.default_rng(4)
     s, d, w = rmat_lines(oracle, 9, edge_factor=8, weighted=True)
     pid = rng.integers(0, 5, len(s)).astype(np.int32)                      # 5 user partitions on `world` GPUs
     f = tmp_path / "vcut.txt"
     f.write_text("".join("%d %d %d %g\n" % (a, b, c, x) for a, b, c, x in zip(s, d, pid, w)))
     g = oracle.Graph.load(str(f), partitioned=True)
-    ses = [sharded.HipShardEngine(0, r, world, owner_from_partitions=True) for r in range(world)]
-    for se in ses:
-        se.engine.load_edgelist(str(f), partitioned=True)
-        assert se.engine.stats() == (g.num_vertices, g.num_entries)
-    # ownership follows the recorded partition (last pId seen for the vertex), modulo world
-    owned = [set(se.engine.vertices().tolist()) for se in ses]
-    assert sum(len(o) for o in owned) == g.num_vertices and not (owned[0] & owned[1])
-    for v in list(owned[0])[:50]:
-        assert ses[0].engine.partition(v) % world == 0
-    L, it = 8, 1
-    stride, nv = L + 2, g.num_vertices
-    P = pkg().Engine.params(p=p, q=q, walk_length=L, first_walk=it, seed=33)
-    dev = ses[0].device
-    paths = [torch.full((nv, stride), sharded.UNWRITTEN, dtype=torch.int32, device=dev) for _ in range(world)]
-    cur = [torch.empty((nv, 4), dtype=torch.int32, device=dev) for _ in range(world)]
-    out = [torch.empty((nv, 4), dtype=torch.int32, device=dev) for _ in range(world)]
-    n = [ses[r].seed(0, cur[r], paths[r], stride) for r in range(world)]
-    for step in range(1, L + 2):
-        res = [ses[r].step(P, it, step, cur[r], n[r], out[r], paths[r], stride, world) for r in range(world)]
-        torch.cuda.synchronize()
-        newn = [0] * world
-        for r in range(world):
-            counts, off = res[r][0], 0
-            for dst in range(world):
-                c = counts[dst]
-                cur[dst][newn[dst]:newn[dst] + c] = out[r][off:off + c]
-                newn[dst] += c
-                off += c
-        torch.cuda.synchronize()
-        n = newn
-    full = torch.stack(paths).max(dim=0).values
-    written = full != sharded.UNWRITTEN
-    got = torch.where(written, full, torch.full_like(full, -1)).cpu().numpy()
-    rp, rl, _ = g.walk(p=p, q=q, walk_length=L, first_walk=it, seed=33, threads=8)
-    assert np.array_equal(got, rp) and np.array_equal(written.sum(dim=1).cpu().numpy().astype(np.int32), rl)
-    for se in ses:
-        se.engine.close()
+    P = pkg()
+    with P.Cluster([0] * world, owner_from_partitions=True) as cl:
+        cl.load_edgelist(str(f), partitioned=True)
+        assert cl.stats() == (g.num_vertices, g.num_entries)
+        # ownership follows the recorded partition (last pId seen for the vertex), modulo world
+        shards = [cl.shard(r) for r in range(world)]
+        owned = [set(e.vertices().tolist()) for e in shards]
+        assert sum(len(o) for o in owned) == g.num_vertices and not (owned[0] & owned[1])
+        for v in list(owned[0])[:50]:
+            assert shards[0].partition(v) % world == 0
+        rp, rl, _ = g.walk(p=p, q=q, walk_length=8, first_walk=1, seed=33, threads=8)
+        paths, lens, _ = cl.walk(p=p, q=q, walk_length=8, first_walk=1, seed=33)
+        assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
 
 
 def test_table_variants_agree_beyond_cache_size(eng):

@@ -1,9 +1,10 @@
 """world_size-2 (and 3) gloo tests of the vertex-sharded walk driver on CPU.
 
-The product's step engine is HIP-only; here the CPU oracle is plugged in as the step engine so that the
-exchange protocol (counts all-to-all, record all-to-all-v, MAX path combine) is exercised for real across
-processes.  The sharded result must equal the single-process oracle walk bit for bit (keyed RNG => the result
-does not depend on the number of shards)."""
+The product's step engine is HIP-only; here the CPU oracle is plugged in as the step engine (same chunk format as the HIP
+kernels) so that the driver's protocol — one equal-split all_to_all_single of fixed-capacity chunks per super-step, path
+returns to the home rank, the flush after the last super-step, the overflow retry, the canonical assembly — is exercised
+for real across processes.  The sharded result must equal the single-process oracle walk bit for bit (keyed RNG => the
+result does not depend on the number of shards)."""
 import os
 import socket
 import sys
@@ -47,10 +48,17 @@ def _worker(rank, world, port, directed, p, q, L, rng, out_dir):
         # both iterations shared their super-steps (one population); one iteration per population must give the same
         p1, l1, _ = drv.walk(num_walks=2, first_walk=3, batch=1, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
         assert len(stats) == 1 and np.array_equal(p1, paths) and np.array_equal(l1, lens)
+        # chunks deliberately too small at first: every rank must see the overflow and retry together with more slack
+        drv2 = sharded.ShardedWalker(rank=rank, world=world, step_engine=OracleShardEngine(g, rank, world, tiny_chunks=True))
+        p2, l2, _ = drv2.walk(num_walks=2, first_walk=3, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
+        assert np.array_equal(p2, paths) and np.array_equal(l2, lens)
+        # memory: a rank holds the paths of ITS walkers only
+        pl, ll, _ = drv.walk_batch(iteration=3, num_walks=2, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
+        assert pl.shape[0] == 2 * drv.se.capacity()[0]
         np.save(os.path.join(out_dir, "paths_%d.npy" % rank), paths)
         np.save(os.path.join(out_dir, "lens_%d.npy" % rank), lens)
         np.save(os.path.join(out_dir, "steps_%d.npy" % rank), np.array([sum(s["n_steps_global"] for s in stats),
-                                                                          sum(s["exchanged"] for s in stats)]))
+                                                                          sum(s["exchange_bytes_per_superstep"] for s in stats)]))
     finally:
         dist.destroy_process_group()
 

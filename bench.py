@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--sampler", choices=["reference", "alias"], default="reference")
     ap.add_argument("--shard", choices=["both", "replicate", "vertex"], default="both",
                     help="N > 1: which multi-GPU mode(s) to run; `value` is always the replicated mode when it runs")
+    ap.add_argument("--shard-driver", choices=["cluster", "rccl"], default="cluster",
+                    help="vertex-sharded leg: rank 0 drives all devices in-process (default) or one process per GPU over RCCL")
     ap.add_argument("--nt-loads", type=int, default=-1, help="-1 auto, 0 cached, 1 nontemporal record loads")
     ap.add_argument("--compact", type=int, default=1, help="0: do not use the 16-byte lattice records")
     ap.add_argument("--configs", type=int, default=1, help="1 GPU: also run BASELINE configs C2, C3 (Mode R / A), C5 stand-in")
@@ -216,10 +218,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        import datetime
+        tmo = datetime.timedelta(minutes=30)     # the other ranks wait at a barrier while rank 0 runs the cluster leg
         try:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         except TypeError:  # older signature without device_id
-            dist.init_process_group(backend="nccl")
+            dist.init_process_group(backend="nccl", timeout=tmo)
 
     def barrier_sync():
         if dist is not None:
@@ -320,19 +324,51 @@ def main():
         del eng
 
     # ---- vertex-sharded mode (north_star's split) --------------------------------------------------------------------
+    # Default driver: rank 0 alone drives all N devices through srw_cluster_* (one process, peer stores over xGMI, events
+    # between the shards' streams) while the other ranks wait — no collective inside the leg, so a failure in it cannot
+    # hang the job or cost the headline line.  --shard-driver rccl runs the one-process-per-GPU driver instead
+    # (stellar-random-walk_amd/distributed.py: one RCCL all_to_all_single per super-step).
     if dist is not None and args.shard in ("both", "vertex"):
-        from importlib import import_module
-        sharded = import_module("stellar_random_walk_amd.distributed")
-        if not hasattr(sharded, "bench_vertex_sharded"):
-            raise SystemExit("vertex-sharded bench entry missing")
-        vs = sharded.bench_vertex_sharded(dist, local_rank, rank, world, args.scale, n_edges, bool(args.weighted),
-                                          bool(args.directed), walk_kw, K, W, barrier_sync)
+        vs = None
+        if args.shard_driver == "rccl":
+            from importlib import import_module
+            sharded = import_module("stellar_random_walk_amd.distributed")
+            vs = sharded.bench_vertex_sharded(dist, local_rank, rank, world, args.scale, n_edges, bool(args.weighted),
+                                              bool(args.directed), walk_kw, K, W, barrier_sync)
+        else:
+            if rank == 0:
+                try:
+                    if torch.cuda.device_count() < world:
+                        raise RuntimeError("rank 0 sees %d devices, needs %d" % (torch.cuda.device_count(), world))
+                    t0 = time.perf_counter()
+                    with pkg.Cluster(list(range(world))) as cl:
+                        cl.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
+                        cnv, cne = cl.stats()
+                        torch.cuda.synchronize()
+                        t_graph = time.perf_counter() - t0
+                        kw = dict(p=args.p, q=args.q, walk_length=args.walk_length, seed=42)
+                        B = max(1, min(K, 4))
+                        cl.walk(fetch=False, num_walks=K, first_walk=0, batch=B, **kw)          # warm-up: tables + buffers
+                        st = cl.walk(fetch=False, num_walks=K, first_walk=K, batch=B, **kw)
+                        dt_v = st["kernel_ms"] * 1e-3
+                        vs = {"value": st["n_steps"] / dt_v, "unit": "walk-steps/s", "ms_per_step": dt_v / max(K, 1) * 1e3,
+                              "scaling": "strong", "steps": K, "warmup": K, "iterations_per_population": B,
+                              "workload": "RMAT scale-%d (%d edge lines, %d adjacency entries, %d vertices) p=%g q=%g walkLength=%d"
+                                          % (args.scale, n_edges, cne, cnv, args.p, args.q, args.walk_length),
+                              "parallelism": "graph sharded by source vertex x%d (owner = id mod world), one process driving all devices: "
+                                             "chunks stored into the peers' buffers over xGMI, super-steps ordered by events, paths on the "
+                                             "home GPU, no host sync per super-step" % world,
+                              "timed": "wall time of the super-steps of K iterations (srw_cluster_walk), result buffers preallocated",
+                              "setup_s": {"graph_generate_and_csr_all_shards": t_graph}}
+                except Exception as ex:
+                    vs = {"error": str(ex)[:300]}
+            dist.barrier()
         if rank == 0:
             if out is None:
-                out = {"metric": "walk-steps/sec", "value": vs["value"], "unit": "walk-steps/s", "n_gpus": world, "steps": K,
-                       "warmup": W, "ms_per_step": vs["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                out = {"metric": "walk-steps/sec", "value": vs.get("value"), "unit": "walk-steps/s", "n_gpus": world, "steps": K,
+                       "warmup": W, "ms_per_step": vs.get("ms_per_step"), "higher_is_better": True, "scaling": "strong",
                        "vs_baseline": None, "dtype": "f64 CDF tables, int32 ids", "data": "synthetic",
-                       "config": {"workload": vs["workload"], "parallelism": vs["parallelism"]}}
+                       "config": {"workload": vs.get("workload"), "parallelism": vs.get("parallelism")}}
             out["vertex_sharded"] = vs
 
     if rank == 0:

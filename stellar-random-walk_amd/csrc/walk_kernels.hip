@@ -609,6 +609,7 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
 }
 
 // p = q = 1 on a shard: one record per lane through the precomputed CDF + guide table.
+template <bool NT>
 __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
                                                     RngSpec rng, Walker *__restrict__ scratch, uint32_t *__restrict__ blk,
                                                     DevCounters *ctr) {
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int
           next = g.ent[r.off + lane_pick_sequential(g.ent + r.off, r.deg, nb, u)].id; ++fb;
         } else {
           unsigned rd; int32_t k;
-          FoEnt e = fo_pick<false>(g.fo + r.off, r.deg, u, k, rd); reads += rd;
+          FoEnt e = fo_pick<NT>(g.fo + r.off, r.deg, u, k, rd); reads += rd;
           next = e.id;
         }
         Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
@@ -1219,17 +1220,38 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
   h->shard_flag.ensure(1);
   RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
   const int32_t last = step == P.walk_length + 1 ? 1 : 0;
-  if (step > 1) hipLaunchKernelGGL(k_sh_apply, dim3(n_blocks), dim3(TPB), 0, st, io, step - 1, d_paths, d_lens, stride);
-  if (first_order)
-    hipLaunchKernelGGL(k_sh_step_fo, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng, h->shard_scratch.p,
-                       h->shard_blk.p, h->counters.p);
-  else
-    hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng, P.p, P.q,
-                       h->shard_scratch.p, h->shard_blk.p, h->counters.p);
-  hipLaunchKernelGGL(k_sh_offsets, dim3(1), dim3(1024), 0, st, h->shard_blk.p, n_blocks, io, sd, h->shard_flag.p);
-  hipLaunchKernelGGL(k_sh_bucket, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, first_order ? TPB : TPB / 64, last,
-                     h->shard_scratch.p, h->shard_blk.p, sd);
+  // SRW_SHARD_PROFILE=1 (debug): per-kernel hipEvent times, synchronising after each kernel, printed at the last step
+  static const bool prof = getenv("SRW_SHARD_PROFILE") != nullptr;
+  static double acc[4] = {0, 0, 0, 0};
+  auto timed = [&](int slot, auto &&launch) {
+    if (!prof) { launch(); return; }
+    SRW_HIP(hipEventRecord(h->ev0, st)); launch(); SRW_HIP(hipEventRecord(h->ev1, st)); SRW_HIP(hipEventSynchronize(h->ev1));
+    float ms = 0.f; SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); acc[slot] += ms;
+  };
+  if (step > 1) timed(0, [&] { hipLaunchKernelGGL(k_sh_apply, dim3(n_blocks), dim3(TPB), 0, st, io, step - 1, d_paths, d_lens, stride); });
+  timed(1, [&] {
+    if (first_order) {
+      // records larger than the caches are read once per fetch: L1-bypassing loads (as k_walk_first_order)
+      if ((size_t)g.n_entries * sizeof(FoEnt) > ((size_t)2 << 30))
+        hipLaunchKernelGGL(k_sh_step_fo<true>, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng,
+                           h->shard_scratch.p, h->shard_blk.p, h->counters.p);
+      else
+        hipLaunchKernelGGL(k_sh_step_fo<false>, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng,
+                           h->shard_scratch.p, h->shard_blk.p, h->counters.p);
+    } else
+      hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng, P.p, P.q,
+                         h->shard_scratch.p, h->shard_blk.p, h->counters.p);
+  });
+  timed(2, [&] { hipLaunchKernelGGL(k_sh_offsets, dim3(1), dim3(1024), 0, st, h->shard_blk.p, n_blocks, io, sd, h->shard_flag.p); });
+  timed(3, [&] {
+    hipLaunchKernelGGL(k_sh_bucket, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, first_order ? TPB : TPB / 64, last,
+                       h->shard_scratch.p, h->shard_blk.p, sd);
+  });
   SRW_HIP(hipGetLastError());
+  if (prof && last) {
+    fprintf(stderr, "[shard profile] rank %d: apply %.1f ms, step %.1f ms, offsets %.1f ms, bucket %.1f ms (cumulative)\n", h->cfg.rank, acc[0],
+            acc[1], acc[2], acc[3]);
+  }
 }
 
 // After the exchange that follows the last super-step: its path returns.

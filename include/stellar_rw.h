@@ -210,8 +210,17 @@ int32_t srw_alias_row(srw_handle *h, int32_t v, float *prob, int32_t *alias, int
  * straight into the peers' receive buffers (srw_cluster_*, below).  No host synchronisation per super-step: counts live
  * in the chunk headers; an overflowing chunk drops its surplus and srw_shard_finish reports it (retry with more slack).
  * The keyed RNG makes the paths bit-identical for any world size (tests assert it against the oracle). */
-typedef struct { int32_t lw, src, prev, curr; } srw_walker;   /* lw = local vertex index on the home rank * batch + iteration in batch */
-typedef struct { int32_t lw, v; } srw_path_ret;               /* vertex sampled for walker lw, returned to its home rank */
+typedef struct {            /* 32 bytes on the wire */
+  int32_t lw;               /* home rank's path row: local vertex index * batch + iteration in batch */
+  int32_t src, prev, curr;
+  int32_t h0, h1, h2;       /* vertices of the current group of four path slots not yet returned home */
+  int32_t kind;             /* 0 on the wire */
+} srw_walker;
+typedef struct {            /* 24 bytes: up to four consecutive path slots of walker lw, returned to its home rank */
+  int32_t lw;               /* top bit set: death notice (the walker stopped; path length = first slot + count) */
+  int32_t first_cnt;        /* first path slot | count << 24 */
+  int32_t v[4];
+} srw_path_ret;
 typedef struct { int64_t cap_walkers, cap_rets, chunk_bytes; } srw_shard_layout;
 /* vertices owned by this handle / present in the whole graph (the walker seeds, UniformRandomWalk.scala:81-87) */
 int32_t srw_shard_capacity(const srw_handle *h, int64_t *n_local_vertices, int64_t *n_global_vertices);

@@ -133,7 +133,7 @@ struct srw_handle {
   srw::DevBuf<srw::DevCounters> counters;
   srw::DevBuf<unsigned long long> walk_cursor;   // next walker of the persistent general kernel
   int n_cus = 256;
-  srw::DevBuf<srw::Walker> shard_scratch;        // sampled records before bucketing (persistent)
+  srw::DevBuf<char> shard_scratch;               // sampled 32-byte records before bucketing (persistent)
   srw::DevBuf<uint32_t> shard_blk;               // [blocks][2 * world] per-block survivor / return counts, then write cursors
   srw::DevBuf<uint32_t> shard_flag;              // chunk overflow flag of the sharded walk
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -920,10 +920,16 @@ __device__ inline void edge_exists4(const uint64_t *tab, uint64_t mask, uint32_t
 // staged once in LDS and searched there.  Loads are batched: (1) S + the first search round, (2) 256 candidates'
 // entries and prefix sums (4 per lane), (3) their probes; the chosen candidate's id comes from the registers of the
 // lane that held it (id_out).
+// candidates evaluated per lane and round of the located chunk (4: one round per 256-candidate chunk; 2: the second half
+// of the chunk is only read when the answer is not in the first)
+#ifndef SRW_RESOLVE_PER_LANE
+#define SRW_RESOLVE_PER_LANE 4
+#endif
 template <bool ABS>
 __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, const Bias &b, const double *bins,
                                          const BinGeom geo, float r, unsigned &fallback, unsigned &served, Member &tm,
                                          int32_t &id_out, uint32_t *stage) {
+  constexpr int PL = SRW_RESOLVE_PER_LANE;
   const int lane = lane_id();
   const int32_t deg = rc.deg;
   const int csh = geo.csh;
@@ -995,13 +1001,13 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     __builtin_amdgcn_wave_barrier();
   }
   served = 1;
-  for (int32_t base = k0; base <= k1; base += 256) {
+  for (int32_t base = k0; base <= k1; base += 64 * PL) {
     Ent e[4]; double pqk[4]; bool valid[4], in[4], want[4]; uint32_t xs[4];
-    tm.res_bytes += 16ull * (unsigned long long)((k1 - base + 1) < 256 ? (k1 - base + 1) : 256);
+    tm.res_bytes += 16ull * (unsigned long long)((k1 - base + 1) < 64 * PL ? (k1 - base + 1) : 64 * PL);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int32_t k = base + u * 64 + lane;
-      valid[u] = k <= k1;
+      valid[u] = u < PL && k <= k1;
       e[u].id = b.prev; e[u].w = 0.0f; pqk[u] = 0.0;
       if (valid[u]) { e[u] = row[k]; pqk[u] = PQ[k]; }
     }
@@ -1037,7 +1043,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int32_t k = base + u * 64 + lane;
-      if (base + u * 64 > k1) break;                 // wave-uniform
+      if (u >= PL || base + u * 64 > k1) break;       // wave-uniform
       double corr = 0.0;
       if (valid[u] && !no_specials) {
         if (e[u].id == b.prev) corr = (double)(e[u].w / p_) - (double)(e[u].w / q_);

@@ -464,7 +464,14 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
 // The general kernel keeps one wave per record and the same samplers as k_walk_general (bit-identical paths for any
 // world, asserted against the oracle).
 constexpr int SHARD_MAX_WORLD = 64;
-struct alignas(8) PathRet { int32_t lw, v; };
+// Walker on the wire: 32 bytes.  h0..h2 = the vertices of the walker's current group of four path slots that are not
+// yet returned to the home rank (slots 4g .. 4g+3 travel home together: one 16-byte store instead of four scattered
+// 4-byte ones — the path stores were half of a super-step's memory requests).  kind (scratch only): what the bucket
+// kernel has to emit for the record.
+struct alignas(16) SWalker { int32_t lw, src, prev, curr, h0, h1, h2, kind; };
+struct alignas(8) PathRet { int32_t lw, first_cnt, v[4]; };     // lw top bit: death notice; first slot | count << 24
+enum : int32_t { SK_WALKER = 0, SK_WALKER_RET = 1, SK_RET = 2, SK_DEAD = 3 };
+constexpr int64_t SW_BYTES = 32, PR_BYTES = 24;
 struct ShardIO {
   const char *recv;        // world chunks, one per sender
   int64_t chunk_bytes;
@@ -472,9 +479,9 @@ struct ShardIO {
 };
 struct ShardDst { char *p[SHARD_MAX_WORLD]; };   // where chunk (me -> d) is written
 __device__ inline const uint32_t *chunk_hdr(const char *base, int64_t cb, int c) { return reinterpret_cast<const uint32_t *>(base + c * cb); }
-__device__ inline const Walker *chunk_walkers(const char *base, int64_t cb, int c) { return reinterpret_cast<const Walker *>(base + c * cb + 16); }
+__device__ inline const SWalker *chunk_walkers(const char *base, int64_t cb, int c) { return reinterpret_cast<const SWalker *>(base + c * cb + 16); }
 __device__ inline const PathRet *chunk_rets(const char *base, int64_t cb, int32_t cap_w, int c) {
-  return reinterpret_cast<const PathRet *>(base + c * cb + 16 + (int64_t)cap_w * 16);
+  return reinterpret_cast<const PathRet *>(base + c * cb + 16 + (int64_t)cap_w * SW_BYTES);
 }
 
 __device__ inline void block_flush_counters(DevCounters *ctr, unsigned long long *red, unsigned long long steps,
@@ -512,7 +519,7 @@ __device__ inline uint32_t shard_in_prefix(const ShardIO &io, uint32_t *pre) {
   __syncthreads();
   return pre[io.world];
 }
-__device__ inline Walker shard_in_record(const ShardIO &io, const uint32_t *pre, uint32_t i) {
+__device__ inline SWalker shard_in_record(const ShardIO &io, const uint32_t *pre, uint32_t i) {
   int c = 0;
   while (c + 1 < io.world && i >= pre[c + 1]) ++c;
   return chunk_walkers(io.recv, io.chunk_bytes, c)[i - pre[c]];
@@ -525,14 +532,43 @@ __device__ inline void shard_slice(uint32_t n, uint32_t unit, uint32_t &lo, uint
   lo = (uint32_t)(l < n ? l : n); hi = (uint32_t)(h < n ? h : n);
 }
 
+// What happens to a walker that has just sampled `next` for path slot `step` (or died there): the forwarded record and
+// whether its group of path slots goes home now.  j = step & 3 entries of the group are already in h0..h{j-1}.
+__device__ inline SWalker shard_advance(const SWalker &wk, int32_t step, int32_t next, bool last) {
+  SWalker nw = wk;
+  nw.prev = wk.curr; nw.curr = next;
+  const int j = step & 3;
+  if (j == 3 || last) nw.kind = last ? SK_RET : SK_WALKER_RET;        // slots step - j .. step: h0..h{j-1}, next
+  else {
+    nw.kind = SK_WALKER;
+    if (j == 0) nw.h0 = next; else if (j == 1) nw.h1 = next; else nw.h2 = next;
+  }
+  return nw;
+}
+__device__ inline SWalker shard_dead(const SWalker &wk) { SWalker d = wk; d.kind = SK_DEAD; return d; }
+__device__ inline PathRet shard_ret_of(const SWalker &w, int32_t step) {      // w: a scratch record of super-step `step`
+  PathRet r;
+  const int j = step & 3;
+  r.v[0] = w.h0; r.v[1] = w.h1; r.v[2] = w.h2; r.v[3] = 0;
+  if (w.kind == SK_DEAD) {                       // stopped before sampling slot `step`: j unreturned entries, length = step
+    r.lw = (int32_t)((uint32_t)w.lw | 0x80000000u);
+    r.first_cnt = (step - j) | (j << 24);
+  } else {
+    r.lw = w.lw;
+    r.v[j] = w.curr;
+    r.first_cnt = (step - j) | ((j + 1) << 24);
+  }
+  return r;
+}
+
 __global__ void k_sh_seed(const int32_t *__restrict__ verts, int64_t n_local, ShardIO io, char *recv_w,
                           int32_t *__restrict__ paths, int32_t *__restrict__ lens, int64_t stride) {
   const int64_t n = n_local * io.batch;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t src = verts[i / io.batch];
-    Walker w; w.wid = (int32_t)i; w.src = src; w.prev = src; w.curr = src;
+    SWalker w; w.lw = (int32_t)i; w.src = src; w.prev = src; w.curr = src; w.h0 = src; w.h1 = 0; w.h2 = 0; w.kind = SK_WALKER;
     const int c = (int)(i % io.world);
-    reinterpret_cast<Walker *>(recv_w + c * io.chunk_bytes + 16)[i / io.world] = w;
+    reinterpret_cast<SWalker *>(recv_w + c * io.chunk_bytes + 16)[i / io.world] = w;
     paths[i * stride] = src;
     lens[i] = (int32_t)stride;        // full length unless a death notice says otherwise (k_sh_apply)
   }
@@ -543,21 +579,28 @@ __global__ void k_sh_seed(const int32_t *__restrict__ verts, int64_t n_local, Sh
   }
 }
 
-// returns produced in super-step `slot` (the vertex sampled for path position `slot`) arrive one exchange later
-__global__ void k_sh_apply(ShardIO io, int32_t slot, int32_t *__restrict__ paths, int32_t *__restrict__ lens, int64_t stride) {
+// path returns of the previous super-step: up to four consecutive path slots per record; death notices set lens
+__global__ void k_sh_apply(ShardIO io, int32_t *__restrict__ paths, int32_t *__restrict__ lens, int64_t stride) {
   for (int c = 0; c < io.world; ++c) {
     const uint32_t n = min(chunk_hdr(io.recv, io.chunk_bytes, c)[1], (uint32_t)io.cap_r);
     const PathRet *r = chunk_rets(io.recv, io.chunk_bytes, io.cap_w, c);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
       const PathRet x = r[i];
-      if (x.lw < 0) lens[x.lw & 0x7FFFFFFF] = x.v;             // death notice: the walker stopped with x.v path entries
-      else paths[(int64_t)x.lw * stride + slot] = x.v;
+      const int32_t lw = x.lw & 0x7FFFFFFF, first = x.first_cnt & 0xFFFFFF, cnt = x.first_cnt >> 24;
+      int32_t *row = paths + (int64_t)lw * stride + first;
+      if (cnt == 4 && ((reinterpret_cast<uintptr_t>(row) & 7u) == 0)) {
+        reinterpret_cast<int2 *>(row)[0] = make_int2(x.v[0], x.v[1]);
+        reinterpret_cast<int2 *>(row)[1] = make_int2(x.v[2], x.v[3]);
+      } else {
+        for (int t = 0; t < cnt; ++t) row[t] = x.v[t];
+      }
+      if (x.lw < 0) lens[lw] = first + cnt;                     // death notice: the walker stopped with that many entries
     }
   }
 }
 
 __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
-                                                    RngSpec rng, float p, float q, Walker *__restrict__ scratch,
+                                                    RngSpec rng, float p, float q, SWalker *__restrict__ scratch,
                                                     uint32_t *__restrict__ blk, DevCounters *ctr) {
   __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
   __shared__ uint32_t cnt[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
@@ -571,19 +614,19 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
   uint32_t lo, hi;
   shard_slice(n_in, TPB / 64, lo, hi);
   for (uint32_t ri = lo + wv; ri < hi; ri += TPB / 64) {     // one wave per record
-    Walker wk = shard_in_record(io, pre, ri);
+    const SWalker wk = shard_in_record(io, pre, ri);
     const Row *rp = row_of(g, wk.curr);
     Row r; r.off = 0; r.deg = 0; r.flags = 0;
     if (rp) r = *rp;
     if (r.deg == 0) {                                  // dead end (or a source without neighbors): tell the home rank the length
       if (lane == 0) {
-        Walker dw = wk; dw.wid = (int32_t)((uint32_t)wk.wid | 0x80000000u); dw.curr = step; scratch[ri] = dw;
+        scratch[ri] = shard_dead(wk);
         atomicAdd(&cnt[SHARD_MAX_WORLD + owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
       }
       if (step > 1) dead += (lane == 0);
       continue;
     }
-    const uint32_t iter = (uint32_t)(first_walk + wk.wid % io.batch);
+    const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
     Bias b = make_bias(g, p, q, wk.prev, step > 1);
     float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
     unsigned f = 0, sv = 0;
@@ -593,10 +636,10 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
     if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
     const int32_t next = g.ent[r.off + k].id;
     if (lane == 0) {
-      Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
-      scratch[ri] = nw;                                // in place; dead records carry lw = -1
-      if (!last) atomicAdd(&cnt[owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
-      atomicAdd(&cnt[SHARD_MAX_WORLD + owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
+      const SWalker nw = shard_advance(wk, step, next, last != 0);
+      scratch[ri] = nw;
+      if (nw.kind != SK_RET) atomicAdd(&cnt[owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
+      if (nw.kind != SK_WALKER) atomicAdd(&cnt[SHARD_MAX_WORLD + owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
       steps += 1; degc += (unsigned long long)r.deg; fb += f;
       if (b.need_member) degp += (unsigned long long)b.prev_deg;
     }
@@ -611,7 +654,7 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
 // p = q = 1 on a shard: one record per lane through the precomputed CDF + guide table.
 template <bool NT>
 __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
-                                                    RngSpec rng, Walker *__restrict__ scratch, uint32_t *__restrict__ blk,
+                                                    RngSpec rng, SWalker *__restrict__ scratch, uint32_t *__restrict__ blk,
                                                     DevCounters *ctr) {
   __shared__ uint32_t cnt[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
   __shared__ unsigned long long red[6];
@@ -625,16 +668,16 @@ __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int
     const uint32_t ri = base + threadIdx.x;
     int32_t o = -1, hm = -1;
     if (ri < hi) {
-      Walker wk = shard_in_record(io, pre, ri);
+      const SWalker wk = shard_in_record(io, pre, ri);
       const Row *rp = row_of(g, wk.curr);
       Row r; r.off = 0; r.deg = 0; r.flags = 0;
       if (rp) r = *rp;
       if (r.deg == 0) {
         if (step > 1) ++dead;
-        Walker dw = wk; dw.wid = (int32_t)((uint32_t)wk.wid | 0x80000000u); dw.curr = step; scratch[ri] = dw;
+        scratch[ri] = shard_dead(wk);
         hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);     // death notice to the home rank
       } else {
-        const uint32_t iter = (uint32_t)(first_walk + wk.wid % io.batch);
+        const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
         float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
         int32_t next;
         if (r.flags & ROW_IRREGULAR) {
@@ -646,11 +689,11 @@ __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int
           FoEnt e = fo_pick<NT>(g.fo + r.off, r.deg, u, k, rd); reads += rd;
           next = e.id;
         }
-        Walker nw; nw.wid = wk.wid; nw.src = wk.src; nw.prev = wk.curr; nw.curr = next;
+        const SWalker nw = shard_advance(wk, step, next, last != 0);
         scratch[ri] = nw;
         ++steps;
-        if (!last) o = owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots);
-        hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+        if (nw.kind != SK_RET) o = owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots);
+        if (nw.kind != SK_WALKER) hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
       }
     }
     for (int32_t d = 0; d < io.world; ++d) {               // one LDS atomic per wave, destination and kind
@@ -695,8 +738,8 @@ __global__ void k_sh_offsets(uint32_t *__restrict__ blk, int32_t n_blocks, Shard
   }
 }
 
-__global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int32_t unit, int32_t last,
-                                                   const Walker *__restrict__ recs, const uint32_t *__restrict__ blk, ShardDst dst) {
+__global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int32_t unit, int32_t step,
+                                                   const SWalker *__restrict__ recs, const uint32_t *__restrict__ blk, ShardDst dst) {
   __shared__ uint32_t cur[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
   const uint32_t n_in = shard_in_prefix(io, pre);
   if ((int)threadIdx.x < io.world) {
@@ -709,12 +752,12 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
   shard_slice(n_in, (uint32_t)unit, lo, hi);
   for (uint32_t base = lo; base < hi; base += TPB) {
     const uint32_t i = base + threadIdx.x;
-    Walker w; w.wid = 0; w.src = 0; w.prev = 0; w.curr = 0;
+    SWalker w; w.lw = 0; w.src = 0; w.prev = 0; w.curr = 0; w.h0 = w.h1 = w.h2 = 0; w.kind = SK_WALKER;
     int32_t o = -1, hm = -1;
     if (i < hi) {
       w = recs[i];
-      if (w.wid >= 0 && !last) o = owner_of_tab(w.curr, io.world, g.owner_tab, g.vmin, g.n_slots);
-      hm = owner_of_tab(w.src, io.world, g.owner_tab, g.vmin, g.n_slots);   // sampled vertex, or (wid < 0) the death notice
+      if (w.kind == SK_WALKER || w.kind == SK_WALKER_RET) o = owner_of_tab(w.curr, io.world, g.owner_tab, g.vmin, g.n_slots);
+      if (w.kind != SK_WALKER) hm = owner_of_tab(w.src, io.world, g.owner_tab, g.vmin, g.n_slots);
     }
     for (int32_t d = 0; d < io.world; ++d) {
       const unsigned long long m = __ballot(o == d);
@@ -724,7 +767,10 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
         if (lane == leader) b0 = atomicAdd(&cur[d], (uint32_t)__popcll(m));
         b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
         const uint32_t pos = b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (o == d && pos < (uint32_t)io.cap_w) reinterpret_cast<Walker *>(dst.p[d] + 16)[pos] = w;
+        if (o == d && pos < (uint32_t)io.cap_w) {
+          SWalker fw = w; fw.kind = SK_WALKER;
+          reinterpret_cast<SWalker *>(dst.p[d] + 16)[pos] = fw;
+        }
       }
       const unsigned long long mh = __ballot(hm == d);
       if (mh) {
@@ -733,10 +779,8 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
         if (lane == leader) b0 = atomicAdd(&cur[SHARD_MAX_WORLD + d], (uint32_t)__popcll(mh));
         b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
         const uint32_t pos = b0 + (uint32_t)__popcll(mh & ((1ull << lane) - 1ull));
-        if (hm == d && pos < (uint32_t)io.cap_r) {
-          PathRet r; r.lw = w.wid; r.v = w.curr;
-          reinterpret_cast<PathRet *>(dst.p[d] + 16 + (int64_t)io.cap_w * 16)[pos] = r;
-        }
+        if (hm == d && pos < (uint32_t)io.cap_r)
+          reinterpret_cast<PathRet *>(dst.p[d] + 16 + (int64_t)io.cap_w * SW_BYTES)[pos] = shard_ret_of(w, step);
       }
     }
   }
@@ -1155,9 +1199,9 @@ void shard_layout(const srw_handle *h, int32_t batch, double slack, srw_shard_la
   // (or the recorded partition) mixes hubs and leaves, so the pairs are even up to sampling noise
   const double per_pair = (double)batch * (double)h->g.n_vertices / (double)(world * world);
   const int64_t cap = (int64_t)(per_pair * slack) + 4096;
-  if (cap >= ((int64_t)1 << 31) / 16) throw Error(SRW_ERR_INVALID, "shard chunk too large: lower the batch");
+  if (cap >= ((int64_t)1 << 31) / 64) throw Error(SRW_ERR_INVALID, "shard chunk too large: lower the batch");
   out->cap_walkers = cap; out->cap_rets = cap;
-  out->chunk_bytes = 16 + cap * 16 + cap * 8;
+  out->chunk_bytes = 16 + cap * SW_BYTES + cap * PR_BYTES;
 }
 
 namespace {
@@ -1170,7 +1214,7 @@ ShardIO make_io(const srw_handle *h, int32_t batch, const srw_shard_layout &lay,
 void check_shard(const srw_handle *h, int32_t batch, const srw_shard_layout &lay) {
   if (!h->g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
   if (h->cfg.world > SHARD_MAX_WORLD) throw Error(SRW_ERR_INVALID, "world larger than 64 shards");
-  if (batch < 1 || lay.cap_walkers < 1 || lay.cap_rets < 1 || lay.chunk_bytes != 16 + lay.cap_walkers * 16 + lay.cap_rets * 8)
+  if (batch < 1 || lay.cap_walkers < 1 || lay.cap_rets < 1 || lay.chunk_bytes != 16 + lay.cap_walkers * SW_BYTES + lay.cap_rets * PR_BYTES)
     throw Error(SRW_ERR_INVALID, "bad shard layout");
   if ((int64_t)batch * h->g.n_local_vertices >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "batch * local vertices must stay below 2^31");
 }
@@ -1215,7 +1259,8 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
   ShardDst sd;
   for (int d = 0; d < SHARD_MAX_WORLD; ++d) sd.p[d] = d < world ? (char *)dst[d] : nullptr;
   const int n_blocks = h->n_cus * 4;
-  h->shard_scratch.ensure((size_t)world * (size_t)lay.cap_walkers);
+  h->shard_scratch.ensure((size_t)world * (size_t)lay.cap_walkers * (size_t)SW_BYTES);
+  SWalker *scratch = reinterpret_cast<SWalker *>(h->shard_scratch.p);
   h->shard_blk.ensure((size_t)n_blocks * 2 * world);
   h->shard_flag.ensure(1);
   RngSpec rng; rng.mode = P.rng_mode; rng.const_r = P.const_r; rng.seed = P.seed;
@@ -1228,24 +1273,24 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     SRW_HIP(hipEventRecord(h->ev0, st)); launch(); SRW_HIP(hipEventRecord(h->ev1, st)); SRW_HIP(hipEventSynchronize(h->ev1));
     float ms = 0.f; SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); acc[slot] += ms;
   };
-  if (step > 1) timed(0, [&] { hipLaunchKernelGGL(k_sh_apply, dim3(n_blocks), dim3(TPB), 0, st, io, step - 1, d_paths, d_lens, stride); });
+  if (step > 1) timed(0, [&] { hipLaunchKernelGGL(k_sh_apply, dim3(n_blocks), dim3(TPB), 0, st, io, d_paths, d_lens, stride); });
   timed(1, [&] {
     if (first_order) {
       // records larger than the caches are read once per fetch: L1-bypassing loads (as k_walk_first_order)
       if ((size_t)g.n_entries * sizeof(FoEnt) > ((size_t)2 << 30))
         hipLaunchKernelGGL(k_sh_step_fo<true>, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng,
-                           h->shard_scratch.p, h->shard_blk.p, h->counters.p);
+                           scratch, h->shard_blk.p, h->counters.p);
       else
         hipLaunchKernelGGL(k_sh_step_fo<false>, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng,
-                           h->shard_scratch.p, h->shard_blk.p, h->counters.p);
+                           scratch, h->shard_blk.p, h->counters.p);
     } else
       hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng, P.p, P.q,
-                         h->shard_scratch.p, h->shard_blk.p, h->counters.p);
+                         scratch, h->shard_blk.p, h->counters.p);
   });
   timed(2, [&] { hipLaunchKernelGGL(k_sh_offsets, dim3(1), dim3(1024), 0, st, h->shard_blk.p, n_blocks, io, sd, h->shard_flag.p); });
   timed(3, [&] {
-    hipLaunchKernelGGL(k_sh_bucket, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, first_order ? TPB : TPB / 64, last,
-                       h->shard_scratch.p, h->shard_blk.p, sd);
+    hipLaunchKernelGGL(k_sh_bucket, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, first_order ? TPB : TPB / 64, step,
+                       scratch, h->shard_blk.p, sd);
   });
   SRW_HIP(hipGetLastError());
   if (prof && last) {
@@ -1259,7 +1304,7 @@ void run_shard_flush(srw_handle *h, const srw_walk_params &P, int32_t batch, con
                      int32_t *d_paths, int32_t *d_lens, int64_t stride) {
   check_shard(h, batch, lay);
   const ShardIO io = make_io(h, batch, lay, d_recv);
-  hipLaunchKernelGGL(k_sh_apply, dim3(h->n_cus * 4), dim3(TPB), 0, h->stream, io, P.walk_length + 1, d_paths, d_lens, stride);
+  hipLaunchKernelGGL(k_sh_apply, dim3(h->n_cus * 4), dim3(TPB), 0, h->stream, io, d_paths, d_lens, stride);
   SRW_HIP(hipGetLastError());
 }
 

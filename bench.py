@@ -355,7 +355,7 @@ def main():
                               "scaling": "strong", "steps": K, "warmup": K, "iterations_per_population": B,
                               "workload": "RMAT scale-%d (%d edge lines, %d adjacency entries, %d vertices) p=%g q=%g walkLength=%d"
                                           % (args.scale, n_edges, cne, cnv, args.p, args.q, args.walk_length),
-                              "parallelism": "graph sharded by source vertex x%d (owner = id mod world), one process driving all devices: "
+                              "parallelism": "graph sharded by source vertex x%d (owner = mix32(id) mod world), one process driving all devices: "
                                              "chunks stored into the peers' buffers over xGMI, super-steps ordered by events, paths on the "
                                              "home GPU, no host sync per super-step" % world,
                               "timed": "wall time of the super-steps of K iterations (srw_cluster_walk), result buffers preallocated",

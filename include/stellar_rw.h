@@ -49,15 +49,16 @@ enum {
 
 typedef struct {
   int32_t device; /* HIP device ordinal */
-  int32_t rank;   /* vertex sharding: this handle stores the rows of vertices v with            */
-  int32_t world;  /*   nonNegativeMod(v, world) == rank (HashPartitioner, RandomWalk.scala:16); */
-                  /*   world = 1 keeps the whole graph (single-GPU and replicated modes)         */
+  int32_t rank;   /* vertex sharding: this handle stores the rows of the vertices v with owner(v) == rank,   */
+  int32_t world;  /*   owner(v) = mix32(v) mod world — the role of HashPartitioner (RandomWalk.scala:16), with */
+                  /*   the ids mixed first so that skewed id spaces (RMAT: hubs at round ids) stay balanced;  */
+                  /*   world = 1 keeps the whole graph (single-GPU and replicated modes)                       */
   int32_t flags;  /* SRW_CFG_* */
 } srw_config;
 enum {
   /* sharded handles (world > 1): a vertex is owned by the partition id recorded for it by a partitioned load
    * (VCutRandomWalk: GraphMap.getPartition(steps.last), M/algorithm/VCutRandomWalk.scala:121-134), modulo world;
-   * vertices without a recorded partition fall back to nonNegativeMod(v, world). */
+   * vertices without a recorded partition fall back to mix32(v) mod world. */
   SRW_CFG_OWNER_FROM_PARTITIONS = 1
 };
 

@@ -60,7 +60,7 @@ class HipRandomWalk(config: Params, seed: Int = 42, constR: Option[Float] = None
 
   /**
     * The same job with the graph sharded by source vertex over several GPUs of this node — owner(v) =
-    * nonNegativeMod(v, #GPUs) as HashPartitioner (RandomWalk.scala:16), or the VCut partition ids when
+    * mix32(v) mod #GPUs, the role of HashPartitioner (RandomWalk.scala:16), or the VCut partition ids when
     * config.partitioned — and the walkers crossing shards every super-step over xGMI: what replaces
     * transferWalkersToTheirPartitions (RandomWalk.scala:186-192).  Same files as execute().
     */

@@ -2,13 +2,15 @@
 //
 // Replaces the Spark super-step loop with its shuffle (M/algorithm/RandomWalk.scala:91-162, transferWalkersToTheirPartitions
 // :186-192) for callers that are a single process: the stellar-rw CLI (--gpus N) and the JNI host.  One sharded srw_handle
-// per device (owner(v) = nonNegativeMod(v, world), RandomWalk.scala:16, or the VCut partition ids); peer access enabled;
+// per device (owner(v) = mix32(v) mod world, RandomWalk.scala:16, or the VCut partition ids); peer access enabled;
 // every super-step each shard's bucket kernel stores chunk (me -> d) straight into device d's receive buffer over xGMI
 // (fully connected: every pair has its own link), and the shards' streams are ordered by one event per shard per
 // super-step — no collective library and no host synchronisation inside a walk iteration.  Receive buffers are double
 // buffered by super-step parity: a peer may run at most one super-step ahead of the slowest shard.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -151,7 +153,7 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
     tot.kernel_kind = (P0.p == 1.0f && P0.q == 1.0f && !(P0.flags & SRW_WALK_FORCE_GENERAL)) ? 1 : 2;
     if (n_global == 0 || P0.num_walks == 0) { if (stats) *stats = tot; c->valid = true; return; }
     if (batch <= 0) {   // as many iterations per population as keep a shard's chunk buffers under ~2 GiB
-      const int64_t per_iter = std::max<int64_t>(1, n_global / world * 30);
+      const int64_t per_iter = std::max<int64_t>(1, n_global / world * 70);      // 56 B of chunk space per resident walker x slack
       batch = (int32_t)std::max<int64_t>(1, std::min<int64_t>(P0.num_walks, ((int64_t)2 << 30) / per_iter));
     }
     batch = std::min(batch, P0.num_walks);
@@ -207,6 +209,7 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
         bt.ent_reads += s.ent_reads; bt.fallbacks += s.fallbacks;
       }
       if (overflow) {                 // a chunk was too small for this graph's skew: same batch again with more room
+        if (getenv("SRW_TIMING")) fprintf(stderr, "[cluster] chunk overflow at slack %.2f (batch %d, iteration %d): retrying\n", slack, B, it0);
         slack *= 2.0;
         if (slack > 64.0) throw Error(SRW_ERR_NOMEM, "vertex-sharded walk: chunk overflow persists at 64x slack");
         continue;

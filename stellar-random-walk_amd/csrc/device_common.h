@@ -146,9 +146,16 @@ __device__ inline float draw_uniform(const RngSpec &rng, uint32_t iter, uint32_t
   return (float)walk_bits24(rng.seed, iter, src, step) * (1.0f / 16777216.0f);
 }
 
+// Which shard owns vertex v.  The reference partitions by HashPartitioner = nonNegativeMod(id.hashCode, n) with
+// Int.hashCode = identity (RandomWalk.scala:16) — and inherits the skew of the ids: an RMAT graph without a vertex
+// permutation puts 44 % of its edge endpoints on ids whose three low bits are 000, so `v mod 8` hands one shard 44 % of
+// the walkers and another 1.4 % (measured: chunk overflow up to 16x the mean).  The partition is invisible in the output
+// (paths are identical for any partitioning, tests), so the ids are mixed first; a VCut input's own partition ids
+// (owner_of_tab) are honoured as given.
 __host__ __device__ inline int32_t owner_of(int32_t v, int32_t world) {
-  int32_t m = v % world;   // Utils.nonNegativeMod of HashPartitioner (RandomWalk.scala:16)
-  return m < 0 ? m + world : m;
+  uint32_t h = (uint32_t)v * 0x9E3779B1u;
+  h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+  return (int32_t)(h % (uint32_t)world);
 }
 // Edge-existence test through the hash set (linear probing, EMPTY = all ones).
 // 32-bit mixing only (a 64-bit multiply costs ~8 VALU instructions on CDNA): murmur3's finalizer over the two halves of

@@ -921,9 +921,10 @@ __device__ inline void edge_exists4(const uint64_t *tab, uint64_t mask, uint32_t
 // entries and prefix sums (4 per lane), (3) their probes; the chosen candidate's id comes from the registers of the
 // lane that held it (id_out).
 // candidates evaluated per lane and round of the located chunk (4: one round per 256-candidate chunk; 2: the second half
-// of the chunk is only read when the answer is not in the first)
+// of a 256-candidate chunk is only read when the answer is not in the first — the kernel is bound by memory requests as
+// much as by latency, profiles/r02c_general_kernel_c3.md)
 #ifndef SRW_RESOLVE_PER_LANE
-#define SRW_RESOLVE_PER_LANE 4
+#define SRW_RESOLVE_PER_LANE 2   // measured at config 3: 2 -> 182 M steps/s, 4 -> 169 M, 1 -> 168 M (request-bound vs latency-bound)
 #endif
 template <bool ABS>
 __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, const Bias &b, const double *bins,

@@ -1199,7 +1199,7 @@ void shard_layout(const srw_handle *h, int32_t batch, double slack, srw_shard_la
   // (or the recorded partition) mixes hubs and leaves, so the pairs are even up to sampling noise
   const double per_pair = (double)batch * (double)h->g.n_vertices / (double)(world * world);
   const int64_t cap = (int64_t)(per_pair * slack) + 4096;
-  if (cap >= ((int64_t)1 << 31) / 64) throw Error(SRW_ERR_INVALID, "shard chunk too large: lower the batch");
+  if (cap * world >= ((int64_t)1 << 31)) throw Error(SRW_ERR_INVALID, "shard chunks too large (world * capacity must stay below 2^31 records): lower the batch");
   out->cap_walkers = cap; out->cap_rets = cap;
   out->chunk_bytes = 16 + cap * SW_BYTES + cap * PR_BYTES;
 }

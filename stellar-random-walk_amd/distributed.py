@@ -2,21 +2,22 @@
 
 Replaces the Spark shuffle of the reference's super-step loop
 (M/algorithm/RandomWalk.scala:91-162: prepareWalkersToTransfer -> partitionBy(HashPartitioner) -> zipPartitions,
-UniformRandomWalk.scala:103-112): the graph is sharded by source vertex, owner(v) = nonNegativeMod(v, world)
+UniformRandomWalk.scala:103-112): the graph is sharded by source vertex, owner(v) = mix32(v) mod world
 (RandomWalk.scala:16) or the VCut partition ids, and a walker standing on v is processed by owner(v).
 
 What moves (xGMI, RCCL `all_to_all_single`, equal splits): per (sender, receiver) pair one fixed-capacity chunk
-    { n_walkers, n_rets, 0, 0 } | {lw, src, prev, curr}[cap] | {lw, vertex}[cap]
-— 16-byte walker records (not the path and not N(prev) as in the reference, RandomWalk.scala:135) and 8-byte path returns
-to the walker's HOME rank, which alone stores its path: memory per rank is 1/world of the paths plus 30 B per resident
-walker of chunk buffers.  The counts travel in the chunk headers, so a super-step is: kernels -> one collective -> kernels,
-with no host synchronisation; an overflowing chunk raises a flag that is read once per batch (retry with more slack).
+    { n_walkers, n_rets, 0, 0 } | {lw, src, prev, curr, h0, h1, h2, 0}[cap] | {lw, first slot | count << 24, v[4]}[cap]
+— 32-byte walker records (not the path and not N(prev) as in the reference, RandomWalk.scala:135) that carry the current
+group of four path slots, and 24-byte path returns (four slots at a time) to the walker's HOME rank, which alone stores
+its path: memory per rank is 1/world of the paths plus 56 B per resident walker of chunk buffers.  The counts travel in
+the chunk headers, so a super-step is: kernels -> one collective -> kernels, with no host synchronisation; an overflowing
+chunk raises a flag that is read once per batch (every rank then retries together with more slack).
 Because the RNG is keyed by (iteration, source vertex, step), the result is bit-identical to the single-GPU walk for any
 world size — tests assert exactly that.
 
 q != 1 needs N(prev), which lives on owner(prev): every shard therefore also keeps a replicated *membership
 structure* of the whole graph (row boundaries + sorted neighbor ids, 4 B/entry; graph_build.hip), so the p/q bias is
-evaluated locally and the exchanged record stays 16 bytes — see DESIGN.md §6.
+evaluated locally and no second query/response exchange is needed — see DESIGN.md §6.
 
 The same kernels serve the single-process form (csrc/cluster.cpp: peer stores instead of the collective).  The step
 engine is injectable so that this driver's protocol can be tested with the gloo backend on CPU (the tests plug the CPU
@@ -201,7 +202,7 @@ def bench_vertex_sharded(dist_mod, local_rank, rank, world, scale, n_edges, weig
             "steps": K, "warmup": W, "iterations_per_population": B,
             "workload": "RMAT scale-%d (%d edge lines, %d adjacency entries, %d vertices), p=%g q=%g walkLength=%d" % (
                 scale, n_edges, ne, nv, kw.get("p", 1.0), kw.get("q", 1.0), kw.get("walk_length", 80)),
-            "parallelism": "graph sharded by source vertex x%d (owner = id mod world), 1 RCCL all_to_all_single per super-step, "
+            "parallelism": "graph sharded by source vertex x%d (owner = mix32(id) mod world), 1 RCCL all_to_all_single per super-step, "
                            "paths on the home GPU" % world,
             "local_vertices_rank0": n_local, "exchange_bytes_per_superstep_per_rank": st["exchange_bytes_per_superstep"] if st else 0,
             "setup_s": {"graph_generate_and_csr": t_graph}}

@@ -19,7 +19,9 @@ struct alignas(16) Row {
   uint32_t flags;
 };
 enum : uint32_t { ROW_PRESENT = 1u, ROW_IRREGULAR = 2u, ROW_ALIAS_IRREGULAR = 4u,
-                  ROW_PQ_OK = 8u };
+                  ROW_PQ_OK = 8u,
+                  ROW_PQ_F32 = 16u };  // (with ROW_PQ_OK) every sum the samplers form over this row is a multiple of 2^G below 2^(24+G):
+                                       // exactly representable in binary32 -> its per-edge tables are stored as floats
 constexpr int ROW_HUB_SHIFT = 8;   // Row::flags >> 8 = 1 + ordinal of the row's neighbor-set bitmap (0: none); world == 1 only   // certified for the prefix-sum samplers under the current call's (p, q); set by k_pq_*
 
 struct alignas(8) Ent {
@@ -107,6 +109,7 @@ struct GraphView {
   // or the offset, in 16-byte units, of its mask words in em_bits (bit k = candidate k of N(curr) is in N(prev))
   const uint32_t *em_bits;
   int32_t eb_mask_max;
+  int32_t eb_f32;           // 1: tables of ROW_PQ_F32 rows hold floats (half the bytes)
 };
 constexpr uint32_t EB_NONE = 0xFFFFFFFFu;
 

@@ -45,6 +45,7 @@ struct EbSel {          // which pairs get a table
   int64_t min_cost;     // bins tables: smallest priority (saved wave-cycles per 64 B of table, see eb_units) that still fits the budget
   int32_t min_sh;       // bins tables: smallest chunk shift
   int32_t has_ehash, has_hub;
+  int32_t f32;          // tables of ROW_PQ_F32 rows are stored as floats
 };
 constexpr int INLINE_MAX_DEG = 32;   // masks of rows up to 32 candidates live in eb_off[e] itself
 
@@ -62,7 +63,7 @@ __device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s
   const BinnedCost c = binned_cost(rv.deg, ru.deg, s.has_hub && (ru.flags >> ROW_HUB_SHIFT) != 0u, s.has_ehash != 0);
   const int64_t cost = c.c1 < c.c2 ? (c.c1 < c.cw ? c.c1 : c.cw) : (c.c2 < c.cw ? c.c2 : c.cw);
   const BinGeom geo = bin_geometry(rv.deg, s.min_sh, EB_BINS);
-  const uint32_t units = (uint32_t)((geo.n_bins + 7) >> 3);
+  const uint32_t units = (s.f32 && (rv.flags & ROW_PQ_F32)) ? (uint32_t)((geo.n_bins + 15) >> 4) : (uint32_t)((geo.n_bins + 7) >> 3);
   // priority = wave-cycles a table saves per visit, per 64 bytes of table: an on-the-fly step costs its intersection
   // work plus ~20 us of dependent round trips whatever its size (measured: 38 .. 43 us per P1 / W step at config 3
   // against 10 .. 25 us per table step), so short cheap tables are worth as much per byte as the hub <-> hub ones
@@ -263,10 +264,15 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
       double *out = eb_bins + (size_t)eb_off[e] * 8;
       const int up = gc.csh - gf.csh;
       const double *PQ = g.pq + rv.off;            // the table keeps the complete numerator A'_end(j) = PQ[end_j] + corrections
+      const bool as_f32 = g.eb_f32 && (rv.flags & ROW_PQ_F32);      // every such sum is exactly representable in binary32
       for (int32_t j = lane; j < gc.n_bins; j += 64) {
         const int64_t fi = (((int64_t)j + 1) << up) - 1;
         const int64_t ke = (((int64_t)j + 1) << gc.csh) - 1;
-        out[j] = PQ[ke < rv.deg ? ke : rv.deg - 1] + bins[fi < gf.n_bins ? fi : gf.n_bins - 1];
+        const double a = PQ[ke < rv.deg ? ke : rv.deg - 1] + bins[fi < gf.n_bins ? fi : gf.n_bins - 1];
+        if (as_f32) {
+          reinterpret_cast<float *>(out)[j] = (float)a;
+          if ((double)(float)a != a) atomicAdd(&strat_count[7], 1ull);      // must never happen (pq_row_f32's bound)
+        } else out[j] = a;
       }
       __builtin_amdgcn_wave_barrier();          // the next fill clears the bins
     }
@@ -286,7 +292,8 @@ size_t env_gb(const char *name, size_t dflt_gb) {
 void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   Graph &g = h->g;
   uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);
-  if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode) return;
+  { const char *e = getenv("SRW_EB_NO_F32"); const int want_f32 = (e && *e == '1') ? 0 : 1;
+    if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.eb_f32 == want_f32) return; }
   hipStream_t st = h->stream;
   g.has_eb = false; g.eb_tables = 0; g.eb_bytes = 0; g.eb_build_ms = 0.0;
   g.eb_bins.release(); g.em_bits.release();
@@ -298,6 +305,8 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : 8;
   { const char *e = getenv("SRW_EB_MIN_COST"); sel.min_cost = (!mode && e && *e) ? atoll(e) : 0; }
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
+  { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
+  g.eb_f32 = sel.f32;
   sel.has_ehash = (g.has_ehash && g.use_ehash) ? 1 : 0; sel.has_hub = (g.has_hub && g.use_hub) ? 1 : 0;
   g.eb_min_sh = sel.min_sh;
   // budget: what is free now minus the offsets and a reserve for the walk's own buffers
@@ -373,6 +382,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   }
   SRW_HIP(hipStreamSynchronize(st));
+  if (sc[7]) throw Error(SRW_ERR_INVALID, "per-edge tables: a prefix sum of a ROW_PQ_F32 row was not exactly representable in binary32");
   g.eb_pbits = pb; g.eb_qbits = qb; g.eb_mode = mode;
   g.eb_tables = (int64_t)all_pairs;
   g.eb_bytes = (int64_t)(units * 64 + munits * 16 + (unsigned long long)g.n_entries * 4);

@@ -91,7 +91,7 @@ struct Graph {
   DevBuf<uint32_t> eb_off;        // [n_entries] per-edge bias tables (edge_tables.hip): offset of entry e's table, 64-B units
   DevBuf<double> eb_bins;         // the tables
   DevBuf<uint32_t> em_bits;       // membership masks of the pairs whose curr row has 33 .. eb_mask_max candidates
-  int32_t eb_mask_max = 0;
+  int32_t eb_mask_max = 0, eb_f32 = 0;
   bool has_eb = false, use_eb = false; uint32_t eb_pbits = 0, eb_qbits = 0; int32_t eb_min_sh = 8, eb_mode = 0;
   int64_t eb_tables = 0, eb_bytes = 0; double eb_build_ms = 0.0;
   DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
@@ -103,7 +103,7 @@ struct Graph {
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
-                     (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max}; }
+                     (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32}; }
 };
 
 struct WalkResult {

@@ -320,7 +320,8 @@ __global__ void k_fo_from_slim(const Row *__restrict__ rows, const Ent *__restri
 // four times earlier — at config 3 every row beyond 524 288 entries, which then took the streaming scan.)
 struct PqCert {
   int emin; bool bad; double mass;
-  __device__ PqCert() : emin(1 << 20), bad(false), mass(0.0) {}
+  int glsb;   // lowest set bit position over all nonzero variants: every variant (hence every sum) is a multiple of 2^glsb
+  __device__ PqCert() : emin(1 << 20), bad(false), mass(0.0), glsb(1 << 20) {}
   __device__ inline void add(float x) {
     uint32_t b = __float_as_uint(x);
     int ex = (int)((b >> 23) & 0xFFu);
@@ -328,6 +329,8 @@ struct PqCert {
     if ((b & 0x7FFFFFFFu) == 0u) return;
     int e = ex ? ex - 127 : -126;
     emin = min(emin, e);
+    const uint32_t mant = (b & 0x7FFFFFu) | (ex ? 0x800000u : 0u);
+    glsb = min(glsb, e - 23 + (int)__builtin_ctz(mant));
   }
   __device__ inline void add_entry(float w, float p, float q) {
     const float a = w / q, c = w / p;
@@ -335,6 +338,12 @@ struct PqCert {
     mass += (double)fmaxf(w, fmaxf(a, c));      // NaN-free once !bad
   }
 };
+// every sum over the row is a multiple of 2^glsb and at most 2 * mass: below 2^(24 + glsb) it has at most 24 significant
+// bits and is exactly representable in binary32 (mass carries a relative error <= n 2^-53: one bit of margin)
+__device__ inline bool pq_row_f32(int glsb, double mass) {
+  if (glsb > (1 << 19) || glsb < -1000) return false;
+  return mass < ldexp(1.0, 22 + glsb);
+}
 __device__ inline bool pq_row_ok(int emin, bool bad, double mass) {
   if (bad) return false;
   if (emin > (1 << 19)) return false;                 // all-zero row: leave it to the literal sampler
@@ -346,7 +355,7 @@ __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, 
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
     Row r = rows[v];
     ok[v] = 0;
-    if (r.flags & ROW_PQ_OK) rows[v].flags = r.flags & ~ROW_PQ_OK;   // the flag mirrors ok[v] (one load less per step)
+    if (r.flags & (ROW_PQ_OK | ROW_PQ_F32)) { r.flags &= ~(ROW_PQ_OK | ROW_PQ_F32); rows[v].flags = r.flags; }   // the flag mirrors ok[v] (one load less per step)
     if (r.deg <= 0 || r.deg > SMALL_DEG) continue;
     PqCert c;
     for (int32_t k = 0; k < r.deg; ++k) c.add_entry(ent[r.off + k].w, p, q);
@@ -354,7 +363,7 @@ __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, 
     double acc = 0.0;
     for (int32_t k = 0; k < r.deg; ++k) { acc += (double)(ent[r.off + k].w / q); pq[r.off + k] = acc; }
     ok[v] = 1;
-    rows[v].flags = r.flags | ROW_PQ_OK;
+    rows[v].flags = r.flags | ROW_PQ_OK | (pq_row_f32(c.glsb, c.mass) ? ROW_PQ_F32 : 0u);
   }
 }
 
@@ -373,7 +382,7 @@ __global__ void k_pq_large(Row *__restrict__ rows, const Ent *__restrict__ ent, 
       const Ent *row = ent + r.off;
       PqCert c;
       for (int32_t k = lane; k < r.deg; k += 64) c.add_entry(row[k].w, p, q);
-      const int emin = wave_min_i32(c.emin);
+      const int emin = wave_min_i32(c.emin), glsb = wave_min_i32(c.glsb);
       const bool bad = __any(c.bad);
       const double mass = wave_sum_f64(bad ? 0.0 : c.mass);
       if (!pq_row_ok(emin, bad, mass)) continue;                     // ok[v] stays 0 (set by k_pq_small)
@@ -385,7 +394,7 @@ __global__ void k_pq_large(Row *__restrict__ rows, const Ent *__restrict__ ent, 
         if (k < r.deg) pq[r.off + k] = carry + x;
         carry += readlane_f64(x, 63);
       }
-      if (lane == 0) { ok[v] = 1; rows[v].flags = r.flags | ROW_PQ_OK; }
+      if (lane == 0) { ok[v] = 1; rows[v].flags = r.flags | ROW_PQ_OK | (pq_row_f32(glsb, mass) ? ROW_PQ_F32 : 0u); }
     }
   }
 }

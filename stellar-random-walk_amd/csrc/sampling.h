@@ -330,12 +330,25 @@ __device__ inline void fill_member_bitmap(const Bias &b, Member &m, const uint32
   __builtin_amdgcn_wave_barrier();
 }
 
+// Inclusive scan over the 64 lanes with DPP moves (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 /
+// row_bcast:31 across the rows): 6 x (2 v_mov_dpp + v_add_f64), no LDS traffic and no s_waitcnt — the __shfl_up form
+// (2 ds_bpermute per step) was a visible share of the second-order kernel's 1 100 VALU + 1 000 SALU instructions per
+// step.  Lanes without a source add 0.0 (the identity), so the result is the same sum in another order; every caller
+// either works with exactly representable partial sums or carries a tolerance that covers any summation order.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_add_f64(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+  return v + __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+}
 __device__ inline double wave_incl_scan_f64(double v) {
-  const int lane = lane_id();
-  for (int o = 1; o < 64; o <<= 1) {
-    double t = __shfl_up(v, o);
-    if (lane >= o) v += t;
-  }
+  v = dpp_add_f64<0x111, 0xF>(v);   // row_shr:1
+  v = dpp_add_f64<0x112, 0xF>(v);   // row_shr:2
+  v = dpp_add_f64<0x114, 0xF>(v);   // row_shr:4
+  v = dpp_add_f64<0x118, 0xF>(v);   // row_shr:8
+  v = dpp_add_f64<0x142, 0xA>(v);   // row_bcast:15 -> rows 1 and 3
+  v = dpp_add_f64<0x143, 0xC>(v);   // row_bcast:31 -> rows 2 and 3
   return v;
 }
 
@@ -943,20 +956,27 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   const uint32_t *hubbits = (b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
   const double *PQ = g.pq + rc.off;
   auto chunk_end = [&](int32_t j) { const int64_t e = (((int64_t)j + 1) << csh) - 1; return (int32_t)(e < deg ? e : deg - 1); };
+  // tables of rows whose every sum is binary32-exact are stored as floats (edge_tables.hip); LDS bins are always f64
+  const bool f32t = ABS && g.eb_f32 && (rc.flags & ROW_PQ_F32);
+  auto BIN = [&](int32_t j) { return f32t ? (double)reinterpret_cast<const float *>(bins)[j] : bins[j]; };
   // round trip 1: everything the search needs first
   int32_t lo = 0, hi = n_bins - 1;                 // the chunk of the first not-certain-miss index lies in [lo, hi]
   int32_t j1 = hi >= 64 ? (int32_t)(((int64_t)hi * (lane + 1)) >> 6) : (lane <= hi ? lane : hi);   // lane 63 probes hi
-  const double b_last = bins[n_bins - 1];
-  double pq_last = 0.0, pq_j = 0.0, b_j = bins[j1];
+  const double b_last = BIN(n_bins - 1);
+  double pq_last = 0.0, pq_j = 0.0, b_j = BIN(j1);
   if (!ABS) { pq_last = PQ[deg - 1]; pq_j = PQ[chunk_end(j1)]; }
   const double S = pq_last + b_last;
   if (!(S > 0.0)) return -1;
   const double p = (double)r;
-  auto not_miss = [&](int32_t k, double num) {
-    const double X = num / S;
-    const double tol = (double)(k + 8) * 0x1p-51 * X;
-    return !(X + tol < p);
-  };
+  // Certified compares without a divide.  The reference's acc_k = sum of fl(w'_i / S) differs from num / S (num exact)
+  // by at most (k + 2) u num / S.  With t = (k + 8) 2^-51 = 4 (k + 8) u:
+  //   fl(num (1 + t)) <  fl(p S)  =>  num (1 + t)(1 - 3u) < p S  =>  (num / S)(1 + (k + 2) u) < p   : a CERTAIN miss
+  //   fl(num (1 - t)) >= fl(p S)  =>  num (1 - t)(1 + 3u) >= p S =>  (num / S)(1 - (k + 2) u) >= p  : a CERTAIN hit
+  // (1 +- t is exact in f64; each product rounds once).  NaN compares false both ways -> "not a certain miss, not a
+  // certain hit" -> the sequential chain, as before.
+  const double pS = p * S;
+  auto not_miss = [&](int32_t k, double num) { return !(num * (1.0 + (double)(k + 8) * 0x1p-51) < pS); };
+  auto sure_hit = [&](int32_t k, double num) { return num * (1.0 - (double)(k + 8) * 0x1p-51) >= pS; };
   while (hi - lo >= 64) {
     const unsigned long long mm = __ballot(not_miss(chunk_end(j1), pq_j + b_j));
     if (!mm) { id_out = row[0].id; return 0; }      // even the last candidate is a certain miss -> edges.head
@@ -966,7 +986,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     hi = jf; lo = jprev + 1;
     const int64_t span = (int64_t)hi - lo;
     j1 = span >= 64 ? lo + (int32_t)((span * (lane + 1)) >> 6) : (lo + lane <= hi ? lo + lane : hi);
-    b_j = bins[j1];
+    b_j = BIN(j1);
     if (!ABS) pq_j = PQ[chunk_end(j1)];
   }
   int32_t jc;
@@ -978,7 +998,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   }
   // candidate-by-candidate evaluation of chunk jc, 256 candidates per round
   const int32_t k0 = (int32_t)((int64_t)jc << csh), k1 = chunk_end(jc);
-  const double b_prev = jc ? bins[jc - 1] : 0.0, b_this = bins[jc];
+  const double b_prev = jc ? BIN(jc - 1) : 0.0, b_this = BIN(jc);
   // exact value of the numerator just before the chunk, and the exact sum of the chunk's corrections
   double carry, pq_base = 0.0, chunk_corr;
   if (ABS) {
@@ -1051,10 +1071,9 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
         else if (in[u]) corr = (double)e[u].w - (double)(e[u].w / q_);
       }
       const double incl = wave_incl_scan_f64(corr);
-      const double X = ((pqk[u] - pq_base) + carry + incl) / S;
-      const double tol = (double)(k + 8) * 0x1p-51 * X;
-      const bool nm = valid[u] && !(X + tol < p);
-      const bool hit = X - tol >= p;
+      const double num = (pqk[u] - pq_base) + carry + incl;
+      const bool nm = valid[u] && not_miss(k, num);
+      const bool hit = sure_hit(k, num);
       const unsigned long long mm = __ballot(nm);
       if (mm) {
         const int f = __ffsll((long long)mm) - 1;
@@ -1111,7 +1130,8 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   }
   const int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
   const bool bad = __any(cert.bad) || __any(neg);
-  if (bad || !sum_is_exact(emin, emax, false, deg)) {
+  const double S_par = wave_sum_f64(part);
+  if (bad || !sum_is_exact(emin, emax, false, deg) || !(S_par > 0.0)) {     // (S = 0: the reference divides by zero -> chain)
     unsigned f = 0;
     const double Sc = wave_sum_exact_or_chain(row, deg, b, f);
     fallback = 1;
@@ -1119,20 +1139,23 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
     id_out = row[kk].id;
     return kk;
   }
-  const double S = wave_sum_f64(part);
+  // Under the certificate every partial sum of the w' is exact in any order, so A'_k = sum_{i <= k} w'_i is exact and
+  // S = A'_{deg-1} is the reference's sum bit for bit; the reference's acc_k = sum of fl(w'_i / S) differs from A'_k / S
+  // by at most (k + 2) u A'_k / S: the divide-free certified compares of binned_resolve apply.
+  const double S = S_par;
   const double p = (double)r;
+  const double pS = p * S;
   double carry = 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (i >= ni) break;
     const int32_t k = i * 64 + lane;
     const bool valid = k < deg;
-    const double d = valid ? (double)wv[i] / S : 0.0;
-    const double incl = wave_incl_scan_f64(d);
-    const double acc = carry + incl;
-    const double tol = (double)(k + 1) * 0x1p-51 * acc;
-    const bool nm = valid && !(acc + tol < p);
-    const bool hit = acc - tol >= p;
+    const double incl = wave_incl_scan_f64(valid ? (double)wv[i] : 0.0);
+    const double num = carry + incl;
+    const double t = (double)(k + 8) * 0x1p-51;
+    const bool nm = valid && !(num * (1.0 + t) < pS);
+    const bool hit = num * (1.0 - t) >= pS;
     const unsigned long long mm = __ballot(nm);
     if (mm) {
       const int f = __ffsll((long long)mm) - 1;

@@ -3,6 +3,8 @@ the device, the same graph rebuilt in the CPU oracle from the same (seed, edge i
 including the 20 highest-degree hubs compared BIT FOR BIT for the biased configs of BASELINE.json, with the DEFAULT
 strategy selection — hub bitmaps, the edge hash set, the per-edge bias tables and the on-the-fly searches must fire on
 their own (asserted through srw_walk_stats.strategy_steps)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -53,6 +55,15 @@ def test_weighted_rmat_biased_walks_equal_oracle(eng, oracle, scale, n_sample, L
         ss = st["strategy_steps"]
         if q != 1.0:
             assert st["edge_tables"] > 0 and ss["edge_table"] > 0 and ss["edge_mask"] > 0, st
+            if scale == 16:     # tables of binary32-exact rows are stored as floats: the f64 layout must give the same paths
+                os.environ["SRW_EB_NO_F32"] = "1"
+                try:
+                    p64, l64, st64 = eng.walk(p=p, q=q, walk_length=L, seed=1234)
+                finally:
+                    del os.environ["SRW_EB_NO_F32"]
+                assert np.array_equal(p64, paths) and np.array_equal(l64, lens)
+                assert st64["edge_table_bytes"] > st["edge_table_bytes"], (st64["edge_table_bytes"], st["edge_table_bytes"])
+                eng.walk(p=p, q=q, walk_length=1, seed=1234)       # back to the default layout for what follows
             # without the tables the on-the-fly strategies carry the hub steps: they must fire on their own
             paths2, lens2, st2 = eng.walk(p=p, q=q, walk_length=L, seed=1234, edge_tables=False)
             assert np.array_equal(paths2, paths) and np.array_equal(lens2, lens)

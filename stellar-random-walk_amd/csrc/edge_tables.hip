@@ -295,7 +295,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   { const char *e = getenv("SRW_EB_NO_F32"); const int want_f32 = (e && *e == '1') ? 0 : 1;
     if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.eb_f32 == want_f32) return; }
   hipStream_t st = h->stream;
-  g.has_eb = false; g.eb_tables = 0; g.eb_bytes = 0; g.eb_build_ms = 0.0;
+  g.has_eb = false; g.eb_tables = 0; g.eb_bytes = 0; g.eb_build_ms = 0.0; g.eb_complete = false;
   g.eb_bins.release(); g.em_bits.release();
   if (!g.has_pq || !g.has_member || g.n_entries <= 0) return;
   const auto t0 = std::chrono::steady_clock::now();
@@ -338,6 +338,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
     if (nu * 64 + np * 8 > budget || nu >= 0xFFFFFFF0ull) break;
     units = nu; pairs = np; --cls;
   }
+  g.eb_complete = cls <= 1 && sel.mask_max > 0;      // nothing was cut by the budget (k_walk_tables may run)
   if (cls > 1) sel.min_cost = std::max<int64_t>(sel.min_cost, prio_class_floor(cls));
   if (pairs == 0) sel.min_deg = 0x7FFFFFFF;      // no bins tables at all
   if (pairs + mpairs == 0 && sel.mask_max == 0) return;

@@ -92,6 +92,7 @@ struct Graph {
   DevBuf<double> eb_bins;         // the tables
   DevBuf<uint32_t> em_bits;       // membership masks of the pairs whose curr row has 33 .. eb_mask_max candidates
   int32_t eb_mask_max = 0, eb_f32 = 0;
+  bool eb_complete = false;       // the HBM budget did not bind: every pair into a certified row has a table
   bool has_eb = false, use_eb = false; uint32_t eb_pbits = 0, eb_qbits = 0; int32_t eb_min_sh = 8, eb_mode = 0;
   int64_t eb_tables = 0, eb_bytes = 0; double eb_build_ms = 0.0;
   DevBuf<double> rsum;            // [n_slots] Mode A: exact row weight sums
@@ -131,7 +132,8 @@ struct srw_handle {
   srw::Graph g;
   srw::WalkResult res;
   srw::DevBuf<srw::DevCounters> counters;
-  srw::DevBuf<unsigned long long> walk_cursor;   // next walker of the persistent general kernel
+  srw::DevBuf<unsigned long long> walk_cursor;   // [0] next walker of the persistent kernels, [1] walkers handed over by k_walk_tables
+  srw::DevBuf<int32_t> walk_todo;                // their indices
   int n_cus = 256;
   srw::DevBuf<char> shard_scratch;               // sampled 32-byte records before bucketing (persistent)
   srw::DevBuf<uint32_t> shard_blk;               // [blocks][2 * world] per-block survivor / return counts, then write cursors

@@ -895,26 +895,30 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
   strat_used = (unsigned)strat;
 }
 
-// Four edge-hash probes per lane in lockstep: the probe loads of one round are independent, so four candidates cost the
+// N edge-hash probes per lane in lockstep: the probe loads of one round are independent, so N candidates cost the
 // round trips of one.
-__device__ inline void edge_exists4(const uint64_t *tab, uint64_t mask, uint32_t row_slot, const uint32_t id_slot[4],
-                                    const bool want[4], bool out[4]) {
-  uint64_t key[4], s[4]; bool act[4];
+template <int N>
+__device__ inline void edge_exists_n(const uint64_t *tab, uint64_t mask, uint32_t row_slot, const uint32_t (&id_slot)[N],
+                                     const bool (&want)[N], bool (&out)[N]) {
+  uint64_t key[N], s[N]; bool act[N];
+  bool any = false;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < N; ++u) {
     key[u] = ((uint64_t)row_slot << 32) | id_slot[u];
-    s[u] = edge_hash(key[u], mask); act[u] = want[u]; out[u] = false;
+    s[u] = edge_hash(key[u], mask); act[u] = want[u]; out[u] = false; any |= act[u];
   }
-  while (act[0] | act[1] | act[2] | act[3]) {
-    uint64_t v[4];
+  while (any) {
+    uint64_t v[N];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = act[u] ? tab[s[u]] : 0ull;
+    for (int u = 0; u < N; ++u) v[u] = act[u] ? tab[s[u]] : 0ull;
+    any = false;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < N; ++u)
       if (act[u]) {
         if (v[u] == key[u]) { out[u] = true; act[u] = false; }
         else if (v[u] == 0xFFFFFFFFFFFFFFFFull) act[u] = false;
         else s[u] = (s[u] + 1) & mask;
+        any |= act[u];
       }
   }
 }
@@ -1023,48 +1027,50 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   }
   served = 1;
   for (int32_t base = k0; base <= k1; base += 64 * PL) {
-    Ent e[4]; double pqk[4]; bool valid[4], in[4], want[4]; uint32_t xs[4];
+    Ent e[PL]; double pqk[PL]; bool valid[PL], in[PL], want[PL]; uint32_t xs[PL];
     tm.res_bytes += 16ull * (unsigned long long)((k1 - base + 1) < 64 * PL ? (k1 - base + 1) : 64 * PL);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PL; ++u) {
       const int32_t k = base + u * 64 + lane;
-      valid[u] = u < PL && k <= k1;
+      valid[u] = k <= k1;
       e[u].id = b.prev; e[u].w = 0.0f; pqk[u] = 0.0;
       if (valid[u]) { e[u] = row[k]; pqk[u] = PQ[k]; }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PL; ++u) {
       xs[u] = (uint32_t)((int64_t)e[u].id - b.vmin); in[u] = false;
       want[u] = !no_specials && valid[u] && e[u].id != b.prev;
     }
     if (no_specials) {
     } else if (stage_levels) {
-      uint32_t pos[4] = {0u, 0u, 0u, 0u};
+      uint32_t pos[PL];
+#pragma unroll
+      for (int u = 0; u < PL; ++u) pos[u] = 0u;
       for (int st = stage_levels > 0 ? (1 << (stage_levels - 1)) : 0; st >= 1; st >>= 1) {
-        uint32_t probe[4];
+        uint32_t probe[PL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) probe[u] = stage[pos[u] + st - 1];
+        for (int u = 0; u < PL; ++u) probe[u] = stage[pos[u] + st - 1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (probe[u] < xs[u]) pos[u] += st;
+        for (int u = 0; u < PL; ++u) if (probe[u] < xs[u]) pos[u] += st;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) in[u] = want[u] && stage[pos[u]] == xs[u];
+      for (int u = 0; u < PL; ++u) in[u] = want[u] && stage[pos[u]] == xs[u];
     } else if (hubbits) {
-      uint32_t wd[4];
+      uint32_t wd[PL];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) wd[u] = want[u] ? hubbits[xs[u] >> 5] : 0u;
+      for (int u = 0; u < PL; ++u) wd[u] = want[u] ? hubbits[xs[u] >> 5] : 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) in[u] = (wd[u] >> (xs[u] & 31)) & 1u;
+      for (int u = 0; u < PL; ++u) in[u] = (wd[u] >> (xs[u] & 31)) & 1u;
     } else if (g.ehash) {
-      edge_exists4(g.ehash, g.ehash_mask, xprev, xs, want, in);
+      edge_exists_n<PL>(g.ehash, g.ehash_mask, xprev, xs, want, in);
     } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) in[u] = want[u] && sorted_contains(B, m, xs[u]);
+      for (int u = 0; u < PL; ++u) in[u] = want[u] && sorted_contains(B, m, xs[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PL; ++u) {
       const int32_t k = base + u * 64 + lane;
-      if (u >= PL || base + u * 64 > k1) break;       // wave-uniform
+      if (base + u * 64 > k1) break;                 // wave-uniform
       double corr = 0.0;
       if (valid[u] && !no_specials) {
         if (e[u].id == b.prev) corr = (double)(e[u].w / p_) - (double)(e[u].w / q_);
@@ -1093,21 +1099,77 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   return kk;
 }
 
-// ---- rows of at most 512 candidates with a precomputed membership MASK of the (prev -> curr) pair ---------------------
-// (edge_tables.hip: bit k = "candidate k of N(curr) is in N(prev)".)  The whole row sits in registers (8 candidates per
+// ---- first step of a walk (initFirstStep, RandomWalk.scala:51-66): RandomSample.sample on the RAW row -------------------
+// Certified like the masked path: exact parallel sum under the certificate, exact prefix sums, divide-free compares;
+// the sequential chain otherwise.  No membership, no LDS.
+__device__ inline int32_t wave_pick_first(const GraphView &g, const Row &rc, float r, unsigned &fallback, int32_t &id_out) {
+  const int lane = lane_id();
+  const Ent *row = g.ent + rc.off;
+  const int32_t deg = rc.deg;
+  Bias nb; nb.second_order = false; nb.need_member = false; nb.p = nb.q = 1.0f; nb.prev = 0; nb.prev_sids = nullptr; nb.prev_deg = 0; nb.vmin = g.vmin;
+  double part = 0.0;
+  SumCert cert;
+  bool neg = false;
+  for (int32_t base = 0; base < deg; base += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int32_t k = base + u * 64 + lane;
+      if (k < deg) { const float w = row[k].w; part += (double)w; cert.add(w); neg |= !(w >= 0.0f); }
+    }
+  }
+  const int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
+  const bool bad = __any(cert.bad) || __any(neg);
+  const double S = wave_sum_f64(part);
+  if (bad || !sum_is_exact(emin, emax, false, deg) || !(S > 0.0)) {
+    unsigned f = 0;
+    const double Sc = wave_sum_exact_or_chain(row, deg, nb, f);
+    fallback = 1;
+    const int32_t kk = wave_chain_pick(row, deg, nb, r, Sc);
+    id_out = row[kk].id;
+    return kk;
+  }
+  const double pS = (double)r * S;
+  double carry = 0.0;
+  for (int32_t base = 0; base < deg; base += 64) {
+    const int32_t k = base + lane;
+    const bool valid = k < deg;
+    Ent e; e.id = 0; e.w = 0.0f;
+    if (valid) e = row[k];
+    const double incl = wave_incl_scan_f64((double)e.w);
+    const double num = carry + incl;
+    const double t = (double)(k + 8) * 0x1p-51;
+    const bool nm = valid && !(num * (1.0 + t) < pS);
+    const bool hit = num * (1.0 - t) >= pS;
+    const unsigned long long mm = __ballot(nm);
+    if (mm) {
+      const int f = __ffsll((long long)mm) - 1;
+      if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(e.id, f); return base + f; }
+      fallback = 1;
+      const int32_t kk = wave_chain_pick(row, deg, nb, r, S);
+      id_out = row[kk].id;
+      return kk;
+    }
+    carry += readlane_f64(incl, 63);
+  }
+  id_out = row[0].id;     // edges.head (:24)
+  return 0;
+}
+
+// ---- rows of fewer than 256 candidates with a precomputed membership MASK of the (prev -> curr) pair -------------------
+// (edge_tables.hip: bit k = "candidate k of N(curr) is in N(prev)".)  The whole row sits in registers (4 candidates per
 // lane), so the step is: one round trip for the mask + the row, then RandomSample.sample's certified evaluation — the
-// same arithmetic as wave_pick_scan (certified-exact parallel S, any-order scan of the quotients with the certain-miss
-// / certain-hit tolerance, the sequential chain otherwise) without a single membership lookup.
-constexpr int MASK_MAX_DEG = 512;
+// same certified evaluation as the table path (exact parallel S and prefix sums under the certificate, divide-free
+// certain-miss / certain-hit compares, the sequential chain otherwise) without a single membership lookup.
+constexpr int MASK_MAX_DEG = 256;       // rows up to 255 candidates: 4 per lane stay in registers
 __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, const Bias &b, uint32_t inline_mask,
                                            const uint32_t *words, float r, unsigned &fallback, int32_t &id_out) {
   const int lane = lane_id();
   const Ent *row = g.ent + rc.off;
   const int32_t deg = rc.deg;
-  const int ni = (deg + 63) >> 6;                  // <= 8
-  float wv[8]; int32_t idv[8]; uint32_t mw[8];
+  const int ni = (deg + 63) >> 6;                  // <= 4
+  float wv[4]; int32_t idv[4]; uint32_t mw[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     mw[i] = 0u;
     if (i < ni) mw[i] = words ? words[2 * i + (lane >> 5)] : ((i == 0 && lane < 32) ? inline_mask : 0u);
   }
@@ -1115,7 +1177,7 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   SumCert cert;
   bool neg = false;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int32_t k = i * 64 + lane;
     wv[i] = 0.0f; idv[i] = 0;
     if (i < ni && k < deg) {
@@ -1147,7 +1209,7 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   const double pS = p * S;
   double carry = 0.0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     if (i >= ni) break;
     const int32_t k = i * 64 + lane;
     const bool valid = k < deg;
@@ -1190,9 +1252,9 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
 constexpr int EB_BINS = 64;                    // chunks per table: one lane each in the search
 __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc, const Bias &b, const double *table,
                                                float r, unsigned &fallback, unsigned &served, Member &tm, int32_t &id_out,
-                                               uint32_t *lds) {
+                                               uint32_t *stage /* 1024 words of the wave's LDS */) {
   const BinGeom geo = bin_geometry(rc.deg, g.eb_min_sh, EB_BINS);
-  return binned_resolve<true>(g, rc, b, table, geo, r, fallback, served, tm, id_out, lds + 2 * BIN_CAP);
+  return binned_resolve<true>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage);
 }
 
 }  // namespace srw

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
                                                       int64_t n_verts, int64_t n_walkers, int32_t L,
                                                       int32_t first_walk, RngSpec rng, float p, float q,
                                                       int32_t *__restrict__ paths, int32_t *__restrict__ lens,
-                                                      DevCounters *ctr, unsigned long long *cursor, int32_t tune) {
+                                                      DevCounters *ctr, unsigned long long *cursor, int32_t tune,
+                                                      const int32_t *__restrict__ todo, const unsigned long long *todo_n) {
   __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
   const int lane = lane_id();
   Member mem; mem.mode = 0; mem.bm = bitmap[threadIdx.x >> 6]; mem.seg_base = 0;
@@ -161,9 +162,12 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
   while (true) {
     unsigned long long grab = 0;
     if (lane == 0) grab = atomicAdd(cursor, 1ull);
-    const int64_t wi = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab));
-    if (wi >= n_walkers) break;
+    int64_t wi = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab));
+    if (todo) {                                      // only the walkers k_walk_tables handed over
+      if (wi >= (int64_t)*todo_n) break;
+      wi = todo[wi];
+    } else if (wi >= n_walkers) break;
     int64_t it = wi / n_verts, vi = wi - it * n_verts;
     const uint32_t iter = (uint32_t)(first_walk + it);
     const int32_t src = verts[vi];
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
           }
         } else if (eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
           // chunk prefixes of the pair's corrections: search + one chunk, no intersection
-          k = wave_pick_edge_table(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, mem.bm);
+          k = wave_pick_edge_table(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, mem.bm + 2 * BIN_CAP);
           if (k >= 0) { have_next = true; binned_served = true; which = SRW_STRAT_EDGE_TABLE; srch += 8ull * EB_BINS; }
         }
       }
@@ -256,6 +260,104 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     for (int i = 0; i < 12; ++i) atomicAdd(&ctr->dbg[24 + i], mem.t_strat[i] >> 10);
     atomicAdd(&ctr->dbg[16], mem.t_w_lb >> 10); atomicAdd(&ctr->dbg[17], mem.t_w_ins >> 10); atomicAdd(&ctr->dbg[18], mem.t_w_la >> 10); atomicAdd(&ctr->dbg[19], mem.t_w_probe >> 10);
 #endif
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same walk for the walkers whose EVERY step finds a per-edge table (edge_tables.hip): first step on the raw row,
+// then membership masks / chunk-prefix tables only.  Without the on-the-fly samplers the kernel needs a fraction of
+// k_walk_general's registers (128 VGPRs + scratch there) and 4 KB of LDS per wave, so more waves hide the dependent
+// round trips of a step.  A walker that meets a pair without a table is handed over untouched (its index goes to
+// `todo`; k_walk_general redoes it from its first step: the keyed RNG makes that the same path).
+#ifndef SRW_LEAN_WAVES
+#define SRW_LEAN_WAVES 5   // measured at config 3: 4 waves/SIMD (126 VGPRs, no spill) 221 M steps/s, 5 (96 + 168 B scratch) 239 M, 6 (80 + 204 B) 235 M; without this kernel 195 M
+#endif
+__device__ inline Row uniform_row(Row r) {            // the row descriptor of a wave's walker is wave-uniform: keep it in SGPRs
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r.off), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)r.off >> 32));
+  Row o; o.off = (int64_t)(((uint64_t)hi << 32) | lo); o.deg = __builtin_amdgcn_readfirstlane(r.deg);
+  o.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.flags);
+  return o;
+}
+__global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
+                                                     int64_t n_walkers, int32_t L, int32_t first_walk, RngSpec rng, float p,
+                                                     float q, int32_t *__restrict__ paths, int32_t *__restrict__ lens,
+                                                     DevCounters *ctr, unsigned long long *cursor, int32_t *__restrict__ todo,
+                                                     unsigned long long *todo_n) {
+  __shared__ __attribute__((aligned(16))) uint32_t stage_all[TPB / 64][1024];
+  const int lane = lane_id();
+  uint32_t *stage = stage_all[threadIdx.x >> 6];
+  Member mem; mem.mode = 0; mem.bm = stage; mem.seg_base = 0;
+  const int64_t stride = (int64_t)L + 2;
+  unsigned long long steps = 0, srch = 0;
+  uint32_t fb = 0, dead = 0, fast = 0, n_tab = 0, n_mask = 0, n_first = 0;
+  while (true) {
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(cursor, 1ull);
+    const int64_t wi = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab));
+    if (wi >= n_walkers) break;
+    const int64_t it = wi / n_verts, vi = wi - it * n_verts;
+    const uint32_t iter = (uint32_t)(first_walk + it);
+    const int32_t src = __builtin_amdgcn_readfirstlane(verts[vi]);
+    int32_t *path = paths + wi * stride;
+    if (lane == 0) path[0] = src;
+    int32_t prev = src, curr = src, len = 1;
+    Row rprev; rprev.off = 0; rprev.deg = 0; rprev.flags = 0;
+    int64_t eprev = 0;
+    uint32_t w_fb = 0, w_dead = 0, w_fast = 0, w_srch = 0, w_tab = 0, w_mask = 0;    // (a handed-over walker is not counted here)
+    bool handed_over = false;
+    for (int32_t s = 1; s <= L + 1; ++s) {
+      const bool second = s > 1;
+      const int64_t cslot = (int64_t)curr - g.vmin;
+      const bool in_range = cslot >= 0 && cslot < g.n_slots;
+      Row r = g.rows[in_range ? cslot : 0];
+      uint32_t eo = EB_NONE;
+      if (second) eo = g.eb_off[eprev];
+      r = uniform_row(r); eo = (uint32_t)__builtin_amdgcn_readfirstlane((int)eo);
+      if (!in_range) { r.off = 0; r.deg = 0; r.flags = 0; }
+      if (r.deg == 0) { w_dead += s > 1; break; }
+      const float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
+      unsigned f = 0, sv = 0;
+      int32_t k, next = 0;
+      if (!second) {
+        k = wave_pick_first(g, r, u, f, next);
+      } else {
+        Bias b;
+        b.p = p; b.q = q; b.prev = prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
+        b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT;
+        if (r.deg <= g.eb_mask_max && (r.deg <= 32 || eo != EB_NONE)) {
+          k = wave_pick_masked(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
+          w_mask += 1; w_srch += 8u * (uint32_t)r.deg + 4u * (uint32_t)((r.deg + 31) >> 5);
+        } else if (r.deg > g.eb_mask_max && eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
+          k = wave_pick_edge_table(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage);
+          if (k >= 0) { w_tab += 1; w_srch += 8u * EB_BINS; w_fast += sv; }
+        } else k = -1;
+        if (k < 0) { handed_over = true; break; }          // no table for this pair: the general kernel takes the walker
+      }
+      k = __builtin_amdgcn_readfirstlane(k); next = __builtin_amdgcn_readfirstlane(next);
+      w_fb += f;
+      if (lane == 0) path[s] = next;
+      prev = curr; curr = next; ++len; rprev = r; eprev = r.off + k;
+    }
+    if (handed_over) {
+      if (lane == 0) todo[atomicAdd(todo_n, 1ull)] = (int32_t)wi;
+      continue;
+    }
+    for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
+    if (lane == 0) lens[wi] = len;
+    steps += (unsigned long long)(len - 1); n_first += len > 1 ? 1u : 0u;
+    fb += w_fb; dead += w_dead; fast += w_fast; srch += w_srch; n_tab += w_tab; n_mask += w_mask;
+  }
+  if (lane == 0) {
+    srch += mem.res_bytes;
+    if (steps) atomicAdd(&ctr->steps, steps);
+    if (dead) atomicAdd(&ctr->dead_ends, (unsigned long long)dead);
+    if (fb) { atomicAdd(&ctr->fallbacks, (unsigned long long)fb); atomicAdd(&ctr->strat[SRW_STRAT_CHAIN], (unsigned long long)fb); }
+    if (fast) atomicAdd(&ctr->ent_reads, (unsigned long long)fast);
+    if (srch) atomicAdd(&ctr->trials, srch);
+    if (n_tab) atomicAdd(&ctr->strat[SRW_STRAT_EDGE_TABLE], (unsigned long long)n_tab);
+    if (n_mask) atomicAdd(&ctr->strat[SRW_STRAT_EDGE_MASK], (unsigned long long)n_mask);
+    if (n_first) atomicAdd(&ctr->strat[SRW_STRAT_SCAN], (unsigned long long)n_first);
   }
 }
 
@@ -912,11 +1014,24 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
   } else {
     // persistent waves taking walkers from a cursor: enough blocks to fill every CU at the kernel's occupancy
     int64_t blocks = std::min<int64_t>((n_walkers * 64 + TPB - 1) / TPB, (int64_t)h->n_cus * 8);
-    h->walk_cursor.ensure(1);
-    SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, sizeof(unsigned long long), st));
+    h->walk_cursor.ensure(2);
+    SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, 2 * sizeof(unsigned long long), st));
+    const int32_t tune = (int32_t)(((P.flags >> 12) & 15) | ((P.flags & SRW_WALK_NO_BINNED) ? 16 : 0));
+    // every (prev -> curr) pair has a table: the lean kernel walks, the general one only redoes what it hands over
+    const bool lean = gv.eb_off && g.eb_complete && P.q != 1.0f && tune == 0 && !getenv("SRW_NO_LEAN_KERNEL");
+    const int32_t *todo = nullptr;
+    if (lean) {
+      h->walk_todo.ensure((size_t)n_walkers);
+      int64_t lb = std::min<int64_t>((n_walkers * 64 + TPB - 1) / TPB, (int64_t)h->n_cus * 16);
+      hipLaunchKernelGGL(k_walk_tables, dim3((unsigned)lb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
+                         first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, h->walk_todo.p,
+                         h->walk_cursor.p + 1);
+      SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, sizeof(unsigned long long), st));
+      todo = h->walk_todo.p;
+    }
     hipLaunchKernelGGL(k_walk_general, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
-                       P.walk_length, first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p,
-                       (int32_t)(((P.flags >> 12) & 15) | ((P.flags & SRW_WALK_NO_BINNED) ? 16 : 0)));
+                       P.walk_length, first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, tune, todo,
+                       h->walk_cursor.p + 1);
   }
   SRW_HIP(hipGetLastError());
   LaunchInfo li;

@@ -791,6 +791,35 @@ def test_giant_row_mass_certificate(eng, oracle):
             assert served > 0.4 * st["n_steps"], st     # every step that lands on a hub is served by a search, not the scan
 
 
+def test_wide_id_range_is_refused_up_front(eng):
+    """Every per-vertex table is dense over id - min(id): a sparse id space is refused
+    with SRW_ERR_NOMEM and a message that says what to do, before any allocation proportional to the range — and the
+    handle stays usable."""
+    P = pkg()
+    for s, d in (([0, 2000000000], [1, 3]), ([2147483647], [-2147483648])):
+        with pytest.raises(P.SrwError) as ei:
+            eng.load_coo(np.array(s, np.int32), np.array(d, np.int32))
+        assert ei.value.code == P.ERR_NOMEM and "renumber" in str(ei.value), str(ei.value)
+    pid = np.zeros(2, np.int32)
+    with pytest.raises(P.SrwError) as ei:           # the partitioned load used to build a host table of the range first
+        eng.load_coo(np.array([0, 2000000000], np.int32), np.array([1, 3], np.int32), pid=pid)
+    assert ei.value.code == P.ERR_NOMEM
+    eng.load_edgelist(KARATE)
+    assert eng.stats() == (34, 156)
+
+
+def test_num_walks_zero_writes_an_empty_job(eng, tmp_path):
+    """--numWalks 0: the reference's `0 until numWalks` loop runs zero times and still writes path/ + _SUCCESS."""
+    eng.load_edgelist(KARATE)
+    st = eng.walk(fetch=False, num_walks=0, walk_length=5)
+    assert st["n_walkers"] == 0 and st["n_steps"] == 0
+    out = tmp_path / "out"
+    st, dead = eng.walk_and_save(str(out), n_parts=1, num_walks=0, walk_length=5)
+    assert (out / "path" / "_SUCCESS").exists() and (out / "path" / "part-00000").read_bytes() == b""
+    with pytest.raises(pkg().SrwError):
+        eng.walk(fetch=False, num_walks=-1)
+
+
 def test_randomized_differential_fuzz(eng):
     # ~8 s of tests/fuzz_parity.py: random multigraphs / hub graphs / RMATs, every sampler variant vs the CPU oracle
     import fuzz_parity

@@ -158,7 +158,8 @@ enum { /* srw_walk_stats.strategy_steps: which sampler of the general (second-or
   SRW_STRAT_SCAN = 5,       /* certified streaming scan (small rows, rows without a certificate, first steps) */
   SRW_STRAT_PREFIX = 6,     /* q == 1: prefix-sum search with the return edges as a short list */
   SRW_STRAT_CHAIN = 7,      /* the reference's sequential f64 chain (irregular rows, draws on a CDF boundary) */
-  SRW_STRAT_EDGE_MASK = 8   /* precomputed per-edge membership mask (rows up to 511 candidates): no lookup at all */
+  SRW_STRAT_EDGE_MASK = 8,  /* precomputed per-edge membership mask (rows below 256 candidates): no lookup at all */
+  SRW_STRAT_Q1_LANE = 9     /* p != 1, q == 1: one walker per lane (first-order guide table + exact prefix sums + return edge) */
 };
 
 /* Replaces RandomWalk.randomWalk (M/algorithm/RandomWalk.scala:75-176) incl. initFirstStep (:51-66):

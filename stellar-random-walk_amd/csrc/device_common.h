@@ -110,7 +110,13 @@ struct GraphView {
   const uint32_t *em_bits;
   int32_t eb_mask_max;
   int32_t eb_f32;           // 1: tables of ROW_PQ_F32 rows hold floats (half the bytes)
+  // rev[e], e = (u -> v): (count << 24) | index in v's SORTED row of the first entry that leads back to u (the return
+  // edges of the step u -> v -> ?; sperm / sw give their input-order positions and weights), REV_NONE if there is none
+  // (directed graphs); null if not built
+  const uint32_t *rev;
 };
+constexpr uint32_t REV_NONE = 0xFFFFFFFFu;
+constexpr int REV_MAX_RETURNS = 4;          // return edges of one step the per-lane kernel keeps in registers
 constexpr uint32_t EB_NONE = 0xFFFFFFFFu;
 
 // Philox4x32-10 (Random123).  Same constants as oracle/srw_oracle.c:orc_philox4x32_10.

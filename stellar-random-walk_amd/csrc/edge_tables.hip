@@ -281,6 +281,29 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
     for (int i = 0; i < 8; ++i) if (ns[i]) atomicAdd(&strat_count[i], ns[i]);
 }
 
+// rev[e] for every entry e = (u -> v): where the return edges sit in N(v) (k_walk_q1) — the index, in v's SORTED row, of
+// the first entry that leads back to u, and how many there are (multi-edges).  One lane per entry: lower bound of u in
+// v's sorted row, then the run of equal ids.
+__global__ __launch_bounds__(TPB) void k_rev_build(GraphView g, unsigned long long *cursor, uint32_t *__restrict__ rev) {
+  const int lane = lane_id();
+  while (true) {
+    const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
+    if (v0 >= g.n_slots) break;
+    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < g.n_slots; ++u) {
+      const Row ru = g.rows[u];
+      for (int32_t k = lane; k < ru.deg; k += 64) {
+        const Row rv = g.rows[(int64_t)g.ent[ru.off + k].id - g.vmin];
+        const uint32_t *cs = g.sids + rv.off;
+        int32_t lo = 0, hi = rv.deg;
+        while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < (uint32_t)u) lo = mid + 1; else hi = mid; }
+        uint32_t cnt = 0;
+        while (cnt < 255u && lo + (int32_t)cnt < rv.deg && cs[lo + cnt] == (uint32_t)u) ++cnt;
+        rev[ru.off + k] = cnt ? ((cnt << 24) | (uint32_t)lo) : REV_NONE;          // (rows have fewer than 2^23 entries: CFO_NDEG_MAX)
+      }
+    }
+  }
+}
+
 size_t env_gb(const char *name, size_t dflt_gb) {
   const char *e = getenv(name);
   if (!e || !*e) return dflt_gb << 30;
@@ -392,6 +415,20 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
     fprintf(stderr, "[edge tables] %llu bins tables (%.2f GB, min priority %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
             "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
             sc[3], sc[4], mpairs, (double)munits * 16 / 1e9, (double)g.n_entries * 4 / 1e9, g.eb_build_ms);
+}
+
+void build_rev_table(srw_handle *h) {
+  Graph &g = h->g;
+  if (g.has_rev) return;
+  build_membership(h);
+  hipStream_t st = h->stream;
+  g.rev.alloc((size_t)std::max<int64_t>(g.n_entries, 1));
+  DevBuf<unsigned long long> cursor; cursor.alloc(1);
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  hipLaunchKernelGGL(k_rev_build, dim3(h->n_cus * 8), dim3(TPB), 0, st, g.view(), cursor.p, g.rev.p);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipStreamSynchronize(st));
+  g.has_rev = true;
 }
 
 }  // namespace srw

@@ -92,6 +92,9 @@ struct Graph {
   DevBuf<double> eb_bins;         // the tables
   DevBuf<uint32_t> em_bits;       // membership masks of the pairs whose curr row has 33 .. eb_mask_max candidates
   int32_t eb_mask_max = 0, eb_f32 = 0;
+  DevBuf<uint32_t> rev;           // [n_entries] position of the return edge of every entry (k_walk_q1), built lazily
+  bool has_rev = false;
+  int64_t pq_bad_rows = 0;        // rows the per-call certificate turned away (build_pq_tables)
   bool eb_complete = false;       // the HBM budget did not bind: every pair into a certified row has a table
   bool has_eb = false, use_eb = false; uint32_t eb_pbits = 0, eb_qbits = 0; int32_t eb_min_sh = 8, eb_mode = 0;
   int64_t eb_tables = 0, eb_bytes = 0; double eb_build_ms = 0.0;
@@ -104,7 +107,8 @@ struct Graph {
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
-                     (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32}; }
+                     (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
+                     has_rev ? rev.p : nullptr}; }
 };
 
 struct WalkResult {
@@ -232,6 +236,7 @@ void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap);   // 
 // Per-edge bias tables for the general kernel under (p, q): mode 0 = automatic (most expensive pairs first, within the
 // HBM budget), 1 = every certified pair (tests: tiny chunks, no cost threshold).  Needs build_pq_tables first.
 void build_edge_tables(srw_handle *h, float p, float q, int mode);
+void build_rev_table(srw_handle *h);             // return-edge positions (k_walk_q1: p != 1, q == 1)
 
 // ---- walk_kernels.hip ----
 void run_walk(srw_handle *h, const srw_walk_params &P, srw_walk_stats *stats);

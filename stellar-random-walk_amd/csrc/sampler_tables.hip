@@ -351,7 +351,7 @@ __device__ inline bool pq_row_ok(int emin, bool bad, double mass) {
 }
 
 __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, double *__restrict__ pq,
-                           uint8_t *__restrict__ ok, int64_t n_slots, float p, float q) {
+                           uint8_t *__restrict__ ok, int64_t n_slots, float p, float q, unsigned long long *bad_rows) {
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
     Row r = rows[v];
     ok[v] = 0;
@@ -359,7 +359,7 @@ __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, 
     if (r.deg <= 0 || r.deg > SMALL_DEG) continue;
     PqCert c;
     for (int32_t k = 0; k < r.deg; ++k) c.add_entry(ent[r.off + k].w, p, q);
-    if (!pq_row_ok(c.emin, c.bad, c.mass)) continue;
+    if (!pq_row_ok(c.emin, c.bad, c.mass)) { atomicAdd(bad_rows, 1ull); continue; }
     double acc = 0.0;
     for (int32_t k = 0; k < r.deg; ++k) { acc += (double)(ent[r.off + k].w / q); pq[r.off + k] = acc; }
     ok[v] = 1;
@@ -385,7 +385,7 @@ __global__ void k_pq_large(Row *__restrict__ rows, const Ent *__restrict__ ent, 
       const int emin = wave_min_i32(c.emin), glsb = wave_min_i32(c.glsb);
       const bool bad = __any(c.bad);
       const double mass = wave_sum_f64(bad ? 0.0 : c.mass);
-      if (!pq_row_ok(emin, bad, mass)) continue;                     // ok[v] stays 0 (set by k_pq_small)
+      if (!pq_row_ok(emin, bad, mass)) { if (lane == 0) atomicAdd(next_slot + 1, 1ull); continue; }   // ok[v] stays 0 (set by k_pq_small)
       double carry = 0.0;                                            // exact sums: any order gives the same bits
       for (int32_t base = 0; base < r.deg; base += 64) {
         int32_t k = base + lane;
@@ -414,13 +414,16 @@ void build_pq_tables(srw_handle *h, float p, float q) {
   g.pq.ensure((size_t)g.n_entries);
   g.pq_ok.ensure((size_t)g.n_slots);
   int gs = (int)std::min<int64_t>(std::max<int64_t>((g.n_slots + 255) / 256, 1), 256 * 32);
-  DevBuf<unsigned long long> next_slot; next_slot.alloc(1);
-  SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
-  hipLaunchKernelGGL(k_pq_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.ent.p, g.pq.p, g.pq_ok.p, g.n_slots, p, q);
+  DevBuf<unsigned long long> next_slot; next_slot.alloc(2);      // [0] cursor, [1] rows without the certificate
+  SRW_HIP(hipMemsetAsync(next_slot.p, 0, 16, st));
+  hipLaunchKernelGGL(k_pq_small, dim3(gs), dim3(256), 0, st, g.rows.p, g.ent.p, g.pq.p, g.pq_ok.p, g.n_slots, p, q, next_slot.p + 1);
   hipLaunchKernelGGL(k_pq_large, dim3(256 * 8), dim3(256), 0, st, g.rows.p, g.ent.p, g.pq.p, g.pq_ok.p, g.n_slots, p, q,
                      next_slot.p);
   SRW_HIP(hipGetLastError());
+  unsigned long long nbad = 0;
+  SRW_HIP(hipMemcpyAsync(&nbad, next_slot.p + 1, 8, hipMemcpyDeviceToHost, st));
   SRW_HIP(hipStreamSynchronize(st));
+  g.pq_bad_rows = (int64_t)nbad;
   g.pq_pbits = pb; g.pq_qbits = qb; g.has_pq = true;
 }
 

@@ -84,7 +84,7 @@ __device__ inline CfoEnt load_cfo(const CfoEnt *p) {
 
 // Lattice draw (p = m * 2^-24) through the compact table: same index as fo_pick, one 16-byte load per probe.
 template <bool NT>
-__device__ inline CfoEnt cfo_pick(const CfoEnt *row, int32_t deg, uint32_t m, unsigned &reads) {
+__device__ inline CfoEnt cfo_pick(const CfoEnt *row, int32_t deg, uint32_t m, unsigned &reads, int32_t &k_out) {
   const uint32_t j = (uint32_t)(((uint64_t)m * (uint64_t)(uint32_t)deg) >> 24);
   CfoEnt e = load_cfo<NT>(row + j);
   reads = 1;
@@ -99,16 +99,23 @@ __device__ inline CfoEnt cfo_pick(const CfoEnt *row, int32_t deg, uint32_t m, un
     }
     k = lo < deg ? lo : 0;                      // no crossing: edges.head (:24)
     e = load_cfo<NT>(row + k); ++reads;
+    k_out = k;
     return e;
   }
   k = (int32_t)j - gd;
   if (gd) { e = load_cfo<NT>(row + k); ++reads; }
   while ((e.cg & 0xFFFFFFu) < m) {              // min(floor(cdf * 2^24), 2^24 - 1) < m  <=>  cdf < p
     ++k;
-    if (k >= deg) { e = load_cfo<NT>(row); ++reads; break; }   // edges.head fallback (:24)
+    if (k >= deg) { k = 0; e = load_cfo<NT>(row); ++reads; break; }   // edges.head fallback (:24)
     e = load_cfo<NT>(row + k); ++reads;
   }
+  k_out = k;
   return e;
+}
+template <bool NT>
+__device__ inline CfoEnt cfo_pick(const CfoEnt *row, int32_t deg, uint32_t m, unsigned &reads) {
+  int32_t k;
+  return cfo_pick<NT>(row, deg, m, reads, k);
 }
 
 // Returns the chosen record (id + the neighbor's row descriptor); k_out = its position.

@@ -362,6 +362,167 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// p != 1, q == 1: the only biased candidates are the return edges, so a step is a first-order step plus one
+// correction — one walker per LANE, like k_walk_first_order (r01 ran this case one walker per wave: 4.6e8 steps/s).
+// Per step, under the row certificate of sampler_tables.hip (every prefix sum exact):
+//   A'_k = PQ[k] + sum over the return edges r_i <= k of c_i,  r_i from rev[e] (up to 4 multi-edges), c_i = fl(w_i / p) - w_i,
+//   S = PQ[deg-1] + sum of all c_i
+// and the reference's acc_k = sum of fl(w'_i / S) differs from A'_k / S by at most (k + 2) u A'_k / S — the certified
+// divide-free compares of binned_resolve.  The first k that is not a certain miss is located from the first-order guide
+// table (a start position; the exact prefix sums decide) and must be a certain hit, else the walker is handed over to
+// k_walk_general — as are irregular rows, more than four return edges, and rows that need a bisection of the guide.
+// The picked compact record carries the next row descriptor, as in k_walk_first_order.
+template <bool NT>
+__global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
+                                                 int64_t n_walkers, int32_t L, int32_t first_walk, RngSpec rng, float p,
+                                                 int32_t *__restrict__ paths, int32_t *__restrict__ lens, DevCounters *ctr,
+                                                 int32_t *__restrict__ todo, unsigned long long *todo_n) {
+  __shared__ int32_t tile[TPB / 64][64][TILE + 1];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const int64_t wi = blockIdx.x * (int64_t)TPB + threadIdx.x;
+  const int64_t wave_base = wi - lane;
+  const int64_t stride = (int64_t)L + 2;
+  bool alive = wi < n_walkers, handed = false;
+  uint32_t iter = 0; int32_t src = 0;
+  Row r; r.off = 0; r.deg = 0; r.flags = 0;
+  if (alive) {
+    const int64_t it = wi / n_verts, vi = wi - it * n_verts;
+    iter = (uint32_t)(first_walk + it);
+    src = verts[vi];
+    const Row *rp = row_of(g, src);
+    if (rp) r = *rp;
+  }
+  int32_t len = 1;
+  int64_t eprev = 0;
+  unsigned long long reads = 0, dead = 0;
+  tile[wv][lane][0] = src;
+  for (int32_t s = 1; s <= L + 1; ++s) {
+    const int c = s & (TILE - 1);
+    int32_t val = -1;
+    if (alive) {
+      if (r.deg == 0) {
+        alive = false; if (s > 1) ++dead;
+      } else if (r.flags & ROW_IRREGULAR) {
+        alive = false; handed = true;
+      } else {
+        const uint32_t m = walk_bits24(rng.seed, iter, (uint32_t)src, (uint32_t)s);
+        const CfoEnt *crow = g.cfo + r.off;
+        CfoEnt e; int32_t k = -1;
+        if (s == 1) {                               // initFirstStep: raw weights = the first-order draw
+          unsigned rd; e = cfo_pick<NT>(crow, r.deg, m, rd, k); reads += rd;
+        } else {
+          const double *PQ = g.pq + r.off;
+          const uint32_t rv = g.rev[eprev];
+          int32_t rp[REV_MAX_RETURNS]; double rc[REV_MAX_RETURNS];      // return edges: input-order position, correction
+          int nr = 0;
+          double corr_all = 0.0;
+          if (rv != REV_NONE) {
+            nr = (int)(rv >> 24);
+            if (nr > REV_MAX_RETURNS) { alive = false; handed = true; nr = 0; }
+            const int64_t so = r.off + (int64_t)(rv & 0xFFFFFFu);
+#pragma unroll
+            for (int i = 0; i < REV_MAX_RETURNS; ++i) {
+              rp[i] = r.deg; rc[i] = 0.0;
+              if (i < nr) { rp[i] = (int32_t)g.sperm[so + i]; const float w = g.sw[so + i]; rc[i] = (double)(w / p) - (double)w; corr_all += rc[i]; }
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < REV_MAX_RETURNS; ++i) { rp[i] = r.deg; rc[i] = 0.0; }
+          }
+          if (alive) {
+            const double S0 = PQ[r.deg - 1], S = S0 + corr_all;
+            const double pS = (double)m * 0x1p-24 * S;
+            auto corr_upto = [&](int32_t kk) {
+              double a = 0.0;
+#pragma unroll
+              for (int i = 0; i < REV_MAX_RETURNS; ++i) a += (rp[i] <= kk) ? rc[i] : 0.0;       // exact under the certificate
+              return a;
+            };
+            auto numer = [&](int32_t kk) { return PQ[kk] + corr_upto(kk); };
+            auto not_miss = [&](int32_t kk, double num) { return !(num * (1.0 + (double)(kk + 8) * 0x1p-51) < pS); };
+            // start position: the guide entry of the bucket the target falls into in UNBIASED units (any start is
+            // correct, the loops below decide with the exact sums; a good one makes them O(1))
+            auto guide_start = [&](double tau, bool &ok) {
+              double f = tau / S0;
+              f = f < 0.0 ? 0.0 : (f > 0.99999994 ? 0.99999994 : f);
+              const uint32_t mm = (uint32_t)(f * 16777216.0);
+              const uint32_t j = (uint32_t)(((uint64_t)mm * (uint64_t)(uint32_t)r.deg) >> 24);
+              const CfoEnt ge = load_cfo<NT>(crow + j); ++reads;
+              const int32_t gd = cfo_delta(ge.cg, ge.link);
+              if (gd == CFO_GD_SAT) { ok = false; return 0; }
+              const int32_t st = (int32_t)j - gd;
+              return st < 0 ? 0 : (st >= r.deg ? r.deg - 1 : st);
+            };
+            bool ok = S > 0.0 && S0 > 0.0;
+            int32_t k0 = 0;
+            if (ok) {
+              k0 = guide_start(pS, ok);
+              const double cb = ok ? corr_upto(k0) : 0.0;
+              if (ok && cb != 0.0) {                           // past a return edge: its correction moves the answer
+                int32_t first_r = r.deg;
+#pragma unroll
+                for (int i = 0; i < REV_MAX_RETURNS; ++i) first_r = rp[i] < first_r ? rp[i] : first_r;
+                const int32_t k1 = guide_start(pS - cb, ok);
+                k0 = k1 < first_r ? first_r : k1;
+              }
+            }
+            if (!ok) { alive = false; handed = true; }
+            else {
+              // first k that is not a certain miss (A' is non-decreasing, the tolerance grows with k: monotone)
+              int guard = 0;
+              double nk = numer(k0);
+              bool nm = not_miss(k0, nk);
+              while (nm && k0 > 0 && guard < 64) {             // step back while the predecessor is not a certain miss either
+                const double np = numer(k0 - 1);
+                if (!not_miss(k0 - 1, np)) break;
+                --k0; nk = np; ++guard;
+              }
+              while (!nm && guard < 64) {                      // step forward to the first not-certain-miss
+                ++k0; ++guard;
+                if (k0 >= r.deg) break;
+                nk = numer(k0); nm = not_miss(k0, nk);
+              }
+              reads += (unsigned)guard + 1u;
+              if (guard >= 64) { alive = false; handed = true; }
+              else if (k0 >= r.deg) { k = 0; e = load_cfo<NT>(crow); ++reads; }                    // no crossing: edges.head (:24)
+              else if (nk * (1.0 - (double)(k0 + 8) * 0x1p-51) >= pS) { k = k0; e = load_cfo<NT>(crow + k); ++reads; }   // a certain hit
+              else { alive = false; handed = true; }         // a draw within rounding distance of a boundary: exact chain
+            }
+          }
+        }
+        if (alive) {
+          val = e.id; ++len;
+          eprev = r.off + k;
+          r.off = (int64_t)(e.link & CFO_NOFF_MASK); r.deg = (int32_t)((e.link >> 40) & 0x7FFFFFu);
+          r.flags = (e.link >> 63) ? ROW_IRREGULAR : 0u;
+        }
+      }
+    }
+    tile[wv][lane][c] = val;
+    if (c == TILE - 1 || s == L + 1) {
+      const int ncols = c + 1;
+      const int64_t base_slot = s - c;
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        int row = rr * 4 + (lane >> 4), col = lane & 15;
+        int64_t w = wave_base + row;
+        if (col < ncols && w < n_walkers) paths[w * stride + base_slot + col] = tile[wv][row][col];
+      }
+      __syncthreads();
+    }
+  }
+  if (wi < n_walkers) {
+    if (handed) todo[atomicAdd(todo_n, 1ull)] = (int32_t)wi;     // k_walk_general redoes it from its first step
+    else lens[wi] = len;
+  }
+  const unsigned long long my_steps = handed ? 0ull : (unsigned long long)(len - 1);
+  flush_counters(ctr, my_steps, handed ? 0ull : dead, 0, 0, reads, 0);
+  const unsigned long long tot = wave_sum_u64(my_steps);
+  if (lane == 0 && tot) atomicAdd(&ctr->strat[SRW_STRAT_Q1_LANE], tot);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Mode A: per-vertex alias draw + rejection for the p/q bias (KnightKing-style), one walker per lane, each lane
 // its own (step, trial) state machine so that lanes do not wait for each other's rejections.  Spec shared with
 // oracle/srw_oracle.c:alias_pick — trial t of step s draws Philox(ctr = (iter, src, s, t), key = (seed, 0xA11A5)):
@@ -1019,7 +1180,21 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
     const int32_t tune = (int32_t)(((P.flags >> 12) & 15) | ((P.flags & SRW_WALK_NO_BINNED) ? 16 : 0));
     // every (prev -> curr) pair has a table: the lean kernel walks, the general one only redoes what it hands over
     const bool lean = gv.eb_off && g.eb_complete && P.q != 1.0f && tune == 0 && !getenv("SRW_NO_LEAN_KERNEL");
+    // p != 1, q == 1: one walker per lane over the first-order guide table + exact prefix sums + return-edge positions
+    const bool q1 = P.q == 1.0f && P.p != 1.0f && P.rng_mode == SRW_RNG_PHILOX && g.has_cfo && g.has_pq && g.has_rev &&
+                    g.pq_bad_rows == 0 && tune == 0 && !(P.flags & SRW_WALK_NO_PREFIX) && !getenv("SRW_NO_Q1_KERNEL");
     const int32_t *todo = nullptr;
+    if (q1) {
+      h->walk_todo.ensure((size_t)n_walkers);
+      const int64_t qb = (n_walkers + TPB - 1) / TPB;
+      if ((size_t)g.n_entries * sizeof(CfoEnt) > ((size_t)2 << 30))
+        hipLaunchKernelGGL(k_walk_q1<true>, dim3((unsigned)qb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
+                           first_walk, rng, P.p, d_paths, d_lens, h->counters.p, h->walk_todo.p, h->walk_cursor.p + 1);
+      else
+        hipLaunchKernelGGL(k_walk_q1<false>, dim3((unsigned)qb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
+                           first_walk, rng, P.p, d_paths, d_lens, h->counters.p, h->walk_todo.p, h->walk_cursor.p + 1);
+      todo = h->walk_todo.p;
+    }
     if (lean) {
       h->walk_todo.ensure((size_t)n_walkers);
       int64_t lb = std::min<int64_t>((n_walkers * 64 + TPB - 1) / TPB, (int64_t)h->n_cus * 16);
@@ -1045,6 +1220,12 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
   if (first_order) build_first_order_tables(h, P.rng_mode != SRW_RNG_PHILOX || (P.flags & SRW_WALK_NO_COMPACT));
   else build_membership(h);                           // sorted rows: general and alias kernels only
+  // p != 1, q == 1 (k_walk_q1): the compact first-order records (guide + linked rows) and the return-edge positions
+  if (!alias && !first_order && P.q == 1.0f && P.p != 1.0f && P.rng_mode == SRW_RNG_PHILOX && h->cfg.world == 1 &&
+      !(P.flags & (SRW_WALK_NO_PREFIX | SRW_WALK_NO_COMPACT)) && !getenv("SRW_NO_Q1_KERNEL")) {
+    build_first_order_tables(h, false);
+    build_rev_table(h);
+  }
   if (alias) build_alias_tables(h);
   const bool general = !alias && !first_order;
   // optional accelerators, most valuable first (each one skips itself when HBM is short):

@@ -791,19 +791,74 @@ def test_giant_row_mass_certificate(eng, oracle):
             assert served > 0.4 * st["n_steps"], st     # every step that lands on a hub is served by a search, not the scan
 
 
+# ---- p != 1, q == 1: one walker per lane (k_walk_q1) ----------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["rmat12", "rmat12w", "rmat11wd", "rmat12f", "rmat12x", "multi", "multi_neg", "karate", "hub"])
+def test_q1_per_lane_kernel(eng, oracle, case):
+    """Return-edge-only bias: the per-lane kernel (guide table + exact prefix sums + return-edge position) must equal the
+    oracle, hand over what it cannot certify (several return edges, irregular rows, lattice ties) and say so."""
+    directed = False
+    if case.startswith("rmat"):
+        sc = int(case[4:6])
+        weighted, directed = "w" in case[6:], case.endswith("d")
+        s, d, w = rmat_lines(oracle, sc, edge_factor=16, weighted=weighted)
+        if case.endswith("f"):
+            w = (0.5 + 1.5 * np.random.default_rng(4).random(len(s))).astype(np.float32)
+        if case.endswith("x"):      # exponents spread over 2^-20 .. 2^20: hub rows fail the certificate -> general kernel for all
+            w = (2.0 ** np.random.default_rng(5).integers(-20, 21, len(s))).astype(np.float32)
+    elif case == "karate":
+        eng.load_edgelist(KARATE)
+        g = oracle.Graph.load(KARATE)
+        s = None
+    elif case == "hub":
+        n = 30000
+        s = np.concatenate([np.zeros(n, np.int32), np.arange(1, n, dtype=np.int32)])
+        d = np.concatenate([np.arange(1, n + 1, dtype=np.int32), np.arange(2, n + 1, dtype=np.int32)])
+        w = np.random.default_rng(9).integers(1, 5, len(s)).astype(np.float32)
+    else:
+        s, d, w = random_multigraph(np.random.default_rng(11), 80, 900, True, id_lo=-30 if case == "multi_neg" else 3)
+    if s is not None:
+        g = oracle.Graph.from_coo(s, d, w, directed=directed)
+        eng.load_coo(s, d, w, directed=directed)
+    for p in (0.25, 4.0, 0.5):
+        ref = g.walk(p=p, q=1.0, walk_length=30, num_walks=2, first_walk=1, seed=77, threads=8)
+        paths, lens, st = eng.walk(p=p, q=1.0, walk_length=30, num_walks=2, first_walk=1, seed=77)
+        assert np.array_equal(lens, ref[1]) and np.array_equal(paths, ref[0]) and st["n_steps"] == ref[2], (case, p)
+        ss = st["strategy_steps"]
+        if case in ("rmat12", "rmat12w", "rmat11wd", "rmat12f", "karate", "hub"):
+            assert ss["q1_lane"] > 0.5 * st["n_steps"], (case, st)
+        if case == "rmat12x":
+            assert ss["q1_lane"] == 0, st                       # uncertified rows: the whole call stays with the general kernel
+        # draws exactly on CDF boundaries: constant r runs the general kernel (no lattice stream), must agree as well
+        refc = g.walk(p=p, q=1.0, walk_length=8, rng="const", const_r=0.5, threads=8)
+        pc, lc, _ = eng.walk(p=p, q=1.0, walk_length=8, rng="const", const_r=0.5)
+        assert np.array_equal(pc, refc[0]) and np.array_equal(lc, refc[1])
+
+
 def test_wide_id_range_is_refused_up_front(eng):
     """Every per-vertex table is dense over id - min(id): a sparse id space is refused
     with SRW_ERR_NOMEM and a message that says what to do, before any allocation proportional to the range — and the
     handle stays usable."""
     P = pkg()
-    for s, d in (([0, 2000000000], [1, 3]), ([2147483647], [-2147483648])):
-        with pytest.raises(P.SrwError) as ei:
-            eng.load_coo(np.array(s, np.int32), np.array(d, np.int32))
-        assert ei.value.code == P.ERR_NOMEM and "renumber" in str(ei.value), str(ei.value)
-    pid = np.zeros(2, np.int32)
+    with pytest.raises(P.SrwError) as ei:                       # the whole int32 range: never
+        eng.load_coo(np.array([2147483647], np.int32), np.array([-2147483648], np.int32))
+    assert ei.value.code == P.ERR_NOMEM and "renumber" in str(ei.value), str(ei.value)
+    pid = np.zeros(1, np.int32)
     with pytest.raises(P.SrwError) as ei:           # the partitioned load used to build a host table of the range first
-        eng.load_coo(np.array([0, 2000000000], np.int32), np.array([1, 3], np.int32), pid=pid)
+        eng.load_coo(np.array([2147483647], np.int32), np.array([-2147483648], np.int32), pid=pid)
     assert ei.value.code == P.ERR_NOMEM
+    # two billion slots for four vertices: refused when HBM is short, else it must simply work (96 GB of tables on a 288 GB part)
+    s, d = np.array([0, 2000000000], np.int32), np.array([1, 3], np.int32)
+    try:
+        eng.load_coo(s, d)
+    except P.SrwError as e:
+        assert e.code == P.ERR_NOMEM and "renumber" in str(e)
+    else:
+        import oracle_py
+        g = oracle_py.Graph.from_coo(s, d, None)
+        assert eng.stats() == (4, 4)
+        paths, lens, _ = eng.walk(walk_length=5, seed=3)
+        rp, rl, _ = g.walk(walk_length=5, seed=3)
+        assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
     eng.load_edgelist(KARATE)
     assert eng.stats() == (34, 156)
 

@@ -72,7 +72,13 @@ def test_weighted_rmat_biased_walks_equal_oracle(eng, oracle, scale, n_sample, L
             if scale >= 20:
                 assert s2["w"] + s2["p2"] + s2["p3"] > 0, st2
         else:
-            assert ss["prefix"] > 0 and st["edge_tables"] == 0, st
+            assert ss["q1_lane"] > 0.99 * st["n_steps"] and st["edge_tables"] == 0, st      # one walker per lane
+            os.environ["SRW_NO_Q1_KERNEL"] = "1"
+            try:
+                pw, lw, stw = eng.walk(p=p, q=q, walk_length=L, seed=1234)                   # one walker per wave
+            finally:
+                del os.environ["SRW_NO_Q1_KERNEL"]
+            assert np.array_equal(pw, paths) and np.array_equal(lw, lens) and stw["strategy_steps"]["prefix"] > 0
 
 
 def test_directed_rmat_biased_walk_equals_oracle(eng, oracle):

@@ -365,12 +365,12 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
 // p != 1, q == 1: the only biased candidates are the return edges, so a step is a first-order step plus one
 // correction — one walker per LANE, like k_walk_first_order (r01 ran this case one walker per wave: 4.6e8 steps/s).
 // Per step, under the row certificate of sampler_tables.hip (every prefix sum exact):
-//   A'_k = PQ[k] + sum over the return edges r_i <= k of c_i,  r_i from rev[e] (up to 4 multi-edges), c_i = fl(w_i / p) - w_i,
+//   A'_k = PQ[k] + sum over the return edges r_i <= k of c_i,  r_i from rev[e] (multi-edges: four in registers, more by loop), c_i = fl(w_i / p) - w_i,
 //   S = PQ[deg-1] + sum of all c_i
 // and the reference's acc_k = sum of fl(w'_i / S) differs from A'_k / S by at most (k + 2) u A'_k / S — the certified
 // divide-free compares of binned_resolve.  The first k that is not a certain miss is located from the first-order guide
 // table (a start position; the exact prefix sums decide) and must be a certain hit, else the walker is handed over to
-// k_walk_general — as are irregular rows, more than four return edges, and rows that need a bisection of the guide.
+// k_walk_general — as are irregular rows, 255+ parallel return edges, and rows that need a bisection of the guide.
 // The picked compact record carries the next row descriptor, as in k_walk_first_order.
 template <bool NT>
 __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
@@ -416,15 +416,17 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
           int32_t rp[REV_MAX_RETURNS]; double rc[REV_MAX_RETURNS];      // return edges: input-order position, correction
           int nr = 0;
           double corr_all = 0.0;
+          int64_t so = 0;                                   // first return edge in curr's sorted row
           if (rv != REV_NONE) {
             nr = (int)(rv >> 24);
-            if (nr > REV_MAX_RETURNS) { alive = false; handed = true; nr = 0; }
-            const int64_t so = r.off + (int64_t)(rv & 0xFFFFFFu);
+            if (nr >= 255) { alive = false; handed = true; nr = 0; }      // the count saturated: more multi-edges than it can say
+            so = r.off + (int64_t)(rv & 0xFFFFFFu);
 #pragma unroll
             for (int i = 0; i < REV_MAX_RETURNS; ++i) {
               rp[i] = r.deg; rc[i] = 0.0;
               if (i < nr) { rp[i] = (int32_t)g.sperm[so + i]; const float w = g.sw[so + i]; rc[i] = (double)(w / p) - (double)w; corr_all += rc[i]; }
             }
+            for (int i = REV_MAX_RETURNS; i < nr; ++i) { const float w = g.sw[so + i]; corr_all += (double)(w / p) - (double)w; }   // (small graphs: dozens of duplicates between hubs)
           } else {
 #pragma unroll
             for (int i = 0; i < REV_MAX_RETURNS; ++i) { rp[i] = r.deg; rc[i] = 0.0; }
@@ -436,6 +438,8 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
               double a = 0.0;
 #pragma unroll
               for (int i = 0; i < REV_MAX_RETURNS; ++i) a += (rp[i] <= kk) ? rc[i] : 0.0;       // exact under the certificate
+              for (int i = REV_MAX_RETURNS; i < nr; ++i)
+                if ((int32_t)g.sperm[so + i] <= kk) { const float w = g.sw[so + i]; a += (double)(w / p) - (double)w; }
               return a;
             };
             auto numer = [&](int32_t kk) { return PQ[kk] + corr_upto(kk); };
@@ -462,6 +466,7 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
                 int32_t first_r = r.deg;
 #pragma unroll
                 for (int i = 0; i < REV_MAX_RETURNS; ++i) first_r = rp[i] < first_r ? rp[i] : first_r;
+                for (int i = REV_MAX_RETURNS; i < nr; ++i) { const int32_t q_ = (int32_t)g.sperm[so + i]; first_r = q_ < first_r ? q_ : first_r; }
                 const int32_t k1 = guide_start(pS - cb, ok);
                 k0 = k1 < first_r ? first_r : k1;
               }

@@ -14,7 +14,7 @@ srw_walk_and_save: walk + device formatter + PCIe + part files, text bytes per s
 
 After the headline, with one GPU, `configs` carries the other BASELINE.json configurations that fit one GPU — C2
 (RMAT-20, p = q = 1), C3 (weighted RMAT-24, p = .25 q = 4; Mode R = bit-exact reference sampler, and Mode A = alias tables
-+ rejection), C5's stand-in (directed RMAT-26 ef 27, p = 4 q = .5; Mode R and Mode A) — each with its own value, kernel
++ rejection; the same graph with q = 1), C5's stand-in (directed RMAT-26 ef 27, p = 4 q = .5; Mode R and Mode A) — each with its own value, kernel
 time, setup and roofline.
 
 Multi-GPU (`--gpus N` under torch.distributed.run): `value` is the replicated mode (the graph fits one 288 GB GPU, so
@@ -78,12 +78,18 @@ def roofline_of(stats, steps_per_launch, avg_ms, scale=None):
         alg = steps_per_launch * 4 + stats["ent_reads"] * 32 + stats["n_walkers"] * 24
         name = "k_walk_alias"
         formula = "alias records read*32 + 4 B path/step + 24 B/walker (probes of the rejection test not counted: lower bound)"
+    elif kind == 2 and stats.get("strategy_steps", {}).get("q1_lane", 0) > 0.5 * max(stats["n_steps"], 1):
+        # p != 1, q == 1, one walker per lane (§4.8): per step 4 B path + 4 B rev + 8 B return edge (position, weight) + 8 B
+        # row sum; + the guide records (16 B) and prefix probes (8 B) the kernel counts, taken at 12 B each
+        alg = steps_per_launch * 24 + stats["ent_reads"] * 12 + stats["n_walkers"] * 24
+        name = "k_walk_q1"
+        formula = "24 B/step (path, rev, return edge, row sum) + counted guide records / prefix probes * 12 B + 24 B/walker"
     else:
         # general kernel (§4.4, SURVEY §8d Mode R): 16 B row + 4 B path per step; + what the step's sampler reads:
         # streamed rows 8*deg(curr) (+ 4*deg(prev) of membership), searches their strategy's bytes, per-edge tables
         # 512 B + 16 B per evaluated candidate, membership masks 8*deg + mask words (all counted by the kernel)
         alg = steps_per_launch * 20 + stats["sum_deg_curr"] * 8 + stats.get("sum_deg_prev", 0) * 4 + stats.get("trials", 0)
-        name = "k_walk_general"
+        name = "k_walk_tables + k_walk_general" if stats.get("edge_tables", 0) else "k_walk_general"
         formula = "20 B/step + 8*deg(curr) (+4*deg(prev)) for streamed rows + bytes read by the searches / per-edge tables / masks (kernel counters)"
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -377,6 +383,7 @@ def main():
             plan = [("C2", 20, 16, False, False, 1.0, 1.0, "reference", 10, 1),
                     ("C3 Mode R", 24, 16, True, False, 0.25, 4.0, "reference", 2, 1),
                     ("C3 Mode A", 24, 16, True, False, 0.25, 4.0, "alias", 3, 1),
+                    ("C3's graph with q = 1 (return-edge bias only), Mode R", 24, 16, True, False, 0.25, 1.0, "reference", 3, 1),
                     ("C5 stand-in Mode R", 26, 27, False, True, 4.0, 0.5, "reference", 1, 1),
                     ("C5 stand-in Mode A", 26, 27, False, True, 4.0, 0.5, "alias", 2, 1)]
             for (name, sc, ef, wt, dr, p, q, smp, k, w) in plan:

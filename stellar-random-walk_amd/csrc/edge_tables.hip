@@ -10,13 +10,13 @@
 //
 // — the exact chunk prefixes of the corrections the binned search of sampling.h accumulates in LDS (same binned_fill,
 // same certificate: every such sum is exact in any order), at most 64 chunks per pair (one lane each in the search),
-// 512 B per pair.  A step over a pair with a table is then: 64 chunk ends compared in one wave instruction + ONE chunk
+// 512 B per pair (256 B where every prefix is exactly representable in binary32: ROW_PQ_F32).  A step over a pair with a table is then: 64 chunk ends compared in one wave instruction + ONE chunk
 // evaluated candidate by candidate (sampling.h:binned_resolve) — the same arithmetic, hence the same bits, as the
 // on-the-fly search.  Pairs are prioritised by the cost model of the on-the-fly strategies (binned_cost) and take what
 // HBM is left after every other structure; everything else keeps the on-the-fly path.
 //
-// Rows of at most 512 candidates get a second, smaller kind of table instead: the membership MASK of the pair (bit k =
-// "candidate k of N(curr) is in N(prev)", 4 .. 64 bytes; rows of at most 32 candidates keep it inline in the per-entry
+// Rows of fewer than 256 candidates get a second, smaller kind of table instead: the membership MASK of the pair (bit k =
+// "candidate k of N(curr) is in N(prev)", 4 .. 32 bytes; rows of at most 32 candidates keep it inline in the per-entry
 // offset word).  The step then needs no membership lookup at all (sampling.h:wave_pick_masked) — q-independent, but
 // rebuilt with the rest for simplicity.
 //

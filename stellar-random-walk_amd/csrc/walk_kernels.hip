@@ -1248,7 +1248,9 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
                        !(P.flags & SRW_WALK_NO_BINNED);
   // with per-edge tables the bitmaps only serve the tables' own construction and the probes of a located chunk: a
   // quarter of the budget is plenty, the rest goes to the tables
-  if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, want_eb ? (size_t)16 << 30 : (size_t)64 << 30);
+  size_t hub_cap = want_eb ? (size_t)16 << 30 : (size_t)64 << 30;
+  { const char *e = getenv("SRW_HUB_BUDGET_GB"); if (e && *e) hub_cap = (size_t)(atof(e) * (double)((size_t)1 << 30)); }
+  if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, hub_cap);
   h->g.use_hub = want_hub;
   // ... and, last (they take what HBM is left), the per-edge bias tables: the most expensive (prev, curr) pairs get
   // their N(prev) ∩ N(curr) corrections precomputed once per (p, q) instead of once per visit

@@ -74,9 +74,6 @@ struct alignas(32) AEnt {
   uint32_t nflags;
 };
 
-struct alignas(16) Walker {
-  int32_t wid, src, prev, curr;
-};
 
 struct GraphView {
   const Row *rows;

@@ -139,7 +139,9 @@ Paths RandomWalk::walkImpl(bool useConst, float constR) {
 // super-step (srw_cluster_*: what replaces transferWalkersToTheirPartitions, RandomWalk.scala:186-192); same files.
 void RandomWalk::executeAndSaveSharded(int partitions, const std::string &output) {
   std::vector<int32_t> devs;
-  for (int i = 0; i < config_.gpus; ++i) devs.push_back(config_.device + i);
+  // SRW_CLUSTER_SAME_DEVICE=1 (tests on a one-GPU box): every shard on --device
+  const bool same = getenv("SRW_CLUSTER_SAME_DEVICE") != nullptr;
+  for (int i = 0; i < config_.gpus; ++i) devs.push_back(same ? config_.device : config_.device + i);
   srw_cluster *cl = nullptr;
   if (srw_cluster_create(devs.data(), (int32_t)devs.size(), config_.partitioned ? SRW_CFG_OWNER_FROM_PARTITIONS : 0, &cl) != SRW_OK)
     throw std::runtime_error(std::string("srw_cluster_create: ") + srw_last_error(nullptr));

@@ -715,20 +715,22 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
 //
 // A walker standing on v is processed by owner(v); its PATH lives on its home rank = owner(source).  What moves between
 // ranks each super-step is fixed-size records in fixed-capacity CHUNKS, one chunk per (sender, receiver) pair:
-//     chunk = { u32 n_walkers, n_rets, overflow, pad } | Walker[cap_w] {lw, src, prev, curr} | PathRet[cap_r] {lw, v}
+//     chunk = { u32 n_walkers, n_rets, 0, 0 } | SWalker[cap_w] {lw, src, prev, curr, h0, h1, h2, -} | PathRet[cap_r] {lw, first | count << 24, v[4]}
 // lw = (local index of the source vertex on its home rank) * batch + (walk iteration inside the batch): the home rank's
-// path row, and lw % batch is the RNG's iteration word.  A return with the top bit of lw set is a death notice
-// {lw, path length}: lens start at walk_length + 2 and only walkers that stop early are corrected.  A rank's receive buffer is `world` chunks (one per sender),
-// its send side is `world` destination pointers — the local send buffer (one equal-split all_to_all_single moves it,
-// distributed.py) or, inside one process, the peers' receive buffers themselves (xGMI peer stores, cluster.cpp).
+// path row, and lw % batch is the RNG's iteration word.  A walker carries the vertices of its current group of four
+// path slots (h0..h2) and returns them home together; a return with the top bit of lw set is a death notice (the
+// path length is first slot + count): lens start at walk_length + 2 and only walkers that stop early are corrected.
+// A rank's receive buffer is `world` chunks (one per sender), its send side is `world` destination pointers — the
+// local send buffer (one equal-split all_to_all_single moves it, distributed.py) or, inside one process, the peers'
+// receive buffers themselves (xGMI peer stores, cluster.cpp).
 // Everything is sized and counted on the device: NO host synchronisation per super-step; an overflowing chunk drops
-// its surplus and raises a flag the host reads once per walk call (it then retries with more slack).
+// its surplus and raises a flag the host reads once per batch (the batch is then redone with more slack).
 //   k_sh_seed    : the rank's own walkers, spread over the chunks of its receive buffer; path slot 0, lens = L + 2
-//   k_sh_apply   : path returns of the previous super-step -> paths[lw][step - 1]; death notices -> lens[lw]
-//   k_sh_step(_fo): sample every incoming walker in place into `scratch` (dead ends: lw = -1), count the block's
-//                  survivors per destination owner and the returns per home rank in LDS -> blk[b][2 * world]
+//   k_sh_apply   : path returns of the previous super-step -> up to four consecutive path slots; death notices -> lens
+//   k_sh_step(_fo): sample every incoming walker once into `scratch` (kind says what the bucket kernel must emit), count
+//                  the block's survivors per destination owner and the returns per home rank in LDS -> blk[b][2 * world]
 //   k_sh_offsets : one block: scan of blk over the blocks -> every block's write cursors; chunk headers
-//   k_sh_bucket  : re-reads the slice, writes walkers to chunk[owner(next)] and {lw, next} to chunk[home(src)]
+//   k_sh_bucket  : re-reads the slice, writes walkers to chunk[owner(next)] and path returns to chunk[home(src)]
 // The general kernel keeps one wave per record and the same samplers as k_walk_general (bit-identical paths for any
 // world, asserted against the oracle).
 constexpr int SHARD_MAX_WORLD = 64;

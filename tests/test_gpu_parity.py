@@ -328,6 +328,26 @@ def test_cli_end_to_end(oracle, tmp_path):
     assert r2.returncode == 1 and "already exists" in r2.stderr
 
 
+def test_cli_sharded_gpus_flag(oracle, tmp_path):
+    """stellar-rw --gpus 3: the graph sharded by source vertex over three shards (all on device 0 here), same files as the
+    single-GPU run, for a biased directed walk with dead ends."""
+    import subprocess
+    env = dict(os.environ, SRW_CLUSTER_SAME_DEVICE="1")
+    out = tmp_path / "out3"
+    r = subprocess.run([pkg().CLI_PATH, "--cmd", "randomwalk", "--numWalks", "2", "--p", "0.5", "--q", "2", "--walkLength", "12",
+                        "--input", KARATE, "--output", str(out), "--directed", "true", "--seed", "7", "--gpus", "3"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines()[:2] == ["edges: 78", "vertices: 34"]
+    g = oracle.Graph.load(KARATE, directed=True)
+    rp, rl, _ = g.walk(p=0.5, q=2.0, walk_length=12, num_walks=2, seed=7)
+    want = "".join("\t".join(str(int(x)) for x in p[:n]) + "\n" for p, n in zip(rp, rl))
+    assert (out / "path" / "part-00000").read_text() == want
+    r2 = subprocess.run([pkg().CLI_PATH, "--cmd", "randomwalk", "--input", KARATE, "--output", str(out), "--gpus", "3"],
+                        capture_output=True, text=True, env=env)
+    assert r2.returncode == 1 and "already exists" in r2.stderr
+
+
 # ---- vertex-sharded path: several shards on one GPU, the in-process cluster (peer stores + events) -----------------
 @pytest.mark.parametrize("world,p,q,directed", [(1, 1.0, 1.0, False), (2, 1.0, 1.0, False), (2, 0.5, 1.0, True), (3, 4.0, 1.0, False),
                                                  (2, 0.25, 4.0, False), (3, 4.0, 0.5, True), (8, 1.0, 1.0, True)])

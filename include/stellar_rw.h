@@ -159,7 +159,8 @@ enum { /* srw_walk_stats.strategy_steps: which sampler of the general (second-or
   SRW_STRAT_PREFIX = 6,     /* q == 1: prefix-sum search with the return edges as a short list */
   SRW_STRAT_CHAIN = 7,      /* the reference's sequential f64 chain (irregular rows, draws on a CDF boundary) */
   SRW_STRAT_EDGE_MASK = 8,  /* precomputed per-edge membership mask (rows below 256 candidates): no lookup at all */
-  SRW_STRAT_Q1_LANE = 9     /* p != 1, q == 1: one walker per lane (first-order guide table + exact prefix sums + return edge) */
+  SRW_STRAT_Q1_LANE = 9,    /* p != 1, q == 1: one walker per lane (first-order guide table + exact prefix sums + return edge) */
+  SRW_STAT_HANDED_OVER = 10 /* not a sampler: WALKERS the per-edge-table / per-lane kernels handed to the general kernel (redone there) */
 };
 
 /* Replaces RandomWalk.randomWalk (M/algorithm/RandomWalk.scala:75-176) incl. initFirstStep (:51-66):
@@ -214,7 +215,7 @@ int32_t srw_alias_row(srw_handle *h, int32_t v, float *prob, int32_t *alias, int
  * The keyed RNG makes the paths bit-identical for any world size (tests assert it against the oracle). */
 typedef struct {            /* 32 bytes on the wire */
   int32_t lw;               /* home rank's path row: local vertex index * batch + iteration in batch */
-  int32_t src, prev, curr;
+  int32_t src, prev, curr;  /* (linked p = q = 1 walk: prev | kind << 32 = row link of curr on its owner) */
   int32_t h0, h1, h2;       /* vertices of the current group of four path slots not yet returned home */
   int32_t kind;             /* 0 on the wire */
 } srw_walker;
@@ -245,6 +246,25 @@ int32_t srw_shard_flush(srw_handle *h, const srw_walk_params *params, int32_t ba
                         const void *d_recv, void *d_paths, void *d_lens);
 /* Synchronises the stream; steps / dead ends since srw_shard_begin; *overflow != 0: a chunk was too small. */
 int32_t srw_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow);
+/* Device memory on the handle's GPU for callers without an allocator of their own (exchange buffers of the sharded
+ * walk: one hipMalloc per buffer — RCCL faulted on multi-GB buffers that were sub-blocks of a caching allocator's
+ * segment, profiles/r02i).  srw_device_free(h, NULL) is a no-op. */
+int32_t srw_device_alloc(srw_handle *h, int64_t bytes, void **d_ptr);
+int32_t srw_device_free(srw_handle *h, void *d_ptr);
+/* Optional, once per loaded graph, before the first p = q = 1 walk: row descriptors across shards.  The replicated
+ * first-order records carry the row descriptor of the neighbor they name, so a step never reads the row table; on a
+ * shard that row lives on the neighbor's OWNER.  Each shard exports its row table (16 bytes per dense id slot:
+ * int64 offset, int32 degree, uint32 flags; zeros for vertices it does not own), the tables are combined by an
+ * element-wise maximum of their int64 words (an all-reduce MAX; inside one process srw_shard_rows_merge over peer
+ * pointers), and srw_shard_rows_commit derives 16-byte records whose links point into the owners' tables.  The walkers
+ * of a p = q = 1 Philox walk then travel with the link of the vertex they stand on (srw_walker.prev / kind hold it),
+ * and sampling + bucketing run as one kernel.  EVERY shard must end up linked (*linked == 1) — if one does not (a
+ * record needing an escape), call srw_shard_rows_release on all of them: the unlinked path keeps working. */
+int32_t srw_shard_rows_count(const srw_handle *h, int64_t *n_slots);
+int32_t srw_shard_rows_export(srw_handle *h, void *d_rows, int64_t n_slots);
+int32_t srw_shard_rows_merge(srw_handle *h, void *d_rows, const void *d_other_rows, int64_t n_slots);
+int32_t srw_shard_rows_commit(srw_handle *h, const void *d_rows_all, int64_t n_slots, int32_t *linked);
+int32_t srw_shard_rows_release(srw_handle *h);
 
 /* ---- the same walk inside ONE process over several devices (CLI --gpus N, the JNI host) ------------------------------ */
 /* One sharded handle per device, peer access enabled; the bucket kernels store every chunk directly into the receiving

@@ -64,7 +64,7 @@ class ShardLayout(C.Structure):
     _fields_ = [("cap_walkers", C.c_int64), ("cap_rets", C.c_int64), ("chunk_bytes", C.c_int64)]
 
 
-STRATEGIES = ("edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain", "edge_mask", "q1_lane", "_10", "_11")   # SRW_STRAT_*
+STRATEGIES = ("edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain", "edge_mask", "q1_lane", "handed_over_walkers", "_11")   # SRW_STRAT_*
 
 
 # every symbol include/stellar_rw.h declares
@@ -73,7 +73,8 @@ EXPORTS = [
     "srw_load_adjacency", "srw_generate_rmat", "srw_graph_stats", "srw_graph_vertices", "srw_graph_neighbors",
     "srw_graph_partition", "srw_alias_row", "srw_walk", "srw_walk_to_host", "srw_walk_and_save", "srw_host_alloc", "srw_host_free", "srw_fetch_paths", "srw_device_paths", "srw_write_paths",
     "srw_shard_capacity", "srw_shard_vertex_ranks", "srw_shard_layout_for", "srw_shard_begin", "srw_shard_superstep",
-    "srw_shard_flush", "srw_shard_finish", "srw_cluster_create", "srw_cluster_destroy", "srw_cluster_last_error",
+    "srw_shard_flush", "srw_shard_finish", "srw_shard_rows_count", "srw_shard_rows_export", "srw_shard_rows_merge",
+    "srw_shard_rows_commit", "srw_shard_rows_release", "srw_device_alloc", "srw_device_free", "srw_cluster_create", "srw_cluster_destroy", "srw_cluster_last_error",
     "srw_cluster_shard", "srw_cluster_load_edgelist", "srw_cluster_load_coo", "srw_cluster_generate_rmat",
     "srw_cluster_graph_stats", "srw_cluster_walk", "srw_cluster_fetch_paths", "srw_cluster_walk_and_save",
     "srw_sample", "srw_second_order_weights",
@@ -126,6 +127,13 @@ def lib():
                                       C.POINTER(vp), vp, vp]
     L.srw_shard_flush.argtypes = [vp, C.POINTER(WalkParams), C.c_int32, C.POINTER(ShardLayout), vp, vp, vp]
     L.srw_shard_finish.argtypes = [vp, C.POINTER(WalkStats), i32p]
+    L.srw_shard_rows_count.argtypes = [vp, i64p]
+    L.srw_shard_rows_export.argtypes = [vp, vp, C.c_int64]
+    L.srw_shard_rows_merge.argtypes = [vp, vp, vp, C.c_int64]
+    L.srw_shard_rows_commit.argtypes = [vp, vp, C.c_int64, i32p]
+    L.srw_shard_rows_release.argtypes = [vp]
+    L.srw_device_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
+    L.srw_device_free.argtypes = [vp, vp]
     L.srw_cluster_create.argtypes = [i32p, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.srw_cluster_destroy.argtypes = [vp]
     L.srw_cluster_destroy.restype = None

@@ -372,7 +372,7 @@ int32_t srw_shard_begin(srw_handle *h, const srw_walk_params *params, int32_t ba
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
     need(params && layout && d_recv && d_paths && d_lens, "null argument");
-    run_shard_begin(h, batch, *layout, d_recv, (int32_t *)d_paths, (int32_t *)d_lens, (int64_t)params->walk_length + 2);
+    run_shard_begin(h, *params, batch, *layout, d_recv, (int32_t *)d_paths, (int32_t *)d_lens, (int64_t)params->walk_length + 2);
   });
 }
 
@@ -399,6 +399,45 @@ int32_t srw_shard_flush(srw_handle *h, const srw_walk_params *params, int32_t ba
 int32_t srw_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] { run_shard_finish(h, stats, overflow); });
+}
+
+int32_t srw_device_alloc(srw_handle *h, int64_t bytes, void **d_ptr) {
+  if (!h || !d_ptr || bytes < 0) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    void *p = nullptr;
+    const hipError_t e = hipMalloc(&p, (size_t)std::max<int64_t>(bytes, 1));
+    if (e != hipSuccess) { (void)hipGetLastError(); throw Error(SRW_ERR_NOMEM, std::string("hipMalloc of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(e)); }
+    *d_ptr = p;
+  });
+}
+int32_t srw_device_free(srw_handle *h, void *d_ptr) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { if (d_ptr) SRW_HIP(hipFree(d_ptr)); });
+}
+
+int32_t srw_shard_rows_count(const srw_handle *h, int64_t *n_slots) {
+  if (!h || !h->g.loaded || !n_slots) return SRW_ERR_INVALID;
+  *n_slots = h->g.n_slots;
+  return SRW_OK;
+}
+int32_t srw_shard_rows_export(srw_handle *h, void *d_rows, int64_t n_slots) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { need(d_rows, "null argument"); shard_rows_export(h, d_rows, n_slots); });
+}
+int32_t srw_shard_rows_merge(srw_handle *h, void *d_rows, const void *d_other_rows, int64_t n_slots) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { need(d_rows && d_other_rows, "null argument"); shard_rows_merge(h, d_rows, d_other_rows, n_slots); });
+}
+int32_t srw_shard_rows_commit(srw_handle *h, const void *d_rows_all, int64_t n_slots, int32_t *linked) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(d_rows_all && linked, "null argument");
+    *linked = shard_rows_commit(h, d_rows_all, n_slots) ? 1 : 0;
+  });
+}
+int32_t srw_shard_rows_release(srw_handle *h) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { shard_rows_release(h); });
 }
 
 int32_t srw_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index) {

@@ -33,6 +33,7 @@ struct srw_cluster {
   std::vector<Batch> batches;                      // of the last walk
   int32_t walk_length = 0, num_walks = 0;
   bool valid = false;
+  int rows_linked = -1;                            // -1: not tried for this graph; 0: some shard could not; 1: every shard linked
   int32_t world() const { return (int32_t)sh.size(); }
 };
 
@@ -49,6 +50,40 @@ void ck(srw_cluster *c, int r, int32_t rc) {
 }
 void each(srw_cluster *c, const std::function<int32_t(int, srw_handle *)> &f) {
   for (int r = 0; r < c->world(); ++r) ck(c, r, f(r, c->sh[(size_t)r]));
+}
+}  // namespace
+
+namespace {
+// Row descriptors across the shards (srw_shard_rows_*): every shard exports its table, takes the element-wise maximum
+// with the others' (peer reads), and derives its linked first-order records.  All or nothing.
+void link_rows(srw_cluster *c) {
+  const int32_t world = c->world();
+  c->rows_linked = 0;
+  if (getenv("SRW_SHARD_NO_LINKS")) return;
+  int64_t n_slots = 0;
+  ck(c, 0, srw_shard_rows_count(c->sh[0], &n_slots));
+  if (n_slots <= 0) return;
+  std::vector<DevBuf<char>> own((size_t)world), acc((size_t)world);
+  for (int r = 0; r < world; ++r) {
+    SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
+    own[(size_t)r].alloc((size_t)n_slots * 16);
+    ck(c, r, srw_shard_rows_export(c->sh[(size_t)r], own[(size_t)r].p, n_slots));
+  }
+  bool all = true;
+  for (int r = 0; r < world; ++r) {
+    SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
+    acc[(size_t)r].alloc((size_t)n_slots * 16);
+    SRW_HIP(hipMemcpyAsync(acc[(size_t)r].p, own[(size_t)r].p, (size_t)n_slots * 16, hipMemcpyDeviceToDevice, c->sh[(size_t)r]->stream));   // (stream order with the merges)
+    for (int o = 0; o < world; ++o)
+      if (o != r) ck(c, r, srw_shard_rows_merge(c->sh[(size_t)r], acc[(size_t)r].p, own[(size_t)o].p, n_slots));
+    int32_t linked = 0;
+    ck(c, r, srw_shard_rows_commit(c->sh[(size_t)r], acc[(size_t)r].p, n_slots, &linked));
+    acc[(size_t)r].release();
+    all = all && linked != 0;
+  }
+  for (int r = 0; r < world; ++r) { SRW_HIP(hipSetDevice(c->dev[(size_t)r])); own[(size_t)r].release(); }
+  if (!all) { for (int r = 0; r < world; ++r) ck(c, r, srw_shard_rows_release(c->sh[(size_t)r])); return; }
+  c->rows_linked = 1;
 }
 }  // namespace
 
@@ -109,7 +144,7 @@ int32_t srw_cluster_load_edgelist(srw_cluster *c, const char *path, int32_t dire
                                   int32_t rdd_partitions) {
   if (!c) return SRW_ERR_INVALID;
   return cguard(c, [&] {
-    c->valid = false;
+    c->valid = false; c->rows_linked = -1;
     each(c, [&](int, srw_handle *h) { return srw_load_edgelist(h, path, directed, weighted, partitioned, rdd_partitions); });
     for (auto &v : c->vrank) v.clear();
   });
@@ -118,7 +153,7 @@ int32_t srw_cluster_load_coo(srw_cluster *c, const int32_t *src, const int32_t *
                              int64_t n_lines, int32_t directed) {
   if (!c) return SRW_ERR_INVALID;
   return cguard(c, [&] {
-    c->valid = false;
+    c->valid = false; c->rows_linked = -1;
     each(c, [&](int, srw_handle *h) { return srw_load_coo(h, src, dst, w, pid, n_lines, directed); });
     for (auto &v : c->vrank) v.clear();
   });
@@ -126,7 +161,7 @@ int32_t srw_cluster_load_coo(srw_cluster *c, const int32_t *src, const int32_t *
 int32_t srw_cluster_generate_rmat(srw_cluster *c, int32_t scale, int64_t n_edges, uint32_t seed, int32_t weighted, int32_t directed) {
   if (!c) return SRW_ERR_INVALID;
   return cguard(c, [&] {
-    c->valid = false;
+    c->valid = false; c->rows_linked = -1;
     each(c, [&](int, srw_handle *h) { return srw_generate_rmat(h, scale, n_edges, seed, weighted, directed); });
     for (auto &v : c->vrank) v.clear();
   });
@@ -152,6 +187,7 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
     srw_walk_stats tot; memset(&tot, 0, sizeof tot);
     tot.kernel_kind = (P0.p == 1.0f && P0.q == 1.0f && !(P0.flags & SRW_WALK_FORCE_GENERAL)) ? 1 : 2;
     if (n_global == 0 || P0.num_walks == 0) { if (stats) *stats = tot; c->valid = true; return; }
+    if (tot.kernel_kind == 1 && P0.rng_mode == SRW_RNG_PHILOX && c->rows_linked < 0) link_rows(c);
     if (batch <= 0) {   // as many iterations per population as keep a shard's chunk buffers under ~2 GiB
       const int64_t per_iter = std::max<int64_t>(1, n_global / world * 70);      // 56 B of chunk space per resident walker x slack
       batch = (int32_t)std::max<int64_t>(1, std::min<int64_t>(P0.num_walks, ((int64_t)2 << 30) / per_iter));

@@ -80,6 +80,8 @@ struct Graph {
   DevBuf<CfoEnt> cfo;             // [n_entries] compact lattice records (optional)
   bool has_cfo = false;
   bool cfo_rejected = false;      // the compact table was tried and some entry needed an escape
+  DevBuf<Row> rows_all;           // vertex-sharded walk: every vertex's row descriptor as its OWNER stores it (srw_shard_rows_*)
+  bool cfo_linked = false;        // cfo holds records whose links point into the owners' tables (k_sh_step_cfo only)
   DevBuf<AEnt> al;                // [n_entries] Mode A alias records, built lazily
   DevBuf<double> pq;              // [n_entries] per-(p,q) exact base prefix sums (general kernel fast path)
   DevBuf<uint8_t> pq_ok;          // [n_slots]
@@ -103,7 +105,7 @@ struct Graph {
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
-  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, has_cfo ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
+  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, (has_cfo || cfo_linked) ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
@@ -121,6 +123,7 @@ struct WalkResult {
 struct DevCounters {  // device-side accumulators, one 64-bit word each
   unsigned long long steps, dead_ends, sum_deg_curr, sum_deg_prev, ent_reads, fallbacks, owned_entries, trials;
   unsigned long long strat[12];   // general kernel, steps per sampler: SRW_STRAT_* (include/stellar_rw.h)
+  unsigned long long why[4];      // hand-overs of k_walk_q1 by cause: irregular row, non-positive sum, boundary draw (SRW_DEBUG_HANDOVER)
 #ifdef SRW_PHASE_TIMING
   unsigned long long dbg[40];   // wave-time per phase of the general kernel, 100 MHz ticks >> 10 (tools/phase_timing.py)
 #endif
@@ -142,6 +145,7 @@ struct srw_handle {
   srw::DevBuf<char> shard_scratch;               // sampled 32-byte records before bucketing (persistent)
   srw::DevBuf<uint32_t> shard_blk;               // [blocks][2 * world] per-block survivor / return counts, then write cursors
   srw::DevBuf<uint32_t> shard_flag;              // chunk overflow flag of the sharded walk
+  srw::DevBuf<uint32_t> shard_cur;               // fused first-order step: device-wide chunk cursors + finished-block counter
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // srw_walk_to_host: second stream + two staging buffers for compute/copy overlap
   hipStream_t copy_stream = nullptr;
@@ -244,8 +248,12 @@ void run_walk_to_host(srw_handle *h, const srw_walk_params &P, int32_t *paths, i
 void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *output_dir, int n_parts, bool write_crc,
                        srw_walk_stats *stats, int64_t *dead_per_iter);
 void shard_layout(const srw_handle *h, int32_t batch, double slack, srw_shard_layout *out);
-void run_shard_begin(srw_handle *h, int32_t batch, const srw_shard_layout &lay, void *d_recv, int32_t *d_paths, int32_t *d_lens,
-                     int64_t stride);
+void run_shard_begin(srw_handle *h, const srw_walk_params &P, int32_t batch, const srw_shard_layout &lay, void *d_recv,
+                     int32_t *d_paths, int32_t *d_lens, int64_t stride);
+void shard_rows_export(srw_handle *h, void *d_rows, int64_t n_slots);
+void shard_rows_merge(srw_handle *h, void *d_rows, const void *d_other, int64_t n_slots);
+bool shard_rows_commit(srw_handle *h, const void *d_rows_all, int64_t n_slots);
+void shard_rows_release(srw_handle *h);
 void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch, int32_t step, const srw_shard_layout &lay,
                          const void *d_recv, void *const *dst, int32_t *d_paths, int32_t *d_lens, int64_t stride);
 void run_shard_flush(srw_handle *h, const srw_walk_params &P, int32_t batch, const srw_shard_layout &lay, const void *d_recv,

@@ -172,6 +172,8 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
   g.has_cfo = false;
   g.cfo_rejected = false;
   g.cfo.release();
+  g.cfo_linked = false;
+  g.rows_all.release();
   g.has_al = false;
   g.al.release();
   g.has_pq = false;

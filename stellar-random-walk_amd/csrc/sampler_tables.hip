@@ -253,7 +253,7 @@ __global__ void k_fo_link(const Row *__restrict__ rows, FoEnt *__restrict__ fo, 
 
 // ---- compact 16-byte records (lattice draws) derived from the CDF / guide store ------------------------------------
 template <class ST>
-__device__ inline void cfo_write(const ST &st, const Row *__restrict__ rows, const Ent *__restrict__ ent, int32_t vmin,
+__device__ inline void cfo_write(const ST &st, const Row *__restrict__ rows /* of the neighbors: the links */, const Ent *__restrict__ ent, int32_t vmin,
                                  int64_t n_slots, const Row &r, int32_t j, bool regular, CfoEnt *__restrict__ cfo,
                                  unsigned long long *escapes) {
   const int64_t e = r.off + j;
@@ -280,8 +280,9 @@ __device__ inline void cfo_write(const ST &st, const Row *__restrict__ rows, con
 }
 // every row gets records (irregular rows are never sampled through cg, but their links are used)
 template <class ST>
-__global__ void k_cfo_rows(const Row *__restrict__ rows, const Ent *__restrict__ ent, ST st, CfoEnt *__restrict__ cfo,
-                           int64_t n_slots, int32_t vmin, unsigned long long *escapes, unsigned long long *next_slot) {
+__global__ void k_cfo_rows(const Row *__restrict__ rows, const Row *__restrict__ link_rows, const Ent *__restrict__ ent, ST st,
+                           CfoEnt *__restrict__ cfo, int64_t n_slots, int32_t vmin, unsigned long long *escapes,
+                           unsigned long long *next_slot) {
   const int lane = lane_id();
   while (true) {
     unsigned long long grab = 0;
@@ -292,7 +293,7 @@ __global__ void k_cfo_rows(const Row *__restrict__ rows, const Ent *__restrict__
     for (int64_t v = (int64_t)grab; v < (int64_t)grab + 4 && v < n_slots; ++v) {
       const Row r = rows[v];
       const bool regular = !(r.flags & ROW_IRREGULAR);
-      for (int32_t j = lane; j < r.deg; j += 64) cfo_write(st, rows, ent, vmin, n_slots, r, j, regular, cfo, escapes);
+      for (int32_t j = lane; j < r.deg; j += 64) cfo_write(st, link_rows, ent, vmin, n_slots, r, j, regular, cfo, escapes);
     }
   }
 }
@@ -449,14 +450,14 @@ static void run_cdf_and_guide(srw_handle *h, ST st, DevBuf<uint2> &items, DevBuf
 }
 
 template <class ST>
-static unsigned long long run_cfo(srw_handle *h, ST st, unsigned long long *esc_word) {
+static unsigned long long run_cfo(srw_handle *h, ST st, unsigned long long *esc_word, const Row *link_rows = nullptr) {
   Graph &g = h->g;
   hipStream_t stq = h->stream;
   DevBuf<unsigned long long> next_slot; next_slot.alloc(1);
   SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, stq));
   SRW_HIP(hipMemsetAsync(esc_word, 0, 8, stq));
-  hipLaunchKernelGGL((k_cfo_rows<ST>), dim3(256 * 8), dim3(256), 0, stq, g.rows.p, g.ent.p, st, g.cfo.p, g.n_slots, g.vmin,
-                     esc_word, next_slot.p);
+  hipLaunchKernelGGL((k_cfo_rows<ST>), dim3(256 * 8), dim3(256), 0, stq, g.rows.p, link_rows ? link_rows : g.rows.p, g.ent.p, st,
+                     g.cfo.p, g.n_slots, g.vmin, esc_word, next_slot.p);
   unsigned long long n_esc = 0;
   SRW_HIP(hipMemcpyAsync(&n_esc, esc_word, 8, hipMemcpyDeviceToHost, stq));
   SRW_HIP(hipStreamSynchronize(stq));
@@ -509,6 +510,66 @@ void build_first_order_tables(srw_handle *h, bool want_exact) {
   SRW_HIP(hipGetLastError());
   SRW_HIP(hipStreamSynchronize(st));
   g.has_fo = true;
+}
+
+// ---- vertex-sharded walk: row descriptors across shards (srw_shard_rows_*) -------------------------------------------
+// A record of the replicated first-order table carries the row descriptor of the neighbor it names, so a step never
+// reads the row table.  On a shard the neighbor's row lives on ANOTHER shard: the shards exchange their row tables once
+// (16 B per id slot; element-wise maximum — only the owner of a vertex has a non-zero descriptor for it), and the compact
+// records are derived with links into the owners' tables; a walker then travels with the link of the vertex it stands on.
+namespace {
+__global__ void k_rows_max(unsigned long long *__restrict__ acc, const unsigned long long *__restrict__ other, int64_t n_words) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
+    const long long a = (long long)acc[i], b = (long long)other[i];
+    acc[i] = (unsigned long long)(a > b ? a : b);
+  }
+}
+}  // namespace
+
+void shard_rows_export(srw_handle *h, void *d_rows, int64_t n_slots) {
+  Graph &g = h->g;
+  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
+  if (n_slots != g.n_slots) throw Error(SRW_ERR_INVALID, "row table size mismatch");
+  build_first_order_tables(h, true);           // the irregular-row flags are final after the CDF pass
+  SRW_HIP(hipMemcpyAsync(d_rows, g.rows.p, (size_t)n_slots * sizeof(Row), hipMemcpyDeviceToDevice, h->stream));
+  SRW_HIP(hipStreamSynchronize(h->stream));
+}
+
+void shard_rows_merge(srw_handle *h, void *d_rows, const void *d_other, int64_t n_slots) {
+  if (n_slots != h->g.n_slots) throw Error(SRW_ERR_INVALID, "row table size mismatch");
+  const int64_t n_words = n_slots * 2;
+  const int blocks = (int)std::min<int64_t>(std::max<int64_t>((n_words + 255) / 256, 1), 256 * 32);
+  hipLaunchKernelGGL(k_rows_max, dim3(blocks), dim3(256), 0, h->stream, (unsigned long long *)d_rows, (const unsigned long long *)d_other, n_words);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipStreamSynchronize(h->stream));
+}
+
+// true: the compact linked table is in place (k_sh_step_cfo); false: some record needs an escape, nothing changed
+bool shard_rows_commit(srw_handle *h, const void *d_rows_all, int64_t n_slots) {
+  Graph &g = h->g;
+  if (!g.loaded) throw Error(SRW_ERR_INVALID, "no graph loaded");
+  if (n_slots != g.n_slots) throw Error(SRW_ERR_INVALID, "row table size mismatch");
+  build_first_order_tables(h, true);
+  shard_rows_release(h);
+  g.rows_all.alloc((size_t)n_slots);
+  SRW_HIP(hipMemcpyAsync(g.rows_all.p, d_rows_all, (size_t)n_slots * sizeof(Row), hipMemcpyDeviceToDevice, h->stream));
+  if (g.n_entries == 0) { SRW_HIP(hipStreamSynchronize(h->stream)); g.cfo_linked = true; return true; }
+  DevBuf<unsigned long long> esc; esc.alloc(1);
+  if (g.has_cfo) {      // world == 1 after a replicated walk: the local links are the owners' links
+    if (h->cfg.world != 1) throw Error(SRW_ERR_INVALID, "srw_shard_rows_commit: the handle already holds an unsharded compact table");
+    SRW_HIP(hipStreamSynchronize(h->stream)); g.cfo_linked = true; return true;
+  }
+  g.cfo.alloc((size_t)g.n_entries);
+  if (run_cfo(h, FoStore{g.fo.p}, esc.p, g.rows_all.p) != 0) { g.cfo.release(); g.rows_all.release(); return false; }
+  g.cfo_linked = true;
+  return true;
+}
+
+void shard_rows_release(srw_handle *h) {
+  Graph &g = h->g;
+  if (g.cfo_linked && !g.has_cfo) g.cfo.release();
+  g.cfo_linked = false;
+  g.rows_all.release();
 }
 
 }  // namespace srw

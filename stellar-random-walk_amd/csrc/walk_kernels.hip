@@ -340,7 +340,7 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
       prev = curr; curr = next; ++len; rprev = r; eprev = r.off + k;
     }
     if (handed_over) {
-      if (lane == 0) todo[atomicAdd(todo_n, 1ull)] = (int32_t)wi;
+      if (lane == 0) { todo[atomicAdd(todo_n, 1ull)] = (int32_t)wi; atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], 1ull); }
       continue;
     }
     for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
@@ -369,8 +369,9 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
 //   S = PQ[deg-1] + sum of all c_i
 // and the reference's acc_k = sum of fl(w'_i / S) differs from A'_k / S by at most (k + 2) u A'_k / S — the certified
 // divide-free compares of binned_resolve.  The first k that is not a certain miss is located from the first-order guide
-// table (a start position; the exact prefix sums decide) and must be a certain hit, else the walker is handed over to
-// k_walk_general — as are irregular rows, 255+ parallel return edges, and rows that need a bisection of the guide.
+// table (a start position; the exact prefix sums decide; a saturated guide entry or a start more than a few positions
+// off — rows with many parallel return edges — is replaced by a bisection) and must be a certain hit, else the walker is
+// handed over to k_walk_general, as are walkers that meet an irregular row.
 // The picked compact record carries the next row descriptor, as in k_walk_first_order.
 template <bool NT>
 __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
   }
   int32_t len = 1;
   int64_t eprev = 0;
+  int32_t prev_id = src, curr_id = src;
   unsigned long long reads = 0, dead = 0;
   tile[wv][lane][0] = src;
   for (int32_t s = 1; s <= L + 1; ++s) {
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
       if (r.deg == 0) {
         alive = false; if (s > 1) ++dead;
       } else if (r.flags & ROW_IRREGULAR) {
-        alive = false; handed = true;
+        alive = false; handed = true; atomicAdd(&ctr->why[0], 1ull);
       } else {
         const uint32_t m = walk_bits24(rng.seed, iter, (uint32_t)src, (uint32_t)s);
         const CfoEnt *crow = g.cfo + r.off;
@@ -419,8 +421,12 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
           int64_t so = 0;                                   // first return edge in curr's sorted row
           if (rv != REV_NONE) {
             nr = (int)(rv >> 24);
-            if (nr >= 255) { alive = false; handed = true; nr = 0; }      // the count saturated: more multi-edges than it can say
             so = r.off + (int64_t)(rv & 0xFFFFFFu);
+            if (nr >= 255) {                                 // the count saturated (hub <-> hub multi-edges): count the run of prev
+              const uint32_t xprev = (uint32_t)((int64_t)prev_id - g.vmin);
+              const int64_t row_end = r.off + r.deg;
+              while (so + nr < row_end && g.sids[so + nr] == xprev) ++nr;
+            }
 #pragma unroll
             for (int i = 0; i < REV_MAX_RETURNS; ++i) {
               rp[i] = r.deg; rc[i] = 0.0;
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
               const uint32_t j = (uint32_t)(((uint64_t)mm * (uint64_t)(uint32_t)r.deg) >> 24);
               const CfoEnt ge = load_cfo<NT>(crow + j); ++reads;
               const int32_t gd = cfo_delta(ge.cg, ge.link);
-              if (gd == CFO_GD_SAT) { ok = false; return 0; }
+              if (gd == CFO_GD_SAT) { ok = false; return 0; }      // no guide for this bucket: bisection below
               const int32_t st = (int32_t)j - gd;
               return st < 0 ? 0 : (st >= r.deg ? r.deg - 1 : st);
             };
@@ -471,32 +477,47 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
                 k0 = k1 < first_r ? first_r : k1;
               }
             }
-            if (!ok) { alive = false; handed = true; }
+            const bool usable = S > 0.0 && S0 > 0.0;
+            if (!usable) { alive = false; handed = true; atomicAdd(&ctr->why[1], 1ull); }
             else {
-              // first k that is not a certain miss (A' is non-decreasing, the tolerance grows with k: monotone)
+              // first k that is not a certain miss (A' is non-decreasing, the tolerance grows with k: monotone) — a few
+              // steps from the guide's start, else (saturated guide entry, many parallel return edges) by bisection
               int guard = 0;
-              double nk = numer(k0);
-              bool nm = not_miss(k0, nk);
-              while (nm && k0 > 0 && guard < 64) {             // step back while the predecessor is not a certain miss either
-                const double np = numer(k0 - 1);
-                if (!not_miss(k0 - 1, np)) break;
-                --k0; nk = np; ++guard;
+              double nk = 0.0;
+              if (ok) {
+                nk = numer(k0);
+                bool nm = not_miss(k0, nk);
+                while (nm && k0 > 0 && guard < 12) {             // step back while the predecessor is not a certain miss either
+                  const double np = numer(k0 - 1);
+                  if (!not_miss(k0 - 1, np)) break;
+                  --k0; nk = np; ++guard;
+                }
+                while (!nm && guard < 12) {                      // step forward to the first not-certain-miss
+                  ++k0; ++guard;
+                  if (k0 >= r.deg) break;
+                  nk = numer(k0); nm = not_miss(k0, nk);
+                }
+                reads += (unsigned)guard + 1u;
               }
-              while (!nm && guard < 64) {                      // step forward to the first not-certain-miss
-                ++k0; ++guard;
-                if (k0 >= r.deg) break;
-                nk = numer(k0); nm = not_miss(k0, nk);
+              if (!ok || guard >= 12) {
+                int32_t lo = 0, hi = r.deg;
+                while (lo < hi) {
+                  const int32_t mid = lo + ((hi - lo) >> 1);
+                  if (not_miss(mid, numer(mid))) hi = mid; else lo = mid + 1;
+                  ++reads;
+                }
+                k0 = lo;
+                if (k0 < r.deg) nk = numer(k0);
               }
-              reads += (unsigned)guard + 1u;
-              if (guard >= 64) { alive = false; handed = true; }
-              else if (k0 >= r.deg) { k = 0; e = load_cfo<NT>(crow); ++reads; }                    // no crossing: edges.head (:24)
+              if (k0 >= r.deg) { k = 0; e = load_cfo<NT>(crow); ++reads; }                    // no crossing: edges.head (:24)
               else if (nk * (1.0 - (double)(k0 + 8) * 0x1p-51) >= pS) { k = k0; e = load_cfo<NT>(crow + k); ++reads; }   // a certain hit
-              else { alive = false; handed = true; }         // a draw within rounding distance of a boundary: exact chain
+              else { alive = false; handed = true; atomicAdd(&ctr->why[2], 1ull); }   // a draw within rounding distance of a boundary: exact chain
             }
           }
         }
         if (alive) {
           val = e.id; ++len;
+          prev_id = curr_id; curr_id = val;
           eprev = r.off + k;
           r.off = (int64_t)(e.link & CFO_NOFF_MASK); r.deg = (int32_t)((e.link >> 40) & 0x7FFFFFu);
           r.flags = (e.link >> 63) ? ROW_IRREGULAR : 0u;
@@ -518,7 +539,7 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
     }
   }
   if (wi < n_walkers) {
-    if (handed) todo[atomicAdd(todo_n, 1ull)] = (int32_t)wi;     // k_walk_general redoes it from its first step
+    if (handed) { todo[atomicAdd(todo_n, 1ull)] = (int32_t)wi; atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], 1ull); }   // k_walk_general redoes it from its first step
     else lens[wi] = len;
   }
   const unsigned long long my_steps = handed ? 0ull : (unsigned long long)(len - 1);
@@ -831,12 +852,19 @@ __device__ inline PathRet shard_ret_of(const SWalker &w, int32_t step) {      //
   return r;
 }
 
+// linked walkers (k_sh_step_cfo): prev | kind << 32 = the link of the vertex the walker stands on, laid out as CfoEnt::link
+__device__ inline uint64_t shard_link_of(const Row &r) {
+  return ((uint64_t)r.off & CFO_NOFF_MASK) | ((uint64_t)(uint32_t)min(r.deg, (int32_t)CFO_NDEG_MAX) << 40) |
+         ((uint64_t)((r.flags & ROW_IRREGULAR) != 0) << 63);
+}
 __global__ void k_sh_seed(const int32_t *__restrict__ verts, int64_t n_local, ShardIO io, char *recv_w,
-                          int32_t *__restrict__ paths, int32_t *__restrict__ lens, int64_t stride) {
+                          int32_t *__restrict__ paths, int32_t *__restrict__ lens, int64_t stride,
+                          const Row *__restrict__ link_rows, int32_t vmin) {
   const int64_t n = n_local * io.batch;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t src = verts[i / io.batch];
     SWalker w; w.lw = (int32_t)i; w.src = src; w.prev = src; w.curr = src; w.h0 = src; w.h1 = 0; w.h2 = 0; w.kind = SK_WALKER;
+    if (link_rows) { const uint64_t l = shard_link_of(link_rows[(int64_t)src - vmin]); w.prev = (int32_t)(uint32_t)l; w.kind = (int32_t)(uint32_t)(l >> 32); }
     const int c = (int)(i % io.world);
     reinterpret_cast<SWalker *>(recv_w + c * io.chunk_bytes + 16)[i / io.world] = w;
     paths[i * stride] = src;
@@ -981,6 +1009,148 @@ __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int
   }
 }
 
+// p = q = 1 on a shard whose compact records carry links into the owners' tables (srw_shard_rows_*): sampling and
+// bucketing in ONE pass.  A walker arrives with the link of the vertex it stands on (no row-table read), picks a 16-byte
+// record like k_walk_first_order and leaves with that record's link.  Per tile of TPB * SH_R records: every lane samples
+// its SH_R records into registers; the waves count their survivors per destination and their returns per home rank in
+// LDS (one LDS atomic per wave and distinct destination); 2 * world threads move the block's counts onto the device-wide
+// chunk cursors (one global atomic per tile, destination and kind); the lanes store their records straight into the
+// destination chunks.  The last block to finish writes the chunk headers and clears the cursors for the next super-step.
+#ifndef SRW_SH_R
+#define SRW_SH_R 4
+#endif
+constexpr int SH_R = SRW_SH_R;      // records per lane and tile
+constexpr int SH_CUR_DONE = 2 * SHARD_MAX_WORLD;      // cursors[0 .. 2 * MAX): walkers / returns per destination; [DONE]: finished blocks
+template <bool NT>
+__global__ __launch_bounds__(TPB) void k_sh_step_cfo(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
+                                                     RngSpec rng, uint32_t *__restrict__ cursors, ShardDst dst,
+                                                     uint32_t *__restrict__ overflow, DevCounters *ctr) {
+  __shared__ uint32_t cnt[2 * SHARD_MAX_WORLD], gbase[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
+  __shared__ unsigned long long red[6];
+  __shared__ uint32_t is_last;
+  const int lane = lane_id();
+  if (threadIdx.x < 2 * SHARD_MAX_WORLD) cnt[threadIdx.x] = 0u;
+  if (threadIdx.x < 6) red[threadIdx.x] = 0ull;
+  const uint32_t n_in = shard_in_prefix(io, pre);          // contains the __syncthreads() cnt / red need
+  unsigned long long steps = 0, dead = 0, reads = 0, fb = 0;
+  Bias nobias; nobias.second_order = false; nobias.need_member = false; nobias.p = nobias.q = 1.0f;
+  nobias.prev = 0; nobias.prev_sids = nullptr; nobias.prev_deg = 0; nobias.vmin = g.vmin;
+  const int j4 = step & 3;
+  uint32_t lo, hi;
+  shard_slice(n_in, TPB * SH_R, lo, hi);
+  for (uint32_t base = lo; base < hi; base += TPB * SH_R) {
+    SWalker nw[SH_R];
+    int32_t o[SH_R], hm[SH_R], kind[SH_R];
+    uint32_t wpos[SH_R], rpos[SH_R];
+#pragma unroll
+    for (int r = 0; r < SH_R; ++r) {
+      const uint32_t ri = base + (uint32_t)r * TPB + threadIdx.x;
+      o[r] = -1; hm[r] = -1; kind[r] = SK_WALKER; wpos[r] = 0; rpos[r] = 0;
+      if (ri < hi) {
+        const SWalker wk = shard_in_record(io, pre, ri);
+        const uint64_t link = (uint64_t)(uint32_t)wk.prev | ((uint64_t)(uint32_t)wk.kind << 32);
+        const int64_t off = (int64_t)(link & CFO_NOFF_MASK);
+        const int32_t deg = (int32_t)((link >> 40) & 0x7FFFFFu);
+        nw[r] = wk;
+        if (deg == 0) {                                   // dead end (or a source without neighbors): death notice to the home rank
+          if (step > 1) ++dead;
+          kind[r] = SK_DEAD;
+          hm[r] = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+        } else {
+          const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
+          CfoEnt e;
+          if (!(link >> 63)) {
+            const uint32_t m = walk_bits24(rng.seed, iter, (uint32_t)wk.src, (uint32_t)step);
+            unsigned rd;
+            e = cfo_pick<NT>(g.cfo + off, deg, m, rd); reads += rd;
+          } else {                                        // irregular row: the reference's scan, literally; the links are valid for every row
+            const float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
+            e = g.cfo[off + lane_pick_sequential(g.ent + off, deg, nobias, u)]; ++fb;
+          }
+          ++steps;
+          const uint64_t nl = e.link & ~(0xFull << 36);
+          nw[r].curr = e.id; nw[r].prev = (int32_t)(uint32_t)nl; nw[r].kind = (int32_t)(uint32_t)(nl >> 32);
+          if (j4 == 3 || last) kind[r] = last ? SK_RET : SK_WALKER_RET;        // slots step - j .. step go home: h0..h{j-1}, next
+          else if (j4 == 0) nw[r].h0 = e.id; else if (j4 == 1) nw[r].h1 = e.id; else nw[r].h2 = e.id;
+          if (kind[r] != SK_RET) o[r] = owner_of_tab(e.id, io.world, g.owner_tab, g.vmin, g.n_slots);
+          if (kind[r] != SK_WALKER) hm[r] = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+        }
+      }
+    }
+    // positions inside the block's share of every chunk: wave-aggregated LDS atomics, one per distinct destination
+#pragma unroll
+    for (int r = 0; r < SH_R; ++r) {
+      unsigned long long todo = __ballot(o[r] >= 0);
+      while (todo) {
+        const int d = __builtin_amdgcn_readlane(o[r], __ffsll((long long)todo) - 1);
+        const unsigned long long m = __ballot(o[r] == d);
+        uint32_t b0 = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) b0 = atomicAdd(&cnt[d], (uint32_t)__popcll(m));
+        b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
+        if (o[r] == d) wpos[r] = b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+      }
+      todo = __ballot(hm[r] >= 0);
+      while (todo) {
+        const int d = __builtin_amdgcn_readlane(hm[r], __ffsll((long long)todo) - 1);
+        const unsigned long long m = __ballot(hm[r] == d);
+        uint32_t b0 = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) b0 = atomicAdd(&cnt[SHARD_MAX_WORLD + d], (uint32_t)__popcll(m));
+        b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
+        if (hm[r] == d) rpos[r] = b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * io.world) {
+      const int d = (int)threadIdx.x < io.world ? (int)threadIdx.x : (int)threadIdx.x - io.world;
+      const int idx = (int)threadIdx.x < io.world ? d : SHARD_MAX_WORLD + d;
+      const uint32_t c = cnt[idx];
+      cnt[idx] = 0u;
+      uint32_t gb = 0;
+      if (c) {
+        gb = atomicAdd(&cursors[idx], c);
+        if ((uint64_t)gb + c > (uint64_t)((int)threadIdx.x < io.world ? io.cap_w : io.cap_r)) atomicOr(overflow, 1u);
+      }
+      gbase[idx] = gb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SH_R; ++r) {
+      if (o[r] >= 0) {
+        const uint32_t pos = gbase[o[r]] + wpos[r];
+        if (pos < (uint32_t)io.cap_w) reinterpret_cast<SWalker *>(dst.p[o[r]] + 16)[pos] = nw[r];
+      }
+      if (hm[r] >= 0) {
+        const uint32_t pos = gbase[SHARD_MAX_WORLD + hm[r]] + rpos[r];
+        if (pos < (uint32_t)io.cap_r) {
+          SWalker t = nw[r]; t.kind = kind[r];
+          reinterpret_cast<PathRet *>(dst.p[hm[r]] + 16 + (int64_t)io.cap_w * SW_BYTES)[pos] = shard_ret_of(t, step);
+        }
+      }
+    }
+  }
+  block_flush_counters(ctr, red, steps, dead, 0, 0, reads, fb);
+  // the last block: chunk headers from the cursors, cursors cleared for the next super-step
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(&cursors[SH_CUR_DONE], 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (is_last) {
+    __threadfence();
+    if ((int)threadIdx.x < 2 * io.world) {
+      const bool rets = (int)threadIdx.x >= io.world;
+      const int d = rets ? (int)threadIdx.x - io.world : (int)threadIdx.x;
+      const uint32_t total = atomicExch(&cursors[rets ? SHARD_MAX_WORLD + d : d], 0u);
+      const uint32_t cap = (uint32_t)(rets ? io.cap_r : io.cap_w);
+      reinterpret_cast<uint32_t *>(dst.p[d])[rets ? 1 : 0] = total < cap ? total : cap;
+    }
+    if (threadIdx.x == 0) cursors[SH_CUR_DONE] = 0u;
+  }
+}
+
 // blk[b][col] (counts) -> blk[b][col] (write cursor of block b inside chunk col's record array); the chunk headers get
 // the totals (clamped to the capacity, overflow flagged).  One block; wave w handles columns w, w + nwaves, ...
 __global__ void k_sh_offsets(uint32_t *__restrict__ blk, int32_t n_blocks, ShardIO io, ShardDst dst, uint32_t *overflow) {
@@ -1098,6 +1268,9 @@ void read_counters(srw_handle *h, srw_walk_stats *stats) {
             (double)c.dbg[17] * 1024.0 / 100e3, (double)c.dbg[18] * 1024.0 / 100e3, (double)c.dbg[19] * 1024.0 / 100e3);
   }
 #endif
+  if (getenv("SRW_DEBUG_HANDOVER"))
+    fprintf(stderr, "[handover] walkers %llu | q1 reasons: irregular row %llu, non-positive sum %llu, boundary draw %llu\n",
+            c.strat[SRW_STAT_HANDED_OVER], c.why[0], c.why[1], c.why[2]);
   if (!stats) return;
   stats->n_steps = (int64_t)c.steps; stats->dead_ends = (int64_t)c.dead_ends;
   stats->sum_deg_curr = (int64_t)c.sum_deg_curr; stats->sum_deg_prev = (int64_t)c.sum_deg_prev;
@@ -1526,8 +1699,14 @@ void check_shard(const srw_handle *h, int32_t batch, const srw_shard_layout &lay
 }  // namespace
 
 // Seeds this rank's batch * n_local walkers into its receive buffer, path slot 0 and lens; clears the counters.
-void run_shard_begin(srw_handle *h, int32_t batch, const srw_shard_layout &lay, void *d_recv, int32_t *d_paths, int32_t *d_lens,
-                     int64_t stride) {
+// p = q = 1, Philox draws and linked compact records on every shard (srw_shard_rows_commit): the fused kernel
+static bool shard_fo_linked(const srw_handle *h, const srw_walk_params &P) {
+  return h->g.cfo_linked && P.p == 1.0f && P.q == 1.0f && !(P.flags & (SRW_WALK_FORCE_GENERAL | SRW_WALK_NO_COMPACT)) &&
+         P.rng_mode == SRW_RNG_PHILOX;
+}
+
+void run_shard_begin(srw_handle *h, const srw_walk_params &P, int32_t batch, const srw_shard_layout &lay, void *d_recv,
+                     int32_t *d_paths, int32_t *d_lens, int64_t stride) {
   check_shard(h, batch, lay);
   Graph &g = h->g;
   hipStream_t st = h->stream;
@@ -1539,7 +1718,11 @@ void run_shard_begin(srw_handle *h, int32_t batch, const srw_shard_layout &lay, 
   if (n > 0) SRW_HIP(hipMemsetAsync(d_paths, 0xFF, (size_t)n * stride * 4, st));     // -1: unused tail
   const ShardIO io = make_io(h, batch, lay, d_recv);
   const int blocks = (int)std::min<int64_t>(std::max<int64_t>((n + TPB - 1) / TPB, 1), 8192);
-  hipLaunchKernelGGL(k_sh_seed, dim3(blocks), dim3(TPB), 0, st, g.verts.p, g.n_local_vertices, io, (char *)d_recv, d_paths, d_lens, stride);
+  const bool linked = shard_fo_linked(h, P);
+  h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
+  SRW_HIP(hipMemsetAsync(h->shard_cur.p, 0, ((size_t)SH_CUR_DONE + 1) * 4, st));
+  hipLaunchKernelGGL(k_sh_seed, dim3(blocks), dim3(TPB), 0, st, g.verts.p, g.n_local_vertices, io, (char *)d_recv, d_paths, d_lens, stride,
+                     linked ? (const Row *)g.rows.p : (const Row *)nullptr, g.vmin);
   SRW_HIP(hipGetLastError());
 }
 
@@ -1554,6 +1737,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
   hipStream_t st = h->stream;
   const int32_t world = h->cfg.world;
   const bool first_order = P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL);
+  const bool linked = shard_fo_linked(h, P);
   if (first_order) build_first_order_tables(h, true);
   else {
     build_membership(h);
@@ -1579,6 +1763,21 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     float ms = 0.f; SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); acc[slot] += ms;
   };
   if (step > 1) timed(0, [&] { hipLaunchKernelGGL(k_sh_apply, dim3(n_blocks), dim3(TPB), 0, st, io, d_paths, d_lens, stride); });
+  if (linked) {      // sampling + bucketing in one pass; no scratch, no per-block counts
+    h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
+    timed(1, [&] {
+      if ((size_t)g.n_entries * sizeof(CfoEnt) > ((size_t)2 << 30))
+        hipLaunchKernelGGL(k_sh_step_cfo<true>, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng,
+                           h->shard_cur.p, sd, h->shard_flag.p, h->counters.p);
+      else
+        hipLaunchKernelGGL(k_sh_step_cfo<false>, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng,
+                           h->shard_cur.p, sd, h->shard_flag.p, h->counters.p);
+    });
+    SRW_HIP(hipGetLastError());
+    if (prof && last)
+      fprintf(stderr, "[shard profile] rank %d: apply %.1f ms, fused step %.1f ms (cumulative)\n", h->cfg.rank, acc[0], acc[1]);
+    return;
+  }
   timed(1, [&] {
     if (first_order) {
       // records larger than the caches are read once per fetch: L1-bypassing loads (as k_walk_first_order)

@@ -24,6 +24,7 @@ engine is injectable so that this driver's protocol can be tested with the gloo 
 oracle in; the product default is the HIP engine, which needs a GPU).
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -77,6 +78,55 @@ class HipShardEngine:
         self.engine._ck(lib().srw_shard_finish(self.engine.h, C.byref(st), C.byref(of)))
         return st.as_dict(), of.value
 
+    def link_rows(self, group=None):
+        """Row descriptors across the shards (srw_shard_rows_*): one all-reduce MAX of the row tables, then every rank
+        derives first-order records whose links point into the owners' tables.  All ranks or none.  Returns linked?"""
+        if os.environ.get("SRW_SHARD_NO_LINKS"):
+            return False
+        L, h = lib(), self.engine.h
+        n = C.c_int64(0)
+        self.engine._ck(L.srw_shard_rows_count(h, C.byref(n)))
+        rows = torch.zeros(max(n.value, 1) * 2, dtype=torch.int64, device=self.device)
+        self.engine._ck(L.srw_shard_rows_export(h, C.c_void_p(rows.data_ptr()), n.value))
+        torch.cuda.current_stream(self.device).synchronize()
+        dist.all_reduce(rows, op=dist.ReduceOp.MAX, group=group)
+        linked = C.c_int32(0)
+        self.engine._ck(L.srw_shard_rows_commit(h, C.c_void_p(rows.data_ptr()), n.value, C.byref(linked)))
+        ok = torch.tensor([linked.value], dtype=torch.int64, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok[0]) == 0:
+            self.engine._ck(L.srw_shard_rows_release(h))
+            return False
+        return True
+
+
+class _DeviceBuffer:
+    """One hipMalloc through the library, seen by torch through __cuda_array_interface__ (zero copy).  The exchange
+    buffers are NOT taken from torch's caching allocator: RCCL faulted (memory access fault inside the collective) on
+    multi-GB buffers that were sub-blocks of a cached segment freed by an earlier, smaller population
+    (profiles/r02i_rccl_driver_buffers.md)."""
+
+    def __init__(self, engine, nbytes, device):
+        self.engine, self.nbytes = engine, int(nbytes)
+        p = C.c_void_p()
+        engine._ck(lib().srw_device_alloc(engine.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2,
+                                         "strides": None}
+        self.tensor = torch.as_tensor(self, device=device)
+
+    def free(self):
+        if self.ptr:
+            self.tensor = None
+            lib().srw_device_free(self.engine.h, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
 
 class ShardedWalker:
     def __init__(self, device=0, rank=None, world=None, step_engine=None, group=None, owner_from_partitions=False):
@@ -88,24 +138,49 @@ class ShardedWalker:
         self.engine = getattr(self.se, "engine", None)
         self.device = self.se.device
         self._bufs = {}
+        self._linked = None          # row links across the shards: not tried yet for the loaded graph
 
     # ---- graph (each rank keeps only the rows it owns) ----
     def generate_rmat(self, scale, n_edges=None, seed=42, weighted=False, directed=False):
         self.engine.generate_rmat(scale, n_edges, seed=seed, weighted=weighted, directed=directed)
+        self._linked = None
         return self
 
     def load_edgelist(self, path, **kw):
         self.engine.load_edgelist(path, **kw)
+        self._linked = None
         return self
 
     def load_coo(self, src, dst, w=None, pid=None, directed=False):
         self.engine.load_coo(src, dst, w, pid=pid, directed=directed)
+        self._linked = None
         return self
+
+    # One (sender, receiver) message of the equal-split all-to-all; RCCL / torch fault on messages beyond 2 GiB
+    # (observed: world 1, 2.5 GB chunk — memory access fault inside the collective), so the driver refuses them.
+    MAX_MESSAGE_BYTES = int(os.environ.get("SRW_MAX_MESSAGE_BYTES", (1 << 31) - 4096))
+
+    def max_batch(self, want, slack=1.25):
+        """Largest number of walk iterations <= want that one population may hold under MAX_MESSAGE_BYTES."""
+        b = max(1, int(want))
+        while b > 1 and self.se.layout(b, slack).chunk_bytes > self.MAX_MESSAGE_BYTES:
+            b -= 1
+        return b
 
     def _buffers(self, nbytes):
         b = self._bufs.get("x")
         if b is None or b[0].numel() < nbytes:
-            b = (torch.empty(nbytes, dtype=torch.uint8, device=self.device), torch.empty(nbytes, dtype=torch.uint8, device=self.device))
+            if self.engine is not None and self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+                old = self._bufs.pop("mem", None)
+                if old:
+                    for m in old:
+                        m.free()
+                mem = (_DeviceBuffer(self.engine, nbytes, self.device), _DeviceBuffer(self.engine, nbytes, self.device))
+                self._bufs["mem"] = mem
+                b = (mem[0].tensor, mem[1].tensor)
+            else:                           # the CPU protocol tests (gloo + the oracle as step engine)
+                b = (torch.empty(nbytes, dtype=torch.uint8, device=self.device), torch.empty(nbytes, dtype=torch.uint8, device=self.device))
             self._bufs["x"] = b
         return b[0][:nbytes], b[1][:nbytes]
 
@@ -118,17 +193,23 @@ class ShardedWalker:
         world, B = self.world, num_walks
         n_local, n_global = self.se.capacity()
         stride = walk_length + 2
+        if self._linked is None and p == 1.0 and q == 1.0 and rng == "philox":
+            self._linked = bool(self.se.link_rows(self.group)) if hasattr(self.se, "link_rows") else False
         P = Engine.params(p=p, q=q, walk_length=walk_length, num_walks=B, first_walk=iteration, rng=rng, const_r=const_r, seed=seed)
         dev = self.device
         paths = torch.empty((max(B * n_local, 1), stride), dtype=torch.int32, device=dev)
         lens = torch.empty(max(B * n_local, 1), dtype=torch.int32, device=dev)
         while True:
             lay = self.se.layout(B, slack)
+            if lay.chunk_bytes > self.MAX_MESSAGE_BYTES:
+                raise ValueError("vertex-sharded walk: a chunk of %d bytes per peer exceeds the %d-byte exchange message limit "
+                                 "(batch %d, slack %.2f): walk fewer iterations per population (max_batch())"
+                                 % (lay.chunk_bytes, self.MAX_MESSAGE_BYTES, B, slack))
             recv, send = self._buffers(world * lay.chunk_bytes)
             self.se.begin(P, B, lay, recv, paths, lens)
             for step in range(1, walk_length + 2):
                 self.se.superstep(P, B, step, lay, recv, send, paths, lens)
-                dist.all_to_all_single(recv, send, group=self.group)       # chunk (me -> d) -> rank d's slot `me`
+                dist.all_to_all_single(recv.view(torch.int64), send.view(torch.int64), group=self.group)   # chunk (me -> d) -> rank d's slot `me`
             self.se.flush(P, B, lay, recv, paths, lens)
             st, overflow = self.se.finish()
             t = torch.tensor([st["n_steps"], st["dead_ends"], overflow], dtype=torch.int64, device=dev)
@@ -181,7 +262,7 @@ def bench_vertex_sharded(dist_mod, local_rank, rank, world, scale, n_edges, weig
     n_local, _ = drv.se.capacity()
     t_graph = time.perf_counter() - t0
     kw = {k: v for k, v in walk_kw.items() if k in ("p", "q", "walk_length", "seed")}
-    B = max(1, min(K, 4))
+    B = drv.max_batch(max(1, min(K, 4)))
     for it in range(0, W, B):
         drv.walk_batch(iteration=it, num_walks=min(B, W - it), **kw)
     if W == 0:

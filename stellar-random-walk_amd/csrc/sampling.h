@@ -174,18 +174,78 @@ __device__ inline double wave_sum_exact_or_chain(const Ent *row, int32_t deg, co
   return S;
 }
 
+// The reference's chain acc = fl(acc + d_i), first acc >= p (:18-22) — evaluated 64 elements at a time, bit for bit.
+// While acc stays inside one binade [2^e, 2^(e+1)) it is an integer N of units u = 2^(e-52), and adding d rounds to
+//   N + D + t,   D = floor(d / u),   t = 1 / 0 as the remainder is above / below u/2, and on a tie t makes N + D + t even
+// (round-half-even) — a map N -> N + c[N & 1] whose composition has the same form, so 64 of them are combined by a wave
+// scan.  The first element that would leave the binade (N + D >= 2^53, or d >= 2^(e+1), or acc still zero) is added with a
+// real f64 addition and the scan restarts behind it: ~1.1 scans + 0.25 single steps per 64 elements on the rows measured
+// (tools/chain_model.c is the CPU model this was checked with: 120 000 rows, ties included).  Long rows are where the chain
+// hurts: a draw on a CDF boundary of a 10^6-neighbor hub used to cost 10^6 dependent additions of one lane.
+__device__ inline void chain_elem_map(double d, int e, unsigned long long &c0, unsigned long long &c1) {
+  const unsigned long long BIG = 1ull << 53;               // "leaves the binade": handled by a real addition
+  c0 = c1 = 0ull;
+  if (d == 0.0) return;
+  const unsigned long long bb = (unsigned long long)__double_as_longlong(d);
+  const int ed = (int)((bb >> 52) & 0x7FFull);
+  if (ed == 0 || ed == 0x7FF || (bb >> 63)) { c0 = c1 = BIG; return; }   // subnormal, infinite, NaN, negative
+  const unsigned long long md = (bb & ((1ull << 52) - 1ull)) | (1ull << 52);
+  const int shift = e - (ed - 1023);
+  if (shift <= 0) { c0 = c1 = BIG; return; }
+  if (shift >= 64) return;
+  const unsigned long long D = md >> shift, rem = md & ((1ull << shift) - 1ull), half = 1ull << (shift - 1);
+  if (rem > half) c0 = c1 = D + 1ull;
+  else if (rem < half) c0 = c1 = D;
+  else { c0 = D + (D & 1ull); c1 = D + ((D + 1ull) & 1ull); }
+}
+__device__ inline unsigned long long shfl_up_u64(unsigned long long v, int off) {
+  const int lo = __shfl_up((int)(uint32_t)v, off), hi = __shfl_up((int)(uint32_t)(v >> 32), off);
+  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
 __device__ inline int32_t wave_chain_pick(const Ent *row, int32_t deg, const Bias &b, float r, double S) {
   const int lane = lane_id();
   const double p = (double)r;
-  double acc = 0.0;
-  for (int32_t base = 0; base < deg; base += 64) {     // acc += w' / S ; first acc >= p   (:18-22)
-    int32_t k = base + lane;
+  double acc = 0.0;                                      // wave-uniform
+  for (int32_t base = 0; base < deg; base += 64) {
+    const int32_t k = base + lane;
     double d = 0.0;
     if (k < deg) { Ent e = row[k]; d = (double)biased_weight(b, e.id, e.w) / S; }
-    int cnt = min(64, deg - base);
-    for (int i = 0; i < cnt; ++i) {
-      acc = acc + readlane_f64(d, i);
-      if (__builtin_amdgcn_readfirstlane((int)(acc >= p))) return base + i;  // acc is wave-uniform
+    const int cnt = min(64, deg - base);
+    int start = 0;
+    while (start < cnt) {
+      const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
+      const int ea = (int)((ab >> 52) & 0x7FFull);
+      int f = start;                                     // acc zero / subnormal / not finite: one plain addition
+      if (!(ea == 0 || ea == 0x7FF || (ab >> 63))) {
+        const int e = ea - 1023;
+        const unsigned long long N0 = (ab & ((1ull << 52) - 1ull)) | (1ull << 52);
+        unsigned long long c0 = 0ull, c1 = 0ull;
+        if (lane >= start && lane < cnt) chain_elem_map(d, e, c0, c1);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned long long f0 = shfl_up_u64(c0, off), f1 = shfl_up_u64(c1, off);
+          if (lane >= off) {
+            const unsigned long long g0 = c0, g1 = c1;
+            c0 = f0 + ((f0 & 1ull) ? g1 : g0);
+            c1 = f1 + (((f1 + 1ull) & 1ull) ? g1 : g0);
+          }
+        }
+        const unsigned long long N = N0 + ((N0 & 1ull) ? c1 : c0);
+        const bool mine = lane >= start && lane < cnt;
+        const unsigned long long cross = __ballot(mine && N >= (1ull << 53));
+        f = cross ? __ffsll((long long)cross) - 1 : -1;
+        const int lim = f < 0 ? cnt : f;
+        // inside the binade N < 2^53: the accumulator after my element, exactly
+        const double a = __longlong_as_double((long long)(((unsigned long long)ea << 52) | (N & ((1ull << 52) - 1ull))));
+        const unsigned long long hit = __ballot(lane >= start && lane < lim && a >= p);
+        if (hit) return base + (__ffsll((long long)hit) - 1);
+        if (f < 0) { acc = readlane_f64(a, cnt - 1); break; }
+        if (f > start) acc = readlane_f64(a, f - 1);
+      }
+      acc = acc + readlane_f64(d, f);
+      if (acc >= p) return base + f;
+      start = f + 1;
     }
   }
   return 0;  // edges.head (:24)

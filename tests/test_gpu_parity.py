@@ -85,6 +85,30 @@ def test_sample_lattice_ties_all_degrees(eng, oracle):
             assert eng.sample(w, r) == oracle.sample_index(w, r), (deg, r)
 
 
+def test_sample_chain_long_rows(eng, oracle):
+    """The sequential chain on LONG rows (the wave-parallel exact evaluation of acc = fl(acc + d_i), sampling.h): uniform
+    weights (every lattice draw of a power-of-two degree sits on a boundary), power-of-two weights (round-half-even ties in
+    every binade), wide dynamic range, zeros — against the oracle's plain loop."""
+    rng = np.random.default_rng(7)
+    for trial in range(24):
+        n = int(rng.integers(3000, 40000)) if trial % 6 else 1 << int(rng.integers(12, 18))
+        kind = trial % 6
+        if kind == 0:
+            w = np.ones(n, dtype=np.float32)
+        elif kind == 1:
+            w = (rng.integers(1, 5, n) * 0.25).astype(np.float32)
+        elif kind == 2:
+            w = np.float32(2.0) ** rng.integers(-6, 6, n).astype(np.float32)
+        elif kind == 3:
+            w = np.exp(rng.random(n) * 20.0 - 10.0).astype(np.float32)
+        elif kind == 4:
+            w = rng.random(n).astype(np.float32); w[::97] = 0.0
+        else:
+            w = rng.integers(1, 1000, n).astype(np.float32)
+        for r in (0.0, 0.5, 0.25, 0.75, float(np.float32(rng.random())), float(np.float32(rng.random())), 0.99999994):
+            assert eng.sample(w, r) == oracle.sample_index(w, r), (trial, n, r)
+
+
 def test_sample_degenerate_weights(eng, oracle):
     for w in ([0.0, 0.0, 0.0], [1.0, -1.0, 1.0], [float("nan"), 1.0], [float("inf"), 1.0], [-2.0, -3.0],
               [0.0, 5.0, 0.0], [1e38, 1e38, 1e38, 1e38]):
@@ -413,6 +437,11 @@ def test_sharded_walker_world1_nccl(oracle):
             rp, rl, rs = g.walk(num_walks=3, first_walk=2, p=0.25, q=q, walk_length=15, seed=8)
             assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
             assert sum(s["n_steps_global"] for s in stats) == rs
+        # p = q = 1: the shards exchange their row tables (all-reduce MAX) and walk through the fused linked kernel
+        paths, lens, stats = drv.walk(num_walks=3, first_walk=1, batch=2, walk_length=25, seed=11)
+        rp, rl, rs = g.walk(num_walks=3, first_walk=1, walk_length=25, seed=11)
+        assert drv._linked is True
+        assert np.array_equal(paths, rp) and np.array_equal(lens, rl) and sum(s["n_steps_global"] for s in stats) == rs
     finally:
         dist.destroy_process_group()
 

@@ -95,3 +95,19 @@ def test_directed_rmat_biased_walk_equals_oracle(eng, oracle):
     paths, lens, st = eng.walk(p=4.0, q=0.5, walk_length=40, seed=99)
     assert np.array_equal(lens[idx], rl) and np.array_equal(paths[idx], rp)
     assert st["edge_tables"] > 0 and st["strategy_steps"]["edge_table"] > 0, st
+
+
+@pytest.mark.parametrize("world,weighted", [(4, False), (3, True)])
+def test_sharded_linked_first_order_equals_replicated_at_scale(eng, world, weighted):
+    """RMAT-18 through the in-process cluster (row links across the shards + the fused sample-and-bucket kernel) must give
+    the replicated single-launch kernel's paths bit for bit — which the tests above pin to the oracle."""
+    scale = 18
+    eng.generate_rmat(scale, 16 << scale, seed=7, weighted=weighted)
+    paths, lens, st = eng.walk(walk_length=40, num_walks=2, first_walk=3, seed=99)
+    with pkg().Cluster([0] * world) as cl:
+        cl.generate_rmat(scale, 16 << scale, seed=7, weighted=weighted)
+        assert cl.stats() == eng.stats()
+        for batch in (1, 2):
+            cp, clens, cst = cl.walk(walk_length=40, num_walks=2, first_walk=3, seed=99, batch=batch)
+            assert np.array_equal(clens, lens) and np.array_equal(cp, paths), (world, batch)
+            assert cst["n_steps"] == st["n_steps"]

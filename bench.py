@@ -178,6 +178,40 @@ def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, 
         eng.close()
 
 
+def run_sharded_world1(pkg, device, scale=24, K=4, L=80):
+    """The vertex-sharded protocol (chunks, home-rank paths, row links, fused sample-and-bucket kernel) at world = 1 on this
+    GPU, next to the single-launch replicated kernel on the same graph — the only sharded measurement a 1-GPU run allows;
+    what it shows is the cost of the super-step machinery, not scaling."""
+    import torch
+    kw = dict(p=1.0, q=1.0, walk_length=L, seed=42)
+    with pkg.Engine(device=device) as eng:
+        eng.generate_rmat(scale, 16 << scale, seed=42)
+        nv, ne = eng.stats()
+        eng.walk(fetch=False, num_walks=1, **kw)
+        st = eng.walk(fetch=False, num_walks=K, first_walk=1, **kw)
+        rep = st["n_steps"] / (st["kernel_ms"] * 1e-3)
+    torch.cuda.synchronize()
+    with pkg.Cluster([device]) as cl:
+        t0 = time.perf_counter()
+        cl.generate_rmat(scale, 16 << scale, seed=42)
+        torch.cuda.synchronize()
+        t_graph = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cl.walk(fetch=False, num_walks=1, batch=1, **kw)                     # tables, row links, buffers
+        torch.cuda.synchronize()
+        t_tables = time.perf_counter() - t0
+        cl.walk(fetch=False, num_walks=K, first_walk=1, batch=K, **kw)
+        st = cl.walk(fetch=False, num_walks=K, first_walk=1 + K, batch=K, **kw)
+        val = st["n_steps"] / (st["kernel_ms"] * 1e-3)
+    return {"name": "vertex-sharded protocol at world 1 (north_star's split on one GPU)",
+            "workload": "RMAT scale-%d ef16 undirected unweighted p=1 q=1 walkLength=%d, Mode R; %d walk iterations as one walker "
+                        "population (srw_cluster_walk: %d super-steps, 2 kernels each)" % (scale, L, K, L + 1),
+            "vertices": nv, "adjacency_entries": ne, "value": val, "unit": "walk-steps/s", "steps": K, "warmup": K,
+            "ms_per_step": st["kernel_ms"] / K, "replicated_kernel_same_graph": rep, "fraction_of_replicated": val / rep,
+            "setup_s": {"graph_generate_and_csr": t_graph, "tables_row_links_first_walk": t_tables},
+            "timed": "wall time of srw_cluster_walk (all super-steps of K iterations, no host sync inside)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -391,6 +425,11 @@ def main():
                     cfgs.append(run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w))
                 except Exception as ex:
                     cfgs.append({"name": name, "error": str(ex)[:300]})
+            if args.shard in ("both", "vertex"):
+                try:
+                    cfgs.append(run_sharded_world1(pkg, local_rank))
+                except Exception as ex:
+                    cfgs.append({"name": "vertex-sharded protocol at world 1", "error": str(ex)[:300]})
             out["configs"] = cfgs
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

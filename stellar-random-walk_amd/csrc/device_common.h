@@ -75,6 +75,8 @@ struct alignas(32) AEnt {
 };
 
 
+struct alignas(16) RevEnt { uint32_t cl, pos0; float w0; uint32_t pad; };
+
 struct GraphView {
   const Row *rows;
   const Ent *ent;
@@ -107,10 +109,11 @@ struct GraphView {
   const uint32_t *em_bits;
   int32_t eb_mask_max;
   int32_t eb_f32;           // 1: tables of ROW_PQ_F32 rows hold floats (half the bytes)
-  // rev[e], e = (u -> v): (count << 24) | index in v's SORTED row of the first entry that leads back to u (the return
+  // rev[e], e = (u -> v): cl = (count << 24) | index in v's SORTED row of the first entry that leads back to u (the return
   // edges of the step u -> v -> ?; sperm / sw give their input-order positions and weights), REV_NONE if there is none
-  // (directed graphs); null if not built
-  const uint32_t *rev;
+  // (directed graphs); pos0 / w0 = input-order position and weight of that first return edge, so that the common case of
+  // ONE return edge costs one 16-byte request instead of three; null if not built
+  const RevEnt *rev;
 };
 constexpr uint32_t REV_NONE = 0xFFFFFFFFu;
 constexpr int REV_MAX_RETURNS = 4;          // return edges of one step the per-lane kernel keeps in registers

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
 // rev[e] for every entry e = (u -> v): where the return edges sit in N(v) (k_walk_q1) — the index, in v's SORTED row, of
 // the first entry that leads back to u, and how many there are (multi-edges).  One lane per entry: lower bound of u in
 // v's sorted row, then the run of equal ids.
-__global__ __launch_bounds__(TPB) void k_rev_build(GraphView g, unsigned long long *cursor, uint32_t *__restrict__ rev) {
+__global__ __launch_bounds__(TPB) void k_rev_build(GraphView g, unsigned long long *cursor, RevEnt *__restrict__ rev) {
   const int lane = lane_id();
   while (true) {
     const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
@@ -298,7 +298,9 @@ __global__ __launch_bounds__(TPB) void k_rev_build(GraphView g, unsigned long lo
         while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (cs[mid] < (uint32_t)u) lo = mid + 1; else hi = mid; }
         uint32_t cnt = 0;
         while (cnt < 255u && lo + (int32_t)cnt < rv.deg && cs[lo + cnt] == (uint32_t)u) ++cnt;
-        rev[ru.off + k] = cnt ? ((cnt << 24) | (uint32_t)lo) : REV_NONE;          // (rows have fewer than 2^23 entries: CFO_NDEG_MAX)
+        RevEnt o; o.cl = cnt ? ((cnt << 24) | (uint32_t)lo) : REV_NONE; o.pos0 = 0u; o.w0 = 0.0f; o.pad = 0u;   // (rows have fewer than 2^23 entries: CFO_NDEG_MAX)
+        if (cnt) { o.pos0 = g.sperm[rv.off + lo]; o.w0 = g.sw[rv.off + lo]; }
+        rev[ru.off + k] = o;
       }
     }
   }

@@ -94,7 +94,7 @@ struct Graph {
   DevBuf<double> eb_bins;         // the tables
   DevBuf<uint32_t> em_bits;       // membership masks of the pairs whose curr row has 33 .. eb_mask_max candidates
   int32_t eb_mask_max = 0, eb_f32 = 0;
-  DevBuf<uint32_t> rev;           // [n_entries] position of the return edge of every entry (k_walk_q1), built lazily
+  DevBuf<RevEnt> rev;             // [n_entries] the return edge(s) of every entry (k_walk_q1), built lazily
   bool has_rev = false;
   int64_t pq_bad_rows = 0;        // rows the per-call certificate turned away (build_pq_tables)
   bool eb_complete = false;       // the HBM budget did not bind: every pair into a certified row has a table

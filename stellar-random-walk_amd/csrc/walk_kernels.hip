@@ -414,7 +414,9 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
           unsigned rd; e = cfo_pick<NT>(crow, r.deg, m, rd, k); reads += rd;
         } else {
           const double *PQ = g.pq + r.off;
-          const uint32_t rv = g.rev[eprev];
+          const int4v rv4 = NT ? __builtin_nontemporal_load(reinterpret_cast<const int4v *>(g.rev + eprev))
+                               : *reinterpret_cast<const int4v *>(g.rev + eprev);
+          const uint32_t rv = (uint32_t)rv4.x;
           int32_t rp[REV_MAX_RETURNS]; double rc[REV_MAX_RETURNS];      // return edges: input-order position, correction
           int nr = 0;
           double corr_all = 0.0;
@@ -430,7 +432,12 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
 #pragma unroll
             for (int i = 0; i < REV_MAX_RETURNS; ++i) {
               rp[i] = r.deg; rc[i] = 0.0;
-              if (i < nr) { rp[i] = (int32_t)g.sperm[so + i]; const float w = g.sw[so + i]; rc[i] = (double)(w / p) - (double)w; corr_all += rc[i]; }
+              if (i < nr) {
+                float w;
+                if (i == 0) { rp[0] = rv4.y; w = __int_as_float(rv4.z); }             // the first return edge travels with rev[e]
+                else { rp[i] = (int32_t)g.sperm[so + i]; w = g.sw[so + i]; }
+                rc[i] = (double)(w / p) - (double)w; corr_all += rc[i];
+              }
             }
             for (int i = REV_MAX_RETURNS; i < nr; ++i) { const float w = g.sw[so + i]; corr_all += (double)(w / p) - (double)w; }   // (small graphs: dozens of duplicates between hubs)
           } else {

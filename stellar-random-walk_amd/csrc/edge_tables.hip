@@ -314,6 +314,32 @@ size_t env_gb(const char *name, size_t dflt_gb) {
 
 }  // namespace
 
+// HBM a COMPLETE set of tables would take (every pair into a certified row + every mask + offsets + the work list):
+// prepare_tables sizes the hub bitmaps with what is left beside it.  0: no tables possible.
+size_t edge_tables_full_bytes(srw_handle *h, int mode) {
+  Graph &g = h->g;
+  if (!g.has_pq || !g.has_member || g.n_entries <= 0) return 0;
+  hipStream_t st = h->stream;
+  EbSel sel;
+  sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
+  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : 8; sel.min_cost = 0;
+  { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
+  { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
+  sel.has_ehash = 1; sel.has_hub = 1;               // (they only move priorities, not sizes)
+  DevBuf<unsigned long long> cursor, hist;
+  cursor.alloc(1); hist.alloc(128);
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  SRW_HIP(hipMemsetAsync(hist.p, 0, 128 * 8, st));
+  hipLaunchKernelGGL(k_eb_hist, dim3(h->n_cus * 8), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p, hist.p);
+  SRW_HIP(hipGetLastError());
+  unsigned long long hh[128];
+  SRW_HIP(hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  unsigned long long bytes = hh[126] * 16 + hh[127] * 8;
+  for (int cls = 1; cls <= 62; ++cls) bytes += hh[cls * 2] * 64 + hh[cls * 2 + 1] * 8;
+  return (size_t)bytes + (size_t)g.n_entries * 4 + (size_t)g.n_slots * 24;
+}
+
 void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   Graph &g = h->g;
   uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);

@@ -240,6 +240,7 @@ void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap);   // 
 // Per-edge bias tables for the general kernel under (p, q): mode 0 = automatic (most expensive pairs first, within the
 // HBM budget), 1 = every certified pair (tests: tiny chunks, no cost threshold).  Needs build_pq_tables first.
 void build_edge_tables(srw_handle *h, float p, float q, int mode);
+size_t edge_tables_full_bytes(srw_handle *h, int mode);   // HBM of a complete set of per-edge tables (0: none possible)
 void build_rev_table(srw_handle *h);             // return-edge positions (k_walk_q1: p != 1, q == 1)
 
 // ---- walk_kernels.hip ----

@@ -1071,13 +1071,16 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   const int32_t k0 = (int32_t)((int64_t)jc << csh), k1 = chunk_end(jc);
   const double b_prev = jc ? BIN(jc - 1) : 0.0, b_this = BIN(jc);
   // exact value of the numerator just before the chunk, and the exact sum of the chunk's corrections
-  double carry, pq_base = 0.0, chunk_corr;
+  // (inside the chunk the base prefix sums PQ[k] - PQ[k0-1] are not loaded: under the row certificate every partial sum of
+  // the base weights fl(w / q) is exact in any order, so the wave scan that adds up the corrections adds them up as well —
+  // 8 bytes per candidate fewer to request)
+  double carry, chunk_corr;
+  const double pq_base = k0 ? PQ[k0 - 1] : 0.0;
   if (ABS) {
-    pq_base = k0 ? PQ[k0 - 1] : 0.0;
     carry = b_prev;                                          // A'_{k0-1}
     chunk_corr = (b_this - b_prev) - (PQ[k1] - pq_base);
   } else {
-    carry = b_prev;                                          // corrections before the chunk
+    carry = b_prev + pq_base;                                // corrections before the chunk + base weights before the chunk
     chunk_corr = b_this - b_prev;
   }
   // q > 1 and p <= q: every correction (w - w/q for a member, w/p - w/q for a return edge) is >= 0; q < 1 and p >= q:
@@ -1093,15 +1096,23 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     __builtin_amdgcn_wave_barrier();
   }
   served = 1;
+#ifdef SRW_PHASE_TIMING
+  tm.n_binned += 1;                                             // resolved chunks ...
+  tm.n_w_elems += (unsigned long long)(k1 - k0 + 1);             // ... their candidates
+  if (no_specials) tm.n_w += 1; else if (stage_levels) tm.n_p1 += 1; else if (hubbits) tm.n_w_windows += 1; else tm.n_p1_elems += 1;
+#endif
   for (int32_t base = k0; base <= k1; base += 64 * PL) {
-    Ent e[PL]; double pqk[PL]; bool valid[PL], in[PL], want[PL]; uint32_t xs[PL];
-    tm.res_bytes += 16ull * (unsigned long long)((k1 - base + 1) < 64 * PL ? (k1 - base + 1) : 64 * PL);
+#ifdef SRW_PHASE_TIMING
+    tm.t_fin += 1;                                              // rounds of 64 * PL candidates
+#endif
+    Ent e[PL]; bool valid[PL], in[PL], want[PL]; uint32_t xs[PL];
+    tm.res_bytes += 8ull * (unsigned long long)((k1 - base + 1) < 64 * PL ? (k1 - base + 1) : 64 * PL);
 #pragma unroll
     for (int u = 0; u < PL; ++u) {
       const int32_t k = base + u * 64 + lane;
       valid[u] = k <= k1;
-      e[u].id = b.prev; e[u].w = 0.0f; pqk[u] = 0.0;
-      if (valid[u]) { e[u] = row[k]; pqk[u] = PQ[k]; }
+      e[u].id = b.prev; e[u].w = 0.0f;
+      if (valid[u]) e[u] = row[k];
     }
 #pragma unroll
     for (int u = 0; u < PL; ++u) {
@@ -1138,19 +1149,21 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     for (int u = 0; u < PL; ++u) {
       const int32_t k = base + u * 64 + lane;
       if (base + u * 64 > k1) break;                 // wave-uniform
-      double corr = 0.0;
-      if (valid[u] && !no_specials) {
-        if (e[u].id == b.prev) corr = (double)(e[u].w / p_) - (double)(e[u].w / q_);
-        else if (in[u]) corr = (double)e[u].w - (double)(e[u].w / q_);
+      double term = 0.0;                                // the candidate's variant: base weight + correction (exact)
+      if (valid[u]) {
+        term = (double)(e[u].w / q_);
+        if (!no_specials) {
+          if (e[u].id == b.prev) term += (double)(e[u].w / p_) - (double)(e[u].w / q_);
+          else if (in[u]) term += (double)e[u].w - (double)(e[u].w / q_);
+        }
       }
-      const double incl = wave_incl_scan_f64(corr);
-      const double num = (pqk[u] - pq_base) + carry + incl;
+      const double incl = wave_incl_scan_f64(term);
+      const double num = carry + incl;
       const bool nm = valid[u] && not_miss(k, num);
       const bool hit = sure_hit(k, num);
       const unsigned long long mm = __ballot(nm);
       if (mm) {
         const int f = __ffsll((long long)mm) - 1;
-        SRW_T1(tm, t_fin);
         if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(e[u].id, f); return base + u * 64 + f; }
         fallback = 1;
         const int32_t kk = wave_chain_pick(row, deg, b, r, S);

@@ -325,12 +325,18 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
         Bias b;
         b.p = p; b.q = q; b.prev = prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
         b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT;
+        SRW_T0(mem);
         if (r.deg <= g.eb_mask_max && (r.deg <= 32 || eo != EB_NONE)) {
           k = wave_pick_masked(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
           w_mask += 1; w_srch += 8u * (uint32_t)r.deg + 4u * (uint32_t)((r.deg + 31) >> 5);
+          SRW_T1(mem, t_a);
         } else if (r.deg > g.eb_mask_max && eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
           k = wave_pick_edge_table(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage);
           if (k >= 0) { w_tab += 1; w_srch += 8u * EB_BINS; w_fast += sv; }
+          SRW_T1(mem, t_p1);
+#ifdef SRW_PHASE_TIMING
+          if (rprev.deg > 1024) mem.t_p2 += wall_clock64() - mem.t_mark;      // ... of which steps with a long N(prev)
+#endif
         } else k = -1;
         if (k < 0) { handed_over = true; break; }          // no table for this pair: the general kernel takes the walker
       }
@@ -358,6 +364,13 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
     if (n_tab) atomicAdd(&ctr->strat[SRW_STRAT_EDGE_TABLE], (unsigned long long)n_tab);
     if (n_mask) atomicAdd(&ctr->strat[SRW_STRAT_EDGE_MASK], (unsigned long long)n_mask);
     if (n_first) atomicAdd(&ctr->strat[SRW_STRAT_SCAN], (unsigned long long)n_first);
+#ifdef SRW_PHASE_TIMING
+    // lean kernel: dbg[1] mask-step time, [2] table-step time, [3] ... with deg(prev) > 1024, [10..15] resolve statistics
+    atomicAdd(&ctr->dbg[1], mem.t_a >> 10); atomicAdd(&ctr->dbg[2], mem.t_p1 >> 10); atomicAdd(&ctr->dbg[3], mem.t_p2 >> 10);
+    atomicAdd(&ctr->dbg[10], mem.n_w); atomicAdd(&ctr->dbg[11], mem.n_w_elems); atomicAdd(&ctr->dbg[12], mem.n_w_windows);
+    atomicAdd(&ctr->dbg[13], mem.n_p1); atomicAdd(&ctr->dbg[14], mem.n_p1_elems); atomicAdd(&ctr->dbg[15], mem.n_binned);
+    atomicAdd(&ctr->dbg[16], mem.t_fin);
+#endif
   }
 }
 
@@ -1271,6 +1284,12 @@ void read_counters(srw_handle *h, srw_walk_stats *stats) {
                                 (double)c.dbg[24 + i] * 1024.0 / 100.0 / (double)c.strat[i]);
       fprintf(stderr, "\n");
     }
+    if (c.strat[SRW_STRAT_EDGE_TABLE])                   // the lean table kernel's own statistics (valid when it served the table steps)
+      fprintf(stderr, "[lean] wave-ms: mask steps %.0f (%llu steps), table steps %.0f (%llu steps; %.0f with deg(prev) > 1024) | chunks %llu: "
+              "no specials %llu, N(prev) staged %llu, hub bitmap %llu, edge hash %llu; candidates per chunk %.0f, rounds per chunk %.2f\n",
+              (double)c.dbg[1] * 1024.0 / 100e3, c.strat[SRW_STRAT_EDGE_MASK], (double)c.dbg[2] * 1024.0 / 100e3, c.strat[SRW_STRAT_EDGE_TABLE],
+              (double)c.dbg[3] * 1024.0 / 100e3, c.dbg[15], c.dbg[10], c.dbg[13], c.dbg[12], c.dbg[14],
+              (double)c.dbg[11] / (double)std::max<unsigned long long>(c.dbg[15], 1), (double)c.dbg[16] / (double)std::max<unsigned long long>(c.dbg[15], 1));
     fprintf(stderr, "[phase] W detail wave-ms: wait-B %.0f clear+insert %.0f wait-A %.0f probe %.0f\n", (double)c.dbg[16] * 1024.0 / 100e3,
             (double)c.dbg[17] * 1024.0 / 100e3, (double)c.dbg[18] * 1024.0 / 100e3, (double)c.dbg[19] * 1024.0 / 100e3);
   }
@@ -1428,15 +1447,33 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool want_hub = general && P.q != 1.0f && h->cfg.world == 1 && !(P.flags & SRW_WALK_NO_HUB_BITMAPS);
   const bool want_eb = general && P.q != 1.0f && h->cfg.world == 1 && h->g.has_pq && !(P.flags & SRW_WALK_NO_EDGE_TABLES) &&
                        !(P.flags & SRW_WALK_NO_BINNED);
-  // with per-edge tables the bitmaps only serve the tables' own construction and the probes of a located chunk: a
-  // quarter of the budget is plenty, the rest goes to the tables
+  // With per-edge tables the bitmaps serve the tables' own construction and the membership probes of a located chunk
+  // whose N(prev) is too long for LDS — one probe into a bitmap that the hub's many walkers keep in L2, against one
+  // HBM request into the edge hash (config 3: 16 / 40 / 80 GB of bitmaps -> 223 / 258 / 272 M steps/s, s44).  The tables
+  // come first: the bitmaps get what a COMPLETE set of tables leaves (16 GB when the tables will not fit anyway).
   size_t hub_cap = want_eb ? (size_t)16 << 30 : (size_t)64 << 30;
-  { const char *e = getenv("SRW_HUB_BUDGET_GB"); if (e && *e) hub_cap = (size_t)(atof(e) * (double)((size_t)1 << 30)); }
+  const int eb_mode = (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0;
+  if (const char *e = getenv("SRW_HUB_BUDGET_GB"); e && *e) hub_cap = (size_t)(atof(e) * (double)((size_t)1 << 30));
+  else if (want_eb && want_hub) {
+    Graph &g = h->g;
+    uint32_t pb, qb; memcpy(&pb, &P.p, 4); memcpy(&qb, &P.q, 4);
+    if (g.has_eb && g.has_hub && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode) hub_cap = g.hub_budget_cap;   // standing tables: keep their bitmaps
+    else {
+      const size_t need = edge_tables_full_bytes(h, eb_mode);
+      size_t free_b = 0, total_b = 0;
+      SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+      free_b += g.hub_bm.n * sizeof(uint32_t) + g.eb_bins.n * sizeof(double) + g.em_bits.n * sizeof(uint32_t) + g.eb_off.n * sizeof(uint32_t);
+      size_t reserve = (size_t)24 << 30;
+      if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
+      const size_t keep = need + reserve + ((size_t)8 << 30);
+      if (need > 0 && free_b > keep + ((size_t)16 << 30)) hub_cap = std::min<size_t>(free_b - keep, (size_t)96 << 30);
+    }
+  }
   if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, hub_cap);
   h->g.use_hub = want_hub;
   // ... and, last (they take what HBM is left), the per-edge bias tables: the most expensive (prev, curr) pairs get
   // their N(prev) ∩ N(curr) corrections precomputed once per (p, q) instead of once per visit
-  if (want_eb) build_edge_tables(h, P.p, P.q, (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0);
+  if (want_eb) build_edge_tables(h, P.p, P.q, eb_mode);
   h->g.use_eb = want_eb;
 }
 double timed_prepare_tables(srw_handle *h, const srw_walk_params &P) {   // builders synchronise the stream themselves

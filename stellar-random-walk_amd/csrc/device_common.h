@@ -114,6 +114,7 @@ struct GraphView {
   // (directed graphs); pos0 / w0 = input-order position and weight of that first return edge, so that the common case of
   // ONE return edge costs one 16-byte request instead of three; null if not built
   const RevEnt *rev;
+  int32_t eb_cap;           // chunks per table at most (64 / 128 / 256: finer tables on hub rows when HBM allows, edge_tables.hip)
 };
 constexpr uint32_t REV_NONE = 0xFFFFFFFFu;
 constexpr int REV_MAX_RETURNS = 4;          // return edges of one step the per-lane kernel keeps in registers

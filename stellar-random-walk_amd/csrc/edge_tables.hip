@@ -46,6 +46,7 @@ struct EbSel {          // which pairs get a table
   int32_t min_sh;       // bins tables: smallest chunk shift
   int32_t has_ehash, has_hub;
   int32_t f32;          // tables of ROW_PQ_F32 rows are stored as floats
+  int32_t bins_cap;     // chunks per table at most (GraphView::eb_cap)
 };
 constexpr int INLINE_MAX_DEG = 32;   // masks of rows up to 32 candidates live in eb_off[e] itself
 
@@ -62,7 +63,7 @@ __device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s
   if (rv.deg < s.min_deg || !(rv.flags & ROW_PQ_OK)) return 0u;
   const BinnedCost c = binned_cost(rv.deg, ru.deg, s.has_hub && (ru.flags >> ROW_HUB_SHIFT) != 0u, s.has_ehash != 0);
   const int64_t cost = c.c1 < c.c2 ? (c.c1 < c.cw ? c.c1 : c.cw) : (c.c2 < c.cw ? c.c2 : c.cw);
-  const BinGeom geo = bin_geometry(rv.deg, s.min_sh, EB_BINS);
+  const BinGeom geo = bin_geometry(rv.deg, s.min_sh, s.bins_cap);
   const uint32_t units = (s.f32 && (rv.flags & ROW_PQ_F32)) ? (uint32_t)((geo.n_bins + 15) >> 4) : (uint32_t)((geo.n_bins + 7) >> 3);
   // priority = wave-cycles a table saves per visit, per 64 bytes of table: an on-the-fly step costs its intersection
   // work plus ~20 us of dependent round trips whatever its size (measured: 38 .. 43 us per P1 / W step at config 3
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, EbSel sel, unsig
 // pass 4: the tables.  One wave per pair: binned_fill exactly as a walk step over that pair would run it, then the
 // prefix at every table chunk end goes to HBM.
 __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
-                                                     float q, int32_t min_sh, int32_t mask_max, const uint32_t *__restrict__ eb_off,
+                                                     float q, int32_t min_sh, int32_t mask_max, int32_t bins_cap, const uint32_t *__restrict__ eb_off,
                                                      double *__restrict__ eb_bins, uint32_t *__restrict__ em_bits, unsigned long long *cursor,
                                                      unsigned long long *strat_count /* [8] */) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][BINNED_LDS_WORDS];
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
         ns[0] += 1;
         continue;
       }
-      const BinGeom gc = bin_geometry(rv.deg, min_sh, EB_BINS);
+      const BinGeom gc = bin_geometry(rv.deg, min_sh, bins_cap);
       const BinGeom gf = gc.csh < 6 ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
       unsigned long long ab = 0; unsigned su = 0;
       binned_fill(g, rv, b, mine, 0, gf, tm, ab, su);
@@ -316,7 +317,7 @@ size_t env_gb(const char *name, size_t dflt_gb) {
 
 // HBM a COMPLETE set of tables would take (every pair into a certified row + every mask + offsets + the work list):
 // prepare_tables sizes the hub bitmaps with what is left beside it.  0: no tables possible.
-size_t edge_tables_full_bytes(srw_handle *h, int mode) {
+size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
   Graph &g = h->g;
   if (!g.has_pq || !g.has_member || g.n_entries <= 0) return 0;
   hipStream_t st = h->stream;
@@ -326,6 +327,7 @@ size_t edge_tables_full_bytes(srw_handle *h, int mode) {
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
   { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
   sel.has_ehash = 1; sel.has_hub = 1;               // (they only move priorities, not sizes)
+  sel.bins_cap = bins_cap;
   DevBuf<unsigned long long> cursor, hist;
   cursor.alloc(1); hist.alloc(128);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
@@ -340,11 +342,13 @@ size_t edge_tables_full_bytes(srw_handle *h, int mode) {
   return (size_t)bytes + (size_t)g.n_entries * 4 + (size_t)g.n_slots * 24;
 }
 
-void build_edge_tables(srw_handle *h, float p, float q, int mode) {
+void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) {
   Graph &g = h->g;
   uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);
+  if (bins_cap < EB_BINS) bins_cap = EB_BINS;
+  if (bins_cap > BIN_CAP) bins_cap = BIN_CAP;
   { const char *e = getenv("SRW_EB_NO_F32"); const int want_f32 = (e && *e == '1') ? 0 : 1;
-    if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.eb_f32 == want_f32) return; }
+    if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.eb_f32 == want_f32 && g.eb_cap == bins_cap) return; }
   hipStream_t st = h->stream;
   g.has_eb = false; g.eb_tables = 0; g.eb_bytes = 0; g.eb_build_ms = 0.0; g.eb_complete = false;
   g.eb_bins.release(); g.em_bits.release();
@@ -358,6 +362,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
   { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
   g.eb_f32 = sel.f32;
+  sel.bins_cap = bins_cap; g.eb_cap = bins_cap;
   sel.has_ehash = (g.has_ehash && g.use_ehash) ? 1 : 0; sel.has_hub = (g.has_hub && g.use_hub) ? 1 : 0;
   g.eb_min_sh = sel.min_sh;
   // budget: what is free now minus the offsets and a reserve for the walk's own buffers
@@ -429,7 +434,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
     SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
     hipLaunchKernelGGL(k_eb_build, dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
-                       g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p);
+                       sel.bins_cap, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   }
@@ -440,8 +445,8 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode) {
   g.eb_bytes = (int64_t)(units * 64 + munits * 16 + (unsigned long long)g.n_entries * 4);
   g.eb_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("SRW_TIMING"))
-    fprintf(stderr, "[edge tables] %llu bins tables (%.2f GB, min priority %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
-            "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
+    fprintf(stderr, "[edge tables] up to %d chunks per table; %llu bins tables (%.2f GB, min priority %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
+            "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", sel.bins_cap, pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
             sc[3], sc[4], mpairs, (double)munits * 16 / 1e9, (double)g.n_entries * 4 / 1e9, g.eb_build_ms);
 }
 

@@ -93,7 +93,7 @@ struct Graph {
   DevBuf<uint32_t> eb_off;        // [n_entries] per-edge bias tables (edge_tables.hip): offset of entry e's table, 64-B units
   DevBuf<double> eb_bins;         // the tables
   DevBuf<uint32_t> em_bits;       // membership masks of the pairs whose curr row has 33 .. eb_mask_max candidates
-  int32_t eb_mask_max = 0, eb_f32 = 0;
+  int32_t eb_mask_max = 0, eb_f32 = 0, eb_cap = 64;
   DevBuf<RevEnt> rev;             // [n_entries] the return edge(s) of every entry (k_walk_q1), built lazily
   bool has_rev = false;
   int64_t pq_bad_rows = 0;        // rows the per-call certificate turned away (build_pq_tables)
@@ -110,7 +110,7 @@ struct Graph {
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
                      (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
-                     has_rev ? rev.p : nullptr}; }
+                     has_rev ? rev.p : nullptr, eb_cap}; }
 };
 
 struct WalkResult {
@@ -239,8 +239,8 @@ void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap);   // 
 // ---- edge_tables.hip ----
 // Per-edge bias tables for the general kernel under (p, q): mode 0 = automatic (most expensive pairs first, within the
 // HBM budget), 1 = every certified pair (tests: tiny chunks, no cost threshold).  Needs build_pq_tables first.
-void build_edge_tables(srw_handle *h, float p, float q, int mode);
-size_t edge_tables_full_bytes(srw_handle *h, int mode);   // HBM of a complete set of per-edge tables (0: none possible)
+void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap);
+size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap);   // HBM of a complete set of per-edge tables (0: none possible)
 void build_rev_table(srw_handle *h);             // return-edge positions (k_walk_q1: p != 1, q == 1)
 
 // ---- walk_kernels.hip ----

@@ -1329,11 +1329,15 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
 
 // Per-edge bias table (edge_tables.hip): the chunk prefixes of this (prev -> curr) pair were computed once per (p, q)
 // by k_eb_build with the same binned_fill; the step is the search + one chunk, no intersection of the two rows.
-constexpr int EB_BINS = 64;                    // chunks per table: one lane each in the search
+#ifndef SRW_EB_BINS
+#define SRW_EB_BINS 64
+#endif
+constexpr int EB_BINS = SRW_EB_BINS;           // chunks per table at least offered: one lane each in the search.  GraphView::eb_cap (64 / 128 /
+                                               // 256) is what the standing tables were built with: more chunks = a second search round, shorter chunks
 __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc, const Bias &b, const double *table,
                                                float r, unsigned &fallback, unsigned &served, Member &tm, int32_t &id_out,
                                                uint32_t *stage /* 1024 words of the wave's LDS */) {
-  const BinGeom geo = bin_geometry(rc.deg, g.eb_min_sh, EB_BINS);
+  const BinGeom geo = bin_geometry(rc.deg, g.eb_min_sh, g.eb_cap);
   return binned_resolve<true>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage);
 }
 

@@ -1451,29 +1451,47 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   // whose N(prev) is too long for LDS — one probe into a bitmap that the hub's many walkers keep in L2, against one
   // HBM request into the edge hash (config 3: 16 / 40 / 80 GB of bitmaps -> 223 / 258 / 272 M steps/s, s44).  The tables
   // come first: the bitmaps get what a COMPLETE set of tables leaves (16 GB when the tables will not fit anyway).
+  // Table resolution: a table has at most eb_cap chunks, so on a hub row a chunk is deg / eb_cap candidates long and the
+  // located chunk is what a table step streams (64 chunks: 628 candidates on average at config 3).  Finer tables cost HBM on
+  // the hub pairs only (config 3: 41.8 / 59.7 / 77.0 / 111.9 GB at 64 / 128 / 256 / 512 chunks -> 376 / 448 / 497 / 513 M steps/s,
+  // s45 / s47): the finest of 256 / 128 / 64 whose COMPLETE set fits next to 32 GB of bitmaps is taken.
   size_t hub_cap = want_eb ? (size_t)16 << 30 : (size_t)64 << 30;
   const int eb_mode = (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0;
-  if (const char *e = getenv("SRW_HUB_BUDGET_GB"); e && *e) hub_cap = (size_t)(atof(e) * (double)((size_t)1 << 30));
-  else if (want_eb && want_hub) {
+  int eb_cap = EB_BINS;
+  const char *env_hub = getenv("SRW_HUB_BUDGET_GB"), *env_cap = getenv("SRW_EB_CHUNKS");
+  if (env_hub && *env_hub) hub_cap = (size_t)(atof(env_hub) * (double)((size_t)1 << 30));
+  if (env_cap && *env_cap) eb_cap = atoi(env_cap);
+  if (want_eb) {
     Graph &g = h->g;
     uint32_t pb, qb; memcpy(&pb, &P.p, 4); memcpy(&qb, &P.q, 4);
-    if (g.has_eb && g.has_hub && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode) hub_cap = g.hub_budget_cap;   // standing tables: keep their bitmaps
-    else {
-      const size_t need = edge_tables_full_bytes(h, eb_mode);
+    if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode && (!want_hub || g.has_hub)) {
+      eb_cap = g.eb_cap;                                           // standing tables: keep them and the bitmaps they were built with
+      if (want_hub) hub_cap = g.hub_budget_cap;
+    } else {
       size_t free_b = 0, total_b = 0;
       SRW_HIP(hipMemGetInfo(&free_b, &total_b));
       free_b += g.hub_bm.n * sizeof(uint32_t) + g.eb_bins.n * sizeof(double) + g.em_bits.n * sizeof(uint32_t) + g.eb_off.n * sizeof(uint32_t);
       size_t reserve = (size_t)24 << 30;
       if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
+      const size_t table_cap = (size_t)160 << 30;                  // build_edge_tables' own ceiling (SRW_EB_BUDGET_GB)
+      size_t need = 0;
+      if (!(env_cap && *env_cap)) {
+        for (int c : {256, 128}) {
+          const size_t n = edge_tables_full_bytes(h, eb_mode, c);
+          if (n > 0 && n < table_cap && free_b > n + reserve + ((size_t)40 << 30)) { eb_cap = c; need = n; break; }
+        }
+      }
+      if (need == 0) need = edge_tables_full_bytes(h, eb_mode, eb_cap);
       const size_t keep = need + reserve + ((size_t)8 << 30);
-      if (need > 0 && free_b > keep + ((size_t)16 << 30)) hub_cap = std::min<size_t>(free_b - keep, (size_t)96 << 30);
+      if (!(env_hub && *env_hub) && want_hub && need > 0 && free_b > keep + ((size_t)16 << 30))
+        hub_cap = std::min<size_t>(free_b - keep, (size_t)96 << 30);
     }
   }
   if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, hub_cap);
   h->g.use_hub = want_hub;
   // ... and, last (they take what HBM is left), the per-edge bias tables: the most expensive (prev, curr) pairs get
   // their N(prev) ∩ N(curr) corrections precomputed once per (p, q) instead of once per visit
-  if (want_eb) build_edge_tables(h, P.p, P.q, eb_mode);
+  if (want_eb) build_edge_tables(h, P.p, P.q, eb_mode, eb_cap);
   h->g.use_eb = want_eb;
 }
 double timed_prepare_tables(srw_handle *h, const srw_walk_params &P) {   // builders synchronise the stream themselves

@@ -345,7 +345,7 @@ size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
 void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) {
   Graph &g = h->g;
   uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);
-  if (bins_cap < EB_BINS) bins_cap = EB_BINS;
+  if (bins_cap < 8) bins_cap = 8;
   if (bins_cap > BIN_CAP) bins_cap = BIN_CAP;
   { const char *e = getenv("SRW_EB_NO_F32"); const int want_f32 = (e && *e == '1') ? 0 : 1;
     if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.eb_f32 == want_f32 && g.eb_cap == bins_cap) return; }

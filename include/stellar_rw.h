@@ -59,7 +59,12 @@ enum {
   /* sharded handles (world > 1): a vertex is owned by the partition id recorded for it by a partitioned load
    * (VCutRandomWalk: GraphMap.getPartition(steps.last), M/algorithm/VCutRandomWalk.scala:121-134), modulo world;
    * vertices without a recorded partition fall back to mix32(v) mod world. */
-  SRW_CFG_OWNER_FROM_PARTITIONS = 1
+  SRW_CFG_OWNER_FROM_PARTITIONS = 1,
+  /* whole-graph handles (world == 1): always compact the vertex ids at load (slot = rank among the sorted distinct ids).
+   * Without the flag this happens only when the id space is sparse — the reference's HashMap-keyed GraphMap
+   * (M/algorithm/GraphMap.scala:13-15) takes any int32 ids, e.g. "-2147483648 2147483647".  Results are the same
+   * either way (the Philox stream stays keyed by the input's ids); the flag exists for tests. */
+  SRW_CFG_COMPACT_IDS = 2
 };
 
 /* Replaces: SparkContext + GraphMap singleton lifetime (M/Main.scala:21-23, M/algorithm/GraphMap.scala:11). */

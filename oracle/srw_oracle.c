@@ -333,6 +333,7 @@ static int parse_line(const char *s, size_t n, int weighted, int partitioned, in
 struct orc_graph {
   int64_t n_lines; int32_t *l_src, *l_dst, *l_pid; float *l_w;
   int32_t vmin, vmax; int64_t n_slots;
+  int32_t *uid;                   /* sparse id space: the sorted distinct ids, slot = rank (NULL: slot = id - vmin) */
   uint8_t *present; int64_t *off; /* n_slots + 1 */
   int32_t *ids; float *w; int32_t *sorted_ids;
   int64_t n_entries, n_vertices;
@@ -340,6 +341,15 @@ struct orc_graph {
 };
 
 static int cmp_i32(const void *a, const void *b) { int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return (x > y) - (x < y); }
+/* index of id v in the per-vertex arrays; -1 if v cannot be a vertex (presence is checked by the callers) */
+static inline int64_t raw_slot(const orc_graph *g, int32_t v) {
+  if (g->n_slots == 0 || v < g->vmin || v > g->vmax) return -1;
+  if (!g->uid) return (int64_t)v - g->vmin;
+  int64_t lo = 0, hi = g->n_slots - 1;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (g->uid[mid] < v) lo = mid + 1; else hi = mid; }
+  return g->uid[lo] == v ? lo : -1;
+}
+static inline int32_t slot_id(const orc_graph *g, int64_t s) { return g->uid ? g->uid[s] : (int32_t)(s + g->vmin); }
 
 /* Adjacency of v = concatenation, in line order, of every line's contribution to v
  * (UniformRandomWalk.scala:35-41: flatMap then reduceByKey(_ ++ _); canonical order). */
@@ -353,11 +363,20 @@ static orc_graph *graph_build(line_vec *lv, int directed) {
     if (lv->dst[i] < vmin) vmin = lv->dst[i]; if (lv->dst[i] > vmax) vmax = lv->dst[i];
   }
   g->vmin = vmin; g->vmax = vmax; g->n_slots = (int64_t)vmax - (int64_t)vmin + 1;
-  if (g->n_slots > ((int64_t)1 << 31)) { free(g); return NULL; } /* dense index would not fit; oracle is for small cases */
+  /* The reference keys vertices in a HashMap (GraphMap.scala:13-15): any int32 ids.  This index is an array; when the id
+   * space is sparse the array is over the RANK of the id among the sorted distinct ids instead of id - vmin. */
+  if (g->n_slots > 64 * lv->n + ((int64_t)1 << 20)) {
+    g->uid = (int32_t *)malloc(sizeof(int32_t) * (size_t)lv->n * 2);
+    for (int64_t i = 0; i < lv->n; ++i) { g->uid[2 * i] = lv->src[i]; g->uid[2 * i + 1] = lv->dst[i]; }
+    qsort(g->uid, (size_t)lv->n * 2, sizeof(int32_t), cmp_i32);
+    int64_t m = 0;
+    for (int64_t i = 0; i < 2 * lv->n; ++i) if (m == 0 || g->uid[m - 1] != g->uid[i]) g->uid[m++] = g->uid[i];
+    g->n_slots = m;
+  }
   g->present = (uint8_t *)calloc((size_t)g->n_slots, 1);
   g->off = (int64_t *)calloc((size_t)g->n_slots + 1, sizeof(int64_t));
   for (int64_t i = 0; i < lv->n; ++i) {
-    int64_t s = (int64_t)lv->src[i] - vmin, d = (int64_t)lv->dst[i] - vmin;
+    int64_t s = raw_slot(g, lv->src[i]), d = raw_slot(g, lv->dst[i]);
     g->present[s] = 1; g->present[d] = 1;
     g->off[s + 1]++;
     if (!directed) g->off[d + 1]++;
@@ -369,7 +388,7 @@ static orc_graph *graph_build(line_vec *lv, int directed) {
   int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)g->n_slots);
   memcpy(cur, g->off, sizeof(int64_t) * (size_t)g->n_slots);
   for (int64_t i = 0; i < lv->n; ++i) {
-    int64_t s = (int64_t)lv->src[i] - vmin, d = (int64_t)lv->dst[i] - vmin;
+    int64_t s = raw_slot(g, lv->src[i]), d = raw_slot(g, lv->dst[i]);
     g->ids[cur[s]] = lv->dst[i]; g->w[cur[s]] = lv->w[i]; cur[s]++;          /* (src, [(dst, w)]) */
     if (!directed) { g->ids[cur[d]] = lv->src[i]; g->w[cur[d]] = lv->w[i]; cur[d]++; } /* (dst, [(src, w)]) */
   }
@@ -419,7 +438,7 @@ orc_graph *orc_graph_load_edgelist(const char *path, int directed, int weighted,
 void orc_graph_free(orc_graph *g) {
   if (!g) return;
   free(g->l_src); free(g->l_dst); free(g->l_pid); free(g->l_w);
-  free(g->present); free(g->off); free(g->ids); free(g->w); free(g->sorted_ids);
+  free(g->uid); free(g->present); free(g->off); free(g->ids); free(g->w); free(g->sorted_ids);
   free(g->a_prob); free(g->a_alias); free(g->a_regular); free(g);
 }
 int64_t orc_graph_num_vertices(const orc_graph *g) { return g->n_vertices; }
@@ -427,12 +446,11 @@ int64_t orc_graph_num_entries(const orc_graph *g) { return g->n_entries; }
 int64_t orc_graph_num_lines(const orc_graph *g) { return g->n_lines; }
 void orc_graph_vertices(const orc_graph *g, int32_t *out) {
   int64_t k = 0;
-  for (int64_t v = 0; v < g->n_slots; ++v) if (g->present[v]) out[k++] = (int32_t)(v + g->vmin);
+  for (int64_t v = 0; v < g->n_slots; ++v) if (g->present[v]) out[k++] = slot_id(g, v);
 }
 static inline int64_t slot_of(const orc_graph *g, int32_t v) {
-  if (g->n_slots == 0 || v < g->vmin || v > g->vmax) return -1;
-  int64_t s = (int64_t)v - g->vmin;
-  return g->present[s] ? s : -1;
+  int64_t s = raw_slot(g, v);
+  return (s >= 0 && g->present[s]) ? s : -1;
 }
 int64_t orc_graph_degree(const orc_graph *g, int32_t v) {
   int64_t s = slot_of(g, v); if (s < 0) return -1; return g->off[s + 1] - g->off[s];
@@ -523,9 +541,10 @@ static void graph_build_alias(orc_graph *g) {
 }
 
 int orc_graph_alias_row(const orc_graph *g, int32_t v, float *prob, int32_t *alias) {
-  if (g->n_slots == 0 || v < g->vmin || v > g->vmax || !g->present[(int64_t)v - g->vmin]) return -1;
+  int64_t s = raw_slot(g, v);
+  if (s < 0 || !g->present[s]) return -1;
   graph_build_alias((orc_graph *)g);
-  int64_t s = (int64_t)v - g->vmin, n = g->off[s + 1] - g->off[s];
+  int64_t n = g->off[s + 1] - g->off[s];
   for (int64_t k = 0; k < n; ++k) { prob[k] = g->a_prob[g->off[s] + k]; alias[k] = g->a_alias[g->off[s] + k]; }
   return g->a_regular[s];
 }

@@ -18,6 +18,7 @@ OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_HIP, ERR_EXISTS, ERR_NOMEM = range(7)
 SAMPLER_REFERENCE, SAMPLER_ALIAS = 0, 1
 RNG_CONST, RNG_PHILOX = 0, 1
 CFG_OWNER_FROM_PARTITIONS = 1
+CFG_COMPACT_IDS = 2
 WALK_FORCE_GENERAL = 1
 WALK_NT_LOADS = 2
 WALK_CACHED_LOADS = 4
@@ -207,9 +208,10 @@ def save_paths(paths, lens, output_dir, n_parts=1, write_crc=False):
 class Engine:
     """One handle = one GPU.  Mirrors the life of the reference's SparkContext + GraphMap + RandomWalk object."""
 
-    def __init__(self, device=0, rank=0, world=1, owner_from_partitions=False):
+    def __init__(self, device=0, rank=0, world=1, owner_from_partitions=False, compact_ids=False):
         self.h = C.c_void_p()
-        cfg = Config(device, rank, world, CFG_OWNER_FROM_PARTITIONS if owner_from_partitions else 0)
+        cfg = Config(device, rank, world, (CFG_OWNER_FROM_PARTITIONS if owner_from_partitions else 0) |
+                     (CFG_COMPACT_IDS if compact_ids else 0))
         rc = lib().srw_create(C.byref(cfg), C.byref(self.h))
         if rc != OK:
             self.h = None

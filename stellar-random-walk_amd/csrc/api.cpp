@@ -49,7 +49,8 @@ void load_lines(srw_handle *h, const int32_t *src, const int32_t *dst, const flo
     vmin = std::min(vmin, std::min(src[i], dst[i]));
     vmax = std::max(vmax, std::max(src[i], dst[i]));
   }
-  check_id_range(vmin, vmax);                    // before any allocation that is proportional to the id range
+  const bool sparse = ids_are_sparse(h, 2 * n, vmin, vmax);
+  if (!sparse) check_id_range(vmin, vmax);       // before any allocation that is proportional to the id range
   hipStream_t st = h->stream;
   DevBuf<int32_t> d_src, d_dst; DevBuf<float> d_w;
   d_src.alloc((size_t)n); d_dst.alloc((size_t)n);
@@ -58,16 +59,22 @@ void load_lines(srw_handle *h, const int32_t *src, const int32_t *dst, const flo
   if (w) { d_w.alloc((size_t)n); SRW_HIP(hipMemcpyAsync(d_w.p, w, (size_t)n * 4, hipMemcpyHostToDevice, st)); }
   SRW_HIP(hipStreamSynchronize(st));
   // VCut: vertexPartitionMap.put(dst, pId) for every adjacency entry, last put wins (GraphMap.scala:28-32).
+  IdMap idmap;
+  if (sparse) compact_ids(h, d_src.p, d_dst.p, n, vmin, vmax, idmap);     // [vmin, vmax] is the rank range from here on
   std::vector<int32_t> part_of;
   if (pid) {
+    auto slot = [&](int32_t v) -> size_t {
+      if (!idmap.compact) return (size_t)((int64_t)v - vmin);
+      return (size_t)(std::lower_bound(idmap.h_orig_id.begin(), idmap.h_orig_id.end(), v) - idmap.h_orig_id.begin());
+    };
     part_of.assign((size_t)((int64_t)vmax - vmin + 1), -1);
     for (int64_t i = 0; i < n; ++i) {
-      part_of[(size_t)((int64_t)dst[i] - vmin)] = pid[i];
-      if (!directed) part_of[(size_t)((int64_t)src[i] - vmin)] = pid[i];
+      part_of[slot(dst[i])] = pid[i];
+      if (!directed) part_of[slot(src[i])] = pid[i];
     }
   }
   build_graph_from_device_lines(h, d_src.p, d_dst.p, w ? d_w.p : nullptr, n, directed, vmin, vmax,
-                                part_of.empty() ? nullptr : part_of.data());
+                                part_of.empty() ? nullptr : part_of.data(), &idmap);
   h->g.part_of = std::move(part_of);
 }
 }  // namespace
@@ -189,10 +196,10 @@ int32_t srw_load_adjacency(srw_handle *h, const int32_t *vids, const int64_t *of
       h->g.part_of.assign((size_t)h->g.n_slots, -1);
       std::vector<char> seen((size_t)h->g.n_slots, 0);
       for (int64_t i = 0; i < n_rows; ++i) {
-        size_t s = (size_t)((int64_t)vids[i] - h->g.vmin);
+        size_t s = (size_t)h->g.slot_of_id(vids[i]);
         if (seen[s]) continue;   // a re-added vertex is ignored entirely (GraphMap.scala:37)
         seen[s] = 1;
-        for (int64_t e = offs[i]; e < offs[i + 1]; ++e) h->g.part_of[(size_t)((int64_t)ids[e] - h->g.vmin)] = pids[e];
+        for (int64_t e = offs[i]; e < offs[i + 1]; ++e) h->g.part_of[(size_t)h->g.slot_of_id(ids[e])] = pids[e];
       }
     }
   });
@@ -223,6 +230,7 @@ int32_t srw_graph_vertices(const srw_handle *ch, int32_t *out) {
     need(h->g.loaded && (out || h->g.n_local_vertices == 0), "no graph / null out");
     if (h->g.n_local_vertices > 0)
       SRW_HIP(hipMemcpy(out, h->g.verts.p, (size_t)h->g.n_local_vertices * 4, hipMemcpyDeviceToHost));
+    if (h->g.compact) for (int64_t i = 0; i < h->g.n_local_vertices; ++i) out[i] = h->g.id_of_slot(out[i]);
   });
 }
 
@@ -232,8 +240,8 @@ int32_t srw_graph_neighbors(const srw_handle *ch, int32_t v, int32_t *ids, float
   return guarded(h, [&] {
     need(h->g.loaded && n, "no graph / null n");
     const Graph &g = h->g;
-    int64_t s = (int64_t)v - g.vmin;
-    if (s < 0 || s >= g.n_slots) { *n = -1; return; }
+    const int64_t s = g.slot_of_id(v);
+    if (s < 0) { *n = -1; return; }
     Row r;
     SRW_HIP(hipMemcpy(&r, g.rows.p + s, sizeof(Row), hipMemcpyDeviceToHost));
     if (!(r.flags & ROW_PRESENT)) { *n = -1; return; }       // case None => null
@@ -242,7 +250,7 @@ int32_t srw_graph_neighbors(const srw_handle *ch, int32_t v, int32_t *ids, float
     if (m > 0 && (ids || w)) {
       std::vector<Ent> tmp((size_t)m);
       SRW_HIP(hipMemcpy(tmp.data(), g.ent.p + r.off, (size_t)m * sizeof(Ent), hipMemcpyDeviceToHost));
-      for (int64_t k = 0; k < m; ++k) { if (ids) ids[k] = tmp[k].id; if (w) w[k] = tmp[k].w; }
+      for (int64_t k = 0; k < m; ++k) { if (ids) ids[k] = g.compact ? g.id_of_slot(tmp[k].id) : tmp[k].id; if (w) w[k] = tmp[k].w; }
     }
   });
 }
@@ -250,8 +258,8 @@ int32_t srw_graph_neighbors(const srw_handle *ch, int32_t v, int32_t *ids, float
 int32_t srw_graph_partition(const srw_handle *h, int32_t v, int32_t *pid, int32_t *known) {
   if (!h || !h->g.loaded || !known) return SRW_ERR_INVALID;
   *known = 0;
-  int64_t s = (int64_t)v - h->g.vmin;
-  if (h->g.part_of.empty() || s < 0 || s >= h->g.n_slots || h->g.part_of[(size_t)s] < 0) return SRW_OK;
+  const int64_t s = h->g.slot_of_id(v);
+  if (h->g.part_of.empty() || s < 0 || h->g.part_of[(size_t)s] < 0) return SRW_OK;
   if (pid) *pid = h->g.part_of[(size_t)s];
   *known = 1;
   return SRW_OK;
@@ -264,8 +272,8 @@ int32_t srw_alias_row(srw_handle *h, int32_t v, float *prob, int32_t *alias, int
     build_membership(h);
     build_alias_tables(h);
     const Graph &g = h->g;
-    int64_t s = (int64_t)v - g.vmin;
-    if (s < 0 || s >= g.n_slots) { *n = -1; return; }
+    const int64_t s = g.slot_of_id(v);
+    if (s < 0) { *n = -1; return; }
     Row r;
     SRW_HIP(hipMemcpy(&r, g.rows.p + s, sizeof(Row), hipMemcpyDeviceToHost));
     if (!(r.flags & ROW_PRESENT)) { *n = -1; return; }

@@ -114,8 +114,13 @@ struct GraphView {
   // (directed graphs); pos0 / w0 = input-order position and weight of that first return edge, so that the common case of
   // ONE return edge costs one 16-byte request instead of three; null if not built
   const RevEnt *rev;
-  int32_t eb_cap;           // chunks per table at most (64 / 128 / 256: finer tables on hub rows when HBM allows, edge_tables.hip)
+  int32_t eb_cap;           // chunks per table at most (32 … 256: finer tables on hub rows when HBM allows, a complete coarser set when it does not; edge_tables.hip)
+  // Compacted id space (graph_build.hip:compact_ids): every id inside the engine is the RANK of the vertex among the sorted
+  // distinct ids of the input (vmin = 0), orig_id[rank] is the id the files carry.  Null: ids are used as they are.
+  const int32_t *orig_id;
 };
+// The id the walk's Philox stream is keyed with (ctr = (iteration, SOURCE ID, step, 0)) is the input's, not the rank.
+__device__ inline int32_t rng_source(const GraphView &g, int32_t src) { return g.orig_id ? g.orig_id[src - g.vmin] : src; }
 constexpr uint32_t REV_NONE = 0xFFFFFFFFu;
 constexpr int REV_MAX_RETURNS = 4;          // return edges of one step the per-lane kernel keeps in registers
 constexpr uint32_t EB_NONE = 0xFFFFFFFFu;

@@ -208,7 +208,9 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool w
   SRW_HIP(hipGetLastError());
   if (bad) return false;
   d_text.release(); nlpos.release();
-  build_graph_from_device_lines(h, d_src.p, d_dst.p, weighted ? d_w.p : nullptr, n_lines, directed, mm[0], mm[1], nullptr);
+  IdMap idmap;                                   // a sparse id space is compacted to ranks (graph_build.hip:compact_ids)
+  if (ids_are_sparse(h, 2 * n_lines, mm[0], mm[1])) compact_ids(h, d_src.p, d_dst.p, n_lines, mm[0], mm[1], idmap);
+  build_graph_from_device_lines(h, d_src.p, d_dst.p, weighted ? d_w.p : nullptr, n_lines, directed, mm[0], mm[1], nullptr, &idmap);
   h->g.part_of.clear();
   return true;
 }

@@ -8,6 +8,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/stellar_rw.h"
 #include "device_common.h"
@@ -104,13 +105,25 @@ struct Graph {
   bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
+  // Compacted ids (sparse id spaces, SRW_CFG_COMPACT_IDS): slots are ranks among the sorted distinct input ids
+  bool compact = false;
+  DevBuf<int32_t> orig_id;        // [n_slots] rank -> input id (ascending)
+  std::vector<int32_t> h_orig_id; // host mirror (boundary look-ups: srw_graph_neighbors, partitions)
+  int32_t id_lo = 0, id_hi = -1;  // smallest / largest id a path can print (text capacity of the formatter)
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
   GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, (has_cfo || cfo_linked) ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
                      (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
-                     has_rev ? rev.p : nullptr, eb_cap}; }
+                     has_rev ? rev.p : nullptr, eb_cap, compact ? orig_id.p : nullptr}; }
+  // id <-> slot at the boundary (api.cpp): -1 if the id cannot be a vertex of this graph
+  int64_t slot_of_id(int32_t v) const {
+    if (!compact) { const int64_t s = (int64_t)v - vmin; return (s < 0 || s >= n_slots) ? -1 : s; }
+    auto it = std::lower_bound(h_orig_id.begin(), h_orig_id.end(), v);
+    return (it == h_orig_id.end() || *it != v) ? -1 : (int64_t)(it - h_orig_id.begin());
+  }
+  int32_t id_of_slot(int64_t s) const { return compact ? h_orig_id[(size_t)s] : (int32_t)(s + vmin); }
 };
 
 struct WalkResult {
@@ -220,9 +233,19 @@ void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d
 // ---- graph_build.hip ----
 void check_id_range(int32_t vmin, int32_t vmax);   // throws SRW_ERR_NOMEM when the dense slot tables cannot hold [vmin, vmax]
 // Lines already on the device (d_src/d_dst/d_w; d_w may be null = 1.0f).  Builds rows/ent/sids/verts.
+// Compacted ids: decision + the rewrite of the lines (d_src / d_dst become ranks, [vmin, vmax] becomes [0, n_ids - 1]);
+// the IdMap travels into the Graph through build_graph_from_device_lines.
+struct IdMap {
+  bool compact = false;
+  DevBuf<int32_t> orig_id;
+  std::vector<int32_t> h_orig_id;
+  int32_t id_lo = 0, id_hi = -1;
+};
+bool ids_are_sparse(const srw_handle *h, int64_t n_ids, int32_t vmin, int32_t vmax);
+void compact_ids(srw_handle *h, int32_t *d_src, int32_t *d_dst, int64_t n_lines, int32_t &vmin, int32_t &vmax, IdMap &m);
 void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
                                    int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
-                                   const int32_t *host_owner_tab = nullptr);
+                                   const int32_t *host_owner_tab = nullptr, IdMap *idmap = nullptr);
 void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_t *offs, int64_t n_rows,
                                 const int32_t *ids, const float *w);
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,

@@ -159,6 +159,27 @@ int bits_for(uint64_t max_value) {
   return b;
 }
 
+// ---- compacted ids (sparse id spaces) ----
+// key = id with the sign bit flipped: unsigned order == int32 order
+__global__ void k_ids_concat(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, int64_t n, uint32_t *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    out[i] = (uint32_t)src[i] ^ 0x80000000u; out[n + i] = (uint32_t)dst[i] ^ 0x80000000u;
+  }
+}
+__global__ void k_ids_unflip(const uint32_t *__restrict__ in, int64_t n, int32_t *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (int32_t)(in[i] ^ 0x80000000u);
+}
+// ids[i] <- rank of ids[i] in tab (ascending, distinct, contains every id)
+__global__ void k_ids_rank(int32_t *__restrict__ ids, int64_t n, const int32_t *__restrict__ tab, int64_t m) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t v = ids[i];
+    int64_t lo = 0, hi = m - 1;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tab[mid] < v) lo = mid + 1; else hi = mid; }
+    ids[i] = (int32_t)lo;
+  }
+}
+
 // keys/vals: n_total unsorted entries; n_owned of them carry a real key.  present: [n_slots] flags.
 void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals, int64_t n_total, int64_t n_owned,
                   DevBuf<uint32_t> &present, int32_t vmin, int32_t vmax, bool sharded) {
@@ -259,9 +280,9 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
 }  // namespace
 
 // Every per-vertex structure is dense over slot = id - vmin: the row table, the presence scan, the
-// optional owner table, hub bitmaps.  The reference keys vertices in a HashMap and takes any int32 ids; here a sparse id
-// space (two ids 2^31 apart) would need tens of GB for nothing, so it is refused up front with a clear message instead of
-// failing somewhere inside an allocation (documented deviation).
+// optional owner table, hub bitmaps.  A sparse id space (two ids 2^31 apart) would need tens of GB for nothing: whole-graph
+// handles compact it (compact_ids below); a sharded handle refuses it up front with a clear message instead of failing
+// somewhere inside an allocation (documented deviation).
 void check_id_range(int32_t vmin, int32_t vmax) {
   const int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
   if (n_slots <= 0) throw Error(SRW_ERR_INVALID, "empty vertex id range");
@@ -279,9 +300,60 @@ void check_id_range(int32_t vmin, int32_t vmax) {
   }
 }
 
+// The reference keys vertices in a HashMap (GraphMap.scala:13-15) and takes any int32 ids.  When the id space is sparse
+// (the dense tables would be mostly holes, or would not fit at all) the ids are COMPACTED at load: slot = rank of the id
+// among the sorted distinct ids of the input.  The rank is monotone, so every order-based structure (sorted rows,
+// membership searches, the ascending source order of the output) is the same as over the ids themselves; the two places
+// where the id VALUE matters are translated: the Philox key of a walker (rng_source) and the ids of the finished paths
+// (k_paths_to_ids at the end of launch_walk).  Whole-graph handles only: a sharded handle keeps the up-front refusal.
+bool ids_are_sparse(const srw_handle *h, int64_t n_ids, int32_t vmin, int32_t vmax) {
+  if (h->cfg.world > 1) return false;
+  if (h->cfg.flags & SRW_CFG_COMPACT_IDS) return true;
+  const int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
+  if (n_slots > 16 * n_ids + ((int64_t)1 << 22)) return true;      // > 256 B of row descriptors per id that occurs
+  try { check_id_range(vmin, vmax); } catch (const Error &) { return true; }
+  return false;
+}
+
+void compact_ids(srw_handle *h, int32_t *d_src, int32_t *d_dst, int64_t n_lines, int32_t &vmin, int32_t &vmax, IdMap &m) {
+  hipStream_t st = h->stream;
+  DevBuf<uint32_t> a, b, uniq; DevBuf<char> temp; DevBuf<unsigned long long> cnt;
+  const size_t n2 = (size_t)n_lines * 2;
+  a.alloc(n2); b.alloc(n2); cnt.alloc(1);
+  hipLaunchKernelGGL(k_ids_concat, dim3(grid_for(n_lines)), dim3(TPB), 0, st, d_src, d_dst, n_lines, a.p);
+  size_t tb = 0;
+  SRW_HIP(rocprim::radix_sort_keys(nullptr, tb, a.p, b.p, n2, 0u, 32u, st));
+  temp.alloc(tb);
+  SRW_HIP(rocprim::radix_sort_keys((void *)temp.p, tb, a.p, b.p, n2, 0u, 32u, st));
+  SRW_HIP(rocprim::unique(nullptr, tb, b.p, a.p, cnt.p, n2, rocprim::equal_to<uint32_t>(), st));
+  temp.alloc(tb);
+  SRW_HIP(rocprim::unique((void *)temp.p, tb, b.p, a.p, cnt.p, n2, rocprim::equal_to<uint32_t>(), st));
+  unsigned long long n_u = 0;
+  SRW_HIP(hipMemcpyAsync(&n_u, cnt.p, 8, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  b.release(); temp.release();
+  m.orig_id.alloc((size_t)n_u);
+  hipLaunchKernelGGL(k_ids_unflip, dim3(grid_for((int64_t)n_u)), dim3(TPB), 0, st, a.p, (int64_t)n_u, m.orig_id.p);
+  hipLaunchKernelGGL(k_ids_rank, dim3(grid_for(n_lines)), dim3(TPB), 0, st, d_src, n_lines, (const int32_t *)m.orig_id.p, (int64_t)n_u);
+  hipLaunchKernelGGL(k_ids_rank, dim3(grid_for(n_lines)), dim3(TPB), 0, st, d_dst, n_lines, (const int32_t *)m.orig_id.p, (int64_t)n_u);
+  SRW_HIP(hipGetLastError());
+  m.h_orig_id.resize((size_t)n_u);
+  SRW_HIP(hipMemcpyAsync(m.h_orig_id.data(), m.orig_id.p, (size_t)n_u * 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  m.compact = true; m.id_lo = vmin; m.id_hi = vmax;
+  vmin = 0; vmax = (int32_t)(n_u - 1);
+}
+
+static void install_id_map(Graph &g, IdMap *m) {
+  g.id_lo = g.vmin; g.id_hi = g.vmax;
+  if (!m || !m->compact) return;
+  g.compact = true; g.orig_id = std::move(m->orig_id); g.h_orig_id = std::move(m->h_orig_id);
+  g.id_lo = m->id_lo; g.id_hi = m->id_hi;
+}
+
 void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
                                    int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
-                                   const int32_t *host_owner_tab) {
+                                   const int32_t *host_owner_tab, IdMap *idmap) {
   if (n_lines <= 0) throw Error(SRW_ERR_INVALID, "empty edge list");
   int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
   check_id_range(vmin, vmax);
@@ -332,6 +404,7 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
   }
   finish_build(h, keys, vals, n_total, (int64_t)owned, present, vmin, vmax, sharded);
   if (sharded) { g.mrows = std::move(mrows); g.msids = std::move(msids); }
+  install_id_map(g, idmap);
 }
 
 void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_t *offs, int64_t n_rows,
@@ -343,18 +416,30 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
   int64_t n_ent_in = offs[n_rows];
   for (int64_t i = 0; i < n_rows; ++i) { vmin = std::min(vmin, vids[i]); vmax = std::max(vmax, vids[i]); }
   for (int64_t e = 0; e < n_ent_in; ++e) { vmin = std::min(vmin, ids[e]); vmax = std::max(vmax, ids[e]); }
+  IdMap idmap;
+  if (ids_are_sparse(h, n_rows + n_ent_in, vmin, vmax)) {      // this surface hands over host arrays: compact on the host
+    std::vector<int32_t> &u = idmap.h_orig_id;
+    u.assign(vids, vids + n_rows); u.insert(u.end(), ids, ids + n_ent_in);
+    std::sort(u.begin(), u.end()); u.erase(std::unique(u.begin(), u.end()), u.end());
+    idmap.compact = true; idmap.id_lo = vmin; idmap.id_hi = vmax;
+    vmin = 0; vmax = (int32_t)(u.size() - 1);
+  }
+  auto slot = [&](int32_t v) -> uint32_t {
+    if (!idmap.compact) return (uint32_t)((int64_t)v - vmin);
+    return (uint32_t)(std::lower_bound(idmap.h_orig_id.begin(), idmap.h_orig_id.end(), v) - idmap.h_orig_id.begin());
+  };
   int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
   check_id_range(vmin, vmax);
   std::vector<uint32_t> hkeys; std::vector<uint64_t> hvals; std::vector<uint32_t> hpresent((size_t)n_slots, 0u);
   hkeys.reserve((size_t)n_ent_in); hvals.reserve((size_t)n_ent_in);
   for (int64_t i = 0; i < n_rows; ++i) {
-    uint32_t k = (uint32_t)((int64_t)vids[i] - vmin);
+    uint32_t k = slot(vids[i]);
     if (hpresent[k]) continue;
     hpresent[k] = 1u;
     for (int64_t e = offs[i]; e < offs[i + 1]; ++e) {
       float ww = w ? w[e] : 1.0f; uint32_t wb; memcpy(&wb, &ww, 4);
       hkeys.push_back(k);
-      hvals.push_back(((uint64_t)wb << 32) | (uint32_t)ids[e]);
+      hvals.push_back(((uint64_t)wb << 32) | (uint32_t)(idmap.compact ? (int32_t)slot(ids[e]) : ids[e]));
     }
   }
   hipStream_t st = h->stream;
@@ -371,6 +456,11 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
   SRW_HIP(hipMemcpyAsync(present.p, hpresent.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
   SRW_HIP(hipStreamSynchronize(st));
   finish_build(h, keys, vals, n_total, n_total, present, vmin, vmax, false);
+  if (idmap.compact) {
+    idmap.orig_id.alloc(idmap.h_orig_id.size());
+    SRW_HIP(hipMemcpy(idmap.orig_id.p, idmap.h_orig_id.data(), idmap.h_orig_id.size() * 4, hipMemcpyHostToDevice));
+  }
+  install_id_map(g, &idmap);
 }
 
 namespace {

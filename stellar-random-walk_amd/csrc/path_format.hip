@@ -113,7 +113,7 @@ void ensure_pinned_text(srw_handle *h, size_t slice_cap, size_t n_off) {
 bool write_result_device(srw_handle *h, const char *output_dir, int n_parts, bool write_crc) {
   const int64_t n = h->res.n_walkers, stride = h->res.stride;
   Graph &g = h->g;
-  const size_t per_walker = format_capacity(1, stride, g.vmin, (int32_t)((int64_t)g.vmin + g.n_slots - 1));
+  const size_t per_walker = format_capacity(1, stride, g.id_lo, g.id_hi);
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(((size_t)1 << 30) / per_walker)));
   const size_t cap = (size_t)chunk * per_walker + 16;
   size_t free_b = 0, total_b = 0;

@@ -1332,8 +1332,8 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
 #ifndef SRW_EB_BINS
 #define SRW_EB_BINS 64
 #endif
-constexpr int EB_BINS = SRW_EB_BINS;           // chunks per table at least offered: one lane each in the search.  GraphView::eb_cap (64 / 128 /
-                                               // 256) is what the standing tables were built with: more chunks = a second search round, shorter chunks
+constexpr int EB_BINS = SRW_EB_BINS;           // default chunks per table: one lane each in the search.  GraphView::eb_cap (32 / 64 /
+                                               // 128 / 256) is what the standing tables were built with: more chunks = a second search round, shorter chunks
 __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc, const Bias &b, const double *table,
                                                float r, unsigned &fallback, unsigned &served, Member &tm, int32_t &id_out,
                                                uint32_t *stage /* 1024 words of the wave's LDS */) {

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(TPB, MINW) void k_walk_first_order(GraphView g, con
   Bias nobias; nobias.second_order = false; nobias.need_member = false; nobias.p = nobias.q = 1.0f;
   nobias.prev = 0; nobias.prev_sids = nullptr; nobias.prev_deg = 0; nobias.vmin = g.vmin;
   tile[wv][lane][0] = src;
+  src = rng_source(g, src);                            // from here on src only keys the Philox stream (compacted ids: the input's id)
   for (int32_t s = 1; s <= L + 1; ++s) {
     const int c = s & (TILE - 1);
     int32_t val = -1;
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     int64_t it = wi / n_verts, vi = wi - it * n_verts;
     const uint32_t iter = (uint32_t)(first_walk + it);
     const int32_t src = verts[vi];
+    const uint32_t ksrc = (uint32_t)rng_source(g, src);   // Philox key: the input's id of the source
     int32_t *path = paths + wi * stride;
     if (lane == 0) path[0] = src;
     int32_t prev = src, curr = src, len = 1;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
       Bias b;                                          // N(prev) = last step's row (whole-graph handle)
       b.p = p; b.q = q; b.prev = prev; b.second_order = second; b.need_member = second && (q != 1.0f); b.vmin = g.vmin;
       b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT;
-      float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
+      float u = draw_uniform(rng, iter, ksrc, (uint32_t)s);
       unsigned f = 0, sv = 0;
 #ifdef SRW_PHASE_TIMING
       mem.t_step0 = wall_clock64();
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
     const int64_t it = wi / n_verts, vi = wi - it * n_verts;
     const uint32_t iter = (uint32_t)(first_walk + it);
     const int32_t src = __builtin_amdgcn_readfirstlane(verts[vi]);
+    const uint32_t ksrc = (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, src));
     int32_t *path = paths + wi * stride;
     if (lane == 0) path[0] = src;
     int32_t prev = src, curr = src, len = 1;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
       r = uniform_row(r); eo = (uint32_t)__builtin_amdgcn_readfirstlane((int)eo);
       if (!in_range) { r.off = 0; r.deg = 0; r.flags = 0; }
       if (r.deg == 0) { w_dead += s > 1; break; }
-      const float u = draw_uniform(rng, iter, (uint32_t)src, (uint32_t)s);
+      const float u = draw_uniform(rng, iter, ksrc, (uint32_t)s);
       unsigned f = 0, sv = 0;
       int32_t k, next = 0;
       if (!second) {
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
   int32_t prev_id = src, curr_id = src;
   unsigned long long reads = 0, dead = 0;
   tile[wv][lane][0] = src;
+  src = rng_source(g, src);                            // from here on src only keys the Philox stream
   for (int32_t s = 1; s <= L + 1; ++s) {
     const int c = s & (TILE - 1);
     int32_t val = -1;
@@ -611,6 +615,7 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
     const int64_t it = wi / n_verts, vi = wi - it * n_verts;
     const uint32_t iter = (uint32_t)(first_walk + it);
     const int32_t src = verts[vi];
+    const uint32_t ksrc = (uint32_t)rng_source(g, src);   // Philox key: the input's id of the source
     int32_t *path = paths + wi * stride;
     Row rc; rc.off = 0; rc.deg = 0; rc.flags = 0;
     { const Row *rp0 = row_of(g, src); if (rp0) rc = *rp0; }
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
       if (rc.deg == 0) { if (s > 1) ++dead; break; }
       const bool second = s > 1, biased = second && biased_cfg;
       uint32_t o[4];
-      philox4x32_10(iter, (uint32_t)src, (uint32_t)s, t, seed, 0xA11A5u, o);
+      philox4x32_10(iter, ksrc, (uint32_t)s, t, seed, 0xA11A5u, o);
       AEnt e;
       const AEnt *ep = nullptr;                 // record whose link is still to be fetched
       bool accepted = true;
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
         bool appendix = false;
         if (fold) {
           uint32_t y[4];
-          philox4x32_10(iter, (uint32_t)src, (uint32_t)s, t, seed, 0xA11A6u, y);
+          philox4x32_10(iter, ksrc, (uint32_t)s, t, seed, 0xA11A6u, y);
           const float u5 = (float)(y[0] >> 8) * (1.0f / 16777216.0f);
           if ((double)u5 * ftot < fa) {       // appendix: return to prev; occurrence ~ w in input order
             appendix = true;
@@ -1333,6 +1338,17 @@ struct StreamDrain {
 };
 
 // Enqueue the walk kernel(s) of num_walks iterations starting at P.first_walk into d_paths / d_lens.
+// Compacted ids (graph_build.hip:compact_ids): rank -> input id over the written part of every path, one wave per path.
+__global__ void k_paths_to_ids(int32_t *__restrict__ paths, const int32_t *__restrict__ lens, int64_t n_walkers, int64_t stride,
+                               const int32_t *__restrict__ orig_id) {
+  const int lane = lane_id();
+  for (int64_t w = blockIdx.x * (int64_t)(TPB / 64) + (threadIdx.x >> 6); w < n_walkers; w += (int64_t)gridDim.x * (TPB / 64)) {
+    const int32_t len = lens[w];
+    int32_t *row = paths + w * stride;
+    for (int32_t k = lane; k < len; k += 64) row[k] = orig_id[row[k]];
+  }
+}
+
 LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walks, int32_t first_walk, int32_t *d_paths,
                        int32_t *d_lens) {
   Graph &g = h->g;
@@ -1418,6 +1434,13 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
   LaunchInfo li;
   li.kind = alias ? 3 : first_order ? 1 : 2;
   li.record_bytes = first_order_compact ? 16 : (first_order || alias) ? 32 : 0;
+  // compacted ids: the kernels walked over ranks; the paths leave with the ids of the input
+  if (g.compact && n_walkers > 0) {
+    const int64_t nb = std::min<int64_t>((n_walkers + TPB / 64 - 1) / (TPB / 64), (int64_t)h->n_cus * 32);
+    hipLaunchKernelGGL(k_paths_to_ids, dim3((unsigned)nb), dim3(TPB), 0, st, d_paths, d_lens, n_walkers, (int64_t)P.walk_length + 2,
+                       (const int32_t *)g.orig_id.p);
+    SRW_HIP(hipGetLastError());
+  }
   return li;
 }
 
@@ -1481,7 +1504,16 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
           if (n > 0 && n < table_cap && free_b > n + reserve + ((size_t)40 << 30)) { eb_cap = c; need = n; break; }
         }
       }
-      if (need == 0) need = edge_tables_full_bytes(h, eb_mode, eb_cap);
+      if (need == 0) {
+        need = edge_tables_full_bytes(h, eb_mode, eb_cap);
+        // A set that is cut by the budget sends its uncovered steps to the on-the-fly samplers of the monolithic kernel
+        // (config 5's stand-in at 64 chunks: 125 of 142 GB fit, 10 % of the steps uncovered, 1.36e8 steps/s); a COMPLETE
+        // coarser set runs every step in the lean table kernel (32 chunks: 129 GB, 1.68e8; 16 chunks: 84 GB, 1.07e8 — s50).
+        if (!(env_cap && *env_cap) && need > 0 && (need >= table_cap || free_b < need + reserve + ((size_t)8 << 30))) {
+          const size_t n = edge_tables_full_bytes(h, eb_mode, 32);
+          if (n > 0 && n < table_cap && free_b > n + reserve + ((size_t)8 << 30)) { eb_cap = 32; need = n; }
+        }
+      }
       const size_t keep = need + reserve + ((size_t)8 << 30);
       if (!(env_hub && *env_hub) && want_hub && need > 0 && free_b > keep + ((size_t)16 << 30))
         hub_cap = std::min<size_t>(free_b - keep, (size_t)96 << 30);
@@ -1602,7 +1634,7 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   const size_t need = (size_t)nv * stride * 4;
   bool device_format = (P.flags & SRW_WALK_DEVICE_FORMAT) != 0;
-  const size_t cap = format_capacity(nv, stride, g.vmin, (int32_t)((int64_t)g.vmin + g.n_slots - 1));
+  const size_t cap = format_capacity(nv, stride, g.id_lo, g.id_hi);
   if (device_format) {        // two text slots in HBM: fall back to the host formatter when they do not fit
     size_t free_b = 0, total_b = 0;
     SRW_HIP(hipMemGetInfo(&free_b, &total_b));

@@ -883,31 +883,21 @@ def test_q1_per_lane_kernel(eng, oracle, case):
         assert np.array_equal(pc, refc[0]) and np.array_equal(lc, refc[1])
 
 
-def test_wide_id_range_is_refused_up_front(eng):
-    """Every per-vertex table is dense over id - min(id): a sparse id space is refused
-    with SRW_ERR_NOMEM and a message that says what to do, before any allocation proportional to the range — and the
-    handle stays usable."""
-    P = pkg()
-    with pytest.raises(P.SrwError) as ei:                       # the whole int32 range: never
-        eng.load_coo(np.array([2147483647], np.int32), np.array([-2147483648], np.int32))
-    assert ei.value.code == P.ERR_NOMEM and "renumber" in str(ei.value), str(ei.value)
-    pid = np.zeros(1, np.int32)
-    with pytest.raises(P.SrwError) as ei:           # the partitioned load used to build a host table of the range first
-        eng.load_coo(np.array([2147483647], np.int32), np.array([-2147483648], np.int32), pid=pid)
-    assert ei.value.code == P.ERR_NOMEM
-    # two billion slots for four vertices: refused when HBM is short, else it must simply work (96 GB of tables on a 288 GB part)
-    s, d = np.array([0, 2000000000], np.int32), np.array([1, 3], np.int32)
-    try:
-        eng.load_coo(s, d)
-    except P.SrwError as e:
-        assert e.code == P.ERR_NOMEM and "renumber" in str(e)
-    else:
-        import oracle_py
-        g = oracle_py.Graph.from_coo(s, d, None)
-        assert eng.stats() == (4, 4)
+def test_wide_id_range_is_compacted(eng, oracle):
+    """The reference's GraphMap is a HashMap: any int32 ids load.  A sparse id space is compacted at load (slot = rank
+    among the sorted distinct ids) — the whole int32 range included, with and without partition ids — and
+    the handle stays usable for a dense graph afterwards.  tests/test_sparse_ids.py holds the parity tests proper."""
+    for s, d, pid in [(np.array([2147483647], np.int32), np.array([-2147483648], np.int32), None),
+                      (np.array([2147483647], np.int32), np.array([-2147483648], np.int32), np.zeros(1, np.int32)),
+                      (np.array([0, 2000000000], np.int32), np.array([1, 3], np.int32), None)]:
+        eng.load_coo(s, d, pid=pid)
+        g = oracle.Graph.from_coo(s, d, None)
+        assert eng.stats() == (g.num_vertices, g.num_entries)
         paths, lens, _ = eng.walk(walk_length=5, seed=3)
         rp, rl, _ = g.walk(walk_length=5, seed=3)
         assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
+    eng.load_edgelist(KARATE)
+    assert eng.stats() == (34, 156)
     eng.load_edgelist(KARATE)
     assert eng.stats() == (34, 156)
 

@@ -26,6 +26,7 @@ import argparse
 import json
 import os
 import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -212,6 +213,37 @@ def run_sharded_world1(pkg, device, scale=24, K=4, L=80):
             "timed": "wall time of srw_cluster_walk (all super-steps of K iterations, no host sync inside)"}
 
 
+def cluster_leg(pkg, torch, args, world, K):
+    """Vertex-sharded walk of the whole job on `world` devices driven by ONE process (srw_cluster_*): peer stores over xGMI,
+    super-steps ordered by events, paths on the home GPU.  Returns the `vertex_sharded` object of the bench line."""
+    n_edges = args.edge_factor << args.scale
+    try:
+        if torch.cuda.device_count() < world:
+            raise RuntimeError("the process sees %d devices, needs %d" % (torch.cuda.device_count(), world))
+        t0 = time.perf_counter()
+        with pkg.Cluster(list(range(world))) as cl:
+            cl.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
+            cnv, cne = cl.stats()
+            torch.cuda.synchronize()
+            t_graph = time.perf_counter() - t0
+            kw = dict(p=args.p, q=args.q, walk_length=args.walk_length, seed=42)
+            B = max(1, min(K, 4))
+            cl.walk(fetch=False, num_walks=K, first_walk=0, batch=B, **kw)          # warm-up: tables + buffers
+            st = cl.walk(fetch=False, num_walks=K, first_walk=K, batch=B, **kw)
+            dt_v = st["kernel_ms"] * 1e-3
+            return {"value": st["n_steps"] / dt_v, "unit": "walk-steps/s", "ms_per_step": dt_v / max(K, 1) * 1e3,
+                    "scaling": "strong", "steps": K, "warmup": K, "iterations_per_population": B,
+                    "workload": "RMAT scale-%d (%d edge lines, %d adjacency entries, %d vertices) p=%g q=%g walkLength=%d"
+                                % (args.scale, n_edges, cne, cnv, args.p, args.q, args.walk_length),
+                    "parallelism": "graph sharded by source vertex x%d (owner = mix32(id) mod world), one process driving all devices: "
+                                   "chunks stored into the peers' buffers over xGMI, super-steps ordered by events, paths on the "
+                                   "home GPU, no host sync per super-step" % world,
+                    "timed": "wall time of the super-steps of K iterations (srw_cluster_walk), result buffers preallocated",
+                    "setup_s": {"graph_generate_and_csr_all_shards": t_graph}}
+    except Exception as ex:
+        return {"error": str(ex)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,11 +269,18 @@ def main():
     ap.add_argument("--cpu-scale", type=int, default=20)
     ap.add_argument("--cpu-sources", type=int, default=0, help="0 = max(64, 3 per host core)")
     ap.add_argument("--cpu-walk-length", type=int, default=80)
+    ap.add_argument("--cluster-leg", type=int, default=0, help=argparse.SUPPRESS)   # child of an N > 1 run: see cluster_leg
     args = ap.parse_args()
 
     import torch
     import _pkg
     pkg = _pkg.load()
+    if args.cluster_leg:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X")
+        torch.zeros(1, device="cuda")
+        print(json.dumps(cluster_leg(pkg, torch, args, args.cluster_leg, args.steps)), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -377,29 +416,18 @@ def main():
                                               bool(args.directed), walk_kw, K, W, barrier_sync)
         else:
             if rank == 0:
+                # in a child process: a fault on a peer device (this path never met 8 real GPUs before the driver's run)
+                # costs the leg, not the headline line or the job
                 try:
-                    if torch.cuda.device_count() < world:
-                        raise RuntimeError("rank 0 sees %d devices, needs %d" % (torch.cuda.device_count(), world))
-                    t0 = time.perf_counter()
-                    with pkg.Cluster(list(range(world))) as cl:
-                        cl.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
-                        cnv, cne = cl.stats()
-                        torch.cuda.synchronize()
-                        t_graph = time.perf_counter() - t0
-                        kw = dict(p=args.p, q=args.q, walk_length=args.walk_length, seed=42)
-                        B = max(1, min(K, 4))
-                        cl.walk(fetch=False, num_walks=K, first_walk=0, batch=B, **kw)          # warm-up: tables + buffers
-                        st = cl.walk(fetch=False, num_walks=K, first_walk=K, batch=B, **kw)
-                        dt_v = st["kernel_ms"] * 1e-3
-                        vs = {"value": st["n_steps"] / dt_v, "unit": "walk-steps/s", "ms_per_step": dt_v / max(K, 1) * 1e3,
-                              "scaling": "strong", "steps": K, "warmup": K, "iterations_per_population": B,
-                              "workload": "RMAT scale-%d (%d edge lines, %d adjacency entries, %d vertices) p=%g q=%g walkLength=%d"
-                                          % (args.scale, n_edges, cne, cnv, args.p, args.q, args.walk_length),
-                              "parallelism": "graph sharded by source vertex x%d (owner = mix32(id) mod world), one process driving all devices: "
-                                             "chunks stored into the peers' buffers over xGMI, super-steps ordered by events, paths on the "
-                                             "home GPU, no host sync per super-step" % world,
-                              "timed": "wall time of the super-steps of K iterations (srw_cluster_walk), result buffers preallocated",
-                              "setup_s": {"graph_generate_and_csr_all_shards": t_graph}}
+                    env = {k: v for k, v in os.environ.items()
+                           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT",
+                                        "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS")}
+                    cmd = [sys.executable, os.path.abspath(__file__), "--cluster-leg", str(world), "--steps", str(K), "--scale", str(args.scale),
+                           "--edge-factor", str(args.edge_factor), "--walk-length", str(args.walk_length), "--p", repr(args.p), "--q", repr(args.q),
+                           "--weighted", str(args.weighted), "--directed", str(args.directed)]
+                    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, text=True)
+                    line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+                    vs = json.loads(line) if line.startswith("{") else {"error": "cluster leg exit %d: %s" % (r.returncode, r.stderr[-300:])}
                 except Exception as ex:
                     vs = {"error": str(ex)[:300]}
             dist.barrier()

@@ -425,7 +425,7 @@ def main():
                     cmd = [sys.executable, os.path.abspath(__file__), "--cluster-leg", str(world), "--steps", str(K), "--scale", str(args.scale),
                            "--edge-factor", str(args.edge_factor), "--walk-length", str(args.walk_length), "--p", repr(args.p), "--q", repr(args.q),
                            "--weighted", str(args.weighted), "--directed", str(args.directed)]
-                    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, text=True)
+                    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, text=True)
                     line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
                     vs = json.loads(line) if line.startswith("{") else {"error": "cluster leg exit %d: %s" % (r.returncode, r.stderr[-300:])}
                 except Exception as ex:

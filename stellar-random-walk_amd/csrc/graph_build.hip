@@ -305,9 +305,9 @@ void check_id_range(int32_t vmin, int32_t vmax) {
 // among the sorted distinct ids of the input.  The rank is monotone, so every order-based structure (sorted rows,
 // membership searches, the ascending source order of the output) is the same as over the ids themselves; the two places
 // where the id VALUE matters are translated: the Philox key of a walker (rng_source) and the ids of the finished paths
-// (k_paths_to_ids at the end of launch_walk).  Whole-graph handles only: a sharded handle keeps the up-front refusal.
+// (k_paths_to_ids at the end of launch_walk / run_shard_flush).  Sharded handles compact the same way: every shard sees the
+// whole edge list, so every shard computes the same ranks, and owner(v) is taken over the rank.
 bool ids_are_sparse(const srw_handle *h, int64_t n_ids, int32_t vmin, int32_t vmax) {
-  if (h->cfg.world > 1) return false;
   if (h->cfg.flags & SRW_CFG_COMPACT_IDS) return true;
   const int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
   if (n_slots > 16 * n_ids + ((int64_t)1 << 22)) return true;      // > 256 B of row descriptors per id that occurs

@@ -951,7 +951,7 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
     }
     const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
     Bias b = make_bias(g, p, q, wk.prev, step > 1);
-    float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
+    float u = draw_uniform(rng, iter, (uint32_t)rng_source(g, wk.src), (uint32_t)step);
     unsigned f = 0, sv = 0;
     int32_t k = -1, nid = 0;                         // same routing as k_walk_general (no per-edge tables on a shard)
     if (!b.need_member) k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int
         hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);     // death notice to the home rank
       } else {
         const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
-        float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
+        float u = draw_uniform(rng, iter, (uint32_t)rng_source(g, wk.src), (uint32_t)step);
         int32_t next;
         if (r.flags & ROW_IRREGULAR) {
           Bias nb; nb.second_order = false; nb.need_member = false; nb.p = nb.q = 1.0f; nb.prev = 0;
@@ -1085,11 +1085,11 @@ __global__ __launch_bounds__(TPB) void k_sh_step_cfo(GraphView g, ShardIO io, in
           const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
           CfoEnt e;
           if (!(link >> 63)) {
-            const uint32_t m = walk_bits24(rng.seed, iter, (uint32_t)wk.src, (uint32_t)step);
+            const uint32_t m = walk_bits24(rng.seed, iter, (uint32_t)rng_source(g, wk.src), (uint32_t)step);
             unsigned rd;
             e = cfo_pick<NT>(g.cfo + off, deg, m, rd); reads += rd;
           } else {                                        // irregular row: the reference's scan, literally; the links are valid for every row
-            const float u = draw_uniform(rng, iter, (uint32_t)wk.src, (uint32_t)step);
+            const float u = draw_uniform(rng, iter, (uint32_t)rng_source(g, wk.src), (uint32_t)step);
             e = g.cfo[off + lane_pick_sequential(g.ent + off, deg, nobias, u)]; ++fb;
           }
           ++steps;
@@ -1904,6 +1904,13 @@ void run_shard_flush(srw_handle *h, const srw_walk_params &P, int32_t batch, con
   const ShardIO io = make_io(h, batch, lay, d_recv);
   hipLaunchKernelGGL(k_sh_apply, dim3(h->n_cus * 4), dim3(TPB), 0, h->stream, io, d_paths, d_lens, stride);
   SRW_HIP(hipGetLastError());
+  // compacted ids: the home rank's paths are complete now (one flush per begin); they leave with the ids of the input
+  const int64_t n = h->g.n_local_vertices * batch;
+  if (h->g.compact && n > 0) {
+    const int64_t nb = std::min<int64_t>((n + TPB / 64 - 1) / (TPB / 64), (int64_t)h->n_cus * 32);
+    hipLaunchKernelGGL(k_paths_to_ids, dim3((unsigned)nb), dim3(TPB), 0, h->stream, d_paths, d_lens, n, stride, (const int32_t *)h->g.orig_id.p);
+    SRW_HIP(hipGetLastError());
+  }
 }
 
 // Synchronises the handle's stream; counters accumulated since run_shard_begin and the overflow flag.

@@ -165,10 +165,38 @@ def test_sparse_ids_partitioned_load_and_adjacency_surface(oracle):
 
 
 @pytest.mark.gpu
-def test_sparse_ids_sharded_handles_still_refuse(oracle):
-    """A vertex-sharded handle keeps the dense index: the refusal stays, with its message."""
+@pytest.mark.parametrize("world,p,q,directed", [(2, 1.0, 1.0, False), (3, 0.25, 4.0, False), (4, 4.0, 0.5, True), (2, 0.5, 1.0, False)])
+def test_sparse_ids_vertex_sharded_cluster(oracle, tmp_path, world, p, q, directed):
+    """Vertex-sharded handles compact the same way (every shard sees the whole edge list and computes the same ranks;
+    owner(v) is taken over the rank): the in-process cluster equals the oracle for every batching, and its part files too."""
     P = pkg()
-    with P.Engine(device=0, rank=0, world=2) as sh:
-        with pytest.raises(P.SrwError) as ei:
-            sh.load_coo(np.array([I32_MAX], np.int32), np.array([I32_MIN], np.int32))
-        assert ei.value.code == P.ERR_NOMEM and "renumber" in str(ei.value)
+    s, d, w = sparse_multigraph(20 + world, n_vertices=90, n_lines=700, weighted=True)
+    g = oracle.Graph.from_coo(s, d, w, directed=directed)
+    with P.Cluster([0] * world) as cl:
+        cl.load_coo(s, d, w, directed=directed)
+        assert cl.stats() == (g.num_vertices, g.num_entries)
+        rp, rl, rs = g.walk(p=p, q=q, walk_length=11, num_walks=3, first_walk=2, seed=9)
+        for batch in (0, 1, 2):
+            paths, lens, st = cl.walk(p=p, q=q, walk_length=11, num_walks=3, first_walk=2, seed=9, batch=batch)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (world, batch)
+            assert st["n_steps"] == rs
+        out = tmp_path / "out"
+        cl.walk_and_save(str(out), n_parts=2, p=p, q=q, walk_length=11, num_walks=3, first_walk=2, seed=9)
+        ref = tmp_path / "ref"
+        oracle.write_paths(rp, rl, str(ref), n_parts=2)
+        for f in sorted(os.listdir(ref / "path")):
+            assert (out / "path" / f).read_bytes() == (ref / "path" / f).read_bytes(), f
+
+
+@pytest.mark.gpu
+def test_sparse_ids_sharded_by_user_partitions(oracle):
+    """SRW_CFG_OWNER_FROM_PARTITIONS over compacted ids: the owner table is indexed by rank."""
+    P = pkg()
+    s, d, w = sparse_multigraph(31, n_vertices=60, n_lines=400, weighted=False)
+    pid = (np.abs(d.astype(np.int64)) % 5).astype(np.int32)
+    g = oracle.Graph.from_coo(s, d, w)
+    with P.Cluster([0, 0, 0], owner_from_partitions=True) as cl:
+        cl.load_coo(s, d, w, pid=pid)
+        rp, rl, rs = g.walk(p=0.5, q=2.0, walk_length=8, num_walks=2, seed=4)
+        paths, lens, st = cl.walk(p=0.5, q=2.0, walk_length=8, num_walks=2, seed=4)
+        assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs

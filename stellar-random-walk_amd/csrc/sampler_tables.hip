@@ -334,7 +334,7 @@ struct PqCert {
     glsb = min(glsb, e - 23 + (int)__builtin_ctz(mant));
   }
   __device__ inline void add_entry(float w, float p, float q) {
-    const float a = w / q, c = w / p;
+    const float a = div_exact(w, q), c = div_exact(w, p);
     add(w); add(a); add(c);
     mass += (double)fmaxf(w, fmaxf(a, c));      // NaN-free once !bad
   }
@@ -362,7 +362,7 @@ __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, 
     for (int32_t k = 0; k < r.deg; ++k) c.add_entry(ent[r.off + k].w, p, q);
     if (!pq_row_ok(c.emin, c.bad, c.mass)) { atomicAdd(bad_rows, 1ull); continue; }
     double acc = 0.0;
-    for (int32_t k = 0; k < r.deg; ++k) { acc += (double)(ent[r.off + k].w / q); pq[r.off + k] = acc; }
+    for (int32_t k = 0; k < r.deg; ++k) { acc += (double)div_exact(ent[r.off + k].w, q); pq[r.off + k] = acc; }
     ok[v] = 1;
     rows[v].flags = r.flags | ROW_PQ_OK | (pq_row_f32(c.glsb, c.mass) ? ROW_PQ_F32 : 0u);
   }
@@ -390,7 +390,7 @@ __global__ void k_pq_large(Row *__restrict__ rows, const Ent *__restrict__ ent, 
       double carry = 0.0;                                            // exact sums: any order gives the same bits
       for (int32_t base = 0; base < r.deg; base += 64) {
         int32_t k = base + lane;
-        double x = k < r.deg ? (double)(row[k].w / q) : 0.0;
+        double x = k < r.deg ? (double)div_exact(row[k].w, q) : 0.0;
         for (int o = 1; o < 64; o <<= 1) { double t = __shfl_up(x, o); if (lane >= o) x += t; }
         if (k < r.deg) pq[r.off + k] = carry + x;
         carry += readlane_f64(x, 63);

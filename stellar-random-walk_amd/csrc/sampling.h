@@ -16,6 +16,17 @@ struct Bias {
   int32_t vmin;
 };
 
+
+// x / d, evaluated as x * 2^-k when d = 2^k: both are the correctly rounded value of the SAME real number (2^-k is exact
+// for |k| <= 126; FP32 denormals are on, .amdhsa_float_denorm_mode_32 3), so the bits are those of the reference's
+// `weight / q` (RandomSample.scala:33,35) — without the ~11-instruction correctly-rounded f32 divide per candidate.  d is
+// wave-uniform (p or q), so the test is scalar.  node2vec's usual p, q (0.25, 0.5, 2, 4) all qualify.
+__device__ inline float div_exact(float x, float d) {
+  const uint32_t bits = __float_as_uint(d), ex = bits >> 23;
+  if ((bits & 0x007FFFFFu) == 0u && ex >= 1u && ex <= 253u) return x * __uint_as_float((254u - ex) << 23);
+  return x / d;
+}
+
 __device__ inline bool sorted_contains(const uint32_t *a, int32_t n, uint32_t x) {
   int32_t lo = 0, hi = n;
   while (lo < hi) {
@@ -27,10 +38,10 @@ __device__ inline bool sorted_contains(const uint32_t *a, int32_t n, uint32_t x)
 
 __device__ inline float biased_weight(const Bias &b, int32_t id, float w) {
   if (!b.second_order) return w;
-  if (id == b.prev) return w / b.p;                 // :35  (checked first)
-  if (!b.need_member) return w / b.q;               // q == 1.0f
+  if (id == b.prev) return div_exact(w, b.p);       // :35  (checked first)
+  if (!b.need_member) return div_exact(w, b.q);     // q == 1.0f
   if (sorted_contains(b.prev_sids, b.prev_deg, (uint32_t)((int64_t)id - b.vmin))) return w;  // :37
-  return w / b.q;                                   // :33
+  return div_exact(w, b.q);                         // :33
 }
 
 // ---- exact pick, one lane, fully sequential (irregular rows and tiny degrees) ---------------------------
@@ -295,14 +306,14 @@ struct Member {
 
 __device__ inline float biased_weight_m(const Bias &b, const Member &m, int32_t pos, int32_t id, float w) {
   if (!b.second_order) return w;
-  if (id == b.prev) return w / b.p;
-  if (m.mode == 0) return w / b.q;
+  if (id == b.prev) return div_exact(w, b.p);
+  if (m.mode == 0) return div_exact(w, b.q);
   bool in;
   if (m.mode == 2) { uint32_t t = (uint32_t)(pos - m.seg_base); in = (m.bm[t >> 5] >> (t & 31)) & 1u; }
   else if (m.hub) { const uint32_t x = (uint32_t)((int64_t)id - b.vmin); in = (m.hub[x >> 5] >> (x & 31)) & 1u; }
   else if (m.ehash) in = edge_exists(m.ehash, m.ehash_mask, (uint32_t)((int64_t)b.prev - b.vmin), (uint32_t)((int64_t)id - b.vmin));
   else in = sorted_contains(b.prev_sids, b.prev_deg, (uint32_t)((int64_t)id - b.vmin));
-  return in ? w : w / b.q;
+  return in ? w : div_exact(w, b.q);
 }
 
 // Mark the candidates of segment [seg_base, seg_base + seg_len) that occur in N(prev).
@@ -569,7 +580,7 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
       const uint32_t orig = cp[c];
       const float w = row[orig].w;
       const uint32_t idx = atomicAdd(counter, 1u);
-      if (idx < (uint32_t)SP_CAP) { sp_pos[idx] = orig; sp_corr[idx] = (double)(w / b.p) - (double)(w / b.q); }
+      if (idx < (uint32_t)SP_CAP) { sp_pos[idx] = orig; sp_corr[idx] = (double)div_exact(w, b.p) - (double)div_exact(w, b.q); }
     }
   }
   // (b) members of N(prev) (only matter when q != 1)
@@ -583,7 +594,7 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
         const uint32_t orig = cp[c];
         const float w = row[orig].w;
         const uint32_t idx = atomicAdd(counter, 1u);
-        if (idx < (uint32_t)SP_CAP) { sp_pos[idx] = orig; sp_corr[idx] = (double)w - (double)(w / b.q); }
+        if (idx < (uint32_t)SP_CAP) { sp_pos[idx] = orig; sp_corr[idx] = (double)w - (double)div_exact(w, b.q); }
       }
     }
   }
@@ -789,8 +800,8 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
         const int32_t k = k0 + u * 64 + lane;
         if (k >= deg) continue;
         const uint32_t x = (uint32_t)((int64_t)e[u].id - b.vmin);
-        if (e[u].id == b.prev) atomicAdd(&bins[k >> csh], (double)(e[u].w / p_) - (double)(e[u].w / q_));
-        else if ((wd[u] >> (x & 31)) & 1u) atomicAdd(&bins[k >> csh], (double)e[u].w - (double)(e[u].w / q_));
+        if (e[u].id == b.prev) atomicAdd(&bins[k >> csh], (double)div_exact(e[u].w, p_) - (double)div_exact(e[u].w, q_));
+        else if ((wd[u] >> (x & 31)) & 1u) atomicAdd(&bins[k >> csh], (double)e[u].w - (double)div_exact(e[u].w, q_));
       }
     }
   } else if (strat == 3 && lo_id <= hi_id) {
@@ -802,7 +813,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
   }
   // (a) return edges: occurrences of prev in N(curr)
   for (int32_t c = ret_lo + lane; c < deg && cs[c] == xprev; c += 64)
-    atomicAdd(&bins[cp[c] >> csh], (double)(csw[c] / p_) - (double)(csw[c] / q_));
+    atomicAdd(&bins[cp[c] >> csh], (double)div_exact(csw[c], p_) - (double)div_exact(csw[c], q_));
   SRW_T1(tm, t_a); SRW_T0(tm);
   // (b) members of N(prev)
   if (m > 0 && strat != 4) {
@@ -836,7 +847,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
             for (int32_t c = lo[i]; c < deg && cs[c] == x[i]; ++c) {
               const uint32_t orig = cp[c];
               const float w = csw[c];
-              atomicAdd(&bins[orig >> csh], (double)w - (double)(w / q_));
+              atomicAdd(&bins[orig >> csh], (double)w - (double)div_exact(w, q_));
             }
       }
     } else if (strat == 2) {
@@ -845,7 +856,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
         if (e.id == b.prev) continue;
         const uint32_t xs = (uint32_t)((int64_t)e.id - b.vmin);
         if (g.ehash ? edge_exists(g.ehash, g.ehash_mask, xprev, xs) : sorted_contains(B, m, xs))
-          atomicAdd(&bins[k >> csh], (double)e.w - (double)(e.w / q_));
+          atomicAdd(&bins[k >> csh], (double)e.w - (double)div_exact(e.w, q_));
       }
     } else {
       if (lo_id <= hi_id) {
@@ -915,7 +926,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (want[j] && bch[pos[j]] == AI[j]) atomicAdd(&bins[AC[j] >> csh], (double)AW[j] - (double)(AW[j] / q_));
+            if (want[j] && bch[pos[j]] == AI[j]) atomicAdd(&bins[AC[j] >> csh], (double)AW[j] - (double)div_exact(AW[j], q_));
           // advance the list that ends first
           const int32_t na = (deg - pa) < 256 ? (deg - pa) : 256;
           const int jl = (na - 1) & 3;
@@ -1151,10 +1162,10 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       if (base + u * 64 > k1) break;                 // wave-uniform
       double term = 0.0;                                // the candidate's variant: base weight + correction (exact)
       if (valid[u]) {
-        term = (double)(e[u].w / q_);
+        term = (double)div_exact(e[u].w, q_);
         if (!no_specials) {
-          if (e[u].id == b.prev) term += (double)(e[u].w / p_) - (double)(e[u].w / q_);
-          else if (in[u]) term += (double)e[u].w - (double)(e[u].w / q_);
+          if (e[u].id == b.prev) term += (double)div_exact(e[u].w, p_) - (double)div_exact(e[u].w, q_);
+          else if (in[u]) term += (double)e[u].w - (double)div_exact(e[u].w, q_);
         }
       }
       const double incl = wave_incl_scan_f64(term);
@@ -1263,9 +1274,9 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
     if (i < ni && k < deg) {
       const Ent e = row[k];
       float w;
-      if (e.id == b.prev) w = e.w / b.p;
+      if (e.id == b.prev) w = div_exact(e.w, b.p);
       else if ((mw[i] >> (lane & 31)) & 1u) w = e.w;
-      else w = e.w / b.q;
+      else w = div_exact(e.w, b.q);
       wv[i] = w; idv[i] = e.id;
       part += (double)w; cert.add(w); neg |= !(w >= 0.0f);
     }

@@ -453,10 +453,10 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
                 float w;
                 if (i == 0) { rp[0] = rv4.y; w = __int_as_float(rv4.z); }             // the first return edge travels with rev[e]
                 else { rp[i] = (int32_t)g.sperm[so + i]; w = g.sw[so + i]; }
-                rc[i] = (double)(w / p) - (double)w; corr_all += rc[i];
+                rc[i] = (double)div_exact(w, p) - (double)w; corr_all += rc[i];
               }
             }
-            for (int i = REV_MAX_RETURNS; i < nr; ++i) { const float w = g.sw[so + i]; corr_all += (double)(w / p) - (double)w; }   // (small graphs: dozens of duplicates between hubs)
+            for (int i = REV_MAX_RETURNS; i < nr; ++i) { const float w = g.sw[so + i]; corr_all += (double)div_exact(w, p) - (double)w; }   // (small graphs: dozens of duplicates between hubs)
           } else {
 #pragma unroll
             for (int i = 0; i < REV_MAX_RETURNS; ++i) { rp[i] = r.deg; rc[i] = 0.0; }
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
 #pragma unroll
               for (int i = 0; i < REV_MAX_RETURNS; ++i) a += (rp[i] <= kk) ? rc[i] : 0.0;       // exact under the certificate
               for (int i = REV_MAX_RETURNS; i < nr; ++i)
-                if ((int32_t)g.sperm[so + i] <= kk) { const float w = g.sw[so + i]; a += (double)(w / p) - (double)w; }
+                if ((int32_t)g.sperm[so + i] <= kk) { const float w = g.sw[so + i]; a += (double)div_exact(w, p) - (double)w; }
               return a;
             };
             auto numer = [&](int32_t kk) { return PQ[kk] + corr_upto(kk); };

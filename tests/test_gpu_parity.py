@@ -127,6 +127,26 @@ def test_f32_division_bitwise(eng, oracle):
         assert a.view(np.uint32).tolist() == b.view(np.uint32).tolist()
 
 
+def test_power_of_two_bias_is_a_multiplication_with_the_same_bits(eng, oracle):
+    """sampling.h:div_exact evaluates weight / q as weight * 2^-k when q = 2^k (and the same for p): the bits must be the
+    divide's for every weight — subnormal results, subnormal and huge weights, signed zeros, infinities — at every power of
+    two incl. the ends of the range the shortcut takes (2^-126 .. 2^126) and just outside it (2^127, subnormal q)."""
+    rng = np.random.default_rng(5)
+    special = np.array([0.0, -0.0, 1e-45, 3e-45, 1e-40, 1.1754942e-38, 1.17549435e-38, 1.1754945e-38, 2.3509887e-38, 1.0, 1.0000001,
+                        0.99999994, 3.0, 16.0, 1e30, 1.7014117e38, 3.4028235e38, np.inf, 5e-324], dtype=np.float32)
+    bits = rng.integers(0, 0x7F800000, size=512 - len(special), dtype=np.int64).astype(np.uint32)     # every exponent, positive
+    w = np.concatenate([special, bits.view(np.float32)])
+    ids = np.arange(len(w), dtype=np.int32) + 10
+    prev_ids = ids[::3]
+    pows = [2.0 ** k for k in (-126, -125, -100, -24, -2, -1, 1, 2, 24, 100, 126, 127)] + [float(np.float32(1e-45)), float(np.float32(2.0 ** -127)), 3.0]
+    with np.errstate(all="ignore"):
+        for q in pows:
+            for p in (0.25, 4.0, 2.0 ** -126, 2.0 ** 126, 0.3):
+                a = eng.second_order_weights(p, q, int(ids[5]), prev_ids, ids, w)
+                b = oracle.second_order_weights(p, q, int(ids[5]), prev_ids, ids, w)
+                assert a.view(np.uint32).tolist() == b.view(np.uint32).tolist(), (p, q)
+
+
 def test_rng_stream(eng, oracle):
     it = np.array([0, 0, 0, 5, 123456], dtype=np.uint32)
     src = np.array([1, 1, 1, 4000000000, 77], dtype=np.uint32)

@@ -332,6 +332,7 @@ void compact_ids(srw_handle *h, int32_t *d_src, int32_t *d_dst, int64_t n_lines,
   SRW_HIP(hipMemcpyAsync(&n_u, cnt.p, 8, hipMemcpyDeviceToHost, st));
   SRW_HIP(hipStreamSynchronize(st));
   b.release(); temp.release();
+  if (n_u > 0x7FFFFFFFull) throw Error(SRW_ERR_INVALID, "more than 2^31 - 1 distinct vertex ids");   // ranks are int32
   m.orig_id.alloc((size_t)n_u);
   hipLaunchKernelGGL(k_ids_unflip, dim3(grid_for((int64_t)n_u)), dim3(TPB), 0, st, a.p, (int64_t)n_u, m.orig_id.p);
   hipLaunchKernelGGL(k_ids_rank, dim3(grid_for(n_lines)), dim3(TPB), 0, st, d_src, n_lines, (const int32_t *)m.orig_id.p, (int64_t)n_u);

@@ -221,7 +221,7 @@ def cluster_leg(pkg, torch, args, world, K):
         if torch.cuda.device_count() < world:
             raise RuntimeError("the process sees %d devices, needs %d" % (torch.cuda.device_count(), world))
         t0 = time.perf_counter()
-        with pkg.Cluster(list(range(world))) as cl:
+        with pkg.Cluster(list(range(world)), membership=(args.q != 1.0)) as cl:       # q == 1: memory per shard ~ 1 / world
             cl.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
             cnv, cne = cl.stats()
             torch.cuda.synchronize()

@@ -64,7 +64,13 @@ enum {
    * Without the flag this happens only when the id space is sparse — the reference's HashMap-keyed GraphMap
    * (M/algorithm/GraphMap.scala:13-15) takes any int32 ids, e.g. "-2147483648 2147483647".  Results are the same
    * either way (the Philox stream stays keyed by the input's ids); the flag exists for tests. */
-  SRW_CFG_COMPACT_IDS = 2
+  SRW_CFG_COMPACT_IDS = 2,
+  /* sharded handles (world > 1): do NOT build the replicated membership structure (the sorted neighbor ids of the WHOLE
+   * graph on every shard: 4 B per adjacency entry + 16 B per id slot, and the largest sort of the load).  It is what a
+   * shard needs to evaluate "x in N(prev)" for a prev it does not own, i.e. only when q != 1
+   * (M/algorithm/RandomSample.scala:37); walks with q == 1 (config 4: p = q = 1) never read it.  A walk with q != 1 on
+   * such a handle fails with SRW_ERR_INVALID.  With the flag a shard's memory is proportional to 1/world. */
+  SRW_CFG_NO_MEMBERSHIP = 4
 };
 
 /* Replaces: SparkContext + GraphMap singleton lifetime (M/Main.scala:21-23, M/algorithm/GraphMap.scala:11). */

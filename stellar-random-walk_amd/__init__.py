@@ -19,6 +19,7 @@ SAMPLER_REFERENCE, SAMPLER_ALIAS = 0, 1
 RNG_CONST, RNG_PHILOX = 0, 1
 CFG_OWNER_FROM_PARTITIONS = 1
 CFG_COMPACT_IDS = 2
+CFG_NO_MEMBERSHIP = 4
 WALK_FORCE_GENERAL = 1
 WALK_NT_LOADS = 2
 WALK_CACHED_LOADS = 4
@@ -445,11 +446,12 @@ class Cluster:
     """srw_cluster_*: the vertex-sharded walk inside one process over several devices (peer stores over xGMI, no
     collective).  `devices` may repeat an ordinal: several shards on one GPU (how single-GPU boxes test the protocol)."""
 
-    def __init__(self, devices, owner_from_partitions=False):
+    def __init__(self, devices, owner_from_partitions=False, membership=True):
+        """membership=False (SRW_CFG_NO_MEMBERSHIP): the shards skip the replicated neighbor-id structure; q == 1 walks only."""
         devs = np.ascontiguousarray(devices, dtype=np.int32)
         self.h = C.c_void_p()
-        rc = lib().srw_cluster_create(_i32(devs), len(devs), CFG_OWNER_FROM_PARTITIONS if owner_from_partitions else 0,
-                                      C.byref(self.h))
+        rc = lib().srw_cluster_create(_i32(devs), len(devs), (CFG_OWNER_FROM_PARTITIONS if owner_from_partitions else 0) |
+                                      (0 if membership else CFG_NO_MEMBERSHIP), C.byref(self.h))
         if rc != OK:
             raise SrwError(rc, lib().srw_last_error(None).decode())
         self.world = len(devs)

@@ -371,20 +371,22 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
     SRW_HIP(hipMemcpyAsync(g.owner_tab.p, host_owner_tab, (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
   }
 
+  // SRW_CFG_NO_MEMBERSHIP: a shard that will only run q == 1 walks skips the replicated membership structure
+  const bool want_membership = sharded && !(h->cfg.flags & SRW_CFG_NO_MEMBERSHIP);
   DevBuf<uint32_t> keys, present, gkeys; DevBuf<uint64_t> vals;
   keys.alloc((size_t)n_total); vals.alloc((size_t)n_total); present.alloc((size_t)n_slots);
-  if (sharded) gkeys.alloc((size_t)n_total);
+  if (want_membership) gkeys.alloc((size_t)n_total);
   SRW_HIP(hipMemsetAsync(present.p, 0, (size_t)n_slots * 4, st));
   h->counters.ensure(1);
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   hipLaunchKernelGGL(k_expand, dim3(grid_for(n_lines)), dim3(TPB), 0, st, d_src, d_dst, d_w, n_lines, directed ? 1 : 0,
                      vmin, h->cfg.rank, h->cfg.world, keys.p, vals.p, present.p, &h->counters.p->owned_entries,
-                     sharded ? gkeys.p : (uint32_t *)nullptr, (const int32_t *)g.owner_tab.p, n_slots);
+                     want_membership ? gkeys.p : (uint32_t *)nullptr, (const int32_t *)g.owner_tab.p, n_slots);
   unsigned long long owned = 0;
   SRW_HIP(hipMemcpyAsync(&owned, &h->counters.p->owned_entries, 8, hipMemcpyDeviceToHost, st));
   SRW_HIP(hipStreamSynchronize(st));
   DevBuf<Row> mrows; DevBuf<uint32_t> msids;
-  if (sharded) {
+  if (want_membership) {
     // replicated membership structure of the WHOLE graph (N(prev) must be testable on the shard that owns curr):
     // sort every entry by (row, id - vmin); keep the row boundaries and the sorted ids (4 B/entry)
     DevBuf<uint64_t> mk, mk2; DevBuf<char> temp;
@@ -404,7 +406,7 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
     gkeys.release();
   }
   finish_build(h, keys, vals, n_total, (int64_t)owned, present, vmin, vmax, sharded);
-  if (sharded) { g.mrows = std::move(mrows); g.msids = std::move(msids); }
+  if (want_membership) { g.mrows = std::move(mrows); g.msids = std::move(msids); }
   install_id_map(g, idmap);
 }
 

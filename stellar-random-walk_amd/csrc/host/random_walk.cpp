@@ -143,7 +143,9 @@ void RandomWalk::executeAndSaveSharded(int partitions, const std::string &output
   const bool same = getenv("SRW_CLUSTER_SAME_DEVICE") != nullptr;
   for (int i = 0; i < config_.gpus; ++i) devs.push_back(same ? config_.device : config_.device + i);
   srw_cluster *cl = nullptr;
-  if (srw_cluster_create(devs.data(), (int32_t)devs.size(), config_.partitioned ? SRW_CFG_OWNER_FROM_PARTITIONS : 0, &cl) != SRW_OK)
+  // q == 1: no shard ever tests "x in N(prev)" — skip the replicated membership structure (memory per shard ~ 1 / N)
+  const int32_t cflags = (config_.partitioned ? SRW_CFG_OWNER_FROM_PARTITIONS : 0) | ((float)config_.q == 1.0f ? SRW_CFG_NO_MEMBERSHIP : 0);
+  if (srw_cluster_create(devs.data(), (int32_t)devs.size(), cflags, &cl) != SRW_OK)
     throw std::runtime_error(std::string("srw_cluster_create: ") + srw_last_error(nullptr));
   struct Guard { srw_cluster *c; ~Guard() { srw_cluster_destroy(c); } } guard{cl};
   auto ckc = [&](int32_t rc, const char *what) {

@@ -1832,6 +1832,9 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
   const int32_t world = h->cfg.world;
   const bool first_order = P.p == 1.0f && P.q == 1.0f && !(P.flags & SRW_WALK_FORCE_GENERAL);
   const bool linked = shard_fo_linked(h, P);
+  if (world > 1 && P.q != 1.0f && !g.mrows.p)
+    throw Error(SRW_ERR_INVALID, "this shard was loaded with SRW_CFG_NO_MEMBERSHIP: it can only run walks with q == 1 "
+                                 "(q != 1 needs the neighbor sets of vertices the shard does not own)");
   if (first_order) build_first_order_tables(h, true);
   else {
     build_membership(h);

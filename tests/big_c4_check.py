@@ -28,7 +28,7 @@ print("replicated walk L=80: %.2f G steps/s (kernel %.1f ms)" % (st80["n_steps"]
 eng.close(); del eng
 t = time.time()
 ok = True
-with pkg.Cluster([0] * world) as cl:
+with pkg.Cluster([0] * world, membership=False) as cl:      # config 4 is p = q = 1: SRW_CFG_NO_MEMBERSHIP
     cl.generate_rmat(scale, n_edges, seed=42)
     assert cl.stats() == (nv, ne), (cl.stats(), nv, ne)
     print("cluster of %d virtual shards: graph %.1f s" % (world, time.time() - t), flush=True)
@@ -38,9 +38,12 @@ with pkg.Cluster([0] * world) as cl:
     print("sharded walk L=%d, world %d: %s (%d walkers, %d steps; super-steps %.1f ms; overflow retries %s)"
           % (L, world, "IDENTICAL" if same else "MISMATCH", len(clens), cst["n_steps"], cst["kernel_ms"], cst.get("overflow_retries")), flush=True)
     del cp, clens, paths, lens
-    c80 = cl.walk(fetch=False, walk_length=80, seed=2026, num_walks=2, batch=2)
-    c80 = cl.walk(fetch=False, walk_length=80, seed=2026, num_walks=2, first_walk=2, batch=2)
-    print("sharded walk L=80, 2 iterations as one population: %.2f G steps/s on ONE device (the %d shards' kernels run one after the other)"
-          % (c80["n_steps"] / c80["kernel_ms"] / 1e6, world), flush=True)
+    try:
+        c80 = cl.walk(fetch=False, walk_length=80, seed=2026, num_walks=2, batch=2)
+        c80 = cl.walk(fetch=False, walk_length=80, seed=2026, num_walks=2, first_walk=2, batch=2)
+        print("sharded walk L=80, 2 iterations as one population: %.2f G steps/s on ONE device (the %d shards' kernels run one after the other)"
+              % (c80["n_steps"] / c80["kernel_ms"] / 1e6, world), flush=True)
+    except pkg.SrwError as ex:      # all the shards' tables, buffers and two iterations of paths on ONE device: timing only
+        print("sharded walk L=80 (timing only) skipped: %s" % str(ex)[:120], flush=True)
 print("config 4 shape (RMAT-%d, world %d):" % (scale, world), "parity OK" if ok else "PARITY FAILED")
 sys.exit(0 if ok else 1)

@@ -416,6 +416,27 @@ def test_cluster_inprocess_shards(oracle, world, p, q, directed):
             assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs
 
 
+def test_cluster_without_replicated_membership(oracle):
+    """SRW_CFG_NO_MEMBERSHIP: shards that skip the replicated neighbor-id structure (memory per shard ~ 1 / world) run every
+    q == 1 walk — p = q = 1 through the linked records, p != 1 through the general step — and refuse q != 1."""
+    P = pkg()
+    s, d, w = rmat_lines(oracle, 10, edge_factor=8, weighted=True)
+    g = oracle.Graph.from_coo(s, d, w)
+    with P.Cluster([0, 0, 0], membership=False) as cl:
+        cl.load_coo(s, d, w)
+        assert cl.stats() == (g.num_vertices, g.num_entries)
+        for p in (1.0, 0.5, 4.0):
+            rp, rl, rs = g.walk(p=p, q=1.0, walk_length=12, num_walks=2, seed=8, threads=8)
+            paths, lens, st = cl.walk(p=p, q=1.0, walk_length=12, num_walks=2, seed=8)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs, p
+        with pytest.raises(P.SrwError) as ei:
+            cl.walk(p=1.0, q=4.0, walk_length=4)
+        assert ei.value.code == P.ERR_INVALID and "SRW_CFG_NO_MEMBERSHIP" in str(ei.value)
+        rp, rl, rs = g.walk(walk_length=5, seed=1, threads=8)            # the cluster stays usable after the refusal
+        paths, lens, st = cl.walk(walk_length=5, seed=1)
+        assert np.array_equal(lens, rl) and np.array_equal(paths, rp)
+
+
 def test_cluster_walk_and_save_and_hub(oracle, tmp_path):
     """A hub every walker runs into (chunk skew: the overflow retry must kick in or the slack must hold) + the
     cluster's RandomWalk.save."""

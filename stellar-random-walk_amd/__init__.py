@@ -209,10 +209,10 @@ def save_paths(paths, lens, output_dir, n_parts=1, write_crc=False):
 class Engine:
     """One handle = one GPU.  Mirrors the life of the reference's SparkContext + GraphMap + RandomWalk object."""
 
-    def __init__(self, device=0, rank=0, world=1, owner_from_partitions=False, compact_ids=False):
+    def __init__(self, device=0, rank=0, world=1, owner_from_partitions=False, compact_ids=False, membership=True):
         self.h = C.c_void_p()
         cfg = Config(device, rank, world, (CFG_OWNER_FROM_PARTITIONS if owner_from_partitions else 0) |
-                     (CFG_COMPACT_IDS if compact_ids else 0))
+                     (CFG_COMPACT_IDS if compact_ids else 0) | (0 if membership else CFG_NO_MEMBERSHIP))
         rc = lib().srw_create(C.byref(cfg), C.byref(self.h))
         if rc != OK:
             self.h = None

@@ -37,11 +37,12 @@ from . import Engine, ShardLayout, WalkStats, lib
 class HipShardEngine:
     """Thin adapter: srw_shard_* on torch CUDA tensors (device pointers), kernels on torch's current stream."""
 
-    def __init__(self, device, rank, world, owner_from_partitions=False):
+    def __init__(self, device, rank, world, owner_from_partitions=False, membership=True):
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         torch.zeros(1, device=self.device)       # torch's device context first (it ships its own HIP runtime)
-        self.engine = Engine(device=device, rank=rank, world=world, owner_from_partitions=owner_from_partitions)
+        self.engine = Engine(device=device, rank=rank, world=world, owner_from_partitions=owner_from_partitions,
+                             membership=membership)     # False: SRW_CFG_NO_MEMBERSHIP (q == 1 walks only)
         self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.world = world
 
@@ -129,12 +130,13 @@ class _DeviceBuffer:
 
 
 class ShardedWalker:
-    def __init__(self, device=0, rank=None, world=None, step_engine=None, group=None, owner_from_partitions=False):
+    def __init__(self, device=0, rank=None, world=None, step_engine=None, group=None, owner_from_partitions=False,
+                 membership=True):
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.se = step_engine if step_engine is not None else HipShardEngine(device, self.rank, self.world,
-                                                                            owner_from_partitions)
+                                                                            owner_from_partitions, membership)
         self.engine = getattr(self.se, "engine", None)
         self.device = self.se.device
         self._bufs = {}
@@ -255,7 +257,7 @@ class ShardedWalker:
 
 def bench_vertex_sharded(dist_mod, local_rank, rank, world, scale, n_edges, weighted, directed, walk_kw, K, W, barrier_sync):
     """bench.py's vertex-sharded leg: K walk iterations (strong scaling: every rank works on every iteration)."""
-    drv = ShardedWalker(device=local_rank, rank=rank, world=world)
+    drv = ShardedWalker(device=local_rank, rank=rank, world=world, membership=(walk_kw.get("q", 1.0) != 1.0))
     t0 = time.perf_counter()
     drv.generate_rmat(scale, n_edges, seed=42, weighted=weighted, directed=directed)
     nv, ne = drv.engine.stats()

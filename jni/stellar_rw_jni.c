@@ -143,7 +143,9 @@ JNIEXPORT jlongArray JNICALL FN(walkAndSaveSharded)(JNIEnv *env, jobject self, j
     (*env)->ReleasePrimitiveArrayCritical(env, devices, d, 0);
   }
   srw_cluster *c = NULL;
-  int32_t rc = srw_cluster_create((const int32_t *)devs, n, partitioned ? SRW_CFG_OWNER_FROM_PARTITIONS : 0, &c);
+  /* q == 1: no shard ever tests "x in N(prev)" — the replicated neighbor-id structure is skipped (memory per shard ~ 1 / n) */
+  int32_t rc = srw_cluster_create((const int32_t *)devs, n, (partitioned ? SRW_CFG_OWNER_FROM_PARTITIONS : 0) |
+                                                              (q == 1.0f ? SRW_CFG_NO_MEMBERSHIP : 0), &c);
   if (rc != SRW_OK) { throw_status(env, rc, NULL); return NULL; }
   jlongArray a = NULL;
   const char *in = (*env)->GetStringUTFChars(env, input, NULL);

@@ -488,6 +488,7 @@ void build_first_order_tables(srw_handle *h, bool want_exact) {
     SlimStore slim{c.p, gd.p};
     run_cdf_and_guide(h, slim, items, n_items);
     g.cfo.alloc((size_t)g.n_entries);
+    if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] compact first-order table: %zu bytes at %p\n", (size_t)g.n_entries * sizeof(CfoEnt), (void *)g.cfo.p);
     if (run_cfo(h, slim, n_items.p + 1) == 0) { g.has_cfo = true; return; }
     // some entry needs an escape (large guide delta on weighted hubs, giant degree): exact records instead
     g.cfo.release(); g.cfo_rejected = true;

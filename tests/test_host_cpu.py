@@ -286,3 +286,16 @@ def test_jni_shim_syntax():
     header = open(os.path.join(ROOT, "include", "stellar_rw.h")).read()
     for fn in set(re.findall(r"\b(srw_\w+)\(", shim)):
         assert re.search(r"\b%s\(" % fn, header), fn
+
+
+def test_scala_spec_digests_match_the_python_goldens():
+    """jni/HipRandomWalkSpec.scala (the ScalaTest counterpart for a machine with a JDK and a GPU) carries the same
+    (directed, walkLength, r, p, q, steps, digest) cases as the DERIVED table the oracle and the HIP path are tested with."""
+    import re
+    import test_oracle_reference_vectors as ref
+    src = open(os.path.join(ROOT, "jni", "HipRandomWalkSpec.scala")).read()
+    rows = re.findall(r"\((true|false), (\d+), ([0-9.]+)f, ([0-9.]+), ([0-9.]+), (\d+)L, \"([0-9a-f]{16})\"", src)
+    got = sorted((d == "true", int(L), float(r), float(p), float(q), int(steps), dig) for d, L, r, p, q, steps, dig in rows)
+    want = sorted((d, L, r, p, q, steps, dig) for d, L, r, p, q, _, steps, dig in ref.DERIVED)
+    assert got == want and len(got) == 7
+    assert src.count("{") == src.count("}") and src.count("(") == src.count(")")

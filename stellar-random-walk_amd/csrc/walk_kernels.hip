@@ -1463,13 +1463,52 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   else if (general) h->g.has_pq = false;
   // ... the edge hash set answers "x in N(prev)?" in one probe: Mode A's rejection test, and the general kernel's
   // candidate-by-candidate membership (small rows, the located chunk of the binned search)
-  const bool want_ehash = P.q != 1.0f && !(P.flags & SRW_WALK_NO_EDGE_HASH) && (alias || (general && h->cfg.world == 1));
-  if (want_ehash) build_edge_hash(h);
-  h->g.use_ehash = want_ehash;
+  bool want_ehash = P.q != 1.0f && !(P.flags & SRW_WALK_NO_EDGE_HASH) && (alias || (general && h->cfg.world == 1));
   // neighbor-set bitmaps of the hub rows: the general kernel's "x in N(prev)" for steps that come from a hub
   const bool want_hub = general && P.q != 1.0f && h->cfg.world == 1 && !(P.flags & SRW_WALK_NO_HUB_BITMAPS);
   const bool want_eb = general && P.q != 1.0f && h->cfg.world == 1 && h->g.has_pq && !(P.flags & SRW_WALK_NO_EDGE_TABLES) &&
                        !(P.flags & SRW_WALK_NO_BINNED);
+  const int eb_mode = (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0;
+  const char *env_hub = getenv("SRW_HUB_BUDGET_GB"), *env_cap = getenv("SRW_EB_CHUNKS");
+  // The edge hash (8 B x 2-3 per entry) against table resolution: when a COMPLETE 64-chunk set of per-edge tables fits only
+  // without the hash, the hash goes — the located chunks' probes of a long non-hub N(prev) fall back to the sorted row, and
+  // every step still gains from chunks half as long (config 5's stand-in: 34 GB of hash; 32 chunks + hash 1.67e8 steps/s,
+  // 32 chunks without 1.56e8, 64 chunks without 2.0e8 — s68, s69).
+  bool drop_ehash = false;
+  if (want_eb && want_ehash && !(env_cap && *env_cap)) {
+    Graph &g = h->g;
+    uint32_t pb, qb; memcpy(&pb, &P.p, 4); memcpy(&qb, &P.q, 4);
+    if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode && (!want_hub || g.has_hub)) {
+      drop_ehash = g.eb_no_ehash;                                  // standing tables: as they were built
+    } else {
+      uint64_t slots = 1024;
+      while (slots < (uint64_t)g.n_entries + (uint64_t)g.n_entries / 2) slots <<= 1;      // build_edge_hash's sizing
+      const size_t eh_bytes = (size_t)slots * 8;
+      size_t free_b = 0, total_b = 0;
+      SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+      free_b += g.hub_bm.n * sizeof(uint32_t) + g.eb_bins.n * sizeof(double) + g.em_bits.n * sizeof(uint32_t) + g.eb_off.n * sizeof(uint32_t);
+      if (g.has_ehash) free_b += g.ehash.n * sizeof(uint64_t);     // free_b: with neither hash nor tables nor bitmaps
+      size_t reserve = (size_t)24 << 30;
+      if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
+      const size_t n64 = edge_tables_full_bytes(h, eb_mode, EB_BINS);
+      // what build_edge_tables will have: free - bitmaps (16 GB when the tables are tight) - reserve; 2 GB of margin
+      const size_t slack = reserve + (want_hub ? (size_t)16 << 30 : 0) + ((size_t)2 << 30);
+      const bool with_hash = n64 > 0 && n64 < ((size_t)160 << 30) && free_b > eh_bytes && free_b - eh_bytes > n64 + slack;
+      const bool without = n64 > 0 && n64 < ((size_t)200 << 30) && free_b > n64 + slack;
+      drop_ehash = !with_hash && without;
+      if (getenv("SRW_TIMING"))
+        fprintf(stderr, "[timing] edge hash vs table resolution: %.1f GB free, hash %.1f GB, complete 64-chunk set %.1f GB, slack %.1f GB -> %s\n",
+                (double)free_b / 1e9, (double)eh_bytes / 1e9, (double)n64 / 1e9, (double)slack / 1e9,
+                with_hash ? "both fit" : without ? "the hash goes" : "neither: coarser tables");
+    }
+  }
+  if (want_eb && want_ehash && getenv("SRW_EB_DROP_EHASH")) drop_ehash = true;      // tests: the traded configuration on any graph
+  if (drop_ehash) {
+    want_ehash = false;
+    if (h->g.has_ehash) { h->g.ehash.release(); h->g.has_ehash = false; }
+  }
+  if (want_ehash) build_edge_hash(h);
+  h->g.use_ehash = want_ehash;
   // With per-edge tables the bitmaps serve the tables' own construction and the membership probes of a located chunk
   // whose N(prev) is too long for LDS — one probe into a bitmap that the hub's many walkers keep in L2, against one
   // HBM request into the edge hash (config 3: 16 / 40 / 80 GB of bitmaps -> 223 / 258 / 272 M steps/s, s44).  The tables
@@ -1479,9 +1518,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   // the hub pairs only (config 3: 41.8 / 59.7 / 77.0 / 111.9 GB at 64 / 128 / 256 / 512 chunks -> 376 / 448 / 497 / 513 M steps/s,
   // s45 / s47): the finest of 256 / 128 / 64 whose COMPLETE set fits next to 32 GB of bitmaps is taken.
   size_t hub_cap = want_eb ? (size_t)16 << 30 : (size_t)64 << 30;
-  const int eb_mode = (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0;
   int eb_cap = EB_BINS;
-  const char *env_hub = getenv("SRW_HUB_BUDGET_GB"), *env_cap = getenv("SRW_EB_CHUNKS");
   if (env_hub && *env_hub) hub_cap = (size_t)(atof(env_hub) * (double)((size_t)1 << 30));
   if (env_cap && *env_cap) eb_cap = atoi(env_cap);
   if (want_eb) {
@@ -1496,7 +1533,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
       free_b += g.hub_bm.n * sizeof(uint32_t) + g.eb_bins.n * sizeof(double) + g.em_bits.n * sizeof(uint32_t) + g.eb_off.n * sizeof(uint32_t);
       size_t reserve = (size_t)24 << 30;
       if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
-      const size_t table_cap = (size_t)160 << 30;                  // build_edge_tables' own ceiling (SRW_EB_BUDGET_GB)
+      const size_t table_cap = (size_t)(drop_ehash ? 200 : 160) << 30;   // build_edge_tables' own ceiling (Graph::eb_budget_gb)
       size_t need = 0;
       if (!(env_cap && *env_cap)) {
         for (int c : {256, 128}) {
@@ -1523,7 +1560,11 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   h->g.use_hub = want_hub;
   // ... and, last (they take what HBM is left), the per-edge bias tables: the most expensive (prev, curr) pairs get
   // their N(prev) ∩ N(curr) corrections precomputed once per (p, q) instead of once per visit
-  if (want_eb) build_edge_tables(h, P.p, P.q, eb_mode, eb_cap);
+  if (want_eb) {
+    h->g.eb_budget_gb = drop_ehash ? 200 : 160;
+    build_edge_tables(h, P.p, P.q, eb_mode, eb_cap);
+    h->g.eb_no_ehash = drop_ehash;
+  }
   h->g.use_eb = want_eb;
 }
 double timed_prepare_tables(srw_handle *h, const srw_walk_params &P) {   // builders synchronise the stream themselves

@@ -347,6 +347,8 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);
   if (bins_cap < 8) bins_cap = 8;
   if (bins_cap > BIN_CAP) bins_cap = BIN_CAP;
+  if (const char *e = getenv("SRW_EB_FAIL_ABOVE"); e && *e && bins_cap > atoi(e))      // tests: prepare_tables' fallback
+    throw Error(SRW_ERR_NOMEM, "simulated allocation failure of the per-edge tables (SRW_EB_FAIL_ABOVE)");
   { const char *e = getenv("SRW_EB_NO_F32"); const int want_f32 = (e && *e == '1') ? 0 : 1;
     if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.eb_f32 == want_f32 && g.eb_cap == bins_cap) return; }
   hipStream_t st = h->stream;

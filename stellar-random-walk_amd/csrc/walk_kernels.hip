@@ -1562,7 +1562,20 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   // their N(prev) ∩ N(curr) corrections precomputed once per (p, q) instead of once per visit
   if (want_eb) {
     h->g.eb_budget_gb = drop_ehash ? 200 : 160;
-    build_edge_tables(h, P.p, P.q, eb_mode, eb_cap);
+    // The sizing above works from hipMemGetInfo; if an allocation of the build fails all the same (fragmentation), the
+    // walk goes on with a coarser set, or with none (the on-the-fly samplers) — an optional accelerator never fails a walk.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      try { build_edge_tables(h, P.p, P.q, eb_mode, attempt == 0 ? eb_cap : 32); break; }
+      catch (const Error &e) {
+        if (e.code != SRW_ERR_NOMEM) throw;
+        (void)hipGetLastError();
+        Graph &g = h->g;
+        g.eb_bins.release(); g.em_bits.release(); g.has_eb = false; g.eb_complete = false; g.eb_tables = 0; g.eb_bytes = 0;
+        h->g.eb_budget_gb = 160;
+        if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] per-edge tables: %s — %s\n", e.what(), attempt == 0 && eb_cap > 32 ? "retrying with 32 chunks" : "walking without them");
+        if (eb_cap <= 32) break;
+      }
+    }
     h->g.eb_no_ehash = drop_ehash;
   }
   h->g.use_eb = want_eb;

@@ -111,3 +111,23 @@ def test_sharded_linked_first_order_equals_replicated_at_scale(eng, world, weigh
             cp, clens, cst = cl.walk(walk_length=40, num_walks=2, first_walk=3, seed=99, batch=batch)
             assert np.array_equal(clens, lens) and np.array_equal(cp, paths), (world, batch)
             assert cst["n_steps"] == st["n_steps"]
+
+
+@pytest.mark.parametrize("fail_above,expect_tables", [("32", True), ("0", False)])
+def test_table_build_failure_degrades_instead_of_failing(oracle, monkeypatch, fail_above, expect_tables):
+    """An allocation of the per-edge table build that fails (simulated: SRW_EB_FAIL_ABOVE) must not fail the walk:
+    prepare_tables retries with 32 chunks, then walks without tables — same paths either way."""
+    monkeypatch.setenv("SRW_EB_FAIL_ABOVE", fail_above)
+    scale, L = 16, 24
+    with pkg().Engine(device=0) as e:
+        e.generate_rmat(scale, 16 << scale, seed=11, weighted=True)
+        s, d = oracle.rmat_edges(scale, 16 << scale, seed=11)
+        from helpers import rmat_weights_np
+        g = oracle.Graph.from_coo(s, d, rmat_weights_np(s, d, 11))
+        verts = e.vertices()
+        src = np.unique(np.random.default_rng(1).choice(verts, 600, replace=False)).astype(np.int32)
+        idx = np.searchsorted(verts, src)
+        paths, lens, st = e.walk(p=0.25, q=4.0, walk_length=L, seed=77)
+        rp, rl, _ = g.walk(sources=src, p=0.25, q=4.0, walk_length=L, seed=77, threads=16)
+        assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl)
+        assert (st["edge_tables"] > 0) == expect_tables, st["edge_tables"]

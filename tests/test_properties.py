@@ -50,7 +50,7 @@ def walk_args(draw):
     return kw
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(g=multigraphs(), kw=walk_args())
 def test_oracle_variants_agree(oracle, g, kw):
     s, d, w, directed = g
@@ -76,7 +76,7 @@ def test_oracle_variants_agree(oracle, g, kw):
     assert fast[2] == int((fast[1] - 1).sum())
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(g=multigraphs(), kw=walk_args(), n_parts=st.integers(1, 4))
 def test_writer_text_round_trip_through_the_c_abi(oracle, tmp_path_factory, g, kw, n_parts):
     """paths -> srw_save_paths (part files) -> text -> the same lines the oracle's writer prints; the edge list written as
@@ -106,7 +106,7 @@ def eng():
 
 
 @pytest.mark.gpu
-@settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(g=multigraphs(max_vertices=40, max_lines=400), kw=walk_args(), general=st.booleans())
 def test_gpu_equals_oracle(oracle, eng, g, kw, general):
     s, d, w, directed = g
@@ -121,7 +121,7 @@ def test_gpu_equals_oracle(oracle, eng, g, kw, general):
 
 
 @pytest.mark.gpu
-@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(g=multigraphs(max_vertices=40, max_lines=400), kw=walk_args())
 def test_gpu_mode_a_equals_oracle_mode_a(oracle, eng, g, kw):
     if kw.get("rng") == "const":

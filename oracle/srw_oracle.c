@@ -215,15 +215,41 @@ int orc_graphmap_get_partition(const orc_graphmap *g, int32_t v, int32_t *pid) {
 
 static int java_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == 0x0B || c == '\f' || c == '\r'; }
 
+/* Character.digit(ch, 10) of the UTF-16 char encoded as UTF-8 at s[*i ..): Integer.parseInt takes any decimal digit of the
+ * Basic Multilingual Plane, char by char (a surrogate pair is never a digit); malformed UTF-8 is U+FFFD after Hadoop's
+ * Text.toString, i.e. not a digit.  Zero code points of the BMP's Nd blocks (Unicode 6.2 = Java 8, + U+0DE6, U+A9F0). */
+static const uint16_t ND_ZERO[] = {
+    0x0660, 0x06F0, 0x07C0, 0x0966, 0x09E6, 0x0A66, 0x0AE6, 0x0B66, 0x0BE6, 0x0C66, 0x0CE6, 0x0D66, 0x0DE6, 0x0E50, 0x0ED0, 0x0F20,
+    0x1040, 0x1090, 0x17E0, 0x1810, 0x1946, 0x19D0, 0x1A80, 0x1A90, 0x1B50, 0x1BB0, 0x1C40, 0x1C50, 0xA620, 0xA8D0, 0xA900, 0xA9D0,
+    0xA9F0, 0xAA50, 0xABF0, 0xFF10};
+static int java_digit(const char *s, size_t n, size_t *i) {
+  unsigned char c = (unsigned char)s[*i];
+  if (c < 0x80) { ++*i; return (c >= '0' && c <= '9') ? c - '0' : -1; }
+  uint32_t cp;
+  if ((c & 0xE0) == 0xC0 && *i + 1 < n && ((unsigned char)s[*i + 1] & 0xC0) == 0x80) {
+    cp = ((uint32_t)(c & 0x1F) << 6) | ((unsigned char)s[*i + 1] & 0x3F);
+    if (cp < 0x80) return -1;
+    *i += 2;
+  } else if ((c & 0xF0) == 0xE0 && *i + 2 < n && ((unsigned char)s[*i + 1] & 0xC0) == 0x80 && ((unsigned char)s[*i + 2] & 0xC0) == 0x80) {
+    cp = ((uint32_t)(c & 0x0F) << 12) | (((uint32_t)(unsigned char)s[*i + 1] & 0x3F) << 6) | ((unsigned char)s[*i + 2] & 0x3F);
+    if (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF)) return -1;
+    *i += 3;
+  } else return -1;
+  for (size_t k = 0; k < sizeof(ND_ZERO) / sizeof(ND_ZERO[0]); ++k)
+    if (cp >= ND_ZERO[k] && cp <= (uint32_t)ND_ZERO[k] + 9) return (int)(cp - ND_ZERO[k]);
+  return -1;
+}
+
 /* java.lang.Integer.parseInt on [s, s+n): 1 ok, 0 NumberFormatException */
 static int java_parse_int(const char *s, size_t n, int32_t *out) {
   if (n == 0) return 0;
   size_t i = 0; int neg = 0;
   if (s[0] == '-' || s[0] == '+') { neg = (s[0] == '-'); i = 1; if (n == 1) return 0; }
   int64_t v = 0;
-  for (; i < n; ++i) {
-    if (s[i] < '0' || s[i] > '9') return 0;
-    v = v * 10 + (s[i] - '0');
+  while (i < n) {
+    int d = java_digit(s, n, &i);
+    if (d < 0) return 0;
+    v = v * 10 + d;
     if (v > 2147483648LL) return 0;
   }
   if (neg) v = -v;

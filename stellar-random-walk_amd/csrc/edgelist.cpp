@@ -28,6 +28,31 @@ namespace {
 
 inline bool java_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == 0x0B || c == '\f' || c == '\r'; }
 
+// Integer.parseInt reads its digits with Character.digit(s.charAt(i), 10): any decimal digit of the Basic Multilingual
+// Plane counts ("١٢" and "１２" are 12), one UTF-16 char at a time — so a digit beyond the BMP (a surrogate pair) does not.
+// The line arrives as UTF-8 (Hadoop Text); a malformed or overlong sequence decodes to U+FFFD there: not a digit.
+// Zero code points of the BMP's Nd blocks (Unicode 6.2 = Java 8, plus U+0DE6 and U+A9F0 of later JDKs).
+constexpr uint16_t ND_ZERO[] = {
+    0x0660, 0x06F0, 0x07C0, 0x0966, 0x09E6, 0x0A66, 0x0AE6, 0x0B66, 0x0BE6, 0x0C66, 0x0CE6, 0x0D66, 0x0DE6, 0x0E50, 0x0ED0, 0x0F20,
+    0x1040, 0x1090, 0x17E0, 0x1810, 0x1946, 0x19D0, 0x1A80, 0x1A90, 0x1B50, 0x1BB0, 0x1C40, 0x1C50, 0xA620, 0xA8D0, 0xA900, 0xA9D0,
+    0xA9F0, 0xAA50, 0xABF0, 0xFF10};
+inline int java_digit(const char *s, size_t n, size_t &i) {   // digit value or -1; i moves past the character
+  const unsigned char c = (unsigned char)s[i];
+  if (c < 0x80) { ++i; return (c >= '0' && c <= '9') ? (int)(c - '0') : -1; }
+  uint32_t cp;
+  if ((c & 0xE0) == 0xC0 && i + 1 < n && ((unsigned char)s[i + 1] & 0xC0) == 0x80) {
+    cp = ((uint32_t)(c & 0x1F) << 6) | ((unsigned char)s[i + 1] & 0x3F);
+    if (cp < 0x80) return -1;
+    i += 2;
+  } else if ((c & 0xF0) == 0xE0 && i + 2 < n && ((unsigned char)s[i + 1] & 0xC0) == 0x80 && ((unsigned char)s[i + 2] & 0xC0) == 0x80) {
+    cp = ((uint32_t)(c & 0x0F) << 12) | (((uint32_t)(unsigned char)s[i + 1] & 0x3F) << 6) | ((unsigned char)s[i + 2] & 0x3F);
+    if (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF)) return -1;
+    i += 3;
+  } else return -1;
+  for (uint16_t z : ND_ZERO) if (cp >= z && cp <= (uint32_t)z + 9) return (int)(cp - z);
+  return -1;
+}
+
 bool parse_int_token(const char *s, size_t n, int32_t &out) {
   if (n == 0) return false;
   size_t i = 0;
@@ -38,9 +63,9 @@ bool parse_int_token(const char *s, size_t n, int32_t &out) {
     if (n == 1) return false;
   }
   int64_t v = 0;
-  for (; i < n; ++i) {
-    unsigned d = (unsigned)(s[i] - '0');
-    if (d > 9u) return false;
+  while (i < n) {
+    const int d = java_digit(s, n, i);
+    if (d < 0) return false;
     v = v * 10 + d;
     if (v > 2147483648LL) return false;
   }

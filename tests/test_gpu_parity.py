@@ -924,6 +924,20 @@ def test_q1_per_lane_kernel(eng, oracle, case):
         assert np.array_equal(pc, refc[0]) and np.array_equal(lc, refc[1])
 
 
+def test_non_ascii_digits_reach_the_host_tokenizer(eng, oracle, tmp_path):
+    """A file with Unicode decimal digits (which Integer.parseInt accepts) is not for the device tokenizer: it must hand the
+    file over to the host tokenizer, and the graph must be the oracle's."""
+    f = tmp_path / "u.txt"
+    f.write_bytes("1 2\n２ ٣\n3 1\n٣ ४\n".encode("utf-8"))
+    eng.load_edgelist(str(f), weighted=False)
+    g = oracle.Graph.load(str(f), weighted=False)
+    assert eng.stats() == (g.num_vertices, g.num_entries) == (4, 8)
+    assert eng.vertices().tolist() == [1, 2, 3, 4]
+    paths, lens, _ = eng.walk(walk_length=6, seed=5, p=0.5, q=2.0)
+    rp, rl, _ = g.walk(walk_length=6, seed=5, p=0.5, q=2.0)
+    assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
+
+
 def test_wide_id_range_is_compacted(eng, oracle):
     """The reference's GraphMap is a HashMap: any int32 ids load.  A sparse id space is compacted at load (slot = rank
     among the sorted distinct ids) — the whole int32 range included, with and without partition ids — and

@@ -299,3 +299,30 @@ def test_scala_spec_digests_match_the_python_goldens():
     want = sorted((d, L, r, p, q, steps, dig) for d, L, r, p, q, _, steps, dig in ref.DERIVED)
     assert got == want and len(got) == 7
     assert src.count("{") == src.count("}") and src.count("(") == src.count(")")
+
+
+def test_tokenizer_unicode_digits_like_integer_parseint(oracle, tmp_path):
+    """Integer.parseInt reads digits with Character.digit(s.charAt(i), 10): any BMP decimal digit counts (Arabic-Indic,
+    Devanagari, fullwidth ...), a digit beyond the BMP (a surrogate pair in UTF-16) does not, nor does malformed UTF-8
+    (U+FFFD after Text.toString).  Float.parseFloat takes ASCII only: such a weight falls back to 1.0f as any unparsable one."""
+    P = pkg()
+    ok = [("１２ ٣ 1\n", (12, 3, 1.0)), ("1２ -९ 2\n", (12, -9, 2.0)), ("+٣ ४ 0.5\n", (3, 4, 0.5)),
+          ("٢١٤٧٤٨٣٦٤٧ -٢١٤٧٤٨٣٦٤٨ 1\n", (2147483647, -2147483648, 1.0)), ("1 2 ٣\n", (1, 2, 1.0))]
+    for text, (a, b, w) in ok:
+        f = tmp_path / "u.txt"
+        f.write_bytes(text.encode("utf-8"))
+        s, d, ww, _ = P.parse_edgelist(str(f), weighted=True)
+        assert (s.tolist(), d.tolist(), ww.tolist()) == ([a], [b], [w]), text
+        g = oracle.Graph.load(str(f), weighted=True)
+        os_, od, ow, _ = g.lines()
+        assert (os_.tolist(), od.tolist(), ow.tolist()) == ([a], [b], [w]), text
+    bad = ["𝟏 2 1\n".encode("utf-8"), b"1\xc0\xb1 2 1\n", b"1\xe0\x80\xb1 2 1\n", "٢١٤٧٤٨٣٦٤٨ 1 1\n".encode("utf-8"), "−1 2 1\n".encode("utf-8"),
+           b"1\xd9 2 1\n"]
+    for raw in bad:
+        f = tmp_path / "b.txt"
+        f.write_bytes(raw)
+        with pytest.raises(P.SrwError) as ei:
+            P.parse_edgelist(str(f), weighted=True)
+        assert ei.value.code == P.ERR_PARSE, raw
+        with pytest.raises(Exception):
+            oracle.Graph.load(str(f), weighted=True)

@@ -445,6 +445,8 @@ orc_graph *orc_graph_load_edgelist(const char *path, int directed, int weighted,
   line_vec lv; memset(&lv, 0, sizeof(lv));
   /* Hadoop LineRecordReader: a line ends at \n, \r\n or a lone \r; a final unterminated line counts. */
   size_t pos = 0; int64_t lineno = 0;
+  /* LineRecordReader.skipUtfByteOrderMark (Hadoop 2.6+, MAPREDUCE-5777): a UTF-8 BOM at the start of the file is not part of line 1 */
+  if (sz >= 3 && (unsigned char)buf[0] == 0xEF && (unsigned char)buf[1] == 0xBB && (unsigned char)buf[2] == 0xBF) pos = 3;
   while (pos < (size_t)sz) {
     size_t b = pos;
     while (pos < (size_t)sz && buf[pos] != '\n' && buf[pos] != '\r') ++pos;

@@ -10,6 +10,7 @@
 //   * weight = Float.parseFloat of the LAST column iff weighted && parts.length > 2 (> 3 when partitioned),
 //     Try(...).getOrElse(1.0f); pId = parts(2).toInt iff partitioned && parts.length > 2.
 // The file is split into byte ranges parsed by one std::thread each and concatenated in file order.
+#include <dirent.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -188,7 +189,8 @@ void parse_range(const char *data, size_t size, size_t b, size_t e, bool weighte
 
 }  // namespace
 
-void parse_edgelist_file(const char *path, bool weighted, bool partitioned, ParsedLines &out) {
+namespace {
+void parse_one_file(const char *path, bool weighted, bool partitioned, ParsedLines &out) {
   int fd = open(path, O_RDONLY);
   if (fd < 0) throw Error(SRW_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
   struct stat sb;
@@ -204,11 +206,14 @@ void parse_edgelist_file(const char *path, bool weighted, bool partitioned, Pars
   // split points: each range starts at a record start
   std::vector<size_t> cut(nthreads + 1, size);
   cut[0] = 0;
+  // Hadoop's LineRecordReader skips a UTF-8 byte order mark at the start of a file (skipUtfByteOrderMark, MAPREDUCE-5777,
+  // in the Hadoop 2.6+ that Spark 2.2 ships with): the first line of such a file parses in the reference
+  if (size >= 3 && (unsigned char)data[0] == 0xEF && (unsigned char)data[1] == 0xBB && (unsigned char)data[2] == 0xBF) cut[0] = 3;
   for (size_t t = 1; t < nthreads; ++t) {
     size_t p = size / nthreads * t;
     while (p < size && data[p - 1] != '\n' && data[p - 1] != '\r') ++p;
     if (p < size && data[p] == '\n' && data[p - 1] == '\r') ++p;
-    cut[t] = std::max(p, cut[t - 1]);
+    cut[t] = std::max(p, cut[t - 1]);      // (cut[0] may be 3: never before the byte order mark)
   }
   std::vector<Chunk> chunks(nthreads);
   std::vector<std::thread> th;
@@ -240,6 +245,46 @@ void parse_edgelist_file(const char *path, bool weighted, bool partitioned, Pars
       memcpy(out.pid.data() + at[t], c.pid.data(), k * 4);
     });
   for (auto &x : th) x.join();
+}
+}  // namespace
+
+// `--input` may name a directory, as with sc.textFile (FileInputFormat): every file in it whose name does not start with
+// '_' or '.' (hiddenFileFilter: _SUCCESS, .crc files) is read, here in byte order of the names (what HDFS lists; the
+// adjacency order — and with it the walk — follows the line order, so it is fixed like this), each with its own byte
+// order mark rule and its own last unterminated line.  A subdirectory is "Not a file", as in the old mapred API.
+void parse_edgelist_file(const char *path, bool weighted, bool partitioned, ParsedLines &out) {
+  struct stat sb;
+  if (stat(path, &sb) != 0 || !S_ISDIR(sb.st_mode)) { parse_one_file(path, weighted, partitioned, out); return; }
+  std::vector<std::string> names;
+  DIR *dir = opendir(path);
+  if (!dir) throw Error(SRW_ERR_IO, std::string("cannot open directory ") + path + ": " + strerror(errno));
+  while (struct dirent *de = readdir(dir)) {
+    const std::string n = de->d_name;
+    if (n.empty() || n[0] == '_' || n[0] == '.') continue;
+    names.push_back(n);
+  }
+  closedir(dir);
+  std::sort(names.begin(), names.end());
+  std::vector<ParsedLines> parts(names.size());
+  size_t total = 0;
+  for (size_t i = 0; i < names.size(); ++i) {
+    const std::string f = std::string(path) + "/" + names[i];
+    struct stat fs;
+    if (stat(f.c_str(), &fs) != 0 || !S_ISREG(fs.st_mode)) throw Error(SRW_ERR_IO, "Not a file: " + f);
+    try { parse_one_file(f.c_str(), weighted, partitioned, parts[i]); }
+    catch (const Error &e) { throw Error(e.code, names[i] + ": " + e.what()); }
+    total += parts[i].src.size();
+  }
+  out = ParsedLines();
+  out.src.resize_uninit(total); out.dst.resize_uninit(total); out.w.resize_uninit(total); out.pid.resize_uninit(total);
+  size_t at = 0;
+  for (auto &pt : parts) {
+    const size_t k = pt.src.size();
+    if (!k) continue;
+    memcpy(out.src.data() + at, pt.src.data(), k * 4); memcpy(out.dst.data() + at, pt.dst.data(), k * 4);
+    memcpy(out.w.data() + at, pt.w.data(), k * 4); memcpy(out.pid.data() + at, pt.pid.data(), k * 4);
+    at += k;
+  }
 }
 
 }  // namespace srw

@@ -159,6 +159,7 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool w
   const unsigned char *data = (const unsigned char *)mmap(nullptr, (size_t)size, PROT_READ, MAP_PRIVATE, fd, 0);
   close(fd);
   if (data == MAP_FAILED) return false;
+  if (size >= 3 && data[0] == 0xEF && data[1] == 0xBB && data[2] == 0xBF) { munmap((void *)data, (size_t)size); return false; }   // byte order mark: the host tokenizer skips it (as Hadoop does)
   {   // cheap shape check on the first line: exactly two tokens, else do not even upload
     int64_t e = 0; int tokens = 0; bool in_tok = false;
     while (e < size && data[e] != '\n' && e < 4096) { const bool ws = data[e] == ' ' || data[e] == '\t'; if (!ws && !in_tok) ++tokens; in_tok = !ws; ++e; }

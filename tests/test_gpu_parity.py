@@ -938,6 +938,31 @@ def test_non_ascii_digits_reach_the_host_tokenizer(eng, oracle, tmp_path):
     assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
 
 
+def test_input_directory_and_byte_order_mark(eng, oracle, tmp_path):
+    """--input naming a directory of part files (sc.textFile semantics: hidden files skipped, files in name order) and a file
+    that starts with a UTF-8 byte order mark (skipped by Hadoop's LineRecordReader): both leave the device tokenizer for the
+    host tokenizer, and the graph is the oracle's graph of the concatenated lines."""
+    lines = open(KARATE).read().splitlines()
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "part-00000").write_text("\n".join(lines[:30]) + "\n")
+    (d / "part-00001").write_text("\n".join(lines[30:]))                 # no final newline
+    (d / "_SUCCESS").write_text("")
+    (d / ".part-00000.crc").write_bytes(b"crc\x00junk")
+    g = oracle.Graph.load(KARATE, weighted=False)
+    rp, rl, _ = g.walk(walk_length=10, seed=3, p=0.25, q=4.0)
+    eng.load_edgelist(str(d), weighted=False)
+    assert eng.stats() == (34, 156)
+    paths, lens, _ = eng.walk(walk_length=10, seed=3, p=0.25, q=4.0)
+    assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
+    bom = tmp_path / "bom.txt"
+    bom.write_bytes(b"\xef\xbb\xbf" + open(KARATE, "rb").read())
+    eng.load_edgelist(str(bom), weighted=False)
+    assert eng.stats() == (34, 156)
+    paths, lens, _ = eng.walk(walk_length=10, seed=3, p=0.25, q=4.0)
+    assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
+
+
 def test_wide_id_range_is_compacted(eng, oracle):
     """The reference's GraphMap is a HashMap: any int32 ids load.  A sparse id space is compacted at load (slot = rank
     among the sorted distinct ids) — the whole int32 range included, with and without partition ids — and

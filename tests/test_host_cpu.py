@@ -326,3 +326,52 @@ def test_tokenizer_unicode_digits_like_integer_parseint(oracle, tmp_path):
         assert ei.value.code == P.ERR_PARSE, raw
         with pytest.raises(Exception):
             oracle.Graph.load(str(f), weighted=True)
+
+
+def test_tokenizer_skips_a_utf8_byte_order_mark_like_hadoop(oracle, tmp_path):
+    """LineRecordReader.skipUtfByteOrderMark (Hadoop >= 2.6, what Spark 2.2 reads text with): EF BB BF at the start of the
+    file is not part of the first line; anywhere else it is just bytes of a token (NumberFormatException)."""
+    P = pkg()
+    f = tmp_path / "bom.txt"
+    f.write_bytes(b"\xef\xbb\xbf1 2 3\n4 5 6\n")
+    s, d, w, _ = P.parse_edgelist(str(f), weighted=True)
+    assert (s.tolist(), d.tolist(), w.tolist()) == ([1, 4], [2, 5], [3.0, 6.0])
+    g = oracle.Graph.load(str(f), weighted=True)
+    os_, od, ow, _ = g.lines()
+    assert (os_.tolist(), od.tolist(), ow.tolist()) == ([1, 4], [2, 5], [3.0, 6.0])
+    f.write_bytes(b"1 2 3\n\xef\xbb\xbf4 5 6\n")
+    with pytest.raises(P.SrwError) as ei:
+        P.parse_edgelist(str(f), weighted=True)
+    assert ei.value.code == P.ERR_PARSE
+    f.write_bytes(b"\xef\xbb\xbf")              # a mark and nothing else: an empty edge list
+    s, d, w, _ = P.parse_edgelist(str(f), weighted=True)
+    assert len(s) == 0
+
+
+def test_tokenizer_reads_a_directory_like_textfile(oracle, tmp_path):
+    """sc.textFile(dir): every file whose name does not start with '_' or '.' (FileInputFormat's hiddenFileFilter), here in
+    byte order of the names; each file keeps its own last unterminated line and its own byte order mark rule."""
+    P = pkg()
+    d = tmp_path / "edges"
+    d.mkdir()
+    (d / "part-00001").write_bytes(b"7 8 2.5\n9 10 1\n")
+    (d / "part-00000").write_bytes(b"\xef\xbb\xbf1 2 3\n4 5 6")          # BOM, no final newline
+    (d / "part-00002").write_bytes(b"")
+    (d / "_SUCCESS").write_bytes(b"")
+    (d / ".part-00000.crc").write_bytes(b"crc\x00\x01garbage that must never be parsed\n")
+    s, dd, w, _ = P.parse_edgelist(str(d), weighted=True)
+    assert (s.tolist(), dd.tolist(), w.tolist()) == ([1, 4, 7, 9], [2, 5, 8, 10], [3.0, 6.0, 2.5, 1.0])
+    one = tmp_path / "one.txt"
+    one.write_bytes(b"1 2 3\n4 5 6\n7 8 2.5\n9 10 1\n")
+    g = oracle.Graph.load(str(one), weighted=True)
+    os_, od, ow, _ = g.lines()
+    assert (os_.tolist(), od.tolist(), ow.tolist()) == (s.tolist(), dd.tolist(), w.tolist())
+    (d / "part-00001").write_bytes(b"7 8 2.5\nx 10 1\n")
+    with pytest.raises(P.SrwError) as ei:
+        P.parse_edgelist(str(d), weighted=True)
+    assert ei.value.code == P.ERR_PARSE and "part-00001" in str(ei.value) and "line 2" in str(ei.value)
+    (d / "part-00001").write_bytes(b"7 8 2.5\n")
+    (d / "sub").mkdir()
+    with pytest.raises(P.SrwError) as ei:
+        P.parse_edgelist(str(d), weighted=True)
+    assert ei.value.code == P.ERR_IO and "Not a file" in str(ei.value)

@@ -15,6 +15,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <cerrno>
 #include <cmath>
@@ -190,17 +191,10 @@ void parse_range(const char *data, size_t size, size_t b, size_t e, bool weighte
 }  // namespace
 
 namespace {
-void parse_one_file(const char *path, bool weighted, bool partitioned, ParsedLines &out) {
-  int fd = open(path, O_RDONLY);
-  if (fd < 0) throw Error(SRW_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
-  struct stat sb;
-  if (fstat(fd, &sb) != 0) { close(fd); throw Error(SRW_ERR_IO, std::string("cannot stat ") + path); }
-  size_t size = (size_t)sb.st_size;
+// the lines of one file's (decompressed) bytes
+void parse_buffer(const char *data, size_t size, bool weighted, bool partitioned, ParsedLines &out) {
   out = ParsedLines();
-  if (size == 0) { close(fd); return; }
-  const char *data = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-  close(fd);
-  if (data == MAP_FAILED) throw Error(SRW_ERR_IO, std::string("cannot mmap ") + path);
+  if (size == 0) return;
   unsigned hw = std::thread::hardware_concurrency();
   size_t nthreads = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, size / (1 << 20) + 1));
   // split points: each range starts at a record start
@@ -220,7 +214,6 @@ void parse_one_file(const char *path, bool weighted, bool partitioned, ParsedLin
   for (size_t t = 0; t < nthreads; ++t)
     th.emplace_back([&, t] { parse_range(data, size, cut[t], cut[t + 1], weighted, partitioned, chunks[t]); });
   for (auto &x : th) x.join();
-  munmap((void *)data, size);
   int64_t lines_before = 0;
   size_t total = 0;
   for (auto &c : chunks) {
@@ -245,6 +238,51 @@ void parse_one_file(const char *path, bool weighted, bool partitioned, ParsedLin
       memcpy(out.pid.data() + at[t], c.pid.data(), k * 4);
     });
   for (auto &x : th) x.join();
+}
+
+// One input file.  `name.gz` is decompressed first, as sc.textFile does (Hadoop picks the codec by the file extension;
+// gzip members may be concatenated) — zlib's gzread; the other codecs (.bz2, .snappy, .lz4, .deflate) are not read.
+void parse_one_file(const char *path, bool weighted, bool partitioned, ParsedLines &out) {
+  const size_t len = strlen(path);
+  if (len > 3 && strcmp(path + len - 3, ".gz") == 0) {
+    {   // zlib would pass a file without the gzip magic through unchanged; Hadoop's GzipCodec fails on it ("not in gzip format")
+      FILE *f = fopen(path, "rb");
+      if (!f) throw Error(SRW_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+      unsigned char m[2] = {0, 0};
+      const size_t got = fread(m, 1, 2, f);
+      fclose(f);
+      if (got == 0) { out = ParsedLines(); return; }                    // an empty file: no lines
+      if (got < 2 || m[0] != 0x1F || m[1] != 0x8B) throw Error(SRW_ERR_IO, std::string(path) + ": not in gzip format");
+    }
+    gzFile gz = gzopen(path, "rb");
+    if (!gz) throw Error(SRW_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+    gzbuffer(gz, 1u << 20);
+    std::vector<char> buf;
+    size_t used = 0;
+    while (true) {
+      if (buf.size() - used < ((size_t)4 << 20)) buf.resize(std::max<size_t>(buf.size() * 2, (size_t)16 << 20));
+      const int got = gzread(gz, buf.data() + used, (unsigned)std::min<size_t>(buf.size() - used, (size_t)1 << 30));
+      if (got < 0) { int en = 0; const std::string m = gzerror(gz, &en); gzclose(gz); throw Error(SRW_ERR_IO, std::string(path) + ": " + m); }
+      if (got == 0) break;
+      used += (size_t)got;
+    }
+    // a stream that ends in the middle of a member is only reported at close ("unexpected end of file"): Hadoop's
+    // DecompressorStream throws EOFException there and the job fails
+    if (gzclose(gz) != Z_OK) throw Error(SRW_ERR_IO, std::string(path) + ": unexpected end of the gzip stream");
+    parse_buffer(buf.data(), used, weighted, partitioned, out);
+    return;
+  }
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) throw Error(SRW_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); throw Error(SRW_ERR_IO, std::string("cannot stat ") + path); }
+  const size_t size = (size_t)sb.st_size;
+  if (size == 0) { close(fd); out = ParsedLines(); return; }
+  const char *data = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (data == MAP_FAILED) throw Error(SRW_ERR_IO, std::string("cannot mmap ") + path);
+  struct Unmap { const char *p; size_t n; ~Unmap() { munmap((void *)p, n); } } unmap{data, size};
+  parse_buffer(data, size, weighted, partitioned, out);
 }
 }  // namespace
 

@@ -151,6 +151,7 @@ __global__ void k_parse(const unsigned char *__restrict__ text, int64_t size, co
 }  // namespace
 
 bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool weighted) {
+  { const size_t len = strlen(path); if (len > 3 && strcmp(path + len - 3, ".gz") == 0) return false; }      // compressed: the host tokenizer inflates it
   int fd = open(path, O_RDONLY);
   if (fd < 0) return false;                                           // the host path reports the error
   struct stat sb;

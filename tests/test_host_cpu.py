@@ -375,3 +375,33 @@ def test_tokenizer_reads_a_directory_like_textfile(oracle, tmp_path):
     with pytest.raises(P.SrwError) as ei:
         P.parse_edgelist(str(d), weighted=True)
     assert ei.value.code == P.ERR_IO and "Not a file" in str(ei.value)
+
+
+def test_tokenizer_inflates_gz_like_textfile(oracle, tmp_path):
+    """sc.textFile picks the codec by the file extension: name.gz is gunzipped (concatenated members included) before the
+    lines are split; in a directory, next to plain part files."""
+    import gzip
+    P = pkg()
+    text = open(KARATE, "rb").read()
+    one = tmp_path / "karate.txt.gz"
+    half = text.index(b"\n", len(text) // 2) + 1
+    one.write_bytes(gzip.compress(text[:half]) + gzip.compress(text[half:]))      # two gzip members
+    s, d, w, _ = P.parse_edgelist(str(one), weighted=False)
+    rs, rd, rw, _ = P.parse_edgelist(KARATE, weighted=False)
+    assert np.array_equal(s, rs) and np.array_equal(d, rd) and np.array_equal(w, rw) and len(s) == 78
+    dd = tmp_path / "dir"
+    dd.mkdir()
+    (dd / "part-00000.gz").write_bytes(gzip.compress(text[:half]))
+    (dd / "part-00001").write_bytes(text[half:])
+    s, d, w, _ = P.parse_edgelist(str(dd), weighted=False)
+    assert np.array_equal(s, rs) and np.array_equal(d, rd)
+    bad = tmp_path / "bad.gz"
+    bad.write_bytes(b"this is not gzip at all\n1 2\n")
+    with pytest.raises(P.SrwError) as ei:                      # GzipCodec: "not in gzip format" (zlib alone would pass it through)
+        P.parse_edgelist(str(bad), weighted=False)
+    assert ei.value.code == P.ERR_IO and "not in gzip format" in str(ei.value)
+    trunc = tmp_path / "trunc.gz"
+    trunc.write_bytes(gzip.compress(text)[:-20])
+    with pytest.raises(P.SrwError) as ei:
+        P.parse_edgelist(str(trunc), weighted=False)
+    assert ei.value.code in (P.ERR_IO, P.ERR_PARSE)

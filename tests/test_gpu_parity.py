@@ -963,6 +963,29 @@ def test_input_directory_and_byte_order_mark(eng, oracle, tmp_path):
     assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
 
 
+def test_gz_input_through_the_cli(oracle, tmp_path):
+    """stellar-rw --input karate.txt.gz: the device tokenizer declines, the host tokenizer inflates; the part file is the
+    oracle's."""
+    import gzip, subprocess
+    from conftest import ROOT
+    gz = tmp_path / "karate.txt.gz"
+    gz.write_bytes(gzip.compress(open(KARATE, "rb").read()))
+    out = tmp_path / "out"
+    cli = os.path.join(ROOT, "stellar-random-walk_amd", "stellar-rw")
+    r = subprocess.run([cli, "--cmd", "randomwalk", "--input", str(gz), "--output", str(out), "--walkLength", "12", "--numWalks", "2",
+                        "--p", "0.5", "--q", "2.0", "--weighted", "false", "--seed", "9"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "vertices: 34" in r.stdout and "edges: 156" in r.stdout
+    g = oracle.Graph.load(KARATE, weighted=False)
+    rp, rl, _ = g.walk(walk_length=12, num_walks=2, seed=9, p=0.5, q=2.0)
+    want = sorted("\t".join(str(int(x)) for x in p_[:n]) for p_, n in zip(rp, rl))
+    got = []
+    for name in sorted(os.listdir(out / "path")):
+        if name.startswith("part-"):
+            got += (out / "path" / name).read_text().splitlines()
+    assert sorted(got) == want
+
+
 def test_wide_id_range_is_compacted(eng, oracle):
     """The reference's GraphMap is a HashMap: any int32 ids load.  A sparse id space is compacted at load (slot = rank
     among the sorted distinct ids) — the whole int32 range included, with and without partition ids — and

@@ -118,7 +118,28 @@ struct GraphView {
   // Compacted id space (graph_build.hip:compact_ids): every id inside the engine is the RANK of the vertex among the sorted
   // distinct ids of the input (vmin = 0), orig_id[rank] is the id the files carry.  Null: ids are used as they are.
   const int32_t *orig_id;
+  // Neighbor-set filters of the long rows (deg > 1024: too long for the LDS staging of binned_resolve): a word-blocked Bloom
+  // filter per row, 16-32 bits per neighbor, every element's 3 bits inside ONE 32-bit word — "x in N(prev)?" is one 4-byte read
+  // that the ~500 candidates of a located chunk keep in L2, and only a positive (members, ~1 % false positives) goes on to the
+  // exact test (edge hash / sorted row).  bf_off[slot]: first word of the row's filter in bf_bits, BF_NONE = none.  Null if not built.
+  const uint32_t *bf_off;
+  const uint32_t *bf_bits;
 };
+constexpr uint32_t BF_NONE = 0xFFFFFFFFu;
+constexpr int32_t BF_MIN_DEG = 1025;
+// words of the filter of a row of `deg` neighbors (a power of two, 16-32 bits per neighbor)
+__host__ __device__ inline uint32_t bf_words(int32_t deg) {
+  uint32_t half = (uint32_t)(deg - 1) >> 1, w = 1u;
+  while (w <= half) w <<= 1;
+  return w;
+}
+// word and 3-bit mask of id slot x in a filter of nw words
+__host__ __device__ inline void bf_hash(uint32_t x, uint32_t nw, uint32_t &word, uint32_t &mask) {
+  uint32_t h = x * 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
+  word = h & (nw - 1u);
+  uint32_t k = (x ^ 0x7F4A7C15u) * 0x2545F491u; k ^= k >> 16; k *= 0x9E3779B1u; k ^= k >> 15;
+  mask = (1u << (k & 31u)) | (1u << ((k >> 5) & 31u)) | (1u << ((k >> 10) & 31u));
+}
 // The id the walk's Philox stream is keyed with (ctr = (iteration, SOURCE ID, step, 0)) is the input's, not the rank.
 __device__ inline int32_t rng_source(const GraphView &g, int32_t src) { return g.orig_id ? g.orig_id[src - g.vmin] : src; }
 constexpr uint32_t REV_NONE = 0xFFFFFFFFu;

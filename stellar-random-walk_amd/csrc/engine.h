@@ -107,6 +107,8 @@ struct Graph {
   bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
+  DevBuf<uint32_t> bf_off, bf_bits; // neighbor-set filters of the rows beyond 1024 neighbors (GraphView::bf_off), built with the per-edge tables
+  bool has_bf = false;
   // Compacted ids (sparse id spaces, SRW_CFG_COMPACT_IDS): slots are ranks among the sorted distinct input ids
   bool compact = false;
   DevBuf<int32_t> orig_id;        // [n_slots] rank -> input id (ascending)
@@ -118,7 +120,8 @@ struct Graph {
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
                      (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
-                     has_rev ? rev.p : nullptr, eb_cap, compact ? orig_id.p : nullptr}; }
+                     has_rev ? rev.p : nullptr, eb_cap, compact ? orig_id.p : nullptr,
+                     (has_bf && use_eb && !(has_ehash && use_ehash)) ? bf_off.p : nullptr, bf_bits.p}; }
   // id <-> slot at the boundary (api.cpp): -1 if the id cannot be a vertex of this graph
   int64_t slot_of_id(int32_t v) const {
     if (!compact) { const int64_t s = (int64_t)v - vmin; return (s < 0 || s >= n_slots) ? -1 : s; }
@@ -253,6 +256,7 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,
                          DevBuf<int32_t> &d_src, DevBuf<int32_t> &d_dst, DevBuf<float> &d_w);
 void build_membership(srw_handle *h);
+void build_row_filters(srw_handle *h);            // word-blocked Bloom filters of the long rows (GraphView::bf_off)
 void build_first_order_tables(srw_handle *h, bool want_exact);
 void build_pq_tables(srw_handle *h, float p, float q);
 

@@ -159,6 +159,38 @@ int bits_for(uint64_t max_value) {
   return b;
 }
 
+// ---- neighbor-set filters of the long rows (GraphView::bf_off) ----
+__global__ void k_bf_sizes(const Row *__restrict__ rows, int64_t n_slots, unsigned long long *__restrict__ sizes) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x)
+    sizes[v] = rows[v].deg >= BF_MIN_DEG ? (unsigned long long)bf_words(rows[v].deg) : 0ull;
+}
+__global__ void k_bf_offsets(const Row *__restrict__ rows, int64_t n_slots, const unsigned long long *__restrict__ pre, uint32_t *__restrict__ off) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x)
+    off[v] = rows[v].deg >= BF_MIN_DEG ? (uint32_t)pre[v] : BF_NONE;
+}
+__global__ void k_bf_fill(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots, int32_t vmin,
+                          const uint32_t *__restrict__ off, uint32_t *__restrict__ bits, unsigned long long *next_slot) {
+  const int lane = threadIdx.x & 63;
+  while (true) {
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(next_slot, 16ull);
+    grab = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab);
+    if ((int64_t)grab >= n_slots) break;
+    for (int64_t v = (int64_t)grab; v < (int64_t)grab + 16 && v < n_slots; ++v) {
+      const Row r = rows[v];
+      if (r.deg < BF_MIN_DEG) continue;
+      const uint32_t nw = bf_words(r.deg);
+      uint32_t *f = bits + off[v];
+      for (int32_t k = lane; k < r.deg; k += 64) {
+        uint32_t word, mask;
+        bf_hash((uint32_t)((int64_t)ent[r.off + k].id - vmin), nw, word, mask);
+        atomicOr(&f[word], mask);
+      }
+    }
+  }
+}
+
 // ---- compacted ids (sparse id spaces) ----
 // key = id with the sign bit flipped: unsigned order == int32 order
 __global__ void k_ids_concat(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, int64_t n, uint32_t *__restrict__ out) {
@@ -343,6 +375,37 @@ void compact_ids(srw_handle *h, int32_t *d_src, int32_t *d_dst, int64_t n_lines,
   SRW_HIP(hipStreamSynchronize(st));
   m.compact = true; m.id_lo = vmin; m.id_hi = vmax;
   vmin = 0; vmax = (int32_t)(n_u - 1);
+}
+
+// Optional accelerator of the table steps (binned_resolve): skipped when HBM is short or the offsets would not fit 32 bits.
+void build_row_filters(srw_handle *h) {
+  Graph &g = h->g;
+  if (g.has_bf || g.n_entries <= 0 || h->cfg.world != 1) return;
+  hipStream_t st = h->stream;
+  DevBuf<unsigned long long> sizes, next_slot; DevBuf<char> temp;
+  sizes.alloc((size_t)g.n_slots + 1); next_slot.alloc(1);
+  SRW_HIP(hipMemsetAsync(sizes.p + g.n_slots, 0, 8, st));
+  hipLaunchKernelGGL(k_bf_sizes, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, g.rows.p, g.n_slots, sizes.p);
+  size_t tb = 0;
+  SRW_HIP(rocprim::exclusive_scan(nullptr, tb, sizes.p, sizes.p, 0ull, (size_t)g.n_slots + 1, rocprim::plus<unsigned long long>(), st));
+  temp.alloc(tb);
+  SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, sizes.p, sizes.p, 0ull, (size_t)g.n_slots + 1, rocprim::plus<unsigned long long>(), st));
+  unsigned long long total = 0;
+  SRW_HIP(hipMemcpyAsync(&total, sizes.p + g.n_slots, 8, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  if (total == 0 || total >= 0xFFFFFFF0ull) return;
+  size_t free_b = 0, total_b = 0;
+  SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+  if (free_b < (size_t)total * 4 + (size_t)g.n_slots * 4 + ((size_t)32 << 30)) return;
+  g.bf_off.alloc((size_t)g.n_slots); g.bf_bits.alloc((size_t)total);
+  hipLaunchKernelGGL(k_bf_offsets, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, g.rows.p, g.n_slots, sizes.p, g.bf_off.p);
+  SRW_HIP(hipMemsetAsync(g.bf_bits.p, 0, (size_t)total * 4, st));
+  SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
+  hipLaunchKernelGGL(k_bf_fill, dim3(256 * 8), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, g.bf_off.p, g.bf_bits.p, next_slot.p);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipStreamSynchronize(st));
+  g.has_bf = true;
+  if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] row filters: %.2f GB for the rows beyond %d neighbors\n", (double)total * 4 / 1e9, BF_MIN_DEG - 1);
 }
 
 static void install_id_map(Graph &g, IdMap *m) {

@@ -1021,7 +1021,7 @@ __device__ inline void edge_exists_n(const uint64_t *tab, uint64_t mask, uint32_
 #ifndef SRW_RESOLVE_PER_LANE
 #define SRW_RESOLVE_PER_LANE 2   // measured at config 3: 2 -> 182 M steps/s, 4 -> 169 M, 1 -> 168 M (request-bound vs latency-bound)
 #endif
-template <bool ABS>
+template <bool ABS, bool BF = false>
 __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, const Bias &b, const double *bins,
                                          const BinGeom geo, float r, unsigned &fallback, unsigned &served, Member &tm,
                                          int32_t &id_out, uint32_t *stage) {
@@ -1106,6 +1106,12 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     if (stage_levels == 0) stage_levels = -1;               // m == 1: one compare, no search level
     __builtin_amdgcn_wave_barrier();
   }
+  // a long N(prev) without a bitmap: its neighbor-set filter (device_common.h:bf_hash), if the graph has them
+  const uint32_t *bf = nullptr; uint32_t bf_nw = 0;
+  if (BF && !no_specials && !stage_levels && !hubbits && g.bf_off && m >= BF_MIN_DEG) {
+    const uint32_t bo = g.bf_off[xprev];
+    if (bo != BF_NONE) { bf = g.bf_bits + bo; bf_nw = bf_words(m); }
+  }
   served = 1;
 #ifdef SRW_PHASE_TIMING
   tm.n_binned += 1;                                             // resolved chunks ...
@@ -1150,6 +1156,17 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       for (int u = 0; u < PL; ++u) wd[u] = want[u] ? hubbits[xs[u] >> 5] : 0u;
 #pragma unroll
       for (int u = 0; u < PL; ++u) in[u] = (wd[u] >> (xs[u] & 31)) & 1u;
+    } else if (BF && bf) {                            // long N(prev), no bitmap: the row's filter first, the exact test on a positive
+#pragma unroll
+      for (int u = 0; u < PL; ++u) {
+        in[u] = false;
+        if (want[u]) {
+          uint32_t word, mask;
+          bf_hash(xs[u], bf_nw, word, mask);
+          if ((bf[word] & mask) == mask)
+            in[u] = g.ehash ? edge_exists(g.ehash, g.ehash_mask, xprev, xs[u]) : sorted_contains(B, m, xs[u]);
+        }
+      }
     } else if (g.ehash) {
       edge_exists_n<PL>(g.ehash, g.ehash_mask, xprev, xs, want, in);
     } else {
@@ -1345,11 +1362,12 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
 #endif
 constexpr int EB_BINS = SRW_EB_BINS;           // default chunks per table: one lane each in the search.  GraphView::eb_cap (32 / 64 /
                                                // 128 / 256) is what the standing tables were built with: more chunks = a second search round, shorter chunks
+template <bool BF = false>
 __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc, const Bias &b, const double *table,
                                                float r, unsigned &fallback, unsigned &served, Member &tm, int32_t &id_out,
                                                uint32_t *stage /* 1024 words of the wave's LDS */) {
   const BinGeom geo = bin_geometry(rc.deg, g.eb_min_sh, g.eb_cap);
-  return binned_resolve<true>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage);
+  return binned_resolve<true, BF>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage);
 }
 
 }  // namespace srw

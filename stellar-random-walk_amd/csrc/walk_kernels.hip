@@ -280,6 +280,7 @@ __device__ inline Row uniform_row(Row r) {            // the row descriptor of a
   o.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.flags);
   return o;
 }
+template <bool BF>   // BF: the located chunk's probes of a long N(prev) go through the row filters (no edge hash; GraphView::bf_off)
 __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
                                                      int64_t n_walkers, int32_t L, int32_t first_walk, RngSpec rng, float p,
                                                      float q, int32_t *__restrict__ paths, int32_t *__restrict__ lens,
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
           w_mask += 1; w_srch += 8u * (uint32_t)r.deg + 4u * (uint32_t)((r.deg + 31) >> 5);
           SRW_T1(mem, t_a);
         } else if (r.deg > g.eb_mask_max && eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
-          k = wave_pick_edge_table(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage);
+          k = wave_pick_edge_table<BF>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage);
           if (k >= 0) { w_tab += 1; w_srch += 8u * EB_BINS; w_fast += sv; }
           SRW_T1(mem, t_p1);
 #ifdef SRW_PHASE_TIMING
@@ -1420,9 +1421,15 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
     if (lean) {
       h->walk_todo.ensure((size_t)n_walkers);
       int64_t lb = std::min<int64_t>((n_walkers * 64 + TPB - 1) / TPB, (int64_t)h->n_cus * 16);
-      hipLaunchKernelGGL(k_walk_tables, dim3((unsigned)lb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
+      if (gv.bf_off) {
+        hipLaunchKernelGGL((k_walk_tables<true>), dim3((unsigned)lb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
                          first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, h->walk_todo.p,
                          h->walk_cursor.p + 1);
+      } else {
+        hipLaunchKernelGGL((k_walk_tables<false>), dim3((unsigned)lb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
+                         first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, h->walk_todo.p,
+                         h->walk_cursor.p + 1);
+      }
       SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, sizeof(unsigned long long), st));
       todo = h->walk_todo.p;
     }
@@ -1494,7 +1501,8 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
       // what build_edge_tables will have: free - bitmaps (16 GB when the tables are tight) - reserve; 2 GB of margin
       const size_t slack = reserve + (want_hub ? (size_t)16 << 30 : 0) + ((size_t)2 << 30);
       const bool with_hash = n64 > 0 && n64 < ((size_t)160 << 30) && free_b > eh_bytes && free_b - eh_bytes > n64 + slack;
-      const bool without = n64 > 0 && n64 < ((size_t)200 << 30) && free_b > n64 + slack;
+      // (without the hash the long rows get their neighbor-set filters: at most 4 B per adjacency entry, graph_build.hip)
+      const bool without = n64 > 0 && n64 < ((size_t)200 << 30) && free_b > n64 + slack + (size_t)g.n_entries * 4;
       drop_ehash = !with_hash && without;
       if (getenv("SRW_TIMING"))
         fprintf(stderr, "[timing] edge hash vs table resolution: %.1f GB free, hash %.1f GB, complete 64-chunk set %.1f GB, slack %.1f GB -> %s\n",
@@ -1509,6 +1517,10 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   }
   if (want_ehash) build_edge_hash(h);
   h->g.use_ehash = want_ehash;
+  // no edge hash for the table steps (traded above, or not wanted): the long rows' neighbor-set filters answer most of the
+  // located chunks' probes from L2 (config 5's stand-in: 2.0e8 -> 2.73e8 steps/s, 3 GB).  With the hash they are not worth
+  // their registers (config 3: -1 ... -4 %): k_walk_tables<false>.
+  if (want_eb && !want_ehash && !getenv("SRW_NO_ROW_FILTERS")) build_row_filters(h);
   // With per-edge tables the bitmaps serve the tables' own construction and the membership probes of a located chunk
   // whose N(prev) is too long for LDS — one probe into a bitmap that the hub's many walkers keep in L2, against one
   // HBM request into the edge hash (config 3: 16 / 40 / 80 GB of bitmaps -> 223 / 258 / 272 M steps/s, s44).  The tables

@@ -242,7 +242,8 @@ __global__ void k_alias_link(const Row *__restrict__ rows, const Ent *__restrict
 }
 
 // Edge hash set: one 64-bit key per distinct directed edge, open addressing with linear probing, load factor <= 2/3.
-__global__ void k_ehash_build(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots, int32_t vmin,
+// msids != null: rows / ids are the replicated membership structure of a sharded handle (slot ids of the WHOLE graph)
+__global__ void k_ehash_build(const Row *__restrict__ rows, const Ent *__restrict__ ent, const uint32_t *__restrict__ msids, int64_t n_slots, int32_t vmin,
                               uint64_t *__restrict__ tab, uint64_t mask, unsigned long long *next_slot) {
   const int lane = lane_id();
   while (true) {
@@ -254,7 +255,7 @@ __global__ void k_ehash_build(const Row *__restrict__ rows, const Ent *__restric
     for (int64_t v = (int64_t)grab; v < (int64_t)grab + 4 && v < n_slots; ++v) {
       const Row r = rows[v];
       for (int32_t k = lane; k < r.deg; k += 64) {
-        const uint64_t key = ((uint64_t)(uint32_t)v << 32) | (uint32_t)((int64_t)ent[r.off + k].id - vmin);
+        const uint64_t key = ((uint64_t)(uint32_t)v << 32) | (msids ? msids[r.off + k] : (uint32_t)((int64_t)ent[r.off + k].id - vmin));
         uint64_t s = edge_hash(key, mask);
         while (true) {
           const unsigned long long old = atomicCAS((unsigned long long *)&tab[s], 0xFFFFFFFFFFFFFFFFull, (unsigned long long)key);
@@ -270,9 +271,13 @@ __global__ void k_ehash_build(const Row *__restrict__ rows, const Ent *__restric
 
 void build_edge_hash(srw_handle *h) {
   Graph &g = h->g;
-  if (g.has_ehash || g.n_entries == 0) return;
+  // a sharded handle asks "x in N(prev)?" for any prev: the set is that of the WHOLE graph, built from the replicated
+  // membership structure (a shard without it never asks)
+  const bool whole = g.mrows.p != nullptr;
+  const int64_t n_ent = whole ? g.n_entries_global : g.n_entries;
+  if (g.has_ehash || n_ent == 0 || (h->cfg.world != 1 && !whole)) return;
   uint64_t slots = 1024;
-  while (slots < (uint64_t)g.n_entries + (uint64_t)g.n_entries / 2) slots <<= 1;
+  while (slots < (uint64_t)n_ent + (uint64_t)n_ent / 2) slots <<= 1;
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));
   if (free_b < slots * 8 + ((size_t)16 << 30)) return;      // optional accelerator: the sorted rows remain the fallback
@@ -281,8 +286,8 @@ void build_edge_hash(srw_handle *h) {
   SRW_HIP(hipMemsetAsync(g.ehash.p, 0xFF, (size_t)slots * 8, st));
   DevBuf<unsigned long long> next_slot; next_slot.alloc(1);
   SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
-  hipLaunchKernelGGL(k_ehash_build, dim3(256 * 8), dim3(256), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, g.ehash.p, slots - 1,
-                     next_slot.p);
+  hipLaunchKernelGGL(k_ehash_build, dim3(256 * 8), dim3(256), 0, st, whole ? (const Row *)g.mrows.p : (const Row *)g.rows.p, g.ent.p,
+                     whole ? (const uint32_t *)g.msids.p : (const uint32_t *)nullptr, g.n_slots, g.vmin, g.ehash.p, slots - 1, next_slot.p);
   SRW_HIP(hipGetLastError());
   SRW_HIP(hipStreamSynchronize(st));
   g.ehash_mask = slots - 1;

@@ -34,6 +34,12 @@ int32_t guarded(srw_handle *h, F &&f) {
 }
 
 void need(bool ok, const char *msg) { if (!ok) throw Error(SRW_ERR_INVALID, msg); }
+}  // namespace
+
+// what srw_last_error(NULL) reports: failures of the entry points that have no handle yet (srw_create, srw_cluster_create)
+void srw::set_create_error(const std::string &m) { std::lock_guard<std::mutex> l(g_err_mu); g_create_error = m; }
+
+namespace {
 
 void load_lines(srw_handle *h, const int32_t *src, const int32_t *dst, const float *w, const int32_t *pid,
                 int64_t n, bool directed) {

@@ -70,6 +70,7 @@ void link_rows(srw_cluster *c) {
     ck(c, r, srw_shard_rows_export(c->sh[(size_t)r], own[(size_t)r].p, n_slots));
   }
   bool all = true;
+  try {
   for (int r = 0; r < world; ++r) {
     SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
     acc[(size_t)r].alloc((size_t)n_slots * 16);
@@ -80,6 +81,13 @@ void link_rows(srw_cluster *c) {
     ck(c, r, srw_shard_rows_commit(c->sh[(size_t)r], acc[(size_t)r].p, n_slots, &linked));
     acc[(size_t)r].release();
     all = all && linked != 0;
+  }
+  } catch (...) {
+    // a shard that already committed must not keep linked records while the others do not: linked and unlinked walkers
+    // interpret srw_walker.prev / kind differently (all or nothing)
+    for (int r = 0; r < world; ++r) (void)srw_shard_rows_release(c->sh[(size_t)r]);
+    c->rows_linked = 0;
+    throw;
   }
   for (int r = 0; r < world; ++r) { SRW_HIP(hipSetDevice(c->dev[(size_t)r])); own[(size_t)r].release(); }
   if (!all) { for (int r = 0; r < world; ++r) ck(c, r, srw_shard_rows_release(c->sh[(size_t)r])); return; }
@@ -111,6 +119,11 @@ int32_t srw_cluster_create(const int32_t *devices, int32_t n_devices, int32_t fl
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) SRW_HIP(e);
         (void)hipGetLastError();
       }
+    for (int a = 0; a < n_devices; ++a) {
+      int same = 0;
+      for (int b = 0; b < n_devices; ++b) same += devices[a] == devices[b];
+      c->sh[(size_t)a]->dev_share = same;
+    }
     c->recv[0].resize((size_t)n_devices); c->recv[1].resize((size_t)n_devices);
     c->paths.resize((size_t)n_devices); c->lens.resize((size_t)n_devices); c->vrank.resize((size_t)n_devices);
     c->ev.assign((size_t)n_devices, nullptr);
@@ -119,7 +132,12 @@ int32_t srw_cluster_create(const int32_t *devices, int32_t n_devices, int32_t fl
       SRW_HIP(hipEventCreateWithFlags(&c->ev[(size_t)r], hipEventDisableTiming));
     }
   });
-  if (rc != SRW_OK) { { std::string m = c->last_error; srw_cluster_destroy(c); (void)m; } return rc; }
+  if (rc != SRW_OK) {      // no cluster to ask: the message goes where srw_last_error(NULL) finds it
+    if (c->last_error.find("srw_create on device") != 0) set_create_error("srw_cluster_create: " + c->last_error);
+    else set_create_error(c->last_error);
+    srw_cluster_destroy(c);
+    return rc;
+  }
   *out = c;
   return SRW_OK;
 }
@@ -242,7 +260,9 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
         ck(c, r, srw_shard_finish(c->sh[(size_t)r], &s, &of));
         overflow |= of != 0;
         bt.n_steps += s.n_steps; bt.dead_ends += s.dead_ends; bt.sum_deg_curr += s.sum_deg_curr; bt.sum_deg_prev += s.sum_deg_prev;
-        bt.ent_reads += s.ent_reads; bt.fallbacks += s.fallbacks;
+        bt.ent_reads += s.ent_reads; bt.fallbacks += s.fallbacks; bt.trials += s.trials;
+        for (int i = 0; i < 12; ++i) bt.strategy_steps[i] += s.strategy_steps[i];
+        bt.edge_tables += s.edge_tables; bt.edge_table_bytes += s.edge_table_bytes;      // per shard: summed = the whole graph's set
       }
       if (overflow) {                 // a chunk was too small for this graph's skew: same batch again with more room
         if (getenv("SRW_TIMING")) fprintf(stderr, "[cluster] chunk overflow at slack %.2f (batch %d, iteration %d): retrying\n", slack, B, it0);
@@ -251,7 +271,9 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
         continue;
       }
       tot.n_steps += bt.n_steps; tot.dead_ends += bt.dead_ends; tot.sum_deg_curr += bt.sum_deg_curr; tot.sum_deg_prev += bt.sum_deg_prev;
-      tot.ent_reads += bt.ent_reads; tot.fallbacks += bt.fallbacks;
+      tot.ent_reads += bt.ent_reads; tot.fallbacks += bt.fallbacks; tot.trials += bt.trials;
+      for (int i = 0; i < 12; ++i) tot.strategy_steps[i] += bt.strategy_steps[i];
+      tot.edge_tables = bt.edge_tables; tot.edge_table_bytes = bt.edge_table_bytes;
       c->batches.push_back({it0, B});
       it0 += B;
     }

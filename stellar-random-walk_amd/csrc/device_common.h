@@ -77,6 +77,7 @@ struct alignas(32) AEnt {
 
 struct alignas(16) RevEnt { uint32_t cl, pos0; float w0; uint32_t pad; };
 
+struct PairSlot;
 struct GraphView {
   const Row *rows;
   const Ent *ent;
@@ -124,6 +125,11 @@ struct GraphView {
   // exact test (edge hash / sorted row).  bf_off[slot]: first word of the row's filter in bf_bits, BF_NONE = none.  Null if not built.
   const uint32_t *bf_off;
   const uint32_t *bf_bits;
+  // Vertex-sharded handles: the per-edge tables of the pairs (prev -> curr) whose CURR this shard owns are found through a
+  // hash of the pair (PairSlot below) instead of eb_off[entry of prev's row] — prev's row lives on another shard, and a
+  // walker arrives with (prev, curr) only.  Null on whole-graph handles walked through srw_walk.
+  const PairSlot *ph;
+  uint32_t ph_buckets;
 };
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;
 constexpr int32_t BF_MIN_DEG = 1025;
@@ -216,6 +222,50 @@ __device__ inline bool edge_exists(const uint64_t *tab, uint64_t mask, uint32_t 
     if (v == key) return true;
     if (v == 0xFFFFFFFFFFFFFFFFull) return false;
     s = (s + 1) & mask;
+  }
+}
+
+// ---- pair hash of a shard's per-edge tables -----------------------------------------------------------------------
+// One 16-byte slot per pair (u -> x), x owned by the shard: key = u slot << 32 | x slot, val = what eb_off[e] holds on a
+// whole-graph handle (table offset in 64-byte units, mask offset in 16-byte units, or the inline mask of a row of <= 32
+// candidates).  Buckets of four slots = one 64-byte line; linear probing over slots from the bucket's first one, so a
+// key sits in the run of occupied slots that starts there.  A step's probe (8 slots = two lines read by eight lanes of
+// the wave, issued together with the row of curr) almost always ends in the first line (load <= 0.55).
+struct alignas(16) PairSlot { unsigned long long key; uint32_t val, pad; };
+constexpr unsigned long long PAIR_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+__host__ __device__ inline uint32_t pair_bucket(uint32_t u, uint32_t x, uint32_t n_buckets) {
+  uint32_t a = (u * 0x9E3779B1u) ^ (x * 0x85EBCA77u + 0x165667B1u);
+  a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;
+  return (uint32_t)(((uint64_t)a * (uint64_t)n_buckets) >> 32);
+}
+__device__ inline void pair_insert(PairSlot *tab, uint32_t n_buckets, uint32_t u, uint32_t x, uint32_t val) {
+  const unsigned long long key = ((unsigned long long)u << 32) | x;
+  const uint64_t cap = (uint64_t)n_buckets * 4;
+  uint64_t s = (uint64_t)pair_bucket(u, x, n_buckets) * 4;
+  while (true) {
+    const unsigned long long old = atomicCAS(&tab[s].key, PAIR_EMPTY, key);
+    if (old == PAIR_EMPTY || old == key) { tab[s].val = val; return; }
+    if (++s == cap) s = 0;
+  }
+}
+// wave-uniform lookup: all 64 lanes call with the same (u, x); true = found (val_out wave-uniform)
+__device__ inline bool pair_lookup_wave(const PairSlot *tab, uint32_t n_buckets, uint32_t u, uint32_t x, uint32_t &val_out) {
+  const unsigned long long key = ((unsigned long long)u << 32) | x;
+  const uint64_t cap = (uint64_t)n_buckets * 4;
+  uint64_t s0 = (uint64_t)pair_bucket(u, x, n_buckets) * 4;
+  const int lane = (int)(threadIdx.x & 63u);
+  while (true) {
+    unsigned long long k = 0ull; uint32_t v = 0u;
+    if (lane < 8) {
+      uint64_t s = s0 + (uint64_t)lane; if (s >= cap) s -= cap;
+      const uint4 q = *reinterpret_cast<const uint4 *>(tab + s);
+      k = ((unsigned long long)q.y << 32) | q.x; v = q.z;
+    }
+    const unsigned long long hit = __ballot(lane < 8 && k == key), emp = __ballot(lane < 8 && k == PAIR_EMPTY);
+    const int fh = hit ? __ffsll((long long)hit) - 1 : 64, fe = emp ? __ffsll((long long)emp) - 1 : 64;
+    if (fh < fe) { val_out = (uint32_t)__builtin_amdgcn_readlane((int)v, fh); return true; }
+    if (fe < 64) return false;
+    s0 += 8; if (s0 >= cap) s0 -= cap;
   }
 }
 

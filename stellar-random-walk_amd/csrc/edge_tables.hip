@@ -93,9 +93,27 @@ __device__ inline int64_t grab_u64(unsigned long long *cursor, unsigned long lon
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab));
 }
 
+// Which pairs (u -> x) a handle builds tables for, and where their table words go:
+//   SH = false (whole-graph handle, srw_walk): every entry k of u's row in input order; word -> eb_off[ru.off + k]
+//   SH = true  (vertex-sharded handle, srw_shard_*): every DISTINCT neighbor x of u that this shard owns — enumerated from
+//              the replicated membership structure (mrows / msids: sorted neighbor ids of the whole graph; at world 1 they
+//              alias rows / sids), because prev's row lives on owner(prev) while the table describes N(curr) and belongs to
+//              owner(curr); word -> pair hash (device_common.h:PairSlot), k = position in u's SORTED row.
+struct ShardSel { int32_t rank, world; };
+template <bool SH>
+__device__ inline Row eb_urow(const GraphView &g, int64_t u) { return SH ? g.mrows[u] : g.rows[u]; }
+template <bool SH>
+__device__ inline bool eb_pair(const GraphView &g, const Row &ru, int32_t k, const ShardSel &ss, uint32_t &xs) {
+  if (!SH) { xs = (uint32_t)((int64_t)g.ent[ru.off + k].id - g.vmin); return true; }
+  xs = g.msids[ru.off + k];
+  if (k > 0 && g.msids[ru.off + k - 1] == xs) return false;                     // multi-edge: one table per pair
+  return ss.world == 1 || owner_of_tab((int32_t)((int64_t)xs + g.vmin), ss.world, g.owner_tab, g.vmin, g.n_slots) == ss.rank;
+}
+
 // pass 1: table bytes per cost class (class = bit length of the cost), so that the host can fit a threshold to the budget
-__global__ __launch_bounds__(TPB) void k_eb_hist(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots,
-                                                 int32_t vmin, EbSel sel, unsigned long long *cursor,
+// (hist[0][1]: pairs whose mask is inline — a shard's pair hash needs their count)
+template <bool SH>
+__global__ __launch_bounds__(TPB) void k_eb_hist(GraphView g, ShardSel ss, EbSel sel, unsigned long long *cursor,
                                                  unsigned long long *hist /* [64][2]: units, pairs */) {
   __shared__ unsigned long long lh[64][2];
   if (threadIdx.x < 128) lh[threadIdx.x >> 1][threadIdx.x & 1] = 0ull;
@@ -103,11 +121,13 @@ __global__ __launch_bounds__(TPB) void k_eb_hist(const Row *__restrict__ rows, c
   const int lane = lane_id();
   while (true) {
     const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
-    if (v0 >= n_slots) break;
-    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < n_slots; ++u) {
-      const Row ru = rows[u];
+    if (v0 >= g.n_slots) break;
+    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < g.n_slots; ++u) {
+      const Row ru = eb_urow<SH>(g, u);
       for (int32_t k = lane; k < ru.deg; k += 64) {
-        const Row rv = rows[(int64_t)ent[ru.off + k].id - vmin];
+        uint32_t xs;
+        if (!eb_pair<SH>(g, ru, k, ss, xs)) continue;
+        const Row rv = g.rows[xs];
         int64_t cost; int kind;
         const uint32_t un = eb_units(ru, rv, sel, cost, kind);
         if (kind == 1) {
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(TPB) void k_eb_hist(const Row *__restrict__ rows, c
         } else if (kind == 2) {                                            // slot 63: the masks (all or nothing)
           atomicAdd(&lh[63][0], (unsigned long long)un);
           atomicAdd(&lh[63][1], 1ull);
-        }
+        } else if (kind == 3) atomicAdd(&lh[0][1], 1ull);
       }
     }
   }
@@ -127,20 +147,22 @@ __global__ __launch_bounds__(TPB) void k_eb_hist(const Row *__restrict__ rows, c
 }
 
 // pass 2: per row of prev, the units (bins: 64 B, masks: 16 B) and the number of its pairs that get a table in HBM
-__global__ __launch_bounds__(TPB) void k_eb_rowsum(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots,
-                                                   int32_t vmin, EbSel sel, unsigned long long *cursor,
+template <bool SH>
+__global__ __launch_bounds__(TPB) void k_eb_rowsum(GraphView g, ShardSel ss, EbSel sel, unsigned long long *cursor,
                                                    unsigned long long *__restrict__ row_units,
                                                    unsigned long long *__restrict__ row_munits,
                                                    unsigned long long *__restrict__ row_pairs) {
   const int lane = lane_id();
   while (true) {
     const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
-    if (v0 >= n_slots) break;
-    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < n_slots; ++u) {
-      const Row ru = rows[u];
+    if (v0 >= g.n_slots) break;
+    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < g.n_slots; ++u) {
+      const Row ru = eb_urow<SH>(g, u);
       unsigned long long un = 0, mu = 0, np = 0;
       for (int32_t k = lane; k < ru.deg; k += 64) {
-        const Row rv = rows[(int64_t)ent[ru.off + k].id - vmin];
+        uint32_t xs;
+        if (!eb_pair<SH>(g, ru, k, ss, xs)) continue;
+        const Row rv = g.rows[xs];
         int64_t cost; int kind;
         const uint32_t x = eb_units(ru, rv, sel, cost, kind);
         if (kind == 1) un += x; else if (kind == 2) mu += x;
@@ -153,25 +175,28 @@ __global__ __launch_bounds__(TPB) void k_eb_rowsum(const Row *__restrict__ rows,
 }
 
 // pass 3: table offsets per entry + the work list (row slot of prev, position inside the row).  Rows of curr up to 32
-// candidates are not listed: k_eb_inline writes their masks into eb_off itself.
-__global__ __launch_bounds__(TPB) void k_eb_assign(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots,
-                                                   int32_t vmin, EbSel sel, unsigned long long *cursor,
+// candidates are not listed: k_eb_inline writes their masks into eb_off itself (SH: into the pair hash).
+template <bool SH>
+__global__ __launch_bounds__(TPB) void k_eb_assign(GraphView g, ShardSel ss, EbSel sel, unsigned long long *cursor,
                                                    const unsigned long long *__restrict__ row_units,
                                                    const unsigned long long *__restrict__ row_munits,
                                                    const unsigned long long *__restrict__ row_pairs,
-                                                   uint32_t *__restrict__ eb_off, uint2 *__restrict__ items) {
+                                                   uint32_t *__restrict__ eb_off, uint2 *__restrict__ items,
+                                                   PairSlot *__restrict__ ph, uint32_t ph_buckets, uint32_t *__restrict__ item_off) {
   const int lane = lane_id();
   while (true) {
     const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
-    if (v0 >= n_slots) break;
-    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < n_slots; ++u) {
-      const Row ru = rows[u];
+    if (v0 >= g.n_slots) break;
+    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < g.n_slots; ++u) {
+      const Row ru = eb_urow<SH>(g, u);
       unsigned long long ubase = row_units[u], mbase = row_munits[u], pbase = row_pairs[u];
       for (int32_t base = 0; base < ru.deg; base += 64) {
         const int32_t k = base + lane;
-        uint32_t x = 0; int kind = 0;
-        if (k < ru.deg) {
-          const Row rv = rows[(int64_t)ent[ru.off + k].id - vmin];
+        uint32_t x = 0, xs = 0; int kind = 0;
+        bool mine = false;
+        if (k < ru.deg && eb_pair<SH>(g, ru, k, ss, xs)) {
+          mine = true;
+          const Row rv = g.rows[xs];
           int64_t cost;
           x = eb_units(ru, rv, sel, cost, kind);
         }
@@ -182,9 +207,14 @@ __global__ __launch_bounds__(TPB) void k_eb_assign(const Row *__restrict__ rows,
         }
         const bool listed = kind == 1 || kind == 2;
         const unsigned long long has = __ballot(listed);
-        if (k < ru.deg && kind != 3)
-          eb_off[ru.off + k] = kind == 1 ? (uint32_t)(ubase + ib - xb) : kind == 2 ? (uint32_t)(mbase + im - xm) : EB_NONE;
-        if (listed) items[pbase + (unsigned long long)__popcll(has & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)u, (uint32_t)k);
+        const uint32_t word = kind == 1 ? (uint32_t)(ubase + ib - xb) : kind == 2 ? (uint32_t)(mbase + im - xm) : EB_NONE;
+        if (!SH) { if (k < ru.deg && kind != 3) eb_off[ru.off + k] = word; }
+        else if (mine && listed) pair_insert(ph, ph_buckets, (uint32_t)u, xs, word);
+        if (listed) {
+          const unsigned long long idx = pbase + (unsigned long long)__popcll(has & ((1ull << lane) - 1ull));
+          items[idx] = make_uint2((uint32_t)u, (uint32_t)k);
+          if (SH) item_off[idx] = word;
+        }
         ubase += (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
         mbase += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         pbase += (unsigned long long)__popcll(has);
@@ -198,24 +228,29 @@ __device__ inline bool eb_member(const GraphView &g, const Row &ru, uint32_t usl
   const uint32_t hub = ru.flags >> ROW_HUB_SHIFT;
   if (hub && g.hub_bm) return (g.hub_bm[(int64_t)(hub - 1) * g.hub_words + (xs >> 5)] >> (xs & 31)) & 1u;
   if (g.ehash) return edge_exists(g.ehash, g.ehash_mask, uslot, xs);
-  return sorted_contains(g.sids + ru.off, ru.deg, xs);
+  return sorted_contains(g.msids + ru.off, ru.deg, xs);     // (msids == sids on a whole-graph handle)
 }
 
 // inline masks: one LANE per pair (u -> v) with deg(v) <= 32
-__global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, EbSel sel, unsigned long long *cursor, uint32_t *__restrict__ eb_off) {
+template <bool SH>
+__global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, ShardSel ss, EbSel sel, unsigned long long *cursor, uint32_t *__restrict__ eb_off,
+                                                   PairSlot *__restrict__ ph, uint32_t ph_buckets) {
   const int lane = lane_id();
   while (true) {
     const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
     if (v0 >= g.n_slots) break;
     for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < g.n_slots; ++u) {
-      const Row ru = g.rows[u];
+      const Row ru = eb_urow<SH>(g, u);
       for (int32_t k = lane; k < ru.deg; k += 64) {
-        const Row rv = g.rows[(int64_t)g.ent[ru.off + k].id - g.vmin];
+        uint32_t xs;
+        if (!eb_pair<SH>(g, ru, k, ss, xs)) continue;
+        const Row rv = g.rows[xs];
         if (rv.deg <= 0 || rv.deg > sel.mask_max || rv.deg > INLINE_MAX_DEG) continue;
         uint32_t mask = 0u;
         for (int32_t c = 0; c < rv.deg; ++c)
           if (eb_member(g, ru, (uint32_t)u, (uint32_t)((int64_t)g.ent[rv.off + c].id - g.vmin))) mask |= 1u << c;
-        eb_off[ru.off + k] = mask;
+        if (SH) pair_insert(ph, ph_buckets, (uint32_t)u, xs, mask);
+        else eb_off[ru.off + k] = mask;
       }
     }
   }
@@ -223,6 +258,7 @@ __global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, EbSel sel, unsig
 
 // pass 4: the tables.  One wave per pair: binned_fill exactly as a walk step over that pair would run it, then the
 // prefix at every table chunk end goes to HBM.
+template <bool SH>
 __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
                                                      float q, int32_t min_sh, int32_t mask_max, int32_t bins_cap, const uint32_t *__restrict__ eb_off,
                                                      double *__restrict__ eb_bins, uint32_t *__restrict__ em_bits, unsigned long long *cursor,
@@ -237,15 +273,16 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
     if (i0 >= n_items) break;
     for (int64_t i = i0; i < i0 + GRAB_ITEMS && i < n_items; ++i) {
       const uint2 it = items[i];
-      const Row ru = g.rows[it.x];
+      // SH: it.y = position in u's SORTED row of the membership structure, eb_off = the work list's own offsets (item_off)
+      const Row ru = eb_urow<SH>(g, it.x);
       const int64_t e = ru.off + it.y;
-      const int32_t v = g.ent[e].id;
-      const Row rv = g.rows[(int64_t)v - g.vmin];
+      const Row rv = g.rows[SH ? (int64_t)g.msids[e] : (int64_t)g.ent[e].id - g.vmin];
+      const uint32_t tab_word = eb_off[SH ? i : e];
       Bias b;
       b.p = p; b.q = q; b.prev = (int32_t)((int64_t)it.x + g.vmin); b.second_order = true; b.need_member = true;
-      b.prev_sids = g.sids + ru.off; b.prev_deg = ru.deg; b.vmin = g.vmin; b.prev_hub = ru.flags >> ROW_HUB_SHIFT;
+      b.prev_sids = g.msids + ru.off; b.prev_deg = ru.deg; b.vmin = g.vmin; b.prev_hub = ru.flags >> ROW_HUB_SHIFT;
       if (rv.deg <= mask_max) {                   // membership mask: 64 candidates per round, one probe each
-        uint32_t *out = em_bits + (size_t)eb_off[e] * 4;
+        uint32_t *out = em_bits + (size_t)tab_word * 4;
         const int32_t n_words = ((((rv.deg + 31) >> 5) + 3) >> 2) << 2;
         for (int32_t c0 = 0; c0 < n_words * 32; c0 += 64) {
           const int32_t c = c0 + lane;
@@ -262,7 +299,7 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
       binned_fill(g, rv, b, mine, 0, gf, tm, ab, su);
       ns[su & 7] += 1;
       const double *bins = reinterpret_cast<const double *>(mine);
-      double *out = eb_bins + (size_t)eb_off[e] * 8;
+      double *out = eb_bins + (size_t)tab_word * 8;
       const int up = gc.csh - gf.csh;
       const double *PQ = g.pq + rv.off;            // the table keeps the complete numerator A'_end(j) = PQ[end_j] + corrections
       const bool as_f32 = g.eb_f32 && (rv.flags & ROW_PQ_F32);      // every such sum is exactly representable in binary32
@@ -332,7 +369,7 @@ size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
   cursor.alloc(1); hist.alloc(128);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
   SRW_HIP(hipMemsetAsync(hist.p, 0, 128 * 8, st));
-  hipLaunchKernelGGL(k_eb_hist, dim3(h->n_cus * 8), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p, hist.p);
+  hipLaunchKernelGGL((k_eb_hist<false>), dim3(h->n_cus * 8), dim3(TPB), 0, st, g.view(), ShardSel{0, 1}, sel, cursor.p, hist.p);
   SRW_HIP(hipGetLastError());
   unsigned long long hh[128];
   SRW_HIP(hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, st));
@@ -350,7 +387,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   if (const char *e = getenv("SRW_EB_FAIL_ABOVE"); e && *e && bins_cap > atoi(e))      // tests: prepare_tables' fallback
     throw Error(SRW_ERR_NOMEM, "simulated allocation failure of the per-edge tables (SRW_EB_FAIL_ABOVE)");
   { const char *e = getenv("SRW_EB_NO_F32"); const int want_f32 = (e && *e == '1') ? 0 : 1;
-    if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.eb_f32 == want_f32 && g.eb_cap == bins_cap) return; }
+    if (g.has_eb && !g.eb_sharded && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.eb_f32 == want_f32 && g.eb_cap == bins_cap) return; }
   hipStream_t st = h->stream;
   g.has_eb = false; g.eb_tables = 0; g.eb_bytes = 0; g.eb_build_ms = 0.0; g.eb_complete = false;
   g.eb_bins.release(); g.em_bits.release();
@@ -379,7 +416,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   cursor.alloc(1); hist.alloc(128);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
   SRW_HIP(hipMemsetAsync(hist.p, 0, 128 * 8, st));
-  hipLaunchKernelGGL(k_eb_hist, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p, hist.p);
+  hipLaunchKernelGGL((k_eb_hist<false>), dim3(blocks), dim3(TPB), 0, st, g.view(), ShardSel{0, 1}, sel, cursor.p, hist.p);
   SRW_HIP(hipGetLastError());
   unsigned long long hh[128];
   SRW_HIP(hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, st));
@@ -402,7 +439,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   if (pairs + mpairs == 0 && sel.mask_max == 0) return;
   row_units.alloc((size_t)g.n_slots + 1); row_munits.alloc((size_t)g.n_slots + 1); row_pairs.alloc((size_t)g.n_slots + 1);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
-  hipLaunchKernelGGL(k_eb_rowsum, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p,
+  hipLaunchKernelGGL((k_eb_rowsum<false>), dim3(blocks), dim3(TPB), 0, st, g.view(), ShardSel{0, 1}, sel, cursor.p,
                      row_units.p, row_munits.p, row_pairs.p);
   SRW_HIP(hipGetLastError());
   {
@@ -420,22 +457,23 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   g.em_bits.alloc((size_t)munits * 4);
   DevBuf<uint2> items; items.alloc((size_t)all_pairs);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
-  hipLaunchKernelGGL(k_eb_assign, dim3(blocks), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, sel, cursor.p,
-                     row_units.p, row_munits.p, row_pairs.p, g.eb_off.p, items.p);
+  g.eb_sharded = false; g.ph.release(); g.ph_buckets = 0;
+  hipLaunchKernelGGL((k_eb_assign<false>), dim3(blocks), dim3(TPB), 0, st, g.view(), ShardSel{0, 1}, sel, cursor.p,
+                     row_units.p, row_munits.p, row_pairs.p, g.eb_off.p, items.p, (PairSlot *)nullptr, 0u, (uint32_t *)nullptr);
   SRW_HIP(hipGetLastError());
   g.has_eb = true; g.use_eb = true; g.eb_mask_max = sel.mask_max;
   GraphView gv = g.view();
   gv.eb_off = nullptr;                          // the builders never read the tables they are writing
   if (sel.mask_max > 0) {
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
-    hipLaunchKernelGGL(k_eb_inline, dim3(blocks), dim3(TPB), 0, st, gv, sel, cursor.p, g.eb_off.p);
+    hipLaunchKernelGGL((k_eb_inline<false>), dim3(blocks), dim3(TPB), 0, st, gv, ShardSel{0, 1}, sel, cursor.p, g.eb_off.p, (PairSlot *)nullptr, 0u);
     SRW_HIP(hipGetLastError());
   }
   unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (all_pairs) {
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
     SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
-    hipLaunchKernelGGL(k_eb_build, dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
+    hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
                        sel.bins_cap, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
@@ -450,6 +488,178 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
     fprintf(stderr, "[edge tables] up to %d chunks per table; %llu bins tables (%.2f GB, min priority %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
             "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", sel.bins_cap, pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
             sc[3], sc[4], mpairs, (double)munits * 16 / 1e9, (double)g.n_entries * 4 / 1e9, g.eb_build_ms);
+}
+
+// ---- the same tables on a vertex-sharded handle ------------------------------------------------------------------------
+// north_star's biased multi-GPU walk (directed, p = 4, q = .5 on 8 GPUs) replaces RandomWalk.scala:92-139 — the shuffle
+// ships N(prev) with every walker and the receiving partition recomputes computeSecondOrderWeights (RandomSample.scala:
+// 27-44).  Here owner(curr) holds the precomputed table of every pair (prev -> curr) into its own rows: 1 / world of the
+// whole graph's set (config 5: 168 GB -> 21 GB per GPU at world 8), found through the pair hash because a walker arrives
+// with (prev, curr) and nothing else.  The pairs are enumerated from the replicated membership structure (every shard sees
+// every (u, sorted N(u)) and keeps those whose x it owns); N(prev) for the fill and for the located chunk's probes comes
+// from the same structure.  A COMPLETE set at the finest resolution that fits, or none (the on-the-fly samplers).
+namespace {
+struct ShardTabPlan { unsigned long long units, pairs, munits, mpairs, inl; size_t bytes; uint32_t buckets; };
+
+EbSel shard_sel(int mode, int bins_cap) {
+  EbSel sel;
+  sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
+  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : 8; sel.min_cost = 0;
+  { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
+  { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
+  sel.has_ehash = 0; sel.has_hub = 1; sel.bins_cap = bins_cap;
+  return sel;
+}
+
+bool shard_plan(srw_handle *h, const EbSel &sel, ShardTabPlan &pl) {
+  Graph &g = h->g;
+  hipStream_t st = h->stream;
+  DevBuf<unsigned long long> cursor, hist;
+  cursor.alloc(1); hist.alloc(128);
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  SRW_HIP(hipMemsetAsync(hist.p, 0, 128 * 8, st));
+  hipLaunchKernelGGL((k_eb_hist<true>), dim3(h->n_cus * 8), dim3(TPB), 0, st, g.view(), ShardSel{h->cfg.rank, h->cfg.world}, sel, cursor.p, hist.p);
+  SRW_HIP(hipGetLastError());
+  unsigned long long hh[128];
+  SRW_HIP(hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  pl.units = pl.pairs = 0;
+  for (int cls = 1; cls <= 62; ++cls) { pl.units += hh[cls * 2]; pl.pairs += hh[cls * 2 + 1]; }
+  pl.munits = hh[126]; pl.mpairs = hh[127]; pl.inl = hh[1];
+  const unsigned long long all = pl.pairs + pl.mpairs + pl.inl;
+  if (all == 0 || pl.units >= 0xFFFFFFF0ull || pl.munits >= 0xFFFFFFF0ull) return false;
+  const unsigned long long nb = all * 20 / 44 + 16;                 // 4 slots per bucket at load <= 0.55
+  if (nb >= 0xFFFFFFF0ull) return false;
+  pl.buckets = (uint32_t)nb;
+  pl.bytes = (size_t)(pl.units * 64 + pl.munits * 16 + (pl.pairs + pl.mpairs) * 12 + nb * 64) + (size_t)g.n_slots * 24;
+  return true;
+}
+
+void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap, const ShardTabPlan &pl, const EbSel &sel) {
+  Graph &g = h->g;
+  hipStream_t st = h->stream;
+  const auto t0 = std::chrono::steady_clock::now();
+  const ShardSel ss{h->cfg.rank, h->cfg.world};
+  const int blocks = h->n_cus * 8;
+  g.eb_f32 = sel.f32; g.eb_cap = bins_cap; g.eb_min_sh = sel.min_sh; g.eb_mask_max = sel.mask_max;
+  DevBuf<unsigned long long> cursor, hist, row_units, row_munits, row_pairs;
+  cursor.alloc(1); hist.alloc(8);
+  row_units.alloc((size_t)g.n_slots + 1); row_munits.alloc((size_t)g.n_slots + 1); row_pairs.alloc((size_t)g.n_slots + 1);
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  hipLaunchKernelGGL((k_eb_rowsum<true>), dim3(blocks), dim3(TPB), 0, st, g.view(), ss, sel, cursor.p, row_units.p, row_munits.p, row_pairs.p);
+  SRW_HIP(hipGetLastError());
+  {
+    size_t tb = 0;
+    SRW_HIP(rocprim::exclusive_scan(nullptr, tb, row_units.p, row_units.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
+    DevBuf<char> temp; temp.alloc(tb);
+    SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_units.p, row_units.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
+    SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_munits.p, row_munits.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
+    SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_pairs.p, row_pairs.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
+    SRW_HIP(hipStreamSynchronize(st));
+  }
+  const unsigned long long all_pairs = pl.pairs + pl.mpairs;
+  g.eb_bins.alloc((size_t)pl.units * 8);
+  g.em_bits.alloc((size_t)pl.munits * 4);
+  g.ph.alloc((size_t)pl.buckets * 4); g.ph_buckets = pl.buckets;
+  SRW_HIP(hipMemsetAsync(g.ph.p, 0xFF, (size_t)pl.buckets * 4 * sizeof(PairSlot), st));
+  DevBuf<uint2> items; DevBuf<uint32_t> item_off;
+  items.alloc((size_t)all_pairs); item_off.alloc((size_t)all_pairs);
+  GraphView gv = g.view();                      // (has_eb still false: the builders never read the tables they are writing)
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  hipLaunchKernelGGL((k_eb_assign<true>), dim3(blocks), dim3(TPB), 0, st, gv, ss, sel, cursor.p, row_units.p, row_munits.p, row_pairs.p,
+                     (uint32_t *)nullptr, items.p, g.ph.p, g.ph_buckets, item_off.p);
+  SRW_HIP(hipGetLastError());
+  if (sel.mask_max > 0) {
+    SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+    hipLaunchKernelGGL((k_eb_inline<true>), dim3(blocks), dim3(TPB), 0, st, gv, ss, sel, cursor.p, (uint32_t *)nullptr, g.ph.p, g.ph_buckets);
+    SRW_HIP(hipGetLastError());
+  }
+  unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (all_pairs) {
+    SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+    SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
+    hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
+                       sel.bins_cap, item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p);
+    SRW_HIP(hipGetLastError());
+    SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
+  }
+  SRW_HIP(hipStreamSynchronize(st));
+  if (sc[7]) throw Error(SRW_ERR_INVALID, "per-edge tables: a prefix sum of a ROW_PQ_F32 row was not exactly representable in binary32");
+  uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);
+  g.eb_pbits = pb; g.eb_qbits = qb; g.eb_mode = mode;
+  g.eb_tables = (int64_t)all_pairs;
+  g.eb_bytes = (int64_t)(pl.units * 64 + pl.munits * 16 + (unsigned long long)pl.buckets * 64);
+  g.eb_complete = sel.mask_max > 0;
+  g.eb_sharded = true; g.has_eb = true; g.use_eb = true;
+  g.eb_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (getenv("SRW_TIMING"))
+    fprintf(stderr, "[shard %d/%d edge tables] up to %d chunks per table; %llu bins tables (%.2f GB; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
+            "+ %llu inline masks; pair hash %.2f GB; built in %.0f ms\n", h->cfg.rank, h->cfg.world, sel.bins_cap, pl.pairs, (double)pl.units * 64 / 1e9, sc[1], sc[2],
+            sc[3], sc[4], pl.mpairs, (double)pl.munits * 16 / 1e9, pl.inl, (double)pl.buckets * 64 / 1e9, g.eb_build_ms);
+}
+}  // namespace
+
+// Called at every super-step of a q != 1 Mode R walk (cheap once the tables stand).  Needs build_membership + build_pq_tables.
+void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
+  Graph &g = h->g;
+  const bool want = P.q != 1.0f && g.has_pq && g.has_member && g.n_entries > 0 && !(P.flags & (SRW_WALK_NO_EDGE_TABLES | SRW_WALK_NO_BINNED)) &&
+                    ((P.flags >> 12) & 7) == 0 && !getenv("SRW_SHARD_NO_TABLES");
+  if (!want) { g.use_eb = false; return; }
+  const int mode = (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0;
+  uint32_t pb, qb; memcpy(&pb, &P.p, 4); memcpy(&qb, &P.q, 4);
+  if (g.has_eb && g.eb_sharded && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode) { g.use_eb = true; return; }
+  // new (p, q) or first use: drop what stands, then size the new set against what is free
+  g.has_eb = false; g.use_eb = false; g.eb_complete = false; g.eb_tables = 0; g.eb_bytes = 0;
+  g.eb_bins.release(); g.em_bits.release(); g.ph.release(); g.ph_buckets = 0; g.eb_off.release();
+  // 1. the finest complete set that fits
+  size_t free_b = 0, total_b = 0;
+  SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+  free_b += g.hub_bm.n * sizeof(uint32_t);                  // rebuilt below with what the tables leave
+  const size_t reserve = env_gb("SRW_EB_RESERVE_GB", 16);
+  const char *env_cap = getenv("SRW_EB_CHUNKS");
+  ShardTabPlan pl; EbSel sel; int cap_sel = 0;
+  for (int cap : {256, 128, 64, 32}) {
+    if (env_cap && *env_cap) cap = std::min(std::max(atoi(env_cap), 8), BIN_CAP);
+    sel = shard_sel(mode, cap);
+    if (shard_plan(h, sel, pl) && pl.bytes + reserve < free_b && pl.bytes < env_gb("SRW_EB_BUDGET_GB", 200)) { cap_sel = cap; break; }
+    if (env_cap && *env_cap) break;
+  }
+  if (!cap_sel) {
+    if (getenv("SRW_TIMING")) fprintf(stderr, "[shard %d/%d edge tables] no complete set fits: on-the-fly samplers\n", h->cfg.rank, h->cfg.world);
+    return;
+  }
+  // 2. the located chunk's probes of a long N(prev), with what the tables leave (a shard of a sharded graph has room: its
+  //    tables are 1 / world of the set): the edge hash set of the whole graph (one probe per candidate) or, when it does not
+  //    fit, the long rows' neighbor-set filters in front of the sorted rows; neighbor-set bitmaps of the hubs take the rest
+  size_t left = (free_b - pl.bytes - reserve) / (size_t)std::max(1, h->dev_share);
+  uint64_t eh_slots = 1024;
+  while (eh_slots < (uint64_t)g.n_entries_global + (uint64_t)g.n_entries_global / 2) eh_slots <<= 1;
+  bool ehash = !(P.flags & SRW_WALK_NO_EDGE_HASH) && !getenv("SRW_EB_DROP_EHASH") && (g.has_ehash || left > eh_slots * 8 + ((size_t)8 << 30));
+  if (ehash && !g.has_ehash) { build_edge_hash(h); if (g.has_ehash) left -= eh_slots * 8; }
+  ehash = ehash && g.has_ehash;
+  if (!ehash && g.has_ehash) { g.ehash.release(); g.has_ehash = false; }
+  g.use_ehash = ehash;
+  if (!ehash && !getenv("SRW_NO_ROW_FILTERS")) build_row_filters(h);
+  const bool hubs = !(P.flags & SRW_WALK_NO_HUB_BITMAPS);
+  if (hubs) {
+    size_t hub_cap = std::min<size_t>((size_t)96 << 30, left > ((size_t)4 << 30) ? left - ((size_t)4 << 30) : 0);
+    if (const char *e = getenv("SRW_HUB_BUDGET_GB"); e && *e) hub_cap = (size_t)(atof(e) * (double)((size_t)1 << 30));
+    build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, hub_cap);
+  }
+  g.use_hub = hubs;
+  // 3. the tables (an optional accelerator never fails a walk)
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    try { build_shard_edge_tables(h, P.p, P.q, mode, cap_sel, pl, sel); return; }
+    catch (const Error &e) {
+      if (e.code != SRW_ERR_NOMEM) throw;
+      (void)hipGetLastError();
+      g.eb_bins.release(); g.em_bits.release(); g.ph.release(); g.ph_buckets = 0; g.has_eb = false;
+      if (attempt || cap_sel <= 32) break;
+      cap_sel = 32; sel = shard_sel(mode, 32);
+      if (!shard_plan(h, sel, pl)) break;
+    }
+  }
+  if (getenv("SRW_TIMING")) fprintf(stderr, "[shard %d/%d edge tables] no complete set fits: on-the-fly samplers\n", h->cfg.rank, h->cfg.world);
 }
 
 void build_rev_table(srw_handle *h) {

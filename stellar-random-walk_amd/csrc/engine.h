@@ -107,6 +107,9 @@ struct Graph {
   bool has_al = false;
   DevBuf<int32_t> verts;          // owned present vertices, ascending
   DevBuf<int32_t> vrank;          // global rank (among all present vertices) of each entry of verts
+  DevBuf<PairSlot> ph;            // sharded per-edge tables: pair (prev, curr) -> table / mask word (device_common.h)
+  uint32_t ph_buckets = 0;
+  bool eb_sharded = false;        // the standing per-edge tables are keyed by the pair hash (built by build_shard_edge_tables)
   DevBuf<uint32_t> bf_off, bf_bits; // neighbor-set filters of the rows beyond 1024 neighbors (GraphView::bf_off), built with the per-edge tables
   bool has_bf = false;
   // Compacted ids (sparse id spaces, SRW_CFG_COMPACT_IDS): slots are ranks among the sorted distinct input ids
@@ -119,9 +122,10 @@ struct Graph {
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
-                     (has_eb && use_eb) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
+                     (has_eb && use_eb && !eb_sharded) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
                      has_rev ? rev.p : nullptr, eb_cap, compact ? orig_id.p : nullptr,
-                     (has_bf && use_eb && !(has_ehash && use_ehash)) ? bf_off.p : nullptr, bf_bits.p}; }
+                     (has_bf && use_eb && !(has_ehash && use_ehash)) ? bf_off.p : nullptr, bf_bits.p,
+                     (has_eb && use_eb && eb_sharded) ? ph.p : nullptr, ph_buckets}; }
   // id <-> slot at the boundary (api.cpp): -1 if the id cannot be a vertex of this graph
   int64_t slot_of_id(int32_t v) const {
     if (!compact) { const int64_t s = (int64_t)v - vmin; return (s < 0 || s >= n_slots) ? -1 : s; }
@@ -160,6 +164,7 @@ struct srw_handle {
   srw::DevBuf<unsigned long long> walk_cursor;   // [0] next walker of the persistent kernels, [1] walkers handed over by k_walk_tables
   srw::DevBuf<int32_t> walk_todo;                // their indices
   int n_cus = 256;
+  int dev_share = 1;                             // handles of one cluster on this device (virtual shards of a single-GPU box): optional structures take 1 / dev_share of what is free
   srw::DevBuf<char> shard_scratch;               // sampled 32-byte records before bucketing (persistent)
   srw::DevBuf<uint32_t> shard_blk;               // [blocks][2 * world] per-block survivor / return counts, then write cursors
   srw::DevBuf<uint32_t> shard_flag;              // chunk overflow flag of the sharded walk
@@ -178,6 +183,9 @@ struct srw_handle {
 };
 
 namespace srw {
+
+// ---- api.cpp ----
+void set_create_error(const std::string &m);     // message behind srw_last_error(NULL)
 
 // ---- edgelist.cpp (host) ----
 // Uninitialised, non-copyable array: the tokenizer's threads fill it in place (a std::vector would zero 268 MB first
@@ -270,6 +278,9 @@ void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap);   // 
 // HBM budget), 1 = every certified pair (tests: tiny chunks, no cost threshold).  Needs build_pq_tables first.
 void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap);
 size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap);   // HBM of a complete set of per-edge tables (0: none possible)
+// Vertex-sharded handles (and whole-graph handles walked through srw_shard_*): the tables of the pairs (prev -> curr) whose
+// curr this handle owns, keyed by the pair hash; a complete set at the finest resolution that fits, or none.
+void prepare_shard_tables(srw_handle *h, const srw_walk_params &P);
 void build_rev_table(srw_handle *h);             // return-edge positions (k_walk_q1: p != 1, q == 1)
 
 // ---- walk_kernels.hip ----

@@ -168,7 +168,8 @@ __global__ void k_bf_offsets(const Row *__restrict__ rows, int64_t n_slots, cons
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x)
     off[v] = rows[v].deg >= BF_MIN_DEG ? (uint32_t)pre[v] : BF_NONE;
 }
-__global__ void k_bf_fill(const Row *__restrict__ rows, const Ent *__restrict__ ent, int64_t n_slots, int32_t vmin,
+// msids != null: rows / ids come from the replicated membership structure of a sharded handle (slot ids, sorted)
+__global__ void k_bf_fill(const Row *__restrict__ rows, const Ent *__restrict__ ent, const uint32_t *__restrict__ msids, int64_t n_slots, int32_t vmin,
                           const uint32_t *__restrict__ off, uint32_t *__restrict__ bits, unsigned long long *next_slot) {
   const int lane = threadIdx.x & 63;
   while (true) {
@@ -184,7 +185,7 @@ __global__ void k_bf_fill(const Row *__restrict__ rows, const Ent *__restrict__ 
       uint32_t *f = bits + off[v];
       for (int32_t k = lane; k < r.deg; k += 64) {
         uint32_t word, mask;
-        bf_hash((uint32_t)((int64_t)ent[r.off + k].id - vmin), nw, word, mask);
+        bf_hash(msids ? msids[r.off + k] : (uint32_t)((int64_t)ent[r.off + k].id - vmin), nw, word, mask);
         atomicOr(&f[word], mask);
       }
     }
@@ -380,12 +381,15 @@ void compact_ids(srw_handle *h, int32_t *d_src, int32_t *d_dst, int64_t n_lines,
 // Optional accelerator of the table steps (binned_resolve): skipped when HBM is short or the offsets would not fit 32 bits.
 void build_row_filters(srw_handle *h) {
   Graph &g = h->g;
-  if (g.has_bf || g.n_entries <= 0 || h->cfg.world != 1) return;
+  if (g.has_bf || g.n_entries_global <= 0) return;
+  if (h->cfg.world != 1 && !g.mrows.p) return;          // a shard without the membership structure never asks "x in N(prev)?"
   hipStream_t st = h->stream;
+  const Row *frows = g.mrows.p ? g.mrows.p : g.rows.p;   // N(prev) of ANY vertex: the whole graph's rows
+  const uint32_t *fsids = g.mrows.p ? g.msids.p : nullptr;
   DevBuf<unsigned long long> sizes, next_slot; DevBuf<char> temp;
   sizes.alloc((size_t)g.n_slots + 1); next_slot.alloc(1);
   SRW_HIP(hipMemsetAsync(sizes.p + g.n_slots, 0, 8, st));
-  hipLaunchKernelGGL(k_bf_sizes, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, g.rows.p, g.n_slots, sizes.p);
+  hipLaunchKernelGGL(k_bf_sizes, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, frows, g.n_slots, sizes.p);
   size_t tb = 0;
   SRW_HIP(rocprim::exclusive_scan(nullptr, tb, sizes.p, sizes.p, 0ull, (size_t)g.n_slots + 1, rocprim::plus<unsigned long long>(), st));
   temp.alloc(tb);
@@ -396,12 +400,12 @@ void build_row_filters(srw_handle *h) {
   if (total == 0 || total >= 0xFFFFFFF0ull) return;
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));
-  if (free_b < (size_t)total * 4 + (size_t)g.n_slots * 4 + ((size_t)32 << 30)) return;
+  if (free_b < (size_t)total * 4 + (size_t)g.n_slots * 4 + ((size_t)(h->cfg.world > 1 ? 8 : 32) << 30)) return;
   g.bf_off.alloc((size_t)g.n_slots); g.bf_bits.alloc((size_t)total);
-  hipLaunchKernelGGL(k_bf_offsets, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, g.rows.p, g.n_slots, sizes.p, g.bf_off.p);
+  hipLaunchKernelGGL(k_bf_offsets, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, frows, g.n_slots, sizes.p, g.bf_off.p);
   SRW_HIP(hipMemsetAsync(g.bf_bits.p, 0, (size_t)total * 4, st));
   SRW_HIP(hipMemsetAsync(next_slot.p, 0, 8, st));
-  hipLaunchKernelGGL(k_bf_fill, dim3(256 * 8), dim3(TPB), 0, st, g.rows.p, g.ent.p, g.n_slots, g.vmin, g.bf_off.p, g.bf_bits.p, next_slot.p);
+  hipLaunchKernelGGL(k_bf_fill, dim3(256 * 8), dim3(TPB), 0, st, frows, g.ent.p, fsids, g.n_slots, g.vmin, g.bf_off.p, g.bf_bits.p, next_slot.p);
   SRW_HIP(hipGetLastError());
   SRW_HIP(hipStreamSynchronize(st));
   g.has_bf = true;
@@ -598,7 +602,7 @@ __global__ void k_hub_assign(Row *__restrict__ rows, int64_t n_slots, int32_t th
     rows[v].flags = f;
   }
 }
-__global__ void k_hub_fill(const Row *__restrict__ rows, const Ent *__restrict__ ent, const uint32_t *__restrict__ hub_slot,
+__global__ void k_hub_fill(const Row *__restrict__ rows, const Ent *__restrict__ ent, const uint32_t *__restrict__ msids, const uint32_t *__restrict__ hub_slot,
                            int64_t n_hubs, int32_t vmin, int64_t words, uint32_t *__restrict__ bm,
                            unsigned long long *next_hub) {
   const int lane = threadIdx.x & 63;
@@ -611,7 +615,7 @@ __global__ void k_hub_fill(const Row *__restrict__ rows, const Ent *__restrict__
     const Row r = rows[hub_slot[grab]];
     uint32_t *mine = bm + (int64_t)grab * words;
     for (int32_t k = lane; k < r.deg; k += 64) {
-      const uint32_t x = (uint32_t)((int64_t)ent[r.off + k].id - vmin);
+      const uint32_t x = msids ? msids[r.off + k] : (uint32_t)((int64_t)ent[r.off + k].id - vmin);
       atomicOr(&mine[x >> 5], 1u << (x & 31));
     }
   }
@@ -627,6 +631,11 @@ void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap) {
   if (g.has_hub && g.hub_min_deg == min_deg && g.hub_budget_cap == budget_cap) return;
   hipStream_t st = h->stream;
   g.has_hub = false; g.n_hubs = 0;
+  // A sharded handle asks "x in N(prev)?" for a prev it does not own: the hubs are those of the WHOLE graph, their ordinals
+  // live in the membership rows (Row::flags of mrows, otherwise unused) and their bitmaps are filled from the sorted ids.
+  Row *hrows = g.mrows.p ? g.mrows.p : g.rows.p;
+  const uint32_t *hsids = g.mrows.p ? g.msids.p : nullptr;
+  if (h->cfg.world != 1 && !g.mrows.p) { g.has_hub = true; g.hub_min_deg = min_deg; g.hub_budget_cap = budget_cap; return; }
   const int64_t words = (g.n_slots + 31) / 32;
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -639,7 +648,7 @@ void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap) {
   if (max_hubs > 0 && g.n_slots > max_hubs) {
     DevBuf<uint32_t> d_in, d_out; DevBuf<char> temp;
     d_in.alloc((size_t)g.n_slots); d_out.alloc((size_t)g.n_slots);
-    hipLaunchKernelGGL(k_hub_degrees, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, g.rows.p, g.n_slots, d_in.p);
+    hipLaunchKernelGGL(k_hub_degrees, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, hrows, g.n_slots, d_in.p);
     size_t tb = 0;
     SRW_HIP(rocprim::radix_sort_keys_desc(nullptr, tb, d_in.p, d_out.p, (size_t)g.n_slots, 0u, 32u, st));
     temp.alloc(tb);
@@ -653,7 +662,7 @@ void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap) {
   DevBuf<uint32_t> hub_slot; hub_slot.alloc((size_t)std::max<int64_t>(max_hubs, 1));
   SRW_HIP(hipMemsetAsync(counter.p, 0, 8, st));
   // max_hubs == 0 (no memory): the kernel still clears stale ordinals
-  hipLaunchKernelGGL(k_hub_assign, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, g.rows.p, g.n_slots, thr,
+  hipLaunchKernelGGL(k_hub_assign, dim3(grid_for(g.n_slots)), dim3(TPB), 0, st, hrows, g.n_slots, thr,
                      (unsigned long long)std::max<int64_t>(max_hubs, 0), counter.p, hub_slot.p);
   unsigned long long n = 0;
   SRW_HIP(hipMemcpyAsync(&n, counter.p, 8, hipMemcpyDeviceToHost, st));
@@ -665,7 +674,7 @@ void build_hub_bitmaps(srw_handle *h, int32_t min_deg, size_t budget_cap) {
     g.hub_bm.alloc((size_t)g.n_hubs * words);
     SRW_HIP(hipMemsetAsync(g.hub_bm.p, 0, (size_t)g.n_hubs * words * 4, st));
     SRW_HIP(hipMemsetAsync(counter.p, 0, 8, st));
-    hipLaunchKernelGGL(k_hub_fill, dim3(256 * 8), dim3(TPB), 0, st, g.rows.p, g.ent.p, hub_slot.p, g.n_hubs, g.vmin, words,
+    hipLaunchKernelGGL(k_hub_fill, dim3(256 * 8), dim3(TPB), 0, st, hrows, g.ent.p, hsids, hub_slot.p, g.n_hubs, g.vmin, words,
                        g.hub_bm.p, counter.p);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipStreamSynchronize(st));

@@ -154,6 +154,61 @@ __device__ inline FoEnt fo_pick(const FoEnt *row, int32_t deg, float r, int32_t 
   return e;
 }
 
+// ---- certified parallel form -----------------------------------------------------------------------------
+// Membership of the candidates in N(prev), resolved once per step into an LDS bitmap over the candidate
+// positions ("reverse" marking: each element of the usually short N(prev) is looked up in the sorted N(curr)
+// and its occurrences' input-order positions are marked), or per candidate by binary search when that is
+// cheaper.  Both give the same booleans as prevNeighbors.exists(_._1 == dstId) (:37).
+constexpr int BM_WORDS = 2048;               // per-wave LDS bitmap: 65536 candidate positions per segment
+constexpr int BM_BITS = BM_WORDS * 32;
+
+struct Member {
+  int mode;            // 0: not needed, 1: binary search per candidate, 2: bitmap
+  uint32_t *bm;        // LDS, BM_WORDS words, private to the wave
+  int32_t seg_base;    // first candidate position covered by the bitmap
+  const uint64_t *ehash = nullptr; uint64_t ehash_mask = 0;   // edge hash set (whole-graph handles): mode 1 probes it
+  const uint32_t *hub = nullptr;   // this step's N(prev) bitmap over the id slots, if prev is a hub: mode 1 reads one bit
+  const uint32_t *bf = nullptr; uint32_t bf_nw = 0;   // N(prev)'s neighbor-set filter (device_common.h:bf_hash): a negative needs no search
+  unsigned long long res_bytes = 0;   // binned_resolve: bytes of the candidates it evaluated (entries + prefix sums), bench.py
+#ifdef SRW_PHASE_TIMING
+  unsigned long long t_fill = 0, t_pass1 = 0, t_pass2 = 0, t_prefix = 0, t_mark;
+  unsigned long long t_a = 0, t_p1 = 0, t_p2 = 0, t_w = 0, t_fin = 0;
+  unsigned long long t_w_lb = 0, t_w_ins = 0, t_w_la = 0, t_w_probe = 0, t_mark2;
+  unsigned long long n_w = 0, n_w_elems = 0, n_w_windows = 0, n_p1 = 0, n_p1_elems = 0, n_binned = 0;
+  unsigned long long t_strat[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_step0 = 0;   // wave time per SRW_STRAT_* (whole step)
+#endif
+};
+#ifdef SRW_PHASE_TIMING
+#define SRW_T0(m) ((m).t_mark = wall_clock64())
+#define SRW_T1(m, f) ((m).f += wall_clock64() - (m).t_mark)
+#define SRW_U0(m) ((m).t_mark2 = wall_clock64())
+#define SRW_U1(m, f) ((m).f += wall_clock64() - (m).t_mark2)
+#define SRW_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define SRW_T0(m)
+#define SRW_T1(m, f)
+#define SRW_U0(m)
+#define SRW_U1(m, f)
+#define SRW_DRAIN()
+#endif
+
+__device__ inline float biased_weight_m(const Bias &b, const Member &m, int32_t pos, int32_t id, float w) {
+  if (!b.second_order) return w;
+  if (id == b.prev) return div_exact(w, b.p);
+  if (m.mode == 0) return div_exact(w, b.q);
+  bool in;
+  if (m.mode == 2) { uint32_t t = (uint32_t)(pos - m.seg_base); in = (m.bm[t >> 5] >> (t & 31)) & 1u; }
+  else if (m.hub) { const uint32_t x = (uint32_t)((int64_t)id - b.vmin); in = (m.hub[x >> 5] >> (x & 31)) & 1u; }
+  else if (m.ehash) in = edge_exists(m.ehash, m.ehash_mask, (uint32_t)((int64_t)b.prev - b.vmin), (uint32_t)((int64_t)id - b.vmin));
+  else {
+    const uint32_t x = (uint32_t)((int64_t)id - b.vmin);
+    in = true;
+    if (m.bf) { uint32_t word, mask; bf_hash(x, m.bf_nw, word, mask); in = (m.bf[word] & mask) == mask; }
+    if (in) in = sorted_contains(b.prev_sids, b.prev_deg, x);
+  }
+  return in ? w : div_exact(w, b.q);
+}
+
 // ---- exact pick, one wave per walker (general p, q) -----------------------------------------------------
 // Sequential-chain form: all 64 lanes call with identical arguments.  Returns the chosen position
 // (wave-uniform).  S_known: pass the already-computed sum (fallback of wave_pick_scan) or NaN to compute it.
@@ -214,49 +269,154 @@ __device__ inline unsigned long long shfl_up_u64(unsigned long long v, int off) 
   return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
-__device__ inline int32_t wave_chain_pick(const Ent *row, int32_t deg, const Bias &b, float r, double S) {
+// N edge-hash probes per lane in lockstep: the probe loads of one round are independent, so N candidates cost the
+// round trips of one.
+template <int N>
+__device__ inline void edge_exists_n(const uint64_t *tab, uint64_t mask, uint32_t row_slot, const uint32_t (&id_slot)[N],
+                                     const bool (&want)[N], bool (&out)[N]) {
+  uint64_t key[N], s[N]; bool act[N];
+  bool any = false;
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    key[u] = ((uint64_t)row_slot << 32) | id_slot[u];
+    s[u] = edge_hash(key[u], mask); act[u] = want[u]; out[u] = false; any |= act[u];
+  }
+  while (any) {
+    uint64_t v[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = act[u] ? tab[s[u]] : 0ull;
+    any = false;
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+      if (act[u]) {
+        if (v[u] == key[u]) { out[u] = true; act[u] = false; }
+        else if (v[u] == 0xFFFFFFFFFFFFFFFFull) act[u] = false;
+        else s[u] = (s[u] + 1) & mask;
+        any |= act[u];
+      }
+  }
+}
+
+// mem (optional, mode 1): the step's fast membership test — the chain runs over the WHOLE row up to the answer, and a draw
+// on a CDF boundary of a hub row used to pay one binary search of N(prev) per candidate (tens of ms for one step: the tail
+// of every super-step of the sharded walk, and of the single-launch kernel when it lands late).
+// 256 candidates per round: the four entry loads and the four membership probes of a lane are in flight together (the
+// chain itself stays sequential over the groups of 64: its latency is the scan, not the memory).
+#ifdef SRW_CHAIN_NOINLINE
+#define SRW_CHAIN_ATTR __attribute__((noinline))
+#else
+#define SRW_CHAIN_ATTR inline
+#endif
+__device__ SRW_CHAIN_ATTR int32_t wave_chain_pick(const Ent *row, int32_t deg, const Bias &b, float r, double S, const Member *mem = nullptr) {
   const int lane = lane_id();
   const double p = (double)r;
   double acc = 0.0;                                      // wave-uniform
-  for (int32_t base = 0; base < deg; base += 64) {
-    const int32_t k = base + lane;
-    double d = 0.0;
-    if (k < deg) { Ent e = row[k]; d = (double)biased_weight(b, e.id, e.w) / S; }
-    const int cnt = min(64, deg - base);
-    int start = 0;
-    while (start < cnt) {
+  for (int32_t base4 = 0; base4 < deg; base4 += 256) {
+    Ent e4[4]; double d4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int32_t k = base4 + u * 64 + lane; e4[u].id = 0; e4[u].w = 0.0f; if (k < deg) e4[u] = row[k]; }
+    if (mem && mem->mode == 1 && b.second_order && (mem->hub || mem->ehash)) {
+      // the four membership tests of a lane in lockstep (independent loads; edge_exists' probe loop would serialise them)
+      uint32_t xs[4]; bool want[4], in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xs[u] = (uint32_t)((int64_t)e4[u].id - b.vmin);
+        want[u] = base4 + u * 64 + lane < deg && e4[u].id != b.prev;
+        in[u] = false;
+      }
+      if (mem->hub) {
+        uint32_t wd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wd[u] = want[u] ? mem->hub[xs[u] >> 5] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) in[u] = (wd[u] >> (xs[u] & 31)) & 1u;
+      } else {
+        edge_exists_n<4>(mem->ehash, mem->ehash_mask, (uint32_t)((int64_t)b.prev - b.vmin), xs, want, in);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d4[u] = 0.0;
+        if (base4 + u * 64 + lane < deg) {
+          const float w = e4[u].w;
+          d4[u] = (double)(e4[u].id == b.prev ? div_exact(w, b.p) : in[u] ? w : div_exact(w, b.q)) / S;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int32_t k = base4 + u * 64 + lane;
+        d4[u] = 0.0;
+        if (k < deg) d4[u] = (double)(mem ? biased_weight_m(b, *mem, k, e4[u].id, e4[u].w) : biased_weight(b, e4[u].id, e4[u].w)) / S;
+      }
+    }
+    // Fast path for the whole round: while the accumulator stays inside its binade and no element sits exactly on a
+    // rounding tie (c0 == c1: its increment does not depend on the accumulator's parity), the 256 maps N -> N + c commute,
+    // so the round is ONE exact integer sum; and with every d >= 0 the accumulator is non-decreasing: if it is still below
+    // p after the round, no element of the round was the answer.  Otherwise (a tie, a binade crossing, the answer's round,
+    // a negative / non-finite quotient) the round is evaluated group by group below.
+    {
       const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
       const int ea = (int)((ab >> 52) & 0x7FFull);
-      int f = start;                                     // acc zero / subnormal / not finite: one plain addition
       if (!(ea == 0 || ea == 0x7FF || (ab >> 63))) {
-        const int e = ea - 1023;
         const unsigned long long N0 = (ab & ((1ull << 52) - 1ull)) | (1ull << 52);
-        unsigned long long c0 = 0ull, c1 = 0ull;
-        if (lane >= start && lane < cnt) chain_elem_map(d, e, c0, c1);
+        unsigned long long loc = 0ull; bool odd = false;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const unsigned long long f0 = shfl_up_u64(c0, off), f1 = shfl_up_u64(c1, off);
-          if (lane >= off) {
-            const unsigned long long g0 = c0, g1 = c1;
-            c0 = f0 + ((f0 & 1ull) ? g1 : g0);
-            c1 = f1 + (((f1 + 1ull) & 1ull) ? g1 : g0);
+        for (int u = 0; u < 4; ++u) {
+          unsigned long long c0 = 0ull, c1 = 0ull;
+          if (base4 + u * 64 + lane < deg) chain_elem_map(d4[u], ea - 1023, c0, c1);
+          odd |= (c0 != c1) || (c0 >> 53);
+          loc += c0;
+        }
+        if (!__any(odd)) {
+          const unsigned long long total = wave_sum_u64(loc);
+          if (N0 + total < (1ull << 53)) {
+            const double a = __longlong_as_double((long long)(((unsigned long long)ea << 52) | ((N0 + total) & ((1ull << 52) - 1ull))));
+            if (a < p) { acc = a; continue; }
           }
         }
-        const unsigned long long N = N0 + ((N0 & 1ull) ? c1 : c0);
-        const bool mine = lane >= start && lane < cnt;
-        const unsigned long long cross = __ballot(mine && N >= (1ull << 53));
-        f = cross ? __ffsll((long long)cross) - 1 : -1;
-        const int lim = f < 0 ? cnt : f;
-        // inside the binade N < 2^53: the accumulator after my element, exactly
-        const double a = __longlong_as_double((long long)(((unsigned long long)ea << 52) | (N & ((1ull << 52) - 1ull))));
-        const unsigned long long hit = __ballot(lane >= start && lane < lim && a >= p);
-        if (hit) return base + (__ffsll((long long)hit) - 1);
-        if (f < 0) { acc = readlane_f64(a, cnt - 1); break; }
-        if (f > start) acc = readlane_f64(a, f - 1);
       }
-      acc = acc + readlane_f64(d, f);
-      if (acc >= p) return base + f;
-      start = f + 1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int32_t base = base4 + u * 64;
+      if (base >= deg) break;                            // wave-uniform
+      const double d = d4[u];
+      const int cnt = min(64, deg - base);
+      int start = 0;
+      while (start < cnt) {
+        const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
+        const int ea = (int)((ab >> 52) & 0x7FFull);
+        int f = start;                                     // acc zero / subnormal / not finite: one plain addition
+        if (!(ea == 0 || ea == 0x7FF || (ab >> 63))) {
+          const int e = ea - 1023;
+          const unsigned long long N0 = (ab & ((1ull << 52) - 1ull)) | (1ull << 52);
+          unsigned long long c0 = 0ull, c1 = 0ull;
+          if (lane >= start && lane < cnt) chain_elem_map(d, e, c0, c1);
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long f0 = shfl_up_u64(c0, off), f1 = shfl_up_u64(c1, off);
+            if (lane >= off) {
+              const unsigned long long g0 = c0, g1 = c1;
+              c0 = f0 + ((f0 & 1ull) ? g1 : g0);
+              c1 = f1 + (((f1 + 1ull) & 1ull) ? g1 : g0);
+            }
+          }
+          const unsigned long long N = N0 + ((N0 & 1ull) ? c1 : c0);
+          const bool mine = lane >= start && lane < cnt;
+          const unsigned long long cross = __ballot(mine && N >= (1ull << 53));
+          f = cross ? __ffsll((long long)cross) - 1 : -1;
+          const int lim = f < 0 ? cnt : f;
+          // inside the binade N < 2^53: the accumulator after my element, exactly
+          const double a = __longlong_as_double((long long)(((unsigned long long)ea << 52) | (N & ((1ull << 52) - 1ull))));
+          const unsigned long long hit = __ballot(lane >= start && lane < lim && a >= p);
+          if (hit) return base + (__ffsll((long long)hit) - 1);
+          if (f < 0) { acc = readlane_f64(a, cnt - 1); break; }
+          if (f > start) acc = readlane_f64(a, f - 1);
+        }
+        acc = acc + readlane_f64(d, f);
+        if (acc >= p) return base + f;
+        start = f + 1;
+      }
     }
   }
   return 0;  // edges.head (:24)
@@ -265,55 +425,6 @@ __device__ inline int32_t wave_chain_pick(const Ent *row, int32_t deg, const Bia
 __device__ inline int32_t wave_pick(const Ent *row, int32_t deg, const Bias &b, float r, unsigned &fallback) {
   double S = wave_sum_exact_or_chain(row, deg, b, fallback);   // S = foldLeft(0.0)(_ + w')  (:14)
   return wave_chain_pick(row, deg, b, r, S);
-}
-
-// ---- certified parallel form -----------------------------------------------------------------------------
-// Membership of the candidates in N(prev), resolved once per step into an LDS bitmap over the candidate
-// positions ("reverse" marking: each element of the usually short N(prev) is looked up in the sorted N(curr)
-// and its occurrences' input-order positions are marked), or per candidate by binary search when that is
-// cheaper.  Both give the same booleans as prevNeighbors.exists(_._1 == dstId) (:37).
-constexpr int BM_WORDS = 2048;               // per-wave LDS bitmap: 65536 candidate positions per segment
-constexpr int BM_BITS = BM_WORDS * 32;
-
-struct Member {
-  int mode;            // 0: not needed, 1: binary search per candidate, 2: bitmap
-  uint32_t *bm;        // LDS, BM_WORDS words, private to the wave
-  int32_t seg_base;    // first candidate position covered by the bitmap
-  const uint64_t *ehash = nullptr; uint64_t ehash_mask = 0;   // edge hash set (whole-graph handles): mode 1 probes it
-  const uint32_t *hub = nullptr;   // this step's N(prev) bitmap over the id slots, if prev is a hub: mode 1 reads one bit
-  unsigned long long res_bytes = 0;   // binned_resolve: bytes of the candidates it evaluated (entries + prefix sums), bench.py
-#ifdef SRW_PHASE_TIMING
-  unsigned long long t_fill = 0, t_pass1 = 0, t_pass2 = 0, t_prefix = 0, t_mark;
-  unsigned long long t_a = 0, t_p1 = 0, t_p2 = 0, t_w = 0, t_fin = 0;
-  unsigned long long t_w_lb = 0, t_w_ins = 0, t_w_la = 0, t_w_probe = 0, t_mark2;
-  unsigned long long n_w = 0, n_w_elems = 0, n_w_windows = 0, n_p1 = 0, n_p1_elems = 0, n_binned = 0;
-  unsigned long long t_strat[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_step0 = 0;   // wave time per SRW_STRAT_* (whole step)
-#endif
-};
-#ifdef SRW_PHASE_TIMING
-#define SRW_T0(m) ((m).t_mark = wall_clock64())
-#define SRW_T1(m, f) ((m).f += wall_clock64() - (m).t_mark)
-#define SRW_U0(m) ((m).t_mark2 = wall_clock64())
-#define SRW_U1(m, f) ((m).f += wall_clock64() - (m).t_mark2)
-#define SRW_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define SRW_T0(m)
-#define SRW_T1(m, f)
-#define SRW_U0(m)
-#define SRW_U1(m, f)
-#define SRW_DRAIN()
-#endif
-
-__device__ inline float biased_weight_m(const Bias &b, const Member &m, int32_t pos, int32_t id, float w) {
-  if (!b.second_order) return w;
-  if (id == b.prev) return div_exact(w, b.p);
-  if (m.mode == 0) return div_exact(w, b.q);
-  bool in;
-  if (m.mode == 2) { uint32_t t = (uint32_t)(pos - m.seg_base); in = (m.bm[t >> 5] >> (t & 31)) & 1u; }
-  else if (m.hub) { const uint32_t x = (uint32_t)((int64_t)id - b.vmin); in = (m.hub[x >> 5] >> (x & 31)) & 1u; }
-  else if (m.ehash) in = edge_exists(m.ehash, m.ehash_mask, (uint32_t)((int64_t)b.prev - b.vmin), (uint32_t)((int64_t)id - b.vmin));
-  else in = sorted_contains(b.prev_sids, b.prev_deg, (uint32_t)((int64_t)id - b.vmin));
-  return in ? w : div_exact(w, b.q);
 }
 
 // Mark the candidates of segment [seg_base, seg_base + seg_len) that occur in N(prev).
@@ -973,34 +1084,6 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
   strat_used = (unsigned)strat;
 }
 
-// N edge-hash probes per lane in lockstep: the probe loads of one round are independent, so N candidates cost the
-// round trips of one.
-template <int N>
-__device__ inline void edge_exists_n(const uint64_t *tab, uint64_t mask, uint32_t row_slot, const uint32_t (&id_slot)[N],
-                                     const bool (&want)[N], bool (&out)[N]) {
-  uint64_t key[N], s[N]; bool act[N];
-  bool any = false;
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    key[u] = ((uint64_t)row_slot << 32) | id_slot[u];
-    s[u] = edge_hash(key[u], mask); act[u] = want[u]; out[u] = false; any |= act[u];
-  }
-  while (any) {
-    uint64_t v[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) v[u] = act[u] ? tab[s[u]] : 0ull;
-    any = false;
-#pragma unroll
-    for (int u = 0; u < N; ++u)
-      if (act[u]) {
-        if (v[u] == key[u]) { out[u] = true; act[u] = false; }
-        else if (v[u] == 0xFFFFFFFFFFFFFFFFull) act[u] = false;
-        else s[u] = (s[u] + 1) & mask;
-        any |= act[u];
-      }
-  }
-}
-
 // Given the exact inclusive chunk prefixes of the corrections: 64-ary search over the chunk ends for the ONE chunk
 // holding the first not-certain-miss index, then that chunk candidate by candidate.  -1: not applicable.
 //   ABS = false: `bins` is the wave's LDS right after binned_fill, bins[j] = corrections up to the end of chunk j
@@ -1113,6 +1196,12 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     if (bo != BF_NONE) { bf = g.bf_bits + bo; bf_nw = bf_words(m); }
   }
   served = 1;
+  // membership for the exact chain, should the draw sit on a CDF boundary: the same tests, candidate by candidate
+  Member cm; cm.mode = 1; cm.bm = nullptr; cm.seg_base = 0; cm.hub = hubbits; cm.ehash = g.ehash; cm.ehash_mask = g.ehash_mask;
+  if (!hubbits && !g.ehash && g.bf_off && m >= BF_MIN_DEG) {
+    const uint32_t bo = g.bf_off[xprev];
+    if (bo != BF_NONE) { cm.bf = g.bf_bits + bo; cm.bf_nw = bf_words(m); }
+  }
 #ifdef SRW_PHASE_TIMING
   tm.n_binned += 1;                                             // resolved chunks ...
   tm.n_w_elems += (unsigned long long)(k1 - k0 + 1);             // ... their candidates
@@ -1194,7 +1283,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
         const int f = __ffsll((long long)mm) - 1;
         if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(e[u].id, f); return base + u * 64 + f; }
         fallback = 1;
-        const int32_t kk = wave_chain_pick(row, deg, b, r, S);
+        const int32_t kk = wave_chain_pick(row, deg, b, r, S, &cm);
         id_out = row[kk].id;
         return kk;
       }
@@ -1202,7 +1291,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     }
   }
   fallback = 1;
-  const int32_t kk = wave_chain_pick(row, deg, b, r, S);
+  const int32_t kk = wave_chain_pick(row, deg, b, r, S, &cm);
   id_out = row[kk].id;
   return kk;
 }

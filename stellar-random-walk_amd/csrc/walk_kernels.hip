@@ -137,7 +137,7 @@ __device__ inline Bias make_bias(const GraphView &g, float p, float q, int32_t p
   b.prev_sids = nullptr; b.prev_deg = 0; b.vmin = g.vmin;
   if (b.need_member) {   // N(prev) through the membership structure (replicated on every shard)
     int64_t s = (int64_t)prev - g.vmin;
-    if (s >= 0 && s < g.n_slots) { Row r = g.mrows[s]; b.prev_sids = g.msids + r.off; b.prev_deg = r.deg; }
+    if (s >= 0 && s < g.n_slots) { Row r = g.mrows[s]; b.prev_sids = g.msids + r.off; b.prev_deg = r.deg; b.prev_hub = r.flags >> ROW_HUB_SHIFT; }
   }
   return b;
 }
@@ -883,23 +883,28 @@ __device__ inline uint64_t shard_link_of(const Row &r) {
   return ((uint64_t)r.off & CFO_NOFF_MASK) | ((uint64_t)(uint32_t)min(r.deg, (int32_t)CFO_NDEG_MAX) << 40) |
          ((uint64_t)((r.flags & ROW_IRREGULAR) != 0) << 63);
 }
+// A shard's own seeds must fit the chunks of its receive buffer: n_local * batch / world per chunk against a capacity sized
+// from nVertices / world^2 — skewed ownership (SRW_CFG_OWNER_FROM_PARTITIONS with fewer partitions than GPUs) breaks that,
+// so the surplus is dropped and the overflow flag raised like everywhere else (the batch is redone with more slack).
 __global__ void k_sh_seed(const int32_t *__restrict__ verts, int64_t n_local, ShardIO io, char *recv_w,
                           int32_t *__restrict__ paths, int32_t *__restrict__ lens, int64_t stride,
-                          const Row *__restrict__ link_rows, int32_t vmin) {
+                          const Row *__restrict__ link_rows, int32_t vmin, uint32_t *overflow) {
   const int64_t n = n_local * io.batch;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t src = verts[i / io.batch];
     SWalker w; w.lw = (int32_t)i; w.src = src; w.prev = src; w.curr = src; w.h0 = src; w.h1 = 0; w.h2 = 0; w.kind = SK_WALKER;
     if (link_rows) { const uint64_t l = shard_link_of(link_rows[(int64_t)src - vmin]); w.prev = (int32_t)(uint32_t)l; w.kind = (int32_t)(uint32_t)(l >> 32); }
     const int c = (int)(i % io.world);
-    reinterpret_cast<SWalker *>(recv_w + c * io.chunk_bytes + 16)[i / io.world] = w;
+    if (i / io.world < (int64_t)io.cap_w) reinterpret_cast<SWalker *>(recv_w + c * io.chunk_bytes + 16)[i / io.world] = w;
     paths[i * stride] = src;
     lens[i] = (int32_t)stride;        // full length unless a death notice says otherwise (k_sh_apply)
   }
   if (blockIdx.x == 0 && (int)threadIdx.x < io.world) {
     const int c = (int)threadIdx.x;
     uint32_t *h = reinterpret_cast<uint32_t *>(recv_w + c * io.chunk_bytes);
-    h[0] = (uint32_t)((n - c + io.world - 1) / io.world); h[1] = 0u; h[2] = 0u; h[3] = 0u;
+    const int64_t mine = (n - c + io.world - 1) / io.world;
+    if (mine > (int64_t)io.cap_w) atomicOr(overflow, 1u);
+    h[0] = (uint32_t)(mine < (int64_t)io.cap_w ? mine : (int64_t)io.cap_w); h[1] = 0u; h[2] = 0u; h[3] = 0u;
   }
 }
 
@@ -923,9 +928,12 @@ __global__ void k_sh_apply(ShardIO io, int32_t *__restrict__ paths, int32_t *__r
   }
 }
 
+// todo != null: only the records listed there (those k_sh_step_tab found no table for); k_sh_scatter then buckets the
+// whole scratch array, so no per-block counts are produced.
 __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
                                                     RngSpec rng, float p, float q, SWalker *__restrict__ scratch,
-                                                    uint32_t *__restrict__ blk, DevCounters *ctr) {
+                                                    uint32_t *__restrict__ blk, DevCounters *ctr,
+                                                    const uint32_t *__restrict__ todo, const unsigned long long *todo_n) {
   __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
   __shared__ uint32_t cnt[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
   __shared__ unsigned long long red[6];
@@ -935,9 +943,13 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
   const uint32_t n_in = shard_in_prefix(io, pre);          // contains the __syncthreads() cnt / red need
   Member mem; mem.mode = 0; mem.bm = bitmap[wv]; mem.seg_base = 0;
   unsigned long long steps = 0, dead = 0, degc = 0, degp = 0, fb = 0;
+  uint32_t n_strat[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // SRW_STRAT_* 0 .. 7 (lane 0 counts)
   uint32_t lo, hi;
   shard_slice(n_in, TPB / 64, lo, hi);
-  for (uint32_t ri = lo + wv; ri < hi; ri += TPB / 64) {     // one wave per record
+  uint32_t t_step = TPB / 64;
+  if (todo) { lo = blockIdx.x * (TPB / 64); hi = (uint32_t)*todo_n; t_step = gridDim.x * (TPB / 64); }
+  for (uint32_t ti = lo + wv; ti < hi; ti += t_step) {     // one wave per record
+    const uint32_t ri = todo ? todo[ti] : ti;
     const SWalker wk = shard_in_record(io, pre, ri);
     const Row *rp = row_of(g, wk.curr);
     Row r; r.off = 0; r.deg = 0; r.flags = 0;
@@ -955,9 +967,15 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
     float u = draw_uniform(rng, iter, (uint32_t)rng_source(g, wk.src), (uint32_t)step);
     unsigned f = 0, sv = 0;
     int32_t k = -1, nid = 0;                         // same routing as k_walk_general (no per-edge tables on a shard)
-    if (!b.need_member) k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv);
-    else { unsigned long long ab = 0; unsigned su = 0; k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem, ab, su, nid); }
+    unsigned which = SRW_STRAT_SCAN;
+    if (!b.need_member) { k = wave_pick_prefix(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv); if (k >= 0) which = SRW_STRAT_PREFIX; }
+    else {
+      unsigned long long ab = 0; unsigned su = 0;
+      k = wave_pick_binned(g, r, (int64_t)wk.curr - g.vmin, b, mem.bm, u, f, sv, 0, false, mem, ab, su, nid);
+      if (k >= 0) which = su == 1 ? SRW_STRAT_P1 : su == 2 ? SRW_STRAT_P2 : su == 4 ? SRW_STRAT_P3 : SRW_STRAT_W;
+    }
     if (k < 0) k = wave_pick_scan(g, r, b, mem, u, f);
+    if (lane == 0) { n_strat[which] += 1; n_strat[SRW_STRAT_CHAIN] += f; }
     const int32_t next = g.ent[r.off + k].id;
     if (lane == 0) {
       const SWalker nw = shard_advance(wk, step, next, last != 0);
@@ -968,8 +986,10 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
       if (b.need_member) degp += (unsigned long long)b.prev_deg;
     }
   }
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) if (n_strat[i]) atomicAdd(&ctr->strat[i], (unsigned long long)n_strat[i]);
   block_flush_counters(ctr, red, steps, dead, degc, degp, 0, fb);   // contains the __syncthreads() cnt needs
-  if ((int)threadIdx.x < io.world) {
+  if (!todo && (int)threadIdx.x < io.world) {
     blk[(int64_t)blockIdx.x * 2 * io.world + threadIdx.x] = cnt[threadIdx.x];
     blk[(int64_t)blockIdx.x * 2 * io.world + io.world + threadIdx.x] = cnt[SHARD_MAX_WORLD + threadIdx.x];
   }
@@ -1252,6 +1272,196 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// q != 1 on a shard that holds the per-edge tables of the pairs into its own rows (edge_tables.hip:prepare_shard_tables):
+// the lean table step of k_walk_tables, one super-step at a time.  One wave per incoming walker, persistent waves taking
+// groups of records from a cursor (a step costs anything from one row of registers to a located chunk of a hub row).  The
+// step's first round trip issues together: the row of curr (local), the membership row of prev (replicated) and the pair
+// hash probe that yields the table word eb_off[e] would hold on a whole-graph handle.  Steps without a table (uncertified
+// rows, test configurations) go to the todo list: k_sh_step redoes exactly those with the on-the-fly samplers.  The sampled
+// records land in `scratch` in input order; k_sh_scatter buckets them.
+constexpr int SH_GRAB = 16;         // records per cursor grab (a single counter word saturates at ~88 atomics/us)
+template <bool BF>
+__global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_sh_step_tab(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
+                                                                     RngSpec rng, float p, float q, SWalker *__restrict__ scratch,
+                                                                     unsigned long long *cursor, uint32_t *__restrict__ todo, DevCounters *ctr, int32_t grab_n) {
+  __shared__ __attribute__((aligned(16))) uint32_t stage_all[TPB / 64][1024];
+  __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
+  const int lane = lane_id();
+  uint32_t *stage = stage_all[threadIdx.x >> 6];
+  const uint32_t n_in = shard_in_prefix(io, pre);
+  Member mem; mem.mode = 0; mem.bm = stage; mem.seg_base = 0;
+  const bool second = step > 1;
+  unsigned long long srch = 0;
+  uint32_t steps = 0, fb = 0, dead = 0, fast = 0, n_tab = 0, n_mask = 0, n_first = 0, n_todo = 0;
+  while (true) {
+    unsigned long long grab = 0;
+    if (lane == 0) grab = atomicAdd(cursor, (unsigned long long)grab_n);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(grab > 0xFFFFFFFFull ? 0xFFFFFFFFull : grab));
+    if (r0 >= n_in) break;
+    const uint32_t r1 = r0 + (uint32_t)grab_n < n_in ? r0 + (uint32_t)grab_n : n_in;
+    for (uint32_t ri = r0; ri < r1; ++ri) {
+      SWalker wk = shard_in_record(io, pre, ri);
+      wk.lw = __builtin_amdgcn_readfirstlane(wk.lw); wk.src = __builtin_amdgcn_readfirstlane(wk.src);
+      wk.prev = __builtin_amdgcn_readfirstlane(wk.prev); wk.curr = __builtin_amdgcn_readfirstlane(wk.curr);
+      const int64_t cslot = (int64_t)wk.curr - g.vmin, pslot = (int64_t)wk.prev - g.vmin;
+      const bool in_range = cslot >= 0 && cslot < g.n_slots;
+      Row r = g.rows[in_range ? cslot : 0];
+      Row mr; mr.off = 0; mr.deg = 0; mr.flags = 0;
+      uint32_t eo = EB_NONE; bool found = false;
+      if (second && in_range && pslot >= 0 && pslot < g.n_slots) {
+        mr = g.mrows[pslot];
+        found = pair_lookup_wave(g.ph, g.ph_buckets, (uint32_t)pslot, (uint32_t)cslot, eo);
+        mr = uniform_row(mr);
+      }
+      r = uniform_row(r);
+      if (!in_range) { r.off = 0; r.deg = 0; r.flags = 0; }
+      if (r.deg == 0) {                                  // dead end (or a source without neighbors): tell the home rank the length
+        if (lane == 0) scratch[ri] = shard_dead(wk);
+        dead += second ? 1u : 0u;
+        continue;
+      }
+      const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
+      const float u = draw_uniform(rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
+      unsigned f = 0, sv = 0;
+      int32_t k, next = 0;
+      if (!second) {
+        k = wave_pick_first(g, r, u, f, next);
+        n_first += 1;
+      } else {
+        Bias b;
+        b.p = p; b.q = q; b.prev = wk.prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
+        b.prev_sids = g.msids + mr.off; b.prev_deg = mr.deg; b.prev_hub = mr.flags >> ROW_HUB_SHIFT;
+        if (r.deg <= g.eb_mask_max && found) {
+          k = wave_pick_masked(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
+          n_mask += 1; srch += 8ull * (unsigned long long)r.deg + 4ull * (unsigned long long)((r.deg + 31) >> 5);
+        } else if (r.deg > g.eb_mask_max && found && (r.flags & ROW_PQ_OK)) {
+          k = wave_pick_edge_table<BF>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage);
+          if (k >= 0) { n_tab += 1; srch += 8ull * EB_BINS; fast += sv; }
+        } else k = -1;
+        if (k < 0) {                                       // no table for this pair: the general step takes the record
+          if (lane == 0) todo[atomicAdd(cursor + 1, 1ull)] = ri;
+          n_todo += 1;
+          continue;
+        }
+      }
+      next = __builtin_amdgcn_readfirstlane(next);
+      fb += f; steps += 1;
+      if (lane == 0) scratch[ri] = shard_advance(wk, step, next, last != 0);
+    }
+  }
+  if (lane == 0) {
+    srch += mem.res_bytes;
+    if (steps) atomicAdd(&ctr->steps, (unsigned long long)steps);
+    if (dead) atomicAdd(&ctr->dead_ends, (unsigned long long)dead);
+    if (fb) { atomicAdd(&ctr->fallbacks, (unsigned long long)fb); atomicAdd(&ctr->strat[SRW_STRAT_CHAIN], (unsigned long long)fb); }
+    if (fast) atomicAdd(&ctr->ent_reads, (unsigned long long)fast);
+    if (srch) atomicAdd(&ctr->trials, srch);
+    if (n_tab) atomicAdd(&ctr->strat[SRW_STRAT_EDGE_TABLE], (unsigned long long)n_tab);
+    if (n_mask) atomicAdd(&ctr->strat[SRW_STRAT_EDGE_MASK], (unsigned long long)n_mask);
+    if (n_first) atomicAdd(&ctr->strat[SRW_STRAT_SCAN], (unsigned long long)n_first);
+    if (n_todo) atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], (unsigned long long)n_todo);
+  }
+}
+
+// Buckets a super-step's sampled records (scratch, input order) into the destination chunks in ONE pass, like the second
+// half of k_sh_step_cfo: per tile of TPB * SH_R records the waves count survivors per destination and returns per home rank
+// in LDS, 2 * world threads move the block's counts onto the device-wide chunk cursors, the lanes store straight into the
+// chunks; the last block writes the chunk headers and clears the cursors.  Replaces k_sh_offsets + k_sh_bucket (and the
+// per-block count matrix) for the table steps, whose records are not sampled by fixed slices.
+__global__ __launch_bounds__(TPB) void k_sh_scatter(GraphView g, ShardIO io, int32_t step, const SWalker *__restrict__ recs,
+                                                    uint32_t *__restrict__ cursors, ShardDst dst, uint32_t *__restrict__ overflow) {
+  __shared__ uint32_t cnt[2 * SHARD_MAX_WORLD], gbase[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
+  __shared__ uint32_t is_last;
+  const int lane = lane_id();
+  if (threadIdx.x < 2 * SHARD_MAX_WORLD) cnt[threadIdx.x] = 0u;
+  const uint32_t n_in = shard_in_prefix(io, pre);          // contains the __syncthreads() cnt needs
+  uint32_t lo, hi;
+  shard_slice(n_in, TPB * SH_R, lo, hi);
+  for (uint32_t base = lo; base < hi; base += TPB * SH_R) {
+    SWalker w[SH_R];
+    int32_t o[SH_R], hm[SH_R];
+    uint32_t wpos[SH_R], rpos[SH_R];
+#pragma unroll
+    for (int r = 0; r < SH_R; ++r) {
+      const uint32_t ri = base + (uint32_t)r * TPB + threadIdx.x;
+      o[r] = -1; hm[r] = -1; wpos[r] = 0; rpos[r] = 0;
+      w[r].lw = 0; w[r].src = 0; w[r].prev = 0; w[r].curr = 0; w[r].h0 = w[r].h1 = w[r].h2 = 0; w[r].kind = SK_WALKER;
+      if (ri < hi) {
+        w[r] = recs[ri];
+        if (w[r].kind == SK_WALKER || w[r].kind == SK_WALKER_RET) o[r] = owner_of_tab(w[r].curr, io.world, g.owner_tab, g.vmin, g.n_slots);
+        if (w[r].kind != SK_WALKER) hm[r] = owner_of_tab(w[r].src, io.world, g.owner_tab, g.vmin, g.n_slots);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < SH_R; ++r) {
+      unsigned long long todo = __ballot(o[r] >= 0);
+      while (todo) {
+        const int d = __builtin_amdgcn_readlane(o[r], __ffsll((long long)todo) - 1);
+        const unsigned long long m = __ballot(o[r] == d);
+        uint32_t b0 = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) b0 = atomicAdd(&cnt[d], (uint32_t)__popcll(m));
+        b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
+        if (o[r] == d) wpos[r] = b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+      }
+      todo = __ballot(hm[r] >= 0);
+      while (todo) {
+        const int d = __builtin_amdgcn_readlane(hm[r], __ffsll((long long)todo) - 1);
+        const unsigned long long m = __ballot(hm[r] == d);
+        uint32_t b0 = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) b0 = atomicAdd(&cnt[SHARD_MAX_WORLD + d], (uint32_t)__popcll(m));
+        b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
+        if (hm[r] == d) rpos[r] = b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * io.world) {
+      const int d = (int)threadIdx.x < io.world ? (int)threadIdx.x : (int)threadIdx.x - io.world;
+      const int idx = (int)threadIdx.x < io.world ? d : SHARD_MAX_WORLD + d;
+      const uint32_t c = cnt[idx];
+      cnt[idx] = 0u;
+      uint32_t gb = 0;
+      if (c) {
+        gb = atomicAdd(&cursors[idx], c);
+        if ((uint64_t)gb + c > (uint64_t)((int)threadIdx.x < io.world ? io.cap_w : io.cap_r)) atomicOr(overflow, 1u);
+      }
+      gbase[idx] = gb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SH_R; ++r) {
+      if (o[r] >= 0) {
+        const uint32_t pos = gbase[o[r]] + wpos[r];
+        if (pos < (uint32_t)io.cap_w) { SWalker fw = w[r]; fw.kind = SK_WALKER; reinterpret_cast<SWalker *>(dst.p[o[r]] + 16)[pos] = fw; }
+      }
+      if (hm[r] >= 0) {
+        const uint32_t pos = gbase[SHARD_MAX_WORLD + hm[r]] + rpos[r];
+        if (pos < (uint32_t)io.cap_r) reinterpret_cast<PathRet *>(dst.p[hm[r]] + 16 + (int64_t)io.cap_w * SW_BYTES)[pos] = shard_ret_of(w[r], step);
+      }
+    }
+    __syncthreads();                                      // gbase is rewritten by the next tile
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(&cursors[SH_CUR_DONE], 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (is_last) {
+    __threadfence();
+    if ((int)threadIdx.x < 2 * io.world) {
+      const bool rets = (int)threadIdx.x >= io.world;
+      const int d = rets ? (int)threadIdx.x - io.world : (int)threadIdx.x;
+      const uint32_t total = atomicExch(&cursors[rets ? SHARD_MAX_WORLD + d : d], 0u);
+      const uint32_t cap = (uint32_t)(rets ? io.cap_r : io.cap_w);
+      reinterpret_cast<uint32_t *>(dst.p[d])[rets ? 1 : 0] = total < cap ? total : cap;
+    }
+    if (threadIdx.x == 0) cursors[SH_CUR_DONE] = 0u;
+  }
+}
+
 // ---- unit hooks ------------------------------------------------------------------------------------------
 __global__ void k_hook_pick(const Ent *row, int32_t deg, Bias b, float r, float *out_w, int64_t *index) {
   const int lane = lane_id();
@@ -1485,7 +1695,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   if (want_eb && want_ehash && !(env_cap && *env_cap)) {
     Graph &g = h->g;
     uint32_t pb, qb; memcpy(&pb, &P.p, 4); memcpy(&qb, &P.q, 4);
-    if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode && (!want_hub || g.has_hub)) {
+    if (g.has_eb && !g.eb_sharded && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode && (!want_hub || g.has_hub)) {
       drop_ehash = g.eb_no_ehash;                                  // standing tables: as they were built
     } else {
       uint64_t slots = 1024;
@@ -1536,7 +1746,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   if (want_eb) {
     Graph &g = h->g;
     uint32_t pb, qb; memcpy(&pb, &P.p, 4); memcpy(&qb, &P.q, 4);
-    if (g.has_eb && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode && (!want_hub || g.has_hub)) {
+    if (g.has_eb && !g.eb_sharded && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode && (!want_hub || g.has_hub)) {
       eb_cap = g.eb_cap;                                           // standing tables: keep them and the bitmaps they were built with
       if (want_hub) hub_cap = g.hub_budget_cap;
     } else {
@@ -1882,7 +2092,7 @@ void run_shard_begin(srw_handle *h, const srw_walk_params &P, int32_t batch, con
   h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
   SRW_HIP(hipMemsetAsync(h->shard_cur.p, 0, ((size_t)SH_CUR_DONE + 1) * 4, st));
   hipLaunchKernelGGL(k_sh_seed, dim3(blocks), dim3(TPB), 0, st, g.verts.p, g.n_local_vertices, io, (char *)d_recv, d_paths, d_lens, stride,
-                     linked ? (const Row *)g.rows.p : (const Row *)nullptr, g.vmin);
+                     linked ? (const Row *)g.rows.p : (const Row *)nullptr, g.vmin, h->shard_flag.p);
   SRW_HIP(hipGetLastError());
 }
 
@@ -1901,12 +2111,15 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
   if (world > 1 && P.q != 1.0f && !g.mrows.p)
     throw Error(SRW_ERR_INVALID, "this shard was loaded with SRW_CFG_NO_MEMBERSHIP: it can only run walks with q == 1 "
                                  "(q != 1 needs the neighbor sets of vertices the shard does not own)");
-  if (first_order) build_first_order_tables(h, true);
+  if (first_order) { build_first_order_tables(h, true); g.use_eb = false; }
   else {
     build_membership(h);
     if (!(P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_NO_PREFIX)) build_pq_tables(h, P.p, P.q);
     else g.has_pq = false;
+    // q != 1: the per-edge tables of the pairs into this shard's rows (built at the first super-step of a (p, q))
+    if (P.sampler == SRW_SAMPLER_REFERENCE) prepare_shard_tables(h, P); else g.use_eb = false;
   }
+  const bool tables = !first_order && g.has_eb && g.use_eb && g.eb_sharded && P.q != 1.0f;
   const ShardIO io = make_io(h, batch, lay, d_recv);
   ShardDst sd;
   for (int d = 0; d < SHARD_MAX_WORLD; ++d) sd.p[d] = d < world ? (char *)dst[d] : nullptr;
@@ -1919,11 +2132,12 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
   const int32_t last = step == P.walk_length + 1 ? 1 : 0;
   // SRW_SHARD_PROFILE=1 (debug): per-kernel hipEvent times, synchronising after each kernel, printed at the last step
   static const bool prof = getenv("SRW_SHARD_PROFILE") != nullptr;
-  static double acc[4] = {0, 0, 0, 0};
+  static double acc[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
   auto timed = [&](int slot, auto &&launch) {
     if (!prof) { launch(); return; }
     SRW_HIP(hipEventRecord(h->ev0, st)); launch(); SRW_HIP(hipEventRecord(h->ev1, st)); SRW_HIP(hipEventSynchronize(h->ev1));
-    float ms = 0.f; SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); acc[slot] += ms;
+    float ms = 0.f; SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); acc[slot] += ms; mx[slot] = std::max(mx[slot], (double)ms);
+    if (slot == 1 && getenv("SRW_SHARD_PROFILE_STEPS")) fprintf(stderr, "[shard step] rank %d step %d: %.2f ms\n", h->cfg.rank, step, ms);
   };
   if (step > 1) timed(0, [&] { hipLaunchKernelGGL(k_sh_apply, dim3(n_blocks), dim3(TPB), 0, st, io, d_paths, d_lens, stride); });
   if (linked) {      // sampling + bucketing in one pass; no scratch, no per-block counts
@@ -1941,6 +2155,34 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
       fprintf(stderr, "[shard profile] rank %d: apply %.1f ms, fused step %.1f ms (cumulative)\n", h->cfg.rank, acc[0], acc[1]);
     return;
   }
+  if (tables) {      // lean table step (persistent waves) -> the records without a table through the general step -> one fused bucketing pass
+    h->walk_cursor.ensure(2);
+    h->walk_todo.ensure((size_t)world * (size_t)lay.cap_walkers);
+    h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
+    SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, 2 * sizeof(unsigned long long), st));
+    const GraphView gv = g.view();
+    static const int grab_n = getenv("SRW_SH_GRAB") ? std::max(1, atoi(getenv("SRW_SH_GRAB"))) : SH_GRAB;
+    static const int tb_mult = getenv("SRW_SH_BLOCKS") ? std::max(1, atoi(getenv("SRW_SH_BLOCKS"))) : 8;
+    const int tb = h->n_cus * tb_mult;
+    timed(1, [&] {
+      if (gv.bf_off)
+        hipLaunchKernelGGL((k_sh_step_tab<true>), dim3(tb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch,
+                           h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n);
+      else
+        hipLaunchKernelGGL((k_sh_step_tab<false>), dim3(tb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch,
+                           h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n);
+    });
+    timed(2, [&] {
+      hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch, h->shard_blk.p,
+                         h->counters.p, (const uint32_t *)h->walk_todo.p, (const unsigned long long *)(h->walk_cursor.p + 1));
+    });
+    timed(3, [&] { hipLaunchKernelGGL(k_sh_scatter, dim3(n_blocks), dim3(TPB), 0, st, gv, io, step, scratch, h->shard_cur.p, sd, h->shard_flag.p); });
+    SRW_HIP(hipGetLastError());
+    if (prof && last)
+      fprintf(stderr, "[shard profile] rank %d: apply %.1f ms, table step %.1f ms (longest super-step %.1f ms), general step (todo) %.1f ms, scatter %.1f ms (cumulative)\n", h->cfg.rank,
+              acc[0], acc[1], mx[1], acc[2], acc[3]);
+    return;
+  }
   timed(1, [&] {
     if (first_order) {
       // records larger than the caches are read once per fetch: L1-bypassing loads (as k_walk_first_order)
@@ -1952,7 +2194,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
                            scratch, h->shard_blk.p, h->counters.p);
     } else
       hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, g.view(), io, P.first_walk, step, last, rng, P.p, P.q,
-                         scratch, h->shard_blk.p, h->counters.p);
+                         scratch, h->shard_blk.p, h->counters.p, (const uint32_t *)nullptr, (const unsigned long long *)nullptr);
   });
   timed(2, [&] { hipLaunchKernelGGL(k_sh_offsets, dim3(1), dim3(1024), 0, st, h->shard_blk.p, n_blocks, io, sd, h->shard_flag.p); });
   timed(3, [&] {

@@ -1,0 +1,98 @@
+"""The bit-exact second-order walk on VERTEX SHARDS with the per-edge bias tables (north_star's biased multi-GPU config:
+directed, p = 4, q = .5, graph sharded by source vertex — replacing RandomWalk.scala:92-139, whose shuffle ships N(prev)
+with every walker so that the receiving partition can recompute RandomSample.computeSecondOrderWeights, :27-44).
+Each shard holds the tables of the pairs (prev -> curr) into ITS rows, found through a pair hash; the walk must stay
+bit-identical to the oracle for every world size, and the table / mask steps must actually fire on the shards."""
+import numpy as np
+import pytest
+
+from helpers import pkg, rmat_lines, rmat_weights_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("p,q,directed", [(0.25, 4.0, False), (4.0, 0.5, True), (2.0, 2.0, False)])
+def test_shard_tables_equal_oracle(oracle, world, p, q, directed):
+    s, d, w = rmat_lines(oracle, 11, edge_factor=16, weighted=True)
+    g = oracle.Graph.from_coo(s, d, w, directed=directed)
+    rp, rl, rs = g.walk(p=p, q=q, walk_length=12, num_walks=2, first_walk=1, seed=5, threads=8)
+    with pkg().Cluster([0] * world) as cl:
+        cl.load_coo(s, d, w, directed=directed)
+        assert cl.stats() == (g.num_vertices, g.num_entries)
+        # default selection (masks for rows < 256 candidates, chunk-prefix tables beyond), every table pair with chunks of
+        # 4 candidates, hub bitmaps on rows of any degree, and the on-the-fly samplers alone: the same paths
+        for kw in (dict(), dict(edge_tables_all=True), dict(binned_tune=8), dict(edge_tables=False)):
+            for batch in (0, 1):
+                paths, lens, st = cl.walk(p=p, q=q, walk_length=12, num_walks=2, first_walk=1, seed=5, batch=batch, **kw)
+                assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (world, kw, batch)
+                assert st["n_steps"] == rs
+            ss = st["strategy_steps"]
+            if kw.get("edge_tables", True):
+                assert st["edge_tables"] > 0 and ss["edge_table"] > 0, (kw, st)
+                if not kw.get("edge_tables_all"):
+                    assert ss["edge_mask"] > 0 and ss["handed_over_walkers"] == 0, (kw, st)   # a complete set: nothing left to the general step
+                    assert ss["p1"] + ss["p2"] + ss["w"] + ss["p3"] == 0, st
+            else:
+                assert st["edge_tables"] == 0 and ss["edge_table"] == 0 and ss["edge_mask"] == 0, st
+        # constant r (the reference tests' injection) lands on CDF boundaries: the exact chain behind the tables
+        rp2, rl2, rs2 = g.walk(p=p, q=q, walk_length=6, rng="const", const_r=0.5, threads=8)
+        paths, lens, st = cl.walk(p=p, q=q, walk_length=6, rng="const", const_r=0.5)
+        assert np.array_equal(lens, rl2) and np.array_equal(paths, rp2) and st["n_steps"] == rs2
+
+
+def test_shard_tables_new_pq_rebuilds(oracle):
+    """The standing tables belong to one (p, q): another pair rebuilds them, q = 1 drops them, and a handle walked whole
+    (srw_walk, tables keyed by entry) and sharded (srw_shard_*, tables keyed by the pair hash) in turn stays exact."""
+    s, d, w = rmat_lines(oracle, 10, edge_factor=16, weighted=True)
+    g = oracle.Graph.from_coo(s, d, w)
+    with pkg().Cluster([0]) as cl:
+        cl.load_coo(s, d, w)
+        eng = cl.shard(0)
+        for p, q in [(0.25, 4.0), (4.0, 0.5), (0.5, 1.0), (0.25, 4.0), (1.0, 1.0)]:
+            rp, rl, rs = g.walk(p=p, q=q, walk_length=10, seed=3, threads=8)
+            paths, lens, st = cl.walk(p=p, q=q, walk_length=10, seed=3)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (p, q)
+            assert (st["edge_tables"] > 0) == (q != 1.0)
+            paths, lens, st = eng.walk(p=p, q=q, walk_length=10, seed=3)        # the same handle through srw_walk
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (p, q)
+
+
+@pytest.mark.parametrize("world,scale,ef,weighted,directed,p,q", [(4, 16, 16, True, False, 0.25, 4.0), (3, 18, 27, False, True, 4.0, 0.5)])
+def test_shard_tables_at_scale_equal_replicated(world, scale, ef, weighted, directed, p, q):
+    """The shapes of tests/test_gpu_scale.py (which pins the replicated kernels to the oracle at these sizes) through the
+    sharded protocol: every walker of the graph, default strategy selection, bit-identical; table and mask steps on the shards."""
+    P = pkg()
+    with P.Engine(device=0) as eng:
+        eng.generate_rmat(scale, ef << scale, seed=7, weighted=weighted, directed=directed)
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=24, seed=99)
+        nv = eng.stats()
+    with P.Cluster([0] * world) as cl:
+        cl.generate_rmat(scale, ef << scale, seed=7, weighted=weighted, directed=directed)
+        assert cl.stats() == nv
+        cp, clens, cst = cl.walk(p=p, q=q, walk_length=24, seed=99)
+        assert np.array_equal(clens, lens)
+        bad = np.nonzero((cp != paths).any(axis=1))[0]
+        assert bad.size == 0, (bad[:5], cp[bad[0]], paths[bad[0]])
+        assert cst["n_steps"] == st["n_steps"]
+        ss = cst["strategy_steps"]
+        assert cst["edge_tables"] > 0 and ss["edge_table"] > 0 and ss["edge_mask"] > 0, cst
+        assert ss["edge_table"] + ss["edge_mask"] + ss["scan"] >= 0.999 * cst["n_steps"], cst     # (scan: the first steps)
+
+
+@pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.5, 2.0)])
+def test_all_vertices_in_one_partition(oracle, tmp_path, p, q):
+    """SRW_CFG_OWNER_FROM_PARTITIONS with fewer partitions than shards: one shard owns every vertex, its seeds exceed a chunk
+    sized for an even split (nV / world^2).  The surplus must raise the overflow flag (retry with more slack), never be
+    written past the chunk or silently dropped."""
+    s, d, w = rmat_lines(oracle, 10, edge_factor=8, weighted=True)
+    f = tmp_path / "vcut.txt"
+    f.write_text("".join("%d %d %d %g\n" % (a, b, 2, x) for a, b, x in zip(s, d, w)))      # every edge in partition 2
+    g = oracle.Graph.load(str(f), partitioned=True)
+    with pkg().Cluster([0] * 4, owner_from_partitions=True) as cl:
+        cl.load_edgelist(str(f), partitioned=True)
+        assert [len(cl.shard(r).vertices()) for r in range(4)] == [0, 0, g.num_vertices, 0]
+        rp, rl, rs = g.walk(p=p, q=q, walk_length=10, num_walks=3, seed=12, threads=8)
+        for batch in (0, 1, 3):
+            paths, lens, st = cl.walk(p=p, q=q, walk_length=10, num_walks=3, seed=12, batch=batch)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs, batch

@@ -297,126 +297,139 @@ __device__ inline void edge_exists_n(const uint64_t *tab, uint64_t mask, uint32_
   }
 }
 
-// mem (optional, mode 1): the step's fast membership test — the chain runs over the WHOLE row up to the answer, and a draw
-// on a CDF boundary of a hub row used to pay one binary search of N(prev) per candidate (tens of ms for one step: the tail
-// of every super-step of the sharded walk, and of the single-launch kernel when it lands late).
-// 256 candidates per round: the four entry loads and the four membership probes of a lane are in flight together (the
-// chain itself stays sequential over the groups of 64: its latency is the scan, not the memory).
-#ifdef SRW_CHAIN_NOINLINE
-#define SRW_CHAIN_ATTR __attribute__((noinline))
-#else
-#define SRW_CHAIN_ATTR inline
-#endif
-__device__ SRW_CHAIN_ATTR int32_t wave_chain_pick(const Ent *row, int32_t deg, const Bias &b, float r, double S, const Member *mem = nullptr) {
+// Returned by the CHAIN = false instantiations of the certified samplers (the lean table kernels): the draw sits within
+// rounding distance of a CDF boundary and only the exact chain can decide — the caller hands the step to a kernel that has it.
+constexpr int32_t CHAIN_NEEDED = -2;
+
+// ---- the chain, in pieces (shared by wave_chain_pick and the sharded walk's chain kernels, walk_kernels.hip) ------------
+// One group of up to 64 quotients d (lane l holds element l, lanes >= cnt ignored) appended to the accumulator: the lane of
+// the first element with acc >= p, or -1 (acc then holds the accumulator after the group).
+__device__ inline int chain_group64(double &acc, double d, int cnt, double p) {
   const int lane = lane_id();
+  int start = 0;
+  while (start < cnt) {
+    const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
+    const int ea = (int)((ab >> 52) & 0x7FFull);
+    int f = start;                                     // acc zero / subnormal / not finite: one plain addition
+    if (!(ea == 0 || ea == 0x7FF || (ab >> 63))) {
+      const int e = ea - 1023;
+      const unsigned long long N0 = (ab & ((1ull << 52) - 1ull)) | (1ull << 52);
+      unsigned long long c0 = 0ull, c1 = 0ull;
+      if (lane >= start && lane < cnt) chain_elem_map(d, e, c0, c1);
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long f0 = shfl_up_u64(c0, off), f1 = shfl_up_u64(c1, off);
+        if (lane >= off) {
+          const unsigned long long g0 = c0, g1 = c1;
+          c0 = f0 + ((f0 & 1ull) ? g1 : g0);
+          c1 = f1 + (((f1 + 1ull) & 1ull) ? g1 : g0);
+        }
+      }
+      const unsigned long long N = N0 + ((N0 & 1ull) ? c1 : c0);
+      const bool mine = lane >= start && lane < cnt;
+      const unsigned long long cross = __ballot(mine && N >= (1ull << 53));
+      f = cross ? __ffsll((long long)cross) - 1 : -1;
+      const int lim = f < 0 ? cnt : f;
+      // inside the binade N < 2^53: the accumulator after my element, exactly
+      const double a = __longlong_as_double((long long)(((unsigned long long)ea << 52) | (N & ((1ull << 52) - 1ull))));
+      const unsigned long long hit = __ballot(lane >= start && lane < lim && a >= p);
+      if (hit) return __ffsll((long long)hit) - 1;
+      if (f < 0) { acc = readlane_f64(a, cnt - 1); return -1; }
+      if (f > start) acc = readlane_f64(a, f - 1);
+    }
+    acc = acc + readlane_f64(d, f);
+    if (acc >= p) return f;
+    start = f + 1;
+  }
+  return -1;
+}
+// A whole round of NU * 64 quotients at once (lane l holds elements u * 64 + l; elements at or beyond n_valid hold 0.0).
+// While the accumulator stays inside its binade and no element sits exactly on a rounding tie (c0 == c1: its increment does
+// not depend on the accumulator's parity), the maps N -> N + c commute, so the round is ONE exact integer sum; and with
+// every d >= 0 the accumulator is non-decreasing: if it is still below p after the round, no element of the round was the
+// answer.  true: absorbed (acc updated).  false: a tie, a binade crossing, the answer's round, a negative / non-finite
+// quotient — the caller evaluates the round group by group (chain_group64).
+template <int NU>
+__device__ inline bool chain_round_fast(double &acc, const double (&d)[NU], double p) {
+  const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
+  const int ea = (int)((ab >> 52) & 0x7FFull);
+  if (ea == 0 || ea == 0x7FF || (ab >> 63)) return false;
+  const unsigned long long N0 = (ab & ((1ull << 52) - 1ull)) | (1ull << 52);
+  unsigned long long loc = 0ull; bool odd = false;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    unsigned long long c0 = 0ull, c1 = 0ull;
+    chain_elem_map(d[u], ea - 1023, c0, c1);             // (d == 0: c = 0)
+    odd |= (c0 != c1) || (c0 >> 53);
+    loc += c0;
+  }
+  if (__any(odd)) return false;
+  const unsigned long long total = wave_sum_u64(loc);
+  if (N0 + total >= (1ull << 53)) return false;
+  const double a = __longlong_as_double((long long)(((unsigned long long)ea << 52) | ((N0 + total) & ((1ull << 52) - 1ull))));
+  if (!(a < p)) return false;
+  acc = a;
+  return true;
+}
+
+// The biased quotients w'_k / S of four candidates per lane; mem (optional, mode 1) = the step's fast membership test: the
+// chain runs over the WHOLE row up to the answer, and a draw on a CDF boundary of a hub row used to pay one binary search of
+// N(prev) per candidate.  The four membership tests of a lane run in lockstep (independent loads; edge_exists' probe loop
+// would serialise them).
+__device__ inline void chain_quotients4(const Ent *row, int32_t deg, int32_t base4, const Bias &b, double S, const Member *mem, double (&d4)[4]) {
+  const int lane = lane_id();
+  Ent e4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int32_t k = base4 + u * 64 + lane; e4[u].id = 0; e4[u].w = 0.0f; if (k < deg) e4[u] = row[k]; }
+  if (mem && mem->mode == 1 && b.second_order && b.need_member && (mem->hub || mem->ehash)) {
+    uint32_t xs[4]; bool want[4], in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xs[u] = (uint32_t)((int64_t)e4[u].id - b.vmin);
+      want[u] = base4 + u * 64 + lane < deg && e4[u].id != b.prev;
+      in[u] = false;
+    }
+    if (mem->hub) {
+      uint32_t wd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wd[u] = want[u] ? mem->hub[xs[u] >> 5] : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) in[u] = (wd[u] >> (xs[u] & 31)) & 1u;
+    } else {
+      edge_exists_n<4>(mem->ehash, mem->ehash_mask, (uint32_t)((int64_t)b.prev - b.vmin), xs, want, in);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      d4[u] = 0.0;
+      if (base4 + u * 64 + lane < deg) {
+        const float w = e4[u].w;
+        d4[u] = (double)(e4[u].id == b.prev ? div_exact(w, b.p) : in[u] ? w : div_exact(w, b.q)) / S;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int32_t k = base4 + u * 64 + lane;
+      d4[u] = 0.0;
+      if (k < deg) d4[u] = (double)(mem ? biased_weight_m(b, *mem, k, e4[u].id, e4[u].w) : biased_weight(b, e4[u].id, e4[u].w)) / S;
+    }
+  }
+}
+
+// 256 candidates per round: the four entry loads and the four membership probes of a lane are in flight together.
+__device__ inline int32_t wave_chain_pick(const Ent *row, int32_t deg, const Bias &b, float r, double S, const Member *mem = nullptr) {
   const double p = (double)r;
   double acc = 0.0;                                      // wave-uniform
   for (int32_t base4 = 0; base4 < deg; base4 += 256) {
-    Ent e4[4]; double d4[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int32_t k = base4 + u * 64 + lane; e4[u].id = 0; e4[u].w = 0.0f; if (k < deg) e4[u] = row[k]; }
-    if (mem && mem->mode == 1 && b.second_order && (mem->hub || mem->ehash)) {
-      // the four membership tests of a lane in lockstep (independent loads; edge_exists' probe loop would serialise them)
-      uint32_t xs[4]; bool want[4], in[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        xs[u] = (uint32_t)((int64_t)e4[u].id - b.vmin);
-        want[u] = base4 + u * 64 + lane < deg && e4[u].id != b.prev;
-        in[u] = false;
-      }
-      if (mem->hub) {
-        uint32_t wd[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wd[u] = want[u] ? mem->hub[xs[u] >> 5] : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) in[u] = (wd[u] >> (xs[u] & 31)) & 1u;
-      } else {
-        edge_exists_n<4>(mem->ehash, mem->ehash_mask, (uint32_t)((int64_t)b.prev - b.vmin), xs, want, in);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        d4[u] = 0.0;
-        if (base4 + u * 64 + lane < deg) {
-          const float w = e4[u].w;
-          d4[u] = (double)(e4[u].id == b.prev ? div_exact(w, b.p) : in[u] ? w : div_exact(w, b.q)) / S;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int32_t k = base4 + u * 64 + lane;
-        d4[u] = 0.0;
-        if (k < deg) d4[u] = (double)(mem ? biased_weight_m(b, *mem, k, e4[u].id, e4[u].w) : biased_weight(b, e4[u].id, e4[u].w)) / S;
-      }
-    }
-    // Fast path for the whole round: while the accumulator stays inside its binade and no element sits exactly on a
-    // rounding tie (c0 == c1: its increment does not depend on the accumulator's parity), the 256 maps N -> N + c commute,
-    // so the round is ONE exact integer sum; and with every d >= 0 the accumulator is non-decreasing: if it is still below
-    // p after the round, no element of the round was the answer.  Otherwise (a tie, a binade crossing, the answer's round,
-    // a negative / non-finite quotient) the round is evaluated group by group below.
-    {
-      const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
-      const int ea = (int)((ab >> 52) & 0x7FFull);
-      if (!(ea == 0 || ea == 0x7FF || (ab >> 63))) {
-        const unsigned long long N0 = (ab & ((1ull << 52) - 1ull)) | (1ull << 52);
-        unsigned long long loc = 0ull; bool odd = false;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          unsigned long long c0 = 0ull, c1 = 0ull;
-          if (base4 + u * 64 + lane < deg) chain_elem_map(d4[u], ea - 1023, c0, c1);
-          odd |= (c0 != c1) || (c0 >> 53);
-          loc += c0;
-        }
-        if (!__any(odd)) {
-          const unsigned long long total = wave_sum_u64(loc);
-          if (N0 + total < (1ull << 53)) {
-            const double a = __longlong_as_double((long long)(((unsigned long long)ea << 52) | ((N0 + total) & ((1ull << 52) - 1ull))));
-            if (a < p) { acc = a; continue; }
-          }
-        }
-      }
-    }
+    double d4[4];
+    chain_quotients4(row, deg, base4, b, S, mem, d4);
+    if (chain_round_fast<4>(acc, d4, p)) continue;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int32_t base = base4 + u * 64;
       if (base >= deg) break;                            // wave-uniform
-      const double d = d4[u];
-      const int cnt = min(64, deg - base);
-      int start = 0;
-      while (start < cnt) {
-        const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
-        const int ea = (int)((ab >> 52) & 0x7FFull);
-        int f = start;                                     // acc zero / subnormal / not finite: one plain addition
-        if (!(ea == 0 || ea == 0x7FF || (ab >> 63))) {
-          const int e = ea - 1023;
-          const unsigned long long N0 = (ab & ((1ull << 52) - 1ull)) | (1ull << 52);
-          unsigned long long c0 = 0ull, c1 = 0ull;
-          if (lane >= start && lane < cnt) chain_elem_map(d, e, c0, c1);
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long f0 = shfl_up_u64(c0, off), f1 = shfl_up_u64(c1, off);
-            if (lane >= off) {
-              const unsigned long long g0 = c0, g1 = c1;
-              c0 = f0 + ((f0 & 1ull) ? g1 : g0);
-              c1 = f1 + (((f1 + 1ull) & 1ull) ? g1 : g0);
-            }
-          }
-          const unsigned long long N = N0 + ((N0 & 1ull) ? c1 : c0);
-          const bool mine = lane >= start && lane < cnt;
-          const unsigned long long cross = __ballot(mine && N >= (1ull << 53));
-          f = cross ? __ffsll((long long)cross) - 1 : -1;
-          const int lim = f < 0 ? cnt : f;
-          // inside the binade N < 2^53: the accumulator after my element, exactly
-          const double a = __longlong_as_double((long long)(((unsigned long long)ea << 52) | (N & ((1ull << 52) - 1ull))));
-          const unsigned long long hit = __ballot(lane >= start && lane < lim && a >= p);
-          if (hit) return base + (__ffsll((long long)hit) - 1);
-          if (f < 0) { acc = readlane_f64(a, cnt - 1); break; }
-          if (f > start) acc = readlane_f64(a, f - 1);
-        }
-        acc = acc + readlane_f64(d, f);
-        if (acc >= p) return base + f;
-        start = f + 1;
-      }
+      const int f = chain_group64(acc, d4[u], min(64, deg - base), p);
+      if (f >= 0) return base + f;
     }
   }
   return 0;  // edges.head (:24)
@@ -1104,10 +1117,10 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
 #ifndef SRW_RESOLVE_PER_LANE
 #define SRW_RESOLVE_PER_LANE 2   // measured at config 3: 2 -> 182 M steps/s, 4 -> 169 M, 1 -> 168 M (request-bound vs latency-bound)
 #endif
-template <bool ABS, bool BF = false>
+template <bool ABS, bool BF = false, bool CHAIN = true>
 __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, const Bias &b, const double *bins,
                                          const BinGeom geo, float r, unsigned &fallback, unsigned &served, Member &tm,
-                                         int32_t &id_out, uint32_t *stage) {
+                                         int32_t &id_out, uint32_t *stage, double *S_out = nullptr) {
   constexpr int PL = SRW_RESOLVE_PER_LANE;
   const int lane = lane_id();
   const int32_t deg = rc.deg;
@@ -1198,7 +1211,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   served = 1;
   // membership for the exact chain, should the draw sit on a CDF boundary: the same tests, candidate by candidate
   Member cm; cm.mode = 1; cm.bm = nullptr; cm.seg_base = 0; cm.hub = hubbits; cm.ehash = g.ehash; cm.ehash_mask = g.ehash_mask;
-  if (!hubbits && !g.ehash && g.bf_off && m >= BF_MIN_DEG) {
+  if (CHAIN && !hubbits && !g.ehash && g.bf_off && m >= BF_MIN_DEG) {
     const uint32_t bo = g.bf_off[xprev];
     if (bo != BF_NONE) { cm.bf = g.bf_bits + bo; cm.bf_nw = bf_words(m); }
   }
@@ -1282,6 +1295,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       if (mm) {
         const int f = __ffsll((long long)mm) - 1;
         if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(e[u].id, f); return base + u * 64 + f; }
+        if (!CHAIN) { if (S_out) *S_out = S; return CHAIN_NEEDED; }
         fallback = 1;
         const int32_t kk = wave_chain_pick(row, deg, b, r, S, &cm);
         id_out = row[kk].id;
@@ -1290,6 +1304,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       carry += readlane_f64(incl, 63);
     }
   }
+  if (!CHAIN) { if (S_out) *S_out = S; return CHAIN_NEEDED; }
   fallback = 1;
   const int32_t kk = wave_chain_pick(row, deg, b, r, S, &cm);
   id_out = row[kk].id;
@@ -1299,6 +1314,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
 // ---- first step of a walk (initFirstStep, RandomWalk.scala:51-66): RandomSample.sample on the RAW row -------------------
 // Certified like the masked path: exact parallel sum under the certificate, exact prefix sums, divide-free compares;
 // the sequential chain otherwise.  No membership, no LDS.
+template <bool CHAIN = true>
 __device__ inline int32_t wave_pick_first(const GraphView &g, const Row &rc, float r, unsigned &fallback, int32_t &id_out) {
   const int lane = lane_id();
   const Ent *row = g.ent + rc.off;
@@ -1318,6 +1334,7 @@ __device__ inline int32_t wave_pick_first(const GraphView &g, const Row &rc, flo
   const bool bad = __any(cert.bad) || __any(neg);
   const double S = wave_sum_f64(part);
   if (bad || !sum_is_exact(emin, emax, false, deg) || !(S > 0.0)) {
+    if (!CHAIN) return CHAIN_NEEDED;
     unsigned f = 0;
     const double Sc = wave_sum_exact_or_chain(row, deg, nb, f);
     fallback = 1;
@@ -1341,6 +1358,7 @@ __device__ inline int32_t wave_pick_first(const GraphView &g, const Row &rc, flo
     if (mm) {
       const int f = __ffsll((long long)mm) - 1;
       if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(e.id, f); return base + f; }
+      if (!CHAIN) return CHAIN_NEEDED;
       fallback = 1;
       const int32_t kk = wave_chain_pick(row, deg, nb, r, S);
       id_out = row[kk].id;
@@ -1358,6 +1376,7 @@ __device__ inline int32_t wave_pick_first(const GraphView &g, const Row &rc, flo
 // same certified evaluation as the table path (exact parallel S and prefix sums under the certificate, divide-free
 // certain-miss / certain-hit compares, the sequential chain otherwise) without a single membership lookup.
 constexpr int MASK_MAX_DEG = 256;       // rows up to 255 candidates: 4 per lane stay in registers
+template <bool CHAIN = true>
 __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, const Bias &b, uint32_t inline_mask,
                                            const uint32_t *words, float r, unsigned &fallback, int32_t &id_out) {
   const int lane = lane_id();
@@ -1391,6 +1410,7 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   const bool bad = __any(cert.bad) || __any(neg);
   const double S_par = wave_sum_f64(part);
   if (bad || !sum_is_exact(emin, emax, false, deg) || !(S_par > 0.0)) {     // (S = 0: the reference divides by zero -> chain)
+    if (!CHAIN) return CHAIN_NEEDED;
     unsigned f = 0;
     const double Sc = wave_sum_exact_or_chain(row, deg, b, f);
     fallback = 1;
@@ -1419,6 +1439,7 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
     if (mm) {
       const int f = __ffsll((long long)mm) - 1;
       if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(idv[i], f); return i * 64 + f; }
+      if (!CHAIN) return CHAIN_NEEDED;
       fallback = 1;                                 // within rounding distance of a boundary: exact chain
       const int32_t kk = wave_chain_pick(row, deg, b, r, S);
       id_out = row[kk].id;
@@ -1451,12 +1472,12 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
 #endif
 constexpr int EB_BINS = SRW_EB_BINS;           // default chunks per table: one lane each in the search.  GraphView::eb_cap (32 / 64 /
                                                // 128 / 256) is what the standing tables were built with: more chunks = a second search round, shorter chunks
-template <bool BF = false>
+template <bool BF = false, bool CHAIN = true>
 __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc, const Bias &b, const double *table,
                                                float r, unsigned &fallback, unsigned &served, Member &tm, int32_t &id_out,
-                                               uint32_t *stage /* 1024 words of the wave's LDS */) {
+                                               uint32_t *stage /* 1024 words of the wave's LDS */, double *S_out = nullptr) {
   const BinGeom geo = bin_geometry(rc.deg, g.eb_min_sh, g.eb_cap);
-  return binned_resolve<true, BF>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage);
+  return binned_resolve<true, BF, CHAIN>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage, S_out);
 }
 
 }  // namespace srw

@@ -323,19 +323,22 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g
       const float u = draw_uniform(rng, iter, ksrc, (uint32_t)s);
       unsigned f = 0, sv = 0;
       int32_t k, next = 0;
+      // (CHAIN = false: the exact chain is not in this kernel — a draw within rounding distance of a CDF boundary hands the
+      //  walker over like a missing table; the chain's registers and scratch cost every step otherwise)
       if (!second) {
-        k = wave_pick_first(g, r, u, f, next);
+        k = wave_pick_first<false>(g, r, u, f, next);
+        if (k < 0) { handed_over = true; break; }
       } else {
         Bias b;
         b.p = p; b.q = q; b.prev = prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
         b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT;
         SRW_T0(mem);
         if (r.deg <= g.eb_mask_max && (r.deg <= 32 || eo != EB_NONE)) {
-          k = wave_pick_masked(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
+          k = wave_pick_masked<false>(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
           w_mask += 1; w_srch += 8u * (uint32_t)r.deg + 4u * (uint32_t)((r.deg + 31) >> 5);
           SRW_T1(mem, t_a);
         } else if (r.deg > g.eb_mask_max && eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
-          k = wave_pick_edge_table<BF>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage);
+          k = wave_pick_edge_table<BF, false>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage);
           if (k >= 0) { w_tab += 1; w_srch += 8u * EB_BINS; w_fast += sv; }
           SRW_T1(mem, t_p1);
 #ifdef SRW_PHASE_TIMING
@@ -1281,10 +1284,14 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
 // rows, test configurations) go to the todo list: k_sh_step redoes exactly those with the on-the-fly samplers.  The sampled
 // records land in `scratch` in input order; k_sh_scatter buckets them.
 constexpr int SH_GRAB = 16;         // records per cursor grab (a single counter word saturates at ~88 atomics/us)
+constexpr int CHAIN_CAP = 1024;     // draws on a CDF boundary per super-step that the chain kernels take (more: the general step)
+struct alignas(16) ChainRec { uint32_t ri, pad; double S; };                     // record index in the receive buffer, the reference's sum of the biased row
+struct alignas(16) ChainMeta { long long d_off; int32_t deg; uint32_t u_off; };   // first quotient in the scratch array, row length, first work unit
 template <bool BF>
 __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_sh_step_tab(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
                                                                      RngSpec rng, float p, float q, SWalker *__restrict__ scratch,
-                                                                     unsigned long long *cursor, uint32_t *__restrict__ todo, DevCounters *ctr, int32_t grab_n) {
+                                                                     unsigned long long *cursor, uint32_t *__restrict__ todo, DevCounters *ctr, int32_t grab_n,
+                                                                     ChainRec *__restrict__ chain) {
   __shared__ __attribute__((aligned(16))) uint32_t stage_all[TPB / 64][1024];
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
   const int lane = lane_id();
@@ -1325,25 +1332,35 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_sh_step_tab(GraphView g
       const float u = draw_uniform(rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
       unsigned f = 0, sv = 0;
       int32_t k, next = 0;
+      // CHAIN = false: a draw within rounding distance of a CDF boundary is not decided here.  On a table step the record
+      // goes to the chain list with the reference's sum S (k_chain_*: the quotients of the whole row computed by the whole
+      // GPU, then one sequential pass over them) — one wave running the chain over a hub row alone was the tail of every
+      // other super-step; everywhere else (first steps, rows below 256 candidates) the general step takes the record.
+      bool to_chain = false; double S_tie = 0.0;
       if (!second) {
-        k = wave_pick_first(g, r, u, f, next);
-        n_first += 1;
+        k = wave_pick_first<false>(g, r, u, f, next);
+        n_first += k >= 0 ? 1u : 0u;
       } else {
         Bias b;
         b.p = p; b.q = q; b.prev = wk.prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
         b.prev_sids = g.msids + mr.off; b.prev_deg = mr.deg; b.prev_hub = mr.flags >> ROW_HUB_SHIFT;
         if (r.deg <= g.eb_mask_max && found) {
-          k = wave_pick_masked(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
-          n_mask += 1; srch += 8ull * (unsigned long long)r.deg + 4ull * (unsigned long long)((r.deg + 31) >> 5);
+          k = wave_pick_masked<false>(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
+          if (k >= 0) { n_mask += 1; srch += 8ull * (unsigned long long)r.deg + 4ull * (unsigned long long)((r.deg + 31) >> 5); }
         } else if (r.deg > g.eb_mask_max && found && (r.flags & ROW_PQ_OK)) {
-          k = wave_pick_edge_table<BF>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage);
+          k = wave_pick_edge_table<BF, false>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie);
           if (k >= 0) { n_tab += 1; srch += 8ull * EB_BINS; fast += sv; }
+          to_chain = k == CHAIN_NEEDED;
         } else k = -1;
-        if (k < 0) {                                       // no table for this pair: the general step takes the record
-          if (lane == 0) todo[atomicAdd(cursor + 1, 1ull)] = ri;
-          n_todo += 1;
-          continue;
+      }
+      if (k < 0) {
+        if (lane == 0) {
+          unsigned long long ci = to_chain ? atomicAdd(cursor + 2, 1ull) : (unsigned long long)CHAIN_CAP;
+          if (ci < (unsigned long long)CHAIN_CAP) { ChainRec cr; cr.ri = ri; cr.pad = 0u; cr.S = S_tie; chain[ci] = cr; }
+          else todo[atomicAdd(cursor + 1, 1ull)] = ri;    // no table for this pair / a full chain list: the general step takes the record
         }
+        n_todo += 1;
+        continue;
       }
       next = __builtin_amdgcn_readfirstlane(next);
       fb += f; steps += 1;
@@ -1361,6 +1378,126 @@ __global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_sh_step_tab(GraphView g
     if (n_mask) atomicAdd(&ctr->strat[SRW_STRAT_EDGE_MASK], (unsigned long long)n_mask);
     if (n_first) atomicAdd(&ctr->strat[SRW_STRAT_SCAN], (unsigned long long)n_first);
     if (n_todo) atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], (unsigned long long)n_todo);
+  }
+}
+
+// ---- the exact chain for the table steps whose draw sits on a CDF boundary ---------------------------------------------
+// RandomSample.sample's running sum (RandomSample.scala:18-22) is sequential by nature, but only its ADDITIONS are: the
+// quotients fl(w'_k / S) — the entry loads, the membership probes, the divides: what costs — are independent.  So:
+//   k_chain_setup  one thread: row length, scratch offset and first work unit of every listed record (records whose
+//                  quotients do not fit the scratch array go to the general step)
+//   k_chain_d      the whole GPU: one wave per work unit of 256 candidates computes their quotients into the scratch array
+//   k_chain_seq    one wave per record: the chain over the stored quotients, 1024 per round (chain_round_fast: one integer
+//                  sum per round while no rounding tie / binade crossing / answer is in it), next round prefetched
+// ~3 000 ties per iteration at config 3's size, each up to a million candidates long: one wave alone took 10-40 ms for one.
+__device__ inline SWalker shard_record_uniform(const ShardIO &io, const uint32_t *pre, uint32_t ri) {
+  SWalker wk = shard_in_record(io, pre, ri);
+  wk.lw = __builtin_amdgcn_readfirstlane(wk.lw); wk.src = __builtin_amdgcn_readfirstlane(wk.src);
+  wk.prev = __builtin_amdgcn_readfirstlane(wk.prev); wk.curr = __builtin_amdgcn_readfirstlane(wk.curr);
+  wk.h0 = __builtin_amdgcn_readfirstlane(wk.h0); wk.h1 = __builtin_amdgcn_readfirstlane(wk.h1); wk.h2 = __builtin_amdgcn_readfirstlane(wk.h2);
+  wk.kind = __builtin_amdgcn_readfirstlane(wk.kind);
+  return wk;
+}
+__global__ void k_chain_setup(GraphView g, ShardIO io, const ChainRec *__restrict__ list, unsigned long long *cursor /* [1] todo_n, [2] chain_n */,
+                              ChainMeta *__restrict__ meta, uint32_t *__restrict__ totals /* [0] work units, [1] records */, long long d_cap,
+                              uint32_t *__restrict__ todo) {
+  __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
+  shard_in_prefix(io, pre);
+  if (threadIdx.x != 0) return;
+  const unsigned long long n_all = cursor[2];
+  const uint32_t n = (uint32_t)(n_all < (unsigned long long)CHAIN_CAP ? n_all : (unsigned long long)CHAIN_CAP);
+  long long off = 0; uint32_t units = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const SWalker wk = shard_in_record(io, pre, list[i].ri);
+    const Row r = g.rows[(int64_t)wk.curr - g.vmin];
+    ChainMeta m; m.d_off = off; m.deg = r.deg; m.u_off = units;
+    if (off + (long long)r.deg > d_cap) { m.deg = 0; todo[atomicAdd(cursor + 1, 1ull)] = list[i].ri; }     // scratch full: the general step
+    else { off += (long long)((r.deg + 255) & ~255); units += (uint32_t)((r.deg + 255) >> 8); }
+    meta[i] = m;
+  }
+  totals[0] = units; totals[1] = n;
+}
+__global__ __launch_bounds__(TPB) void k_chain_d(GraphView g, ShardIO io, float p, float q, const ChainRec *__restrict__ list,
+                                                 const ChainMeta *__restrict__ meta, const uint32_t *__restrict__ totals, double *__restrict__ D) {
+  __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
+  shard_in_prefix(io, pre);
+  const int lane = lane_id();
+  const uint32_t n_units = totals[0], n = totals[1];
+  const uint32_t gw = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), nw = gridDim.x * (TPB / 64);
+  uint32_t i = 0;
+  for (uint32_t u = gw; u < n_units; u += nw) {
+    ChainMeta m = meta[i];                                 // the record unit u belongs to (u grows: i only moves forward)
+    while (u >= m.u_off + (uint32_t)((m.deg + 255) >> 8) && i + 1 < n) m = meta[++i];
+    const int32_t base4 = (int32_t)(u - m.u_off) * 256;
+    const SWalker wk = shard_record_uniform(io, pre, list[i].ri);
+    const Row r = uniform_row(g.rows[(int64_t)wk.curr - g.vmin]);
+    const Row mr = uniform_row(g.mrows[(int64_t)wk.prev - g.vmin]);
+    Bias b;
+    b.p = p; b.q = q; b.prev = wk.prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
+    b.prev_sids = g.msids + mr.off; b.prev_deg = mr.deg; b.prev_hub = mr.flags >> ROW_HUB_SHIFT;
+    Member cm; cm.mode = 1; cm.bm = nullptr; cm.seg_base = 0;
+    cm.hub = (b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
+    cm.ehash = g.ehash; cm.ehash_mask = g.ehash_mask;
+    if (!cm.hub && !g.ehash && g.bf_off && mr.deg >= BF_MIN_DEG) {
+      const uint32_t bo = g.bf_off[(int64_t)wk.prev - g.vmin];
+      if (bo != BF_NONE) { cm.bf = g.bf_bits + bo; cm.bf_nw = bf_words(mr.deg); }
+    }
+    double d4[4];
+    chain_quotients4(g.ent + r.off, r.deg, base4, b, list[i].S, &cm, d4);
+    double *out = D + m.d_off + base4;
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) out[uu * 64 + lane] = d4[uu];          // (padding up to the unit's 256 slots holds 0.0)
+  }
+}
+constexpr int CHAIN_NU = 16;     // quotients per lane and round of the sequential pass
+__global__ __launch_bounds__(TPB) void k_chain_seq(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last, RngSpec rng,
+                                                   const ChainRec *__restrict__ list, const ChainMeta *__restrict__ meta,
+                                                   const uint32_t *__restrict__ totals, const double *__restrict__ D,
+                                                   SWalker *__restrict__ scratch, DevCounters *ctr) {
+  __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
+  shard_in_prefix(io, pre);
+  const int lane = lane_id();
+  const uint32_t i = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (i >= totals[1]) return;
+  const ChainMeta m = meta[i];
+  if (m.deg == 0) return;                                 // handed to the general step by k_chain_setup
+  const uint32_t ri = list[i].ri;
+  const SWalker wk = shard_record_uniform(io, pre, ri);
+  const Row r = uniform_row(g.rows[(int64_t)wk.curr - g.vmin]);
+  const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
+  const double p = (double)draw_uniform(rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
+  const double *d = D + m.d_off;
+  const int32_t n_pad = (r.deg + 255) & ~255;             // what k_chain_d wrote (zeros beyond deg)
+  auto load_round = [&](int32_t base, double (&v)[CHAIN_NU]) {
+#pragma unroll
+    for (int u = 0; u < CHAIN_NU; ++u) { const int32_t k = base + u * 64 + lane; v[u] = k < n_pad ? d[k] : 0.0; }
+  };
+  double cur[CHAIN_NU], nxt[CHAIN_NU];
+#pragma unroll
+  for (int u = 0; u < CHAIN_NU; ++u) nxt[u] = 0.0;
+  load_round(0, cur);
+  double acc = 0.0;
+  int32_t k_hit = -1;
+  for (int32_t base = 0; base < r.deg && k_hit < 0; base += CHAIN_NU * 64) {
+    if (base + CHAIN_NU * 64 < r.deg) load_round(base + CHAIN_NU * 64, nxt);      // in flight while this round is added up
+    if (!chain_round_fast<CHAIN_NU>(acc, cur, p)) {
+#pragma unroll
+      for (int u = 0; u < CHAIN_NU; ++u) {
+        const int32_t b0 = base + u * 64;
+        if (b0 >= r.deg || k_hit >= 0) break;               // wave-uniform
+        const int f = chain_group64(acc, cur[u], min(64, r.deg - b0), p);
+        if (f >= 0) k_hit = b0 + f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CHAIN_NU; ++u) cur[u] = nxt[u];
+  }
+  if (k_hit < 0) k_hit = 0;                               // edges.head (:24)
+  if (lane == 0) {
+    const int32_t next = g.ent[r.off + k_hit].id;
+    scratch[ri] = shard_advance(wk, step, next, last != 0);
+    atomicAdd(&ctr->steps, 1ull); atomicAdd(&ctr->fallbacks, 1ull);
+    atomicAdd(&ctr->strat[SRW_STRAT_CHAIN], 1ull); atomicAdd(&ctr->strat[SRW_STRAT_EDGE_TABLE], 1ull);
   }
 }
 
@@ -2156,10 +2293,17 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     return;
   }
   if (tables) {      // lean table step (persistent waves) -> the records without a table through the general step -> one fused bucketing pass
-    h->walk_cursor.ensure(2);
+    h->walk_cursor.ensure(4);                       // [0] record cursor, [1] todo records, [2] chain records
     h->walk_todo.ensure((size_t)world * (size_t)lay.cap_walkers);
     h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
-    SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, 2 * sizeof(unsigned long long), st));
+    SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, 4 * sizeof(unsigned long long), st));
+    // chain scratch: list + meta + totals in one buffer, the quotients of up to d_cap candidates in another
+    static const long long d_cap = (long long)(getenv("SRW_CHAIN_SCRATCH_MB") ? atof(getenv("SRW_CHAIN_SCRATCH_MB")) : 512.0) * (1 << 20) / 8;
+    h->chain_buf.ensure((size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)) + 64);
+    h->chain_d.ensure((size_t)d_cap);
+    ChainRec *chain_list = reinterpret_cast<ChainRec *>(h->chain_buf.p);
+    ChainMeta *chain_meta = reinterpret_cast<ChainMeta *>(h->chain_buf.p + (size_t)CHAIN_CAP * sizeof(ChainRec));
+    uint32_t *chain_totals = reinterpret_cast<uint32_t *>(h->chain_buf.p + (size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)));
     const GraphView gv = g.view();
     static const int grab_n = getenv("SRW_SH_GRAB") ? std::max(1, atoi(getenv("SRW_SH_GRAB"))) : SH_GRAB;
     static const int tb_mult = getenv("SRW_SH_BLOCKS") ? std::max(1, atoi(getenv("SRW_SH_BLOCKS"))) : 8;
@@ -2167,19 +2311,27 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     timed(1, [&] {
       if (gv.bf_off)
         hipLaunchKernelGGL((k_sh_step_tab<true>), dim3(tb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch,
-                           h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n);
+                           h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n, chain_list);
       else
         hipLaunchKernelGGL((k_sh_step_tab<false>), dim3(tb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch,
-                           h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n);
+                           h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n, chain_list);
     });
+    // draws on a CDF boundary of a table step: quotients by the whole GPU, then one sequential pass per record
     timed(2, [&] {
+      hipLaunchKernelGGL(k_chain_setup, dim3(1), dim3(64), 0, st, gv, io, chain_list, h->walk_cursor.p, chain_meta, chain_totals, d_cap,
+                         (uint32_t *)h->walk_todo.p);
+      hipLaunchKernelGGL(k_chain_d, dim3(h->n_cus * 4), dim3(TPB), 0, st, gv, io, P.p, P.q, chain_list, chain_meta, chain_totals, h->chain_d.p);
+      hipLaunchKernelGGL(k_chain_seq, dim3(CHAIN_CAP / (TPB / 64)), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, chain_list, chain_meta,
+                         chain_totals, (const double *)h->chain_d.p, scratch, h->counters.p);
+    });
+    timed(2, [&] {      // (the few records without a table, or whose tie is not a table step's)
       hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch, h->shard_blk.p,
                          h->counters.p, (const uint32_t *)h->walk_todo.p, (const unsigned long long *)(h->walk_cursor.p + 1));
     });
     timed(3, [&] { hipLaunchKernelGGL(k_sh_scatter, dim3(n_blocks), dim3(TPB), 0, st, gv, io, step, scratch, h->shard_cur.p, sd, h->shard_flag.p); });
     SRW_HIP(hipGetLastError());
     if (prof && last)
-      fprintf(stderr, "[shard profile] rank %d: apply %.1f ms, table step %.1f ms (longest super-step %.1f ms), general step (todo) %.1f ms, scatter %.1f ms (cumulative)\n", h->cfg.rank,
+      fprintf(stderr, "[shard profile] rank %d: apply %.1f ms, table step %.1f ms (longest super-step %.1f ms), chain + general step (ties, todo) %.1f ms, scatter %.1f ms (cumulative)\n", h->cfg.rank,
               acc[0], acc[1], mx[1], acc[2], acc[3]);
     return;
   }

@@ -219,21 +219,21 @@ int32_t srw_alias_row(srw_handle *h, int32_t v, float *prob, int32_t *alias, int
  * processed by owner(v); its PATH stays on its home rank = owner(source).  Each super-step every rank consumes one
  * receive buffer of `world` fixed-capacity chunks (one per sender) and fills `world` destination chunks:
  *     chunk = { uint32 n_walkers, n_rets, 0, 0 } | srw_walker[cap_walkers] | srw_path_ret[cap_rets]
+ * — 16 + 8 = 24 bytes per walker-step on the wire (the reference ships the path so far and N(prev), RandomWalk.scala:135).
  * The caller moves chunk (me -> d) to rank d's receive buffer slot `me`: one equal-split all-to-all of chunk_bytes per
  * peer (RCCL over xGMI; stellar-random-walk_amd/distributed.py), or — one process, several devices — the kernels store
  * straight into the peers' receive buffers (srw_cluster_*, below).  No host synchronisation per super-step: counts live
  * in the chunk headers; an overflowing chunk drops its surplus and srw_shard_finish reports it (retry with more slack).
  * The keyed RNG makes the paths bit-identical for any world size (tests assert it against the oracle). */
-typedef struct {            /* 32 bytes on the wire */
+typedef struct {            /* 16 bytes on the wire */
   int32_t lw;               /* home rank's path row: local vertex index * batch + iteration in batch */
-  int32_t src, prev, curr;  /* (linked p = q = 1 walk: prev | kind << 32 = row link of curr on its owner) */
-  int32_t h0, h1, h2;       /* vertices of the current group of four path slots not yet returned home */
-  int32_t kind;             /* 0 on the wire */
+  int32_t src;              /* source vertex (Philox key; owner(src) = home rank) */
+  int32_t prev, curr;       /* the walker stands on curr, came from prev (linked p = q = 1 walk: prev | curr << 32 = row link of the vertex it stands on) */
 } srw_walker;
-typedef struct {            /* 24 bytes: up to four consecutive path slots of walker lw, returned to its home rank */
-  int32_t lw;               /* top bit set: death notice (the walker stopped; path length = first slot + count) */
-  int32_t first_cnt;        /* first path slot | count << 24 */
-  int32_t v[4];
+typedef struct {            /* 8 bytes: one path slot of walker lw, returned to its home rank; the slot is implicit — a return
+                               produced by super-step s is slot s */
+  int32_t lw;               /* top bit set: death notice (the walker stopped before sampling slot s: its path has s entries) */
+  int32_t v;
 } srw_path_ret;
 typedef struct { int64_t cap_walkers, cap_rets, chunk_bytes; } srw_shard_layout;
 /* vertices owned by this handle / present in the whole graph (the walker seeds, UniformRandomWalk.scala:81-87) */

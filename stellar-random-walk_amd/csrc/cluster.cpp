@@ -207,7 +207,7 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
     if (n_global == 0 || P0.num_walks == 0) { if (stats) *stats = tot; c->valid = true; return; }
     if (tot.kernel_kind == 1 && P0.rng_mode == SRW_RNG_PHILOX && c->rows_linked < 0) link_rows(c);
     if (batch <= 0) {   // as many iterations per population as keep a shard's chunk buffers under ~2 GiB
-      const int64_t per_iter = std::max<int64_t>(1, n_global / world * 70);      // 56 B of chunk space per resident walker x slack
+      const int64_t per_iter = std::max<int64_t>(1, n_global / world * 30);      // 24 B of chunk space per resident walker x slack
       batch = (int32_t)std::max<int64_t>(1, std::min<int64_t>(P0.num_walks, ((int64_t)2 << 30) / per_iter));
     }
     batch = std::min(batch, P0.num_walks);

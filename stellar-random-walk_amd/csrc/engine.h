@@ -169,6 +169,7 @@ struct srw_handle {
   srw::DevBuf<uint32_t> shard_blk;               // [blocks][2 * world] per-block survivor / return counts, then write cursors
   srw::DevBuf<uint32_t> shard_flag;              // chunk overflow flag of the sharded walk
   srw::DevBuf<uint32_t> shard_cur;               // fused first-order step: device-wide chunk cursors + finished-block counter
+  srw::DevBuf<int32_t> shard_pt;                 // home rank's paths of the current batch, slot-major [L + 2][rows] (k_sh_apply -> k_sh_transpose)
   srw::DevBuf<char> chain_buf;                   // sharded table steps whose draw sits on a CDF boundary: record list, meta, totals ...
   srw::DevBuf<double> chain_d;                   // ... and the quotients w'_k / S of their rows (k_chain_*)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -765,18 +765,23 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
 //
 // A walker standing on v is processed by owner(v); its PATH lives on its home rank = owner(source).  What moves between
 // ranks each super-step is fixed-size records in fixed-capacity CHUNKS, one chunk per (sender, receiver) pair:
-//     chunk = { u32 n_walkers, n_rets, 0, 0 } | SWalker[cap_w] {lw, src, prev, curr, h0, h1, h2, -} | PathRet[cap_r] {lw, first | count << 24, v[4]}
-// lw = (local index of the source vertex on its home rank) * batch + (walk iteration inside the batch): the home rank's
-// path row, and lw % batch is the RNG's iteration word.  A walker carries the vertices of its current group of four
-// path slots (h0..h2) and returns them home together; a return with the top bit of lw set is a death notice (the
-// path length is first slot + count): lens start at walk_length + 2 and only walkers that stop early are corrected.
+//     chunk = { u32 n_walkers, n_rets, 0, 0 } | WWalker[cap_w] {lw, src, prev, curr} | WRet[cap_r] {lw, v}
+// 16 + 8 = 24 bytes per walker-step on the wire (the reference ships the whole path so far and N(prev) with every walker,
+// RandomWalk.scala:135).  lw = (local index of the source vertex on its home rank) * batch + (walk iteration inside the
+// batch): the home rank's path row, and lw % batch is the RNG's iteration word.  Every sampled vertex goes home at once as
+// an 8-byte return; its path slot is IMPLICIT: a return produced by super-step s belongs to slot s (the receiver applies
+// the returns of the chunk it got after super-step s).  A return with the top bit of lw set is a death notice (the walker
+// stopped before sampling slot s: its path has s entries): lens start at walk_length + 2 and only walkers that stop early
+// are corrected.  On a linked p = q = 1 walk prev | curr << 32 is the row link of the vertex the walker stands on.
+// (Round 2 carried the last three vertices inside a 32-byte walker and returned four slots at a time as 24 bytes: 38 bytes
+// per walker-step — the exchange, not the kernels, bounded a shard on xGMI)
 // A rank's receive buffer is `world` chunks (one per sender), its send side is `world` destination pointers — the
 // local send buffer (one equal-split all_to_all_single moves it, distributed.py) or, inside one process, the peers'
 // receive buffers themselves (xGMI peer stores, cluster.cpp).
 // Everything is sized and counted on the device: NO host synchronisation per super-step; an overflowing chunk drops
 // its surplus and raises a flag the host reads once per batch (the batch is then redone with more slack).
 //   k_sh_seed    : the rank's own walkers, spread over the chunks of its receive buffer; path slot 0, lens = L + 2
-//   k_sh_apply   : path returns of the previous super-step -> up to four consecutive path slots; death notices -> lens
+//   k_sh_apply   : returns of the previous super-step -> their path slot; death notices -> lens
 //   k_sh_step(_fo): sample every incoming walker once into `scratch` (kind says what the bucket kernel must emit), count
 //                  the block's survivors per destination owner and the returns per home rank in LDS -> blk[b][2 * world]
 //   k_sh_offsets : one block: scan of blk over the blocks -> every block's write cursors; chunk headers
@@ -784,14 +789,13 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
 // The general kernel keeps one wave per record and the same samplers as k_walk_general (bit-identical paths for any
 // world, asserted against the oracle).
 constexpr int SHARD_MAX_WORLD = 64;
-// Walker on the wire: 32 bytes.  h0..h2 = the vertices of the walker's current group of four path slots that are not
-// yet returned to the home rank (slots 4g .. 4g+3 travel home together: one 16-byte store instead of four scattered
-// 4-byte ones — the path stores were half of a super-step's memory requests).  kind (scratch only): what the bucket
-// kernel has to emit for the record.
-struct alignas(16) SWalker { int32_t lw, src, prev, curr, h0, h1, h2, kind; };
-struct alignas(8) PathRet { int32_t lw, first_cnt, v[4]; };     // lw top bit: death notice; first slot | count << 24
-enum : int32_t { SK_WALKER = 0, SK_WALKER_RET = 1, SK_RET = 2, SK_DEAD = 3 };
-constexpr int64_t SW_BYTES = 32, PR_BYTES = 24;
+struct alignas(16) WWalker { int32_t lw, src, prev, curr; };      // on the wire: 16 bytes
+struct alignas(8) WRet { int32_t lw, v; };                         // on the wire: 8 bytes; lw top bit: death notice
+// a record between the sampling kernel and the bucketing kernel (scratch, never on the wire): the forwarded walker
+// (prev, curr), the vertex that goes home (v) and what to emit (kind)
+struct alignas(16) SWalker { int32_t lw, src, prev, curr, v, kind, pad0, pad1; };
+enum : int32_t { SK_WALKER_RET = 1, SK_RET = 2, SK_DEAD = 3 };   // walker + return; return only (last step); death notice only
+constexpr int64_t SW_BYTES = 16, PR_BYTES = 8;
 struct ShardIO {
   const char *recv;        // world chunks, one per sender
   int64_t chunk_bytes;
@@ -799,9 +803,9 @@ struct ShardIO {
 };
 struct ShardDst { char *p[SHARD_MAX_WORLD]; };   // where chunk (me -> d) is written
 __device__ inline const uint32_t *chunk_hdr(const char *base, int64_t cb, int c) { return reinterpret_cast<const uint32_t *>(base + c * cb); }
-__device__ inline const SWalker *chunk_walkers(const char *base, int64_t cb, int c) { return reinterpret_cast<const SWalker *>(base + c * cb + 16); }
-__device__ inline const PathRet *chunk_rets(const char *base, int64_t cb, int32_t cap_w, int c) {
-  return reinterpret_cast<const PathRet *>(base + c * cb + 16 + (int64_t)cap_w * SW_BYTES);
+__device__ inline const WWalker *chunk_walkers(const char *base, int64_t cb, int c) { return reinterpret_cast<const WWalker *>(base + c * cb + 16); }
+__device__ inline const WRet *chunk_rets(const char *base, int64_t cb, int32_t cap_w, int c) {
+  return reinterpret_cast<const WRet *>(base + c * cb + 16 + (int64_t)cap_w * SW_BYTES);
 }
 
 __device__ inline void block_flush_counters(DevCounters *ctr, unsigned long long *red, unsigned long long steps,
@@ -842,7 +846,9 @@ __device__ inline uint32_t shard_in_prefix(const ShardIO &io, uint32_t *pre) {
 __device__ inline SWalker shard_in_record(const ShardIO &io, const uint32_t *pre, uint32_t i) {
   int c = 0;
   while (c + 1 < io.world && i >= pre[c + 1]) ++c;
-  return chunk_walkers(io.recv, io.chunk_bytes, c)[i - pre[c]];
+  const WWalker w = chunk_walkers(io.recv, io.chunk_bytes, c)[i - pre[c]];
+  SWalker r; r.lw = w.lw; r.src = w.src; r.prev = w.prev; r.curr = w.curr; r.v = 0; r.kind = 0; r.pad0 = 0; r.pad1 = 0;
+  return r;
 }
 // per-block slice of n records in units of `unit` records (TPB for the per-lane kernels, TPB / 64 for one wave per record)
 __device__ inline void shard_slice(uint32_t n, uint32_t unit, uint32_t &lo, uint32_t &hi) {
@@ -852,36 +858,24 @@ __device__ inline void shard_slice(uint32_t n, uint32_t unit, uint32_t &lo, uint
   lo = (uint32_t)(l < n ? l : n); hi = (uint32_t)(h < n ? h : n);
 }
 
-// What happens to a walker that has just sampled `next` for path slot `step` (or died there): the forwarded record and
-// whether its group of path slots goes home now.  j = step & 3 entries of the group are already in h0..h{j-1}.
+// What happens to a walker that has just sampled `next` (or died): the scratch record the bucketing kernel turns into a
+// forwarded walker (unless this was the last step) and the return that carries `next` home.
 __device__ inline SWalker shard_advance(const SWalker &wk, int32_t step, int32_t next, bool last) {
   SWalker nw = wk;
-  nw.prev = wk.curr; nw.curr = next;
-  const int j = step & 3;
-  if (j == 3 || last) nw.kind = last ? SK_RET : SK_WALKER_RET;        // slots step - j .. step: h0..h{j-1}, next
-  else {
-    nw.kind = SK_WALKER;
-    if (j == 0) nw.h0 = next; else if (j == 1) nw.h1 = next; else nw.h2 = next;
-  }
+  nw.prev = wk.curr; nw.curr = next; nw.v = next;
+  nw.kind = last ? SK_RET : SK_WALKER_RET;
   return nw;
 }
 __device__ inline SWalker shard_dead(const SWalker &wk) { SWalker d = wk; d.kind = SK_DEAD; return d; }
-__device__ inline PathRet shard_ret_of(const SWalker &w, int32_t step) {      // w: a scratch record of super-step `step`
-  PathRet r;
-  const int j = step & 3;
-  r.v[0] = w.h0; r.v[1] = w.h1; r.v[2] = w.h2; r.v[3] = 0;
-  if (w.kind == SK_DEAD) {                       // stopped before sampling slot `step`: j unreturned entries, length = step
-    r.lw = (int32_t)((uint32_t)w.lw | 0x80000000u);
-    r.first_cnt = (step - j) | (j << 24);
-  } else {
-    r.lw = w.lw;
-    r.v[j] = w.curr;
-    r.first_cnt = (step - j) | ((j + 1) << 24);
-  }
+__device__ inline WWalker shard_wire_of(const SWalker &w) { WWalker o; o.lw = w.lw; o.src = w.src; o.prev = w.prev; o.curr = w.curr; return o; }
+__device__ inline WRet shard_ret_of(const SWalker &w) {
+  WRet r;
+  r.lw = w.kind == SK_DEAD ? (int32_t)((uint32_t)w.lw | 0x80000000u) : w.lw;
+  r.v = w.kind == SK_DEAD ? 0 : w.v;
   return r;
 }
 
-// linked walkers (k_sh_step_cfo): prev | kind << 32 = the link of the vertex the walker stands on, laid out as CfoEnt::link
+// linked walkers (k_sh_step_cfo): prev | curr << 32 = the link of the vertex the walker stands on, laid out as CfoEnt::link
 __device__ inline uint64_t shard_link_of(const Row &r) {
   return ((uint64_t)r.off & CFO_NOFF_MASK) | ((uint64_t)(uint32_t)min(r.deg, (int32_t)CFO_NDEG_MAX) << 40) |
          ((uint64_t)((r.flags & ROW_IRREGULAR) != 0) << 63);
@@ -895,11 +889,11 @@ __global__ void k_sh_seed(const int32_t *__restrict__ verts, int64_t n_local, Sh
   const int64_t n = n_local * io.batch;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t src = verts[i / io.batch];
-    SWalker w; w.lw = (int32_t)i; w.src = src; w.prev = src; w.curr = src; w.h0 = src; w.h1 = 0; w.h2 = 0; w.kind = SK_WALKER;
-    if (link_rows) { const uint64_t l = shard_link_of(link_rows[(int64_t)src - vmin]); w.prev = (int32_t)(uint32_t)l; w.kind = (int32_t)(uint32_t)(l >> 32); }
+    WWalker w; w.lw = (int32_t)i; w.src = src; w.prev = src; w.curr = src;
+    if (link_rows) { const uint64_t l = shard_link_of(link_rows[(int64_t)src - vmin]); w.prev = (int32_t)(uint32_t)l; w.curr = (int32_t)(uint32_t)(l >> 32); }
     const int c = (int)(i % io.world);
-    if (i / io.world < (int64_t)io.cap_w) reinterpret_cast<SWalker *>(recv_w + c * io.chunk_bytes + 16)[i / io.world] = w;
-    paths[i * stride] = src;
+    if (i / io.world < (int64_t)io.cap_w) reinterpret_cast<WWalker *>(recv_w + c * io.chunk_bytes + 16)[i / io.world] = w;
+    paths[i] = src;                   // slot 0 of the slot-major staging [stride][n] (k_sh_apply)
     lens[i] = (int32_t)stride;        // full length unless a death notice says otherwise (k_sh_apply)
   }
   if (blockIdx.x == 0 && (int)threadIdx.x < io.world) {
@@ -911,22 +905,49 @@ __global__ void k_sh_seed(const int32_t *__restrict__ verts, int64_t n_local, Sh
   }
 }
 
-// path returns of the previous super-step: up to four consecutive path slots per record; death notices set lens
-__global__ void k_sh_apply(ShardIO io, int32_t *__restrict__ paths, int32_t *__restrict__ lens, int64_t stride) {
+// returns of the previous super-step: each one is path slot `slot` of its walker; death notices set lens.
+// The home rank stages its paths SLOT-MAJOR, pt[slot][row]: the 4-byte stores of one super-step — one per walker, in the
+// order the returns arrive — then fall into one contiguous n_rows * 4 B row that the caches absorb (L2 + Infinity Cache) and
+// write back as full lines; into the final [row][L + 2] matrix they were one partial 64-byte sector each, and k_sh_apply
+// cost as much as the sampling kernel (s15: 1.94 ms vs 1.90 ms per super-step of 35.5 M walkers).  k_sh_transpose turns
+// the staging into the final layout once per batch (two streaming passes over the batch's paths).
+__global__ void k_sh_apply(ShardIO io, int32_t *__restrict__ pt, int32_t *__restrict__ lens, int64_t n_rows, int32_t slot) {
   for (int c = 0; c < io.world; ++c) {
     const uint32_t n = min(chunk_hdr(io.recv, io.chunk_bytes, c)[1], (uint32_t)io.cap_r);
-    const PathRet *r = chunk_rets(io.recv, io.chunk_bytes, io.cap_w, c);
+    const WRet *r = chunk_rets(io.recv, io.chunk_bytes, io.cap_w, c);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-      const PathRet x = r[i];
-      const int32_t lw = x.lw & 0x7FFFFFFF, first = x.first_cnt & 0xFFFFFF, cnt = x.first_cnt >> 24;
-      int32_t *row = paths + (int64_t)lw * stride + first;
-      if (cnt == 4 && ((reinterpret_cast<uintptr_t>(row) & 7u) == 0)) {
-        reinterpret_cast<int2 *>(row)[0] = make_int2(x.v[0], x.v[1]);
-        reinterpret_cast<int2 *>(row)[1] = make_int2(x.v[2], x.v[3]);
-      } else {
-        for (int t = 0; t < cnt; ++t) row[t] = x.v[t];
+      const WRet x = r[i];
+      if (x.lw < 0) lens[x.lw & 0x7FFFFFFF] = slot;             // death notice: the walker stopped with `slot` entries
+      else pt[(int64_t)slot * n_rows + x.lw] = x.v;
+    }
+  }
+}
+
+// pt[slot][row] -> paths[row][slot], -1 beyond the row's length: tiles of 64 rows x 16 slots through LDS, 256-byte reads,
+// 64-byte runs per row on the way out.
+__global__ __launch_bounds__(TPB) void k_sh_transpose(const int32_t *__restrict__ pt, const int32_t *__restrict__ lens, int64_t n_rows,
+                                                      int64_t stride, int32_t *__restrict__ paths) {
+  __shared__ int32_t tile[16][64 + 1];
+  const int t = threadIdx.x;
+  for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < n_rows; w0 += (int64_t)gridDim.x * 64) {
+    const int64_t wr = w0 + (t >> 2);
+    const int32_t len = wr < n_rows ? lens[wr] : 0;
+    for (int64_t s0 = 0; s0 < stride; s0 += 16) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int64_t sl = s0 + pass * 4 + (t >> 6), w = w0 + (t & 63);
+        tile[pass * 4 + (t >> 6)][t & 63] = (sl < stride && w < n_rows) ? pt[sl * n_rows + w] : -1;
       }
-      if (x.lw < 0) lens[lw] = first + cnt;                     // death notice: the walker stopped with that many entries
+      __syncthreads();
+      if (wr < n_rows) {
+        const int c0 = (t & 3) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t sl = s0 + c0 + c;
+          if (sl < stride) paths[wr * stride + sl] = sl < len ? tile[c0 + c][t >> 2] : -1;
+        }
+      }
+      __syncthreads();
     }
   }
 }
@@ -984,7 +1005,7 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
       const SWalker nw = shard_advance(wk, step, next, last != 0);
       scratch[ri] = nw;
       if (nw.kind != SK_RET) atomicAdd(&cnt[owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
-      if (nw.kind != SK_WALKER) atomicAdd(&cnt[SHARD_MAX_WORLD + owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
+      atomicAdd(&cnt[SHARD_MAX_WORLD + owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);      // every sampled vertex goes home
       steps += 1; degc += (unsigned long long)r.deg; fb += f;
       if (b.need_member) degp += (unsigned long long)b.prev_deg;
     }
@@ -1040,7 +1061,7 @@ __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int
         scratch[ri] = nw;
         ++steps;
         if (nw.kind != SK_RET) o = owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots);
-        if (nw.kind != SK_WALKER) hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+        hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
       }
     }
     for (int32_t d = 0; d < io.world; ++d) {               // one LDS atomic per wave, destination and kind
@@ -1084,7 +1105,6 @@ __global__ __launch_bounds__(TPB) void k_sh_step_cfo(GraphView g, ShardIO io, in
   unsigned long long steps = 0, dead = 0, reads = 0, fb = 0;
   Bias nobias; nobias.second_order = false; nobias.need_member = false; nobias.p = nobias.q = 1.0f;
   nobias.prev = 0; nobias.prev_sids = nullptr; nobias.prev_deg = 0; nobias.vmin = g.vmin;
-  const int j4 = step & 3;
   uint32_t lo, hi;
   shard_slice(n_in, TPB * SH_R, lo, hi);
   for (uint32_t base = lo; base < hi; base += TPB * SH_R) {
@@ -1094,10 +1114,10 @@ __global__ __launch_bounds__(TPB) void k_sh_step_cfo(GraphView g, ShardIO io, in
 #pragma unroll
     for (int r = 0; r < SH_R; ++r) {
       const uint32_t ri = base + (uint32_t)r * TPB + threadIdx.x;
-      o[r] = -1; hm[r] = -1; kind[r] = SK_WALKER; wpos[r] = 0; rpos[r] = 0;
+      o[r] = -1; hm[r] = -1; kind[r] = SK_WALKER_RET; wpos[r] = 0; rpos[r] = 0;
       if (ri < hi) {
         const SWalker wk = shard_in_record(io, pre, ri);
-        const uint64_t link = (uint64_t)(uint32_t)wk.prev | ((uint64_t)(uint32_t)wk.kind << 32);
+        const uint64_t link = (uint64_t)(uint32_t)wk.prev | ((uint64_t)(uint32_t)wk.curr << 32);
         const int64_t off = (int64_t)(link & CFO_NOFF_MASK);
         const int32_t deg = (int32_t)((link >> 40) & 0x7FFFFFu);
         nw[r] = wk;
@@ -1118,11 +1138,10 @@ __global__ __launch_bounds__(TPB) void k_sh_step_cfo(GraphView g, ShardIO io, in
           }
           ++steps;
           const uint64_t nl = e.link & ~(0xFull << 36);
-          nw[r].curr = e.id; nw[r].prev = (int32_t)(uint32_t)nl; nw[r].kind = (int32_t)(uint32_t)(nl >> 32);
-          if (j4 == 3 || last) kind[r] = last ? SK_RET : SK_WALKER_RET;        // slots step - j .. step go home: h0..h{j-1}, next
-          else if (j4 == 0) nw[r].h0 = e.id; else if (j4 == 1) nw[r].h1 = e.id; else nw[r].h2 = e.id;
-          if (kind[r] != SK_RET) o[r] = owner_of_tab(e.id, io.world, g.owner_tab, g.vmin, g.n_slots);
-          if (kind[r] != SK_WALKER) hm[r] = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+          nw[r].v = e.id; nw[r].prev = (int32_t)(uint32_t)nl; nw[r].curr = (int32_t)(uint32_t)(nl >> 32);   // forwarded: the link of the vertex it moves to
+          if (last) kind[r] = SK_RET;
+          else o[r] = owner_of_tab(e.id, io.world, g.owner_tab, g.vmin, g.n_slots);
+          hm[r] = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
         }
       }
     }
@@ -1170,13 +1189,13 @@ __global__ __launch_bounds__(TPB) void k_sh_step_cfo(GraphView g, ShardIO io, in
     for (int r = 0; r < SH_R; ++r) {
       if (o[r] >= 0) {
         const uint32_t pos = gbase[o[r]] + wpos[r];
-        if (pos < (uint32_t)io.cap_w) reinterpret_cast<SWalker *>(dst.p[o[r]] + 16)[pos] = nw[r];
+        if (pos < (uint32_t)io.cap_w) reinterpret_cast<WWalker *>(dst.p[o[r]] + 16)[pos] = shard_wire_of(nw[r]);
       }
       if (hm[r] >= 0) {
         const uint32_t pos = gbase[SHARD_MAX_WORLD + hm[r]] + rpos[r];
         if (pos < (uint32_t)io.cap_r) {
           SWalker t = nw[r]; t.kind = kind[r];
-          reinterpret_cast<PathRet *>(dst.p[hm[r]] + 16 + (int64_t)io.cap_w * SW_BYTES)[pos] = shard_ret_of(t, step);
+          reinterpret_cast<WRet *>(dst.p[hm[r]] + 16 + (int64_t)io.cap_w * SW_BYTES)[pos] = shard_ret_of(t);
         }
       }
     }
@@ -1241,12 +1260,12 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
   shard_slice(n_in, (uint32_t)unit, lo, hi);
   for (uint32_t base = lo; base < hi; base += TPB) {
     const uint32_t i = base + threadIdx.x;
-    SWalker w; w.lw = 0; w.src = 0; w.prev = 0; w.curr = 0; w.h0 = w.h1 = w.h2 = 0; w.kind = SK_WALKER;
+    SWalker w; w.lw = 0; w.src = 0; w.prev = 0; w.curr = 0; w.v = 0; w.kind = SK_RET; w.pad0 = w.pad1 = 0;
     int32_t o = -1, hm = -1;
     if (i < hi) {
       w = recs[i];
-      if (w.kind == SK_WALKER || w.kind == SK_WALKER_RET) o = owner_of_tab(w.curr, io.world, g.owner_tab, g.vmin, g.n_slots);
-      if (w.kind != SK_WALKER) hm = owner_of_tab(w.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+      if (w.kind == SK_WALKER_RET) o = owner_of_tab(w.curr, io.world, g.owner_tab, g.vmin, g.n_slots);
+      hm = owner_of_tab(w.src, io.world, g.owner_tab, g.vmin, g.n_slots);
     }
     for (int32_t d = 0; d < io.world; ++d) {
       const unsigned long long m = __ballot(o == d);
@@ -1256,10 +1275,7 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
         if (lane == leader) b0 = atomicAdd(&cur[d], (uint32_t)__popcll(m));
         b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
         const uint32_t pos = b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (o == d && pos < (uint32_t)io.cap_w) {
-          SWalker fw = w; fw.kind = SK_WALKER;
-          reinterpret_cast<SWalker *>(dst.p[d] + 16)[pos] = fw;
-        }
+        if (o == d && pos < (uint32_t)io.cap_w) reinterpret_cast<WWalker *>(dst.p[d] + 16)[pos] = shard_wire_of(w);
       }
       const unsigned long long mh = __ballot(hm == d);
       if (mh) {
@@ -1269,7 +1285,7 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
         b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
         const uint32_t pos = b0 + (uint32_t)__popcll(mh & ((1ull << lane) - 1ull));
         if (hm == d && pos < (uint32_t)io.cap_r)
-          reinterpret_cast<PathRet *>(dst.p[d] + 16 + (int64_t)io.cap_w * SW_BYTES)[pos] = shard_ret_of(w, step);
+          reinterpret_cast<WRet *>(dst.p[d] + 16 + (int64_t)io.cap_w * SW_BYTES)[pos] = shard_ret_of(w);
       }
     }
   }
@@ -1394,8 +1410,6 @@ __device__ inline SWalker shard_record_uniform(const ShardIO &io, const uint32_t
   SWalker wk = shard_in_record(io, pre, ri);
   wk.lw = __builtin_amdgcn_readfirstlane(wk.lw); wk.src = __builtin_amdgcn_readfirstlane(wk.src);
   wk.prev = __builtin_amdgcn_readfirstlane(wk.prev); wk.curr = __builtin_amdgcn_readfirstlane(wk.curr);
-  wk.h0 = __builtin_amdgcn_readfirstlane(wk.h0); wk.h1 = __builtin_amdgcn_readfirstlane(wk.h1); wk.h2 = __builtin_amdgcn_readfirstlane(wk.h2);
-  wk.kind = __builtin_amdgcn_readfirstlane(wk.kind);
   return wk;
 }
 __global__ void k_chain_setup(GraphView g, ShardIO io, const ChainRec *__restrict__ list, unsigned long long *cursor /* [1] todo_n, [2] chain_n */,
@@ -1523,11 +1537,11 @@ __global__ __launch_bounds__(TPB) void k_sh_scatter(GraphView g, ShardIO io, int
     for (int r = 0; r < SH_R; ++r) {
       const uint32_t ri = base + (uint32_t)r * TPB + threadIdx.x;
       o[r] = -1; hm[r] = -1; wpos[r] = 0; rpos[r] = 0;
-      w[r].lw = 0; w[r].src = 0; w[r].prev = 0; w[r].curr = 0; w[r].h0 = w[r].h1 = w[r].h2 = 0; w[r].kind = SK_WALKER;
+      w[r].lw = 0; w[r].src = 0; w[r].prev = 0; w[r].curr = 0; w[r].v = 0; w[r].kind = SK_RET; w[r].pad0 = w[r].pad1 = 0;
       if (ri < hi) {
         w[r] = recs[ri];
-        if (w[r].kind == SK_WALKER || w[r].kind == SK_WALKER_RET) o[r] = owner_of_tab(w[r].curr, io.world, g.owner_tab, g.vmin, g.n_slots);
-        if (w[r].kind != SK_WALKER) hm[r] = owner_of_tab(w[r].src, io.world, g.owner_tab, g.vmin, g.n_slots);
+        if (w[r].kind == SK_WALKER_RET) o[r] = owner_of_tab(w[r].curr, io.world, g.owner_tab, g.vmin, g.n_slots);
+        hm[r] = owner_of_tab(w[r].src, io.world, g.owner_tab, g.vmin, g.n_slots);
       }
     }
 #pragma unroll
@@ -1573,11 +1587,11 @@ __global__ __launch_bounds__(TPB) void k_sh_scatter(GraphView g, ShardIO io, int
     for (int r = 0; r < SH_R; ++r) {
       if (o[r] >= 0) {
         const uint32_t pos = gbase[o[r]] + wpos[r];
-        if (pos < (uint32_t)io.cap_w) { SWalker fw = w[r]; fw.kind = SK_WALKER; reinterpret_cast<SWalker *>(dst.p[o[r]] + 16)[pos] = fw; }
+        if (pos < (uint32_t)io.cap_w) reinterpret_cast<WWalker *>(dst.p[o[r]] + 16)[pos] = shard_wire_of(w[r]);
       }
       if (hm[r] >= 0) {
         const uint32_t pos = gbase[SHARD_MAX_WORLD + hm[r]] + rpos[r];
-        if (pos < (uint32_t)io.cap_r) reinterpret_cast<PathRet *>(dst.p[hm[r]] + 16 + (int64_t)io.cap_w * SW_BYTES)[pos] = shard_ret_of(w[r], step);
+        if (pos < (uint32_t)io.cap_r) reinterpret_cast<WRet *>(dst.p[hm[r]] + 16 + (int64_t)io.cap_w * SW_BYTES)[pos] = shard_ret_of(w[r]);
       }
     }
     __syncthreads();                                      // gbase is rewritten by the next tile
@@ -2222,13 +2236,13 @@ void run_shard_begin(srw_handle *h, const srw_walk_params &P, int32_t batch, con
   h->shard_flag.ensure(1);
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   SRW_HIP(hipMemsetAsync(h->shard_flag.p, 0, 4, st));
-  if (n > 0) SRW_HIP(hipMemsetAsync(d_paths, 0xFF, (size_t)n * stride * 4, st));     // -1: unused tail
+  h->shard_pt.ensure((size_t)std::max<int64_t>(n, 1) * (size_t)stride);                // slot-major staging of this batch's paths (k_sh_apply)
   const ShardIO io = make_io(h, batch, lay, d_recv);
   const int blocks = (int)std::min<int64_t>(std::max<int64_t>((n + TPB - 1) / TPB, 1), 8192);
   const bool linked = shard_fo_linked(h, P);
   h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
   SRW_HIP(hipMemsetAsync(h->shard_cur.p, 0, ((size_t)SH_CUR_DONE + 1) * 4, st));
-  hipLaunchKernelGGL(k_sh_seed, dim3(blocks), dim3(TPB), 0, st, g.verts.p, g.n_local_vertices, io, (char *)d_recv, d_paths, d_lens, stride,
+  hipLaunchKernelGGL(k_sh_seed, dim3(blocks), dim3(TPB), 0, st, g.verts.p, g.n_local_vertices, io, (char *)d_recv, h->shard_pt.p, d_lens, stride,
                      linked ? (const Row *)g.rows.p : (const Row *)nullptr, g.vmin, h->shard_flag.p);
   SRW_HIP(hipGetLastError());
 }
@@ -2261,7 +2275,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
   ShardDst sd;
   for (int d = 0; d < SHARD_MAX_WORLD; ++d) sd.p[d] = d < world ? (char *)dst[d] : nullptr;
   const int n_blocks = h->n_cus * 4;
-  h->shard_scratch.ensure((size_t)world * (size_t)lay.cap_walkers * (size_t)SW_BYTES);
+  h->shard_scratch.ensure((size_t)world * (size_t)lay.cap_walkers * sizeof(SWalker));
   SWalker *scratch = reinterpret_cast<SWalker *>(h->shard_scratch.p);
   h->shard_blk.ensure((size_t)n_blocks * 2 * world);
   h->shard_flag.ensure(1);
@@ -2276,7 +2290,8 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     float ms = 0.f; SRW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); acc[slot] += ms; mx[slot] = std::max(mx[slot], (double)ms);
     if (slot == 1 && getenv("SRW_SHARD_PROFILE_STEPS")) fprintf(stderr, "[shard step] rank %d step %d: %.2f ms\n", h->cfg.rank, step, ms);
   };
-  if (step > 1) timed(0, [&] { hipLaunchKernelGGL(k_sh_apply, dim3(n_blocks), dim3(TPB), 0, st, io, d_paths, d_lens, stride); });
+  const int64_t n_rows = g.n_local_vertices * batch;
+  if (step > 1) timed(0, [&] { hipLaunchKernelGGL(k_sh_apply, dim3(n_blocks), dim3(TPB), 0, st, io, h->shard_pt.p, d_lens, n_rows, step - 1); });
   if (linked) {      // sampling + bucketing in one pass; no scratch, no per-block counts
     h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
     timed(1, [&] {
@@ -2365,7 +2380,12 @@ void run_shard_flush(srw_handle *h, const srw_walk_params &P, int32_t batch, con
                      int32_t *d_paths, int32_t *d_lens, int64_t stride) {
   check_shard(h, batch, lay);
   const ShardIO io = make_io(h, batch, lay, d_recv);
-  hipLaunchKernelGGL(k_sh_apply, dim3(h->n_cus * 4), dim3(TPB), 0, h->stream, io, d_paths, d_lens, stride);
+  const int64_t n_rows = h->g.n_local_vertices * batch;
+  hipLaunchKernelGGL(k_sh_apply, dim3(h->n_cus * 4), dim3(TPB), 0, h->stream, io, h->shard_pt.p, d_lens, n_rows, P.walk_length + 1);
+  if (n_rows > 0) {      // the staging becomes the caller's [row][L + 2] matrix (-1 beyond each row's length)
+    const int64_t tb = std::min<int64_t>((n_rows + 63) / 64, (int64_t)h->n_cus * 16);
+    hipLaunchKernelGGL(k_sh_transpose, dim3((unsigned)tb), dim3(TPB), 0, h->stream, (const int32_t *)h->shard_pt.p, (const int32_t *)d_lens, n_rows, stride, d_paths);
+  }
   SRW_HIP(hipGetLastError());
   // compacted ids: the home rank's paths are complete now (one flush per begin); they leave with the ids of the input
   const int64_t n = h->g.n_local_vertices * batch;

@@ -6,12 +6,12 @@ UniformRandomWalk.scala:103-112): the graph is sharded by source vertex, owner(v
 (RandomWalk.scala:16) or the VCut partition ids, and a walker standing on v is processed by owner(v).
 
 What moves (xGMI, RCCL `all_to_all_single`, equal splits): per (sender, receiver) pair one fixed-capacity chunk
-    { n_walkers, n_rets, 0, 0 } | {lw, src, prev, curr, h0, h1, h2, 0}[cap] | {lw, first slot | count << 24, v[4]}[cap]
-— 32-byte walker records (not the path and not N(prev) as in the reference, RandomWalk.scala:135) that carry the current
-group of four path slots, and 24-byte path returns (four slots at a time) to the walker's HOME rank, which alone stores
-its path: memory per rank is 1/world of the paths plus 56 B per resident walker of chunk buffers.  The counts travel in
-the chunk headers, so a super-step is: kernels -> one collective -> kernels, with no host synchronisation; an overflowing
-chunk raises a flag that is read once per batch (every rank then retries together with more slack).
+    { n_walkers, n_rets, 0, 0 } | {lw, src, prev, curr}[cap] | {lw, v}[cap]
+— 16-byte walker records (not the path and not N(prev) as in the reference, RandomWalk.scala:135) and 8-byte path returns
+(the vertex just sampled, to the walker's HOME rank, which alone stores its path; the slot is implicit: super-step s
+produces slot s): 24 bytes per walker-step.  Memory per rank is 1/world of the paths plus 24 B per resident walker of chunk
+buffers.  The counts travel in the chunk headers, so a super-step is: kernels -> one collective -> kernels, with no host
+synchronisation; an overflowing chunk raises a flag that is read once per batch (every rank then retries together with more slack).
 Because the RNG is keyed by (iteration, source vertex, step), the result is bit-identical to the single-GPU walk for any
 world size — tests assert exactly that.
 
@@ -79,6 +79,32 @@ class HipShardEngine:
         self.engine._ck(lib().srw_shard_finish(self.engine.h, C.byref(st), C.byref(of)))
         return st.as_dict(), of.value
 
+    # Collectives on the engine's device buffers.  Backend nccl (= RCCL over xGMI): as they are.  Backend gloo (the two-process
+    # GPU test on a single-GPU box, tests/test_gpu_two_process.py): staged through host memory — the kernels and the chunk
+    # protocol are the real ones, only the wire is not.
+    @staticmethod
+    def _staged(group):
+        return dist.get_backend(group) != "nccl"
+
+    def all_reduce(self, t, op, group=None):
+        if t.is_cuda and self._staged(group):
+            torch.cuda.current_stream(self.device).synchronize()
+            c = t.cpu()
+            dist.all_reduce(c, op=op, group=group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op, group=group)
+
+    def all_to_all(self, recv, send, group=None):
+        if recv.is_cuda and self._staged(group):
+            torch.cuda.current_stream(self.device).synchronize()
+            s = send.view(torch.int64).cpu()
+            r = torch.empty_like(s)
+            dist.all_to_all_single(r, s, group=group)
+            recv.view(torch.int64).copy_(r)
+        else:
+            dist.all_to_all_single(recv.view(torch.int64), send.view(torch.int64), group=group)
+
     def link_rows(self, group=None):
         """Row descriptors across the shards (srw_shard_rows_*): one all-reduce MAX of the row tables, then every rank
         derives first-order records whose links point into the owners' tables.  All ranks or none.  Returns linked?"""
@@ -90,11 +116,19 @@ class HipShardEngine:
         rows = torch.zeros(max(n.value, 1) * 2, dtype=torch.int64, device=self.device)
         self.engine._ck(L.srw_shard_rows_export(h, C.c_void_p(rows.data_ptr()), n.value))
         torch.cuda.current_stream(self.device).synchronize()
-        dist.all_reduce(rows, op=dist.ReduceOp.MAX, group=group)
-        linked = C.c_int32(0)
-        self.engine._ck(L.srw_shard_rows_commit(h, C.c_void_p(rows.data_ptr()), n.value, C.byref(linked)))
+        self.all_reduce(rows, dist.ReduceOp.MAX, group)
+        # a failing commit on one rank must not leave the others waiting in the MIN all-reduce: take part with
+        # ok = 0, release everywhere, raise afterwards
+        linked, err = C.c_int32(0), None
+        try:
+            self.engine._ck(L.srw_shard_rows_commit(h, C.c_void_p(rows.data_ptr()), n.value, C.byref(linked)))
+        except Exception as ex:      # noqa: BLE001
+            err, linked = ex, C.c_int32(0)
         ok = torch.tensor([linked.value], dtype=torch.int64, device=self.device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        self.all_reduce(ok, dist.ReduceOp.MIN, group)
+        if err is not None:
+            self.engine._ck(L.srw_shard_rows_release(h))
+            raise err
         if int(ok[0]) == 0:
             self.engine._ck(L.srw_shard_rows_release(h))
             return False
@@ -142,6 +176,18 @@ class ShardedWalker:
         self._bufs = {}
         self._linked = None          # row links across the shards: not tried yet for the loaded graph
 
+    def _a2a(self, recv, send):
+        if hasattr(self.se, "all_to_all"):
+            self.se.all_to_all(recv, send, self.group)
+        else:
+            dist.all_to_all_single(recv.view(torch.int64), send.view(torch.int64), group=self.group)
+
+    def _ar(self, t, op):
+        if hasattr(self.se, "all_reduce"):
+            self.se.all_reduce(t, op, self.group)
+        else:
+            dist.all_reduce(t, op=op, group=self.group)
+
     # ---- graph (each rank keeps only the rows it owns) ----
     def generate_rmat(self, scale, n_edges=None, seed=42, weighted=False, directed=False):
         self.engine.generate_rmat(scale, n_edges, seed=seed, weighted=weighted, directed=directed)
@@ -188,7 +234,7 @@ class ShardedWalker:
 
     # ---- walk_length + 1 super-steps over the walkers of `num_walks` consecutive walk iterations ----
     def walk_batch(self, iteration=0, p=1.0, q=1.0, walk_length=80, num_walks=1, seed=42, rng="philox", const_r=0.0,
-                   slack=1.25):
+                   slack=1.25, flags_kw=None):
         """Walk iterations iteration .. iteration + num_walks - 1 as ONE walker population: they share their super-steps,
         so the per-super-step costs (kernel launches, one collective) are paid once per batch.  Returns (paths, lens, stats)
         of THIS rank's walkers (device tensors; row lw = local vertex lw // num_walks, iteration lw % num_walks)."""
@@ -197,7 +243,8 @@ class ShardedWalker:
         stride = walk_length + 2
         if self._linked is None and p == 1.0 and q == 1.0 and rng == "philox":
             self._linked = bool(self.se.link_rows(self.group)) if hasattr(self.se, "link_rows") else False
-        P = Engine.params(p=p, q=q, walk_length=walk_length, num_walks=B, first_walk=iteration, rng=rng, const_r=const_r, seed=seed)
+        P = Engine.params(p=p, q=q, walk_length=walk_length, num_walks=B, first_walk=iteration, rng=rng, const_r=const_r, seed=seed,
+                          **(flags_kw or {}))                 # flags_kw: Engine.params switches (edge_tables=False, ...; tests)
         dev = self.device
         paths = torch.empty((max(B * n_local, 1), stride), dtype=torch.int32, device=dev)
         lens = torch.empty(max(B * n_local, 1), dtype=torch.int32, device=dev)
@@ -211,12 +258,12 @@ class ShardedWalker:
             self.se.begin(P, B, lay, recv, paths, lens)
             for step in range(1, walk_length + 2):
                 self.se.superstep(P, B, step, lay, recv, send, paths, lens)
-                dist.all_to_all_single(recv.view(torch.int64), send.view(torch.int64), group=self.group)   # chunk (me -> d) -> rank d's slot `me`
+                self._a2a(recv, send)                         # chunk (me -> d) -> rank d's slot `me`
             self.se.flush(P, B, lay, recv, paths, lens)
             st, overflow = self.se.finish()
             t = torch.tensor([st["n_steps"], st["dead_ends"], overflow], dtype=torch.int64, device=dev)
             tot = t.clone()
-            dist.all_reduce(tot, group=self.group)
+            self._ar(tot, dist.ReduceOp.SUM)
             if int(tot[2]) == 0:
                 break
             slack *= 2.0                                  # a chunk was too small somewhere: every rank retries together
@@ -246,10 +293,10 @@ class ShardedWalker:
             out_l[canon] = ln
             stats.append(st)
         # every canonical row is owned by exactly one rank; rows of other ranks are (-1.., 0) here
-        dist.all_reduce(out_l, op=dist.ReduceOp.SUM, group=self.group)
+        self._ar(out_l, dist.ReduceOp.SUM)
         out_p += 1                                        # -1 filler -> 0, ids shifted by one: SUM assembles, no sentinel id
         wide = out_p.to(torch.int64)
-        dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=self.group)
+        self._ar(wide, dist.ReduceOp.SUM)
         # rows owned by nobody else contributed 0 = (-1 + 1) from the other ranks
         paths = (wide - 1).to(torch.int32)
         return paths.cpu().numpy(), out_l.cpu().numpy(), stats

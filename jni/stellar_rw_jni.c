@@ -136,11 +136,13 @@ JNIEXPORT jlongArray JNICALL FN(walkAndSaveSharded)(JNIEnv *env, jobject self, j
   jint devs[64];
   jint n = 0;
   {
-    jint *d = (jint *)(*env)->GetPrimitiveArrayCritical(env, devices, NULL);
-    if (!d) return NULL;
-    /* the array length is not needed from the JVM: the Scala side passes at most 64 ordinals, terminated by -1 */
-    while (n < 64 && d[n] >= 0) { devs[n] = d[n]; ++n; }
-    (*env)->ReleasePrimitiveArrayCritical(env, devices, d, 0);
+    /* the JVM's own array length bounds the read; a -1 entry ends the list early (the Scala side may pad) */
+    const jsize len = devices ? (*env)->GetArrayLength(env, devices) : 0;
+    jint tmp[64];
+    const jsize take = len < 64 ? len : 64;
+    if (take > 0) (*env)->GetIntArrayRegion(env, devices, 0, take, tmp);
+    while (n < take && tmp[n] >= 0) { devs[n] = tmp[n]; ++n; }
+    if (n == 0) { throw_status(env, SRW_ERR_INVALID, NULL); return NULL; }
   }
   srw_cluster *c = NULL;
   /* q == 1: no shard ever tests "x in N(prev)" — the replicated neighbor-id structure is skipped (memory per shard ~ 1 / n) */
@@ -182,13 +184,20 @@ JNIEXPORT jintArray JNICALL FN(fetchPaths)(JNIEnv *env, jobject self, jlong hh, 
   int32_t rc = srw_device_paths(H(hh), &dp, &dl, &nw, &stride);
   if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return NULL; }
   if (nw * (int64_t)stride > 0x7FFFFFF0ll) { throw_status(env, SRW_ERR_NOMEM, H(hh)); return NULL; }
+  /* lensOut must hold one length per walker: the copy below writes nw ints into it */
+  if (lensOut && (int64_t)(*env)->GetArrayLength(env, lensOut) < nw) { throw_status(env, SRW_ERR_INVALID, H(hh)); return NULL; }
   jintArray a = (*env)->NewIntArray(env, (jsize)(nw * stride));
   if (!a) return NULL;
-  jint *paths = (jint *)(*env)->GetPrimitiveArrayCritical(env, a, NULL);
-  jint *lens = lensOut ? (jint *)(*env)->GetPrimitiveArrayCritical(env, lensOut, NULL) : NULL;
-  rc = paths ? srw_fetch_paths(H(hh), (int32_t *)paths, (int32_t *)lens) : SRW_ERR_NOMEM;
-  if (lens) (*env)->ReleasePrimitiveArrayCritical(env, lensOut, lens, 0);
-  if (paths) (*env)->ReleasePrimitiveArrayCritical(env, a, paths, 0);
+  /* the device-to-host copies block: they go into C buffers, not into a GetPrimitiveArrayCritical region (which may stall
+   * the collector for their whole duration); Set*ArrayRegion then moves the bytes into the Java arrays */
+  int32_t *paths = (int32_t *)malloc((size_t)(nw * stride > 0 ? nw * stride : 1) * sizeof(int32_t));
+  int32_t *lens = lensOut ? (int32_t *)malloc((size_t)(nw > 0 ? nw : 1) * sizeof(int32_t)) : NULL;
+  rc = (paths && (lens || !lensOut)) ? srw_fetch_paths(H(hh), paths, lens) : SRW_ERR_NOMEM;
+  if (rc == SRW_OK) {
+    (*env)->SetIntArrayRegion(env, a, 0, (jsize)(nw * stride), (const jint *)paths);
+    if (lens) (*env)->SetIntArrayRegion(env, lensOut, 0, (jsize)nw, (const jint *)lens);
+  }
+  free(paths); free(lens);
   if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return NULL; }
   return a;
 }

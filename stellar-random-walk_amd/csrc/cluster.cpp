@@ -14,7 +14,9 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -27,7 +29,7 @@ struct srw_cluster {
   std::string last_error;
   std::vector<DevBuf<char>> recv[2];
   std::vector<DevBuf<int32_t>> paths, lens;
-  std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> ev[2];                   // per shard, alternating by super-step parity
   std::vector<std::vector<int32_t>> vrank;        // host copy: global rank of each local vertex
   struct Batch { int32_t it0, n; };
   std::vector<Batch> batches;                      // of the last walk
@@ -48,9 +50,32 @@ int32_t cguard(srw_cluster *c, F &&f) {
 void ck(srw_cluster *c, int r, int32_t rc) {
   if (rc != SRW_OK) throw Error(rc, std::string("shard ") + std::to_string(r) + ": " + srw_last_error(c->sh[(size_t)r]));
 }
+// One host thread per device: a load (tokenizer + CSR build: seconds per shard) or the super-steps of a walk run on all
+// shards at once instead of shard after shard (round 2: one thread drove everything — 80 serial API calls per super-step at
+// world 8, loads 8x the single-shard time).  SRW_CLUSTER_SERIAL=1 loads shard after shard (debugging).
 void each(srw_cluster *c, const std::function<int32_t(int, srw_handle *)> &f) {
-  for (int r = 0; r < c->world(); ++r) ck(c, r, f(r, c->sh[(size_t)r]));
+  const int world = c->world();
+  if (world == 1 || getenv("SRW_CLUSTER_SERIAL")) {
+    for (int r = 0; r < world; ++r) ck(c, r, f(r, c->sh[(size_t)r]));
+    return;
+  }
+  std::vector<int32_t> rc((size_t)world, SRW_OK);
+  std::vector<std::thread> th;
+  for (int r = 0; r < world; ++r)
+    th.emplace_back([&, r] { (void)hipSetDevice(c->dev[(size_t)r]); rc[(size_t)r] = f(r, c->sh[(size_t)r]); });
+  for (auto &t : th) t.join();
+  for (int r = 0; r < world; ++r) ck(c, r, rc[(size_t)r]);
 }
+// sense-reversing spin barrier for the per-device threads of a walk (a super-step is tens of microseconds of host work)
+struct SpinBarrier {
+  explicit SpinBarrier(int n) : n_(n) {}
+  void wait() {
+    const int gen = gen_.load(std::memory_order_acquire);
+    if (count_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) { count_.store(0, std::memory_order_relaxed); gen_.store(gen + 1, std::memory_order_release); }
+    else while (gen_.load(std::memory_order_acquire) == gen) std::this_thread::yield();
+  }
+  int n_; std::atomic<int> count_{0}, gen_{0};
+};
 }  // namespace
 
 namespace {
@@ -126,10 +151,10 @@ int32_t srw_cluster_create(const int32_t *devices, int32_t n_devices, int32_t fl
     }
     c->recv[0].resize((size_t)n_devices); c->recv[1].resize((size_t)n_devices);
     c->paths.resize((size_t)n_devices); c->lens.resize((size_t)n_devices); c->vrank.resize((size_t)n_devices);
-    c->ev.assign((size_t)n_devices, nullptr);
+    for (int b = 0; b < 2; ++b) c->ev[b].assign((size_t)n_devices, nullptr);
     for (int r = 0; r < n_devices; ++r) {
       SRW_HIP(hipSetDevice(devices[r]));
-      SRW_HIP(hipEventCreateWithFlags(&c->ev[(size_t)r], hipEventDisableTiming));
+      for (int b = 0; b < 2; ++b) SRW_HIP(hipEventCreateWithFlags(&c->ev[b][(size_t)r], hipEventDisableTiming));
     }
   });
   if (rc != SRW_OK) {      // no cluster to ask: the message goes where srw_last_error(NULL) finds it
@@ -147,7 +172,7 @@ void srw_cluster_destroy(srw_cluster *c) {
   for (size_t r = 0; r < c->sh.size(); ++r) {
     (void)hipSetDevice(c->dev[r]);
     if (c->sh[r] && c->sh[r]->stream) (void)hipStreamSynchronize(c->sh[r]->stream);
-    if (r < c->ev.size() && c->ev[r]) (void)hipEventDestroy(c->ev[r]);
+    for (int b = 0; b < 2; ++b) if (r < c->ev[b].size() && c->ev[b][r]) (void)hipEventDestroy(c->ev[b][r]);
     for (int b = 0; b < 2; ++b) if (r < c->recv[b].size()) c->recv[b][r].release();
     if (r < c->paths.size()) { c->paths[r].release(); c->lens[r].release(); }
   }
@@ -189,96 +214,156 @@ int32_t srw_cluster_graph_stats(const srw_cluster *c, int64_t *n_vertices, int64
   return srw_graph_stats(c->sh[0], n_vertices, n_entries);   // every shard reports the whole graph's counts
 }
 
+}  // extern "C"
+
+namespace {
+// One batch (P.num_walks = B walk iterations starting at P.first_walk, one walker population) on every shard: begin,
+// walk_length + 1 super-steps, flush, finish.  pth / len: per shard, device buffers of B * n_local rows.  One host thread per
+// device; per super-step every thread enqueues its shard's kernels, records its event, meets the others at a barrier (so that
+// every event of this super-step IS recorded) and makes its stream wait for theirs — events alternate by super-step parity, so
+// one barrier per super-step is enough.  No host synchronisation with the devices inside the batch.  true: a chunk overflowed.
+bool run_batch(srw_cluster *c, const srw_walk_params &P, int32_t B, double slack, const std::vector<int32_t *> &pth,
+               const std::vector<int32_t *> &len, srw_walk_stats &bt) {
+  const int32_t world = c->world();
+  srw_shard_layout lay;
+  ck(c, 0, srw_shard_layout_for(c->sh[0], B, slack, &lay));
+  const size_t buf_bytes = (size_t)world * (size_t)lay.chunk_bytes;
+  for (int r = 0; r < world; ++r) {
+    SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
+    for (int b = 0; b < 2; ++b) c->recv[b][(size_t)r].ensure(buf_bytes);
+  }
+  SpinBarrier bar(world);
+  std::atomic<bool> failed{false};
+  std::vector<std::string> err((size_t)world);
+  std::vector<int32_t> err_code((size_t)world, SRW_OK);
+  std::vector<srw_walk_stats> st((size_t)world);
+  std::vector<int32_t> of((size_t)world, 0);
+  auto body = [&](int r) {
+    srw_handle *h = c->sh[(size_t)r];
+    auto guard = [&](auto &&f) {                      // a failing shard keeps meeting the others at the barriers
+      if (failed.load(std::memory_order_acquire)) return;
+      try { f(); }
+      catch (const Error &e) { err[(size_t)r] = e.what(); err_code[(size_t)r] = e.code; failed.store(true, std::memory_order_release); }
+      catch (const std::exception &e) { err[(size_t)r] = e.what(); err_code[(size_t)r] = SRW_ERR_INVALID; failed.store(true, std::memory_order_release); }
+    };
+    guard([&] { SRW_HIP(hipSetDevice(c->dev[(size_t)r])); ck(c, r, srw_shard_begin(h, &P, B, &lay, c->recv[0][(size_t)r].p, pth[(size_t)r], len[(size_t)r])); });
+    std::vector<void *> dst((size_t)world);
+    for (int32_t step = 1; step <= P.walk_length + 1; ++step) {
+      const int cur = (step - 1) & 1, nxt = cur ^ 1;
+      guard([&] {
+        for (int d = 0; d < world; ++d) dst[(size_t)d] = c->recv[nxt][(size_t)d].p + (size_t)r * (size_t)lay.chunk_bytes;
+        ck(c, r, srw_shard_superstep(h, &P, B, step, &lay, c->recv[cur][(size_t)r].p, dst.data(), pth[(size_t)r], len[(size_t)r]));
+        SRW_HIP(hipEventRecord(c->ev[cur][(size_t)r], h->stream));
+      });
+      if (world > 1) {
+        bar.wait();
+        guard([&] {
+          for (int o = 0; o < world; ++o)
+            if (o != r) SRW_HIP(hipStreamWaitEvent(h->stream, c->ev[cur][(size_t)o], 0));
+        });
+      }
+    }
+    const int fin = (P.walk_length + 1) & 1;
+    guard([&] {
+      ck(c, r, srw_shard_flush(h, &P, B, &lay, c->recv[fin][(size_t)r].p, pth[(size_t)r], len[(size_t)r]));
+      ck(c, r, srw_shard_finish(h, &st[(size_t)r], &of[(size_t)r]));
+    });
+  };
+  if (world == 1) body(0);
+  else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r) th.emplace_back(body, r);
+    for (auto &t : th) t.join();
+  }
+  for (int r = 0; r < world; ++r)
+    if (err_code[(size_t)r] != SRW_OK) throw Error(err_code[(size_t)r], err[(size_t)r]);
+  bool overflow = false;
+  memset(&bt, 0, sizeof bt);
+  for (int r = 0; r < world; ++r) {
+    const srw_walk_stats &x = st[(size_t)r];
+    overflow |= of[(size_t)r] != 0;
+    bt.n_steps += x.n_steps; bt.dead_ends += x.dead_ends; bt.sum_deg_curr += x.sum_deg_curr; bt.sum_deg_prev += x.sum_deg_prev;
+    bt.ent_reads += x.ent_reads; bt.fallbacks += x.fallbacks; bt.trials += x.trials;
+    for (int i = 0; i < 12; ++i) bt.strategy_steps[i] += x.strategy_steps[i];
+    bt.edge_tables += x.edge_tables; bt.edge_table_bytes += x.edge_table_bytes;      // per shard: summed = the whole graph's set
+  }
+  return overflow;
+}
+
+struct WalkPlan { std::vector<int64_t> n_local; int64_t n_global = 0, stride = 0; int32_t batch = 1; int kind = 1; };
+WalkPlan plan_walk(srw_cluster *c, const srw_walk_params &P0, int32_t batch) {
+  const int32_t world = c->world();
+  if (P0.num_walks < 0 || P0.walk_length < 0) throw Error(SRW_ERR_INVALID, "bad walk parameters");
+  if (P0.sampler != SRW_SAMPLER_REFERENCE) throw Error(SRW_ERR_INVALID, "the vertex-sharded walk runs Mode R");
+  WalkPlan w;
+  w.stride = (int64_t)P0.walk_length + 2;
+  w.n_local.assign((size_t)world, 0);
+  for (int r = 0; r < world; ++r) ck(c, r, srw_shard_capacity(c->sh[(size_t)r], &w.n_local[(size_t)r], &w.n_global));
+  w.kind = (P0.p == 1.0f && P0.q == 1.0f && !(P0.flags & SRW_WALK_FORCE_GENERAL)) ? 1 : 2;
+  if (w.n_global == 0 || P0.num_walks == 0) return w;
+  if (w.kind == 1 && P0.rng_mode == SRW_RNG_PHILOX && c->rows_linked < 0) link_rows(c);
+  if (batch <= 0) {   // as many iterations per population as keep a shard's chunk buffers under ~2 GiB
+    const int64_t per_iter = std::max<int64_t>(1, w.n_global / world * 30);      // 24 B of chunk space per resident walker x slack
+    batch = (int32_t)std::max<int64_t>(1, std::min<int64_t>(P0.num_walks, ((int64_t)2 << 30) / per_iter));
+  }
+  w.batch = std::min(batch, std::max(P0.num_walks, 1));
+  for (int r = 0; r < world; ++r) {
+    if (c->vrank[(size_t)r].size() != (size_t)w.n_local[(size_t)r]) {
+      c->vrank[(size_t)r].assign((size_t)w.n_local[(size_t)r], 0);
+      if (w.n_local[(size_t)r]) ck(c, r, srw_shard_vertex_ranks(c->sh[(size_t)r], c->vrank[(size_t)r].data()));
+    }
+  }
+  return w;
+}
+void add_stats(srw_walk_stats &tot, const srw_walk_stats &bt) {
+  tot.n_steps += bt.n_steps; tot.dead_ends += bt.dead_ends; tot.sum_deg_curr += bt.sum_deg_curr; tot.sum_deg_prev += bt.sum_deg_prev;
+  tot.ent_reads += bt.ent_reads; tot.fallbacks += bt.fallbacks; tot.trials += bt.trials;
+  for (int i = 0; i < 12; ++i) tot.strategy_steps[i] += bt.strategy_steps[i];
+  tot.edge_tables = bt.edge_tables; tot.edge_table_bytes = bt.edge_table_bytes;
+}
+}  // namespace
+
+extern "C" {
+
 int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t batch, srw_walk_stats *stats) {
   if (!c || !params) return SRW_ERR_INVALID;
   return cguard(c, [&] {
     const srw_walk_params P0 = *params;
     const int32_t world = c->world();
-    if (P0.num_walks < 0 || P0.walk_length < 0) throw Error(SRW_ERR_INVALID, "bad walk parameters");
-    if (P0.sampler != SRW_SAMPLER_REFERENCE) throw Error(SRW_ERR_INVALID, "the vertex-sharded walk runs Mode R");
-    const int64_t stride = (int64_t)P0.walk_length + 2;
-    std::vector<int64_t> n_local((size_t)world, 0);
-    int64_t n_global = 0;
-    for (int r = 0; r < world; ++r) ck(c, r, srw_shard_capacity(c->sh[(size_t)r], &n_local[(size_t)r], &n_global));
     c->valid = false; c->batches.clear();
+    const WalkPlan w = plan_walk(c, P0, batch);
     c->walk_length = P0.walk_length; c->num_walks = P0.num_walks;
     srw_walk_stats tot; memset(&tot, 0, sizeof tot);
-    tot.kernel_kind = (P0.p == 1.0f && P0.q == 1.0f && !(P0.flags & SRW_WALK_FORCE_GENERAL)) ? 1 : 2;
-    if (n_global == 0 || P0.num_walks == 0) { if (stats) *stats = tot; c->valid = true; return; }
-    if (tot.kernel_kind == 1 && P0.rng_mode == SRW_RNG_PHILOX && c->rows_linked < 0) link_rows(c);
-    if (batch <= 0) {   // as many iterations per population as keep a shard's chunk buffers under ~2 GiB
-      const int64_t per_iter = std::max<int64_t>(1, n_global / world * 30);      // 24 B of chunk space per resident walker x slack
-      batch = (int32_t)std::max<int64_t>(1, std::min<int64_t>(P0.num_walks, ((int64_t)2 << 30) / per_iter));
-    }
-    batch = std::min(batch, P0.num_walks);
+    tot.kernel_kind = w.kind;
+    if (w.n_global == 0 || P0.num_walks == 0) { if (stats) *stats = tot; c->valid = true; return; }
     for (int r = 0; r < world; ++r) {
       SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
-      c->paths[(size_t)r].ensure((size_t)std::max<int64_t>(1, (int64_t)P0.num_walks * n_local[(size_t)r] * stride));
-      c->lens[(size_t)r].ensure((size_t)std::max<int64_t>(1, (int64_t)P0.num_walks * n_local[(size_t)r]));
-      if (c->vrank[(size_t)r].size() != (size_t)n_local[(size_t)r]) {
-        c->vrank[(size_t)r].assign((size_t)n_local[(size_t)r], 0);
-        if (n_local[(size_t)r]) ck(c, r, srw_shard_vertex_ranks(c->sh[(size_t)r], c->vrank[(size_t)r].data()));
-      }
+      c->paths[(size_t)r].ensure((size_t)std::max<int64_t>(1, (int64_t)P0.num_walks * w.n_local[(size_t)r] * w.stride));
+      c->lens[(size_t)r].ensure((size_t)std::max<int64_t>(1, (int64_t)P0.num_walks * w.n_local[(size_t)r]));
     }
     const auto t0 = std::chrono::steady_clock::now();
     double slack = 1.25;
+    std::vector<int32_t *> pth((size_t)world), len((size_t)world);
     for (int32_t it0 = 0; it0 < P0.num_walks;) {
-      const int32_t B = std::min(batch, P0.num_walks - it0);
+      const int32_t B = std::min(w.batch, P0.num_walks - it0);
       srw_walk_params P = P0; P.first_walk = P0.first_walk + it0; P.num_walks = B;
-      srw_shard_layout lay;
-      ck(c, 0, srw_shard_layout_for(c->sh[0], B, slack, &lay));
-      const size_t buf_bytes = (size_t)world * (size_t)lay.chunk_bytes;
       for (int r = 0; r < world; ++r) {
-        SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
-        for (int b = 0; b < 2; ++b) c->recv[b][(size_t)r].ensure(buf_bytes);
+        pth[(size_t)r] = c->paths[(size_t)r].p + (int64_t)it0 * w.n_local[(size_t)r] * w.stride;
+        len[(size_t)r] = c->lens[(size_t)r].p + (int64_t)it0 * w.n_local[(size_t)r];
       }
-      auto pth = [&](int r) { return c->paths[(size_t)r].p + (int64_t)it0 * n_local[(size_t)r] * stride; };
-      auto len = [&](int r) { return c->lens[(size_t)r].p + (int64_t)it0 * n_local[(size_t)r]; };
-      for (int r = 0; r < world; ++r) ck(c, r, srw_shard_begin(c->sh[(size_t)r], &P, B, &lay, c->recv[0][(size_t)r].p, pth(r), len(r)));
-      std::vector<void *> dst((size_t)world);
-      for (int32_t step = 1; step <= P.walk_length + 1; ++step) {
-        const int cur = (step - 1) & 1, nxt = cur ^ 1;
-        for (int r = 0; r < world; ++r) {
-          for (int d = 0; d < world; ++d) dst[(size_t)d] = c->recv[nxt][(size_t)d].p + (size_t)r * (size_t)lay.chunk_bytes;
-          ck(c, r, srw_shard_superstep(c->sh[(size_t)r], &P, B, step, &lay, c->recv[cur][(size_t)r].p, dst.data(), pth(r), len(r)));
-          SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
-          SRW_HIP(hipEventRecord(c->ev[(size_t)r], c->sh[(size_t)r]->stream));
-        }
-        if (world > 1)
-          for (int r = 0; r < world; ++r) {
-            SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
-            for (int o = 0; o < world; ++o)
-              if (o != r) SRW_HIP(hipStreamWaitEvent(c->sh[(size_t)r]->stream, c->ev[(size_t)o], 0));
-          }
-      }
-      const int fin = (P.walk_length + 1) & 1;
-      for (int r = 0; r < world; ++r) ck(c, r, srw_shard_flush(c->sh[(size_t)r], &P, B, &lay, c->recv[fin][(size_t)r].p, pth(r), len(r)));
-      bool overflow = false;
-      srw_walk_stats bt; memset(&bt, 0, sizeof bt);
-      for (int r = 0; r < world; ++r) {
-        srw_walk_stats s; int32_t of = 0;
-        ck(c, r, srw_shard_finish(c->sh[(size_t)r], &s, &of));
-        overflow |= of != 0;
-        bt.n_steps += s.n_steps; bt.dead_ends += s.dead_ends; bt.sum_deg_curr += s.sum_deg_curr; bt.sum_deg_prev += s.sum_deg_prev;
-        bt.ent_reads += s.ent_reads; bt.fallbacks += s.fallbacks; bt.trials += s.trials;
-        for (int i = 0; i < 12; ++i) bt.strategy_steps[i] += s.strategy_steps[i];
-        bt.edge_tables += s.edge_tables; bt.edge_table_bytes += s.edge_table_bytes;      // per shard: summed = the whole graph's set
-      }
-      if (overflow) {                 // a chunk was too small for this graph's skew: same batch again with more room
+      srw_walk_stats bt;
+      if (run_batch(c, P, B, slack, pth, len, bt)) {      // a chunk was too small for this graph's skew: same batch again with more room
         if (getenv("SRW_TIMING")) fprintf(stderr, "[cluster] chunk overflow at slack %.2f (batch %d, iteration %d): retrying\n", slack, B, it0);
         slack *= 2.0;
-        if (slack > 64.0) throw Error(SRW_ERR_NOMEM, "vertex-sharded walk: chunk overflow persists at 64x slack");
+        if (slack > 64.0 * world) throw Error(SRW_ERR_NOMEM, "vertex-sharded walk: chunk overflow persists at 64x slack");
         continue;
       }
-      tot.n_steps += bt.n_steps; tot.dead_ends += bt.dead_ends; tot.sum_deg_curr += bt.sum_deg_curr; tot.sum_deg_prev += bt.sum_deg_prev;
-      tot.ent_reads += bt.ent_reads; tot.fallbacks += bt.fallbacks; tot.trials += bt.trials;
-      for (int i = 0; i < 12; ++i) tot.strategy_steps[i] += bt.strategy_steps[i];
-      tot.edge_tables = bt.edge_tables; tot.edge_table_bytes = bt.edge_table_bytes;
+      add_stats(tot, bt);
       c->batches.push_back({it0, B});
       it0 += B;
     }
     tot.kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    tot.n_walkers = (int64_t)P0.num_walks * n_global;
+    tot.n_walkers = (int64_t)P0.num_walks * w.n_global;
     tot.record_bytes = 16;
     if (stats) *stats = tot;
     c->valid = true;
@@ -320,18 +405,92 @@ int32_t srw_cluster_fetch_paths(srw_cluster *c, int32_t *paths, int32_t *lens) {
 int32_t srw_cluster_walk_and_save(srw_cluster *c, const srw_walk_params *params, const char *output_dir, int32_t n_parts,
                                   int32_t write_crc, srw_walk_stats *stats) {
   if (!c || !params || !output_dir) return SRW_ERR_INVALID;
+  // RandomWalk.save is per partition (RandomWalk.scala:234-241); here the job is streamed batch by batch and, inside a batch,
+  // slice by slice of the canonical order (walk iteration major, source id ascending): every shard hands over the rows of its
+  // vertices whose global rank falls into the slice (a contiguous local range: local vertices are in id order), the host puts
+  // them at their canonical position and the writer formats and appends the slice.  Host memory: one slice + its staging
+  // (SRW_CLUSTER_SLICE_ROWS rows, default 2 M = 1.3 GB at walkLength 80) instead of every path of every iteration (config 4,
+  // numWalks 10: 207 GB); device memory: one batch of paths per shard instead of all numWalks.
   return cguard(c, [&] {
+    const srw_walk_params P0 = *params;
+    const int32_t world = c->world();
     int64_t nv = 0, ne = 0;
     ck(c, 0, srw_graph_stats(c->sh[0], &nv, &ne));
-    const int64_t n_walkers = (int64_t)params->num_walks * nv, stride = (int64_t)params->walk_length + 2;
-    PathWriter writer(output_dir, n_parts, n_walkers, write_crc != 0);       // fails first if <output>/path exists
-    int32_t rc = srw_cluster_walk(c, params, 0, stats);
-    if (rc != SRW_OK) throw Error(rc, c->last_error);
-    std::vector<int32_t> paths((size_t)std::max<int64_t>(1, n_walkers * stride)), lens((size_t)std::max<int64_t>(1, n_walkers));
-    rc = srw_cluster_fetch_paths(c, paths.data(), lens.data());
-    if (rc != SRW_OK) throw Error(rc, c->last_error);
-    if (n_walkers > 0) writer.append(paths.data(), lens.data(), n_walkers, stride);
+    PathWriter writer(output_dir, n_parts, (int64_t)P0.num_walks * nv, write_crc != 0);       // fails first if <output>/path exists
+    c->valid = false; c->batches.clear();
+    const WalkPlan w = plan_walk(c, P0, 0);
+    srw_walk_stats tot; memset(&tot, 0, sizeof tot);
+    tot.kernel_kind = w.kind;
+    if (w.n_global == 0 || P0.num_walks == 0) { writer.close(); if (stats) *stats = tot; return; }
+    const int64_t stride = w.stride;
+    for (int r = 0; r < world; ++r) {
+      SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
+      c->paths[(size_t)r].ensure((size_t)std::max<int64_t>(1, (int64_t)w.batch * w.n_local[(size_t)r] * stride));
+      c->lens[(size_t)r].ensure((size_t)std::max<int64_t>(1, (int64_t)w.batch * w.n_local[(size_t)r]));
+    }
+    int64_t slice_rows = 2 << 20;
+    if (const char *e = getenv("SRW_CLUSTER_SLICE_ROWS"); e && *e) slice_rows = std::max<int64_t>(1, atoll(e));
+    slice_rows = std::min<int64_t>(slice_rows, w.n_global);
+    std::vector<int32_t> sl_paths((size_t)(slice_rows * stride)), sl_lens((size_t)slice_rows);
+    std::vector<std::vector<int32_t>> st_paths((size_t)world), st_lens((size_t)world);       // per-shard staging of a slice's rows
+    double walk_ms = 0.0, slack = 1.25;
+    std::vector<int32_t *> pth((size_t)world), len((size_t)world);
+    for (int r = 0; r < world; ++r) { pth[(size_t)r] = c->paths[(size_t)r].p; len[(size_t)r] = c->lens[(size_t)r].p; }
+    for (int32_t it0 = 0; it0 < P0.num_walks;) {
+      const int32_t B = std::min(w.batch, P0.num_walks - it0);
+      srw_walk_params P = P0; P.first_walk = P0.first_walk + it0; P.num_walks = B;
+      srw_walk_stats bt;
+      const auto t0 = std::chrono::steady_clock::now();
+      const bool overflow = run_batch(c, P, B, slack, pth, len, bt);
+      walk_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (overflow) {
+        slack *= 2.0;
+        if (slack > 64.0 * world) throw Error(SRW_ERR_NOMEM, "vertex-sharded walk: chunk overflow persists at 64x slack");
+        continue;
+      }
+      add_stats(tot, bt);
+      // the batch's rows leave in canonical order: iteration by iteration, slice by slice of the global ranks
+      for (int32_t i = 0; i < B; ++i) {
+        for (int64_t g0 = 0; g0 < w.n_global; g0 += slice_rows) {
+          const int64_t g1 = std::min<int64_t>(g0 + slice_rows, w.n_global);
+          std::vector<std::thread> th;
+          std::vector<int32_t> rc((size_t)world, SRW_OK);
+          std::vector<std::string> em((size_t)world);
+          for (int r = 0; r < world; ++r)
+            th.emplace_back([&, r] {
+              try {
+                const std::vector<int32_t> &vr = c->vrank[(size_t)r];
+                const int64_t l0 = std::lower_bound(vr.begin(), vr.end(), (int32_t)g0) - vr.begin();
+                const int64_t l1 = std::lower_bound(vr.begin(), vr.end(), (int32_t)std::min<int64_t>(g1, 0x7FFFFFFF)) - vr.begin();
+                const int64_t n = l1 - l0;
+                if (n <= 0) return;
+                SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
+                std::vector<int32_t> &sp = st_paths[(size_t)r], &sn = st_lens[(size_t)r];
+                if (sp.size() < (size_t)(n * stride)) sp.resize((size_t)(n * stride));
+                if (sn.size() < (size_t)n) sn.resize((size_t)n);
+                // row lw = local vertex * B + iteration in the batch: the slice's rows of iteration i are B rows apart
+                SRW_HIP(hipMemcpy2D(sp.data(), (size_t)stride * 4, c->paths[(size_t)r].p + ((int64_t)l0 * B + i) * stride, (size_t)B * stride * 4,
+                                    (size_t)stride * 4, (size_t)n, hipMemcpyDeviceToHost));
+                SRW_HIP(hipMemcpy2D(sn.data(), 4, c->lens[(size_t)r].p + (int64_t)l0 * B + i, (size_t)B * 4, 4, (size_t)n, hipMemcpyDeviceToHost));
+                for (int64_t k = 0; k < n; ++k) {
+                  const int64_t at = (int64_t)vr[(size_t)(l0 + k)] - g0;
+                  memcpy(sl_paths.data() + at * stride, sp.data() + k * stride, (size_t)stride * 4);
+                  sl_lens[(size_t)at] = sn[(size_t)k];
+                }
+              } catch (const Error &e) { rc[(size_t)r] = e.code; em[(size_t)r] = e.what(); }
+            });
+          for (auto &t : th) t.join();
+          for (int r = 0; r < world; ++r) if (rc[(size_t)r] != SRW_OK) throw Error(rc[(size_t)r], em[(size_t)r]);
+          writer.append(sl_paths.data(), sl_lens.data(), g1 - g0, stride);
+        }
+      }
+      it0 += B;
+    }
     writer.close();
+    tot.kernel_ms = walk_ms;
+    tot.n_walkers = (int64_t)P0.num_walks * w.n_global;
+    tot.record_bytes = 16;
+    if (stats) *stats = tot;
   });
 }
 

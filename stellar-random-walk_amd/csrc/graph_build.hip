@@ -344,6 +344,11 @@ bool ids_are_sparse(const srw_handle *h, int64_t n_ids, int32_t vmin, int32_t vm
   if (h->cfg.flags & SRW_CFG_COMPACT_IDS) return true;
   const int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
   if (n_slots > 16 * n_ids + ((int64_t)1 << 22)) return true;      // > 256 B of row descriptors per id that occurs
+  // Shards must ALL take the same decision (ownership is taken over the rank when the ids are compacted, over the id when
+  // they are not): on a sharded handle it is a pure function of the input — never of this device's free memory, which
+  // differs between GPUs and between shards loaded one after the other on one GPU.  Dense tables that do not
+  // fit then fail the load (check_id_range, with its message) instead of silently changing the id space on one shard.
+  if (h->cfg.world > 1) return false;
   try { check_id_range(vmin, vmax); } catch (const Error &) { return true; }
   return false;
 }

@@ -41,10 +41,13 @@ struct JNINativeInterface_ {
   void *pad168[1];                                                                     /* 168 */
   const char *(*GetStringUTFChars)(JNIEnv *, jstring, jboolean *);                     /* 169 */
   void (*ReleaseStringUTFChars)(JNIEnv *, jstring, const char *);                      /* 170 */
-  void *pad171[8];                                                                     /* 171 .. 178 */
+  jsize (*GetArrayLength)(JNIEnv *, jarray);                                           /* 171 */
+  void *pad172[7];                                                                     /* 172 .. 178 */
   jintArray (*NewIntArray)(JNIEnv *, jsize);                                           /* 179 */
   jlongArray (*NewLongArray)(JNIEnv *, jsize);                                         /* 180 */
-  void *pad181[30];                                                                    /* 181 .. 210 */
+  void *pad181[22];                                                                    /* 181 .. 202 */
+  void (*GetIntArrayRegion)(JNIEnv *, jintArray, jsize, jsize, jint *);                /* 203 */
+  void *pad204[7];                                                                     /* 204 .. 210 */
   void (*SetIntArrayRegion)(JNIEnv *, jintArray, jsize, jsize, const jint *);          /* 211 */
   void (*SetLongArrayRegion)(JNIEnv *, jlongArray, jsize, jsize, const jlong *);       /* 212 */
   void *pad213[9];                                                                     /* 213 .. 221 */

@@ -38,31 +38,73 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 REQUEST_CEILING = 50.0e9       # profiles/r02_translation_and_request_rate.md: L2-miss requests/s, any request size
 
 
+def _rmat_weights_np(np, s, d, seed=42):
+    """Vectorised oracle/srw_oracle.c:orc_rmat_weight: w = 1 + (mix32(min, max, seed) & 15)."""
+    a = np.minimum(s, d).astype(np.uint32)
+    b = np.maximum(s, d).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x = b * np.uint32(0x85EBCA77)
+        h = np.uint32(seed) ^ (a * np.uint32(0x9E3779B1)) ^ ((x << np.uint32(13)) | (x >> np.uint32(19)))
+        h ^= h >> np.uint32(16); h *= np.uint32(0x85EBCA6B); h ^= h >> np.uint32(13)
+        h *= np.uint32(0xC2B2AE35); h ^= h >> np.uint32(16)
+    return (np.uint32(1) + (h & np.uint32(15))).astype(np.float32)
+
+
 def cpu_baseline(args):
-    """The CPU restatement of the reference algorithm (oracle/, kind "port": the Scala/Spark reference cannot be
-    built here), timed on this box's host cores on a bounded sample.  The 1 B-edge graph cannot be assembled on
-    the CPU inside the time budget, so the sample runs on the same RMAT family at scale 20 (BASELINE config 2)."""
+    """The CPU restatement of the reference algorithm (oracle/, kind "port": the Scala/Spark reference cannot be built here —
+    no JVM in the image, probed again below), timed on this box's host cores on BOUNDED samples of BASELINE.md §3's plan:
+    karate, RMAT-14, RMAT-16 and an RMAT-20 sample, each at (p, q) = (1, 1) unweighted and (0.25, 4) weighted, the faithful
+    variant (the reference's own O(deg(curr) * deg(prev)) linear `exists`, RandomSample.scala:27-44) and the fast one (sorted
+    membership: same outputs).  The object's own value is the RMAT-20 (1, 1) faithful sample, as in rounds 1-2; `plan` lists
+    every measurement, so that the biased GPU lines have their CPU number beside them."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_py
     cores = os.cpu_count() or 1
-    scale = args.cpu_scale
-    t0 = time.time()
-    s, d = oracle_py.rmat_edges(scale, 16 << scale, seed=42)
-    g = oracle_py.Graph.from_coo(s, d, None, directed=False)
-    t_build = time.time() - t0
-    verts = g.vertices()
-    n_src = args.cpu_sources or max(64, 3 * cores)
-    src = verts[np.linspace(0, len(verts) - 1, n_src).astype(np.int64)]
-    # faithful = the reference's own O(deg(curr) * deg(prev)) computeSecondOrderWeights (linear `exists`)
-    t0 = time.time()
-    _, _, steps = g.walk(sources=src, p=args.p, q=args.q, walk_length=args.cpu_walk_length, num_walks=1, seed=42,
-                         faithful=True, threads=cores)
-    dt = time.time() - t0
-    return {"value": steps / dt, "unit": "walk-steps/s", "cores": cores, "kind": "port",
-            "sample": "CPU restatement of RandomSample/RandomWalk (faithful linear-exists variant), RMAT scale-%d ef16 "
-                      "undirected p=%g q=%g, %d evenly spaced sources x %d steps, %d threads; %.1f s walk, %.1f s graph build"
-                      % (scale, args.p, args.q, n_src, args.cpu_walk_length + 1, cores, dt, t_build)}
+    jvm = {t: shutil.which(t) for t in ("java", "spark-submit")}
+    plan = []
+
+    def timed(g, label, src, p, q, L, faithful):
+        t0 = time.time()
+        _, _, steps = g.walk(sources=src, p=p, q=q, walk_length=L, num_walks=1, seed=42, faithful=faithful, threads=cores)
+        dt = max(time.time() - t0, 1e-9)
+        e = {"workload": label, "p": p, "q": q, "variant": "faithful (linear exists, as the reference)" if faithful else "fast (sorted membership)",
+             "value": steps / dt, "unit": "walk-steps/s", "cores": cores, "kind": "port", "walk_steps": int(steps), "seconds": dt,
+             "sources": int(len(src))}
+        plan.append(e)
+        return e
+
+    karate = os.path.join(ROOT, "tests", "golden", "karate.txt")
+    if os.path.exists(karate):
+        gk = oracle_py.Graph.load(karate, directed=False)
+        for (p, q) in ((1.0, 1.0), (0.25, 4.0)):
+            for faithful in (True, False):
+                timed(gk, "karate.txt (34 vertices), walkLength 10", gk.vertices(), p, q, 10, faithful)
+    head = None
+    t_build = 0.0
+    for scale, n_faithful, n_fast in ((14, 0, 0), (16, 1024, 4096), (args.cpu_scale, args.cpu_sources or max(64, 3 * cores) // 2, 4096)):
+        t0 = time.time()
+        s, d = oracle_py.rmat_edges(scale, 16 << scale, seed=42)
+        graphs = {(1.0, 1.0): oracle_py.Graph.from_coo(s, d, None, directed=False),
+                  (0.25, 4.0): oracle_py.Graph.from_coo(s, d, _rmat_weights_np(np, s, d), directed=False)}
+        t_build += time.time() - t0
+        for (p, q), g in graphs.items():
+            verts = g.vertices()
+            for faithful, n_src in ((True, n_faithful), (False, n_fast)):
+                src = verts if (n_src == 0 or n_src >= len(verts)) else verts[np.linspace(0, len(verts) - 1, n_src).astype(np.int64)]
+                e = timed(g, "RMAT scale-%d ef16 undirected %s, walkLength %d, %s" % (
+                    scale, "unweighted" if q == 1.0 else "weighted", args.cpu_walk_length,
+                    "every vertex" if len(src) == len(verts) else "%d evenly spaced sources" % len(src)), src, p, q, args.cpu_walk_length, faithful)
+                if scale == args.cpu_scale and faithful and q == 1.0:
+                    head = e
+        del graphs
+    if head is None:
+        head = plan[-1]
+    return {"value": head["value"], "unit": "walk-steps/s", "cores": cores, "kind": "port",
+            "sample": "CPU restatement of RandomSample/RandomWalk (faithful linear-exists variant), %s, p=%g q=%g, %d threads; %.1f s walk; "
+                      "graph builds of the whole plan %.1f s" % (head["workload"], head["p"], head["q"], cores, head["seconds"], t_build),
+            "reference_toolchain_probe": {k: (v or "absent") for k, v in jvm.items()},
+            "plan": plan}
 
 
 def roofline_of(stats, steps_per_launch, avg_ms, scale=None):
@@ -215,6 +257,64 @@ def run_sharded_world1(pkg, device, scale=24, K=4, L=80):
             "timed": "wall time of srw_cluster_walk (all super-steps of K iterations, no host sync inside)"}
 
 
+XGMI_LINK_GBS = 153.0           # prompt / MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, point to point
+WIRE_BYTES_PER_WALKER_STEP = 24  # 16-byte walker + 8-byte path return (csrc/walk_kernels.hip: WWalker, WRet)
+
+
+def exchange_model(world, steps_per_s=None):
+    """What the walker exchange of the vertex-sharded walk allows: every walker-step moves one 16-byte walker
+    to owner(next) and one 8-byte return to owner(source); with a mixing owner function (world - 1) / world of them cross
+    GPUs, spread evenly over the world - 1 peers of a fully connected node, each over its own link."""
+    if world < 2:
+        return None
+    cross = (world - 1) / world
+    payload = WIRE_BYTES_PER_WALKER_STEP * cross
+    egress = XGMI_LINK_GBS * 1e9 * (world - 1)             # all links busy at once: the all-to-all's pattern
+    m = {"wire_bytes_per_walker_step": WIRE_BYTES_PER_WALKER_STEP, "crossing_fraction": cross,
+         "xgmi_bytes_per_walker_step": payload, "xgmi_GBs_per_link": XGMI_LINK_GBS, "links_used": world - 1,
+         "ceiling_walker_steps_per_s_per_gpu": egress / payload, "ceiling_walker_steps_per_s_job": world * egress / payload,
+         "note": "payload bound; the RCCL driver ships whole fixed-capacity chunks (slack 1.25: x1.25 / fill), the in-process driver "
+                 "stores payload only.  NOT measured: a prediction for the first multi-GPU run to be held against."}
+    if steps_per_s:
+        m["measured_fraction_of_exchange_ceiling"] = steps_per_s / m["ceiling_walker_steps_per_s_job"]
+    return m
+
+
+def run_sharded_biased_world1(pkg, device, name, scale, ef, weighted, directed, p, q, replicated_value, K=1, L=80):
+    """A biased (q != 1) configuration through the vertex-sharded protocol at world = 1: the shard holds the per-edge tables
+    of the pairs into its own rows behind the pair hash (edge_tables.hip:prepare_shard_tables), walkers arrive as 16-byte
+    records, every super-step is the lean table step + the chain kernels + one fused bucketing pass.  What one GPU can show
+    is the cost of that machinery against the single-launch kernel on the same graph (`fraction_of_replicated`)."""
+    import torch
+    kw = dict(p=p, q=q, walk_length=L, seed=42)
+    torch.cuda.synchronize()
+    with pkg.Cluster([device]) as cl:
+        t0 = time.perf_counter()
+        cl.generate_rmat(scale, ef << scale, seed=42, weighted=weighted, directed=directed)
+        nv, ne = cl.stats()
+        torch.cuda.synchronize()
+        t_graph = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cl.walk(fetch=False, num_walks=1, batch=1, **dict(kw, walk_length=1))     # membership, prefix sums, tables, hash: outside the timed walk
+        torch.cuda.synchronize()
+        t_tables = time.perf_counter() - t0
+        st = cl.walk(fetch=False, num_walks=K, first_walk=1, batch=K, **kw)
+        val = st["n_steps"] / (st["kernel_ms"] * 1e-3)
+    out = {"name": name,
+           "workload": "RMAT scale-%d ef%d %s %s p=%g q=%g walkLength=%d, Mode R; %d walk iteration(s) as one population through "
+                       "srw_cluster_walk at world 1" % (scale, ef, "directed" if directed else "undirected",
+                                                         "weighted" if weighted else "unweighted", p, q, L, K),
+           "vertices": nv, "adjacency_entries": ne, "value": val, "unit": "walk-steps/s", "steps": K, "warmup": 0,
+           "ms_per_step": st["kernel_ms"] / K, "strategy_steps": {k: v for k, v in st["strategy_steps"].items() if v},
+           "edge_tables": {"count": st["edge_tables"], "bytes": st["edge_table_bytes"]},
+           "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables_pair_hash_first_walk": t_tables},
+           "timed": "wall time of srw_cluster_walk (all super-steps, no host sync inside)"}
+    if replicated_value:
+        out["replicated_kernel_same_graph"] = replicated_value
+        out["fraction_of_replicated"] = val / replicated_value
+    return out
+
+
 def cluster_leg(pkg, torch, args, world, K):
     """Vertex-sharded walk of the whole job on `world` devices driven by ONE process (srw_cluster_*): peer stores over xGMI,
     super-steps ordered by events, paths on the home GPU.  Returns the `vertex_sharded` object of the bench line."""
@@ -241,6 +341,9 @@ def cluster_leg(pkg, torch, args, world, K):
                                    "chunks stored into the peers' buffers over xGMI, super-steps ordered by events, paths on the "
                                    "home GPU, no host sync per super-step" % world,
                     "timed": "wall time of the super-steps of K iterations (srw_cluster_walk), result buffers preallocated",
+                    "strategy_steps": {k: v for k, v in st["strategy_steps"].items() if v},
+                    "edge_tables": {"count": st["edge_tables"], "bytes": st["edge_table_bytes"]},
+                    "exchange_model": exchange_model(world, st["n_steps"] / dt_v),
                     "setup_s": {"graph_generate_and_csr_all_shards": t_graph}}
     except Exception as ex:
         return {"error": str(ex)[:300]}
@@ -261,8 +364,12 @@ def main():
     ap.add_argument("--sampler", choices=["reference", "alias"], default="reference")
     ap.add_argument("--shard", choices=["both", "replicate", "vertex"], default="both",
                     help="N > 1: which multi-GPU mode(s) to run; `value` is always the replicated mode when it runs")
-    ap.add_argument("--shard-driver", choices=["cluster", "rccl"], default="cluster",
-                    help="vertex-sharded leg: rank 0 drives all devices in-process (default) or one process per GPU over RCCL")
+    ap.add_argument("--shard-driver", choices=["both", "cluster", "rccl"], default="both",
+                    help="vertex-sharded legs of an N > 1 run: one process driving all devices (peer stores), one process per GPU "
+                         "over RCCL (all_to_all_single per super-step), or both (default)")
+    ap.add_argument("--biased-leg", type=int, default=1,
+                    help="N > 1: also run north_star's biased multi-GPU shape (directed RMAT-26 ef27, p=4 q=.5) vertex-sharded")
+    ap.add_argument("--rccl-leg", type=int, default=0, help=argparse.SUPPRESS)      # child job of an N > 1 run: see main()
     ap.add_argument("--nt-loads", type=int, default=-1, help="-1 auto, 0 cached, 1 nontemporal record loads")
     ap.add_argument("--compact", type=int, default=1, help="0: do not use the 16-byte lattice records")
     ap.add_argument("--configs", type=int, default=1, help="1 GPU: also run BASELINE configs C2, C3 (Mode R / A), C5 stand-in")
@@ -287,6 +394,29 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rccl_leg:
+        # one process per GPU, walkers exchanged by ONE RCCL all_to_all_single per super-step (stellar-random-walk_amd/distributed.py)
+        import datetime
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        torch.zeros(1, device="cuda")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", timeout=datetime.timedelta(minutes=10))
+        from importlib import import_module
+        sharded = import_module("stellar_random_walk_amd.distributed")
+
+        def bs():
+            dist.barrier()
+            torch.cuda.synchronize()
+        kw = dict(p=args.p, q=args.q, walk_length=args.walk_length, num_walks=1, seed=42)
+        vs = sharded.bench_vertex_sharded(dist, local_rank, rank, world, args.scale, args.edge_factor << args.scale, bool(args.weighted),
+                                          bool(args.directed), kw, args.steps, args.warmup, bs)
+        if rank == 0:
+            vs["exchange_model"] = exchange_model(world, vs.get("value"))
+            print(json.dumps(vs), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                          % (args.gpus, args.gpus))
@@ -410,35 +540,51 @@ def main():
     # hang the job or cost the headline line.  --shard-driver rccl runs the one-process-per-GPU driver instead
     # (stellar-random-walk_amd/distributed.py: one RCCL all_to_all_single per super-step).
     if dist is not None and args.shard in ("both", "vertex"):
-        vs = None
-        if args.shard_driver == "rccl":
-            from importlib import import_module
-            sharded = import_module("stellar_random_walk_amd.distributed")
-            vs = sharded.bench_vertex_sharded(dist, local_rank, rank, world, args.scale, n_edges, bool(args.weighted),
-                                              bool(args.directed), walk_kw, K, W, barrier_sync)
-        else:
-            if rank == 0:
-                # in a child process: a fault on a peer device (this path never met 8 real GPUs before the driver's run)
-                # costs the leg, not the headline line or the job
-                try:
-                    env = {k: v for k, v in os.environ.items()
-                           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT",
-                                        "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS")}
-                    cmd = [sys.executable, os.path.abspath(__file__), "--cluster-leg", str(world), "--steps", str(K), "--scale", str(args.scale),
-                           "--edge-factor", str(args.edge_factor), "--walk-length", str(args.walk_length), "--p", repr(args.p), "--q", repr(args.q),
-                           "--weighted", str(args.weighted), "--directed", str(args.directed)]
-                    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, text=True)
-                    line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
-                    vs = json.loads(line) if line.startswith("{") else {"error": "cluster leg exit %d: %s" % (r.returncode, r.stderr[-300:])}
-                except Exception as ex:
-                    vs = {"error": str(ex)[:300]}
-            dist.barrier()
+        vs = {}
         if rank == 0:
+            # Every leg runs in a CHILD job while the ranks of this one wait at a barrier: a fault or a hang on a peer device
+            # (neither driver had met more than one real GPU before the driver's run) costs that leg, not the headline line.
+            import socket
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT",
+                                "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "GROUP_WORLD_SIZE",
+                                "ROLE_WORLD_SIZE", "ROLE_NAME", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
+
+            def workload(scale, ef, weighted, directed, p, q, steps):
+                return ["--steps", str(steps), "--scale", str(scale), "--edge-factor", str(ef), "--walk-length", str(args.walk_length),
+                        "--p", repr(p), "--q", repr(q), "--weighted", str(int(weighted)), "--directed", str(int(directed))]
+
+            def child(cmd, timeout):
+                try:
+                    t0 = time.perf_counter()
+                    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+                    lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+                    out_ = json.loads(lines[-1]) if lines else {"error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
+                    out_["leg_wall_s"] = time.perf_counter() - t0
+                    return out_
+                except Exception as ex:
+                    return {"error": str(ex)[:300]}
+
+            me = [sys.executable, os.path.abspath(__file__)]
+            head = workload(args.scale, args.edge_factor, args.weighted, args.directed, args.p, args.q, K)
+            if args.shard_driver in ("both", "cluster"):
+                vs["cluster"] = child(me + ["--cluster-leg", str(world)] + head, 360)
+            if args.shard_driver in ("both", "rccl"):
+                sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+                vs["rccl"] = child([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                                    "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--rccl-leg", "1",
+                                    "--gpus", str(world), "--warmup", str(min(W, 1))] + head, 480)
+            if args.biased_leg and args.shard_driver in ("both", "cluster"):
+                # north_star's named biased multi-GPU configuration (C5's stand-in): per-edge tables on the shards
+                vs["cluster_c5_shape"] = child(me + ["--cluster-leg", str(world)] + workload(26, 27, 0, 1, 4.0, 0.5, 1), 540)
+        dist.barrier()
+        if rank == 0:
+            first = vs.get("cluster") or vs.get("rccl") or {}
             if out is None:
-                out = {"metric": "walk-steps/sec", "value": vs.get("value"), "unit": "walk-steps/s", "n_gpus": world, "steps": K,
-                       "warmup": W, "ms_per_step": vs.get("ms_per_step"), "higher_is_better": True, "scaling": "strong",
+                out = {"metric": "walk-steps/sec", "value": first.get("value"), "unit": "walk-steps/s", "n_gpus": world, "steps": K,
+                       "warmup": W, "ms_per_step": first.get("ms_per_step"), "higher_is_better": True, "scaling": "strong",
                        "vs_baseline": None, "dtype": "f64 CDF tables, int32 ids", "data": "synthetic",
-                       "config": {"workload": vs.get("workload"), "parallelism": vs.get("parallelism")}}
+                       "config": {"workload": first.get("workload"), "parallelism": first.get("parallelism")}}
             out["vertex_sharded"] = vs
 
     if rank == 0:
@@ -460,6 +606,14 @@ def main():
                     cfgs.append(run_sharded_world1(pkg, local_rank))
                 except Exception as ex:
                     cfgs.append({"name": "vertex-sharded protocol at world 1", "error": str(ex)[:300]})
+                rep = {c.get("name"): c.get("value") for c in cfgs}
+                for (name, sc, ef, wt, dr, p, q, of) in [
+                        ("C3 shape, vertex-sharded, world 1 (per-edge tables on the shard)", 24, 16, True, False, 0.25, 4.0, "C3 Mode R"),
+                        ("C5 shape, vertex-sharded, world 1 (per-edge tables on the shard)", 26, 27, False, True, 4.0, 0.5, "C5 stand-in Mode R")]:
+                    try:
+                        cfgs.append(run_sharded_biased_world1(pkg, local_rank, name, sc, ef, wt, dr, p, q, rep.get(of)))
+                    except Exception as ex:
+                        cfgs.append({"name": name, "error": str(ex)[:300]})
             out["configs"] = cfgs
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

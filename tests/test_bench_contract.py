@@ -1,7 +1,7 @@
 """bench.py's output contract, on a small graph: one JSON line with the keys the driver reads (metric, value, unit, n_gpus,
 steps, warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config.workload), the `roofline` and
-`cpu_baseline` objects, and — launched through torch.distributed.run with one rank — the `vertex_sharded` leg that an N > 1
-run adds (rank 0 runs it in a child process)."""
+`cpu_baseline` objects, and — launched through torch.distributed.run with one rank — the `vertex_sharded` legs that an N > 1
+run adds (child jobs started by rank 0: the in-process cluster and the one-process-per-GPU RCCL driver)."""
 import json
 import os
 import subprocess
@@ -41,6 +41,10 @@ def test_single_gpu_line():
     assert rf["traffic"] is None                      # no PMC file for this graph: never a number that was not measured
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "walk-steps/s" and cb["sample"]
+    # BASELINE.md §3's plan: karate and the RMATs, (1, 1) and (.25, 4), faithful and fast
+    plan = cb["plan"]
+    assert {(e["p"], e["q"]) for e in plan} == {(1.0, 1.0), (0.25, 4.0)} and all(e["value"] > 0 and e["kind"] == "port" for e in plan)
+    assert any("karate" in e["workload"] for e in plan) and any(e["variant"].startswith("fast") for e in plan)
     e2e = d["end_to_end"]
     assert e2e.get("text_bytes", 0) > 0 and e2e["walk_steps_per_s"] > 0, e2e
 
@@ -49,13 +53,15 @@ def test_torchrun_one_rank_adds_the_vertex_sharded_leg():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scale", "16", "--steps", "2", "--warmup", "1",
-                        "--configs", "0", "--end-to-end", "0", "--cpu-baseline", "0"],
+                        "--configs", "0", "--end-to-end", "0", "--cpu-baseline", "0", "--biased-leg", "0"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
     for k in KEYS:
         assert k in d, k
-    vs = d["vertex_sharded"]
-    assert "error" not in vs, vs
-    assert vs["value"] > 0 and vs["scaling"] == "strong" and "sharded by source vertex" in vs["parallelism"]
+    # both exchange drivers report: one process driving all devices (peer stores) and one process per GPU (RCCL)
+    for leg in ("cluster", "rccl"):
+        vs = d["vertex_sharded"][leg]
+        assert "error" not in vs, (leg, vs)
+        assert vs["value"] > 0 and vs["scaling"] == "strong" and "sharded by source vertex" in vs["parallelism"], (leg, vs)
     assert d["scaling"] == "weak" and d["n_gpus"] == 1

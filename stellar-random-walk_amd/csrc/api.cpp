@@ -58,6 +58,27 @@ void load_lines(srw_handle *h, const int32_t *src, const int32_t *dst, const flo
   const bool sparse = ids_are_sparse(h, 2 * n, vmin, vmax);
   if (!sparse) check_id_range(vmin, vmax);       // before any allocation that is proportional to the id range
   hipStream_t st = h->stream;
+  if (h->cfg.world > 1 && !sparse && !getenv("SRW_BUILD_WHOLE")) {
+    // a vertex-sharded handle uploads the lines block by block and keeps only the entries it owns (graph_build.hip)
+    std::vector<int32_t> part_of;
+    if (pid) {
+      part_of.assign((size_t)((int64_t)vmax - vmin + 1), -1);
+      for (int64_t i = 0; i < n; ++i) {                      // VCut: last put wins (GraphMap.scala:28-32)
+        part_of[(size_t)((int64_t)dst[i] - vmin)] = pid[i];
+        if (!directed) part_of[(size_t)((int64_t)src[i] - vmin)] = pid[i];
+      }
+    }
+    DevBuf<int32_t> bs, bd; DevBuf<float> bw;
+    build_graph_blocked(h, [&](int64_t i0, int64_t cnt, const int32_t *&s, const int32_t *&d, const float *&ww) {
+      bs.ensure((size_t)cnt); bd.ensure((size_t)cnt);
+      SRW_HIP(hipMemcpyAsync(bs.p, src + i0, (size_t)cnt * 4, hipMemcpyHostToDevice, st));
+      SRW_HIP(hipMemcpyAsync(bd.p, dst + i0, (size_t)cnt * 4, hipMemcpyHostToDevice, st));
+      if (w) { bw.ensure((size_t)cnt); SRW_HIP(hipMemcpyAsync(bw.p, w + i0, (size_t)cnt * 4, hipMemcpyHostToDevice, st)); }
+      s = bs.p; d = bd.p; ww = w ? bw.p : nullptr;
+    }, n, directed, vmin, vmax, part_of.empty() ? nullptr : part_of.data(), nullptr);
+    h->g.part_of = std::move(part_of);
+    return;
+  }
   DevBuf<int32_t> d_src, d_dst; DevBuf<float> d_w;
   d_src.alloc((size_t)n); d_dst.alloc((size_t)n);
   SRW_HIP(hipMemcpyAsync(d_src.p, src, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -215,6 +236,19 @@ int32_t srw_generate_rmat(srw_handle *h, int32_t scale, int64_t n_edges, uint32_
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
     DevBuf<int32_t> d_src, d_dst; DevBuf<float> d_w;
+    if (h->cfg.world > 1 && !getenv("SRW_BUILD_WHOLE")) {
+      // a shard generates the stream block by block (edge i is a pure function of (seed, i)) and keeps what it owns
+      if (scale < 1 || scale > 30) throw Error(SRW_ERR_INVALID, "rmat scale must be in [1, 30]");
+      if (n_edges <= 0) throw Error(SRW_ERR_INVALID, "rmat n_edges must be > 0");
+      build_graph_blocked(h, [&](int64_t i0, int64_t cnt, const int32_t *&s, const int32_t *&d, const float *&ww) {
+        d_src.ensure((size_t)cnt); d_dst.ensure((size_t)cnt);
+        if (weighted) d_w.ensure((size_t)cnt);
+        generate_rmat_block(h, scale, i0, cnt, seed, weighted != 0, d_src.p, d_dst.p, weighted ? d_w.p : nullptr);
+        s = d_src.p; d = d_dst.p; ww = weighted ? d_w.p : nullptr;
+      }, n_edges, directed != 0, 0, (int32_t)(((int64_t)1 << scale) - 1));
+      h->g.part_of.clear();
+      return;
+    }
     generate_rmat_lines(h, scale, n_edges, seed, weighted != 0, d_src, d_dst, d_w);
     build_graph_from_device_lines(h, d_src.p, d_dst.p, weighted ? d_w.p : nullptr, n_edges, directed != 0, 0,
                                   (int32_t)(((int64_t)1 << scale) - 1));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <stdexcept>
 #include <cstdlib>
 #include <new>
@@ -262,6 +263,12 @@ void compact_ids(srw_handle *h, int32_t *d_src, int32_t *d_dst, int64_t n_lines,
 void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
                                    int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
                                    const int32_t *host_owner_tab = nullptr, IdMap *idmap = nullptr);
+// Vertex-sharded handles: the lines block by block (a slice of device arrays, a generated block, an uploaded block)
+using LineFetch = std::function<void(int64_t i0, int64_t n, const int32_t *&src, const int32_t *&dst, const float *&w)>;
+void build_graph_blocked(srw_handle *h, const LineFetch &fetch, int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
+                         const int32_t *host_owner_tab = nullptr, IdMap *idmap = nullptr);
+void generate_rmat_block(srw_handle *h, int32_t scale, int64_t first_edge, int64_t n_edges, uint32_t seed, bool weighted,
+                         int32_t *d_src, int32_t *d_dst, float *d_w);
 void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_t *offs, int64_t n_rows,
                                 const int32_t *ids, const float *w);
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,

@@ -109,11 +109,11 @@ __global__ void k_scatter_verts(const uint32_t *__restrict__ flags, const uint32
 
 // RMAT edge i = f(seed, i): 4 levels per Philox call; quadrant thresholds floor({.57,.76,.95} * 2^32).
 // Same arithmetic as oracle/srw_oracle.c:orc_rmat_edges / orc_rmat_weight (build-defined synthetic input).
-__global__ void k_rmat(int32_t scale, uint32_t seed, int64_t n_edges, int weighted, int32_t *__restrict__ src,
+__global__ void k_rmat(int32_t scale, uint32_t seed, int64_t first, int64_t n_edges, int weighted, int32_t *__restrict__ src,
                        int32_t *__restrict__ dst, float *__restrict__ w) {
   const uint32_t T1 = 2448131358u, T2 = 3264175144u, T3 = 4080218930u;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_edges; i += (int64_t)gridDim.x * blockDim.x) {
-    uint64_t e = (uint64_t)i;
+    uint64_t e = (uint64_t)(first + i);                     // edge index of the stream: any rank can generate any slice
     uint32_t s = 0, d = 0, o[4] = {0, 0, 0, 0};
     for (int l = 0; l < scale; ++l) {
       if ((l & 3) == 0) philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)(l >> 2), 0x524D4154u, seed, 1u, o);
@@ -215,7 +215,7 @@ __global__ void k_ids_rank(int32_t *__restrict__ ids, int64_t n, const int32_t *
 
 // keys/vals: n_total unsorted entries; n_owned of them carry a real key.  present: [n_slots] flags.
 void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals, int64_t n_total, int64_t n_owned,
-                  DevBuf<uint32_t> &present, int32_t vmin, int32_t vmax, bool sharded) {
+                  DevBuf<uint32_t> &present, int32_t vmin, int32_t vmax, bool sharded, bool has_sentinels = true) {
   hipStream_t st = h->stream;
   Graph &g = h->g;
   g.vmin = vmin; g.vmax = vmax;
@@ -239,7 +239,7 @@ void finish_build(srw_handle *h, DevBuf<uint32_t> &keys, DevBuf<uint64_t> &vals,
   // 1. stable sort of the entry stream by owning vertex
   DevBuf<uint32_t> keys2; DevBuf<uint64_t> vals2; DevBuf<char> temp;
   keys2.alloc((size_t)n_total); vals2.alloc((size_t)n_total);
-  int key_bits = sharded ? 32 : bits_for((uint64_t)std::max<int64_t>(g.n_slots - 1, 1));
+  int key_bits = (sharded && has_sentinels) ? 32 : bits_for((uint64_t)std::max<int64_t>(g.n_slots - 1, 1));
   if (n_total > 0) {
     size_t tb = 0;
     SRW_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, vals.p, vals2.p, (size_t)n_total, 0u,
@@ -428,6 +428,12 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
                                    int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
                                    const int32_t *host_owner_tab, IdMap *idmap) {
   if (n_lines <= 0) throw Error(SRW_ERR_INVALID, "empty edge list");
+  if (h->cfg.world > 1 && !getenv("SRW_BUILD_WHOLE")) {      // a shard keeps only what it owns: blocks of the line arrays
+    build_graph_blocked(h, [&](int64_t i0, int64_t, const int32_t *&s, const int32_t *&d, const float *&w) {
+      s = d_src + i0; d = d_dst + i0; w = d_w ? d_w + i0 : nullptr;
+    }, n_lines, directed, vmin, vmax, host_owner_tab, idmap);
+    return;
+  }
   int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
   check_id_range(vmin, vmax);
   hipStream_t st = h->stream;
@@ -478,6 +484,112 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
     gkeys.release();
   }
   finish_build(h, keys, vals, n_total, (int64_t)owned, present, vmin, vmax, sharded);
+  if (want_membership) { g.mrows = std::move(mrows); g.msids = std::move(msids); }
+  install_id_map(g, idmap);
+}
+
+namespace {
+struct OwnedKey { __host__ __device__ bool operator()(uint32_t k) const { return k != KEY_SENTINEL; } };
+}  // namespace
+
+// The same construction for a VERTEX-SHARDED handle, block by block: the reference's partitionBy hands a partition only its
+// rows (UniformRandomWalk.scala:41-42); round 2's shards each expanded, keyed and sorted the WHOLE entry stream and cut
+// afterwards (24 B per adjacency entry of the whole graph per shard: ~190 GB at RMAT-27 with the membership structure).
+// Here the lines come in blocks (`fetch`: a slice of arrays already on the device, a block generated on the spot, or a block
+// uploaded from the host); pass 1 counts the owned entries and marks the present ids, pass 2 expands every block again and
+// appends its OWNED (key, entry) pairs — stable, so a row keeps its input-line order — to arrays of exactly the owned size,
+// which are then sorted.  Peak: 24 B per OWNED entry + two blocks; the replicated membership structure, when wanted, is
+// still the whole graph's (8 + 8 B per entry while it is sorted, 4 B after).
+void build_graph_blocked(srw_handle *h, const LineFetch &fetch, int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
+                         const int32_t *host_owner_tab, IdMap *idmap) {
+  if (n_lines <= 0) throw Error(SRW_ERR_INVALID, "empty edge list");
+  const int64_t n_slots = (int64_t)vmax - (int64_t)vmin + 1;
+  check_id_range(vmin, vmax);
+  hipStream_t st = h->stream;
+  Graph &g = h->g;
+  g = Graph();
+  g.n_lines = n_lines;
+  g.symmetric = !directed;
+  const int per = directed ? 1 : 2;
+  const int64_t n_total = n_lines * per;
+  g.n_entries_global = n_total;
+  if (host_owner_tab && (h->cfg.flags & SRW_CFG_OWNER_FROM_PARTITIONS)) {
+    g.owner_tab.alloc((size_t)n_slots);
+    SRW_HIP(hipMemcpyAsync(g.owner_tab.p, host_owner_tab, (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
+  }
+  const bool want_membership = !(h->cfg.flags & SRW_CFG_NO_MEMBERSHIP);
+  int64_t BL = (int64_t)32 << 20;
+  if (const char *e = getenv("SRW_BUILD_BLOCK_LINES"); e && *e) BL = std::max<int64_t>(1, atoll(e));
+  BL = std::min(BL, n_lines);
+  DevBuf<uint32_t> bkeys, bgk, present; DevBuf<uint64_t> bvals, mk; DevBuf<unsigned long long> cnt; DevBuf<char> temp;
+  bkeys.alloc((size_t)(BL * per)); bvals.alloc((size_t)(BL * per)); present.alloc((size_t)n_slots); cnt.alloc(2);
+  if (want_membership) { bgk.alloc((size_t)(BL * per)); mk.alloc((size_t)n_total); }
+  SRW_HIP(hipMemsetAsync(present.p, 0, (size_t)n_slots * 4, st));
+  SRW_HIP(hipMemsetAsync(cnt.p, 0, 16, st));
+  auto expand = [&](int64_t i0, int64_t n, unsigned long long *owned_ctr, bool with_gkeys) {
+    const int32_t *s = nullptr, *d = nullptr; const float *w = nullptr;
+    fetch(i0, n, s, d, w);
+    hipLaunchKernelGGL(k_expand, dim3(grid_for(n)), dim3(TPB), 0, st, s, d, w, n, directed ? 1 : 0, vmin, h->cfg.rank, h->cfg.world,
+                       bkeys.p, bvals.p, present.p, owned_ctr, with_gkeys ? bgk.p : (uint32_t *)nullptr, (const int32_t *)g.owner_tab.p, n_slots);
+  };
+  // pass 1: owned entries, present ids, membership keys
+  for (int64_t i0 = 0; i0 < n_lines; i0 += BL) {
+    const int64_t n = std::min(BL, n_lines - i0);
+    expand(i0, n, cnt.p, want_membership);
+    if (want_membership)
+      hipLaunchKernelGGL(k_gmember_keys, dim3(grid_for(n * per)), dim3(TPB), 0, st, bgk.p, bvals.p, n * per, vmin, mk.p + i0 * per);
+    SRW_HIP(hipStreamSynchronize(st));            // the fetch of the next block may reuse its staging
+  }
+  unsigned long long owned = 0;
+  SRW_HIP(hipMemcpyAsync(&owned, cnt.p, 8, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  SRW_HIP(hipGetLastError());
+  bgk.release();
+  // pass 2: the owned (key, entry) pairs, in line order
+  DevBuf<uint32_t> keys; DevBuf<uint64_t> vals;
+  keys.alloc((size_t)std::max<unsigned long long>(owned, 1)); vals.alloc((size_t)std::max<unsigned long long>(owned, 1));
+  {
+    auto flags = rocprim::make_transform_iterator(bkeys.p, OwnedKey());
+    size_t tb = 0, tb2 = 0;
+    SRW_HIP(rocprim::select(nullptr, tb, bkeys.p, flags, keys.p, cnt.p + 1, (size_t)(BL * per), st));
+    SRW_HIP(rocprim::select(nullptr, tb2, bvals.p, flags, vals.p, cnt.p + 1, (size_t)(BL * per), st));
+    temp.alloc(std::max(tb, tb2));
+    tb = tb2 = std::max(tb, tb2);
+    int64_t off = 0;
+    for (int64_t i0 = 0; i0 < n_lines; i0 += BL) {
+      const int64_t n = std::min(BL, n_lines - i0);
+      expand(i0, n, cnt.p + 1, false);
+      size_t t1 = tb;
+      SRW_HIP(rocprim::select((void *)temp.p, t1, bkeys.p, flags, keys.p + off, cnt.p + 1, (size_t)(n * per), st));
+      t1 = tb;
+      SRW_HIP(rocprim::select((void *)temp.p, t1, bvals.p, flags, vals.p + off, cnt.p + 1, (size_t)(n * per), st));
+      unsigned long long got = 0;
+      SRW_HIP(hipMemcpyAsync(&got, cnt.p + 1, 8, hipMemcpyDeviceToHost, st));
+      SRW_HIP(hipStreamSynchronize(st));
+      off += (int64_t)got;
+    }
+    if ((unsigned long long)off != owned) throw Error(SRW_ERR_INVALID, "sharded build: the two passes over the lines disagree");
+  }
+  bkeys.release(); bvals.release(); temp.release();
+  DevBuf<Row> mrows; DevBuf<uint32_t> msids;
+  if (want_membership) {
+    DevBuf<uint64_t> mk2;
+    mk2.alloc((size_t)n_total);
+    const int id_bits = bits_for((uint64_t)std::max<int64_t>(n_slots - 1, 1));
+    size_t tb = 0;
+    SRW_HIP(rocprim::radix_sort_keys(nullptr, tb, mk.p, mk2.p, (size_t)n_total, 0u, (unsigned)(32 + id_bits), st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::radix_sort_keys((void *)temp.p, tb, mk.p, mk2.p, (size_t)n_total, 0u, (unsigned)(32 + id_bits), st));
+    SRW_HIP(hipStreamSynchronize(st));
+    mk.release(); temp.release();
+    mrows.alloc((size_t)n_slots); msids.alloc((size_t)n_total);
+    hipLaunchKernelGGL(k_mrows_init, dim3(grid_for(n_slots)), dim3(TPB), 0, st, mrows.p, n_slots);
+    hipLaunchKernelGGL(k_mrows_start, dim3(grid_for(n_total)), dim3(TPB), 0, st, mk2.p, n_total, mrows.p);
+    hipLaunchKernelGGL(k_mrows_deg, dim3(grid_for(n_total)), dim3(TPB), 0, st, mk2.p, n_total, mrows.p);
+    hipLaunchKernelGGL(k_low32, dim3(grid_for(n_total)), dim3(TPB), 0, st, mk2.p, n_total, msids.p);
+    SRW_HIP(hipStreamSynchronize(st));
+  }
+  finish_build(h, keys, vals, (int64_t)owned, (int64_t)owned, present, vmin, vmax, true, /*has_sentinels=*/false);
   if (want_membership) { g.mrows = std::move(mrows); g.msids = std::move(msids); }
   install_id_map(g, idmap);
 }
@@ -693,8 +805,15 @@ void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t
   if (n_edges <= 0) throw Error(SRW_ERR_INVALID, "rmat n_edges must be > 0");
   d_src.alloc((size_t)n_edges); d_dst.alloc((size_t)n_edges);
   if (weighted) d_w.alloc((size_t)n_edges);
-  hipLaunchKernelGGL(k_rmat, dim3(grid_for(n_edges)), dim3(TPB), 0, h->stream, scale, seed, n_edges, weighted ? 1 : 0,
+  hipLaunchKernelGGL(k_rmat, dim3(grid_for(n_edges)), dim3(TPB), 0, h->stream, scale, seed, (int64_t)0, n_edges, weighted ? 1 : 0,
                      d_src.p, d_dst.p, weighted ? d_w.p : nullptr);
+  SRW_HIP(hipGetLastError());
+}
+
+void generate_rmat_block(srw_handle *h, int32_t scale, int64_t first_edge, int64_t n_edges, uint32_t seed, bool weighted,
+                         int32_t *d_src, int32_t *d_dst, float *d_w) {
+  hipLaunchKernelGGL(k_rmat, dim3(grid_for(n_edges)), dim3(TPB), 0, h->stream, scale, seed, first_edge, n_edges, weighted ? 1 : 0,
+                     d_src, d_dst, weighted ? d_w : nullptr);
   SRW_HIP(hipGetLastError());
 }
 

@@ -800,7 +800,16 @@ struct ShardIO {
   const char *recv;        // world chunks, one per sender
   int64_t chunk_bytes;
   int32_t cap_w, cap_r, world, rank, batch;
+  // this rank's path staging (slot-major) and lengths: a return whose home is THIS rank is applied where it is produced
+  // (no record): all of them at super-step 1 (every walker starts at home: n_local returns into one chunk otherwise —
+  // world times the capacity an even spread needs), 1 / world of them later, every one at world 1
+  int32_t *pt, *lens;
+  int64_t n_rows;
 };
+__device__ inline void shard_return_home(const ShardIO &io, const SWalker &w, int32_t step) {
+  if (w.kind == SK_DEAD) io.lens[w.lw] = step;
+  else io.pt[(int64_t)step * io.n_rows + w.lw] = w.v;
+}
 struct ShardDst { char *p[SHARD_MAX_WORLD]; };   // where chunk (me -> d) is written
 __device__ inline const uint32_t *chunk_hdr(const char *base, int64_t cb, int c) { return reinterpret_cast<const uint32_t *>(base + c * cb); }
 __device__ inline const WWalker *chunk_walkers(const char *base, int64_t cb, int c) { return reinterpret_cast<const WWalker *>(base + c * cb + 16); }
@@ -981,7 +990,8 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
     if (r.deg == 0) {                                  // dead end (or a source without neighbors): tell the home rank the length
       if (lane == 0) {
         scratch[ri] = shard_dead(wk);
-        atomicAdd(&cnt[SHARD_MAX_WORLD + owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
+        const int32_t hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+        if (hm != io.rank) atomicAdd(&cnt[SHARD_MAX_WORLD + hm], 1u);
       }
       if (step > 1) dead += (lane == 0);
       continue;
@@ -1005,7 +1015,8 @@ __global__ __launch_bounds__(TPB, 4) void k_sh_step(GraphView g, ShardIO io, int
       const SWalker nw = shard_advance(wk, step, next, last != 0);
       scratch[ri] = nw;
       if (nw.kind != SK_RET) atomicAdd(&cnt[owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);
-      atomicAdd(&cnt[SHARD_MAX_WORLD + owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots)], 1u);      // every sampled vertex goes home
+      { const int32_t hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);      // every sampled vertex goes home
+        if (hm != io.rank) atomicAdd(&cnt[SHARD_MAX_WORLD + hm], 1u); }
       steps += 1; degc += (unsigned long long)r.deg; fb += f;
       if (b.need_member) degp += (unsigned long long)b.prev_deg;
     }
@@ -1044,6 +1055,7 @@ __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int
         if (step > 1) ++dead;
         scratch[ri] = shard_dead(wk);
         hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);     // death notice to the home rank
+        if (hm == io.rank) hm = -1;                                             // (applied in place by k_sh_bucket)
       } else {
         const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
         float u = draw_uniform(rng, iter, (uint32_t)rng_source(g, wk.src), (uint32_t)step);
@@ -1062,6 +1074,7 @@ __global__ __launch_bounds__(TPB) void k_sh_step_fo(GraphView g, ShardIO io, int
         ++steps;
         if (nw.kind != SK_RET) o = owner_of_tab(next, io.world, g.owner_tab, g.vmin, g.n_slots);
         hm = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+        if (hm == io.rank) hm = -1;
       }
     }
     for (int32_t d = 0; d < io.world; ++d) {               // one LDS atomic per wave, destination and kind
@@ -1125,6 +1138,7 @@ __global__ __launch_bounds__(TPB) void k_sh_step_cfo(GraphView g, ShardIO io, in
           if (step > 1) ++dead;
           kind[r] = SK_DEAD;
           hm[r] = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+          if (hm[r] == io.rank) { hm[r] = -1; io.lens[wk.lw] = step; }
         } else {
           const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
           CfoEnt e;
@@ -1142,6 +1156,7 @@ __global__ __launch_bounds__(TPB) void k_sh_step_cfo(GraphView g, ShardIO io, in
           if (last) kind[r] = SK_RET;
           else o[r] = owner_of_tab(e.id, io.world, g.owner_tab, g.vmin, g.n_slots);
           hm[r] = owner_of_tab(wk.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+          if (hm[r] == io.rank) { hm[r] = -1; io.pt[(int64_t)step * io.n_rows + wk.lw] = e.id; }
         }
       }
     }
@@ -1214,6 +1229,7 @@ __global__ __launch_bounds__(TPB) void k_sh_step_cfo(GraphView g, ShardIO io, in
       const uint32_t total = atomicExch(&cursors[rets ? SHARD_MAX_WORLD + d : d], 0u);
       const uint32_t cap = (uint32_t)(rets ? io.cap_r : io.cap_w);
       reinterpret_cast<uint32_t *>(dst.p[d])[rets ? 1 : 0] = total < cap ? total : cap;
+      atomicMax(&ctr->why[rets ? 1 : 0], (unsigned long long)total);      // the fullest chunk of the batch (run_shard_finish, SRW_TIMING)
     }
     if (threadIdx.x == 0) cursors[SH_CUR_DONE] = 0u;
   }
@@ -1266,6 +1282,7 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
       w = recs[i];
       if (w.kind == SK_WALKER_RET) o = owner_of_tab(w.curr, io.world, g.owner_tab, g.vmin, g.n_slots);
       hm = owner_of_tab(w.src, io.world, g.owner_tab, g.vmin, g.n_slots);
+      if (hm == io.rank) { hm = -1; shard_return_home(io, w, step); }
     }
     for (int32_t d = 0; d < io.world; ++d) {
       const unsigned long long m = __ballot(o == d);
@@ -1521,7 +1538,7 @@ __global__ __launch_bounds__(TPB) void k_chain_seq(GraphView g, ShardIO io, int3
 // chunks; the last block writes the chunk headers and clears the cursors.  Replaces k_sh_offsets + k_sh_bucket (and the
 // per-block count matrix) for the table steps, whose records are not sampled by fixed slices.
 __global__ __launch_bounds__(TPB) void k_sh_scatter(GraphView g, ShardIO io, int32_t step, const SWalker *__restrict__ recs,
-                                                    uint32_t *__restrict__ cursors, ShardDst dst, uint32_t *__restrict__ overflow) {
+                                                    uint32_t *__restrict__ cursors, ShardDst dst, uint32_t *__restrict__ overflow, DevCounters *ctr) {
   __shared__ uint32_t cnt[2 * SHARD_MAX_WORLD], gbase[2 * SHARD_MAX_WORLD], pre[SHARD_MAX_WORLD + 1];
   __shared__ uint32_t is_last;
   const int lane = lane_id();
@@ -1542,6 +1559,7 @@ __global__ __launch_bounds__(TPB) void k_sh_scatter(GraphView g, ShardIO io, int
         w[r] = recs[ri];
         if (w[r].kind == SK_WALKER_RET) o[r] = owner_of_tab(w[r].curr, io.world, g.owner_tab, g.vmin, g.n_slots);
         hm[r] = owner_of_tab(w[r].src, io.world, g.owner_tab, g.vmin, g.n_slots);
+        if (hm[r] == io.rank) { hm[r] = -1; shard_return_home(io, w[r], step); }
       }
     }
 #pragma unroll
@@ -1608,6 +1626,7 @@ __global__ __launch_bounds__(TPB) void k_sh_scatter(GraphView g, ShardIO io, int
       const uint32_t total = atomicExch(&cursors[rets ? SHARD_MAX_WORLD + d : d], 0u);
       const uint32_t cap = (uint32_t)(rets ? io.cap_r : io.cap_w);
       reinterpret_cast<uint32_t *>(dst.p[d])[rets ? 1 : 0] = total < cap ? total : cap;
+      atomicMax(&ctr->why[rets ? 1 : 0], (unsigned long long)total);      // the fullest chunk of the batch (run_shard_finish, SRW_TIMING)
     }
     if (threadIdx.x == 0) cursors[SH_CUR_DONE] = 0u;
   }
@@ -2204,10 +2223,11 @@ void shard_layout(const srw_handle *h, int32_t batch, double slack, srw_shard_la
 }
 
 namespace {
-ShardIO make_io(const srw_handle *h, int32_t batch, const srw_shard_layout &lay, const void *d_recv) {
+ShardIO make_io(const srw_handle *h, int32_t batch, const srw_shard_layout &lay, const void *d_recv, int32_t *d_lens) {
   ShardIO io;
   io.recv = (const char *)d_recv; io.chunk_bytes = lay.chunk_bytes; io.cap_w = (int32_t)lay.cap_walkers; io.cap_r = (int32_t)lay.cap_rets;
   io.world = h->cfg.world; io.rank = h->cfg.rank; io.batch = batch;
+  io.pt = h->shard_pt.p; io.lens = d_lens; io.n_rows = h->g.n_local_vertices * batch;
   return io;
 }
 void check_shard(const srw_handle *h, int32_t batch, const srw_shard_layout &lay) {
@@ -2237,7 +2257,7 @@ void run_shard_begin(srw_handle *h, const srw_walk_params &P, int32_t batch, con
   SRW_HIP(hipMemsetAsync(h->counters.p, 0, sizeof(DevCounters), st));
   SRW_HIP(hipMemsetAsync(h->shard_flag.p, 0, 4, st));
   h->shard_pt.ensure((size_t)std::max<int64_t>(n, 1) * (size_t)stride);                // slot-major staging of this batch's paths (k_sh_apply)
-  const ShardIO io = make_io(h, batch, lay, d_recv);
+  const ShardIO io = make_io(h, batch, lay, d_recv, d_lens);
   const int blocks = (int)std::min<int64_t>(std::max<int64_t>((n + TPB - 1) / TPB, 1), 8192);
   const bool linked = shard_fo_linked(h, P);
   h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
@@ -2271,7 +2291,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     if (P.sampler == SRW_SAMPLER_REFERENCE) prepare_shard_tables(h, P); else g.use_eb = false;
   }
   const bool tables = !first_order && g.has_eb && g.use_eb && g.eb_sharded && P.q != 1.0f;
-  const ShardIO io = make_io(h, batch, lay, d_recv);
+  const ShardIO io = make_io(h, batch, lay, d_recv, d_lens);
   ShardDst sd;
   for (int d = 0; d < SHARD_MAX_WORLD; ++d) sd.p[d] = d < world ? (char *)dst[d] : nullptr;
   const int n_blocks = h->n_cus * 4;
@@ -2343,7 +2363,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
       hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch, h->shard_blk.p,
                          h->counters.p, (const uint32_t *)h->walk_todo.p, (const unsigned long long *)(h->walk_cursor.p + 1));
     });
-    timed(3, [&] { hipLaunchKernelGGL(k_sh_scatter, dim3(n_blocks), dim3(TPB), 0, st, gv, io, step, scratch, h->shard_cur.p, sd, h->shard_flag.p); });
+    timed(3, [&] { hipLaunchKernelGGL(k_sh_scatter, dim3(n_blocks), dim3(TPB), 0, st, gv, io, step, scratch, h->shard_cur.p, sd, h->shard_flag.p, h->counters.p); });
     SRW_HIP(hipGetLastError());
     if (prof && last)
       fprintf(stderr, "[shard profile] rank %d: apply %.1f ms, table step %.1f ms (longest super-step %.1f ms), chain + general step (ties, todo) %.1f ms, scatter %.1f ms (cumulative)\n", h->cfg.rank,
@@ -2379,7 +2399,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
 void run_shard_flush(srw_handle *h, const srw_walk_params &P, int32_t batch, const srw_shard_layout &lay, const void *d_recv,
                      int32_t *d_paths, int32_t *d_lens, int64_t stride) {
   check_shard(h, batch, lay);
-  const ShardIO io = make_io(h, batch, lay, d_recv);
+  const ShardIO io = make_io(h, batch, lay, d_recv, d_lens);
   const int64_t n_rows = h->g.n_local_vertices * batch;
   hipLaunchKernelGGL(k_sh_apply, dim3(h->n_cus * 4), dim3(TPB), 0, h->stream, io, h->shard_pt.p, d_lens, n_rows, P.walk_length + 1);
   if (n_rows > 0) {      // the staging becomes the caller's [row][L + 2] matrix (-1 beyond each row's length)
@@ -2403,6 +2423,11 @@ void run_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow) {
   h->shard_flag.ensure(1);
   SRW_HIP(hipMemcpyAsync(&flag, h->shard_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
   read_counters(h, s);                                  // synchronises
+  if (getenv("SRW_TIMING")) {
+    unsigned long long fill[2] = {0, 0};
+    SRW_HIP(hipMemcpy(fill, h->counters.p->why, 16, hipMemcpyDeviceToHost));
+    if (fill[0] || fill[1]) fprintf(stderr, "[shard %d/%d] fullest chunk of the batch: %llu walkers, %llu returns%s\n", h->cfg.rank, h->cfg.world, fill[0], fill[1], flag ? " (OVERFLOW)" : "");
+  }
   if (overflow) *overflow = (int32_t)flag;
 }
 

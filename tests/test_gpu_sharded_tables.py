@@ -96,3 +96,38 @@ def test_all_vertices_in_one_partition(oracle, tmp_path, p, q):
         for batch in (0, 1, 3):
             paths, lens, st = cl.walk(p=p, q=q, walk_length=10, num_walks=3, seed=12, batch=batch)
             assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs, batch
+
+
+@pytest.mark.parametrize("world,directed", [(2, False), (3, True)])
+def test_shard_build_in_blocks(oracle, monkeypatch, world, directed):
+    """A shard builds its rows from the line stream in blocks and keeps only what it owns (graph_build.hip:
+    build_graph_blocked — the reference's partitionBy, UniformRandomWalk.scala:41-42): blocks of 777 lines must give the rows,
+    in input-line order, that the whole-stream build gives, from host lines (load_coo) and from the device generator."""
+    monkeypatch.setenv("SRW_BUILD_BLOCK_LINES", "777")
+    s, d, w = rmat_lines(oracle, 10, edge_factor=8, weighted=True)
+    g = oracle.Graph.from_coo(s, d, w, directed=directed)
+    P = pkg()
+    with P.Cluster([0] * world) as cl:
+        cl.load_coo(s, d, w, directed=directed)
+        assert cl.stats() == (g.num_vertices, g.num_entries)
+        owned = 0
+        for r in range(world):
+            e = cl.shard(r)
+            for v in e.vertices()[::7]:
+                ids, ws = e.neighbors(int(v))
+                oi, ow = g.neighbors(int(v))
+                assert np.array_equal(ids, oi) and np.array_equal(ws, ow), (r, int(v))
+            owned += len(e.vertices())
+        assert owned == g.num_vertices
+        for p, q in ((1.0, 1.0), (0.25, 4.0)):
+            rp, rl, rs = g.walk(p=p, q=q, walk_length=9, num_walks=2, seed=4, threads=8)
+            paths, lens, st = cl.walk(p=p, q=q, walk_length=9, num_walks=2, seed=4)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs
+        # the device generator, block by block, against the whole-stream build of the same (seed, edge index) stream
+        cl.generate_rmat(12, 16 << 12, seed=9, weighted=True, directed=directed)
+        a = cl.walk(p=0.5, q=2.0, walk_length=7, seed=1)
+    monkeypatch.setenv("SRW_BUILD_WHOLE", "1")
+    with P.Cluster([0] * world) as cl:
+        cl.generate_rmat(12, 16 << 12, seed=9, weighted=True, directed=directed)
+        b = cl.walk(p=0.5, q=2.0, walk_length=7, seed=1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2]["n_steps"] == b[2]["n_steps"]

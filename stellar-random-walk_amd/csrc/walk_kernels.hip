@@ -271,8 +271,14 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
 // k_walk_general's registers (128 VGPRs + scratch there) and 4 KB of LDS per wave, so more waves hide the dependent
 // round trips of a step.  A walker that meets a pair without a table is handed over untouched (its index goes to
 // `todo`; k_walk_general redoes it from its first step: the keyed RNG makes that the same path).
+// Waves per SIMD of the lean table kernels.  Round 2 (the exact chain still inlined): 4 waves/SIMD 221 M steps/s at config 3, 5
+// 239 M, 6 235 M.  Round 3, with the chain out of these kernels (s25): config 3 (edge hash: request-bound) 5 -> 478 M, 6 -> 520 M,
+// 7 -> 433 M; config 5's stand-in (row filters, no hash: latency-bound) 5 -> 290 M, 6 -> 326 M, 7 -> 348 M.  So by instantiation:
 #ifndef SRW_LEAN_WAVES
-#define SRW_LEAN_WAVES 5   // measured at config 3: 4 waves/SIMD (126 VGPRs, no spill) 221 M steps/s, 5 (96 + 168 B scratch) 239 M, 6 (80 + 204 B) 235 M; without this kernel 195 M
+#define SRW_LEAN_WAVES 6
+#endif
+#ifndef SRW_LEAN_WAVES_BF
+#define SRW_LEAN_WAVES_BF 7
 #endif
 __device__ inline Row uniform_row(Row r) {            // the row descriptor of a wave's walker is wave-uniform: keep it in SGPRs
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r.off), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)r.off >> 32));
@@ -281,7 +287,7 @@ __device__ inline Row uniform_row(Row r) {            // the row descriptor of a
   return o;
 }
 template <bool BF>   // BF: the located chunk's probes of a long N(prev) go through the row filters (no edge hash; GraphView::bf_off)
-__global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_walk_tables(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
+__global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_walk_tables(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
                                                      int64_t n_walkers, int32_t L, int32_t first_walk, RngSpec rng, float p,
                                                      float q, int32_t *__restrict__ paths, int32_t *__restrict__ lens,
                                                      DevCounters *ctr, unsigned long long *cursor, int32_t *__restrict__ todo,
@@ -1321,7 +1327,7 @@ constexpr int CHAIN_CAP = 1024;     // draws on a CDF boundary per super-step th
 struct alignas(16) ChainRec { uint32_t ri, pad; double S; };                     // record index in the receive buffer, the reference's sum of the biased row
 struct alignas(16) ChainMeta { long long d_off; int32_t deg; uint32_t u_off; };   // first quotient in the scratch array, row length, first work unit
 template <bool BF>
-__global__ __launch_bounds__(TPB, SRW_LEAN_WAVES) void k_sh_step_tab(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
+__global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_sh_step_tab(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
                                                                      RngSpec rng, float p, float q, SWalker *__restrict__ scratch,
                                                                      unsigned long long *cursor, uint32_t *__restrict__ todo, DevCounters *ctr, int32_t grab_n,
                                                                      ChainRec *__restrict__ chain) {

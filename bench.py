@@ -82,7 +82,7 @@ def cpu_baseline(args):
                 timed(gk, "karate.txt (34 vertices), walkLength 10", gk.vertices(), p, q, 10, faithful)
     head = None
     t_build = 0.0
-    for scale, n_faithful, n_fast in ((14, 0, 0), (16, 1024, 4096), (args.cpu_scale, args.cpu_sources or max(64, 3 * cores) // 2, 4096)):
+    for scale, n_faithful, n_fast in ((14, 2048, 0), (16, 1024, 4096), (args.cpu_scale, args.cpu_sources or max(64, 3 * cores) // 2, 4096)):
         t0 = time.time()
         s, d = oracle_py.rmat_edges(scale, 16 << scale, seed=42)
         graphs = {(1.0, 1.0): oracle_py.Graph.from_coo(s, d, None, directed=False),

@@ -262,16 +262,22 @@ template <bool SH>
 __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
                                                      float q, int32_t min_sh, int32_t mask_max, int32_t bins_cap, const uint32_t *__restrict__ eb_off,
                                                      double *__restrict__ eb_bins, uint32_t *__restrict__ em_bits, unsigned long long *cursor,
-                                                     unsigned long long *strat_count /* [8] */) {
+                                                     unsigned long long *strat_count /* [8] */, int fill_tune) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][BINNED_LDS_WORDS];
   const int lane = lane_id();
   uint32_t *mine = lds[threadIdx.x >> 6];
   Member tm; tm.mode = 0; tm.bm = mine; tm.seg_base = 0; tm.ehash = g.ehash; tm.ehash_mask = g.ehash_mask;
   unsigned long long ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef SRW_PHASE_TIMING
+  unsigned long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // wave time: [0] mask pairs, [1] item header, [2] P3, [3] P1, [4] P2, [5] W fill, [6] prefix sums + table write
+#endif
   while (true) {
     const int64_t i0 = grab_u64(cursor, GRAB_ITEMS);
     if (i0 >= n_items) break;
     for (int64_t i = i0; i < i0 + GRAB_ITEMS && i < n_items; ++i) {
+#ifdef SRW_PHASE_TIMING
+      const unsigned long long t_it0 = wall_clock64();
+#endif
       const uint2 it = items[i];
       // SH: it.y = position in u's SORTED row of the membership structure, eb_off = the work list's own offsets (item_off)
       const Row ru = eb_urow<SH>(g, it.x);
@@ -291,13 +297,24 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
           if (lane == 0) { out[c0 >> 5] = (uint32_t)mm; if ((c0 >> 5) + 1 < n_words) out[(c0 >> 5) + 1] = (uint32_t)(mm >> 32); }
         }
         ns[0] += 1;
+#ifdef SRW_PHASE_TIMING
+        tt[0] += wall_clock64() - t_it0;
+#endif
         continue;
       }
+#ifdef SRW_PHASE_TIMING
+      const unsigned long long t_hdr = wall_clock64();
+      tt[1] += t_hdr - t_it0;
+#endif
       const BinGeom gc = bin_geometry(rv.deg, min_sh, bins_cap);
       const BinGeom gf = gc.csh < 6 ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
       unsigned long long ab = 0; unsigned su = 0;
-      binned_fill(g, rv, b, mine, 0, gf, tm, ab, su);
+      binned_fill(g, rv, b, mine, fill_tune, gf, tm, ab, su);
       ns[su & 7] += 1;
+#ifdef SRW_PHASE_TIMING
+      const unsigned long long t_fill = wall_clock64();
+      tt[2 + (su & 3)] += t_fill - t_hdr;              // su: 1 P1, 2 P2, 3 W, 4 P3 (-> slot 2)
+#endif
       const double *bins = reinterpret_cast<const double *>(mine);
       double *out = eb_bins + (size_t)tab_word * 8;
       const int up = gc.csh - gf.csh;
@@ -313,8 +330,15 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
         } else out[j] = a;
       }
       __builtin_amdgcn_wave_barrier();          // the next fill clears the bins
+#ifdef SRW_PHASE_TIMING
+      tt[6] += wall_clock64() - t_fill;
+#endif
     }
   }
+#ifdef SRW_PHASE_TIMING
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) if (tt[i]) atomicAdd(&strat_count[8 + i], tt[i] >> 10);
+#endif
   if (lane == 0)
     for (int i = 0; i < 8; ++i) if (ns[i]) atomicAdd(&strat_count[i], ns[i]);
 }
@@ -472,13 +496,23 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (all_pairs) {
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
-    SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
+    SRW_HIP(hipMemsetAsync(hist.p, 0, 16 * 8, st));
     hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
-                       sel.bins_cap, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p);
+                       sel.bins_cap, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   }
   SRW_HIP(hipStreamSynchronize(st));
+#ifdef SRW_PHASE_TIMING
+  {
+    unsigned long long tt[8];
+    SRW_HIP(hipMemcpy(tt, hist.p + 8, sizeof(tt), hipMemcpyDeviceToHost));
+    static const char *nm[8] = {"mask pairs", "item header", "fill P3", "fill P1", "fill P2", "fill W", "prefix + write", "-"};
+    fprintf(stderr, "[eb_build phase] wave-ms:");
+    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.0f", nm[i], (double)tt[i] * 1024.0 / 100e3);
+    fprintf(stderr, "\n");
+  }
+#endif
   if (sc[7]) throw Error(SRW_ERR_INVALID, "per-edge tables: a prefix sum of a ROW_PQ_F32 row was not exactly representable in binary32");
   g.eb_pbits = pb; g.eb_qbits = qb; g.eb_mode = mode;
   g.eb_tables = (int64_t)all_pairs;
@@ -579,7 +613,7 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
     SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
     hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
-                       sel.bins_cap, item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p);
+                       sel.bins_cap, item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   }

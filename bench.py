@@ -107,7 +107,7 @@ def cpu_baseline(args):
             "plan": plan}
 
 
-def roofline_of(stats, steps_per_launch, avg_ms, scale=None):
+def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None):
     """Algorithmic bytes per launch / average kernel time of the dominant kernel."""
     kind = stats["kernel_kind"]
     if kind == 1:
@@ -151,9 +151,11 @@ def roofline_of(stats, steps_per_launch, avg_ms, scale=None):
                         r["physical_traffic_frac"] = r["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         except Exception:
             pass
-    if kind == 1 and stats["ent_reads"]:
+    table_bytes = (n_entries or 0) * (stats.get("record_bytes") or 0)
+    if kind == 1 and stats["ent_reads"] and table_bytes > (288 << 20):
         # the kernel's bound is the L2-miss REQUEST rate (one request per record whatever its size, + 1/16 path-store sector
-        # per step), not bytes: profiles/r02_translation_and_request_rate.md
+        # per step), not bytes: profiles/r02_translation_and_request_rate.md.  Printed only for a table that the caches cannot
+        # hold (32 MiB of L2 + 256 MiB of Infinity Cache): a cache-resident table (config 2) is not subject to that ceiling.
         req = (stats["ent_reads"] + steps_per_launch / 16.0) / (avg_ms * 1e-3)
         r["requests_per_s"] = req
         r["request_rate_ceiling"] = REQUEST_CEILING
@@ -210,7 +212,7 @@ def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, 
                "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables},
                # builder-side PMC traffic (profiles/pmc_latest.json) exists for config 3 (Mode R and Mode A) only
                "roofline": roofline_of(st, steps / max(K, 1), avg_ms,
-                                       scale=scale if (weighted and not directed and p == 0.25 and q == 4.0) else None)}
+                                       scale=scale if (weighted and not directed and p == 0.25 and q == 4.0) else None, n_entries=ne)}
         if st["kernel_kind"] == 2:
             out["strategy_steps"] = {k: v for k, v in st["strategy_steps"].items() if v}
             out["edge_tables"] = {"count": st["edge_tables"], "bytes": st["edge_table_bytes"]}
@@ -504,7 +506,7 @@ def main():
                            "walk_steps_per_bench_step": int(steps / max(K, 1)),
                            "parallelism": ("graph replicated, walk iterations sharded x%d, no collective" % world) if world > 1 else "1 GPU",
                            "rng": "Philox4x32-10 keyed (iteration, source, step)"},
-                "roofline": roofline_of(stats, steps / max(K, 1), avg_ms, scale=args.scale),
+                "roofline": roofline_of(stats, steps / max(K, 1), avg_ms, scale=args.scale, n_entries=ne),
                 "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables,
                             "note": "outside the timed region; one-off per graph / per (p, q)"},
             }

@@ -130,6 +130,10 @@ struct GraphView {
   // walker arrives with (prev, curr) only.  Null on whole-graph handles walked through srw_walk.
   const PairSlot *ph;
   uint32_t ph_buckets;
+  // Vertex-sharded handles, p != 1 with q == 1 (k_sh_step_q1): the return edges of the pair (prev -> curr), curr owned — what
+  // rev[e] holds on a whole-graph handle (val = count << 24 | index in curr's sorted row, pad = input-order position of the first one)
+  const PairSlot *rh;
+  uint32_t rh_buckets;
 };
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;
 constexpr int32_t BF_MIN_DEG = 1025;
@@ -238,13 +242,26 @@ __host__ __device__ inline uint32_t pair_bucket(uint32_t u, uint32_t x, uint32_t
   a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;
   return (uint32_t)(((uint64_t)a * (uint64_t)n_buckets) >> 32);
 }
-__device__ inline void pair_insert(PairSlot *tab, uint32_t n_buckets, uint32_t u, uint32_t x, uint32_t val) {
+__device__ inline void pair_insert(PairSlot *tab, uint32_t n_buckets, uint32_t u, uint32_t x, uint32_t val, uint32_t pad = 0u) {
   const unsigned long long key = ((unsigned long long)u << 32) | x;
   const uint64_t cap = (uint64_t)n_buckets * 4;
   uint64_t s = (uint64_t)pair_bucket(u, x, n_buckets) * 4;
   while (true) {
     const unsigned long long old = atomicCAS(&tab[s].key, PAIR_EMPTY, key);
-    if (old == PAIR_EMPTY || old == key) { tab[s].val = val; return; }
+    if (old == PAIR_EMPTY || old == key) { tab[s].val = val; tab[s].pad = pad; return; }
+    if (++s == cap) s = 0;
+  }
+}
+// per-lane lookup (every lane its own pair): one 16-byte slot per probe
+__device__ inline bool pair_lookup_lane(const PairSlot *tab, uint32_t n_buckets, uint32_t u, uint32_t x, uint32_t &val_out, uint32_t &pad_out) {
+  const unsigned long long key = ((unsigned long long)u << 32) | x;
+  const uint64_t cap = (uint64_t)n_buckets * 4;
+  uint64_t s = (uint64_t)pair_bucket(u, x, n_buckets) * 4;
+  while (true) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(tab + s);
+    const unsigned long long k = ((unsigned long long)q.y << 32) | q.x;
+    if (k == key) { val_out = q.z; pad_out = q.w; return true; }
+    if (k == PAIR_EMPTY) return false;
     if (++s == cap) s = 0;
   }
 }

@@ -696,6 +696,61 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
   if (getenv("SRW_TIMING")) fprintf(stderr, "[shard %d/%d edge tables] no complete set fits: on-the-fly samplers\n", h->cfg.rank, h->cfg.world);
 }
 
+// ---- return edges on a vertex-sharded handle (k_sh_step_q1: p != 1, q == 1) ------------------------------------------------
+// rev[e] belongs to the entry e = (u -> x) of u's row and describes x's row: on a shard the two live on different ranks.  The
+// record is therefore keyed by the pair, on owner(x), and comes straight from x's own sorted row: every distinct id u in it
+// is a pair (u -> x) with a return edge — first sorted index, multiplicity, input-order position of the first occurrence.
+namespace {
+__global__ __launch_bounds__(TPB) void k_rev_hash(GraphView g, unsigned long long *cursor, unsigned long long *count, PairSlot *__restrict__ rh,
+                                                  uint32_t rh_buckets) {
+  const int lane = lane_id();
+  unsigned long long n = 0;
+  while (true) {
+    const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
+    if (v0 >= g.n_slots) break;
+    for (int64_t x = v0; x < v0 + GRAB_SLOTS && x < g.n_slots; ++x) {
+      const Row rx = g.rows[x];
+      const uint32_t *cs = g.sids + rx.off;
+      for (int32_t i = lane; i < rx.deg; i += 64) {
+        const uint32_t u = cs[i];
+        if (i > 0 && cs[i - 1] == u) continue;                       // the first occurrence speaks for the run
+        ++n;
+        if (rh) {
+          uint32_t cnt = 1;
+          while (cnt < 255u && i + (int32_t)cnt < rx.deg && cs[i + cnt] == u) ++cnt;
+          pair_insert(rh, rh_buckets, u, (uint32_t)x, (cnt << 24) | (uint32_t)i, g.sperm[rx.off + i]);
+        }
+      }
+    }
+  }
+  n = wave_sum_u64(n);
+  if (lane == 0 && n && count) atomicAdd(count, n);
+}
+}  // namespace
+
+void build_shard_rev_hash(srw_handle *h) {
+  Graph &g = h->g;
+  if (g.has_rh) return;
+  build_membership(h);
+  hipStream_t st = h->stream;
+  DevBuf<unsigned long long> cur; cur.alloc(2);
+  SRW_HIP(hipMemsetAsync(cur.p, 0, 16, st));
+  hipLaunchKernelGGL(k_rev_hash, dim3(h->n_cus * 8), dim3(TPB), 0, st, g.view(), cur.p, cur.p + 1, (PairSlot *)nullptr, 0u);
+  unsigned long long n = 0;
+  SRW_HIP(hipMemcpyAsync(&n, cur.p + 1, 8, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  SRW_HIP(hipGetLastError());
+  const unsigned long long nb = n * 20 / 44 + 16;
+  if (nb >= 0xFFFFFFF0ull) throw Error(SRW_ERR_NOMEM, "return-edge hash: too many pairs");
+  g.rh.alloc((size_t)nb * 4); g.rh_buckets = (uint32_t)nb;
+  SRW_HIP(hipMemsetAsync(g.rh.p, 0xFF, (size_t)nb * 4 * sizeof(PairSlot), st));
+  SRW_HIP(hipMemsetAsync(cur.p, 0, 16, st));
+  hipLaunchKernelGGL(k_rev_hash, dim3(h->n_cus * 8), dim3(TPB), 0, st, g.view(), cur.p, (unsigned long long *)nullptr, g.rh.p, g.rh_buckets);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipStreamSynchronize(st));
+  g.has_rh = true;
+}
+
 void build_rev_table(srw_handle *h) {
   Graph &g = h->g;
   if (g.has_rev) return;

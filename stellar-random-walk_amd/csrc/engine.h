@@ -111,6 +111,9 @@ struct Graph {
   DevBuf<PairSlot> ph;            // sharded per-edge tables: pair (prev, curr) -> table / mask word (device_common.h)
   uint32_t ph_buckets = 0;
   bool eb_sharded = false;        // the standing per-edge tables are keyed by the pair hash (built by build_shard_edge_tables)
+  DevBuf<PairSlot> rh;            // sharded q == 1 walks: return edges of the pairs into this shard's rows (build_shard_rev_hash)
+  uint32_t rh_buckets = 0; bool has_rh = false;
+  bool has_cfo_local = false;     // sharded: compact first-order records over the LOCAL rows (guide + ids; their links are not used)
   DevBuf<uint32_t> bf_off, bf_bits; // neighbor-set filters of the rows beyond 1024 neighbors (GraphView::bf_off), built with the per-edge tables
   bool has_bf = false;
   // Compacted ids (sparse id spaces, SRW_CFG_COMPACT_IDS): slots are ranks among the sorted distinct input ids
@@ -119,14 +122,14 @@ struct Graph {
   std::vector<int32_t> h_orig_id; // host mirror (boundary look-ups: srw_graph_neighbors, partitions)
   int32_t id_lo = 0, id_hi = -1;  // smallest / largest id a path can print (text capacity of the formatter)
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
-  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, (has_cfo || cfo_linked) ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
+  GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, (has_cfo || cfo_linked || has_cfo_local) ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
                      mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
                      (has_eb && use_eb && !eb_sharded) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
                      has_rev ? rev.p : nullptr, eb_cap, compact ? orig_id.p : nullptr,
                      (has_bf && use_eb && !(has_ehash && use_ehash)) ? bf_off.p : nullptr, bf_bits.p,
-                     (has_eb && use_eb && eb_sharded) ? ph.p : nullptr, ph_buckets}; }
+                     (has_eb && use_eb && eb_sharded) ? ph.p : nullptr, ph_buckets, has_rh ? rh.p : nullptr, rh_buckets}; }
   // id <-> slot at the boundary (api.cpp): -1 if the id cannot be a vertex of this graph
   int64_t slot_of_id(int32_t v) const {
     if (!compact) { const int64_t s = (int64_t)v - vmin; return (s < 0 || s >= n_slots) ? -1 : s; }
@@ -291,6 +294,8 @@ size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap);   // HBM o
 // Vertex-sharded handles (and whole-graph handles walked through srw_shard_*): the tables of the pairs (prev -> curr) whose
 // curr this handle owns, keyed by the pair hash; a complete set at the finest resolution that fits, or none.
 void prepare_shard_tables(srw_handle *h, const srw_walk_params &P);
+void build_shard_rev_hash(srw_handle *h);        // return edges of the pairs into this shard's rows, keyed by (prev, curr)
+bool build_local_cfo(srw_handle *h);             // sampler_tables.hip: compact records over the local rows (false: some entry needs an escape)
 void build_rev_table(srw_handle *h);             // return-edge positions (k_walk_q1: p != 1, q == 1)
 
 // ---- walk_kernels.hip ----

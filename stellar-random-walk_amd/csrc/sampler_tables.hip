@@ -472,6 +472,7 @@ static unsigned long long run_cfo(srw_handle *h, ST st, unsigned long long *esc_
 void build_first_order_tables(srw_handle *h, bool want_exact) {
   Graph &g = h->g;
   const bool sharded = h->cfg.world > 1;
+  if (g.has_cfo_local && !sharded) { g.has_cfo = true; g.has_cfo_local = false; }   // world 1: the local records are the whole graph's
   if (want_exact ? g.has_fo : (g.has_cfo || sharded || g.cfo_rejected || g.n_entries == 0) && (g.has_cfo || g.has_fo)) return;
   hipStream_t st = h->stream;
   DevBuf<uint2> items; DevBuf<unsigned long long> n_items;
@@ -513,6 +514,20 @@ void build_first_order_tables(srw_handle *h, bool want_exact) {
   g.has_fo = true;
 }
 
+// Compact records over the LOCAL rows of a sharded handle: the guide deltas, the lattice values c and the ids that the per-lane
+// q == 1 step needs (k_sh_step_q1); the links name local rows only and are not used there.  false: an entry needs an escape.
+bool build_local_cfo(srw_handle *h) {
+  Graph &g = h->g;
+  if (g.has_cfo || g.cfo_linked || g.has_cfo_local) return true;
+  if (g.cfo_rejected || g.n_entries == 0) return false;
+  build_first_order_tables(h, true);
+  DevBuf<unsigned long long> esc; esc.alloc(1);
+  g.cfo.alloc((size_t)g.n_entries);
+  if (run_cfo(h, FoStore{g.fo.p}, esc.p) != 0) { g.cfo.release(); g.cfo_rejected = true; return false; }
+  g.has_cfo_local = true;
+  return true;
+}
+
 // ---- vertex-sharded walk: row descriptors across shards (srw_shard_rows_*) -------------------------------------------
 // A record of the replicated first-order table carries the row descriptor of the neighbor it names, so a step never
 // reads the row table.  On a shard the neighbor's row lives on ANOTHER shard: the shards exchange their row tables once
@@ -552,6 +567,8 @@ bool shard_rows_commit(srw_handle *h, const void *d_rows_all, int64_t n_slots) {
   if (n_slots != g.n_slots) throw Error(SRW_ERR_INVALID, "row table size mismatch");
   build_first_order_tables(h, true);
   shard_rows_release(h);
+  if (g.has_cfo_local && h->cfg.world == 1) { g.has_cfo = true; g.has_cfo_local = false; }
+  if (g.has_cfo_local) { g.cfo.release(); g.has_cfo_local = false; }      // the linked records replace the local ones
   g.rows_all.alloc((size_t)n_slots);
   SRW_HIP(hipMemcpyAsync(g.rows_all.p, d_rows_all, (size_t)n_slots * sizeof(Row), hipMemcpyDeviceToDevice, h->stream));
   if (g.n_entries == 0) { SRW_HIP(hipStreamSynchronize(h->stream)); g.cfo_linked = true; return true; }

@@ -388,6 +388,122 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The second-order step of the q = 1 per-lane kernels (k_walk_q1, k_sh_step_q1): first k that is not a certain miss under the exact
+// prefix sums PQ + the return edges' corrections.  rv / rv_pos0 / rv_w0: the pair's return-edge record (RevEnt: count << 24 | index in
+// curr's sorted row, input-order position and weight of the first one).  0: picked (k, e = its compact record); 1: non-positive sum,
+// 2: a draw within rounding distance of a CDF boundary — the caller hands the walker to the general sampler (or, with the row's
+// sum in *S_out, to the chain kernels).
+template <bool NT>
+__device__ inline int q1_pick(const GraphView &g, const Row &r, const CfoEnt *crow, uint32_t rv, int32_t rv_pos0, float rv_w0, int32_t prev_id,
+                              uint32_t m, float p, CfoEnt &e, int32_t &k, unsigned long long &reads, double *S_out = nullptr) {
+  const double *PQ = g.pq + r.off;
+  int32_t rp[REV_MAX_RETURNS]; double rc[REV_MAX_RETURNS];      // return edges: input-order position, correction
+  int nr = 0;
+  double corr_all = 0.0;
+  int64_t so = 0;                                   // first return edge in curr's sorted row
+  if (rv != REV_NONE) {
+    nr = (int)(rv >> 24);
+    so = r.off + (int64_t)(rv & 0xFFFFFFu);
+    if (nr >= 255) {                                 // the count saturated (hub <-> hub multi-edges): count the run of prev
+      const uint32_t xprev = (uint32_t)((int64_t)prev_id - g.vmin);
+      const int64_t row_end = r.off + r.deg;
+      while (so + nr < row_end && g.sids[so + nr] == xprev) ++nr;
+    }
+#pragma unroll
+    for (int i = 0; i < REV_MAX_RETURNS; ++i) {
+      rp[i] = r.deg; rc[i] = 0.0;
+      if (i < nr) {
+        float w;
+        if (i == 0) { rp[0] = rv_pos0; w = rv_w0; }             // the first return edge travels with rev[e]
+        else { rp[i] = (int32_t)g.sperm[so + i]; w = g.sw[so + i]; }
+        rc[i] = (double)div_exact(w, p) - (double)w; corr_all += rc[i];
+      }
+    }
+    for (int i = REV_MAX_RETURNS; i < nr; ++i) { const float w = g.sw[so + i]; corr_all += (double)div_exact(w, p) - (double)w; }   // (small graphs: dozens of duplicates between hubs)
+  } else {
+#pragma unroll
+    for (int i = 0; i < REV_MAX_RETURNS; ++i) { rp[i] = r.deg; rc[i] = 0.0; }
+  }
+  {
+    const double S0 = PQ[r.deg - 1], S = S0 + corr_all;
+    const double pS = (double)m * 0x1p-24 * S;
+    auto corr_upto = [&](int32_t kk) {
+      double a = 0.0;
+#pragma unroll
+      for (int i = 0; i < REV_MAX_RETURNS; ++i) a += (rp[i] <= kk) ? rc[i] : 0.0;       // exact under the certificate
+      for (int i = REV_MAX_RETURNS; i < nr; ++i)
+        if ((int32_t)g.sperm[so + i] <= kk) { const float w = g.sw[so + i]; a += (double)div_exact(w, p) - (double)w; }
+      return a;
+    };
+    auto numer = [&](int32_t kk) { return PQ[kk] + corr_upto(kk); };
+    auto not_miss = [&](int32_t kk, double num) { return !(num * (1.0 + (double)(kk + 8) * 0x1p-51) < pS); };
+    // start position: the guide entry of the bucket the target falls into in UNBIASED units (any start is
+    // correct, the loops below decide with the exact sums; a good one makes them O(1))
+    auto guide_start = [&](double tau, bool &ok) {
+      double f = tau / S0;
+      f = f < 0.0 ? 0.0 : (f > 0.99999994 ? 0.99999994 : f);
+      const uint32_t mm = (uint32_t)(f * 16777216.0);
+      const uint32_t j = (uint32_t)(((uint64_t)mm * (uint64_t)(uint32_t)r.deg) >> 24);
+      const CfoEnt ge = load_cfo<NT>(crow + j); ++reads;
+      const int32_t gd = cfo_delta(ge.cg, ge.link);
+      if (gd == CFO_GD_SAT) { ok = false; return 0; }      // no guide for this bucket: bisection below
+      const int32_t st = (int32_t)j - gd;
+      return st < 0 ? 0 : (st >= r.deg ? r.deg - 1 : st);
+    };
+    bool ok = S > 0.0 && S0 > 0.0;
+    int32_t k0 = 0;
+    if (ok) {
+      k0 = guide_start(pS, ok);
+      const double cb = ok ? corr_upto(k0) : 0.0;
+      if (ok && cb != 0.0) {                           // past a return edge: its correction moves the answer
+        int32_t first_r = r.deg;
+#pragma unroll
+        for (int i = 0; i < REV_MAX_RETURNS; ++i) first_r = rp[i] < first_r ? rp[i] : first_r;
+        for (int i = REV_MAX_RETURNS; i < nr; ++i) { const int32_t q_ = (int32_t)g.sperm[so + i]; first_r = q_ < first_r ? q_ : first_r; }
+        const int32_t k1 = guide_start(pS - cb, ok);
+        k0 = k1 < first_r ? first_r : k1;
+      }
+    }
+    const bool usable = S > 0.0 && S0 > 0.0;
+    if (!usable) return 1;
+    else {
+      // first k that is not a certain miss (A' is non-decreasing, the tolerance grows with k: monotone) — a few
+      // steps from the guide's start, else (saturated guide entry, many parallel return edges) by bisection
+      int guard = 0;
+      double nk = 0.0;
+      if (ok) {
+        nk = numer(k0);
+        bool nm = not_miss(k0, nk);
+        while (nm && k0 > 0 && guard < 12) {             // step back while the predecessor is not a certain miss either
+          const double np = numer(k0 - 1);
+          if (!not_miss(k0 - 1, np)) break;
+          --k0; nk = np; ++guard;
+        }
+        while (!nm && guard < 12) {                      // step forward to the first not-certain-miss
+          ++k0; ++guard;
+          if (k0 >= r.deg) break;
+          nk = numer(k0); nm = not_miss(k0, nk);
+        }
+        reads += (unsigned)guard + 1u;
+      }
+      if (!ok || guard >= 12) {
+        int32_t lo = 0, hi = r.deg;
+        while (lo < hi) {
+          const int32_t mid = lo + ((hi - lo) >> 1);
+          if (not_miss(mid, numer(mid))) hi = mid; else lo = mid + 1;
+          ++reads;
+        }
+        k0 = lo;
+        if (k0 < r.deg) nk = numer(k0);
+      }
+      if (k0 >= r.deg) { k = 0; e = load_cfo<NT>(crow); ++reads; }                    // no crossing: edges.head (:24)
+      else if (nk * (1.0 - (double)(k0 + 8) * 0x1p-51) >= pS) { k = k0; e = load_cfo<NT>(crow + k); ++reads; }   // a certain hit
+      else { if (S_out) *S_out = S; return 2; }   // a draw within rounding distance of a boundary: exact chain (S: the reference's sum, exact under the certificate)
+    }
+  }
+  return 0;
+}
+
 // p != 1, q == 1: the only biased candidates are the return edges, so a step is a first-order step plus one
 // correction — one walker per LANE, like k_walk_first_order (r01 ran this case one walker per wave: 4.6e8 steps/s).
 // Per step, under the row certificate of sampler_tables.hip (every prefix sum exact):
@@ -440,114 +556,10 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
         if (s == 1) {                               // initFirstStep: raw weights = the first-order draw
           unsigned rd; e = cfo_pick<NT>(crow, r.deg, m, rd, k); reads += rd;
         } else {
-          const double *PQ = g.pq + r.off;
           const int4v rv4 = NT ? __builtin_nontemporal_load(reinterpret_cast<const int4v *>(g.rev + eprev))
                                : *reinterpret_cast<const int4v *>(g.rev + eprev);
-          const uint32_t rv = (uint32_t)rv4.x;
-          int32_t rp[REV_MAX_RETURNS]; double rc[REV_MAX_RETURNS];      // return edges: input-order position, correction
-          int nr = 0;
-          double corr_all = 0.0;
-          int64_t so = 0;                                   // first return edge in curr's sorted row
-          if (rv != REV_NONE) {
-            nr = (int)(rv >> 24);
-            so = r.off + (int64_t)(rv & 0xFFFFFFu);
-            if (nr >= 255) {                                 // the count saturated (hub <-> hub multi-edges): count the run of prev
-              const uint32_t xprev = (uint32_t)((int64_t)prev_id - g.vmin);
-              const int64_t row_end = r.off + r.deg;
-              while (so + nr < row_end && g.sids[so + nr] == xprev) ++nr;
-            }
-#pragma unroll
-            for (int i = 0; i < REV_MAX_RETURNS; ++i) {
-              rp[i] = r.deg; rc[i] = 0.0;
-              if (i < nr) {
-                float w;
-                if (i == 0) { rp[0] = rv4.y; w = __int_as_float(rv4.z); }             // the first return edge travels with rev[e]
-                else { rp[i] = (int32_t)g.sperm[so + i]; w = g.sw[so + i]; }
-                rc[i] = (double)div_exact(w, p) - (double)w; corr_all += rc[i];
-              }
-            }
-            for (int i = REV_MAX_RETURNS; i < nr; ++i) { const float w = g.sw[so + i]; corr_all += (double)div_exact(w, p) - (double)w; }   // (small graphs: dozens of duplicates between hubs)
-          } else {
-#pragma unroll
-            for (int i = 0; i < REV_MAX_RETURNS; ++i) { rp[i] = r.deg; rc[i] = 0.0; }
-          }
-          if (alive) {
-            const double S0 = PQ[r.deg - 1], S = S0 + corr_all;
-            const double pS = (double)m * 0x1p-24 * S;
-            auto corr_upto = [&](int32_t kk) {
-              double a = 0.0;
-#pragma unroll
-              for (int i = 0; i < REV_MAX_RETURNS; ++i) a += (rp[i] <= kk) ? rc[i] : 0.0;       // exact under the certificate
-              for (int i = REV_MAX_RETURNS; i < nr; ++i)
-                if ((int32_t)g.sperm[so + i] <= kk) { const float w = g.sw[so + i]; a += (double)div_exact(w, p) - (double)w; }
-              return a;
-            };
-            auto numer = [&](int32_t kk) { return PQ[kk] + corr_upto(kk); };
-            auto not_miss = [&](int32_t kk, double num) { return !(num * (1.0 + (double)(kk + 8) * 0x1p-51) < pS); };
-            // start position: the guide entry of the bucket the target falls into in UNBIASED units (any start is
-            // correct, the loops below decide with the exact sums; a good one makes them O(1))
-            auto guide_start = [&](double tau, bool &ok) {
-              double f = tau / S0;
-              f = f < 0.0 ? 0.0 : (f > 0.99999994 ? 0.99999994 : f);
-              const uint32_t mm = (uint32_t)(f * 16777216.0);
-              const uint32_t j = (uint32_t)(((uint64_t)mm * (uint64_t)(uint32_t)r.deg) >> 24);
-              const CfoEnt ge = load_cfo<NT>(crow + j); ++reads;
-              const int32_t gd = cfo_delta(ge.cg, ge.link);
-              if (gd == CFO_GD_SAT) { ok = false; return 0; }      // no guide for this bucket: bisection below
-              const int32_t st = (int32_t)j - gd;
-              return st < 0 ? 0 : (st >= r.deg ? r.deg - 1 : st);
-            };
-            bool ok = S > 0.0 && S0 > 0.0;
-            int32_t k0 = 0;
-            if (ok) {
-              k0 = guide_start(pS, ok);
-              const double cb = ok ? corr_upto(k0) : 0.0;
-              if (ok && cb != 0.0) {                           // past a return edge: its correction moves the answer
-                int32_t first_r = r.deg;
-#pragma unroll
-                for (int i = 0; i < REV_MAX_RETURNS; ++i) first_r = rp[i] < first_r ? rp[i] : first_r;
-                for (int i = REV_MAX_RETURNS; i < nr; ++i) { const int32_t q_ = (int32_t)g.sperm[so + i]; first_r = q_ < first_r ? q_ : first_r; }
-                const int32_t k1 = guide_start(pS - cb, ok);
-                k0 = k1 < first_r ? first_r : k1;
-              }
-            }
-            const bool usable = S > 0.0 && S0 > 0.0;
-            if (!usable) { alive = false; handed = true; atomicAdd(&ctr->why[1], 1ull); }
-            else {
-              // first k that is not a certain miss (A' is non-decreasing, the tolerance grows with k: monotone) — a few
-              // steps from the guide's start, else (saturated guide entry, many parallel return edges) by bisection
-              int guard = 0;
-              double nk = 0.0;
-              if (ok) {
-                nk = numer(k0);
-                bool nm = not_miss(k0, nk);
-                while (nm && k0 > 0 && guard < 12) {             // step back while the predecessor is not a certain miss either
-                  const double np = numer(k0 - 1);
-                  if (!not_miss(k0 - 1, np)) break;
-                  --k0; nk = np; ++guard;
-                }
-                while (!nm && guard < 12) {                      // step forward to the first not-certain-miss
-                  ++k0; ++guard;
-                  if (k0 >= r.deg) break;
-                  nk = numer(k0); nm = not_miss(k0, nk);
-                }
-                reads += (unsigned)guard + 1u;
-              }
-              if (!ok || guard >= 12) {
-                int32_t lo = 0, hi = r.deg;
-                while (lo < hi) {
-                  const int32_t mid = lo + ((hi - lo) >> 1);
-                  if (not_miss(mid, numer(mid))) hi = mid; else lo = mid + 1;
-                  ++reads;
-                }
-                k0 = lo;
-                if (k0 < r.deg) nk = numer(k0);
-              }
-              if (k0 >= r.deg) { k = 0; e = load_cfo<NT>(crow); ++reads; }                    // no crossing: edges.head (:24)
-              else if (nk * (1.0 - (double)(k0 + 8) * 0x1p-51) >= pS) { k = k0; e = load_cfo<NT>(crow + k); ++reads; }   // a certain hit
-              else { alive = false; handed = true; atomicAdd(&ctr->why[2], 1ull); }   // a draw within rounding distance of a boundary: exact chain
-            }
-          }
+          const int why = q1_pick<NT>(g, r, crow, (uint32_t)rv4.x, rv4.y, __int_as_float(rv4.z), prev_id, m, p, e, k, reads);
+          if (why) { alive = false; handed = true; atomicAdd(&ctr->why[why], 1ull); }
         }
         if (alive) {
           val = e.id; ++len;
@@ -1326,6 +1338,7 @@ constexpr int SH_GRAB = 16;         // records per cursor grab (a single counter
 constexpr int CHAIN_CAP = 1024;     // draws on a CDF boundary per super-step that the chain kernels take (more: the general step)
 struct alignas(16) ChainRec { uint32_t ri, pad; double S; };                     // record index in the receive buffer, the reference's sum of the biased row
 struct alignas(16) ChainMeta { long long d_off; int32_t deg; uint32_t u_off; };   // first quotient in the scratch array, row length, first work unit
+struct ChainUnits { double *usum; int32_t *ue; unsigned long long *utot; };       // per unit of 256 quotients: plain sum, guessed binade, integer increment
 template <bool BF>
 __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_sh_step_tab(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
                                                                      RngSpec rng, float p, float q, SWalker *__restrict__ scratch,
@@ -1420,6 +1433,61 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
   }
 }
 
+// p != 1, q == 1 on a shard: one record per LANE (k_walk_q1's step, one super-step at a time; round 2 ran this case one wave
+// per record through k_sh_step).  Per record: the row of curr (local), the Philox draw, and — second-order steps — the pair's
+// return-edge record from the shard's hash (edge_tables.hip:build_shard_rev_hash) + q1_pick over the local compact records and
+// exact prefix sums.  An irregular row or a draw within rounding distance of a CDF boundary puts the record on the todo list
+// (k_sh_step redoes exactly those); k_sh_scatter buckets the scratch records.
+template <bool NT>
+__global__ __launch_bounds__(TPB) void k_sh_step_q1(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last, RngSpec rng, float p,
+                                                    SWalker *__restrict__ scratch, unsigned long long *cursor, uint32_t *__restrict__ todo,
+                                                    ChainRec *__restrict__ chain, DevCounters *ctr) {
+  __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
+  const uint32_t n_in = shard_in_prefix(io, pre);
+  unsigned long long steps = 0, dead = 0, reads = 0, n_todo = 0;
+  uint32_t lo, hi;
+  shard_slice(n_in, TPB, lo, hi);
+  for (uint32_t base = lo; base < hi; base += TPB) {
+    const uint32_t ri = base + threadIdx.x;
+    if (ri >= hi) continue;
+    const SWalker wk = shard_in_record(io, pre, ri);
+    const Row *rp = row_of(g, wk.curr);
+    Row r; r.off = 0; r.deg = 0; r.flags = 0;
+    if (rp) r = *rp;
+    if (r.deg == 0) { if (step > 1) ++dead; scratch[ri] = shard_dead(wk); continue; }
+    bool handed = (r.flags & ROW_IRREGULAR) != 0;
+    CfoEnt e; int32_t k = -1;
+    if (!handed) {
+      const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
+      const uint32_t m = walk_bits24(rng.seed, iter, (uint32_t)rng_source(g, wk.src), (uint32_t)step);
+      const CfoEnt *crow = g.cfo + r.off;
+      if (step == 1) { unsigned rd; e = cfo_pick<NT>(crow, r.deg, m, rd, k); reads += rd; }
+      else {
+        uint32_t rv = REV_NONE, pos0 = 0u;
+        float w0 = 0.0f;
+        if (pair_lookup_lane(g.rh, g.rh_buckets, (uint32_t)((int64_t)wk.prev - g.vmin), (uint32_t)((int64_t)wk.curr - g.vmin), rv, pos0))
+          w0 = g.ent[r.off + pos0].w;
+        else rv = REV_NONE;
+        double S_tie = 0.0;
+        const int why = q1_pick<NT>(g, r, crow, rv, (int32_t)pos0, w0, wk.prev, m, p, e, k, reads, &S_tie);
+        if (why == 2) {       // a tie: the exact chain, its quotients computed by the whole GPU (k_chain_d)
+          const unsigned long long ci = atomicAdd(cursor + 2, 1ull);
+          if (ci < (unsigned long long)CHAIN_CAP) { ChainRec cr; cr.ri = ri; cr.pad = 0u; cr.S = S_tie; chain[ci] = cr; continue; }
+        }
+        handed = why != 0;
+      }
+    }
+    if (handed) { todo[atomicAdd(cursor + 1, 1ull)] = ri; ++n_todo; continue; }
+    scratch[ri] = shard_advance(wk, step, e.id, last != 0);
+    ++steps;
+  }
+  flush_counters(ctr, steps, dead, 0, 0, reads, 0);
+  const unsigned long long tot = wave_sum_u64(steps);
+  if (lane_id() == 0 && tot) atomicAdd(&ctr->strat[SRW_STRAT_Q1_LANE], tot);
+  const unsigned long long nt = wave_sum_u64(n_todo);
+  if (lane_id() == 0 && nt) atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], nt);
+}
+
 // ---- the exact chain for the table steps whose draw sits on a CDF boundary ---------------------------------------------
 // RandomSample.sample's running sum (RandomSample.scala:18-22) is sequential by nature, but only its ADDITIONS are: the
 // quotients fl(w'_k / S) — the entry loads, the membership probes, the divides: what costs — are independent.  So:
@@ -1455,7 +1523,8 @@ __global__ void k_chain_setup(GraphView g, ShardIO io, const ChainRec *__restric
   totals[0] = units; totals[1] = n;
 }
 __global__ __launch_bounds__(TPB) void k_chain_d(GraphView g, ShardIO io, float p, float q, const ChainRec *__restrict__ list,
-                                                 const ChainMeta *__restrict__ meta, const uint32_t *__restrict__ totals, double *__restrict__ D) {
+                                                 const ChainMeta *__restrict__ meta, const uint32_t *__restrict__ totals, double *__restrict__ D,
+                                                 ChainUnits cu) {
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
   shard_in_prefix(io, pre);
   const int lane = lane_id();
@@ -1468,11 +1537,13 @@ __global__ __launch_bounds__(TPB) void k_chain_d(GraphView g, ShardIO io, float 
     const int32_t base4 = (int32_t)(u - m.u_off) * 256;
     const SWalker wk = shard_record_uniform(io, pre, list[i].ri);
     const Row r = uniform_row(g.rows[(int64_t)wk.curr - g.vmin]);
-    const Row mr = uniform_row(g.mrows[(int64_t)wk.prev - g.vmin]);
+    const bool need = q != 1.0f;                           // q == 1 (k_sh_step_q1's ties): only the return edges are biased
+    Row mr; mr.off = 0; mr.deg = 0; mr.flags = 0;
+    if (need) mr = uniform_row(g.mrows[(int64_t)wk.prev - g.vmin]);
     Bias b;
-    b.p = p; b.q = q; b.prev = wk.prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
-    b.prev_sids = g.msids + mr.off; b.prev_deg = mr.deg; b.prev_hub = mr.flags >> ROW_HUB_SHIFT;
-    Member cm; cm.mode = 1; cm.bm = nullptr; cm.seg_base = 0;
+    b.p = p; b.q = q; b.prev = wk.prev; b.second_order = true; b.need_member = need; b.vmin = g.vmin;
+    b.prev_sids = need ? g.msids + mr.off : nullptr; b.prev_deg = mr.deg; b.prev_hub = mr.flags >> ROW_HUB_SHIFT;
+    Member cm; cm.mode = need ? 1 : 0; cm.bm = nullptr; cm.seg_base = 0;
     cm.hub = (b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
     cm.ehash = g.ehash; cm.ehash_mask = g.ehash_mask;
     if (!cm.hub && !g.ehash && g.bf_off && mr.deg >= BF_MIN_DEG) {
@@ -1484,13 +1555,71 @@ __global__ __launch_bounds__(TPB) void k_chain_d(GraphView g, ShardIO io, float 
     double *out = D + m.d_off + base4;
 #pragma unroll
     for (int uu = 0; uu < 4; ++uu) out[uu * 64 + lane] = d4[uu];          // (padding up to the unit's 256 slots holds 0.0)
+    const double us = wave_sum_f64((d4[0] + d4[1]) + (d4[2] + d4[3]));    // approximate: only places the unit in a binade (k_chain_scan)
+    if (lane == 0) cu.usum[u] = us;
   }
 }
-constexpr int CHAIN_NU = 16;     // quotients per lane and round of the sequential pass
+// One wave per record: the approximate accumulator at every unit's start and end (a plain scan of the units' sums) names the
+// binade the unit is expected to run in (-1: the two ends differ).  A guess only: k_chain_seq checks it against the exact accumulator.
+__global__ __launch_bounds__(TPB) void k_chain_scan(const ChainMeta *__restrict__ meta, const uint32_t *__restrict__ totals, ChainUnits cu) {
+  const int lane = lane_id();
+  const uint32_t i = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (i >= totals[1]) return;
+  const ChainMeta m = meta[i];
+  if (m.deg == 0) return;
+  const int32_t nu = (m.deg + 255) >> 8;
+  double carry = 0.0;
+  for (int32_t base = 0; base < nu; base += 64) {
+    const int32_t j = base + lane;
+    const double v = j < nu ? cu.usum[m.u_off + j] : 0.0;
+    double incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    const double a0 = carry + (incl - v), a1 = carry + incl;
+    const unsigned long long b0 = (unsigned long long)__double_as_longlong(a0), b1 = (unsigned long long)__double_as_longlong(a1);
+    const int e0 = (int)((b0 >> 52) & 0x7FFull), e1 = (int)((b1 >> 52) & 0x7FFull);
+    if (j < nu) cu.ue[m.u_off + j] = (e0 == e1 && e0 != 0 && e0 != 0x7FF && !(b0 >> 63)) ? e0 : -1;
+    carry += readlane_f64(incl, 63);
+  }
+}
+// The whole GPU, one wave per unit: the unit's 256 quotients as ONE integer increment of the accumulator in the guessed binade
+// (chain_round_fast's argument: without a rounding tie the maps N -> N + c commute); CHAIN_UNIT_SLOW when an element sits on a
+// tie or would leave the binade by itself, or the unit has no guess.
+constexpr unsigned long long CHAIN_UNIT_SLOW = ~0ull;
+__global__ __launch_bounds__(TPB) void k_chain_u(const uint32_t *__restrict__ totals, const double *__restrict__ D, ChainUnits cu) {
+  const int lane = lane_id();
+  const uint32_t n_units = totals[0];
+  const uint32_t gw = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), nw = gridDim.x * (TPB / 64);
+  for (uint32_t u = gw; u < n_units; u += nw) {
+    const int e = cu.ue[u];
+    double d4[4];
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) d4[uu] = D[(long long)u * 256 + uu * 64 + lane];
+    unsigned long long loc = 0ull; bool odd = e < 0;
+    if (e >= 0) {
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        unsigned long long c0 = 0ull, c1 = 0ull;
+        chain_elem_map(d4[uu], e - 1023, c0, c1);
+        odd |= (c0 != c1) || (c0 >> 53);
+        loc += c0;
+      }
+    }
+    const bool slow = __any(odd);
+    const unsigned long long tot = wave_sum_u64(loc);
+    if (lane == 0) cu.utot[u] = (slow || (tot >> 53)) ? CHAIN_UNIT_SLOW : tot;
+  }
+}
+// One wave per record, 64 units (16 384 quotients) per iteration: lane l holds unit j + l's integer increment; a wave scan gives the
+// accumulator after each unit, exactly, while the guessed binade is the accumulator's and the sum stays inside it.  The first unit
+// that is slow (a tie inside, no / wrong guess), would leave the binade or reaches p is evaluated element by element
+// (chain_group64: the reference's additions) — the first ~20 units of a row (the accumulator climbs through the small binades),
+// one per binade crossing afterwards, and the answer's unit.  A 10^6-candidate row: ~64 iterations + ~25 slow units, where
+// one integer sum per 1024 quotients took ~1000 dependent rounds (2.7 ms per super-step on RMAT-24's hubs).
 __global__ __launch_bounds__(TPB) void k_chain_seq(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last, RngSpec rng,
                                                    const ChainRec *__restrict__ list, const ChainMeta *__restrict__ meta,
-                                                   const uint32_t *__restrict__ totals, const double *__restrict__ D,
-                                                   SWalker *__restrict__ scratch, DevCounters *ctr) {
+                                                   const uint32_t *__restrict__ totals, const double *__restrict__ D, ChainUnits cu,
+                                                   SWalker *__restrict__ scratch, DevCounters *ctr, int strat) {
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
   shard_in_prefix(io, pre);
   const int lane = lane_id();
@@ -1504,37 +1633,54 @@ __global__ __launch_bounds__(TPB) void k_chain_seq(GraphView g, ShardIO io, int3
   const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
   const double p = (double)draw_uniform(rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
   const double *d = D + m.d_off;
-  const int32_t n_pad = (r.deg + 255) & ~255;             // what k_chain_d wrote (zeros beyond deg)
-  auto load_round = [&](int32_t base, double (&v)[CHAIN_NU]) {
-#pragma unroll
-    for (int u = 0; u < CHAIN_NU; ++u) { const int32_t k = base + u * 64 + lane; v[u] = k < n_pad ? d[k] : 0.0; }
-  };
-  double cur[CHAIN_NU], nxt[CHAIN_NU];
-#pragma unroll
-  for (int u = 0; u < CHAIN_NU; ++u) nxt[u] = 0.0;
-  load_round(0, cur);
+  const int32_t nu = (r.deg + 255) >> 8;
   double acc = 0.0;
-  int32_t k_hit = -1;
-  for (int32_t base = 0; base < r.deg && k_hit < 0; base += CHAIN_NU * 64) {
-    if (base + CHAIN_NU * 64 < r.deg) load_round(base + CHAIN_NU * 64, nxt);      // in flight while this round is added up
-    if (!chain_round_fast<CHAIN_NU>(acc, cur, p)) {
+  int32_t k_hit = -1, j = 0;
+  unsigned n_slow = 0;
+  while (j < nu && k_hit < 0) {
+    const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
+    const int ea = (int)((ab >> 52) & 0x7FFull);
+    int f = 0;                                            // units absorbed by this iteration
+    if (!(ea == 0 || ea == 0x7FF || (ab >> 63))) {
+      const unsigned long long N0 = (ab & ((1ull << 52) - 1ull)) | (1ull << 52);
+      const bool valid = j + lane < nu;
+      const unsigned long long tot = valid ? cu.utot[m.u_off + j + lane] : 0ull;
+      const int eg = valid ? cu.ue[m.u_off + j + lane] : ea;
+      const bool slow = valid && (tot == CHAIN_UNIT_SLOW || eg != ea);
+      unsigned long long incl = slow ? 0ull : tot;        // (lanes behind the first stop are not used)
 #pragma unroll
-      for (int u = 0; u < CHAIN_NU; ++u) {
-        const int32_t b0 = base + u * 64;
-        if (b0 >= r.deg || k_hit >= 0) break;               // wave-uniform
-        const int f = chain_group64(acc, cur[u], min(64, r.deg - b0), p);
-        if (f >= 0) k_hit = b0 + f;
-      }
+      for (int off = 1; off < 64; off <<= 1) { const unsigned long long t = shfl_up_u64(incl, off); if (lane >= off) incl += t; }
+      const unsigned long long N = N0 + incl;
+      const double a = __longlong_as_double((long long)(((unsigned long long)ea << 52) | (N & ((1ull << 52) - 1ull))));
+      const unsigned long long stop = __ballot(slow || (valid && (N >= (1ull << 53) || !(a < p))));
+      const int n_valid = min(64, nu - j);
+      f = stop ? __ffsll((long long)stop) - 1 : n_valid;
+      if (f > 0) acc = readlane_f64(a, f - 1);
+      j += f;
+      if (!stop) continue;
     }
-#pragma unroll
-    for (int u = 0; u < CHAIN_NU; ++u) cur[u] = nxt[u];
+    // unit j, element by element
+    ++n_slow;
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {
+      const int32_t b0 = j * 256 + u * 64;
+      if (b0 >= r.deg) break;                             // wave-uniform
+      const int cnt = min(64, r.deg - b0);
+      const double dv = lane < cnt ? d[b0 + lane] : 0.0;
+      const int fh = chain_group64(acc, dv, cnt, p);
+      if (fh >= 0) { k_hit = b0 + fh; break; }
+    }
+    ++j;
   }
   if (k_hit < 0) k_hit = 0;                               // edges.head (:24)
   if (lane == 0) {
     const int32_t next = g.ent[r.off + k_hit].id;
     scratch[ri] = shard_advance(wk, step, next, last != 0);
     atomicAdd(&ctr->steps, 1ull); atomicAdd(&ctr->fallbacks, 1ull);
-    atomicAdd(&ctr->strat[SRW_STRAT_CHAIN], 1ull); atomicAdd(&ctr->strat[SRW_STRAT_EDGE_TABLE], 1ull);
+    atomicAdd(&ctr->strat[SRW_STRAT_CHAIN], 1ull); atomicAdd(&ctr->strat[strat], 1ull);
+#ifdef SRW_PHASE_TIMING
+    atomicAdd(&ctr->dbg[20], (unsigned long long)n_slow); atomicAdd(&ctr->dbg[21], (unsigned long long)nu);
+#endif
   }
 }
 
@@ -2273,6 +2419,41 @@ void run_shard_begin(srw_handle *h, const srw_walk_params &P, int32_t batch, con
   SRW_HIP(hipGetLastError());
 }
 
+// Chain scratch of a handle: record list + meta + totals in one buffer, the quotients of up to d_cap candidates in another,
+// the per-unit summaries in a third.
+namespace {
+struct ChainBufs { ChainRec *list; ChainMeta *meta; uint32_t *totals; double *D; ChainUnits cu; long long d_cap; };
+ChainBufs chain_bufs(srw_handle *h) {
+  static const long long d_cap = (long long)(getenv("SRW_CHAIN_SCRATCH_MB") ? atof(getenv("SRW_CHAIN_SCRATCH_MB")) : 512.0) * (1 << 20) / 8;
+  const size_t n_units = (size_t)(d_cap / 256) + CHAIN_CAP;
+  h->chain_buf.ensure((size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)) + 64 + n_units * 24);
+  h->chain_d.ensure((size_t)d_cap);
+  ChainBufs b;
+  char *base = h->chain_buf.p;
+  b.list = reinterpret_cast<ChainRec *>(base);
+  b.meta = reinterpret_cast<ChainMeta *>(base + (size_t)CHAIN_CAP * sizeof(ChainRec));
+  b.totals = reinterpret_cast<uint32_t *>(base + (size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)));
+  char *ub = base + (size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)) + 64;
+  b.cu.usum = reinterpret_cast<double *>(ub);
+  b.cu.utot = reinterpret_cast<unsigned long long *>(ub + n_units * 8);
+  b.cu.ue = reinterpret_cast<int32_t *>(ub + n_units * 16);
+  b.D = h->chain_d.p; b.d_cap = d_cap;
+  return b;
+}
+// draws on a CDF boundary (listed by the step kernel at cursor[2]): quotients by the whole GPU, their units summarised, then one
+// short sequential pass per record; what does not fit goes onto the todo list of the general step
+void enqueue_chain(srw_handle *h, const ChainBufs &cb, const GraphView &gv, const ShardIO &io, const srw_walk_params &P, int32_t step, int32_t last,
+                   const RngSpec &rng, SWalker *scratch, int strat) {
+  hipStream_t st = h->stream;
+  hipLaunchKernelGGL(k_chain_setup, dim3(1), dim3(64), 0, st, gv, io, cb.list, h->walk_cursor.p, cb.meta, cb.totals, cb.d_cap, (uint32_t *)h->walk_todo.p);
+  hipLaunchKernelGGL(k_chain_d, dim3(h->n_cus * 4), dim3(TPB), 0, st, gv, io, P.p, P.q, cb.list, cb.meta, cb.totals, cb.D, cb.cu);
+  hipLaunchKernelGGL(k_chain_scan, dim3(CHAIN_CAP / (TPB / 64)), dim3(TPB), 0, st, cb.meta, cb.totals, cb.cu);
+  hipLaunchKernelGGL(k_chain_u, dim3(h->n_cus * 4), dim3(TPB), 0, st, cb.totals, (const double *)cb.D, cb.cu);
+  hipLaunchKernelGGL(k_chain_seq, dim3(CHAIN_CAP / (TPB / 64)), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, cb.list, cb.meta, cb.totals,
+                     (const double *)cb.D, cb.cu, scratch, h->counters.p, strat);
+}
+}  // namespace
+
 // One super-step, enqueued on the handle's stream without any host synchronisation: returns of the previous
 // super-step applied, every incoming walker sampled once, walkers and path returns bucketed into dst[0 .. world).
 void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch, int32_t step, const srw_shard_layout &lay,
@@ -2297,6 +2478,14 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     if (P.sampler == SRW_SAMPLER_REFERENCE) prepare_shard_tables(h, P); else g.use_eb = false;
   }
   const bool tables = !first_order && g.has_eb && g.use_eb && g.eb_sharded && P.q != 1.0f;
+  // p != 1, q == 1: one record per lane when every row holds the prefix-sum certificate and the compact records exist
+  bool q1 = false;
+  if (!first_order && P.q == 1.0f && P.p != 1.0f && P.rng_mode == SRW_RNG_PHILOX && P.sampler == SRW_SAMPLER_REFERENCE && g.has_pq &&
+      g.pq_bad_rows == 0 && ((P.flags >> 12) & 15) == 0 && !(P.flags & (SRW_WALK_NO_PREFIX | SRW_WALK_NO_COMPACT | SRW_WALK_NO_BINNED)) &&
+      !getenv("SRW_NO_Q1_KERNEL") && g.n_entries > 0 && build_local_cfo(h)) {
+    build_shard_rev_hash(h);
+    q1 = true;
+  }
   const ShardIO io = make_io(h, batch, lay, d_recv, d_lens);
   ShardDst sd;
   for (int d = 0; d < SHARD_MAX_WORLD; ++d) sd.p[d] = d < world ? (char *)dst[d] : nullptr;
@@ -2333,18 +2522,52 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
       fprintf(stderr, "[shard profile] rank %d: apply %.1f ms, fused step %.1f ms (cumulative)\n", h->cfg.rank, acc[0], acc[1]);
     return;
   }
+  if (q1) {          // per-lane step -> ties through the chain kernels, the rest it hands over through the general step -> one fused bucketing pass
+    h->walk_cursor.ensure(4);                       // [1] todo records, [2] chain records
+    h->walk_todo.ensure((size_t)world * (size_t)lay.cap_walkers);
+    h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
+    SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, 4 * sizeof(unsigned long long), st));
+    const ChainBufs cb = chain_bufs(h);
+    ChainRec *chain_list = cb.list;
+    const GraphView gv = g.view();
+    // a latency-bound kernel of fixed slices: exactly as many blocks as are resident at once
+    static int q1_occ[2] = {0, 0};
+    const bool ntq = (size_t)g.n_entries * sizeof(CfoEnt) > ((size_t)2 << 30);
+    if (!q1_occ[ntq]) {
+      int nb = 0;
+      if (ntq) SRW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sh_step_q1<true>, TPB, 0));
+      else SRW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sh_step_q1<false>, TPB, 0));
+      q1_occ[ntq] = std::max(1, nb);
+      if (const char *e = getenv("SRW_SH_Q1_BLOCKS"); e && *e) q1_occ[ntq] = std::max(1, atoi(e));
+    }
+    const int qb = h->n_cus * q1_occ[ntq];
+    timed(1, [&] {
+      if (ntq)
+        hipLaunchKernelGGL(k_sh_step_q1<true>, dim3(qb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, scratch, h->walk_cursor.p,
+                           (uint32_t *)h->walk_todo.p, chain_list, h->counters.p);
+      else
+        hipLaunchKernelGGL(k_sh_step_q1<false>, dim3(qb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, scratch, h->walk_cursor.p,
+                           (uint32_t *)h->walk_todo.p, chain_list, h->counters.p);
+    });
+    timed(2, [&] { enqueue_chain(h, cb, gv, io, P, step, last, rng, scratch, (int)SRW_STRAT_Q1_LANE); });
+    timed(2, [&] {
+      hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch, h->shard_blk.p,
+                         h->counters.p, (const uint32_t *)h->walk_todo.p, (const unsigned long long *)(h->walk_cursor.p + 1));
+    });
+    timed(3, [&] { hipLaunchKernelGGL(k_sh_scatter, dim3(n_blocks), dim3(TPB), 0, st, gv, io, step, scratch, h->shard_cur.p, sd, h->shard_flag.p, h->counters.p); });
+    SRW_HIP(hipGetLastError());
+    if (prof && last)
+      fprintf(stderr, "[shard profile] rank %d: apply %.1f ms, per-lane q = 1 step %.1f ms, general step (handed over) %.1f ms, scatter %.1f ms (cumulative)\n", h->cfg.rank,
+              acc[0], acc[1], acc[2], acc[3]);
+    return;
+  }
   if (tables) {      // lean table step (persistent waves) -> the records without a table through the general step -> one fused bucketing pass
     h->walk_cursor.ensure(4);                       // [0] record cursor, [1] todo records, [2] chain records
     h->walk_todo.ensure((size_t)world * (size_t)lay.cap_walkers);
     h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
     SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, 4 * sizeof(unsigned long long), st));
-    // chain scratch: list + meta + totals in one buffer, the quotients of up to d_cap candidates in another
-    static const long long d_cap = (long long)(getenv("SRW_CHAIN_SCRATCH_MB") ? atof(getenv("SRW_CHAIN_SCRATCH_MB")) : 512.0) * (1 << 20) / 8;
-    h->chain_buf.ensure((size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)) + 64);
-    h->chain_d.ensure((size_t)d_cap);
-    ChainRec *chain_list = reinterpret_cast<ChainRec *>(h->chain_buf.p);
-    ChainMeta *chain_meta = reinterpret_cast<ChainMeta *>(h->chain_buf.p + (size_t)CHAIN_CAP * sizeof(ChainRec));
-    uint32_t *chain_totals = reinterpret_cast<uint32_t *>(h->chain_buf.p + (size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)));
+    const ChainBufs cb = chain_bufs(h);
+    ChainRec *chain_list = cb.list;
     const GraphView gv = g.view();
     static const int grab_n = getenv("SRW_SH_GRAB") ? std::max(1, atoi(getenv("SRW_SH_GRAB"))) : SH_GRAB;
     static const int tb_mult = getenv("SRW_SH_BLOCKS") ? std::max(1, atoi(getenv("SRW_SH_BLOCKS"))) : 8;
@@ -2357,14 +2580,8 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
         hipLaunchKernelGGL((k_sh_step_tab<false>), dim3(tb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch,
                            h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n, chain_list);
     });
-    // draws on a CDF boundary of a table step: quotients by the whole GPU, then one sequential pass per record
-    timed(2, [&] {
-      hipLaunchKernelGGL(k_chain_setup, dim3(1), dim3(64), 0, st, gv, io, chain_list, h->walk_cursor.p, chain_meta, chain_totals, d_cap,
-                         (uint32_t *)h->walk_todo.p);
-      hipLaunchKernelGGL(k_chain_d, dim3(h->n_cus * 4), dim3(TPB), 0, st, gv, io, P.p, P.q, chain_list, chain_meta, chain_totals, h->chain_d.p);
-      hipLaunchKernelGGL(k_chain_seq, dim3(CHAIN_CAP / (TPB / 64)), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, chain_list, chain_meta,
-                         chain_totals, (const double *)h->chain_d.p, scratch, h->counters.p);
-    });
+    // draws on a CDF boundary of a table step
+    timed(2, [&] { enqueue_chain(h, cb, gv, io, P, step, last, rng, scratch, (int)SRW_STRAT_EDGE_TABLE); });
     timed(2, [&] {      // (the few records without a table, or whose tie is not a table step's)
       hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch, h->shard_blk.p,
                          h->counters.p, (const uint32_t *)h->walk_todo.p, (const unsigned long long *)(h->walk_cursor.p + 1));

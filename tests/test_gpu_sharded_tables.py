@@ -131,3 +131,28 @@ def test_shard_build_in_blocks(oracle, monkeypatch, world, directed):
         cl.generate_rmat(12, 16 << 12, seed=9, weighted=True, directed=directed)
         b = cl.walk(p=0.5, q=2.0, walk_length=7, seed=1)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2]["n_steps"] == b[2]["n_steps"]
+
+
+@pytest.mark.parametrize("world,directed,membership", [(1, False, True), (2, False, False), (3, True, True), (8, False, False)])
+def test_shard_q1_per_lane_step(oracle, world, directed, membership):
+    """p != 1 with q == 1 on shards: one record per lane (k_sh_step_q1) over the shard's compact records, exact prefix sums and
+    the return-edge hash of the pairs into its rows — also on handles without the replicated membership structure, which is what
+    q == 1 jobs create.  Multigraph with parallel return edges, weighted RMAT; bit-identical to the oracle."""
+    from helpers import random_multigraph
+    s, d, w = rmat_lines(oracle, 11, edge_factor=16, weighted=True)
+    ms, md, mw = random_multigraph(np.random.default_rng(7), 300, 6000, True, id_lo=5000)     # duplicates, self-loops, unused ids
+    s, d, w = np.concatenate([s, ms]), np.concatenate([d, md]), np.concatenate([w, mw])
+    g = oracle.Graph.from_coo(s, d, w, directed=directed)
+    with pkg().Cluster([0] * world, membership=membership) as cl:
+        cl.load_coo(s, d, w, directed=directed)
+        for p in (0.5, 4.0, 0.25):
+            rp, rl, rs = g.walk(p=p, q=1.0, walk_length=14, num_walks=2, first_walk=1, seed=9, threads=8)
+            for batch in (0, 1):
+                paths, lens, st = cl.walk(p=p, q=1.0, walk_length=14, num_walks=2, first_walk=1, seed=9, batch=batch)
+                assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (world, p, batch)
+                assert st["n_steps"] == rs
+            ss = st["strategy_steps"]
+            assert ss["q1_lane"] > 0.95 * st["n_steps"], (p, ss)           # the rest: draws on a CDF boundary, handed over
+        rp, rl, rs = g.walk(p=0.5, q=1.0, walk_length=5, rng="const", const_r=0.5, threads=8)      # constant r: the general step
+        paths, lens, st = cl.walk(p=0.5, q=1.0, walk_length=5, rng="const", const_r=0.5)
+        assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["strategy_steps"]["q1_lane"] == 0

@@ -769,6 +769,80 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
   return wave_chain_pick(row, deg, b, r, S);
 }
 
+// ---- q == 1, ANY number of return edges (hub <-> hub multi-edges, self-loops of a hub: hundreds of them) ------------------
+// The only biased candidates are the nr return edges, a RUN [so, so + nr) of curr's sorted row whose input-order positions
+// (sperm) increase along the run (the rows are sorted by a stable sort).  Between two of them A'_k = PQ[k] + C with C constant, so
+//   1. the run is walked 64 at a time with a wave scan of the corrections: the first return edge that is not a certain miss
+//      bounds the answer to the interval behind its predecessor;
+//   2. a 64-ary search over the exact prefix sums of that interval (constant correction) finds the first k that is not a
+//      certain miss; a certain hit is the reference's answer, else the chain (CHAIN = false: CHAIN_NEEDED, S in *S_out).
+// O(nr / 64 + log_64 deg) wave steps and no LDS, where wave_pick_prefix keeps at most SP_CAP specials and adds all of them up
+// per probe, and the per-lane q1_pick walks the run once per prefix value.  -1: the row has no usable prefix sums.
+template <bool CHAIN = true>
+__device__ inline int32_t wave_pick_returns(const GraphView &g, const Row &rc, const Bias &b, int64_t so, int32_t nr, float r,
+                                            unsigned &fallback, double *S_out = nullptr) {
+  const int32_t deg = rc.deg;
+  if (!g.pq || !(rc.flags & ROW_PQ_OK) || deg < 1) return -1;
+  const int lane = lane_id();
+  const double *PQ = g.pq + rc.off;
+  auto corr_of = [&](int64_t i) { const float w = g.sw[i]; return (double)div_exact(w, b.p) - (double)w; };
+  double cs = 0.0;
+  for (int32_t i = lane; i < nr; i += 64) cs += corr_of(so + i);
+  cs = wave_sum_f64(cs);                                  // exact under the certificate, in any order
+  const double S0 = PQ[deg - 1], S = S0 + cs;
+  if (!(S > 0.0) || !(S0 > 0.0)) return -1;
+  const double pS = (double)r * S;
+  auto not_miss = [&](int32_t kk, double num) { return !(num * (1.0 + (double)(kk + 8) * 0x1p-51) < pS); };
+  // 1. the first return edge that is not a certain miss
+  int32_t lo = 0, ans = -1;
+  double C = 0.0, ans_num = 0.0, carry = 0.0;
+  int32_t last_pos = -1;
+  for (int32_t base = 0; base < nr; base += 64) {
+    const int32_t i = base + lane;
+    const bool valid = i < nr;
+    const int32_t pos = valid ? (int32_t)g.sperm[so + i] : deg;
+    const double c = valid ? corr_of(so + i) : 0.0;
+    const double incl = wave_incl_scan_f64(c);
+    const double num = valid ? PQ[pos] + (carry + incl) : 0.0;
+    const unsigned long long m = __ballot(valid && not_miss(pos, num));
+    if (m) {
+      const int f = __ffsll((long long)m) - 1;
+      ans = __builtin_amdgcn_readlane(pos, f); ans_num = readlane_f64(num, f);
+      C = readlane_f64(carry + (incl - c), f);
+      lo = f ? __builtin_amdgcn_readlane(pos, f - 1) + 1 : last_pos + 1;
+      break;
+    }
+    const int nv = min(64, nr - base);
+    carry += readlane_f64(incl, 63);
+    last_pos = __builtin_amdgcn_readlane(pos, nv - 1);
+  }
+  if (ans < 0) { lo = last_pos + 1; C = carry; }
+  // 2. the interval [lo, hi] in front of it (behind the last return edge when there is none): constant correction C
+  int32_t hi = ans >= 0 ? ans - 1 : deg - 1;
+  bool none = false;
+  while (hi - lo >= 64) {
+    const int64_t span = (int64_t)hi - lo;
+    const int32_t k = lo + (int32_t)((span * (lane + 1)) >> 6);          // lane 63 probes hi
+    const unsigned long long m = __ballot(not_miss(k, PQ[k] + C));
+    if (!m) { none = true; break; }                  // even k = hi is a certain miss
+    const int f = __ffsll((long long)m) - 1;
+    const int32_t kf = __builtin_amdgcn_readlane(k, f);
+    const int32_t kprev = f ? __builtin_amdgcn_readlane(k, f - 1) : lo - 1;
+    hi = kf; lo = kprev + 1;
+  }
+  if (!none && lo <= hi) {
+    const int32_t k = lo + lane;
+    const double num = k <= hi ? PQ[k] + C : 0.0;
+    const unsigned long long m = __ballot(k <= hi && not_miss(k, num));
+    if (m) { const int f = __ffsll((long long)m) - 1; ans = lo + f; ans_num = readlane_f64(num, f); }
+  }
+  if (ans < 0) return 0;                             // no crossing: edges.head (:24)
+  if (ans_num * (1.0 - (double)(ans + 8) * 0x1p-51) >= pS) return ans;     // a certain hit
+  if (!CHAIN) { if (S_out) *S_out = S; return CHAIN_NEEDED; }
+  fallback = 1;
+  return wave_chain_pick(g.ent + rc.off, deg, b, r, S);
+}
+
 // ---- exact pick by search over exact prefix sums, ANY number of specials (q != 1; hub -> hub steps) ----------------
 // Same mathematics as wave_pick_prefix, but the corrections of the specials are not kept as a list: each one is
 // added (exactly — the row certificate makes every sum of variant differences exact in any order) into an LDS bin

@@ -1441,7 +1441,7 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
 template <bool NT>
 __global__ __launch_bounds__(TPB) void k_sh_step_q1(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last, RngSpec rng, float p,
                                                     SWalker *__restrict__ scratch, unsigned long long *cursor, uint32_t *__restrict__ todo,
-                                                    ChainRec *__restrict__ chain, DevCounters *ctr) {
+                                                    ChainRec *__restrict__ chain, DevCounters *ctr, uint32_t max_ret, uint32_t *__restrict__ many) {
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
   const uint32_t n_in = shard_in_prefix(io, pre);
   unsigned long long steps = 0, dead = 0, reads = 0, n_todo = 0;
@@ -1468,6 +1468,10 @@ __global__ __launch_bounds__(TPB) void k_sh_step_q1(GraphView g, ShardIO io, int
         if (pair_lookup_lane(g.rh, g.rh_buckets, (uint32_t)((int64_t)wk.prev - g.vmin), (uint32_t)((int64_t)wk.curr - g.vmin), rv, pos0))
           w0 = g.ent[r.off + pos0].w;
         else rv = REV_NONE;
+        // many parallel return edges (hub <-> hub multi-edges, a hub's self-loops): every prefix value walks the whole run in ONE
+        // lane, and a super-step ends with its slowest lane (RMAT-24: 450 ms per iteration, 140 without them) — one wave per
+        // such record instead (k_sh_step_q1w)
+        if (rv != REV_NONE && (rv >> 24) > max_ret) { many[atomicAdd(cursor + 3, 1ull)] = ri; continue; }
         double S_tie = 0.0;
         const int why = q1_pick<NT>(g, r, crow, rv, (int32_t)pos0, w0, wk.prev, m, p, e, k, reads, &S_tie);
         if (why == 2) {       // a tie: the exact chain, its quotients computed by the whole GPU (k_chain_d)
@@ -1488,6 +1492,58 @@ __global__ __launch_bounds__(TPB) void k_sh_step_q1(GraphView g, ShardIO io, int
   if (lane_id() == 0 && nt) atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], nt);
 }
 
+__device__ inline SWalker shard_record_uniform(const ShardIO &io, const uint32_t *pre, uint32_t ri) {
+  SWalker wk = shard_in_record(io, pre, ri);
+  wk.lw = __builtin_amdgcn_readfirstlane(wk.lw); wk.src = __builtin_amdgcn_readfirstlane(wk.src);
+  wk.prev = __builtin_amdgcn_readfirstlane(wk.prev); wk.curr = __builtin_amdgcn_readfirstlane(wk.curr);
+  return wk;
+}
+// The records of k_sh_step_q1's "many return edges" list, one wave each (wave_pick_returns): picked -> scratch, a tie -> the chain
+// list, a row without usable prefix sums -> the general step's todo list.
+__global__ __launch_bounds__(TPB) void k_sh_step_q1w(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last, RngSpec rng, float p,
+                                                     SWalker *__restrict__ scratch, unsigned long long *cursor, const uint32_t *__restrict__ many,
+                                                     uint32_t *__restrict__ todo, ChainRec *__restrict__ chain, DevCounters *ctr) {
+  __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
+  shard_in_prefix(io, pre);
+  const int lane = lane_id();
+  const uint32_t n = (uint32_t)cursor[3];
+  unsigned long long steps = 0, n_todo = 0;
+  for (uint32_t ti = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6); ti < n; ti += gridDim.x * (TPB / 64)) {
+    const uint32_t ri = many[ti];
+    const SWalker wk = shard_record_uniform(io, pre, ri);
+    const Row r = uniform_row(*row_of(g, wk.curr));        // (listed: the row exists and is regular)
+    const uint32_t xprev = (uint32_t)((int64_t)wk.prev - g.vmin);
+    uint32_t rv = 0u;
+    int32_t nr = 0; int64_t so = r.off;
+    if (pair_lookup_wave(g.rh, g.rh_buckets, xprev, (uint32_t)((int64_t)wk.curr - g.vmin), rv)) {
+      so = r.off + (int64_t)(rv & 0xFFFFFFu); nr = (int32_t)(rv >> 24);
+      if (nr >= 255) {                                     // the count saturated: the run of prev in the sorted row
+        nr = 0;
+        for (int64_t c = so;; c += 64) {
+          const unsigned long long m = __ballot(c + lane < r.off + r.deg && g.sids[c + lane] == xprev);
+          nr += __popcll(m);
+          if (m != ~0ull) break;
+        }
+      }
+    }
+    Bias b = make_bias(g, p, 1.0f, wk.prev, true);
+    const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
+    const float u = draw_uniform(rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
+    unsigned f = 0; double S_tie = 0.0;
+    const int32_t k = wave_pick_returns<false>(g, r, b, so, nr, u, f, &S_tie);
+    if (k == CHAIN_NEEDED) {
+      unsigned long long ci = CHAIN_CAP;
+      if (lane == 0) ci = atomicAdd(cursor + 2, 1ull);
+      ci = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(ci < (unsigned long long)CHAIN_CAP ? ci : CHAIN_CAP));
+      if (ci < (unsigned long long)CHAIN_CAP) { if (lane == 0) { ChainRec cr; cr.ri = ri; cr.pad = 0u; cr.S = S_tie; chain[ci] = cr; } continue; }
+    }
+    if (k < 0) { if (lane == 0) { todo[atomicAdd(cursor + 1, 1ull)] = ri; ++n_todo; } continue; }
+    if (lane == 0) { scratch[ri] = shard_advance(wk, step, g.ent[r.off + k].id, last != 0); ++steps; }
+  }
+  if (lane == 0 && steps) { atomicAdd(&ctr->steps, steps); atomicAdd(&ctr->strat[SRW_STRAT_PREFIX], steps); }
+  if (lane == 0 && n_todo) atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], n_todo);
+}
+
 // ---- the exact chain for the table steps whose draw sits on a CDF boundary ---------------------------------------------
 // RandomSample.sample's running sum (RandomSample.scala:18-22) is sequential by nature, but only its ADDITIONS are: the
 // quotients fl(w'_k / S) — the entry loads, the membership probes, the divides: what costs — are independent.  So:
@@ -1497,12 +1553,6 @@ __global__ __launch_bounds__(TPB) void k_sh_step_q1(GraphView g, ShardIO io, int
 //   k_chain_seq    one wave per record: the chain over the stored quotients, 1024 per round (chain_round_fast: one integer
 //                  sum per round while no rounding tie / binade crossing / answer is in it), next round prefetched
 // ~3 000 ties per iteration at config 3's size, each up to a million candidates long: one wave alone took 10-40 ms for one.
-__device__ inline SWalker shard_record_uniform(const ShardIO &io, const uint32_t *pre, uint32_t ri) {
-  SWalker wk = shard_in_record(io, pre, ri);
-  wk.lw = __builtin_amdgcn_readfirstlane(wk.lw); wk.src = __builtin_amdgcn_readfirstlane(wk.src);
-  wk.prev = __builtin_amdgcn_readfirstlane(wk.prev); wk.curr = __builtin_amdgcn_readfirstlane(wk.curr);
-  return wk;
-}
 __global__ void k_chain_setup(GraphView g, ShardIO io, const ChainRec *__restrict__ list, unsigned long long *cursor /* [1] todo_n, [2] chain_n */,
                               ChainMeta *__restrict__ meta, uint32_t *__restrict__ totals /* [0] work units, [1] records */, long long d_cap,
                               uint32_t *__restrict__ todo) {
@@ -1636,7 +1686,7 @@ __global__ __launch_bounds__(TPB) void k_chain_seq(GraphView g, ShardIO io, int3
   const int32_t nu = (r.deg + 255) >> 8;
   double acc = 0.0;
   int32_t k_hit = -1, j = 0;
-  unsigned n_slow = 0;
+  [[maybe_unused]] unsigned n_slow = 0;
   while (j < nu && k_hit < 0) {
     const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
     const int ea = (int)((ab >> 52) & 0x7FFull);
@@ -2523,8 +2573,10 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     return;
   }
   if (q1) {          // per-lane step -> ties through the chain kernels, the rest it hands over through the general step -> one fused bucketing pass
-    h->walk_cursor.ensure(4);                       // [1] todo records, [2] chain records
-    h->walk_todo.ensure((size_t)world * (size_t)lay.cap_walkers);
+    h->walk_cursor.ensure(4);                       // [1] todo records, [2] chain records, [3] records with many return edges
+    const size_t n_rec = (size_t)world * (size_t)lay.cap_walkers;
+    h->walk_todo.ensure(2 * n_rec);                 // todo list | many-returns list
+    uint32_t *many_list = (uint32_t *)h->walk_todo.p + n_rec;
     h->shard_cur.ensure((size_t)SH_CUR_DONE + 1);
     SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, 4 * sizeof(unsigned long long), st));
     const ChainBufs cb = chain_bufs(h);
@@ -2541,13 +2593,16 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
       if (const char *e = getenv("SRW_SH_Q1_BLOCKS"); e && *e) q1_occ[ntq] = std::max(1, atoi(e));
     }
     const int qb = h->n_cus * q1_occ[ntq];
+    const uint32_t q1_max_ret = getenv("SRW_Q1_MAX_RET") ? (uint32_t)atoi(getenv("SRW_Q1_MAX_RET")) : 16u;
     timed(1, [&] {
       if (ntq)
         hipLaunchKernelGGL(k_sh_step_q1<true>, dim3(qb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, scratch, h->walk_cursor.p,
-                           (uint32_t *)h->walk_todo.p, chain_list, h->counters.p);
+                           (uint32_t *)h->walk_todo.p, chain_list, h->counters.p, q1_max_ret, many_list);
       else
         hipLaunchKernelGGL(k_sh_step_q1<false>, dim3(qb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, scratch, h->walk_cursor.p,
-                           (uint32_t *)h->walk_todo.p, chain_list, h->counters.p);
+                           (uint32_t *)h->walk_todo.p, chain_list, h->counters.p, q1_max_ret, many_list);
+      hipLaunchKernelGGL(k_sh_step_q1w, dim3(h->n_cus * 8), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, scratch, h->walk_cursor.p,
+                         (const uint32_t *)many_list, (uint32_t *)h->walk_todo.p, chain_list, h->counters.p);
     });
     timed(2, [&] { enqueue_chain(h, cb, gv, io, P, step, last, rng, scratch, (int)SRW_STRAT_Q1_LANE); });
     timed(2, [&] {

@@ -133,12 +133,15 @@ def test_shard_build_in_blocks(oracle, monkeypatch, world, directed):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2]["n_steps"] == b[2]["n_steps"]
 
 
-@pytest.mark.parametrize("world,directed,membership", [(1, False, True), (2, False, False), (3, True, True), (8, False, False)])
-def test_shard_q1_per_lane_step(oracle, world, directed, membership):
+@pytest.mark.parametrize("world,directed,membership,max_ret", [(1, False, True, None), (2, False, False, 1), (3, True, True, 0), (8, False, False, None)])
+def test_shard_q1_per_lane_step(oracle, monkeypatch, world, directed, membership, max_ret):
     """p != 1 with q == 1 on shards: one record per lane (k_sh_step_q1) over the shard's compact records, exact prefix sums and
     the return-edge hash of the pairs into its rows — also on handles without the replicated membership structure, which is what
-    q == 1 jobs create.  Multigraph with parallel return edges, weighted RMAT; bit-identical to the oracle."""
+    q == 1 jobs create.  Multigraph with parallel return edges, weighted RMAT; bit-identical to the oracle.  max_ret: pairs with
+    more parallel return edges than this go one wave per record (k_sh_step_q1w; default 16) — 0 / 1 send most second-order steps there."""
     from helpers import random_multigraph
+    if max_ret is not None:
+        monkeypatch.setenv("SRW_Q1_MAX_RET", str(max_ret))
     s, d, w = rmat_lines(oracle, 11, edge_factor=16, weighted=True)
     ms, md, mw = random_multigraph(np.random.default_rng(7), 300, 6000, True, id_lo=5000)     # duplicates, self-loops, unused ids
     s, d, w = np.concatenate([s, ms]), np.concatenate([d, md]), np.concatenate([w, mw])
@@ -152,7 +155,10 @@ def test_shard_q1_per_lane_step(oracle, world, directed, membership):
                 assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (world, p, batch)
                 assert st["n_steps"] == rs
             ss = st["strategy_steps"]
-            assert ss["q1_lane"] > 0.95 * st["n_steps"], (p, ss)           # the rest: draws on a CDF boundary, handed over
+            # per lane, or per wave for the pairs with many parallel return edges ("prefix"); the rest: irregular rows, handed over
+            assert ss["q1_lane"] + ss["prefix"] > 0.95 * st["n_steps"], (p, ss)
+            assert (ss["q1_lane"] > 0.5 * st["n_steps"]) if max_ret is None else (ss["prefix"] > 0), (p, ss)
+            assert ss["handed_over_walkers"] < 0.05 * st["n_steps"], (p, ss)
         rp, rl, rs = g.walk(p=0.5, q=1.0, walk_length=5, rng="const", const_r=0.5, threads=8)      # constant r: the general step
         paths, lens, st = cl.walk(p=0.5, q=1.0, walk_length=5, rng="const", const_r=0.5)
         assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["strategy_steps"]["q1_lane"] == 0

@@ -283,9 +283,10 @@ def exchange_model(world, steps_per_s=None):
 
 
 def run_sharded_biased_world1(pkg, device, name, scale, ef, weighted, directed, p, q, replicated_value, K=1, L=80):
-    """A biased (q != 1) configuration through the vertex-sharded protocol at world = 1: the shard holds the per-edge tables
+    """A biased configuration through the vertex-sharded protocol at world = 1.  q != 1: the shard holds the per-edge tables
     of the pairs into its own rows behind the pair hash (edge_tables.hip:prepare_shard_tables), walkers arrive as 16-byte
-    records, every super-step is the lean table step + the chain kernels + one fused bucketing pass.  What one GPU can show
+    records, every super-step is the lean table step + the chain kernels + one fused bucketing pass.  q == 1 (p != 1): one record
+    per lane behind the return-edge hash (k_sh_step_q1), pairs with many parallel return edges one wave each.  What one GPU can show
     is the cost of that machinery against the single-launch kernel on the same graph (`fraction_of_replicated`)."""
     import torch
     kw = dict(p=p, q=q, walk_length=L, seed=42)
@@ -611,6 +612,8 @@ def main():
                 rep = {c.get("name"): c.get("value") for c in cfgs}
                 for (name, sc, ef, wt, dr, p, q, of) in [
                         ("C3 shape, vertex-sharded, world 1 (per-edge tables on the shard)", 24, 16, True, False, 0.25, 4.0, "C3 Mode R"),
+                        ("C3's graph with q = 1, vertex-sharded, world 1 (one record per lane behind the return-edge hash)", 24, 16, True, False,
+                         0.25, 1.0, "C3's graph with q = 1 (return-edge bias only), Mode R"),
                         ("C5 shape, vertex-sharded, world 1 (per-edge tables on the shard)", 26, 27, False, True, 4.0, 0.5, "C5 stand-in Mode R")]:
                     try:
                         cfgs.append(run_sharded_biased_world1(pkg, local_rank, name, sc, ef, wt, dr, p, q, rep.get(of)))

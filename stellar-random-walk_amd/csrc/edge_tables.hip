@@ -258,6 +258,9 @@ __global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, ShardSel ss, EbS
 
 // pass 4: the tables.  One wave per pair: binned_fill exactly as a walk step over that pair would run it, then the
 // prefix at every table chunk end goes to HBM.
+#ifndef SRW_EB_PREFETCH
+#define SRW_EB_PREFETCH 2
+#endif
 template <bool SH>
 __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
                                                      float q, int32_t min_sh, int32_t mask_max, int32_t bins_cap, const uint32_t *__restrict__ eb_off,
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
       const BinGeom gc = bin_geometry(rv.deg, min_sh, bins_cap);
       const BinGeom gf = gc.csh < 6 ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
       unsigned long long ab = 0; unsigned su = 0;
-      binned_fill(g, rv, b, mine, fill_tune, gf, tm, ab, su);
+      binned_fill<SRW_EB_PREFETCH>(g, rv, b, mine, fill_tune, gf, tm, ab, su);
       ns[su & 7] += 1;
 #ifdef SRW_PHASE_TIMING
       const unsigned long long t_fill = wall_clock64();
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
     }
   }
 #ifdef SRW_PHASE_TIMING
+  tt[7] = tm.t_pass1;                                  // inside W: the 10-level lower bounds in LDS
   if (lane == 0)
     for (int i = 0; i < 8; ++i) if (tt[i]) atomicAdd(&strat_count[8 + i], tt[i] >> 10);
 #endif
@@ -507,9 +511,9 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   {
     unsigned long long tt[8];
     SRW_HIP(hipMemcpy(tt, hist.p + 8, sizeof(tt), hipMemcpyDeviceToHost));
-    static const char *nm[8] = {"mask pairs", "item header", "fill P3", "fill P1", "fill P2", "fill W", "prefix + write", "-"};
+    static const char *nm[8] = {"mask pairs", "item header", "fill P3", "fill P1", "fill P2", "fill W", "prefix + write", "(of W: LDS lower bounds)"};
     fprintf(stderr, "[eb_build phase] wave-ms:");
-    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.0f", nm[i], (double)tt[i] * 1024.0 / 100e3);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f", nm[i], (double)tt[i] * 1024.0 / 100e3);
     fprintf(stderr, "\n");
   }
 #endif

@@ -951,6 +951,9 @@ __host__ __device__ inline BinnedCost binned_cost(int32_t deg, int32_t m, bool h
 // Fills the wave's LDS bins with the EXACT inclusive prefix, by chunk, of the corrections of the specials of this
 // (prev, curr) pair: bins[j] = sum over positions k < ((j + 1) << csh) of (w'_k - fl(w_k / q)).
 // tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W, 4 = P3 if prev has a bitmap (tests force each one)
+// PF: rounds of candidates the sorted-chunk intersection keeps in flight ahead of the one it works on (12 VGPRs each; the table
+// build runs it with 2 — 72 % of a round was the wait for the next round's loads, profiles/r03_eb_build.md)
+template <int PF = 1>
 __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias &b, uint32_t *lds, int tune,
                                    const BinGeom geo, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used) {
   const int32_t deg = rc.deg;
@@ -1064,8 +1067,8 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
         // four searches per lane in lockstep.  Whichever list ends first in id order advances: at most
         // |N(curr)| / 256 + |N(prev)| / 1024 rounds, independent of the id range.
         uint32_t *bch = win;                                 // 1024 words of the 1280-word region
-        uint32_t AI[4], AC[4], AIn[4], ACn[4];
-        float AW[4], AWn[4];
+        uint32_t AI[4], AC[4], NI[PF][4], NC[PF][4];
+        float AW[4], NW[PF][4];
         auto load_a = [&](int32_t pos, uint32_t v[4], uint32_t c[4], float w[4]) {   // lane holds 4 consecutive entries
           const int32_t i0 = pos + 4 * lane;
           if (i0 + 3 < deg) {
@@ -1095,7 +1098,8 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
         };
         stage_b(pb);
         load_a(pa, AI, AC, AW);
-        load_a(pa + 256, AIn, ACn, AWn);
+#pragma unroll
+        for (int sgi = 0; sgi < PF; ++sgi) load_a(pa + 256 * (sgi + 1), NI[sgi], NC[sgi], NW[sgi]);
         __builtin_amdgcn_wave_barrier();
         uint32_t handled = 0; bool have_handled = false;     // candidates <= handled met every id of N(prev) they could equal
 #ifdef SRW_PHASE_TIMING
@@ -1114,6 +1118,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
             want[j] = AI[j] <= bmax && AI[j] != xprev && !(have_handled && AI[j] <= handled);   // padding never <= bmax
             pos[j] = 0u;
           }
+          SRW_U0(tm);
 #pragma unroll
           for (int step = HCHUNK / 2; step >= 1; step >>= 1) {
             uint32_t probe[4];
@@ -1122,6 +1127,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (probe[j] < AI[j]) pos[j] += step;
           }
+          SRW_U1(tm, t_pass1);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (want[j] && bch[pos[j]] == AI[j]) atomicAdd(&bins[AC[j] >> csh], (double)AW[j] - (double)div_exact(AW[j], q_));
@@ -1134,8 +1140,13 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
             pa += 256;
             if (pa >= deg) break;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { AI[j] = AIn[j]; AC[j] = ACn[j]; AW[j] = AWn[j]; }
-            load_a(pa + 256, AIn, ACn, AWn);
+            for (int j = 0; j < 4; ++j) { AI[j] = NI[0][j]; AC[j] = NC[0][j]; AW[j] = NW[0][j]; }
+#pragma unroll
+            for (int sgi = 0; sgi + 1 < PF; ++sgi) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { NI[sgi][j] = NI[sgi + 1][j]; NC[sgi][j] = NC[sgi + 1][j]; NW[sgi][j] = NW[sgi + 1][j]; }
+            }
+            load_a(pa + 256 * PF, NI[PF - 1], NC[PF - 1], NW[PF - 1]);
           } else {
             handled = bmax; have_handled = true;
             pb += HCHUNK;

@@ -134,6 +134,7 @@ struct GraphView {
   // rev[e] holds on a whole-graph handle (val = count << 24 | index in curr's sorted row, pad = input-order position of the first one)
   const PairSlot *rh;
   uint32_t rh_buckets;
+  int32_t dbg_chain_deg;   // tests (SRW_DEBUG_CHAIN_DEG): sharded steps on rows at least this long are treated as draws on a CDF boundary (0: off)
 };
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;
 constexpr int32_t BF_MIN_DEG = 1025;

@@ -791,6 +791,7 @@ __device__ inline int32_t wave_pick_returns(const GraphView &g, const Row &rc, c
   cs = wave_sum_f64(cs);                                  // exact under the certificate, in any order
   const double S0 = PQ[deg - 1], S = S0 + cs;
   if (!(S > 0.0) || !(S0 > 0.0)) return -1;
+  if (!CHAIN && S_out && g.dbg_chain_deg && deg >= g.dbg_chain_deg) { *S_out = S; return CHAIN_NEEDED; }
   const double pS = (double)r * S;
   auto not_miss = [&](int32_t kk, double num) { return !(num * (1.0 + (double)(kk + 8) * 0x1p-51) < pS); };
   // 1. the first return edge that is not a certain miss
@@ -1230,6 +1231,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   if (!ABS) { pq_last = PQ[deg - 1]; pq_j = PQ[chunk_end(j1)]; }
   const double S = pq_last + b_last;
   if (!(S > 0.0)) return -1;
+  if (!CHAIN && S_out && g.dbg_chain_deg && deg >= g.dbg_chain_deg) { *S_out = S; return CHAIN_NEEDED; }   // tests: the chain kernels on every long row
   const double p = (double)r;
   // Certified compares without a divide.  The reference's acc_k = sum of fl(w'_i / S) differs from num / S (num exact)
   // by at most (k + 2) u num / S.  With t = (k + 8) 2^-51 = 4 (k + 8) u:

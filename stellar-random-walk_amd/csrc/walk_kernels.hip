@@ -466,6 +466,7 @@ __device__ inline int q1_pick(const GraphView &g, const Row &r, const CfoEnt *cr
     }
     const bool usable = S > 0.0 && S0 > 0.0;
     if (!usable) return 1;
+    else if (S_out && g.dbg_chain_deg && r.deg >= g.dbg_chain_deg) { *S_out = S; return 2; }
     else {
       // first k that is not a certain miss (A' is non-decreasing, the tolerance grows with k: monotone) — a few
       // steps from the guide's start, else (saturated guide entry, many parallel return edges) by bisection
@@ -2536,6 +2537,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     build_shard_rev_hash(h);
     q1 = true;
   }
+  { const char *e = getenv("SRW_DEBUG_CHAIN_DEG"); g.dbg_chain_deg = e && *e ? atoi(e) : 0; }
   const ShardIO io = make_io(h, batch, lay, d_recv, d_lens);
   ShardDst sd;
   for (int d = 0; d < SHARD_MAX_WORLD; ++d) sd.p[d] = d < world ? (char *)dst[d] : nullptr;

@@ -162,3 +162,56 @@ def test_shard_q1_per_lane_step(oracle, monkeypatch, world, directed, membership
         rp, rl, rs = g.walk(p=0.5, q=1.0, walk_length=5, rng="const", const_r=0.5, threads=8)      # constant r: the general step
         paths, lens, st = cl.walk(p=0.5, q=1.0, walk_length=5, rng="const", const_r=0.5)
         assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["strategy_steps"]["q1_lane"] == 0
+
+
+@pytest.mark.parametrize("world,kind", [(1, 0), (3, 1), (2, 2), (1, 3)])
+def test_shard_chain_kernels_long_rows(oracle, monkeypatch, world, kind):
+    """k_chain_d / k_chain_scan / k_chain_u / k_chain_seq on LONG rows: a directed hub of 2^15 (or 40 000) out-edges reached from a few
+    sources, constant r so that every table step at the hub sits on a CDF boundary (unit weights, power-of-two weights: rounding ties in
+    every binade, integers, a wide dynamic range) — the chain's units as integer increments, binade crossings, the answer's unit —
+    against the oracle's plain left-to-right loop."""
+    rng = np.random.default_rng(40 + kind)
+    n = 1 << 15 if kind < 2 else 40000
+    hub, t0, s0, n_src = 0, 1, n + 1, 48
+    if kind == 0:
+        hw = np.ones(n, dtype=np.float32)
+    elif kind == 1:
+        hw = np.float32(2.0) ** rng.integers(-6, 6, n).astype(np.float32)
+    elif kind == 2:
+        hw = rng.integers(1, 1000, n).astype(np.float32)
+    else:
+        hw = np.exp(rng.random(n) * 16.0 - 8.0).astype(np.float32)
+    src = [np.full(n, hub)]; dst = [np.arange(t0, t0 + n)]; w = [hw]
+    tt = np.arange(t0, t0 + n)
+    src.append(tt); dst.append(np.where(tt + 1 < t0 + n, tt + 1, t0)); w.append(np.ones(n, dtype=np.float32))          # the targets' ring
+    back = tt[::97]
+    src.append(back); dst.append(s0 + (np.arange(len(back)) % n_src)); w.append(np.full(len(back), 2.0, dtype=np.float32))   # some lead to a source
+    src.append(back[::3]); dst.append(np.full(len(back[::3]), hub)); w.append(np.full(len(back[::3]), 0.5, dtype=np.float32))   # and to the hub (members of N(prev))
+    ss = np.arange(s0, s0 + n_src)
+    src.append(ss); dst.append(np.full(n_src, hub)); w.append(np.full(n_src, 3.0, dtype=np.float32))
+    src.append(ss); dst.append(np.where(ss + 1 < s0 + n_src, ss + 1, s0)); w.append(np.ones(n_src, dtype=np.float32))
+    src.append(ss); dst.append(t0 + (np.arange(n_src) * 131) % n); w.append(np.ones(n_src, dtype=np.float32))                # members: a source's targets
+    s, d, w = (np.concatenate(x) for x in (src, dst, w))
+    s, d, w = s.astype(np.int32), d.astype(np.int32), w.astype(np.float32)
+    g = oracle.Graph.from_coo(s, d, w, directed=True)
+    with pkg().Cluster([0] * world) as cl:
+        cl.load_coo(s, d, w, directed=True)
+        for r in (0.5, 0.25, 0.75):
+            rp, rl, rs = g.walk(p=0.5, q=2.0, walk_length=6, rng="const", const_r=r, threads=8)
+            paths, lens, st = cl.walk(p=0.5, q=2.0, walk_length=6, rng="const", const_r=r)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (world, kind, r)
+            assert st["n_steps"] == rs
+            if kind == 0:
+                assert st["strategy_steps"]["chain"] > 0, st            # ties at the hub went through the chain kernels
+        # Philox draws, and every sharded step on a row of >= 1000 candidates treated as a draw on a boundary (the debug switch of
+        # run_shard_superstep): the chain kernels over arbitrary quotients, q != 1 (table steps) and q == 1 (per-lane steps)
+        for q in (2.0, 1.0):
+            rp, rl, rs = g.walk(p=0.5, q=q, walk_length=6, seed=5, threads=8)
+            monkeypatch.delenv("SRW_DEBUG_CHAIN_DEG", raising=False)
+            paths, lens, st = cl.walk(p=0.5, q=q, walk_length=6, seed=5)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (world, kind, q, "philox")
+            monkeypatch.setenv("SRW_DEBUG_CHAIN_DEG", "1000")
+            paths, lens, st = cl.walk(p=0.5, q=q, walk_length=6, seed=5)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (world, kind, q, "philox, forced chain")
+            assert st["strategy_steps"]["chain"] > 0, st
+            monkeypatch.delenv("SRW_DEBUG_CHAIN_DEG")

@@ -258,8 +258,12 @@ __global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, ShardSel ss, EbS
 
 // pass 4: the tables.  One wave per pair: binned_fill exactly as a walk step over that pair would run it, then the
 // prefix at every table chunk end goes to HBM.
+// experiment switches (profiles/r03_eb_build.md: neither deeper prefetch nor wider lockstep searches move the build)
 #ifndef SRW_EB_PREFETCH
-#define SRW_EB_PREFETCH 2
+#define SRW_EB_PREFETCH 1
+#endif
+#ifndef SRW_EB_P1K
+#define SRW_EB_P1K 2
 #endif
 template <bool SH>
 __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
@@ -293,11 +297,32 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
       if (rv.deg <= mask_max) {                   // membership mask: 64 candidates per round, one probe each
         uint32_t *out = em_bits + (size_t)tab_word * 4;
         const int32_t n_words = ((((rv.deg + 31) >> 5) + 3) >> 2) << 2;
-        for (int32_t c0 = 0; c0 < n_words * 32; c0 += 64) {
-          const int32_t c = c0 + lane;
-          const bool in = c < rv.deg && eb_member(g, ru, it.x, (uint32_t)((int64_t)g.ent[rv.off + c].id - g.vmin));
-          const unsigned long long mm = __ballot(in);
-          if (lane == 0) { out[c0 >> 5] = (uint32_t)mm; if ((c0 >> 5) + 1 < n_words) out[(c0 >> 5) + 1] = (uint32_t)(mm >> 32); }
+        // (a row of at most 255 candidates: its four rounds of 64 in lockstep — the entries, then the probes, each one round trip)
+        uint32_t xs[4]; bool want[4], in[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int32_t c = r4 * 64 + lane;
+          want[r4] = c < rv.deg; in[r4] = false;
+          xs[r4] = want[r4] ? (uint32_t)((int64_t)g.ent[rv.off + c].id - g.vmin) : 0u;
+        }
+        const uint32_t hub = ru.flags >> ROW_HUB_SHIFT;
+        if (hub && g.hub_bm) {
+          uint32_t wd[4];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) wd[r4] = want[r4] ? g.hub_bm[(int64_t)(hub - 1) * g.hub_words + (xs[r4] >> 5)] : 0u;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) in[r4] = (wd[r4] >> (xs[r4] & 31)) & 1u;
+        } else if (g.ehash) {
+          edge_exists_n<4>(g.ehash, g.ehash_mask, it.x, xs, want, in);
+        } else {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) in[r4] = want[r4] && sorted_contains(g.msids + ru.off, ru.deg, xs[r4]);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int32_t c0 = r4 * 64;
+          const unsigned long long mm = __ballot(in[r4]);            // (every lane votes: outside the bounds check)
+          if (c0 < n_words * 32 && lane == 0) { out[c0 >> 5] = (uint32_t)mm; if ((c0 >> 5) + 1 < n_words) out[(c0 >> 5) + 1] = (uint32_t)(mm >> 32); }
         }
         ns[0] += 1;
 #ifdef SRW_PHASE_TIMING
@@ -312,7 +337,7 @@ __global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *_
       const BinGeom gc = bin_geometry(rv.deg, min_sh, bins_cap);
       const BinGeom gf = gc.csh < 6 ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
       unsigned long long ab = 0; unsigned su = 0;
-      binned_fill<SRW_EB_PREFETCH>(g, rv, b, mine, fill_tune, gf, tm, ab, su);
+      binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K>(g, rv, b, mine, fill_tune, gf, tm, ab, su);
       ns[su & 7] += 1;
 #ifdef SRW_PHASE_TIMING
       const unsigned long long t_fill = wall_clock64();

@@ -952,9 +952,9 @@ __host__ __device__ inline BinnedCost binned_cost(int32_t deg, int32_t m, bool h
 // Fills the wave's LDS bins with the EXACT inclusive prefix, by chunk, of the corrections of the specials of this
 // (prev, curr) pair: bins[j] = sum over positions k < ((j + 1) << csh) of (w'_k - fl(w_k / q)).
 // tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W, 4 = P3 if prev has a bitmap (tests force each one)
-// PF: rounds of candidates the sorted-chunk intersection keeps in flight ahead of the one it works on (12 VGPRs each; the table
-// build runs it with 2 — 72 % of a round was the wait for the next round's loads, profiles/r03_eb_build.md)
-template <int PF = 1>
+// PF: rounds of candidates the sorted-chunk intersection keeps in flight ahead of the one it works on (12 VGPRs each); P1K: binary
+// searches per lane in lockstep in P1.  Both are experiment parameters: 2 / 8 did not move the table build (profiles/r03_eb_build.md)
+template <int PF = 1, int P1K = 2>
 __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias &b, uint32_t *lds, int tune,
                                    const BinGeom geo, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used) {
   const int32_t deg = rc.deg;
@@ -981,7 +981,8 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
   if (m > 0 && (strat == 0 || strat == 3)) {
     lo_id = max(cs[0], B[0]); hi_id = min(cs[deg - 1], B[m - 1]);
     if (strat == 0) {
-      const BinnedCost bc = binned_cost(deg, m, hubbits != nullptr, g.ehash != nullptr);
+      BinnedCost bc = binned_cost(deg, m, hubbits != nullptr, g.ehash != nullptr);
+      if (P1K > 2) bc.c1 = bc.c1 * 4 / P1K;                      // the searches with P1K (not two) in lockstep; measured flat between 2 / P1K and 4 / P1K
       strat = (bc.cw < bc.c1 && bc.cw < bc.c2) ? 3 : (bc.c1 <= bc.c2 ? 1 : (hubbits ? 4 : 2));
     }
   }
@@ -1027,24 +1028,32 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
     else if (strat == 2) alg_bytes += 16ull * (unsigned long long)deg;                                            // entries + hash slots
     else alg_bytes += 12ull * (unsigned long long)(deg - pa) + 4ull * (unsigned long long)(m - pb);              // both sorted rows
     if (strat == 1) {
-      // two searches per lane in lockstep: twice the loads in flight on the dependent probe chain
-      for (int32_t t0 = lane; t0 < m; t0 += 128) {
-        int32_t tt[2] = {t0, t0 + 64};
-        uint32_t x[2]; bool act[2]; int32_t lo[2], hi[2];
+      // P1K searches per lane in lockstep: P1K loads in flight on the dependent probe chain
+      for (int32_t t0 = lane; t0 < m; t0 += 64 * P1K) {
+        uint32_t x[P1K]; bool act[P1K]; int32_t lo[P1K], hi[P1K];
+        bool any = false;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          act[i] = tt[i] < m;
-          x[i] = act[i] ? B[tt[i]] : 0u;
-          if (act[i] && (x[i] == xprev || (tt[i] > 0 && B[tt[i] - 1] == x[i]))) act[i] = false;
+        for (int i = 0; i < P1K; ++i) {
+          const int32_t tt = t0 + 64 * i;
+          act[i] = tt < m;
+          x[i] = act[i] ? B[tt] : 0u;
+          if (act[i] && (x[i] == xprev || (tt > 0 && B[tt - 1] == x[i]))) act[i] = false;
           lo[i] = 0; hi[i] = act[i] ? deg : 0;
+          any |= act[i];
         }
-        while (lo[0] < hi[0] || lo[1] < hi[1]) {
+        while (any) {
+          uint32_t v[P1K]; int32_t mid[P1K];
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            if (lo[i] < hi[i]) { const int32_t mid = lo[i] + ((hi[i] - lo[i]) >> 1); if (cs[mid] < x[i]) lo[i] = mid + 1; else hi[i] = mid; }
+          for (int i = 0; i < P1K; ++i) { mid[i] = lo[i] + ((hi[i] - lo[i]) >> 1); v[i] = lo[i] < hi[i] ? cs[mid[i]] : 0u; }
+          any = false;
+#pragma unroll
+          for (int i = 0; i < P1K; ++i) {
+            if (lo[i] < hi[i]) { if (v[i] < x[i]) lo[i] = mid[i] + 1; else hi[i] = mid[i]; }
+            any |= lo[i] < hi[i];
+          }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < P1K; ++i)
           if (act[i])
             for (int32_t c = lo[i]; c < deg && cs[c] == x[i]; ++c) {
               const uint32_t orig = cp[c];

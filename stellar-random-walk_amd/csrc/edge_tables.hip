@@ -405,6 +405,15 @@ size_t env_gb(const char *name, size_t dflt_gb) {
 
 }  // namespace
 
+// smallest chunk of a table: 2^8 = 256 candidates (one round of the located chunk's evaluation); SRW_EB_MIN_SH: experiments
+// The callers try 6 and 7 once the number of chunks is chosen and keep the finest whose complete set still fits (Graph::eb_min_sh_sel):
+// the located chunk is what a table step streams and probes, and the rows of 256 .. 16 384 candidates — half of all steps at config 3 —
+// have fewer than 64 chunks of 256 (config 3: 256 / 128 / 64 candidates 5.1 / 5.8 / 6.8e8 steps/s, 77 / 111 / 138 GB, s52).
+static int eb_min_shift(const Graph &g) {
+  const char *e = getenv("SRW_EB_MIN_SH");
+  const int v = e && *e ? atoi(e) : g.eb_min_sh_sel;
+  return v < 2 ? 2 : v > 12 ? 12 : v;
+}
 // HBM a COMPLETE set of tables would take (every pair into a certified row + every mask + offsets + the work list):
 // prepare_tables sizes the hub bitmaps with what is left beside it.  0: no tables possible.
 size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
@@ -413,7 +422,7 @@ size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
   hipStream_t st = h->stream;
   EbSel sel;
   sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
-  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : 8; sel.min_cost = 0;
+  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : eb_min_shift(g); sel.min_cost = 0;
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
   { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
   sel.has_ehash = 1; sel.has_hub = 1;               // (they only move priorities, not sizes)
@@ -449,7 +458,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   EbSel sel;
   // mode 1 (tests): bins tables for every certified row, chunks of 4 candidates, no masks
   sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
-  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : 8;
+  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : eb_min_shift(g);
   { const char *e = getenv("SRW_EB_MIN_COST"); sel.min_cost = (!mode && e && *e) ? atoll(e) : 0; }
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
   { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
@@ -564,10 +573,10 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
 namespace {
 struct ShardTabPlan { unsigned long long units, pairs, munits, mpairs, inl; size_t bytes; uint32_t buckets; };
 
-EbSel shard_sel(int mode, int bins_cap) {
+EbSel shard_sel(const Graph &g, int mode, int bins_cap) {
   EbSel sel;
   sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
-  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : 8; sel.min_cost = 0;
+  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : eb_min_shift(g); sel.min_cost = 0;
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
   { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
   sel.has_ehash = 0; sel.has_hub = 1; sel.bins_cap = bins_cap;
@@ -681,15 +690,30 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
   const size_t reserve = env_gb("SRW_EB_RESERVE_GB", 16);
   const char *env_cap = getenv("SRW_EB_CHUNKS");
   ShardTabPlan pl; EbSel sel; int cap_sel = 0;
+  g.eb_min_sh_sel = 8;
   for (int cap : {256, 128, 64, 32}) {
     if (env_cap && *env_cap) cap = std::min(std::max(atoi(env_cap), 8), BIN_CAP);
-    sel = shard_sel(mode, cap);
+    sel = shard_sel(g, mode, cap);
     if (shard_plan(h, sel, pl) && pl.bytes + reserve < free_b && pl.bytes < env_gb("SRW_EB_BUDGET_GB", 200)) { cap_sel = cap; break; }
     if (env_cap && *env_cap) break;
   }
   if (!cap_sel) {
     if (getenv("SRW_TIMING")) fprintf(stderr, "[shard %d/%d edge tables] no complete set fits: on-the-fly samplers\n", h->cfg.rank, h->cfg.world);
     return;
+  }
+  // ... and, at that number of chunks, the smallest chunks (64, then 128 candidates instead of 256) whose set still leaves the
+  // edge hash and 16 GB of hub bitmaps their room
+  if (!mode && !getenv("SRW_EB_MIN_SH")) {
+    uint64_t ehs = 1024;
+    while (ehs < (uint64_t)g.n_entries_global + (uint64_t)g.n_entries_global / 2) ehs <<= 1;
+    const size_t room = reserve + (g.has_ehash ? 0 : (size_t)ehs * 8) + ((size_t)24 << 30);
+    for (int sh : {6, 7}) {
+      g.eb_min_sh_sel = sh;
+      const EbSel s2 = shard_sel(g, mode, cap_sel);
+      ShardTabPlan p2;
+      if (shard_plan(h, s2, p2) && p2.bytes * (size_t)std::max(1, h->dev_share) + room < free_b && p2.bytes < env_gb("SRW_EB_BUDGET_GB", 200)) { sel = s2; pl = p2; break; }   // (virtual shards of one device share its HBM)
+      g.eb_min_sh_sel = 8;
+    }
   }
   // 2. the located chunk's probes of a long N(prev), with what the tables leave (a shard of a sharded graph has room: its
   //    tables are 1 / world of the set): the edge hash set of the whole graph (one probe per candidate) or, when it does not
@@ -718,7 +742,7 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
       (void)hipGetLastError();
       g.eb_bins.release(); g.em_bits.release(); g.ph.release(); g.ph_buckets = 0; g.has_eb = false;
       if (attempt || cap_sel <= 32) break;
-      cap_sel = 32; sel = shard_sel(mode, 32);
+      cap_sel = 32; g.eb_min_sh_sel = 8; sel = shard_sel(g, mode, 32);
       if (!shard_plan(h, sel, pl)) break;
     }
   }

@@ -113,6 +113,7 @@ struct Graph {
   bool eb_sharded = false;        // the standing per-edge tables are keyed by the pair hash (built by build_shard_edge_tables)
   DevBuf<PairSlot> rh;            // sharded q == 1 walks: return edges of the pairs into this shard's rows (build_shard_rev_hash)
   uint32_t rh_buckets = 0; bool has_rh = false;
+  int32_t eb_min_sh_sel = 8;      // log2 of the smallest table chunk the next table build uses (prepare_tables / prepare_shard_tables choose it)
   int32_t dbg_chain_deg = 0;      // SRW_DEBUG_CHAIN_DEG (read by run_shard_superstep)
   bool has_cfo_local = false;     // sharded: compact first-order records over the LOCAL rows (guide + ids; their links are not used)
   DevBuf<uint32_t> bf_off, bf_bits; // neighbor-set filters of the rows beyond 1024 neighbors (GraphView::bf_off), built with the per-edge tables

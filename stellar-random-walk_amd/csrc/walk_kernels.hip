@@ -2080,6 +2080,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
       if (g.has_ehash) free_b += g.ehash.n * sizeof(uint64_t);     // free_b: with neither hash nor tables nor bitmaps
       size_t reserve = (size_t)24 << 30;
       if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
+      g.eb_min_sh_sel = 8;                                          // (sized with chunks of 256; refined below once the chunk count is known)
       const size_t n64 = edge_tables_full_bytes(h, eb_mode, EB_BINS);
       // what build_edge_tables will have: free - bitmaps (16 GB when the tables are tight) - reserve; 2 GB of margin
       const size_t slack = reserve + (want_hub ? (size_t)16 << 30 : 0) + ((size_t)2 << 30);
@@ -2130,6 +2131,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
       if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
       const size_t table_cap = (size_t)(drop_ehash ? 200 : 160) << 30;   // build_edge_tables' own ceiling (Graph::eb_budget_gb)
       size_t need = 0;
+      g.eb_min_sh_sel = 8;
       if (!(env_cap && *env_cap)) {
         for (int c : {256, 128}) {
           const size_t n = edge_tables_full_bytes(h, eb_mode, c);
@@ -2144,6 +2146,17 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
         if (!(env_cap && *env_cap) && need > 0 && (need >= table_cap || free_b < need + reserve + ((size_t)8 << 30))) {
           const size_t n = edge_tables_full_bytes(h, eb_mode, 32);
           if (n > 0 && n < table_cap && free_b > n + reserve + ((size_t)8 << 30)) { eb_cap = 32; need = n; }
+        }
+      }
+      // The smallest chunk: 256 candidates (one round of the located chunk's evaluation), or 128 / 64 when the complete set at the
+      // chosen number of chunks still fits next to 40 GB of bitmaps and margin — the rows of 256 .. 16 384 candidates, half of the
+      // steps at config 3, have fewer than 64 chunks of 256 (edge_tables.hip:eb_min_shift)
+      if (need > 0 && !eb_mode && !getenv("SRW_EB_MIN_SH")) {
+        for (int sh : {6, 7}) {
+          g.eb_min_sh_sel = sh;
+          const size_t n = edge_tables_full_bytes(h, eb_mode, eb_cap);
+          if (n > 0 && n < table_cap && free_b > n + reserve + ((size_t)40 << 30)) { need = n; break; }
+          g.eb_min_sh_sel = 8;
         }
       }
       const size_t keep = need + reserve + ((size_t)8 << 30);
@@ -2166,7 +2179,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
         (void)hipGetLastError();
         Graph &g = h->g;
         g.eb_bins.release(); g.em_bits.release(); g.has_eb = false; g.eb_complete = false; g.eb_tables = 0; g.eb_bytes = 0;
-        h->g.eb_budget_gb = 160;
+        h->g.eb_budget_gb = 160; g.eb_min_sh_sel = 8;
         if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] per-edge tables: %s — %s\n", e.what(), attempt == 0 && eb_cap > 32 ? "retrying with 32 chunks" : "walking without them");
         if (eb_cap <= 32) break;
       }

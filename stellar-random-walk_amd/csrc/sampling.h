@@ -1210,7 +1210,9 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
 // of a 256-candidate chunk is only read when the answer is not in the first — the kernel is bound by memory requests as
 // much as by latency, profiles/r02c_general_kernel_c3.md)
 #ifndef SRW_RESOLVE_PER_LANE
-#define SRW_RESOLVE_PER_LANE 2   // measured at config 3: 2 -> 182 M steps/s, 4 -> 169 M, 1 -> 168 M (request-bound vs latency-bound)
+// round 2 (one monolithic kernel, 4 waves/SIMD), config 3: 2 -> 182 M steps/s, 4 -> 169 M, 1 -> 168 M.  Round 3 (lean table kernel at 6-7
+// waves/SIMD, chunks of 64 where they fit): 1 -> 7.05e8 against 6.72e8 at config 3, 3.61e8 against 3.46e8 at config 5's stand-in (s57, s58)
+#define SRW_RESOLVE_PER_LANE 1
 #endif
 template <bool ABS, bool BF = false, bool CHAIN = true>
 __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, const Bias &b, const double *bins,

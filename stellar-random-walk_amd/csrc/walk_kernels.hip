@@ -273,12 +273,14 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
 // `todo`; k_walk_general redoes it from its first step: the keyed RNG makes that the same path).
 // Waves per SIMD of the lean table kernels.  Round 2 (the exact chain still inlined): 4 waves/SIMD 221 M steps/s at config 3, 5
 // 239 M, 6 235 M.  Round 3, with the chain out of these kernels (s25): config 3 (edge hash: request-bound) 5 -> 478 M, 6 -> 520 M,
-// 7 -> 433 M; config 5's stand-in (row filters, no hash: latency-bound) 5 -> 290 M, 6 -> 326 M, 7 -> 348 M.  So by instantiation:
+// 7 -> 433 M; config 5's stand-in (row filters, no hash: latency-bound) 5 -> 290 M, 6 -> 326 M, 7 -> 348 M.  With one candidate per
+// lane and round of the located chunk (SRW_RESOLVE_PER_LANE 1: fewer registers) and chunks of 64 (s59, A / B / C twice on one box):
+// config 3 6 -> 705-719 M, 7 -> 771 M, 8 -> 690 M; config 5's stand-in 7 -> 363 M, 8 -> 387 M.  So by instantiation:
 #ifndef SRW_LEAN_WAVES
-#define SRW_LEAN_WAVES 6
+#define SRW_LEAN_WAVES 7
 #endif
 #ifndef SRW_LEAN_WAVES_BF
-#define SRW_LEAN_WAVES_BF 7
+#define SRW_LEAN_WAVES_BF 8
 #endif
 __device__ inline Row uniform_row(Row r) {            // the row descriptor of a wave's walker is wave-uniform: keep it in SGPRs
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r.off), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)r.off >> 32));

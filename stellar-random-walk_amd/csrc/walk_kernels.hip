@@ -22,6 +22,22 @@
 
 namespace srw {
 namespace {
+// Records shared by the whole-graph kernels and the vertex-sharded ones (described with the k_sh_* kernels below).
+struct alignas(16) WWalker { int32_t lw, src, prev, curr; };      // on the wire: 16 bytes
+struct alignas(16) SWalker { int32_t lw, src, prev, curr, v, kind, pad0, pad1; };   // pad0: position of the chosen candidate (chain kernels)
+enum : int32_t { SK_WALKER_RET = 1, SK_RET = 2, SK_DEAD = 3 };   // walker + return; return only (last step); death notice only
+constexpr int CHAIN_CAP = 1024;     // draws on a CDF boundary per super-step / per launch that the chain kernels take (more: the general step)
+struct alignas(16) ChainRec { uint32_t ri, pad; double S; };      // record index, (whole-graph walks: the step), the reference's sum of the biased row
+// Whole-graph walks: where k_walk_tables leaves a table step whose draw sits on a CDF boundary — one wire record per tie (lw = the
+// iteration's offset) behind a chunk header, so that the chain kernels of the sharded walk read them like a super-step's input;
+// k_walk_general, which redoes the handed-over walkers, takes the resolved step from the chain kernels' output.
+struct TieSink {
+  uint32_t *hdr;                  // [0] records written (the chunk header the chain kernels read)
+  WWalker *recs;                  // [CHAIN_CAP]
+  ChainRec *list;                 // [CHAIN_CAP]
+  unsigned long long *cur;        // [2] ties met
+  int32_t *todo_tie;              // per todo entry: its record, or -1
+};
 
 constexpr int TPB = 256;
 constexpr int TILE = 16;  // path slots staged in LDS between flushes (64 B per walker per flush)
@@ -147,7 +163,9 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
                                                       int32_t first_walk, RngSpec rng, float p, float q,
                                                       int32_t *__restrict__ paths, int32_t *__restrict__ lens,
                                                       DevCounters *ctr, unsigned long long *cursor, int32_t tune,
-                                                      const int32_t *__restrict__ todo, const unsigned long long *todo_n) {
+                                                      const int32_t *__restrict__ todo, const unsigned long long *todo_n,
+                                                      const int32_t *__restrict__ todo_tie, const ChainRec *__restrict__ tie_list,
+                                                      const SWalker *__restrict__ tie_out) {
   __shared__ __attribute__((aligned(16))) uint32_t bitmap[TPB / 64][BINNED_LDS_WORDS];
   const int lane = lane_id();
   Member mem; mem.mode = 0; mem.bm = bitmap[threadIdx.x >> 6]; mem.seg_base = 0;
@@ -165,8 +183,16 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
     if (lane == 0) grab = atomicAdd(cursor, 1ull);
     int64_t wi = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab));
+    int32_t tie_s = -1, tie_k = 0, tie_next = 0;     // the walker's step the chain kernels resolved (k_walk_tables' tie), if any
     if (todo) {                                      // only the walkers k_walk_tables handed over
       if (wi >= (int64_t)*todo_n) break;
+      if (todo_tie) {
+        const int32_t ci = todo_tie[wi];
+        if (ci >= 0) {
+          const SWalker o = tie_out[ci];
+          if (o.kind == SK_WALKER_RET || o.kind == SK_RET) { tie_s = (int32_t)tie_list[ci].pad; tie_k = o.pad0; tie_next = o.curr; }
+        }
+      }
       wi = todo[wi];
     } else if (wi >= n_walkers) break;
     int64_t it = wi / n_verts, vi = wi - it * n_verts;
@@ -201,7 +227,8 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
       int32_t k = -1, next = 0;
       bool binned_served = false, have_next = false;
       unsigned which = SRW_STRAT_SCAN;
-      if (want_tab) {
+      if (s == tie_s) { k = tie_k; next = tie_next; have_next = true; binned_served = true; which = SRW_STRAT_EDGE_TABLE; f = 1; n_strat[11] += 1; }
+      else if (want_tab) {
         if (r.deg <= g.eb_mask_max) {
           // membership mask of the pair (inline for rows up to 32 candidates): no lookup, the row sits in registers
           if (r.deg <= 32 || eo != EB_NONE) {
@@ -293,7 +320,7 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
                                                      int64_t n_walkers, int32_t L, int32_t first_walk, RngSpec rng, float p,
                                                      float q, int32_t *__restrict__ paths, int32_t *__restrict__ lens,
                                                      DevCounters *ctr, unsigned long long *cursor, int32_t *__restrict__ todo,
-                                                     unsigned long long *todo_n) {
+                                                     unsigned long long *todo_n, TieSink tie) {
   __shared__ __attribute__((aligned(16))) uint32_t stage_all[TPB / 64][1024];
   const int lane = lane_id();
   uint32_t *stage = stage_all[threadIdx.x >> 6];
@@ -318,6 +345,7 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
     int64_t eprev = 0;
     uint32_t w_fb = 0, w_dead = 0, w_fast = 0, w_srch = 0, w_tab = 0, w_mask = 0;    // (a handed-over walker is not counted here)
     bool handed_over = false;
+    int32_t tie_rec = -1;
     for (int32_t s = 1; s <= L + 1; ++s) {
       const bool second = s > 1;
       const int64_t cslot = (int64_t)curr - g.vmin;
@@ -346,8 +374,20 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
           w_mask += 1; w_srch += 8u * (uint32_t)r.deg + 4u * (uint32_t)((r.deg + 31) >> 5);
           SRW_T1(mem, t_a);
         } else if (r.deg > g.eb_mask_max && eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
-          k = wave_pick_edge_table<BF, false>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage);
+          double S_tie = 0.0;
+          k = wave_pick_edge_table<BF, false>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie);
           if (k >= 0) { w_tab += 1; w_srch += 8u * EB_BINS; w_fast += sv; }
+          else if (k == CHAIN_NEEDED && tie.list) {      // a tie on a table step: its exact chain by the chain kernels (the whole GPU)
+            if (lane == 0) {
+              const unsigned long long c = atomicAdd(tie.cur, 1ull);
+              if (c < (unsigned long long)CHAIN_CAP) {
+                tie_rec = (int32_t)c;
+                WWalker wr; wr.lw = (int32_t)it; wr.src = src; wr.prev = prev; wr.curr = curr; tie.recs[c] = wr;
+                ChainRec cr; cr.ri = (uint32_t)c; cr.pad = (uint32_t)s; cr.S = S_tie; tie.list[c] = cr;
+                atomicAdd(tie.hdr, 1u);
+              }
+            }
+          }
           SRW_T1(mem, t_p1);
 #ifdef SRW_PHASE_TIMING
           if (rprev.deg > 1024) mem.t_p2 += wall_clock64() - mem.t_mark;      // ... of which steps with a long N(prev)
@@ -361,7 +401,12 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       prev = curr; curr = next; ++len; rprev = r; eprev = r.off + k;
     }
     if (handed_over) {
-      if (lane == 0) { todo[atomicAdd(todo_n, 1ull)] = (int32_t)wi; atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], 1ull); }
+      if (lane == 0) {
+        const unsigned long long t = atomicAdd(todo_n, 1ull);
+        todo[t] = (int32_t)wi;
+        if (tie.todo_tie) tie.todo_tie[t] = tie_rec;
+        atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], 1ull);
+      }
       continue;
     }
     for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
@@ -810,12 +855,9 @@ __global__ __launch_bounds__(TPB, 6) void k_walk_alias(GraphView g, const int32_
 // The general kernel keeps one wave per record and the same samplers as k_walk_general (bit-identical paths for any
 // world, asserted against the oracle).
 constexpr int SHARD_MAX_WORLD = 64;
-struct alignas(16) WWalker { int32_t lw, src, prev, curr; };      // on the wire: 16 bytes
 struct alignas(8) WRet { int32_t lw, v; };                         // on the wire: 8 bytes; lw top bit: death notice
 // a record between the sampling kernel and the bucketing kernel (scratch, never on the wire): the forwarded walker
 // (prev, curr), the vertex that goes home (v) and what to emit (kind)
-struct alignas(16) SWalker { int32_t lw, src, prev, curr, v, kind, pad0, pad1; };
-enum : int32_t { SK_WALKER_RET = 1, SK_RET = 2, SK_DEAD = 3 };   // walker + return; return only (last step); death notice only
 constexpr int64_t SW_BYTES = 16, PR_BYTES = 8;
 struct ShardIO {
   const char *recv;        // world chunks, one per sender
@@ -1338,8 +1380,6 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
 // rows, test configurations) go to the todo list: k_sh_step redoes exactly those with the on-the-fly samplers.  The sampled
 // records land in `scratch` in input order; k_sh_scatter buckets them.
 constexpr int SH_GRAB = 16;         // records per cursor grab (a single counter word saturates at ~88 atomics/us)
-constexpr int CHAIN_CAP = 1024;     // draws on a CDF boundary per super-step that the chain kernels take (more: the general step)
-struct alignas(16) ChainRec { uint32_t ri, pad; double S; };                     // record index in the receive buffer, the reference's sum of the biased row
 struct alignas(16) ChainMeta { long long d_off; int32_t deg; uint32_t u_off; };   // first quotient in the scratch array, row length, first work unit
 struct ChainUnits { double *usum; int32_t *ue; unsigned long long *utot; };       // per unit of 256 quotients: plain sum, guessed binade, integer increment
 template <bool BF>
@@ -1556,24 +1596,35 @@ __global__ __launch_bounds__(TPB) void k_sh_step_q1w(GraphView g, ShardIO io, in
 //   k_chain_seq    one wave per record: the chain over the stored quotients, 1024 per round (chain_round_fast: one integer
 //                  sum per round while no rounding tie / binade crossing / answer is in it), next round prefetched
 // ~3 000 ties per iteration at config 3's size, each up to a million candidates long: one wave alone took 10-40 ms for one.
+// pass_cur (whole-graph walks: ALL ties of a launch are listed at once — several GB of quotients at config 3): the records are taken
+// in several passes of the chain kernels, each one as many as fit the scratch array; *pass_cur = the first record not taken yet.
 __global__ void k_chain_setup(GraphView g, ShardIO io, const ChainRec *__restrict__ list, unsigned long long *cursor /* [1] todo_n, [2] chain_n */,
                               ChainMeta *__restrict__ meta, uint32_t *__restrict__ totals /* [0] work units, [1] records */, long long d_cap,
-                              uint32_t *__restrict__ todo) {
+                              uint32_t *__restrict__ todo, unsigned long long *pass_cur) {
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
   shard_in_prefix(io, pre);
   if (threadIdx.x != 0) return;
   const unsigned long long n_all = cursor[2];
   const uint32_t n = (uint32_t)(n_all < (unsigned long long)CHAIN_CAP ? n_all : (unsigned long long)CHAIN_CAP);
+  const uint32_t start = pass_cur ? (uint32_t)(*pass_cur < (unsigned long long)n ? *pass_cur : (unsigned long long)n) : 0u;
+  uint32_t next_start = start;
+  bool stopped = false;
   long long off = 0; uint32_t units = 0;
   for (uint32_t i = 0; i < n; ++i) {
-    const SWalker wk = shard_in_record(io, pre, list[i].ri);
-    const Row r = g.rows[(int64_t)wk.curr - g.vmin];
-    ChainMeta m; m.d_off = off; m.deg = r.deg; m.u_off = units;
-    if (off + (long long)r.deg > d_cap) { m.deg = 0; todo[atomicAdd(cursor + 1, 1ull)] = list[i].ri; }     // scratch full: the general step
-    else { off += (long long)((r.deg + 255) & ~255); units += (uint32_t)((r.deg + 255) >> 8); }
+    ChainMeta m; m.d_off = off; m.deg = 0; m.u_off = units;          // deg 0: not in this pass
+    if (i >= start && !stopped) {
+      const SWalker wk = shard_in_record(io, pre, list[i].ri);
+      const Row r = g.rows[(int64_t)wk.curr - g.vmin];
+      if (off + (long long)r.deg <= d_cap) {
+        m.deg = r.deg; off += (long long)((r.deg + 255) & ~255); units += (uint32_t)((r.deg + 255) >> 8); next_start = i + 1;
+      } else if (!pass_cur) todo[atomicAdd(cursor + 1, 1ull)] = list[i].ri;     // scratch full: the general step
+      else if (off == 0) next_start = i + 1;                                   // longer than the whole scratch array: stays unresolved
+      else stopped = true;                                                     // the next pass starts here
+    }
     meta[i] = m;
   }
   totals[0] = units; totals[1] = n;
+  if (pass_cur) *pass_cur = next_start;
 }
 __global__ __launch_bounds__(TPB) void k_chain_d(GraphView g, ShardIO io, float p, float q, const ChainRec *__restrict__ list,
                                                  const ChainMeta *__restrict__ meta, const uint32_t *__restrict__ totals, double *__restrict__ D,
@@ -1684,6 +1735,7 @@ __global__ __launch_bounds__(TPB) void k_chain_seq(GraphView g, ShardIO io, int3
   const SWalker wk = shard_record_uniform(io, pre, ri);
   const Row r = uniform_row(g.rows[(int64_t)wk.curr - g.vmin]);
   const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
+  if (list[i].pad) step = (int32_t)list[i].pad;           // whole-graph walks: every tie has its own step (TieSink)
   const double p = (double)draw_uniform(rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
   const double *d = D + m.d_off;
   const int32_t nu = (r.deg + 255) >> 8;
@@ -1728,9 +1780,13 @@ __global__ __launch_bounds__(TPB) void k_chain_seq(GraphView g, ShardIO io, int3
   if (k_hit < 0) k_hit = 0;                               // edges.head (:24)
   if (lane == 0) {
     const int32_t next = g.ent[r.off + k_hit].id;
-    scratch[ri] = shard_advance(wk, step, next, last != 0);
-    atomicAdd(&ctr->steps, 1ull); atomicAdd(&ctr->fallbacks, 1ull);
-    atomicAdd(&ctr->strat[SRW_STRAT_CHAIN], 1ull); atomicAdd(&ctr->strat[strat], 1ull);
+    SWalker nw = shard_advance(wk, step, next, last != 0);
+    nw.pad0 = k_hit;
+    scratch[ri] = nw;
+    if (strat >= 0) {                                     // (whole-graph walks: k_walk_general counts the step it takes from here)
+      atomicAdd(&ctr->steps, 1ull); atomicAdd(&ctr->fallbacks, 1ull);
+      atomicAdd(&ctr->strat[SRW_STRAT_CHAIN], 1ull); atomicAdd(&ctr->strat[strat], 1ull);
+    }
 #ifdef SRW_PHASE_TIMING
     atomicAdd(&ctr->dbg[20], (unsigned long long)n_slow); atomicAdd(&ctr->dbg[21], (unsigned long long)nu);
 #endif
@@ -1909,6 +1965,52 @@ void check_params(const srw_walk_params &P) {
 
 }  // namespace
 
+// Chain scratch of a handle: record list + meta + totals in one buffer, the quotients of up to d_cap candidates in another,
+// the per-unit summaries in a third; behind them the whole-graph walk's tie records (TieSink), their output and a cursor of their own.
+namespace {
+struct ChainBufs {
+  ChainRec *list; ChainMeta *meta; uint32_t *totals; double *D; ChainUnits cu; long long d_cap;
+  uint32_t *tie_hdr; WWalker *tie_recs; SWalker *tie_out; unsigned long long *tie_cur; uint32_t *tie_skip;
+};
+ChainBufs chain_bufs(srw_handle *h) {
+  static const long long d_cap = (long long)(getenv("SRW_CHAIN_SCRATCH_MB") ? atof(getenv("SRW_CHAIN_SCRATCH_MB")) : 512.0) * (1 << 20) / 8;
+  const size_t n_units = (size_t)(d_cap / 256) + CHAIN_CAP;
+  const size_t core = (size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)) + 64 + n_units * 24;
+  const size_t tie = 64 + (size_t)CHAIN_CAP * (sizeof(WWalker) + sizeof(SWalker) + 4) + 64;
+  h->chain_buf.ensure(core + tie);
+  h->chain_d.ensure((size_t)d_cap);
+  ChainBufs b;
+  char *base = h->chain_buf.p;
+  b.list = reinterpret_cast<ChainRec *>(base);
+  b.meta = reinterpret_cast<ChainMeta *>(base + (size_t)CHAIN_CAP * sizeof(ChainRec));
+  b.totals = reinterpret_cast<uint32_t *>(base + (size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)));
+  char *ub = base + (size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)) + 64;
+  b.cu.usum = reinterpret_cast<double *>(ub);
+  b.cu.utot = reinterpret_cast<unsigned long long *>(ub + n_units * 8);
+  b.cu.ue = reinterpret_cast<int32_t *>(ub + n_units * 16);
+  b.D = h->chain_d.p; b.d_cap = d_cap;
+  char *tb = base + ((core + 63) & ~(size_t)63);
+  b.tie_cur = reinterpret_cast<unsigned long long *>(tb);                    // [0..3]: the cursor array of k_chain_setup ([1] skipped, [2] listed)
+  b.tie_hdr = reinterpret_cast<uint32_t *>(tb + 32);                         // 16-byte chunk header, the records right behind it
+  b.tie_recs = reinterpret_cast<WWalker *>(tb + 48);
+  b.tie_out = reinterpret_cast<SWalker *>(tb + 48 + (size_t)CHAIN_CAP * sizeof(WWalker));
+  b.tie_skip = reinterpret_cast<uint32_t *>(tb + 48 + (size_t)CHAIN_CAP * (sizeof(WWalker) + sizeof(SWalker)));
+  return b;
+}
+// draws on a CDF boundary (listed by the step kernel at cursor[2]): quotients by the whole GPU, their units summarised, then one
+// short sequential pass per record; what does not fit goes onto the todo list `skipped` (count at cursor[1]) — the general step's
+void enqueue_chain(srw_handle *h, const ChainBufs &cb, const GraphView &gv, const ShardIO &io, const srw_walk_params &P, int32_t step, int32_t last,
+                   const RngSpec &rng, SWalker *scratch, int strat, unsigned long long *cursor, uint32_t *skipped, unsigned long long *pass_cur = nullptr) {
+  hipStream_t st = h->stream;
+  hipLaunchKernelGGL(k_chain_setup, dim3(1), dim3(64), 0, st, gv, io, cb.list, cursor, cb.meta, cb.totals, cb.d_cap, skipped, pass_cur);
+  hipLaunchKernelGGL(k_chain_d, dim3(h->n_cus * 4), dim3(TPB), 0, st, gv, io, P.p, P.q, cb.list, cb.meta, cb.totals, cb.D, cb.cu);
+  hipLaunchKernelGGL(k_chain_scan, dim3(CHAIN_CAP / (TPB / 64)), dim3(TPB), 0, st, cb.meta, cb.totals, cb.cu);
+  hipLaunchKernelGGL(k_chain_u, dim3(h->n_cus * 4), dim3(TPB), 0, st, cb.totals, (const double *)cb.D, cb.cu);
+  hipLaunchKernelGGL(k_chain_seq, dim3(CHAIN_CAP / (TPB / 64)), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, cb.list, cb.meta, cb.totals,
+                     (const double *)cb.D, cb.cu, scratch, h->counters.p, strat);
+}
+}  // namespace
+
 namespace {
 struct LaunchInfo { int kind; int record_bytes; };
 
@@ -2003,24 +2105,46 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
                            first_walk, rng, P.p, d_paths, d_lens, h->counters.p, h->walk_todo.p, h->walk_cursor.p + 1);
       todo = h->walk_todo.p;
     }
+    const int32_t *todo_tie = nullptr; const ChainRec *tie_list = nullptr; const SWalker *tie_out = nullptr;
     if (lean) {
-      h->walk_todo.ensure((size_t)n_walkers);
+      h->walk_todo.ensure(2 * (size_t)n_walkers);          // handed-over walkers | their tie records
       int64_t lb = std::min<int64_t>((n_walkers * 64 + TPB - 1) / TPB, (int64_t)h->n_cus * 16);
+      // table steps whose draw sits on a CDF boundary: recorded, resolved by the chain kernels (the whole GPU + one short pass per
+      // record) and taken from there by k_walk_general when it redoes the walker — one wave alone took up to ~50 ms for the chain
+      // over a 10^6-candidate row, 5.8 % of a config-3 iteration
+      TieSink tie; tie.hdr = nullptr; tie.recs = nullptr; tie.list = nullptr; tie.cur = nullptr; tie.todo_tie = nullptr;
+      ChainBufs cb; bool ties = P.rng_mode == SRW_RNG_PHILOX && !getenv("SRW_NO_TIE_KERNELS");
+      if (ties) {
+        cb = chain_bufs(h);
+        SRW_HIP(hipMemsetAsync(cb.tie_cur, 0, 48, st));                                   // cursor array + chunk header
+        SRW_HIP(hipMemsetAsync(cb.tie_out, 0xFF, (size_t)CHAIN_CAP * sizeof(SWalker), st));   // kind = -1: not resolved
+        tie.hdr = cb.tie_hdr; tie.recs = cb.tie_recs; tie.list = cb.list; tie.cur = cb.tie_cur + 2;
+        tie.todo_tie = h->walk_todo.p + n_walkers;
+      }
       if (gv.bf_off) {
         hipLaunchKernelGGL((k_walk_tables<true>), dim3((unsigned)lb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
                          first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, h->walk_todo.p,
-                         h->walk_cursor.p + 1);
+                         h->walk_cursor.p + 1, tie);
       } else {
         hipLaunchKernelGGL((k_walk_tables<false>), dim3((unsigned)lb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
                          first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, h->walk_todo.p,
-                         h->walk_cursor.p + 1);
+                         h->walk_cursor.p + 1, tie);
       }
       SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, sizeof(unsigned long long), st));
       todo = h->walk_todo.p;
+      if (ties) {
+        ShardIO io; io.recv = reinterpret_cast<const char *>(cb.tie_hdr); io.chunk_bytes = 0; io.cap_w = CHAIN_CAP; io.cap_r = 0;
+        io.world = 1; io.rank = 0; io.batch = 0x7FFFFFFF; io.pt = nullptr; io.lens = nullptr; io.n_rows = 0;      // lw = the iteration's offset
+        srw_walk_params Pc = P; Pc.first_walk = first_walk;
+        static const int n_pass = getenv("SRW_TIE_PASSES") ? std::max(1, atoi(getenv("SRW_TIE_PASSES"))) : 8;
+        for (int pass = 0; pass < n_pass; ++pass)          // (a pass with nothing left is five empty launches)
+          enqueue_chain(h, cb, gv, io, Pc, 0, 0, rng, cb.tie_out, -1, cb.tie_cur, cb.tie_skip, cb.tie_cur + 3);
+        todo_tie = tie.todo_tie; tie_list = cb.list; tie_out = cb.tie_out;
+      }
     }
     hipLaunchKernelGGL(k_walk_general, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
                        P.walk_length, first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, tune, todo,
-                       h->walk_cursor.p + 1);
+                       h->walk_cursor.p + 1, todo_tie, tie_list, tie_out);
   }
   SRW_HIP(hipGetLastError());
   LaunchInfo li;
@@ -2485,40 +2609,6 @@ void run_shard_begin(srw_handle *h, const srw_walk_params &P, int32_t batch, con
   SRW_HIP(hipGetLastError());
 }
 
-// Chain scratch of a handle: record list + meta + totals in one buffer, the quotients of up to d_cap candidates in another,
-// the per-unit summaries in a third.
-namespace {
-struct ChainBufs { ChainRec *list; ChainMeta *meta; uint32_t *totals; double *D; ChainUnits cu; long long d_cap; };
-ChainBufs chain_bufs(srw_handle *h) {
-  static const long long d_cap = (long long)(getenv("SRW_CHAIN_SCRATCH_MB") ? atof(getenv("SRW_CHAIN_SCRATCH_MB")) : 512.0) * (1 << 20) / 8;
-  const size_t n_units = (size_t)(d_cap / 256) + CHAIN_CAP;
-  h->chain_buf.ensure((size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)) + 64 + n_units * 24);
-  h->chain_d.ensure((size_t)d_cap);
-  ChainBufs b;
-  char *base = h->chain_buf.p;
-  b.list = reinterpret_cast<ChainRec *>(base);
-  b.meta = reinterpret_cast<ChainMeta *>(base + (size_t)CHAIN_CAP * sizeof(ChainRec));
-  b.totals = reinterpret_cast<uint32_t *>(base + (size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)));
-  char *ub = base + (size_t)CHAIN_CAP * (sizeof(ChainRec) + sizeof(ChainMeta)) + 64;
-  b.cu.usum = reinterpret_cast<double *>(ub);
-  b.cu.utot = reinterpret_cast<unsigned long long *>(ub + n_units * 8);
-  b.cu.ue = reinterpret_cast<int32_t *>(ub + n_units * 16);
-  b.D = h->chain_d.p; b.d_cap = d_cap;
-  return b;
-}
-// draws on a CDF boundary (listed by the step kernel at cursor[2]): quotients by the whole GPU, their units summarised, then one
-// short sequential pass per record; what does not fit goes onto the todo list of the general step
-void enqueue_chain(srw_handle *h, const ChainBufs &cb, const GraphView &gv, const ShardIO &io, const srw_walk_params &P, int32_t step, int32_t last,
-                   const RngSpec &rng, SWalker *scratch, int strat) {
-  hipStream_t st = h->stream;
-  hipLaunchKernelGGL(k_chain_setup, dim3(1), dim3(64), 0, st, gv, io, cb.list, h->walk_cursor.p, cb.meta, cb.totals, cb.d_cap, (uint32_t *)h->walk_todo.p);
-  hipLaunchKernelGGL(k_chain_d, dim3(h->n_cus * 4), dim3(TPB), 0, st, gv, io, P.p, P.q, cb.list, cb.meta, cb.totals, cb.D, cb.cu);
-  hipLaunchKernelGGL(k_chain_scan, dim3(CHAIN_CAP / (TPB / 64)), dim3(TPB), 0, st, cb.meta, cb.totals, cb.cu);
-  hipLaunchKernelGGL(k_chain_u, dim3(h->n_cus * 4), dim3(TPB), 0, st, cb.totals, (const double *)cb.D, cb.cu);
-  hipLaunchKernelGGL(k_chain_seq, dim3(CHAIN_CAP / (TPB / 64)), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, cb.list, cb.meta, cb.totals,
-                     (const double *)cb.D, cb.cu, scratch, h->counters.p, strat);
-}
-}  // namespace
 
 // One super-step, enqueued on the handle's stream without any host synchronisation: returns of the previous
 // super-step applied, every incoming walker sampled once, walkers and path returns bucketed into dst[0 .. world).
@@ -2621,7 +2711,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
       hipLaunchKernelGGL(k_sh_step_q1w, dim3(h->n_cus * 8), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, scratch, h->walk_cursor.p,
                          (const uint32_t *)many_list, (uint32_t *)h->walk_todo.p, chain_list, h->counters.p);
     });
-    timed(2, [&] { enqueue_chain(h, cb, gv, io, P, step, last, rng, scratch, (int)SRW_STRAT_Q1_LANE); });
+    timed(2, [&] { enqueue_chain(h, cb, gv, io, P, step, last, rng, scratch, (int)SRW_STRAT_Q1_LANE, h->walk_cursor.p, (uint32_t *)h->walk_todo.p); });
     timed(2, [&] {
       hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch, h->shard_blk.p,
                          h->counters.p, (const uint32_t *)h->walk_todo.p, (const unsigned long long *)(h->walk_cursor.p + 1));
@@ -2653,7 +2743,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
                            h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n, chain_list);
     });
     // draws on a CDF boundary of a table step
-    timed(2, [&] { enqueue_chain(h, cb, gv, io, P, step, last, rng, scratch, (int)SRW_STRAT_EDGE_TABLE); });
+    timed(2, [&] { enqueue_chain(h, cb, gv, io, P, step, last, rng, scratch, (int)SRW_STRAT_EDGE_TABLE, h->walk_cursor.p, (uint32_t *)h->walk_todo.p); });
     timed(2, [&] {      // (the few records without a table, or whose tie is not a table step's)
       hipLaunchKernelGGL(k_sh_step, dim3(n_blocks), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch, h->shard_blk.p,
                          h->counters.p, (const uint32_t *)h->walk_todo.p, (const unsigned long long *)(h->walk_cursor.p + 1));

@@ -171,7 +171,8 @@ enum { /* srw_walk_stats.strategy_steps: which sampler of the general (second-or
   SRW_STRAT_CHAIN = 7,      /* the reference's sequential f64 chain (irregular rows, draws on a CDF boundary) */
   SRW_STRAT_EDGE_MASK = 8,  /* precomputed per-edge membership mask (rows below 256 candidates): no lookup at all */
   SRW_STRAT_Q1_LANE = 9,    /* p != 1, q == 1: one walker per lane (first-order guide table + exact prefix sums + return edge) */
-  SRW_STAT_HANDED_OVER = 10 /* not a sampler: WALKERS the per-edge-table / per-lane kernels handed to the general kernel (redone there) */
+  SRW_STAT_HANDED_OVER = 10, /* not a sampler: WALKERS the per-edge-table / per-lane kernels handed to the general kernel (redone there) */
+  SRW_STAT_TIES_RESOLVED = 11 /* not a sampler: of those, the walkers whose boundary draw the chain kernels resolved ahead of the redo (srw_walk) */
 };
 
 /* Replaces RandomWalk.randomWalk (M/algorithm/RandomWalk.scala:75-176) incl. initFirstStep (:51-66):

@@ -66,7 +66,7 @@ class ShardLayout(C.Structure):
     _fields_ = [("cap_walkers", C.c_int64), ("cap_rets", C.c_int64), ("chunk_bytes", C.c_int64)]
 
 
-STRATEGIES = ("edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain", "edge_mask", "q1_lane", "handed_over_walkers", "_11")   # SRW_STRAT_*
+STRATEGIES = ("edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain", "edge_mask", "q1_lane", "handed_over_walkers", "ties_resolved")   # SRW_STRAT_*
 
 
 # every symbol include/stellar_rw.h declares

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
       int32_t k = -1, next = 0;
       bool binned_served = false, have_next = false;
       unsigned which = SRW_STRAT_SCAN;
-      if (s == tie_s) { k = tie_k; next = tie_next; have_next = true; binned_served = true; which = SRW_STRAT_EDGE_TABLE; f = 1; n_strat[11] += 1; }
+      if (s == tie_s) { k = tie_k; next = tie_next; have_next = true; binned_served = true; which = SRW_STRAT_EDGE_TABLE; f = 1; n_strat[SRW_STAT_TIES_RESOLVED] += 1; }
       else if (want_tab) {
         if (r.deg <= g.eb_mask_max) {
           // membership mask of the pair (inline for rows up to 32 candidates): no lookup, the row sits in registers
@@ -2040,6 +2040,7 @@ __global__ void k_paths_to_ids(int32_t *__restrict__ paths, const int32_t *__res
 LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walks, int32_t first_walk, int32_t *d_paths,
                        int32_t *d_lens) {
   Graph &g = h->g;
+  { const char *e = getenv("SRW_DEBUG_CHAIN_DEG"); g.dbg_chain_deg = e && *e ? atoi(e) : 0; }      // tests: every table step on a long row is a "tie"
   hipStream_t st = h->stream;
   const int64_t n_walkers = (int64_t)num_walks * g.n_vertices;
   const bool alias = P.sampler == SRW_SAMPLER_ALIAS;

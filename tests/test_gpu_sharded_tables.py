@@ -215,3 +215,15 @@ def test_shard_chain_kernels_long_rows(oracle, monkeypatch, world, kind):
             assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (world, kind, q, "philox, forced chain")
             assert st["strategy_steps"]["chain"] > 0, st
             monkeypatch.delenv("SRW_DEBUG_CHAIN_DEG")
+    # the whole-graph walk's ties take the same kernels (k_walk_tables records them, k_walk_general takes the resolved step)
+    with pkg().Engine(device=0) as eng:
+        eng.load_coo(s, d, w, directed=True)
+        rp, rl, rs = g.walk(p=0.5, q=2.0, walk_length=6, seed=5, threads=8)
+        monkeypatch.setenv("SRW_DEBUG_CHAIN_DEG", "1000")
+        paths, lens, st = eng.walk(p=0.5, q=2.0, walk_length=6, seed=5)
+        monkeypatch.delenv("SRW_DEBUG_CHAIN_DEG")
+        assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (kind, "whole graph, forced chain")
+        ss = st["strategy_steps"]
+        assert ss["ties_resolved"] <= ss["handed_over_walkers"], ss
+        if kind < 3:            # (kind 3's hub row has no exact prefix sums, hence no table: its steps are the general kernel's own)
+            assert ss["ties_resolved"] > 0, ss

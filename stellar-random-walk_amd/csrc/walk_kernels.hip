@@ -26,7 +26,7 @@ namespace {
 struct alignas(16) WWalker { int32_t lw, src, prev, curr; };      // on the wire: 16 bytes
 struct alignas(16) SWalker { int32_t lw, src, prev, curr, v, kind, pad0, pad1; };   // pad0: position of the chosen candidate (chain kernels)
 enum : int32_t { SK_WALKER_RET = 1, SK_RET = 2, SK_DEAD = 3 };   // walker + return; return only (last step); death notice only
-constexpr int CHAIN_CAP = 1024;     // draws on a CDF boundary per super-step / per launch that the chain kernels take (more: the general step)
+constexpr int CHAIN_CAP = 4096;     // draws on a CDF boundary per super-step / per launch that the chain kernels take (more: the general step)
 struct alignas(16) ChainRec { uint32_t ri, pad; double S; };      // record index, (whole-graph walks: the step), the reference's sum of the biased row
 // Whole-graph walks: where k_walk_tables leaves a table step whose draw sits on a CDF boundary — one wire record per tie (lw = the
 // iteration's offset) behind a chunk header, so that the chain kernels of the sharded walk read them like a super-step's input;
@@ -1602,10 +1602,16 @@ __global__ void k_chain_setup(GraphView g, ShardIO io, const ChainRec *__restric
                               ChainMeta *__restrict__ meta, uint32_t *__restrict__ totals /* [0] work units, [1] records */, long long d_cap,
                               uint32_t *__restrict__ todo, unsigned long long *pass_cur) {
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
+  __shared__ int32_t degs[CHAIN_CAP];
   shard_in_prefix(io, pre);
-  if (threadIdx.x != 0) return;
   const unsigned long long n_all = cursor[2];
   const uint32_t n = (uint32_t)(n_all < (unsigned long long)CHAIN_CAP ? n_all : (unsigned long long)CHAIN_CAP);
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {       // the rows' lengths, all lanes (one dependent pair of loads each)
+    const SWalker wk = shard_in_record(io, pre, list[i].ri);
+    degs[i] = g.rows[(int64_t)wk.curr - g.vmin].deg;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   const uint32_t start = pass_cur ? (uint32_t)(*pass_cur < (unsigned long long)n ? *pass_cur : (unsigned long long)n) : 0u;
   uint32_t next_start = start;
   bool stopped = false;
@@ -1613,10 +1619,9 @@ __global__ void k_chain_setup(GraphView g, ShardIO io, const ChainRec *__restric
   for (uint32_t i = 0; i < n; ++i) {
     ChainMeta m; m.d_off = off; m.deg = 0; m.u_off = units;          // deg 0: not in this pass
     if (i >= start && !stopped) {
-      const SWalker wk = shard_in_record(io, pre, list[i].ri);
-      const Row r = g.rows[(int64_t)wk.curr - g.vmin];
-      if (off + (long long)r.deg <= d_cap) {
-        m.deg = r.deg; off += (long long)((r.deg + 255) & ~255); units += (uint32_t)((r.deg + 255) >> 8); next_start = i + 1;
+      const int32_t deg = degs[i];
+      if (off + (long long)deg <= d_cap) {
+        m.deg = deg; off += (long long)((deg + 255) & ~255); units += (uint32_t)((deg + 255) >> 8); next_start = i + 1;
       } else if (!pass_cur) todo[atomicAdd(cursor + 1, 1ull)] = list[i].ri;     // scratch full: the general step
       else if (off == 0) next_start = i + 1;                                   // longer than the whole scratch array: stays unresolved
       else stopped = true;                                                     // the next pass starts here
@@ -2002,7 +2007,7 @@ ChainBufs chain_bufs(srw_handle *h) {
 void enqueue_chain(srw_handle *h, const ChainBufs &cb, const GraphView &gv, const ShardIO &io, const srw_walk_params &P, int32_t step, int32_t last,
                    const RngSpec &rng, SWalker *scratch, int strat, unsigned long long *cursor, uint32_t *skipped, unsigned long long *pass_cur = nullptr) {
   hipStream_t st = h->stream;
-  hipLaunchKernelGGL(k_chain_setup, dim3(1), dim3(64), 0, st, gv, io, cb.list, cursor, cb.meta, cb.totals, cb.d_cap, skipped, pass_cur);
+  hipLaunchKernelGGL(k_chain_setup, dim3(1), dim3(256), 0, st, gv, io, cb.list, cursor, cb.meta, cb.totals, cb.d_cap, skipped, pass_cur);
   hipLaunchKernelGGL(k_chain_d, dim3(h->n_cus * 4), dim3(TPB), 0, st, gv, io, P.p, P.q, cb.list, cb.meta, cb.totals, cb.D, cb.cu);
   hipLaunchKernelGGL(k_chain_scan, dim3(CHAIN_CAP / (TPB / 64)), dim3(TPB), 0, st, cb.meta, cb.totals, cb.cu);
   hipLaunchKernelGGL(k_chain_u, dim3(h->n_cus * 4), dim3(TPB), 0, st, cb.totals, (const double *)cb.D, cb.cu);

@@ -265,12 +265,16 @@ __global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, ShardSel ss, EbS
 #ifndef SRW_EB_P1K
 #define SRW_EB_P1K 2
 #endif
+#ifndef SRW_EB_WAVES
+#define SRW_EB_WAVES 4
+#endif
+constexpr int EB_LDS_WORDS = 2 * BIN_CAP + HCHUNK;      // binned_fill's bins + the staged ids of N(prev): 6 KB per wave
 template <bool SH>
-__global__ __launch_bounds__(TPB, 4) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
+__global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
                                                      float q, int32_t min_sh, int32_t mask_max, int32_t bins_cap, const uint32_t *__restrict__ eb_off,
                                                      double *__restrict__ eb_bins, uint32_t *__restrict__ em_bits, unsigned long long *cursor,
                                                      unsigned long long *strat_count /* [8] */, int fill_tune) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][BINNED_LDS_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][EB_LDS_WORDS];
   const int lane = lane_id();
   uint32_t *mine = lds[threadIdx.x >> 6];
   Member tm; tm.mode = 0; tm.bm = mine; tm.seg_base = 0; tm.ehash = g.ehash; tm.ehash_mask = g.ehash_mask;

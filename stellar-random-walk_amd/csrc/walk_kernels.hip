@@ -567,7 +567,7 @@ template <bool NT>
 __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
                                                  int64_t n_walkers, int32_t L, int32_t first_walk, RngSpec rng, float p,
                                                  int32_t *__restrict__ paths, int32_t *__restrict__ lens, DevCounters *ctr,
-                                                 int32_t *__restrict__ todo, unsigned long long *todo_n) {
+                                                 int32_t *__restrict__ todo, unsigned long long *todo_n, uint32_t max_ret) {
   __shared__ int32_t tile[TPB / 64][64][TILE + 1];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
   const int64_t wi = blockIdx.x * (int64_t)TPB + threadIdx.x;
@@ -592,6 +592,7 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
   for (int32_t s = 1; s <= L + 1; ++s) {
     const int c = s & (TILE - 1);
     int32_t val = -1;
+    bool big = false; uint32_t big_rv = 0u, big_m = 0u;
     if (alive) {
       if (r.deg == 0) {
         alive = false; if (s > 1) ++dead;
@@ -606,13 +607,57 @@ __global__ __launch_bounds__(TPB) void k_walk_q1(GraphView g, const int32_t *__r
         } else {
           const int4v rv4 = NT ? __builtin_nontemporal_load(reinterpret_cast<const int4v *>(g.rev + eprev))
                                : *reinterpret_cast<const int4v *>(g.rev + eprev);
-          const int why = q1_pick<NT>(g, r, crow, (uint32_t)rv4.x, rv4.y, __int_as_float(rv4.z), prev_id, m, p, e, k, reads);
-          if (why) { alive = false; handed = true; atomicAdd(&ctr->why[why], 1ull); }
+          if ((uint32_t)rv4.x != REV_NONE && ((uint32_t)rv4.x >> 24) > max_ret) { big = true; big_rv = (uint32_t)rv4.x; big_m = m; }
+          else {
+            const int why = q1_pick<NT>(g, r, crow, (uint32_t)rv4.x, rv4.y, __int_as_float(rv4.z), prev_id, m, p, e, k, reads);
+            if (why) { alive = false; handed = true; atomicAdd(&ctr->why[why], 1ull); }
+          }
         }
-        if (alive) {
+        if (alive && !big) {
           val = e.id; ++len;
           prev_id = curr_id; curr_id = val;
           eprev = r.off + k;
+          r.off = (int64_t)(e.link & CFO_NOFF_MASK); r.deg = (int32_t)((e.link >> 40) & 0x7FFFFFu);
+          r.flags = (e.link >> 63) ? ROW_IRREGULAR : 0u;
+        }
+      }
+    }
+    // Steps with many parallel return edges (a hub's self-loops, hub <-> hub multi-edges: up to hundreds): q1_pick walks the run once
+    // per prefix value in ONE lane while 63 wait — the wave takes them one at a time instead (wave_pick_returns).
+    unsigned long long mb = __ballot(big);
+    while (mb) {
+      const int l = __ffsll((long long)mb) - 1;
+      mb &= mb - 1ull;
+      Row rr;
+      rr.off = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)r.off >> 32), l) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.off, l));
+      rr.deg = __builtin_amdgcn_readlane(r.deg, l); rr.flags = ROW_PQ_OK;          // (q1 runs only when every row holds the certificate)
+      const int32_t pv = __builtin_amdgcn_readlane(prev_id, l);
+      const uint32_t rvl = (uint32_t)__builtin_amdgcn_readlane((int)big_rv, l);
+      const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)big_m, l);
+      const int64_t so = rr.off + (int64_t)(rvl & 0xFFFFFFu);
+      int32_t nr = (int32_t)(rvl >> 24);
+      if (nr >= 255) {                                     // the count saturated: the run of prev in the sorted row
+        const uint32_t xprev = (uint32_t)((int64_t)pv - g.vmin);
+        nr = 0;
+        for (int64_t cc = so;; cc += 64) {
+          const unsigned long long mm = __ballot(cc + lane < rr.off + rr.deg && g.sids[cc + lane] == xprev);
+          nr += __popcll(mm);
+          if (mm != ~0ull) break;
+        }
+      }
+      Bias b; b.p = p; b.q = 1.0f; b.prev = pv; b.second_order = true; b.need_member = false; b.vmin = g.vmin;
+      b.prev_sids = nullptr; b.prev_deg = 0; b.prev_hub = 0;
+      unsigned f = 0;
+      const int32_t kk = wave_pick_returns<false>(g, rr, b, so, nr, (float)ml * (1.0f / 16777216.0f), f);
+      if (lane == l) {
+        big = false;
+        if (kk < 0) { alive = false; handed = true; atomicAdd(&ctr->why[kk == CHAIN_NEEDED ? 2 : 1], 1ull); }
+        else {
+          const CfoEnt e = load_cfo<NT>(g.cfo + r.off + kk); ++reads;
+          val = e.id; ++len;
+          prev_id = curr_id; curr_id = val;
+          eprev = r.off + kk;
           r.off = (int64_t)(e.link & CFO_NOFF_MASK); r.deg = (int32_t)((e.link >> 40) & 0x7FFFFFu);
           r.flags = (e.link >> 63) ? ROW_IRREGULAR : 0u;
         }
@@ -2100,33 +2145,44 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
     const bool q1 = P.q == 1.0f && P.p != 1.0f && P.rng_mode == SRW_RNG_PHILOX && g.has_cfo && g.has_pq && g.has_rev &&
                     g.pq_bad_rows == 0 && tune == 0 && !(P.flags & SRW_WALK_NO_PREFIX) && !getenv("SRW_NO_Q1_KERNEL");
     const int32_t *todo = nullptr;
+    // Steps whose draw sits on a CDF boundary (the per-lane / lean kernels cannot decide them): recorded by those kernels, resolved by
+    // the chain kernels (the whole GPU + one short pass per record, in passes that fit the quotient scratch) and taken from there by
+    // k_walk_general when it redoes the walker — one wave alone took up to ~50 ms for the chain over a 10^6-candidate row
+    const int32_t *todo_tie = nullptr; const ChainRec *tie_list = nullptr; const SWalker *tie_out = nullptr;
+    TieSink tie; tie.hdr = nullptr; tie.recs = nullptr; tie.list = nullptr; tie.cur = nullptr; tie.todo_tie = nullptr;
+    ChainBufs cb;
+    const bool ties = lean && P.rng_mode == SRW_RNG_PHILOX && !getenv("SRW_NO_TIE_KERNELS");   // (the per-lane q == 1 kernel: measured, no gain — the records cost its registers what the redo saves)
+    if (q1 || lean) h->walk_todo.ensure(2 * (size_t)n_walkers);          // handed-over walkers | their tie records
+    if (ties) {
+      cb = chain_bufs(h);
+      SRW_HIP(hipMemsetAsync(cb.tie_cur, 0, 48, st));                                   // cursor array + chunk header
+      SRW_HIP(hipMemsetAsync(cb.tie_out, 0xFF, (size_t)CHAIN_CAP * sizeof(SWalker), st));   // kind = -1: not resolved
+      tie.hdr = cb.tie_hdr; tie.recs = cb.tie_recs; tie.list = cb.list; tie.cur = cb.tie_cur + 2;
+      tie.todo_tie = h->walk_todo.p + n_walkers;
+    }
+    auto resolve_ties = [&]() {
+      if (!ties) return;
+      ShardIO io; io.recv = reinterpret_cast<const char *>(cb.tie_hdr); io.chunk_bytes = 0; io.cap_w = CHAIN_CAP; io.cap_r = 0;
+      io.world = 1; io.rank = 0; io.batch = 0x7FFFFFFF; io.pt = nullptr; io.lens = nullptr; io.n_rows = 0;      // lw = the iteration's offset
+      srw_walk_params Pc = P; Pc.first_walk = first_walk;
+      static const int n_pass = getenv("SRW_TIE_PASSES") ? std::max(1, atoi(getenv("SRW_TIE_PASSES"))) : 8;
+      for (int pass = 0; pass < n_pass; ++pass)          // (a pass with nothing left is five empty launches)
+        enqueue_chain(h, cb, gv, io, Pc, 0, 0, rng, cb.tie_out, -1, cb.tie_cur, cb.tie_skip, cb.tie_cur + 3);
+      todo_tie = tie.todo_tie; tie_list = cb.list; tie_out = cb.tie_out;
+    };
     if (q1) {
-      h->walk_todo.ensure((size_t)n_walkers);
       const int64_t qb = (n_walkers + TPB - 1) / TPB;
+      const uint32_t q1_max_ret = getenv("SRW_Q1_MAX_RET") ? (uint32_t)atoi(getenv("SRW_Q1_MAX_RET")) : 16u;   // more parallel return edges: the whole wave takes the step
       if ((size_t)g.n_entries * sizeof(CfoEnt) > ((size_t)2 << 30))
         hipLaunchKernelGGL(k_walk_q1<true>, dim3((unsigned)qb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
-                           first_walk, rng, P.p, d_paths, d_lens, h->counters.p, h->walk_todo.p, h->walk_cursor.p + 1);
+                           first_walk, rng, P.p, d_paths, d_lens, h->counters.p, h->walk_todo.p, h->walk_cursor.p + 1, q1_max_ret);
       else
         hipLaunchKernelGGL(k_walk_q1<false>, dim3((unsigned)qb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
-                           first_walk, rng, P.p, d_paths, d_lens, h->counters.p, h->walk_todo.p, h->walk_cursor.p + 1);
+                           first_walk, rng, P.p, d_paths, d_lens, h->counters.p, h->walk_todo.p, h->walk_cursor.p + 1, q1_max_ret);
       todo = h->walk_todo.p;
     }
-    const int32_t *todo_tie = nullptr; const ChainRec *tie_list = nullptr; const SWalker *tie_out = nullptr;
     if (lean) {
-      h->walk_todo.ensure(2 * (size_t)n_walkers);          // handed-over walkers | their tie records
       int64_t lb = std::min<int64_t>((n_walkers * 64 + TPB - 1) / TPB, (int64_t)h->n_cus * 16);
-      // table steps whose draw sits on a CDF boundary: recorded, resolved by the chain kernels (the whole GPU + one short pass per
-      // record) and taken from there by k_walk_general when it redoes the walker — one wave alone took up to ~50 ms for the chain
-      // over a 10^6-candidate row, 5.8 % of a config-3 iteration
-      TieSink tie; tie.hdr = nullptr; tie.recs = nullptr; tie.list = nullptr; tie.cur = nullptr; tie.todo_tie = nullptr;
-      ChainBufs cb; bool ties = P.rng_mode == SRW_RNG_PHILOX && !getenv("SRW_NO_TIE_KERNELS");
-      if (ties) {
-        cb = chain_bufs(h);
-        SRW_HIP(hipMemsetAsync(cb.tie_cur, 0, 48, st));                                   // cursor array + chunk header
-        SRW_HIP(hipMemsetAsync(cb.tie_out, 0xFF, (size_t)CHAIN_CAP * sizeof(SWalker), st));   // kind = -1: not resolved
-        tie.hdr = cb.tie_hdr; tie.recs = cb.tie_recs; tie.list = cb.list; tie.cur = cb.tie_cur + 2;
-        tie.todo_tie = h->walk_todo.p + n_walkers;
-      }
       if (gv.bf_off) {
         hipLaunchKernelGGL((k_walk_tables<true>), dim3((unsigned)lb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
                          first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, h->walk_todo.p,
@@ -2138,15 +2194,7 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
       }
       SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, sizeof(unsigned long long), st));
       todo = h->walk_todo.p;
-      if (ties) {
-        ShardIO io; io.recv = reinterpret_cast<const char *>(cb.tie_hdr); io.chunk_bytes = 0; io.cap_w = CHAIN_CAP; io.cap_r = 0;
-        io.world = 1; io.rank = 0; io.batch = 0x7FFFFFFF; io.pt = nullptr; io.lens = nullptr; io.n_rows = 0;      // lw = the iteration's offset
-        srw_walk_params Pc = P; Pc.first_walk = first_walk;
-        static const int n_pass = getenv("SRW_TIE_PASSES") ? std::max(1, atoi(getenv("SRW_TIE_PASSES"))) : 8;
-        for (int pass = 0; pass < n_pass; ++pass)          // (a pass with nothing left is five empty launches)
-          enqueue_chain(h, cb, gv, io, Pc, 0, 0, rng, cb.tie_out, -1, cb.tie_cur, cb.tie_skip, cb.tie_cur + 3);
-        todo_tie = tie.todo_tie; tie_list = cb.list; tie_out = cb.tie_out;
-      }
+      resolve_ties();
     }
     hipLaunchKernelGGL(k_walk_general, dim3((unsigned)blocks), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers,
                        P.walk_length, first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, tune, todo,

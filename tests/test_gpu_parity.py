@@ -882,10 +882,14 @@ def test_giant_row_mass_certificate(eng, oracle):
 
 
 # ---- p != 1, q == 1: one walker per lane (k_walk_q1) ----------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["rmat12", "rmat12w", "rmat11wd", "rmat12f", "rmat12x", "multi", "multi_neg", "karate", "hub"])
-def test_q1_per_lane_kernel(eng, oracle, case):
+@pytest.mark.parametrize("case", ["rmat12", "rmat12w", "rmat11wd", "rmat12f", "rmat12x", "multi", "multi_neg", "karate", "hub", "multi:wave", "rmat12w:wave"])
+def test_q1_per_lane_kernel(eng, oracle, monkeypatch, case):
     """Return-edge-only bias: the per-lane kernel (guide table + exact prefix sums + return-edge position) must equal the
-    oracle, hand over what it cannot certify (several return edges, irregular rows, lattice ties) and say so."""
+    oracle, hand over what it cannot certify (several return edges, irregular rows, lattice ties) and say so.  ":wave": every
+    step with more than ONE return edge is taken by the whole wave (wave_pick_returns; the default threshold is 16)."""
+    if case.endswith(":wave"):
+        case = case[:-5]
+        monkeypatch.setenv("SRW_Q1_MAX_RET", "1")
     directed = False
     if case.startswith("rmat"):
         sc = int(case[4:6])

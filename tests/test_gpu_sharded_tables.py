@@ -3,6 +3,8 @@ directed, p = 4, q = .5, graph sharded by source vertex — replacing RandomWalk
 with every walker so that the receiving partition can recompute RandomSample.computeSecondOrderWeights, :27-44).
 Each shard holds the tables of the pairs (prev -> curr) into ITS rows, found through a pair hash; the walk must stay
 bit-identical to the oracle for every world size, and the table / mask steps must actually fire on the shards."""
+import os
+
 import numpy as np
 import pytest
 
@@ -225,5 +227,5 @@ def test_shard_chain_kernels_long_rows(oracle, monkeypatch, world, kind):
         assert np.array_equal(lens, rl) and np.array_equal(paths, rp), (kind, "whole graph, forced chain")
         ss = st["strategy_steps"]
         assert ss["ties_resolved"] <= ss["handed_over_walkers"], ss
-        if kind < 3:            # (kind 3's hub row has no exact prefix sums, hence no table: its steps are the general kernel's own)
+        if kind < 3 and not os.environ.get("SRW_NO_TIE_KERNELS"):   # (kind 3's hub row has no exact prefix sums, hence no table: its steps are the general kernel's own)
             assert ss["ties_resolved"] > 0, ss

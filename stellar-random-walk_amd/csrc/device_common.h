@@ -134,6 +134,7 @@ struct GraphView {
   // rev[e] holds on a whole-graph handle (val = count << 24 | index in curr's sorted row, pad = input-order position of the first one)
   const PairSlot *rh;
   uint32_t rh_buckets;
+  int32_t eb_cm_max;       // rows of more than eb_mask_max and at most eb_cm_max candidates: the pair's table is followed by its chunk masks (0: none)
   int32_t dbg_chain_deg;   // tests (SRW_DEBUG_CHAIN_DEG): sharded steps on rows at least this long are treated as draws on a CDF boundary (0: off)
 };
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;

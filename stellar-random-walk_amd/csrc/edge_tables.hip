@@ -47,6 +47,7 @@ struct EbSel {          // which pairs get a table
   int32_t has_ehash, has_hub;
   int32_t f32;          // tables of ROW_PQ_F32 rows are stored as floats
   int32_t bins_cap;     // chunks per table at most (GraphView::eb_cap)
+  int32_t cm_max;       // bins tables of rows up to this many candidates are followed by the pair's chunk masks (0: none; needs min_sh >= 6)
 };
 constexpr int INLINE_MAX_DEG = 32;   // masks of rows up to 32 candidates live in eb_off[e] itself
 
@@ -64,7 +65,7 @@ __device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s
   const BinnedCost c = binned_cost(rv.deg, ru.deg, s.has_hub && (ru.flags >> ROW_HUB_SHIFT) != 0u, s.has_ehash != 0);
   const int64_t cost = c.c1 < c.c2 ? (c.c1 < c.cw ? c.c1 : c.cw) : (c.c2 < c.cw ? c.c2 : c.cw);
   const BinGeom geo = bin_geometry(rv.deg, s.min_sh, s.bins_cap);
-  const uint32_t units = (s.f32 && (rv.flags & ROW_PQ_F32)) ? (uint32_t)((geo.n_bins + 15) >> 4) : (uint32_t)((geo.n_bins + 7) >> 3);
+  const uint32_t units = eb_prefix_units(s.f32 && (rv.flags & ROW_PQ_F32), geo.n_bins) + (rv.deg <= s.cm_max ? eb_cmask_units(rv.deg) : 0u);
   // priority = wave-cycles a table saves per visit, per 64 bytes of table: an on-the-fly step costs its intersection
   // work plus ~20 us of dependent round trips whatever its size (measured: 38 .. 43 us per P1 / W step at config 3
   // against 10 .. 25 us per table step), so short cheap tables are worth as much per byte as the hub <-> hub ones
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, ShardSel ss, EbS
 constexpr int EB_LDS_WORDS = 2 * BIN_CAP + HCHUNK;      // binned_fill's bins + the staged ids of N(prev): 6 KB per wave
 template <bool SH>
 __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
-                                                     float q, int32_t min_sh, int32_t mask_max, int32_t bins_cap, const uint32_t *__restrict__ eb_off,
+                                                     float q, int32_t min_sh, int32_t mask_max, int32_t bins_cap, int32_t cm_max, const uint32_t *__restrict__ eb_off,
                                                      double *__restrict__ eb_bins, uint32_t *__restrict__ em_bits, unsigned long long *cursor,
                                                      unsigned long long *strat_count /* [8] */, int fill_tune) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][EB_LDS_WORDS];
@@ -341,7 +342,9 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
       const BinGeom gc = bin_geometry(rv.deg, min_sh, bins_cap);
       const BinGeom gf = gc.csh < 6 ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
       unsigned long long ab = 0; unsigned su = 0;
-      binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K>(g, rv, b, mine, fill_tune, gf, tm, ab, su);
+      // chunk masks (rows up to cm_max <= EB_CM_LIMIT candidates: at most 256 fill bins, the upper half of the bins' LDS is free)
+      uint32_t *mbits = (rv.deg <= cm_max) ? mine + BIN_CAP : nullptr;
+      binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits);
       ns[su & 7] += 1;
 #ifdef SRW_PHASE_TIMING
       const unsigned long long t_fill = wall_clock64();
@@ -360,6 +363,12 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
           reinterpret_cast<float *>(out)[j] = (float)a;
           if ((double)(float)a != a) atomicAdd(&strat_count[7], 1ull);      // must never happen (pq_row_f32's bound)
         } else out[j] = a;
+      }
+      if (mbits) {
+        unsigned long long *mo = reinterpret_cast<unsigned long long *>(out + (size_t)eb_prefix_units(as_f32, gc.n_bins) * 8);
+        const int32_t n_mw = (rv.deg + 63) >> 6, n_w32 = (rv.deg + 31) >> 5;
+        for (int32_t t = lane; t < n_mw; t += 64)
+          mo[t] = (unsigned long long)mbits[2 * t] | ((2 * t + 1 < n_w32) ? ((unsigned long long)mbits[2 * t + 1] << 32) : 0ull);
       }
       __builtin_amdgcn_wave_barrier();          // the next fill clears the bins
 #ifdef SRW_PHASE_TIMING
@@ -418,6 +427,16 @@ static int eb_min_shift(const Graph &g) {
   const int v = e && *e ? atoi(e) : g.eb_min_sh_sel;
   return v < 2 ? 2 : v > 12 ? 12 : v;
 }
+// Chunk masks: the bins table of a pair into a row of at most this many candidates is followed by the pair's membership mask over
+// the candidate positions (one bit per candidate) — the located chunk's evaluation then needs no membership probe at all
+// (profiles/r04_request_attribution.md: the probes were 48 of the 62 HBM requests of an average step at config 3).  Chunks must
+// start on mask words (chunk shift >= 6).  SRW_EB_CM_MAX: experiments.
+static int32_t eb_cm_select(const Graph &g, int mode, int min_sh) {
+  if (mode || min_sh < 6) return 0;
+  const char *e = getenv("SRW_EB_CM_MAX");
+  const int32_t v = e && *e ? atoi(e) : g.eb_cm_sel;
+  return v < MASK_MAX_DEG ? 0 : v > EB_CM_LIMIT ? EB_CM_LIMIT : v;
+}
 // HBM a COMPLETE set of tables would take (every pair into a certified row + every mask + offsets + the work list):
 // prepare_tables sizes the hub bitmaps with what is left beside it.  0: no tables possible.
 size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
@@ -430,7 +449,7 @@ size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
   { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
   sel.has_ehash = 1; sel.has_hub = 1;               // (they only move priorities, not sizes)
-  sel.bins_cap = bins_cap;
+  sel.bins_cap = bins_cap; sel.cm_max = eb_cm_select(g, mode, sel.min_sh);
   DevBuf<unsigned long long> cursor, hist;
   cursor.alloc(1); hist.alloc(128);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
@@ -467,7 +486,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
   { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
   g.eb_f32 = sel.f32;
-  sel.bins_cap = bins_cap; g.eb_cap = bins_cap;
+  sel.bins_cap = bins_cap; g.eb_cap = bins_cap; sel.cm_max = eb_cm_select(g, mode, sel.min_sh); g.eb_cm_max = sel.cm_max;
   sel.has_ehash = (g.has_ehash && g.use_ehash) ? 1 : 0; sel.has_hub = (g.has_hub && g.use_hub) ? 1 : 0;
   g.eb_min_sh = sel.min_sh;
   // budget: what is free now minus the offsets and a reserve for the walk's own buffers
@@ -540,7 +559,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
     SRW_HIP(hipMemsetAsync(hist.p, 0, 16 * 8, st));
     hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
-                       sel.bins_cap, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0);
+                       sel.bins_cap, sel.cm_max, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   }
@@ -583,7 +602,7 @@ EbSel shard_sel(const Graph &g, int mode, int bins_cap) {
   sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : eb_min_shift(g); sel.min_cost = 0;
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
   { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
-  sel.has_ehash = 0; sel.has_hub = 1; sel.bins_cap = bins_cap;
+  sel.has_ehash = 0; sel.has_hub = 1; sel.bins_cap = bins_cap; sel.cm_max = eb_cm_select(g, mode, sel.min_sh);
   return sel;
 }
 
@@ -617,7 +636,7 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
   const auto t0 = std::chrono::steady_clock::now();
   const ShardSel ss{h->cfg.rank, h->cfg.world};
   const int blocks = h->n_cus * 8;
-  g.eb_f32 = sel.f32; g.eb_cap = bins_cap; g.eb_min_sh = sel.min_sh; g.eb_mask_max = sel.mask_max;
+  g.eb_f32 = sel.f32; g.eb_cap = bins_cap; g.eb_min_sh = sel.min_sh; g.eb_mask_max = sel.mask_max; g.eb_cm_max = sel.cm_max;
   DevBuf<unsigned long long> cursor, hist, row_units, row_munits, row_pairs;
   cursor.alloc(1); hist.alloc(8);
   row_units.alloc((size_t)g.n_slots + 1); row_munits.alloc((size_t)g.n_slots + 1); row_pairs.alloc((size_t)g.n_slots + 1);
@@ -655,7 +674,7 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
     SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
     hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
-                       sel.bins_cap, item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0);
+                       sel.bins_cap, sel.cm_max, item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   }

@@ -928,6 +928,11 @@ __device__ inline void wave_lower_bound_multi(LowerBound (&s)[K]) {
 
 // Chunking of a row's candidate positions: chunk j = positions [j << csh, (j + 1) << csh), at most `cap` chunks.
 struct BinGeom { int csh; int32_t n_bins; };
+// 64-byte units of a pair's chunk-prefix table (floats where every prefix of the row is binary32-exact), and of the chunk masks
+// that follow it for rows of at most GraphView::eb_cm_max candidates: one 64-bit word per 64 candidate positions
+__host__ __device__ inline uint32_t eb_prefix_units(bool f32, int32_t n_bins) { return f32 ? (uint32_t)((n_bins + 15) >> 4) : (uint32_t)((n_bins + 7) >> 3); }
+__host__ __device__ inline uint32_t eb_cmask_units(int32_t deg) { return (uint32_t)((((deg + 63) >> 6) + 7) >> 3); }
+constexpr int32_t EB_CM_LIMIT = 16384;         // the build keeps the mask of one pair in 2 KB of the wave's LDS
 __host__ __device__ inline BinGeom bin_geometry(int32_t deg, int min_sh, int cap) {
   BinGeom g; g.csh = min_sh;
   while ((((int64_t)deg + ((int64_t)1 << g.csh) - 1) >> g.csh) > cap) ++g.csh;
@@ -956,7 +961,8 @@ __host__ __device__ inline BinnedCost binned_cost(int32_t deg, int32_t m, bool h
 // searches per lane in lockstep in P1.  Both are experiment parameters: 2 / 8 did not move the table build (profiles/r03_eb_build.md)
 template <int PF = 1, int P1K = 2>
 __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias &b, uint32_t *lds, int tune,
-                                   const BinGeom geo, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used) {
+                                   const BinGeom geo, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used,
+                                   uint32_t *mbits = nullptr /* edge_tables.hip: LDS bitmap over curr's positions, bit k = candidate k is in N(prev) */) {
   const int32_t deg = rc.deg;
   const int lane = lane_id();
   double *bins = reinterpret_cast<double *>(lds);
@@ -965,6 +971,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
   const int csh = geo.csh;
   const int32_t n_bins = geo.n_bins;
   for (int t = lane; t < n_bins; t += 64) bins[t] = 0.0;
+  if (mbits) for (int t = lane; t < ((deg + 31) >> 5); t += 64) mbits[t] = 0u;
   __builtin_amdgcn_wave_barrier();
   const Ent *row = g.ent + rc.off;
   const uint32_t *cs = g.sids + rc.off, *cp = g.sperm + rc.off;
@@ -1004,7 +1011,10 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
         if (k >= deg) continue;
         const uint32_t x = (uint32_t)((int64_t)e[u].id - b.vmin);
         if (e[u].id == b.prev) atomicAdd(&bins[k >> csh], (double)div_exact(e[u].w, p_) - (double)div_exact(e[u].w, q_));
-        else if ((wd[u] >> (x & 31)) & 1u) atomicAdd(&bins[k >> csh], (double)e[u].w - (double)div_exact(e[u].w, q_));
+        else if ((wd[u] >> (x & 31)) & 1u) {
+          atomicAdd(&bins[k >> csh], (double)e[u].w - (double)div_exact(e[u].w, q_));
+          if (mbits) atomicOr(&mbits[k >> 5], 1u << (k & 31));
+        }
       }
     }
   } else if (strat == 3 && lo_id <= hi_id) {
@@ -1059,6 +1069,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
               const uint32_t orig = cp[c];
               const float w = csw[c];
               atomicAdd(&bins[orig >> csh], (double)w - (double)div_exact(w, q_));
+              if (mbits) atomicOr(&mbits[orig >> 5], 1u << (orig & 31));
             }
       }
     } else if (strat == 2) {
@@ -1066,8 +1077,10 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
         const Ent e = row[k];
         if (e.id == b.prev) continue;
         const uint32_t xs = (uint32_t)((int64_t)e.id - b.vmin);
-        if (g.ehash ? edge_exists(g.ehash, g.ehash_mask, xprev, xs) : sorted_contains(B, m, xs))
+        if (g.ehash ? edge_exists(g.ehash, g.ehash_mask, xprev, xs) : sorted_contains(B, m, xs)) {
           atomicAdd(&bins[k >> csh], (double)e.w - (double)div_exact(e.w, q_));
+          if (mbits) atomicOr(&mbits[k >> 5], 1u << (k & 31));
+        }
       }
     } else {
       if (lo_id <= hi_id) {
@@ -1140,7 +1153,10 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
           SRW_U1(tm, t_pass1);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (want[j] && bch[pos[j]] == AI[j]) atomicAdd(&bins[AC[j] >> csh], (double)AW[j] - (double)div_exact(AW[j], q_));
+            if (want[j] && bch[pos[j]] == AI[j]) {
+              atomicAdd(&bins[AC[j] >> csh], (double)AW[j] - (double)div_exact(AW[j], q_));
+              if (mbits) atomicOr(&mbits[AC[j] >> 5], 1u << (AC[j] & 31));
+            }
           // advance the list that ends first
           const int32_t na = (deg - pa) < 256 ? (deg - pa) : 256;
           const int jl = (na - 1) & 3;
@@ -1217,7 +1233,8 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
 template <bool ABS, bool BF = false, bool CHAIN = true>
 __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, const Bias &b, const double *bins,
                                          const BinGeom geo, float r, unsigned &fallback, unsigned &served, Member &tm,
-                                         int32_t &id_out, uint32_t *stage, double *S_out = nullptr) {
+                                         int32_t &id_out, uint32_t *stage, double *S_out = nullptr,
+                                         const unsigned long long *cmask = nullptr /* the pair's chunk masks (edge_tables.hip): bit k = candidate k is in N(prev) */) {
   constexpr int PL = SRW_RESOLVE_PER_LANE;
   const int lane = lane_id();
   const int32_t deg = rc.deg;
@@ -1237,6 +1254,9 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   // round trip 1: everything the search needs first
   int32_t lo = 0, hi = n_bins - 1;                 // the chunk of the first not-certain-miss index lies in [lo, hi]
   int32_t j1 = hi >= 64 ? (int32_t)(((int64_t)hi * (lane + 1)) >> 6) : (lane <= hi ? lane : hi);   // lane 63 probes hi
+#if defined(SRW_ATTR) && SRW_ATTR >= 3 && SRW_ATTR <= 4
+  { const int32_t ka = (int32_t)((double)r * (double)deg); served = 1; id_out = __builtin_amdgcn_readfirstlane(row[ka < deg ? ka : deg - 1].id); return ka < deg ? ka : deg - 1; }
+#endif
   const double b_last = BIN(n_bins - 1);
   double pq_last = 0.0, pq_j = 0.0, b_j = BIN(j1);
   if (!ABS) { pq_last = PQ[deg - 1]; pq_j = PQ[chunk_end(j1)]; }
@@ -1274,6 +1294,9 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   }
   // candidate-by-candidate evaluation of chunk jc, 256 candidates per round
   const int32_t k0 = (int32_t)((int64_t)jc << csh), k1 = chunk_end(jc);
+#if defined(SRW_ATTR) && (SRW_ATTR >= 2 && SRW_ATTR <= 4 || SRW_ATTR == 5)
+  if (SRW_ATTR != 5 || deg > 16384) { const int32_t ka = k0 + (int32_t)(__float_as_uint(r) % (uint32_t)(k1 - k0 + 1)); served = 1; id_out = __builtin_amdgcn_readfirstlane(row[ka].id); return ka; }
+#endif
   const double b_prev = jc ? BIN(jc - 1) : 0.0, b_this = BIN(jc);
   // exact value of the numerator just before the chunk, and the exact sum of the chunk's corrections
   // (inside the chunk the base prefix sums PQ[k] - PQ[k0-1] are not loaded: under the row certificate every partial sum of
@@ -1291,10 +1314,14 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   // q > 1 and p <= q: every correction (w - w/q for a member, w/p - w/q for a return edge) is >= 0; q < 1 and p >= q:
   // every one is <= 0.  Then "the chunk's corrections sum to exactly 0" means "no special in the chunk".
   const bool one_sign = (q_ > 1.0f && p_ <= q_) || (q_ < 1.0f && p_ >= q_);
+#if defined(SRW_ATTR) && SRW_ATTR >= 2 && SRW_ATTR <= 4
+  const bool no_specials = true;
+#else
   const bool no_specials = one_sign && chunk_corr == 0.0;
+#endif
   // a short N(prev): staged in LDS once (sorted, padded to a power of two), searched there
   int stage_levels = 0;
-  if (!no_specials && stage && !hubbits && m > 0 && m <= 1024) {
+  if (!no_specials && !cmask && stage && !hubbits && m > 0 && m <= 1024) {
     int P2 = 1; while (P2 < m) { P2 <<= 1; ++stage_levels; }
     for (int32_t t = lane; t < P2; t += 64) stage[t] = t < m ? B[t] : 0xFFFFFFFFu;
     if (stage_levels == 0) stage_levels = -1;               // m == 1: one compare, no search level
@@ -1302,7 +1329,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   }
   // a long N(prev) without a bitmap: its neighbor-set filter (device_common.h:bf_hash), if the graph has them
   const uint32_t *bf = nullptr; uint32_t bf_nw = 0;
-  if (BF && !no_specials && !stage_levels && !hubbits && g.bf_off && m >= BF_MIN_DEG) {
+  if (BF && !no_specials && !cmask && !stage_levels && !hubbits && g.bf_off && m >= BF_MIN_DEG) {
     const uint32_t bo = g.bf_off[xprev];
     if (bo != BF_NONE) { bf = g.bf_bits + bo; bf_nw = bf_words(m); }
   }
@@ -1335,8 +1362,17 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     for (int u = 0; u < PL; ++u) {
       xs[u] = (uint32_t)((int64_t)e[u].id - b.vmin); in[u] = false;
       want[u] = !no_specials && valid[u] && e[u].id != b.prev;
+#if defined(SRW_ATTR) && SRW_ATTR == 1
+      want[u] = false;
+#endif
     }
     if (no_specials) {
+    } else if (cmask) {                               // the membership of these 64 candidates was precomputed with the table: no probe
+#pragma unroll
+      for (int u = 0; u < PL; ++u) {
+        const unsigned long long mw = (base + u * 64 <= k1) ? cmask[(base >> 6) + u] : 0ull;
+        in[u] = want[u] && ((mw >> lane) & 1ull);
+      }
     } else if (stage_levels) {
       uint32_t pos[PL];
 #pragma unroll
@@ -1393,6 +1429,9 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       if (mm) {
         const int f = __ffsll((long long)mm) - 1;
         if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(e[u].id, f); return base + u * 64 + f; }
+#if defined(SRW_ATTR) && SRW_ATTR == 1
+        id_out = __builtin_amdgcn_readlane(e[u].id, f); return base + u * 64 + f;
+#endif
         if (!CHAIN) { if (S_out) *S_out = S; return CHAIN_NEEDED; }
         fallback = 1;
         const int32_t kk = wave_chain_pick(row, deg, b, r, S, &cm);
@@ -1402,6 +1441,9 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       carry += readlane_f64(incl, 63);
     }
   }
+#if defined(SRW_ATTR) && SRW_ATTR == 1
+  id_out = __builtin_amdgcn_readfirstlane(row[k1].id); return k1;
+#endif
   if (!CHAIN) { if (S_out) *S_out = S; return CHAIN_NEEDED; }
   fallback = 1;
   const int32_t kk = wave_chain_pick(row, deg, b, r, S, &cm);
@@ -1480,6 +1522,9 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   const int lane = lane_id();
   const Ent *row = g.ent + rc.off;
   const int32_t deg = rc.deg;
+#if defined(SRW_ATTR) && SRW_ATTR == 4
+  { const int32_t ka = (int32_t)((double)r * (double)deg); id_out = __builtin_amdgcn_readfirstlane(row[ka < deg ? ka : deg - 1].id); return ka < deg ? ka : deg - 1; }
+#endif
   const int ni = (deg + 63) >> 6;                  // <= 4
   float wv[4]; int32_t idv[4]; uint32_t mw[4];
 #pragma unroll
@@ -1575,7 +1620,9 @@ __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc
                                                float r, unsigned &fallback, unsigned &served, Member &tm, int32_t &id_out,
                                                uint32_t *stage /* 1024 words of the wave's LDS */, double *S_out = nullptr) {
   const BinGeom geo = bin_geometry(rc.deg, g.eb_min_sh, g.eb_cap);
-  return binned_resolve<true, BF, CHAIN>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage, S_out);
+  const unsigned long long *cmask = nullptr;
+  if (rc.deg <= g.eb_cm_max) cmask = reinterpret_cast<const unsigned long long *>(table + (size_t)eb_prefix_units(g.eb_f32 && (rc.flags & ROW_PQ_F32), geo.n_bins) * 8);
+  return binned_resolve<true, BF, CHAIN>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage, S_out, cmask);
 }
 
 }  // namespace srw

@@ -2294,6 +2294,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   // the hub pairs only (config 3: 41.8 / 59.7 / 77.0 / 111.9 GB at 64 / 128 / 256 / 512 chunks -> 376 / 448 / 497 / 513 M steps/s,
   // s45 / s47): the finest of 256 / 128 / 64 whose COMPLETE set fits next to 32 GB of bitmaps is taken.
   size_t hub_cap = want_eb ? (size_t)16 << 30 : (size_t)64 << 30;
+  size_t table_cap_used = 0;
   int eb_cap = EB_BINS;
   if (env_hub && *env_hub) hub_cap = (size_t)(atof(env_hub) * (double)((size_t)1 << 30));
   if (env_cap && *env_cap) eb_cap = atoi(env_cap);
@@ -2339,6 +2340,20 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
           g.eb_min_sh_sel = 8;
         }
       }
+      // Chunk masks (edge_tables.hip:eb_cm_select): the tables of the rows up to 16 384 (else 4 096) candidates also carry the pair's
+      // membership mask over the candidate positions, so that a located chunk is evaluated without a single membership probe — they
+      // come before the hub bitmaps, whose probes they replace (one HBM request per candidate of every located chunk whose N(prev)
+      // is too long for the LDS staging: 48 of the 62 requests of an average step at config 3, profiles/r04_request_attribution.md)
+      g.eb_cm_sel = 0;
+      if (need > 0 && !eb_mode && g.eb_min_sh_sel >= 6 && !getenv("SRW_EB_CM_MAX")) {
+        for (int cm : {16384, 4096}) {
+          g.eb_cm_sel = cm;
+          const size_t n = edge_tables_full_bytes(h, eb_mode, eb_cap);
+          if (n > 0 && n < ((size_t)230 << 30) && free_b > n + reserve + ((size_t)24 << 30)) { need = n; break; }
+          g.eb_cm_sel = 0;
+        }
+      }
+      if (need > table_cap) table_cap_used = (size_t)230 << 30;
       const size_t keep = need + reserve + ((size_t)8 << 30);
       if (!(env_hub && *env_hub) && want_hub && need > 0 && free_b > keep + ((size_t)16 << 30))
         hub_cap = std::min<size_t>(free_b - keep, (size_t)96 << 30);
@@ -2349,7 +2364,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   // ... and, last (they take what HBM is left), the per-edge bias tables: the most expensive (prev, curr) pairs get
   // their N(prev) ∩ N(curr) corrections precomputed once per (p, q) instead of once per visit
   if (want_eb) {
-    h->g.eb_budget_gb = drop_ehash ? 200 : 160;
+    h->g.eb_budget_gb = table_cap_used ? (table_cap_used >> 30) : drop_ehash ? 200 : 160;
     // The sizing above works from hipMemGetInfo; if an allocation of the build fails all the same (fragmentation), the
     // walk goes on with a coarser set, or with none (the on-the-fly samplers) — an optional accelerator never fails a walk.
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -2359,7 +2374,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
         (void)hipGetLastError();
         Graph &g = h->g;
         g.eb_bins.release(); g.em_bits.release(); g.has_eb = false; g.eb_complete = false; g.eb_tables = 0; g.eb_bytes = 0;
-        h->g.eb_budget_gb = 160; g.eb_min_sh_sel = 8;
+        h->g.eb_budget_gb = 160; g.eb_min_sh_sel = 8; g.eb_cm_sel = 0;
         if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] per-edge tables: %s — %s\n", e.what(), attempt == 0 && eb_cap > 32 ? "retrying with 32 chunks" : "walking without them");
         if (eb_cap <= 32) break;
       }

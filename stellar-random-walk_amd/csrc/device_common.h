@@ -78,6 +78,8 @@ struct alignas(32) AEnt {
 struct alignas(16) RevEnt { uint32_t cl, pos0; float w0; uint32_t pad; };
 
 struct PairSlot;
+// geometry policy of the per-edge tables (sampling.h:eb_pair_geometry): shared by the planner, the builder and the walk
+struct EbPolicy { int32_t min_sh, cap, cm_max, cm_min_du, fine_min_du, fine_sh, fine_cap, f32; };
 struct GraphView {
   const Row *rows;
   const Ent *ent;
@@ -134,7 +136,7 @@ struct GraphView {
   // rev[e] holds on a whole-graph handle (val = count << 24 | index in curr's sorted row, pad = input-order position of the first one)
   const PairSlot *rh;
   uint32_t rh_buckets;
-  int32_t eb_cm_max;       // rows of more than eb_mask_max and at most eb_cm_max candidates: the pair's table is followed by its chunk masks (0: none)
+  EbPolicy ebp;            // geometry of the standing per-edge tables (chunk sizes, chunk masks, finer tables of the pairs with a long N(prev))
   int32_t dbg_chain_deg;   // tests (SRW_DEBUG_CHAIN_DEG): sharded steps on rows at least this long are treated as draws on a CDF boundary (0: off)
 };
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;

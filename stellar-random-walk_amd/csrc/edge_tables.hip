@@ -43,11 +43,8 @@ struct EbSel {          // which pairs get a table
   int32_t mask_max;     // rows of curr up to this many candidates: membership mask (0: none)
   int32_t min_deg;      // bins tables: shortest row of curr
   int64_t min_cost;     // bins tables: smallest priority (saved wave-cycles per 64 B of table, see eb_units) that still fits the budget
-  int32_t min_sh;       // bins tables: smallest chunk shift
   int32_t has_ehash, has_hub;
-  int32_t f32;          // tables of ROW_PQ_F32 rows are stored as floats
-  int32_t bins_cap;     // chunks per table at most (GraphView::eb_cap)
-  int32_t cm_max;       // bins tables of rows up to this many candidates are followed by the pair's chunk masks (0: none; needs min_sh >= 6)
+  EbPolicy pol;         // bins tables: chunk sizes, chunk masks, finer tables of the pairs with a long N(prev) (sampling.h:eb_pair_geometry)
 };
 constexpr int INLINE_MAX_DEG = 32;   // masks of rows up to 32 candidates live in eb_off[e] itself
 
@@ -64,8 +61,8 @@ __device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s
   if (rv.deg < s.min_deg || !(rv.flags & ROW_PQ_OK)) return 0u;
   const BinnedCost c = binned_cost(rv.deg, ru.deg, s.has_hub && (ru.flags >> ROW_HUB_SHIFT) != 0u, s.has_ehash != 0);
   const int64_t cost = c.c1 < c.c2 ? (c.c1 < c.cw ? c.c1 : c.cw) : (c.c2 < c.cw ? c.c2 : c.cw);
-  const BinGeom geo = bin_geometry(rv.deg, s.min_sh, s.bins_cap);
-  const uint32_t units = eb_prefix_units(s.f32 && (rv.flags & ROW_PQ_F32), geo.n_bins) + (rv.deg <= s.cm_max ? eb_cmask_units(rv.deg) : 0u);
+  const PairGeom geo = eb_pair_geometry(rv.deg, ru.deg, s.pol);
+  const uint32_t units = eb_layout(s.pol.f32 && (rv.flags & ROW_PQ_F32), geo.n_bins, geo.cmask, rv.deg).units;
   // priority = wave-cycles a table saves per visit, per 64 bytes of table: an on-the-fly step costs its intersection
   // work plus ~20 us of dependent round trips whatever its size (measured: 38 .. 43 us per P1 / W step at config 3
   // against 10 .. 25 us per table step), so short cheap tables are worth as much per byte as the hub <-> hub ones
@@ -272,9 +269,9 @@ __global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, ShardSel ss, EbS
 constexpr int EB_LDS_WORDS = 2 * BIN_CAP + HCHUNK;      // binned_fill's bins + the staged ids of N(prev): 6 KB per wave
 template <bool SH>
 __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
-                                                     float q, int32_t min_sh, int32_t mask_max, int32_t bins_cap, int32_t cm_max, const uint32_t *__restrict__ eb_off,
+                                                     float q, int32_t mask_max, EbPolicy pol, const uint32_t *__restrict__ eb_off,
                                                      double *__restrict__ eb_bins, uint32_t *__restrict__ em_bits, unsigned long long *cursor,
-                                                     unsigned long long *strat_count /* [8] */, int fill_tune) {
+                                                     unsigned long long *strat_count /* [8] */, int fill_tune, double *gscratch, int64_t gs_stride) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][EB_LDS_WORDS];
   const int lane = lane_id();
   uint32_t *mine = lds[threadIdx.x >> 6];
@@ -339,12 +336,18 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
       const unsigned long long t_hdr = wall_clock64();
       tt[1] += t_hdr - t_it0;
 #endif
-      const BinGeom gc = bin_geometry(rv.deg, min_sh, bins_cap);
-      const BinGeom gf = gc.csh < 6 ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
+      const PairGeom pg = eb_pair_geometry(rv.deg, ru.deg, pol);
+      BinGeom gc; gc.csh = pg.csh; gc.n_bins = pg.n_bins;
+      // more chunks than the wave's LDS holds bins for (the finer tables of the pairs with a long N(prev)): the bins live in this
+      // wave's slice of an HBM scratch (exact f64 atomics: every partial sum is exact in any order) and are filled at the table's own granularity
+      const bool big = gc.n_bins > BIN_CAP;
+      const BinGeom gf = (big || gc.csh < 6) ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
+      double *gbins = big ? gscratch + ((int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) * gs_stride : nullptr;
       unsigned long long ab = 0; unsigned su = 0;
-      // chunk masks (rows up to cm_max <= EB_CM_LIMIT candidates: at most 256 fill bins, the upper half of the bins' LDS is free)
-      uint32_t *mbits = (rv.deg <= cm_max) ? mine + BIN_CAP : nullptr;
-      binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits);
+      // chunk masks (rows of at most EB_CM_LIMIT candidates: at most 256 fill bins, the upper half of the bins' LDS is free)
+      uint32_t *mbits = pg.cmask ? mine + BIN_CAP : nullptr;
+      if (big) binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K, true>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits, gbins);
+      else binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K, false>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits);
       ns[su & 7] += 1;
 #ifdef SRW_PHASE_TIMING
       const unsigned long long t_fill = wall_clock64();
@@ -354,18 +357,28 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
       double *out = eb_bins + (size_t)tab_word * 8;
       const int up = gc.csh - gf.csh;
       const double *PQ = g.pq + rv.off;            // the table keeps the complete numerator A'_end(j) = PQ[end_j] + corrections
-      const bool as_f32 = g.eb_f32 && (rv.flags & ROW_PQ_F32);      // every such sum is exactly representable in binary32
-      for (int32_t j = lane; j < gc.n_bins; j += 64) {
-        const int64_t fi = (((int64_t)j + 1) << up) - 1;
-        const int64_t ke = (((int64_t)j + 1) << gc.csh) - 1;
-        const double a = PQ[ke < rv.deg ? ke : rv.deg - 1] + bins[fi < gf.n_bins ? fi : gf.n_bins - 1];
-        if (as_f32) {
-          reinterpret_cast<float *>(out)[j] = (float)a;
-          if ((double)(float)a != a) atomicAdd(&strat_count[7], 1ull);      // must never happen (pq_row_f32's bound)
-        } else out[j] = a;
+      const bool as_f32 = pol.f32 && (rv.flags & ROW_PQ_F32);      // every such sum is exactly representable in binary32
+      const EbLayout lay = eb_layout(as_f32, gc.n_bins, pg.cmask, rv.deg);
+      // level 0 = the chunk prefixes; level 1 / 2 = the last element of every block of 64 of the level below (the walk's search tree)
+      for (int L = 0; L < 3; ++L) {
+        const int32_t cnt = L == 0 ? gc.n_bins : L == 1 ? lay.n1 : lay.n2;
+        double *lo_ = out + (size_t)(L == 0 ? lay.l0_off : L == 1 ? lay.l1_off : lay.l2_off) * 8;
+        for (int32_t t = lane; t < cnt; t += 64) {
+          const int64_t je = (((int64_t)t + 1) << (6 * L)) - 1;
+          const int64_t j = je < gc.n_bins ? je : gc.n_bins - 1;          // the chunk this element is the prefix of
+          const int64_t fi = ((j + 1) << up) - 1;
+          const int64_t ke = ((j + 1) << gc.csh) - 1;
+          const int64_t fb = fi < gf.n_bins ? fi : gf.n_bins - 1;
+          const double corr = big ? __hip_atomic_load(gbins + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bins[fb];
+          const double a = PQ[ke < rv.deg ? ke : rv.deg - 1] + corr;
+          if (as_f32) {
+            reinterpret_cast<float *>(lo_)[t] = (float)a;
+            if ((double)(float)a != a) atomicAdd(&strat_count[7], 1ull);      // must never happen (pq_row_f32's bound)
+          } else lo_[t] = a;
+        }
       }
       if (mbits) {
-        unsigned long long *mo = reinterpret_cast<unsigned long long *>(out + (size_t)eb_prefix_units(as_f32, gc.n_bins) * 8);
+        unsigned long long *mo = reinterpret_cast<unsigned long long *>(out + (size_t)lay.cm_off * 8);
         const int32_t n_mw = (rv.deg + 63) >> 6, n_w32 = (rv.deg + 31) >> 5;
         for (int32_t t = lane; t < n_mw; t += 64)
           mo[t] = (unsigned long long)mbits[2 * t] | ((2 * t + 1 < n_w32) ? ((unsigned long long)mbits[2 * t + 1] << 32) : 0ull);
@@ -437,6 +450,21 @@ static int32_t eb_cm_select(const Graph &g, int mode, int min_sh) {
   const int32_t v = e && *e ? atoi(e) : g.eb_cm_sel;
   return v < MASK_MAX_DEG ? 0 : v > EB_CM_LIMIT ? EB_CM_LIMIT : v;
 }
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+// The geometry of the next set of tables: Graph::eb_min_sh_sel / eb_cm_sel / eb_fine_cap_sel are the planners' choices
+// (prepare_tables, prepare_shard_tables); mode 1 (tests): chunks of 4 candidates, no masks, no finer tables.
+static EbPolicy eb_policy(const Graph &g, int mode, int bins_cap) {
+  EbPolicy P;
+  P.min_sh = mode ? 2 : eb_min_shift(g); P.cap = bins_cap;
+  P.cm_max = eb_cm_select(g, mode, P.min_sh);
+  P.cm_min_du = std::max(0, env_int("SRW_EB_CM_MIN_DU", 1024));      // N(prev) up to 1 024 ids: staged in LDS by the walk, searched there
+  P.fine_min_du = std::max(0, env_int("SRW_EB_FINE_MIN_DU", 1024));
+  P.fine_sh = std::min(12, std::max(6, env_int("SRW_EB_FINE_SH", 6)));
+  P.fine_cap = mode ? 0 : std::min(EB_FINE_CAP_LIMIT, std::max(0, env_int("SRW_EB_FINE_CAP", g.eb_fine_cap_sel)));
+  if (P.fine_cap <= P.cap) P.fine_cap = 0;
+  { const char *e = getenv("SRW_EB_NO_F32"); P.f32 = (e && *e == '1') ? 0 : 1; }
+  return P;
+}
 // HBM a COMPLETE set of tables would take (every pair into a certified row + every mask + offsets + the work list):
 // prepare_tables sizes the hub bitmaps with what is left beside it.  0: no tables possible.
 size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
@@ -445,11 +473,10 @@ size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
   hipStream_t st = h->stream;
   EbSel sel;
   sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
-  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : eb_min_shift(g); sel.min_cost = 0;
+  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_cost = 0;
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
-  { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
   sel.has_ehash = 1; sel.has_hub = 1;               // (they only move priorities, not sizes)
-  sel.bins_cap = bins_cap; sel.cm_max = eb_cm_select(g, mode, sel.min_sh);
+  sel.pol = eb_policy(g, mode, bins_cap);
   DevBuf<unsigned long long> cursor, hist;
   cursor.alloc(1); hist.alloc(128);
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
@@ -472,7 +499,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   if (const char *e = getenv("SRW_EB_FAIL_ABOVE"); e && *e && bins_cap > atoi(e))      // tests: prepare_tables' fallback
     throw Error(SRW_ERR_NOMEM, "simulated allocation failure of the per-edge tables (SRW_EB_FAIL_ABOVE)");
   { const char *e = getenv("SRW_EB_NO_F32"); const int want_f32 = (e && *e == '1') ? 0 : 1;
-    if (g.has_eb && !g.eb_sharded && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.eb_f32 == want_f32 && g.eb_cap == bins_cap) return; }
+    if (g.has_eb && !g.eb_sharded && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == mode && g.ebp.f32 == want_f32 && g.ebp.cap == bins_cap) return; }
   hipStream_t st = h->stream;
   g.has_eb = false; g.eb_tables = 0; g.eb_bytes = 0; g.eb_build_ms = 0.0; g.eb_complete = false;
   g.eb_bins.release(); g.em_bits.release();
@@ -481,14 +508,13 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   EbSel sel;
   // mode 1 (tests): bins tables for every certified row, chunks of 4 candidates, no masks
   sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
-  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : eb_min_shift(g);
+  sel.min_deg = mode ? 1 : MASK_MAX_DEG;
   { const char *e = getenv("SRW_EB_MIN_COST"); sel.min_cost = (!mode && e && *e) ? atoll(e) : 0; }
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
-  { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
-  g.eb_f32 = sel.f32;
-  sel.bins_cap = bins_cap; g.eb_cap = bins_cap; sel.cm_max = eb_cm_select(g, mode, sel.min_sh); g.eb_cm_max = sel.cm_max;
+  sel.pol = eb_policy(g, mode, bins_cap);
+  g.ebp = sel.pol; g.eb_f32 = sel.pol.f32; g.eb_cap = bins_cap;
   sel.has_ehash = (g.has_ehash && g.use_ehash) ? 1 : 0; sel.has_hub = (g.has_hub && g.use_hub) ? 1 : 0;
-  g.eb_min_sh = sel.min_sh;
+  g.eb_min_sh = sel.pol.min_sh;
   // budget: what is free now minus the offsets and a reserve for the walk's own buffers
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -555,11 +581,16 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
     SRW_HIP(hipGetLastError());
   }
   unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // tables of more chunks than the build's LDS holds bins for: one f64 per chunk and wave in an HBM scratch
+  DevBuf<double> gscratch;
+  const int64_t gs_stride = sel.pol.fine_cap > BIN_CAP ? (int64_t)sel.pol.fine_cap : 0;
+  if (gs_stride) gscratch.alloc((size_t)blocks * (TPB / 64) * (size_t)gs_stride);
   if (all_pairs) {
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
     SRW_HIP(hipMemsetAsync(hist.p, 0, 16 * 8, st));
-    hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
-                       sel.bins_cap, sel.cm_max, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0);
+    hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.mask_max,
+                       sel.pol, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0,
+                       gscratch.p, gs_stride);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   }
@@ -580,8 +611,11 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   g.eb_bytes = (int64_t)(units * 64 + munits * 16 + (unsigned long long)g.n_entries * 4);
   g.eb_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("SRW_TIMING"))
+    fprintf(stderr, "[edge tables] chunks of >= %d candidates, chunk masks up to %d candidates (N(prev) > %d), up to %d chunks for unmasked pairs with N(prev) > %d; ",
+            1 << sel.pol.min_sh, sel.pol.cm_max, sel.pol.cm_min_du, sel.pol.fine_cap ? sel.pol.fine_cap : sel.pol.cap, sel.pol.fine_min_du);
+  if (getenv("SRW_TIMING"))
     fprintf(stderr, "[edge tables] up to %d chunks per table; %llu bins tables (%.2f GB, min priority %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
-            "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", sel.bins_cap, pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
+            "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", sel.pol.cap, pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
             sc[3], sc[4], mpairs, (double)munits * 16 / 1e9, (double)g.n_entries * 4 / 1e9, g.eb_build_ms);
 }
 
@@ -599,10 +633,9 @@ struct ShardTabPlan { unsigned long long units, pairs, munits, mpairs, inl; size
 EbSel shard_sel(const Graph &g, int mode, int bins_cap) {
   EbSel sel;
   sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
-  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_sh = mode ? 2 : eb_min_shift(g); sel.min_cost = 0;
+  sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_cost = 0;
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
-  { const char *e = getenv("SRW_EB_NO_F32"); sel.f32 = (e && *e == '1') ? 0 : 1; }
-  sel.has_ehash = 0; sel.has_hub = 1; sel.bins_cap = bins_cap; sel.cm_max = eb_cm_select(g, mode, sel.min_sh);
+  sel.has_ehash = 0; sel.has_hub = 1; sel.pol = eb_policy(g, mode, bins_cap);
   return sel;
 }
 
@@ -636,7 +669,7 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
   const auto t0 = std::chrono::steady_clock::now();
   const ShardSel ss{h->cfg.rank, h->cfg.world};
   const int blocks = h->n_cus * 8;
-  g.eb_f32 = sel.f32; g.eb_cap = bins_cap; g.eb_min_sh = sel.min_sh; g.eb_mask_max = sel.mask_max; g.eb_cm_max = sel.cm_max;
+  g.ebp = sel.pol; g.eb_f32 = sel.pol.f32; g.eb_cap = bins_cap; g.eb_min_sh = sel.pol.min_sh; g.eb_mask_max = sel.mask_max;
   DevBuf<unsigned long long> cursor, hist, row_units, row_munits, row_pairs;
   cursor.alloc(1); hist.alloc(8);
   row_units.alloc((size_t)g.n_slots + 1); row_munits.alloc((size_t)g.n_slots + 1); row_pairs.alloc((size_t)g.n_slots + 1);
@@ -670,11 +703,16 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
     SRW_HIP(hipGetLastError());
   }
   unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // tables of more chunks than the build's LDS holds bins for: one f64 per chunk and wave in an HBM scratch
+  DevBuf<double> gscratch;
+  const int64_t gs_stride = sel.pol.fine_cap > BIN_CAP ? (int64_t)sel.pol.fine_cap : 0;
+  if (gs_stride) gscratch.alloc((size_t)blocks * (TPB / 64) * (size_t)gs_stride);
   if (all_pairs) {
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
     SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
-    hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.min_sh, sel.mask_max,
-                       sel.bins_cap, sel.cm_max, item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0);
+    hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.mask_max,
+                       sel.pol, item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0,
+                       gscratch.p, gs_stride);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   }
@@ -689,7 +727,7 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
   g.eb_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("SRW_TIMING"))
     fprintf(stderr, "[shard %d/%d edge tables] up to %d chunks per table; %llu bins tables (%.2f GB; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
-            "+ %llu inline masks; pair hash %.2f GB; built in %.0f ms\n", h->cfg.rank, h->cfg.world, sel.bins_cap, pl.pairs, (double)pl.units * 64 / 1e9, sc[1], sc[2],
+            "+ %llu inline masks; pair hash %.2f GB; built in %.0f ms\n", h->cfg.rank, h->cfg.world, sel.pol.cap, pl.pairs, (double)pl.units * 64 / 1e9, sc[1], sc[2],
             sc[3], sc[4], pl.mpairs, (double)pl.munits * 16 / 1e9, pl.inl, (double)pl.buckets * 64 / 1e9, g.eb_build_ms);
 }
 }  // namespace
@@ -713,7 +751,7 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
   const size_t reserve = env_gb("SRW_EB_RESERVE_GB", 16);
   const char *env_cap = getenv("SRW_EB_CHUNKS");
   ShardTabPlan pl; EbSel sel; int cap_sel = 0;
-  g.eb_min_sh_sel = 8;
+  g.eb_min_sh_sel = 8; g.eb_cm_sel = 0; g.eb_fine_cap_sel = 0;
   for (int cap : {256, 128, 64, 32}) {
     if (env_cap && *env_cap) cap = std::min(std::max(atoi(env_cap), 8), BIN_CAP);
     sel = shard_sel(g, mode, cap);
@@ -737,6 +775,32 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
       if (shard_plan(h, s2, p2) && p2.bytes * (size_t)std::max(1, h->dev_share) + room < free_b && p2.bytes < env_gb("SRW_EB_BUDGET_GB", 200)) { sel = s2; pl = p2; break; }   // (virtual shards of one device share its HBM)
       g.eb_min_sh_sel = 8;
     }
+  }
+  // ... then the chunk masks of the rows up to 16 384 / 4 096 candidates and the finer tables of the unmasked pairs with a long N(prev)
+  // (sampling.h:eb_pair_geometry), under the same condition
+  if (!mode && g.eb_min_sh_sel >= 6) {
+    uint64_t ehs = 1024;
+    while (ehs < (uint64_t)g.n_entries_global + (uint64_t)g.n_entries_global / 2) ehs <<= 1;
+    const size_t room = reserve + (g.has_ehash ? 0 : (size_t)ehs * 8) + ((size_t)24 << 30);
+    auto fits = [&](EbSel &s2, ShardTabPlan &p2) {
+      s2 = shard_sel(g, mode, cap_sel);
+      return shard_plan(h, s2, p2) && p2.bytes * (size_t)std::max(1, h->dev_share) + room < free_b && p2.bytes < env_gb("SRW_EB_BUDGET_GB", 230);
+    };
+    if (!getenv("SRW_EB_CM_MAX"))
+      for (int cm : {16384, 4096}) {
+        g.eb_cm_sel = cm;
+        EbSel s2; ShardTabPlan p2;
+        if (fits(s2, p2)) { sel = s2; pl = p2; break; }
+        g.eb_cm_sel = 0;
+      }
+    if (!getenv("SRW_EB_FINE_CAP"))
+      for (int fc : {4096, 1024, 512}) {
+        if (fc <= cap_sel) break;
+        g.eb_fine_cap_sel = fc;
+        EbSel s2; ShardTabPlan p2;
+        if (fits(s2, p2)) { sel = s2; pl = p2; break; }
+        g.eb_fine_cap_sel = 0;
+      }
   }
   // 2. the located chunk's probes of a long N(prev), with what the tables leave (a shard of a sharded graph has room: its
   //    tables are 1 / world of the set): the edge hash set of the whole graph (one probe per candidate) or, when it does not

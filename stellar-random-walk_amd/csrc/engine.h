@@ -113,8 +113,9 @@ struct Graph {
   bool eb_sharded = false;        // the standing per-edge tables are keyed by the pair hash (built by build_shard_edge_tables)
   DevBuf<PairSlot> rh;            // sharded q == 1 walks: return edges of the pairs into this shard's rows (build_shard_rev_hash)
   uint32_t rh_buckets = 0; bool has_rh = false;
-  int32_t eb_cm_max = 0;          // standing tables: rows up to this many candidates carry chunk masks (GraphView::eb_cm_max)
-  int32_t eb_cm_sel = 0;          // ... what the next table build uses (prepare_tables / prepare_shard_tables choose it)
+  EbPolicy ebp = {8, 64, 0, 1024, 1024, 6, 0, 1};       // geometry of the standing per-edge tables (GraphView::ebp)
+  int32_t eb_cm_sel = 0;          // what the next table build uses (prepare_tables / prepare_shard_tables choose them): chunk masks up to this row length,
+  int32_t eb_fine_cap_sel = 0;    // ... chunks per table at most for the pairs with a long N(prev) and no mask (0: no finer tables)
   int32_t eb_min_sh_sel = 8;      // log2 of the smallest table chunk the next table build uses (prepare_tables / prepare_shard_tables choose it)
   int32_t dbg_chain_deg = 0;      // SRW_DEBUG_CHAIN_DEG (read by run_shard_superstep)
   bool has_cfo_local = false;     // sharded: compact first-order records over the LOCAL rows (guide + ids; their links are not used)
@@ -133,7 +134,7 @@ struct Graph {
                      (has_eb && use_eb && !eb_sharded) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
                      has_rev ? rev.p : nullptr, eb_cap, compact ? orig_id.p : nullptr,
                      (has_bf && use_eb && !(has_ehash && use_ehash)) ? bf_off.p : nullptr, bf_bits.p,
-                     (has_eb && use_eb && eb_sharded) ? ph.p : nullptr, ph_buckets, has_rh ? rh.p : nullptr, rh_buckets, eb_cm_max, dbg_chain_deg}; }
+                     (has_eb && use_eb && eb_sharded) ? ph.p : nullptr, ph_buckets, has_rh ? rh.p : nullptr, rh_buckets, ebp, dbg_chain_deg}; }
   // id <-> slot at the boundary (api.cpp): -1 if the id cannot be a vertex of this graph
   int64_t slot_of_id(int32_t v) const {
     if (!compact) { const int64_t s = (int64_t)v - vmin; return (s < 0 || s >= n_slots) ? -1 : s; }

@@ -928,10 +928,46 @@ __device__ inline void wave_lower_bound_multi(LowerBound (&s)[K]) {
 
 // Chunking of a row's candidate positions: chunk j = positions [j << csh, (j + 1) << csh), at most `cap` chunks.
 struct BinGeom { int csh; int32_t n_bins; };
-// 64-byte units of a pair's chunk-prefix table (floats where every prefix of the row is binary32-exact), and of the chunk masks
-// that follow it for rows of at most GraphView::eb_cm_max candidates: one 64-bit word per 64 candidate positions
+// ---- geometry of the per-edge tables (edge_tables.hip), shared by the planner, the builder and the walk -------------------------
+// A pair (prev -> curr) with dv candidates in N(curr) and du ids in N(prev) gets chunks of 2^csh candidates:
+//   * the base rule: at least 2^min_sh candidates per chunk, at most `cap` chunks (bin_geometry);
+//   * rows of at most cm_max candidates whose N(prev) is longer than cm_min_du (what the walk stages in LDS and searches
+//     there for free) also get CHUNK MASKS: the pair's membership bits over the candidate positions, one 64-bit word per 64
+//     positions — the located chunk is then evaluated without a single membership probe (profiles/r04_request_attribution.md:
+//     the probes were 48 of the 62 HBM requests of an average step at config 3);
+//   * pairs WITHOUT a mask whose N(prev) is longer than fine_min_du — every candidate of their located chunk costs one probe, one
+//     HBM request — get finer tables: chunks of at least 2^fine_sh candidates, at most fine_cap of them (0: off).
+// A table of more than 64 chunks is a 64-ary tree: level 0 = the n chunk prefixes, level 1 = every 64th of them (the last
+// element of each block of 64), level 2 = every 64th of level 1 — a search reads one block of <= 64 values per level (<= 4 lines
+// of floats) instead of striding over the whole table, and S = the last element of the top level.  Layout of a pair's block,
+// each part padded to 64 bytes: [level 2][level 1][level 0][chunk masks].
+struct PairGeom { int csh; int32_t n_bins; bool cmask; };
+__host__ __device__ inline BinGeom bin_geometry(int32_t deg, int min_sh, int cap);
+__host__ __device__ inline PairGeom eb_pair_geometry(int32_t dv, int32_t du, const EbPolicy &P) {
+  const BinGeom b = bin_geometry(dv, P.min_sh, P.cap);
+  PairGeom g; g.csh = b.csh; g.n_bins = b.n_bins; g.cmask = false;
+  if (dv <= P.cm_max && du > P.cm_min_du && b.csh >= 6) g.cmask = true;
+  else if (P.fine_cap > 0 && du > P.fine_min_du && P.fine_sh >= 6) {
+    const BinGeom f = bin_geometry(dv, P.fine_sh, P.fine_cap);
+    if (f.csh < b.csh) { g.csh = f.csh; g.n_bins = f.n_bins; }
+  }
+  return g;
+}
 __host__ __device__ inline uint32_t eb_prefix_units(bool f32, int32_t n_bins) { return f32 ? (uint32_t)((n_bins + 15) >> 4) : (uint32_t)((n_bins + 7) >> 3); }
 __host__ __device__ inline uint32_t eb_cmask_units(int32_t deg) { return (uint32_t)((((deg + 63) >> 6) + 7) >> 3); }
+struct EbLayout { uint32_t l2_off, l1_off, l0_off, cm_off, units; int32_t n1, n2; };   // offsets in 64-byte units from the pair's block
+__host__ __device__ inline EbLayout eb_layout(bool f32, int32_t n_bins, bool cmask, int32_t dv) {
+  EbLayout L;
+  L.n1 = n_bins > 64 ? (n_bins + 63) >> 6 : 0;
+  L.n2 = L.n1 > 64 ? (L.n1 + 63) >> 6 : 0;          // (at most 64: tables have at most 2^18 chunks)
+  L.l2_off = 0u;
+  L.l1_off = L.n2 ? eb_prefix_units(f32, L.n2) : 0u;
+  L.l0_off = L.l1_off + (L.n1 ? eb_prefix_units(f32, L.n1) : 0u);
+  L.cm_off = L.l0_off + eb_prefix_units(f32, n_bins);
+  L.units = L.cm_off + (cmask ? eb_cmask_units(dv) : 0u);
+  return L;
+}
+constexpr int32_t EB_FINE_CAP_LIMIT = 32768;     // chunks of a table at most (the build keeps one f64 per chunk and wave in an HBM scratch beyond BIN_CAP)
 constexpr int32_t EB_CM_LIMIT = 16384;         // the build keeps the mask of one pair in 2 KB of the wave's LDS
 __host__ __device__ inline BinGeom bin_geometry(int32_t deg, int min_sh, int cap) {
   BinGeom g; g.csh = min_sh;
@@ -959,19 +995,22 @@ __host__ __device__ inline BinnedCost binned_cost(int32_t deg, int32_t m, bool h
 // tune: 0 = automatic strategy, 1 = P1, 2 = P2, 3 = W, 4 = P3 if prev has a bitmap (tests force each one)
 // PF: rounds of candidates the sorted-chunk intersection keeps in flight ahead of the one it works on (12 VGPRs each); P1K: binary
 // searches per lane in lockstep in P1.  Both are experiment parameters: 2 / 8 did not move the table build (profiles/r03_eb_build.md)
-template <int PF = 1, int P1K = 2>
+// GB (edge_tables.hip, tables of more chunks than BIN_CAP): the bins are `gbins`, a slice of an HBM scratch owned by this wave
+template <int PF = 1, int P1K = 2, bool GB = false>
 __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias &b, uint32_t *lds, int tune,
                                    const BinGeom geo, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used,
-                                   uint32_t *mbits = nullptr /* edge_tables.hip: LDS bitmap over curr's positions, bit k = candidate k is in N(prev) */) {
+                                   uint32_t *mbits = nullptr /* edge_tables.hip: LDS bitmap over curr's positions, bit k = candidate k is in N(prev) */,
+                                   double *gbins = nullptr) {
   const int32_t deg = rc.deg;
   const int lane = lane_id();
-  double *bins = reinterpret_cast<double *>(lds);
+  double *bins = GB ? gbins : reinterpret_cast<double *>(lds);
   uint32_t *win = lds + 2 * BIN_CAP;
   SRW_T0(tm);
   const int csh = geo.csh;
   const int32_t n_bins = geo.n_bins;
   for (int t = lane; t < n_bins; t += 64) bins[t] = 0.0;
   if (mbits) for (int t = lane; t < ((deg + 31) >> 5); t += 64) mbits[t] = 0u;
+  if (GB) __threadfence();                            // the zeros reach L2 before the first atomic does
   __builtin_amdgcn_wave_barrier();
   const Ent *row = g.ent + rc.off;
   const uint32_t *cs = g.sids + rc.off, *cp = g.sperm + rc.off;
@@ -1191,7 +1230,18 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
   SRW_T0(tm);
 #endif
   // inclusive prefix over the bins, in place (exact additions)
-  {
+  if (GB) {
+    __threadfence();                                  // every atomic of this wave has been performed
+    double carry = 0.0;
+    for (int32_t base = 0; base < n_bins; base += 64) {
+      const int32_t j = base + lane;
+      const double v = j < n_bins ? __hip_atomic_load(bins + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      const double incl = carry + wave_incl_scan_f64(v);
+      if (j < n_bins) __hip_atomic_store(bins + j, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      carry = readlane_f64(incl, 63);
+    }
+    __threadfence();
+  } else {
     constexpr int PER = BIN_CAP / 64;
     double loc[PER];
     double run = 0.0;
@@ -1249,20 +1299,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   const double *PQ = g.pq + rc.off;
   auto chunk_end = [&](int32_t j) { const int64_t e = (((int64_t)j + 1) << csh) - 1; return (int32_t)(e < deg ? e : deg - 1); };
   // tables of rows whose every sum is binary32-exact are stored as floats (edge_tables.hip); LDS bins are always f64
-  const bool f32t = ABS && g.eb_f32 && (rc.flags & ROW_PQ_F32);
-  auto BIN = [&](int32_t j) { return f32t ? (double)reinterpret_cast<const float *>(bins)[j] : bins[j]; };
-  // round trip 1: everything the search needs first
-  int32_t lo = 0, hi = n_bins - 1;                 // the chunk of the first not-certain-miss index lies in [lo, hi]
-  int32_t j1 = hi >= 64 ? (int32_t)(((int64_t)hi * (lane + 1)) >> 6) : (lane <= hi ? lane : hi);   // lane 63 probes hi
-#if defined(SRW_ATTR) && SRW_ATTR >= 3 && SRW_ATTR <= 4
-  { const int32_t ka = (int32_t)((double)r * (double)deg); served = 1; id_out = __builtin_amdgcn_readfirstlane(row[ka < deg ? ka : deg - 1].id); return ka < deg ? ka : deg - 1; }
-#endif
-  const double b_last = BIN(n_bins - 1);
-  double pq_last = 0.0, pq_j = 0.0, b_j = BIN(j1);
-  if (!ABS) { pq_last = PQ[deg - 1]; pq_j = PQ[chunk_end(j1)]; }
-  const double S = pq_last + b_last;
-  if (!(S > 0.0)) return -1;
-  if (!CHAIN && S_out && g.dbg_chain_deg && deg >= g.dbg_chain_deg) { *S_out = S; return CHAIN_NEEDED; }   // tests: the chain kernels on every long row
+  const bool f32t = ABS && g.ebp.f32 && (rc.flags & ROW_PQ_F32);
   const double p = (double)r;
   // Certified compares without a divide.  The reference's acc_k = sum of fl(w'_i / S) differs from num / S (num exact)
   // by at most (k + 2) u num / S.  With t = (k + 8) 2^-51 = 4 (k + 8) u:
@@ -1270,55 +1307,106 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   //   fl(num (1 - t)) >= fl(p S)  =>  num (1 - t)(1 + 3u) >= p S =>  (num / S)(1 - (k + 2) u) >= p  : a CERTAIN hit
   // (1 +- t is exact in f64; each product rounds once).  NaN compares false both ways -> "not a certain miss, not a
   // certain hit" -> the sequential chain, as before.
-  const double pS = p * S;
+  double S = 0.0, pS = 0.0;
   auto not_miss = [&](int32_t k, double num) { return !(num * (1.0 + (double)(k + 8) * 0x1p-51) < pS); };
   auto sure_hit = [&](int32_t k, double num) { return num * (1.0 - (double)(k + 8) * 0x1p-51) >= pS; };
-  while (hi - lo >= 64) {
-    const unsigned long long mm = __ballot(not_miss(chunk_end(j1), pq_j + b_j));
-    if (!mm) { id_out = row[0].id; return 0; }      // even the last candidate is a certain miss -> edges.head
-    const int f = __ffsll((long long)mm) - 1;
-    const int32_t jf = __builtin_amdgcn_readlane(j1, f);
-    const int32_t jprev = f ? __builtin_amdgcn_readlane(j1, f - 1) : lo - 1;
-    hi = jf; lo = jprev + 1;
-    const int64_t span = (int64_t)hi - lo;
-    j1 = span >= 64 ? lo + (int32_t)((span * (lane + 1)) >> 6) : (lo + lane <= hi ? lo + lane : hi);
-    b_j = BIN(j1);
-    if (!ABS) pq_j = PQ[chunk_end(j1)];
-  }
   int32_t jc;
-  {
-    const bool nm = lo + lane <= hi && not_miss(chunk_end(j1), pq_j + b_j);
-    const unsigned long long mm = __ballot(nm);
-    if (!mm) { id_out = row[0].id; return 0; }
-    jc = lo + (__ffsll((long long)mm) - 1);
+  double b_prev = 0.0, b_this = 0.0;
+  if constexpr (ABS) {
+    // the pair's table in HBM: a 64-ary tree over the chunk prefixes (eb_layout), one block of <= 64 values per level;
+    // S is the last element of the top level
+    const EbLayout lay = eb_layout(f32t, n_bins, false, 0);
+    const int nlev = lay.n2 ? 3 : lay.n1 ? 2 : 1;
+    int32_t blk = 0;
+    double prev_val = 0.0;                            // prefix just before the block being searched
+    jc = 0;
+    for (int L = nlev - 1; L >= 0; --L) {
+      const uint32_t off = L == 2 ? lay.l2_off : L == 1 ? lay.l1_off : lay.l0_off;
+      const int32_t cnt = L == 2 ? lay.n2 : L == 1 ? lay.n1 : n_bins;
+      const int32_t i = blk * 64 + lane;
+      const bool in_r = i < cnt;
+      double v = 0.0;
+      if (in_r) v = f32t ? (double)reinterpret_cast<const float *>(bins + (size_t)off * 8)[i] : bins[(size_t)off * 8 + i];
+      if (L == nlev - 1) {
+        S = readlane_f64(v, cnt - 1);               // (the top level has at most 64 elements)
+        if (!(S > 0.0)) return -1;
+        if (!CHAIN && S_out && g.dbg_chain_deg && deg >= g.dbg_chain_deg) { *S_out = S; return CHAIN_NEEDED; }   // tests: the chain kernels on every long row
+        pS = p * S;
+      }
+      const int64_t je = (((int64_t)i + 1) << (6 * L)) - 1;      // the chunk this element is the prefix of
+      const int32_t j = (int32_t)(je < n_bins ? je : n_bins - 1);
+      const unsigned long long mm = __ballot(in_r && not_miss(chunk_end(j), v));
+      if (!mm) { id_out = row[0].id; return 0; }      // even the last candidate is a certain miss -> edges.head
+      const int f = __ffsll((long long)mm) - 1;
+      if (f) prev_val = readlane_f64(v, f - 1);
+      if (L == 0) { jc = blk * 64 + f; b_this = readlane_f64(v, f); b_prev = prev_val; }
+      else blk = blk * 64 + f;
+    }
+  } else {
+    // the wave's LDS bins right after binned_fill: round trip 1 = everything the search needs first
+    int32_t lo = 0, hi = n_bins - 1;                 // the chunk of the first not-certain-miss index lies in [lo, hi]
+    int32_t j1 = hi >= 64 ? (int32_t)(((int64_t)hi * (lane + 1)) >> 6) : (lane <= hi ? lane : hi);   // lane 63 probes hi
+    const double b_last = bins[n_bins - 1];
+    double b_j = bins[j1];
+    const double pq_last = PQ[deg - 1];
+    double pq_j = PQ[chunk_end(j1)];
+    S = pq_last + b_last;
+    if (!(S > 0.0)) return -1;
+    if (!CHAIN && S_out && g.dbg_chain_deg && deg >= g.dbg_chain_deg) { *S_out = S; return CHAIN_NEEDED; }   // tests: the chain kernels on every long row
+    pS = p * S;
+    while (hi - lo >= 64) {
+      const unsigned long long mm = __ballot(not_miss(chunk_end(j1), pq_j + b_j));
+      if (!mm) { id_out = row[0].id; return 0; }      // even the last candidate is a certain miss -> edges.head
+      const int f = __ffsll((long long)mm) - 1;
+      const int32_t jf = __builtin_amdgcn_readlane(j1, f);
+      const int32_t jprev = f ? __builtin_amdgcn_readlane(j1, f - 1) : lo - 1;
+      hi = jf; lo = jprev + 1;
+      const int64_t span = (int64_t)hi - lo;
+      j1 = span >= 64 ? lo + (int32_t)((span * (lane + 1)) >> 6) : (lo + lane <= hi ? lo + lane : hi);
+      b_j = bins[j1];
+      pq_j = PQ[chunk_end(j1)];
+    }
+    {
+      const bool nm = lo + lane <= hi && not_miss(chunk_end(j1), pq_j + b_j);
+      const unsigned long long mm = __ballot(nm);
+      if (!mm) { id_out = row[0].id; return 0; }
+      jc = lo + (__ffsll((long long)mm) - 1);
+    }
+    b_prev = jc ? bins[jc - 1] : 0.0; b_this = bins[jc];
   }
   // candidate-by-candidate evaluation of chunk jc, 256 candidates per round
   const int32_t k0 = (int32_t)((int64_t)jc << csh), k1 = chunk_end(jc);
-#if defined(SRW_ATTR) && (SRW_ATTR >= 2 && SRW_ATTR <= 4 || SRW_ATTR == 5)
-  if (SRW_ATTR != 5 || deg > 16384) { const int32_t ka = k0 + (int32_t)(__float_as_uint(r) % (uint32_t)(k1 - k0 + 1)); served = 1; id_out = __builtin_amdgcn_readfirstlane(row[ka].id); return ka; }
-#endif
-  const double b_prev = jc ? BIN(jc - 1) : 0.0, b_this = BIN(jc);
+  // The entries (and mask words) of a round are requested one round AHEAD: the first round's together with the reads of PQ below,
+  // round r + 1's before round r's probes are waited for — a located chunk of several rounds (hub rows: deg / cap candidates) costs
+  // one dependent round trip per round instead of two.
+  Ent e_nx[PL]; unsigned long long mw_nx[PL];
+  auto fetch_round = [&](int32_t base) {
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+      const int32_t k = base + u * 64 + lane;
+      e_nx[u].id = b.prev; e_nx[u].w = 0.0f; mw_nx[u] = 0ull;
+      if (k <= k1) e_nx[u] = row[k];
+      if (cmask && base + u * 64 <= k1) mw_nx[u] = cmask[(base >> 6) + u];
+    }
+  };
+  fetch_round(k0);
   // exact value of the numerator just before the chunk, and the exact sum of the chunk's corrections
   // (inside the chunk the base prefix sums PQ[k] - PQ[k0-1] are not loaded: under the row certificate every partial sum of
   // the base weights fl(w / q) is exact in any order, so the wave scan that adds up the corrections adds them up as well —
   // 8 bytes per candidate fewer to request)
-  double carry, chunk_corr;
-  const double pq_base = k0 ? PQ[k0 - 1] : 0.0;
+  double carry, chunk_corr = 1.0;
   if (ABS) {
     carry = b_prev;                                          // A'_{k0-1}
-    chunk_corr = (b_this - b_prev) - (PQ[k1] - pq_base);
+    // (with the pair's chunk masks nothing asks whether the chunk holds a special: two reads of PQ fewer)
+    if (!cmask) chunk_corr = (b_this - b_prev) - (PQ[k1] - (k0 ? PQ[k0 - 1] : 0.0));
   } else {
-    carry = b_prev + pq_base;                                // corrections before the chunk + base weights before the chunk
+    carry = b_prev + (k0 ? PQ[k0 - 1] : 0.0);                // corrections before the chunk + base weights before the chunk
     chunk_corr = b_this - b_prev;
   }
   // q > 1 and p <= q: every correction (w - w/q for a member, w/p - w/q for a return edge) is >= 0; q < 1 and p >= q:
   // every one is <= 0.  Then "the chunk's corrections sum to exactly 0" means "no special in the chunk".
   const bool one_sign = (q_ > 1.0f && p_ <= q_) || (q_ < 1.0f && p_ >= q_);
-#if defined(SRW_ATTR) && SRW_ATTR >= 2 && SRW_ATTR <= 4
-  const bool no_specials = true;
-#else
-  const bool no_specials = one_sign && chunk_corr == 0.0;
-#endif
+  const bool no_specials = one_sign && !cmask && chunk_corr == 0.0;
   // a short N(prev): staged in LDS once (sorted, padded to a power of two), searched there
   int stage_levels = 0;
   if (!no_specials && !cmask && stage && !hubbits && m > 0 && m <= 1024) {
@@ -1349,29 +1437,25 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
 #ifdef SRW_PHASE_TIMING
     tm.t_fin += 1;                                              // rounds of 64 * PL candidates
 #endif
-    Ent e[PL]; bool valid[PL], in[PL], want[PL]; uint32_t xs[PL];
+    Ent e[PL]; bool valid[PL], in[PL], want[PL]; uint32_t xs[PL]; unsigned long long mwc[PL];
     tm.res_bytes += 8ull * (unsigned long long)((k1 - base + 1) < 64 * PL ? (k1 - base + 1) : 64 * PL);
 #pragma unroll
     for (int u = 0; u < PL; ++u) {
       const int32_t k = base + u * 64 + lane;
       valid[u] = k <= k1;
-      e[u].id = b.prev; e[u].w = 0.0f;
-      if (valid[u]) e[u] = row[k];
+      e[u] = e_nx[u]; mwc[u] = mw_nx[u];
     }
+    if (base + 64 * PL <= k1) fetch_round(base + 64 * PL);
 #pragma unroll
     for (int u = 0; u < PL; ++u) {
       xs[u] = (uint32_t)((int64_t)e[u].id - b.vmin); in[u] = false;
       want[u] = !no_specials && valid[u] && e[u].id != b.prev;
-#if defined(SRW_ATTR) && SRW_ATTR == 1
-      want[u] = false;
-#endif
     }
     if (no_specials) {
     } else if (cmask) {                               // the membership of these 64 candidates was precomputed with the table: no probe
 #pragma unroll
       for (int u = 0; u < PL; ++u) {
-        const unsigned long long mw = (base + u * 64 <= k1) ? cmask[(base >> 6) + u] : 0ull;
-        in[u] = want[u] && ((mw >> lane) & 1ull);
+        in[u] = want[u] && ((mwc[u] >> lane) & 1ull);
       }
     } else if (stage_levels) {
       uint32_t pos[PL];
@@ -1429,9 +1513,6 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       if (mm) {
         const int f = __ffsll((long long)mm) - 1;
         if (__builtin_amdgcn_readlane((int)hit, f)) { id_out = __builtin_amdgcn_readlane(e[u].id, f); return base + u * 64 + f; }
-#if defined(SRW_ATTR) && SRW_ATTR == 1
-        id_out = __builtin_amdgcn_readlane(e[u].id, f); return base + u * 64 + f;
-#endif
         if (!CHAIN) { if (S_out) *S_out = S; return CHAIN_NEEDED; }
         fallback = 1;
         const int32_t kk = wave_chain_pick(row, deg, b, r, S, &cm);
@@ -1441,9 +1522,6 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       carry += readlane_f64(incl, 63);
     }
   }
-#if defined(SRW_ATTR) && SRW_ATTR == 1
-  id_out = __builtin_amdgcn_readfirstlane(row[k1].id); return k1;
-#endif
   if (!CHAIN) { if (S_out) *S_out = S; return CHAIN_NEEDED; }
   fallback = 1;
   const int32_t kk = wave_chain_pick(row, deg, b, r, S, &cm);
@@ -1522,9 +1600,6 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   const int lane = lane_id();
   const Ent *row = g.ent + rc.off;
   const int32_t deg = rc.deg;
-#if defined(SRW_ATTR) && SRW_ATTR == 4
-  { const int32_t ka = (int32_t)((double)r * (double)deg); id_out = __builtin_amdgcn_readfirstlane(row[ka < deg ? ka : deg - 1].id); return ka < deg ? ka : deg - 1; }
-#endif
   const int ni = (deg + 63) >> 6;                  // <= 4
   float wv[4]; int32_t idv[4]; uint32_t mw[4];
 #pragma unroll
@@ -1619,9 +1694,10 @@ template <bool BF = false, bool CHAIN = true>
 __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc, const Bias &b, const double *table,
                                                float r, unsigned &fallback, unsigned &served, Member &tm, int32_t &id_out,
                                                uint32_t *stage /* 1024 words of the wave's LDS */, double *S_out = nullptr) {
-  const BinGeom geo = bin_geometry(rc.deg, g.eb_min_sh, g.eb_cap);
+  const PairGeom pg = eb_pair_geometry(rc.deg, b.prev_deg, g.ebp);
+  BinGeom geo; geo.csh = pg.csh; geo.n_bins = pg.n_bins;
   const unsigned long long *cmask = nullptr;
-  if (rc.deg <= g.eb_cm_max) cmask = reinterpret_cast<const unsigned long long *>(table + (size_t)eb_prefix_units(g.eb_f32 && (rc.flags & ROW_PQ_F32), geo.n_bins) * 8);
+  if (pg.cmask) cmask = reinterpret_cast<const unsigned long long *>(table + (size_t)eb_layout(g.ebp.f32 && (rc.flags & ROW_PQ_F32), pg.n_bins, true, rc.deg).cm_off * 8);
   return binned_resolve<true, BF, CHAIN>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage, S_out, cmask);
 }
 

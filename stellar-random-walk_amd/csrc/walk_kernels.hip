@@ -2353,6 +2353,19 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
           g.eb_cm_sel = 0;
         }
       }
+      // ... and finer tables for the pairs that keep probing: no mask (rows beyond 16 384 candidates) and an N(prev) too long for the LDS
+      // staging — a located chunk of deg / 256 candidates is one HBM request per candidate and one dependent round per 64 of them (the hub
+      // rows: 14 % of config 3's steps, half of its requests and a third of its time)
+      g.eb_fine_cap_sel = 0;
+      if (need > 0 && !eb_mode && !getenv("SRW_EB_FINE_CAP")) {
+        for (int fc : {4096, 1024, 512}) {
+          if (fc <= eb_cap) break;
+          g.eb_fine_cap_sel = fc;
+          const size_t n = edge_tables_full_bytes(h, eb_mode, eb_cap);
+          if (n > 0 && n < ((size_t)230 << 30) && free_b > n + reserve + ((size_t)24 << 30)) { need = n; break; }
+          g.eb_fine_cap_sel = 0;
+        }
+      }
       if (need > table_cap) table_cap_used = (size_t)230 << 30;
       const size_t keep = need + reserve + ((size_t)8 << 30);
       if (!(env_hub && *env_hub) && want_hub && need > 0 && free_b > keep + ((size_t)16 << 30))
@@ -2374,7 +2387,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
         (void)hipGetLastError();
         Graph &g = h->g;
         g.eb_bins.release(); g.em_bits.release(); g.has_eb = false; g.eb_complete = false; g.eb_tables = 0; g.eb_bytes = 0;
-        h->g.eb_budget_gb = 160; g.eb_min_sh_sel = 8; g.eb_cm_sel = 0;
+        h->g.eb_budget_gb = 160; g.eb_min_sh_sel = 8; g.eb_cm_sel = 0; g.eb_fine_cap_sel = 0;
         if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] per-edge tables: %s — %s\n", e.what(), attempt == 0 && eb_cap > 32 ? "retrying with 32 chunks" : "walking without them");
         if (eb_cap <= 32) break;
       }

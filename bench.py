@@ -35,7 +35,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-REQUEST_CEILING = 50.0e9       # profiles/r02_translation_and_request_rate.md: L2-miss requests/s, any request size
 
 
 def _rmat_weights_np(np, s, d, seed=42):
@@ -82,7 +81,7 @@ def cpu_baseline(args):
                 timed(gk, "karate.txt (34 vertices), walkLength 10", gk.vertices(), p, q, 10, faithful)
     head = None
     t_build = 0.0
-    for scale, n_faithful, n_fast in ((14, 2048, 0), (16, 1024, 4096), (args.cpu_scale, args.cpu_sources or max(64, 3 * cores) // 2, 4096)):
+    for scale, n_faithful, n_fast in ((14, 2048, 0), (16, 1024, 4096), (args.cpu_scale, args.cpu_sources or max(256, 4 * cores), 16384)):
         t0 = time.time()
         s, d = oracle_py.rmat_edges(scale, 16 << scale, seed=42)
         graphs = {(1.0, 1.0): oracle_py.Graph.from_coo(s, d, None, directed=False),
@@ -90,7 +89,7 @@ def cpu_baseline(args):
         t_build += time.time() - t0
         for (p, q), g in graphs.items():
             verts = g.vertices()
-            for faithful, n_src in ((True, n_faithful), (False, n_fast)):
+            for faithful, n_src in ((True, n_faithful if (q == 1.0 or scale < args.cpu_scale) else max(64, n_faithful // 3)), (False, n_fast)):   # (the biased faithful walk is ~3x slower per step)
                 src = verts if (n_src == 0 or n_src >= len(verts)) else verts[np.linspace(0, len(verts) - 1, n_src).astype(np.int64)]
                 e = timed(g, "RMAT scale-%d ef16 undirected %s, walkLength %d, %s" % (
                     scale, "unweighted" if q == 1.0 else "weighted", args.cpu_walk_length,
@@ -100,14 +99,19 @@ def cpu_baseline(args):
         del graphs
     if head is None:
         head = plan[-1]
+    fast = next((e for e in plan if e["workload"].startswith("RMAT scale-%d" % args.cpu_scale) and e["q"] == 1.0 and e["variant"].startswith("fast")), None)
     return {"value": head["value"], "unit": "walk-steps/s", "cores": cores, "kind": "port",
+            "walk_steps": head["walk_steps"], "seconds": head["seconds"], "value_per_core": head["value"] / max(cores, 1),
+            # the same outputs with a sorted membership test instead of the reference's linear `exists` (what a CPU port that is not
+            # bound to the reference's O(deg * deg) would run): the sample is 16 384 sources, >= 1e6 walk-steps
+            "value_fast_variant": fast["value"] if fast else None, "walk_steps_fast_variant": fast["walk_steps"] if fast else None,
             "sample": "CPU restatement of RandomSample/RandomWalk (faithful linear-exists variant), %s, p=%g q=%g, %d threads; %.1f s walk; "
                       "graph builds of the whole plan %.1f s" % (head["workload"], head["p"], head["q"], cores, head["seconds"], t_build),
             "reference_toolchain_probe": {k: (v or "absent") for k, v in jvm.items()},
             "plan": plan}
 
 
-def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None):
+def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None, ceiling=None, scan=None, q=1.0):
     """Algorithmic bytes per launch / average kernel time of the dominant kernel."""
     kind = stats["kernel_kind"]
     if kind == 1:
@@ -145,22 +149,48 @@ def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None):
             for j in (js if isinstance(js, list) else [js]):
                 if j.get("kernel") == name and j.get("scale") == scale:
                     r["traffic"] = j.get("hbm_bytes_per_launch")
-                    r["traffic_source"] = ("profiles/pmc_latest.json <- %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by the "
-                                           "builder on the same command; NOT measured in this run" % j.get("source", "profiles/"))
+                    r["traffic_source"] = ("profiles/pmc_latest.json <- %s (commit %s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ "
+                                           "passes over the same command; the PMC counters cannot be read from inside bench.py" % (j.get("source", "profiles/"), j.get("commit", "?")))
+                    if j.get("requests_per_launch"):
+                        r["requests_per_launch_pmc"] = j["requests_per_launch"]
                     if r["traffic"]:
                         r["physical_traffic_frac"] = r["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         except Exception:
             pass
+    # The fixed denominator of SURVEY §8(d): what the REFERENCE's algorithm reads for the same walk (RandomSample.sample scans N(curr);
+    # computeSecondOrderWeights scans N(prev) when q != 1) — counted from the finished paths by srw_result_scan_sums, whatever kernel
+    # and tables produced them, so that the figure is comparable across rounds.  (`achieved` above uses what THIS kernel reads.)
+    if scan:
+        sdc, sdp, nst = scan
+        second = max(nst - stats["n_walkers"], 0)
+        b = 20 * nst + 8 * sdc + ((16 * second + 4 * sdp) if q != 1.0 else 0)
+        r["algorithmic_bytes_scan"] = int(b)
+        r["algorithmic_bytes_scan_per_step"] = b / max(nst, 1)
+        r["algorithmic_bytes_scan_formula"] = "SURVEY 8(d) Mode R: 16 + 8*deg(curr) + 4 per step (+ 16 + 4*deg(prev) per second-order step when q != 1), summed over the finished paths (srw_result_scan_sums)"
+        r["scan_equivalent_GBs"] = b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        r["scan_equivalent_frac"] = r["scan_equivalent_GBs"] / HBM_PEAK_GBS
+    # The bound of these kernels is the L2-miss REQUEST rate (one request per record / probe whatever its size), not bytes
+    # (profiles/r02_translation_and_request_rate.md).  The ceiling is MEASURED on this box before the headline (srw_probe_request_rate:
+    # dependent random 16-byte reads over a table of the headline's size); requests of the kernel: counted by the kernel itself for the
+    # first-order walk (records read + 1/16 path-store sector per step), from this round's TCC_EA0_RDREQ pass (profiles/pmc_latest.json)
+    # for the table kernels.
     table_bytes = (n_entries or 0) * (stats.get("record_bytes") or 0)
+    if ceiling:
+        r["request_rate_ceiling"] = ceiling["reads_per_s"]
+        r["request_rate_source"] = "measured in this run: srw_probe_request_rate, %.1f GiB table, dependent random 16-byte reads (csrc/probe.hip)" % ceiling["table_gib"]
     if kind == 1 and stats["ent_reads"] and table_bytes > (288 << 20):
-        # the kernel's bound is the L2-miss REQUEST rate (one request per record whatever its size, + 1/16 path-store sector
-        # per step), not bytes: profiles/r02_translation_and_request_rate.md.  Printed only for a table that the caches cannot
-        # hold (32 MiB of L2 + 256 MiB of Infinity Cache): a cache-resident table (config 2) is not subject to that ceiling.
+        # Printed only for a table that the caches cannot hold (32 MiB of L2 + 256 MiB of Infinity Cache): a cache-resident table
+        # (config 2) is not subject to that ceiling.
         req = (stats["ent_reads"] + steps_per_launch / 16.0) / (avg_ms * 1e-3)
         r["requests_per_s"] = req
-        r["request_rate_ceiling"] = REQUEST_CEILING
-        r["request_rate_frac"] = req / REQUEST_CEILING
-        r["request_rate_source"] = "profiles/r02_translation_and_request_rate.md (builder's microbenchmark: ~50 G L2-miss requests/s for 16 B, 64 B and 128 B requests alike; a constant here, NOT measured in this run)"
+        r["requests_per_step"] = (stats["ent_reads"] + steps_per_launch / 16.0) / max(steps_per_launch, 1)
+        if ceiling:
+            r["request_rate_frac"] = req / ceiling["reads_per_s"]
+    elif r.get("requests_per_launch_pmc"):
+        r["requests_per_step"] = r["requests_per_launch_pmc"] / max(steps_per_launch, 1)
+        r["requests_per_s"] = r["requests_per_launch_pmc"] / (avg_ms * 1e-3)
+        if ceiling:
+            r["request_rate_frac"] = r["requests_per_s"] / ceiling["reads_per_s"]
     return r
 
 
@@ -186,7 +216,7 @@ def measure(eng, walk_kw, K, W, first_walk=0):
     return steps, dt, kernel_ms, stats, (setup_ms + inner_setup) * 1e-3
 
 
-def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L=80):
+def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L=80, ceiling=None):
     """One BASELINE configuration on one GPU: graph generated on the device, W + K walk iterations."""
     import torch
     torch.cuda.synchronize()
@@ -202,6 +232,10 @@ def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, 
             kw["sampler"] = "alias"
         steps, dt, kms, st, t_tables = measure(eng, kw, K, W)
         avg_ms = sum(kms) / max(len(kms), 1)
+        try:
+            scan = eng.result_scan_sums()
+        except Exception:
+            scan = None
         out = {"name": name,
                "workload": "RMAT scale-%d ef%d %s %s p=%g q=%g walkLength=%d, %s" % (
                    scale, ef, "directed" if directed else "undirected", "weighted" if weighted else "unweighted", p, q, L,
@@ -214,7 +248,7 @@ def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, 
                "roofline": roofline_of(st, steps / max(K, 1), avg_ms,
                                        scale=scale if ((weighted and not directed and p == 0.25 and q == 4.0 and scale == 24) or
                                                        (directed and not weighted and p == 4.0 and q == 0.5 and scale == 26 and ef == 27
-                                                        and sampler == "reference")) else None, n_entries=ne)}
+                                                        and sampler == "reference")) else None, n_entries=ne, ceiling=ceiling, scan=scan, q=q)}
         if st["kernel_kind"] == 2:
             out["strategy_steps"] = {k: v for k, v in st["strategy_steps"].items() if v}
             out["edge_tables"] = {"count": st["edge_tables"], "bytes": st["edge_table_bytes"]}
@@ -474,6 +508,15 @@ def main():
         torch.cuda.synchronize()
         t_graph = time.perf_counter() - t0
         base = rank * (W + K)  # disjoint walk-iteration indices per rank: numWalks = world * K in total
+        # the request-rate ceiling of THIS box (about a second; outside the timed region): dependent random 16-byte reads over a
+        # table of the size of the headline's record table
+        ceiling = None
+        if rank == 0:
+            try:
+                rps, gib = eng.probe_request_rate(ne * 16)
+                ceiling = {"reads_per_s": rps, "table_gib": gib}
+            except Exception as ex:
+                ceiling = None
         t_tables = 0.0
         for it in range(W):
             t_tables += eng.walk(fetch=False, first_walk=base + it, **walk_kw)["setup_ms"] * 1e-3
@@ -495,6 +538,10 @@ def main():
         max_dt = allreduce(dt, dist.ReduceOp.MAX) if dist is not None else dt
         if rank == 0:
             avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+            try:
+                scan = eng.result_scan_sums()
+            except Exception:
+                scan = None
             out = {
                 "metric": "walk-steps/sec", "value": total_steps / max_dt, "unit": "walk-steps/s", "n_gpus": world,
                 "steps": K, "warmup": W, "ms_per_step": max_dt / max(K, 1) * 1e3, "higher_is_better": True,
@@ -509,7 +556,7 @@ def main():
                            "walk_steps_per_bench_step": int(steps / max(K, 1)),
                            "parallelism": ("graph replicated, walk iterations sharded x%d, no collective" % world) if world > 1 else "1 GPU",
                            "rng": "Philox4x32-10 keyed (iteration, source, step)"},
-                "roofline": roofline_of(stats, steps / max(K, 1), avg_ms, scale=args.scale, n_entries=ne),
+                "roofline": roofline_of(stats, steps / max(K, 1), avg_ms, scale=args.scale, n_entries=ne, ceiling=ceiling, scan=scan, q=args.q),
                 "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables,
                             "note": "outside the timed region; one-off per graph / per (p, q)"},
             }
@@ -603,7 +650,7 @@ def main():
                     ("C5 stand-in Mode A", 26, 27, False, True, 4.0, 0.5, "alias", 2, 1)]
             for (name, sc, ef, wt, dr, p, q, smp, k, w) in plan:
                 try:
-                    cfgs.append(run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w))
+                    cfgs.append(run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w, ceiling=ceiling))
                 except Exception as ex:
                     cfgs.append({"name": name, "error": str(ex)[:300]})
             if args.shard in ("both", "vertex"):

@@ -298,9 +298,23 @@ int32_t srw_cluster_graph_stats(const srw_cluster *c, int64_t *n_vertices, int64
 int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t batch, srw_walk_stats *stats);
 /* The last walk in canonical order (iteration major, source id ascending): paths [num_walks * nVertices][walk_length + 2]. */
 int32_t srw_cluster_fetch_paths(srw_cluster *c, int32_t *paths, int32_t *lens);
-/* walk + RandomWalk.save (RandomWalk.scala:234-241) over the cluster: <output_dir>/path/part-* + _SUCCESS. */
+/* walk + RandomWalk.save (RandomWalk.scala:234-241) over the cluster: <output_dir>/path/part-* + _SUCCESS.  The job is streamed
+ * batch by batch (device memory: one batch of paths per shard, host memory: one slice), so NO walk result stays behind:
+ * srw_cluster_fetch_paths after this call fails with "no walk result" — use srw_cluster_walk when the paths are wanted in memory. */
 int32_t srw_cluster_walk_and_save(srw_cluster *c, const srw_walk_params *params, const char *output_dir, int32_t n_parts,
                                   int32_t write_crc, srw_walk_stats *stats);
+
+/* ---- measurement hooks (bench.py's `roofline` object; not on the walk's path) ------------------------ */
+/* The ceiling the walk kernels are held against, measured on this handle's GPU in about a second: dependent, uniformly random
+ * 16-byte reads (one chain per lane, 81 hops, the access pattern of a first-order step: one record per step) over a table of
+ * `table_bytes` (0: 32 GiB; clipped to the free HBM).  *reads_per_s: reads = L2-miss requests per second; *table_gib (may be
+ * NULL): the size actually used.  No reference counterpart: the reference has no device. */
+int32_t srw_probe_request_rate(srw_handle *h, int64_t table_bytes, double *reads_per_s, double *table_gib);
+/* What the REFERENCE's algorithm reads for the walk this handle just did (srw_walk; paths still resident), counted from the
+ * finished paths: sums[0] = sum over the steps of deg(curr) (RandomSample.sample scans N(curr), RandomSample.scala:12-25),
+ * sums[1] = sum over the second-order steps of deg(prev) (the `exists` over N(prev), RandomSample.scala:27-44), sums[2] = steps.
+ * SURVEY §8(d)'s algorithmic bytes are 20 * sums[2] + 8 * sums[0] (+ 16 * second-order steps + 4 * sums[1] when q != 1). */
+int32_t srw_result_scan_sums(srw_handle *h, int64_t *sums);
 
 /* ---- unit hooks (device arithmetic of RandomSample, for parity tests) ----------------------- */
 /* RandomSample.sample (M/algorithm/RandomSample.scala:12-25) on the GPU; *index = chosen position. */

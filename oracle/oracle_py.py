@@ -307,7 +307,19 @@ def write_paths(paths, lens, output_dir, n_parts=1):
 def rmat_edges(scale, n_edges, seed=42, first=0):
     s = np.zeros(n_edges, dtype=np.int32)
     d = np.zeros(n_edges, dtype=np.int32)
-    lib().orc_rmat_edges(scale, seed, first, n_edges, _i32(s), _i32(d))
+    L = lib()
+    if n_edges < (1 << 22):
+        L.orc_rmat_edges(scale, seed, first, n_edges, _i32(s), _i32(d))
+        return s, d
+    # edge i is a pure function of (seed, i): slices on threads (ctypes releases the GIL)
+    import concurrent.futures as cf
+    nt = min(64, os.cpu_count() or 1)
+    step = -(-n_edges // (nt * 4))
+    def work(lo):
+        n = min(step, n_edges - lo)
+        L.orc_rmat_edges(scale, seed, first + lo, n, _i32(s[lo:lo + n]), _i32(d[lo:lo + n]))
+    with cf.ThreadPoolExecutor(nt) as ex:
+        list(ex.map(work, range(0, n_edges, step)))
     return s, d
 
 

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 /* ============================================================================================ */
 /* RNG                                                                                          */
@@ -377,6 +378,34 @@ static inline int64_t raw_slot(const orc_graph *g, int32_t v) {
 }
 static inline int32_t slot_id(const orc_graph *g, int64_t s) { return g->uid ? g->uid[s] : (int32_t)(s + g->vmin); }
 
+/* sorted_ids: every row's ids in ascending order (the walk's sorted membership test when faithful == 0).  Rows are independent:
+ * the threads take blocks of slots from a shared cursor (full-size parity checks sort 1.8e9 entries). */
+typedef struct { orc_graph *g; int64_t next; pthread_mutex_t mu; } sort_job;
+static void *sort_worker(void *arg) {
+  sort_job *j = (sort_job *)arg;
+  for (;;) {
+    pthread_mutex_lock(&j->mu);
+    int64_t v0 = j->next; j->next += 4096;
+    pthread_mutex_unlock(&j->mu);
+    if (v0 >= j->g->n_slots) break;
+    int64_t v1 = v0 + 4096 < j->g->n_slots ? v0 + 4096 : j->g->n_slots;
+    for (int64_t v = v0; v < v1; ++v)
+      qsort(j->g->sorted_ids + j->g->off[v], (size_t)(j->g->off[v + 1] - j->g->off[v]), sizeof(int32_t), cmp_i32);
+  }
+  return NULL;
+}
+static void sort_rows(orc_graph *g) {
+  long nc = sysconf(_SC_NPROCESSORS_ONLN);
+  int nt = g->n_entries < ((int64_t)1 << 22) ? 1 : (int)(nc < 1 ? 1 : nc > 64 ? 64 : nc);
+  sort_job j; j.g = g; j.next = 0; pthread_mutex_init(&j.mu, NULL);
+  if (nt == 1) { sort_worker(&j); pthread_mutex_destroy(&j.mu); return; }
+  pthread_t th[64]; int started = 0;
+  for (int t = 0; t < nt; ++t) if (pthread_create(&th[started], NULL, sort_worker, &j) == 0) ++started;
+  if (!started) sort_worker(&j);
+  for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+  pthread_mutex_destroy(&j.mu);
+}
+
 /* Adjacency of v = concatenation, in line order, of every line's contribution to v
  * (UniformRandomWalk.scala:35-41: flatMap then reduceByKey(_ ++ _); canonical order). */
 static orc_graph *graph_build(line_vec *lv, int directed) {
@@ -421,14 +450,18 @@ static orc_graph *graph_build(line_vec *lv, int directed) {
   free(cur);
   g->sorted_ids = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->n_entries ? g->n_entries : 1));
   memcpy(g->sorted_ids, g->ids, sizeof(int32_t) * (size_t)g->n_entries);
-  for (int64_t v = 0; v < g->n_slots; ++v)
-    qsort(g->sorted_ids + g->off[v], (size_t)(g->off[v + 1] - g->off[v]), sizeof(int32_t), cmp_i32);
+  sort_rows(g);
   return g;
 }
 
 orc_graph *orc_graph_from_coo(const int32_t *src, const int32_t *dst, const float *w, int64_t n_lines, int directed) {
   line_vec lv; memset(&lv, 0, sizeof(lv));
-  for (int64_t i = 0; i < n_lines; ++i) lv_push(&lv, src[i], dst[i], w ? w[i] : 1.0f, -1);
+  size_t n = (size_t)(n_lines > 0 ? n_lines : 1);
+  lv.src = (int32_t *)malloc(sizeof(int32_t) * n); lv.dst = (int32_t *)malloc(sizeof(int32_t) * n);
+  lv.pid = (int32_t *)malloc(sizeof(int32_t) * n); lv.w = (float *)malloc(sizeof(float) * n);
+  lv.n = n_lines; lv.cap = (int64_t)n;
+  memcpy(lv.src, src, sizeof(int32_t) * (size_t)n_lines); memcpy(lv.dst, dst, sizeof(int32_t) * (size_t)n_lines);
+  for (int64_t i = 0; i < n_lines; ++i) { lv.pid[i] = -1; lv.w[i] = w ? w[i] : 1.0f; }
   return graph_build(&lv, directed);
 }
 

@@ -79,7 +79,7 @@ EXPORTS = [
     "srw_shard_rows_commit", "srw_shard_rows_release", "srw_device_alloc", "srw_device_free", "srw_cluster_create", "srw_cluster_destroy", "srw_cluster_last_error",
     "srw_cluster_shard", "srw_cluster_load_edgelist", "srw_cluster_load_coo", "srw_cluster_generate_rmat",
     "srw_cluster_graph_stats", "srw_cluster_walk", "srw_cluster_fetch_paths", "srw_cluster_walk_and_save",
-    "srw_sample", "srw_second_order_weights",
+    "srw_probe_request_rate", "srw_result_scan_sums", "srw_sample", "srw_second_order_weights",
     "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_version",
 ]
 
@@ -150,6 +150,8 @@ def lib():
     L.srw_cluster_walk.argtypes = [vp, C.POINTER(WalkParams), C.c_int32, C.POINTER(WalkStats)]
     L.srw_cluster_fetch_paths.argtypes = [vp, i32p, i32p]
     L.srw_cluster_walk_and_save.argtypes = [vp, C.POINTER(WalkParams), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(WalkStats)]
+    L.srw_probe_request_rate.argtypes = [vp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.srw_result_scan_sums.argtypes = [vp, i64p]
     L.srw_sample.argtypes = [vp, f32p, C.c_int64, C.c_float, i64p]
     L.srw_second_order_weights.argtypes = [vp, C.c_float, C.c_float, C.c_int32, i32p, C.c_int64, i32p, f32p,
                                            C.c_int64, f32p]
@@ -406,6 +408,19 @@ class Engine:
 
     def write_paths(self, output_dir, n_parts=1, write_crc=False):
         self._ck(lib().srw_write_paths(self.h, os.fsencode(output_dir), n_parts, int(write_crc)))
+
+    # ---- measurement hooks (bench.py's roofline object) ----
+    def probe_request_rate(self, table_bytes=0):
+        """(dependent random 16-byte reads per second on this GPU, GiB of table used) — csrc/probe.hip."""
+        r, g = C.c_double(0.0), C.c_double(0.0)
+        self._ck(lib().srw_probe_request_rate(self.h, int(table_bytes), C.byref(r), C.byref(g)))
+        return r.value, g.value
+
+    def result_scan_sums(self):
+        """(sum of deg(curr) over the steps, sum of deg(prev) over the second-order steps, steps) of the last srw_walk."""
+        out = (C.c_int64 * 3)()
+        self._ck(lib().srw_result_scan_sums(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     # ---- unit hooks: RandomSample on the GPU ----
     def sample(self, w, r):

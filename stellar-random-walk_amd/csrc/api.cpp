@@ -488,6 +488,16 @@ int32_t srw_shard_rows_release(srw_handle *h) {
   return guarded(h, [&] { shard_rows_release(h); });
 }
 
+int32_t srw_probe_request_rate(srw_handle *h, int64_t table_bytes, double *reads_per_s, double *table_gib) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { need(reads_per_s, "null argument"); probe_request_rate(h, table_bytes, reads_per_s, table_gib); });
+}
+
+int32_t srw_result_scan_sums(srw_handle *h, int64_t *sums) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] { need(sums, "null argument"); result_scan_sums(h, sums); });
+}
+
 int32_t srw_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] { need(w && index, "null argument"); hook_sample(h, w, n, r, index); });

@@ -50,9 +50,11 @@ int32_t cguard(srw_cluster *c, F &&f) {
 void ck(srw_cluster *c, int r, int32_t rc) {
   if (rc != SRW_OK) throw Error(rc, std::string("shard ") + std::to_string(r) + ": " + srw_last_error(c->sh[(size_t)r]));
 }
-// One host thread per device: a load (tokenizer + CSR build: seconds per shard) or the super-steps of a walk run on all
-// shards at once instead of shard after shard (round 2: one thread drove everything — 80 serial API calls per super-step at
-// world 8, loads 8x the single-shard time).  SRW_CLUSTER_SERIAL=1 loads shard after shard (debugging).
+// One host thread per DEVICE: a load (CSR build: seconds per shard) runs on all devices at once instead of shard after shard
+// (round 2: one thread drove everything — loads 8x the single-shard time).  Handles that share a device (virtual shards: tests,
+// one-GPU measurements) are loaded one after the other by that device's thread: their builds size themselves from hipMemGetInfo
+// (row filters, edge hash, hub bitmaps, the blocked build's present[] and sort buffers), and concurrent builds on one device
+// would race each other's decisions and add up their peaks.  SRW_CLUSTER_SERIAL=1: shard after shard (debugging).
 void each(srw_cluster *c, const std::function<int32_t(int, srw_handle *)> &f) {
   const int world = c->world();
   if (world == 1 || getenv("SRW_CLUSTER_SERIAL")) {
@@ -60,9 +62,19 @@ void each(srw_cluster *c, const std::function<int32_t(int, srw_handle *)> &f) {
     return;
   }
   std::vector<int32_t> rc((size_t)world, SRW_OK);
+  std::vector<std::vector<int>> by_dev;                 // shards grouped by device, in rank order
+  for (int r = 0; r < world; ++r) {
+    size_t gidx = 0;
+    for (; gidx < by_dev.size(); ++gidx) if (c->dev[(size_t)by_dev[gidx][0]] == c->dev[(size_t)r]) break;
+    if (gidx == by_dev.size()) by_dev.emplace_back();
+    by_dev[gidx].push_back(r);
+  }
   std::vector<std::thread> th;
-  for (int r = 0; r < world; ++r)
-    th.emplace_back([&, r] { (void)hipSetDevice(c->dev[(size_t)r]); rc[(size_t)r] = f(r, c->sh[(size_t)r]); });
+  for (const auto &grp : by_dev)
+    th.emplace_back([&, grp] {
+      (void)hipSetDevice(c->dev[(size_t)grp[0]]);
+      for (int r : grp) rc[(size_t)r] = f(r, c->sh[(size_t)r]);
+    });
   for (auto &t : th) t.join();
   for (int r = 0; r < world; ++r) ck(c, r, rc[(size_t)r]);
 }
@@ -188,7 +200,24 @@ int32_t srw_cluster_load_edgelist(srw_cluster *c, const char *path, int32_t dire
   if (!c) return SRW_ERR_INVALID;
   return cguard(c, [&] {
     c->valid = false; c->rows_linked = -1;
-    each(c, [&](int, srw_handle *h) { return srw_load_edgelist(h, path, directed, weighted, partitioned, rdd_partitions); });
+    if (c->world() == 1) {
+      ck(c, 0, srw_load_edgelist(c->sh[0], path, directed, weighted, partitioned, rdd_partitions));
+    } else {
+      // The file is tokenized ONCE (host tokenizer, all cores) and every shard builds its rows from the shared lines — each shard
+      // tokenizing its own copy held world x 12-16 bytes per line on the host at the same time.
+      int32_t *src = nullptr, *dst = nullptr, *pid = nullptr; float *w = nullptr; int64_t n = 0;
+      char err[512]; err[0] = 0;
+      const int32_t rc = srw_parse_edgelist(path, weighted, partitioned, &src, &dst, &w, partitioned ? &pid : nullptr, &n, err, sizeof(err));
+      if (rc != SRW_OK) throw Error(rc, err[0] ? err : "cannot parse the edge list");
+      struct Free { int32_t *a, *b, *c; float *d; ~Free() { srw_free(a); srw_free(b); srw_free(c); srw_free(d); } } fr{src, dst, pid, w};
+      if (partitioned && pid) {
+        // a missing / unparsable pId: as srw_load_edgelist (the reference draws Random.nextInt(rddPartitions), VCutRandomWalk.scala:24-25)
+        const int32_t np = rdd_partitions > 0 ? rdd_partitions : 1;
+        for (int64_t i = 0; i < n; ++i)
+          if (pid[i] < 0) pid[i] = (int32_t)(((uint32_t)src[i] * 0x9E3779B1u ^ (uint32_t)dst[i] * 0x85EBCA77u) % (uint32_t)np);
+      }
+      each(c, [&](int, srw_handle *h) { return srw_load_coo(h, src, dst, w, partitioned ? pid : nullptr, n, directed); });
+    }
     for (auto &v : c->vrank) v.clear();
   });
 }
@@ -355,7 +384,7 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
       if (run_batch(c, P, B, slack, pth, len, bt)) {      // a chunk was too small for this graph's skew: same batch again with more room
         if (getenv("SRW_TIMING")) fprintf(stderr, "[cluster] chunk overflow at slack %.2f (batch %d, iteration %d): retrying\n", slack, B, it0);
         slack *= 2.0;
-        if (slack > 64.0 * world) throw Error(SRW_ERR_NOMEM, "vertex-sharded walk: chunk overflow persists at 64x slack");
+        if (slack > 64.0 * world) throw Error(SRW_ERR_NOMEM, "vertex-sharded walk: chunk overflow persists at 64 x world slack");
         continue;
       }
       add_stats(tot, bt);
@@ -373,7 +402,7 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
 int32_t srw_cluster_fetch_paths(srw_cluster *c, int32_t *paths, int32_t *lens) {
   if (!c) return SRW_ERR_INVALID;
   return cguard(c, [&] {
-    if (!c->valid) throw Error(SRW_ERR_INVALID, "no walk result");
+    if (!c->valid) throw Error(SRW_ERR_INVALID, "no walk result (srw_cluster_walk_and_save streams its paths to the files and keeps none; call srw_cluster_walk)");
     const int32_t world = c->world();
     const int64_t stride = (int64_t)c->walk_length + 2;
     int64_t n_global = 0, nl = 0;
@@ -445,7 +474,7 @@ int32_t srw_cluster_walk_and_save(srw_cluster *c, const srw_walk_params *params,
       walk_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (overflow) {
         slack *= 2.0;
-        if (slack > 64.0 * world) throw Error(SRW_ERR_NOMEM, "vertex-sharded walk: chunk overflow persists at 64x slack");
+        if (slack > 64.0 * world) throw Error(SRW_ERR_NOMEM, "vertex-sharded walk: chunk overflow persists at 64 x world slack");
         continue;
       }
       add_stats(tot, bt);

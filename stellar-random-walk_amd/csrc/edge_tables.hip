@@ -747,7 +747,10 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
   // 1. the finest complete set that fits
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));
-  free_b += g.hub_bm.n * sizeof(uint32_t);                  // rebuilt below with what the tables leave
+  if (g.hub_bm.n) {                                          // rebuilt below with what the tables leave: released NOW, so that the credit is real
+    free_b += g.hub_bm.n * sizeof(uint32_t);                // (build_hub_bitmaps returns early on an unchanged (min_deg, budget) — it must not find the old ones standing)
+    g.hub_bm.release(); g.has_hub = false; g.n_hubs = 0; g.hub_budget_cap = 0; g.hub_min_deg = 0;
+  }
   const size_t reserve = env_gb("SRW_EB_RESERVE_GB", 16);
   const char *env_cap = getenv("SRW_EB_CHUNKS");
   ShardTabPlan pl; EbSel sel; int cap_sel = 0;
@@ -755,7 +758,7 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
   for (int cap : {256, 128, 64, 32}) {
     if (env_cap && *env_cap) cap = std::min(std::max(atoi(env_cap), 8), BIN_CAP);
     sel = shard_sel(g, mode, cap);
-    if (shard_plan(h, sel, pl) && pl.bytes + reserve < free_b && pl.bytes < env_gb("SRW_EB_BUDGET_GB", 200)) { cap_sel = cap; break; }
+    if (shard_plan(h, sel, pl) && pl.bytes * (size_t)std::max(1, h->dev_share) + reserve < free_b && pl.bytes < env_gb("SRW_EB_BUDGET_GB", 200)) { cap_sel = cap; break; }   // (virtual shards of one device share its HBM)
     if (env_cap && *env_cap) break;
   }
   if (!cap_sel) {
@@ -809,18 +812,26 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
   uint64_t eh_slots = 1024;
   while (eh_slots < (uint64_t)g.n_entries_global + (uint64_t)g.n_entries_global / 2) eh_slots <<= 1;
   bool ehash = !(P.flags & SRW_WALK_NO_EDGE_HASH) && !getenv("SRW_EB_DROP_EHASH") && (g.has_ehash || left > eh_slots * 8 + ((size_t)8 << 30));
-  if (ehash && !g.has_ehash) { build_edge_hash(h); if (g.has_ehash) left -= eh_slots * 8; }
+  auto optional = [&](const char *what, auto &&build) {      // an optional accelerator never fails a walk: another (virtual) shard may have taken the room since hipMemGetInfo
+    try { build(); }
+    catch (const Error &e) {
+      if (e.code != SRW_ERR_NOMEM) throw;
+      (void)hipGetLastError();
+      if (getenv("SRW_TIMING")) fprintf(stderr, "[shard %d/%d edge tables] %s skipped: %s\n", h->cfg.rank, h->cfg.world, what, e.what());
+    }
+  };
+  if (ehash && !g.has_ehash) { optional("edge hash", [&] { build_edge_hash(h); }); if (g.has_ehash) left -= eh_slots * 8; }
   ehash = ehash && g.has_ehash;
   if (!ehash && g.has_ehash) { g.ehash.release(); g.has_ehash = false; }
   g.use_ehash = ehash;
-  if (!ehash && !getenv("SRW_NO_ROW_FILTERS")) build_row_filters(h);
+  if (!ehash && !getenv("SRW_NO_ROW_FILTERS")) optional("row filters", [&] { build_row_filters(h); });
   const bool hubs = !(P.flags & SRW_WALK_NO_HUB_BITMAPS);
   if (hubs) {
     size_t hub_cap = std::min<size_t>((size_t)96 << 30, left > ((size_t)4 << 30) ? left - ((size_t)4 << 30) : 0);
     if (const char *e = getenv("SRW_HUB_BUDGET_GB"); e && *e) hub_cap = (size_t)(atof(e) * (double)((size_t)1 << 30));
-    build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, hub_cap);
+    optional("hub bitmaps", [&] { build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, hub_cap); });
   }
-  g.use_hub = hubs;
+  g.use_hub = hubs && g.has_hub;
   // 3. the tables (an optional accelerator never fails a walk)
   for (int attempt = 0; attempt < 2; ++attempt) {
     try { build_shard_edge_tables(h, P.p, P.q, mode, cap_sel, pl, sel); return; }

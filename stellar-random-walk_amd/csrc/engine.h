@@ -173,6 +173,8 @@ struct srw_handle {
   srw::DevBuf<unsigned long long> walk_cursor;   // [0] next walker of the persistent kernels, [1] walkers handed over by k_walk_tables
   srw::DevBuf<int32_t> walk_todo;                // their indices
   int n_cus = 256;
+  double shard_prof_acc[4] = {0, 0, 0, 0}, shard_prof_mx[4] = {0, 0, 0, 0};   // SRW_SHARD_PROFILE: per-kernel times of the super-steps (run_shard_superstep)
+  int q1_occ[2] = {0, 0};           // resident blocks per CU of k_sh_step_q1<false / true> (queried once per handle)
   int dev_share = 1;                             // handles of one cluster on this device (virtual shards of a single-GPU box): optional structures take 1 / dev_share of what is free
   srw::DevBuf<char> shard_scratch;               // sampled 32-byte records before bucketing (persistent)
   srw::DevBuf<uint32_t> shard_blk;               // [blocks][2 * world] per-block survivor / return counts, then write cursors
@@ -320,6 +322,9 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
 void run_shard_flush(srw_handle *h, const srw_walk_params &P, int32_t batch, const srw_shard_layout &lay, const void *d_recv,
                      int32_t *d_paths, int32_t *d_lens, int64_t stride);
 void run_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow);
+// probe.hip: measurement hooks of bench.py's roofline object
+void probe_request_rate(srw_handle *h, int64_t table_bytes, double *reads_per_s, double *table_gib);
+void result_scan_sums(srw_handle *h, int64_t *out3);
 void hook_sample(srw_handle *h, const float *w, int64_t n, float r, int64_t *index);
 void hook_second_order(srw_handle *h, float p, float q, int32_t prev_id, const int32_t *prev_ids, int64_t n_prev,
                        const int32_t *curr_ids, const float *curr_w, int64_t n, float r, float *out_w,

@@ -1300,6 +1300,21 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   auto chunk_end = [&](int32_t j) { const int64_t e = (((int64_t)j + 1) << csh) - 1; return (int32_t)(e < deg ? e : deg - 1); };
   // tables of rows whose every sum is binary32-exact are stored as floats (edge_tables.hip); LDS bins are always f64
   const bool f32t = ABS && g.ebp.f32 && (rc.flags & ROW_PQ_F32);
+  // A short N(prev) is staged in LDS and searched there by the located chunk's candidates.  On a table step the copy is started
+  // NOW, with direct-to-LDS loads (global_load_lds: no registers, no wait here), so that it travels together with the table's
+  // first block instead of costing a dependent round trip once the chunk is known.  (Speculative: a chunk that turns out to hold
+  // no special does not need it.)
+  bool pre_staged = false;
+#ifndef SRW_NO_PRESTAGE
+  if (ABS && !cmask && stage && !hubbits && m > 0 && m <= 1024) {
+    int P2 = 1; while (P2 < m) P2 <<= 1;
+    for (int32_t t0 = 0; t0 < m; t0 += 64)
+      if (t0 + lane < m)
+        __builtin_amdgcn_global_load_lds(B + t0 + lane, (__attribute__((address_space(3))) void *)(stage + t0), 4, 0, 0);
+    for (int32_t t = m + lane; t < P2; t += 64) stage[t] = 0xFFFFFFFFu;
+    pre_staged = true;
+  }
+#endif
   const double p = (double)r;
   // Certified compares without a divide.  The reference's acc_k = sum of fl(w'_i / S) differs from num / S (num exact)
   // by at most (k + 2) u num / S.  With t = (k + 8) 2^-51 = 4 (k + 8) u:
@@ -1411,7 +1426,8 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   int stage_levels = 0;
   if (!no_specials && !cmask && stage && !hubbits && m > 0 && m <= 1024) {
     int P2 = 1; while (P2 < m) { P2 <<= 1; ++stage_levels; }
-    for (int32_t t = lane; t < P2; t += 64) stage[t] = t < m ? B[t] : 0xFFFFFFFFu;
+    if (pre_staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the copy started before the table search has landed
+    else for (int32_t t = lane; t < P2; t += 64) stage[t] = t < m ? B[t] : 0xFFFFFFFFu;
     if (stage_levels == 0) stage_levels = -1;               // m == 1: one compare, no search level
     __builtin_amdgcn_wave_barrier();
   }
@@ -1437,6 +1453,9 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
 #ifdef SRW_PHASE_TIMING
     tm.t_fin += 1;                                              // rounds of 64 * PL candidates
 #endif
+#ifdef SRW_NO_PREFETCH_ROUNDS
+    if (base > k0) fetch_round(base);
+#endif
     Ent e[PL]; bool valid[PL], in[PL], want[PL]; uint32_t xs[PL]; unsigned long long mwc[PL];
     tm.res_bytes += 8ull * (unsigned long long)((k1 - base + 1) < 64 * PL ? (k1 - base + 1) : 64 * PL);
 #pragma unroll
@@ -1445,7 +1464,9 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       valid[u] = k <= k1;
       e[u] = e_nx[u]; mwc[u] = mw_nx[u];
     }
+#ifndef SRW_NO_PREFETCH_ROUNDS
     if (base + 64 * PL <= k1) fetch_round(base + 64 * PL);
+#endif
 #pragma unroll
     for (int u = 0; u < PL; ++u) {
       xs[u] = (uint32_t)((int64_t)e[u].id - b.vmin); in[u] = false;

@@ -2737,7 +2737,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
   const int32_t last = step == P.walk_length + 1 ? 1 : 0;
   // SRW_SHARD_PROFILE=1 (debug): per-kernel hipEvent times, synchronising after each kernel, printed at the last step
   static const bool prof = getenv("SRW_SHARD_PROFILE") != nullptr;
-  static double acc[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+  double (&acc)[4] = h->shard_prof_acc, (&mx)[4] = h->shard_prof_mx;      // per handle: one host thread per device calls this (cluster.cpp)
   auto timed = [&](int slot, auto &&launch) {
     if (!prof) { launch(); return; }
     SRW_HIP(hipEventRecord(h->ev0, st)); launch(); SRW_HIP(hipEventRecord(h->ev1, st)); SRW_HIP(hipEventSynchronize(h->ev1));
@@ -2772,7 +2772,7 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     ChainRec *chain_list = cb.list;
     const GraphView gv = g.view();
     // a latency-bound kernel of fixed slices: exactly as many blocks as are resident at once
-    static int q1_occ[2] = {0, 0};
+    int (&q1_occ)[2] = h->q1_occ;                     // per handle (one host thread per device)
     const bool ntq = (size_t)g.n_entries * sizeof(CfoEnt) > ((size_t)2 << 30);
     if (!q1_occ[ntq]) {
       int nb = 0;

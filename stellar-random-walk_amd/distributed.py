@@ -31,7 +31,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import Engine, ShardLayout, WalkStats, lib
+from . import Engine, ShardLayout, SrwError, WalkStats, lib
 
 
 class HipShardEngine:
@@ -124,15 +124,19 @@ class HipShardEngine:
             self.engine._ck(L.srw_shard_rows_commit(h, C.c_void_p(rows.data_ptr()), n.value, C.byref(linked)))
         except Exception as ex:      # noqa: BLE001
             err, linked = ex, C.c_int32(0)
-        ok = torch.tensor([linked.value], dtype=torch.int64, device=self.device)
+        # [linked everywhere?, nobody failed?]: the error flag travels separately, so that EVERY rank raises when one rank's commit
+        # failed — a rank that only saw "not linked" would walk on into the next collective and wait there for the departed one
+        # until the process-group timeout
+        ok = torch.tensor([linked.value, 0 if err is not None else 1], dtype=torch.int64, device=self.device)
         self.all_reduce(ok, dist.ReduceOp.MIN, group)
+        all_linked, nobody_failed = int(ok[0]) != 0, int(ok[1]) != 0
+        if not (all_linked and nobody_failed):
+            self.engine._ck(L.srw_shard_rows_release(h))
         if err is not None:
-            self.engine._ck(L.srw_shard_rows_release(h))
             raise err
-        if int(ok[0]) == 0:
-            self.engine._ck(L.srw_shard_rows_release(h))
-            return False
-        return True
+        if not nobody_failed:
+            raise SrwError("srw_shard_rows_commit failed on another rank: the row links were released on every rank")
+        return all_linked
 
 
 class _DeviceBuffer:

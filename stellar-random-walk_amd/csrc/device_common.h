@@ -22,7 +22,13 @@ enum : uint32_t { ROW_PRESENT = 1u, ROW_IRREGULAR = 2u, ROW_ALIAS_IRREGULAR = 4u
                   ROW_PQ_OK = 8u,
                   ROW_PQ_F32 = 16u };  // (with ROW_PQ_OK) every sum the samplers form over this row is a multiple of 2^G below 2^(24+G):
                                        // exactly representable in binary32 -> its per-edge tables are stored as floats
-constexpr int ROW_HUB_SHIFT = 8;   // Row::flags >> 8 = 1 + ordinal of the row's neighbor-set bitmap (0: none); world == 1 only   // certified for the prefix-sum samplers under the current call's (p, q); set by k_pq_*
+// bits 5 .. 7 (with ROW_PQ_OK): code c > 0: a chunk of up to 2^(c + 5) candidates of this row weighs less than 65 536 units of 2^G under the
+// call's (p, q) — the chunk prefixes of such tables are stored as 16-bit deltas (edge_tables.hip); bits 8 .. 15: G + 128, the row's unit exponent
+// (every variant w, fl(w/p), fl(w/q) of every candidate is a multiple of 2^G); both set by k_pq_*
+constexpr int ROW_U16_SHIFT = 5;
+constexpr int ROW_G_SHIFT = 8;
+constexpr uint32_t ROW_PQ_BITS = ROW_PQ_OK | ROW_PQ_F32 | (7u << ROW_U16_SHIFT) | (0xFFu << ROW_G_SHIFT);
+constexpr int ROW_HUB_SHIFT = 16;  // Row::flags >> 16 = 1 + ordinal of the row's neighbor-set bitmap (0: none)
 
 struct alignas(8) Ent {
   int32_t id;
@@ -79,7 +85,7 @@ struct alignas(16) RevEnt { uint32_t cl, pos0; float w0; uint32_t pad; };
 
 struct PairSlot;
 // geometry policy of the per-edge tables (sampling.h:eb_pair_geometry): shared by the planner, the builder and the walk
-struct EbPolicy { int32_t min_sh, cap, cm_max, cm_min_du, fine_min_du, fine_sh, fine_cap, f32; };
+struct EbPolicy { int32_t min_sh, cap, cm_max, cm_min_du, fine_min_du, fine_sh, fine_cap, f32, u16, cm_ratio; };
 struct GraphView {
   const Row *rows;
   const Ent *ent;

@@ -62,7 +62,7 @@ __device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s
   const BinnedCost c = binned_cost(rv.deg, ru.deg, s.has_hub && (ru.flags >> ROW_HUB_SHIFT) != 0u, s.has_ehash != 0);
   const int64_t cost = c.c1 < c.c2 ? (c.c1 < c.cw ? c.c1 : c.cw) : (c.c2 < c.cw ? c.c2 : c.cw);
   const PairGeom geo = eb_pair_geometry(rv.deg, ru.deg, s.pol);
-  const uint32_t units = eb_layout(s.pol.f32 && (rv.flags & ROW_PQ_F32), geo.n_bins, geo.cmask, rv.deg).units;
+  const uint32_t units = eb_layout(s.pol.f32 && (rv.flags & ROW_PQ_F32), geo.n_bins, geo.cmask, rv.deg, eb_pair_u16(rv.flags, geo.csh, s.pol)).units;
   // priority = wave-cycles a table saves per visit, per 64 bytes of table: an on-the-fly step costs its intersection
   // work plus ~20 us of dependent round trips whatever its size (measured: 38 .. 43 us per P1 / W step at config 3
   // against 10 .. 25 us per table step), so short cheap tables are worth as much per byte as the hub <-> hub ones
@@ -358,7 +358,9 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
       const int up = gc.csh - gf.csh;
       const double *PQ = g.pq + rv.off;            // the table keeps the complete numerator A'_end(j) = PQ[end_j] + corrections
       const bool as_f32 = pol.f32 && (rv.flags & ROW_PQ_F32);      // every such sum is exactly representable in binary32
-      const EbLayout lay = eb_layout(as_f32, gc.n_bins, pg.cmask, rv.deg);
+      const bool as_u16 = eb_pair_u16(rv.flags, gc.csh, pol);           // level 0 as the chunks' own masses, u16 multiples of the row's unit 2^G
+      const double inv_unit = as_u16 ? 1.0 / eb_row_unit(rv.flags) : 0.0;
+      const EbLayout lay = eb_layout(as_f32, gc.n_bins, pg.cmask, rv.deg, as_u16);
       // level 0 = the chunk prefixes; level 1 / 2 = the last element of every block of 64 of the level below (the walk's search tree)
       for (int L = 0; L < 3; ++L) {
         const int32_t cnt = L == 0 ? gc.n_bins : L == 1 ? lay.n1 : lay.n2;
@@ -371,7 +373,17 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
           const int64_t fb = fi < gf.n_bins ? fi : gf.n_bins - 1;
           const double corr = big ? __hip_atomic_load(gbins + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bins[fb];
           const double a = PQ[ke < rv.deg ? ke : rv.deg - 1] + corr;
-          if (as_f32) {
+          if (L == 0 && as_u16) {                  // the chunk's own mass = this prefix - the previous one (exact), in units of 2^G
+            double a0 = 0.0;
+            if (j > 0) {
+              const int64_t fp = (j << up) - 1, kp = (j << gc.csh) - 1;
+              a0 = PQ[kp] + (big ? __hip_atomic_load(gbins + fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bins[fp]);
+            }
+            const double du_ = (a - a0) * inv_unit;
+            const unsigned short q16 = (unsigned short)(du_ >= 0.0 && du_ <= 65535.0 ? du_ : 0.0);
+            if ((double)q16 != du_) atomicAdd(&strat_count[7], 1ull);         // must never happen (pq_row_u16_bits' bound)
+            reinterpret_cast<unsigned short *>(lo_)[t] = q16;
+          } else if (as_f32) {
             reinterpret_cast<float *>(lo_)[t] = (float)a;
             if ((double)(float)a != a) atomicAdd(&strat_count[7], 1ull);      // must never happen (pq_row_f32's bound)
           } else lo_[t] = a;
@@ -458,11 +470,13 @@ static EbPolicy eb_policy(const Graph &g, int mode, int bins_cap) {
   P.min_sh = mode ? 2 : eb_min_shift(g); P.cap = bins_cap;
   P.cm_max = eb_cm_select(g, mode, P.min_sh);
   P.cm_min_du = std::max(0, env_int("SRW_EB_CM_MIN_DU", 1024));      // N(prev) up to 1 024 ids: staged in LDS by the walk, searched there
+  P.cm_ratio = P.cm_max ? std::max(0, env_int("SRW_EB_CM_RATIO", g.eb_cm_ratio_sel)) : 0;
   P.fine_min_du = std::max(0, env_int("SRW_EB_FINE_MIN_DU", 1024));
   P.fine_sh = std::min(12, std::max(6, env_int("SRW_EB_FINE_SH", 6)));
   P.fine_cap = mode ? 0 : std::min(EB_FINE_CAP_LIMIT, std::max(0, env_int("SRW_EB_FINE_CAP", g.eb_fine_cap_sel)));
   if (P.fine_cap <= P.cap) P.fine_cap = 0;
   { const char *e = getenv("SRW_EB_NO_F32"); P.f32 = (e && *e == '1') ? 0 : 1; }
+  { const char *e = getenv("SRW_EB_NO_U16"); P.u16 = (mode || (e && *e == '1')) ? 0 : 1; }
   return P;
 }
 // HBM a COMPLETE set of tables would take (every pair into a certified row + every mask + offsets + the work list):
@@ -605,14 +619,14 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
     fprintf(stderr, "\n");
   }
 #endif
-  if (sc[7]) throw Error(SRW_ERR_INVALID, "per-edge tables: a prefix sum of a ROW_PQ_F32 row was not exactly representable in binary32");
+  if (sc[7]) throw Error(SRW_ERR_INVALID, "per-edge tables: a prefix sum of a ROW_PQ_F32 row was not exactly representable in binary32 (or a chunk mass not in 16 bits)");
   g.eb_pbits = pb; g.eb_qbits = qb; g.eb_mode = mode;
   g.eb_tables = (int64_t)all_pairs;
   g.eb_bytes = (int64_t)(units * 64 + munits * 16 + (unsigned long long)g.n_entries * 4);
   g.eb_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("SRW_TIMING"))
-    fprintf(stderr, "[edge tables] chunks of >= %d candidates, chunk masks up to %d candidates (N(prev) > %d), up to %d chunks for unmasked pairs with N(prev) > %d; ",
-            1 << sel.pol.min_sh, sel.pol.cm_max, sel.pol.cm_min_du, sel.pol.fine_cap ? sel.pol.fine_cap : sel.pol.cap, sel.pol.fine_min_du);
+    fprintf(stderr, "[edge tables] chunks of >= %d candidates, chunk masks up to %d candidates (N(prev) > %d or deg(curr) <= %d deg(prev)), up to %d chunks for unmasked pairs with N(prev) > %d; ",
+            1 << sel.pol.min_sh, sel.pol.cm_max, sel.pol.cm_min_du, sel.pol.cm_ratio, sel.pol.fine_cap ? sel.pol.fine_cap : sel.pol.cap, sel.pol.fine_min_du);
   if (getenv("SRW_TIMING"))
     fprintf(stderr, "[edge tables] up to %d chunks per table; %llu bins tables (%.2f GB, min priority %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
             "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", sel.pol.cap, pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
@@ -717,7 +731,7 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   }
   SRW_HIP(hipStreamSynchronize(st));
-  if (sc[7]) throw Error(SRW_ERR_INVALID, "per-edge tables: a prefix sum of a ROW_PQ_F32 row was not exactly representable in binary32");
+  if (sc[7]) throw Error(SRW_ERR_INVALID, "per-edge tables: a prefix sum of a ROW_PQ_F32 row was not exactly representable in binary32 (or a chunk mass not in 16 bits)");
   uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);
   g.eb_pbits = pb; g.eb_qbits = qb; g.eb_mode = mode;
   g.eb_tables = (int64_t)all_pairs;
@@ -754,7 +768,7 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
   const size_t reserve = env_gb("SRW_EB_RESERVE_GB", 16);
   const char *env_cap = getenv("SRW_EB_CHUNKS");
   ShardTabPlan pl; EbSel sel; int cap_sel = 0;
-  g.eb_min_sh_sel = 8; g.eb_cm_sel = 0; g.eb_fine_cap_sel = 0;
+  g.eb_min_sh_sel = 8; g.eb_cm_sel = 0; g.eb_fine_cap_sel = 0; g.eb_cm_ratio_sel = 0;
   for (int cap : {256, 128, 64, 32}) {
     if (env_cap && *env_cap) cap = std::min(std::max(atoi(env_cap), 8), BIN_CAP);
     sel = shard_sel(g, mode, cap);
@@ -795,6 +809,13 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
         EbSel s2; ShardTabPlan p2;
         if (fits(s2, p2)) { sel = s2; pl = p2; break; }
         g.eb_cm_sel = 0;
+      }
+    if (g.eb_cm_sel && !getenv("SRW_EB_CM_RATIO"))
+      for (int ratio : {16, 4}) {
+        g.eb_cm_ratio_sel = ratio;
+        EbSel s2; ShardTabPlan p2;
+        if (fits(s2, p2)) { sel = s2; pl = p2; break; }
+        g.eb_cm_ratio_sel = 0;
       }
     if (!getenv("SRW_EB_FINE_CAP"))
       for (int fc : {4096, 1024, 512}) {

@@ -113,8 +113,9 @@ struct Graph {
   bool eb_sharded = false;        // the standing per-edge tables are keyed by the pair hash (built by build_shard_edge_tables)
   DevBuf<PairSlot> rh;            // sharded q == 1 walks: return edges of the pairs into this shard's rows (build_shard_rev_hash)
   uint32_t rh_buckets = 0; bool has_rh = false;
-  EbPolicy ebp = {8, 64, 0, 1024, 1024, 6, 0, 1};       // geometry of the standing per-edge tables (GraphView::ebp)
+  EbPolicy ebp = {8, 64, 0, 1024, 1024, 6, 0, 1, 0, 0};       // geometry of the standing per-edge tables (GraphView::ebp)
   int32_t eb_cm_sel = 0;          // what the next table build uses (prepare_tables / prepare_shard_tables choose them): chunk masks up to this row length,
+  int32_t eb_cm_ratio_sel = 0;    // ... chunk masks also where deg(curr) <= ratio x deg(prev) (0: only where N(prev) is too long for the LDS staging),
   int32_t eb_fine_cap_sel = 0;    // ... chunks per table at most for the pairs with a long N(prev) and no mask (0: no finer tables)
   int32_t eb_min_sh_sel = 8;      // log2 of the smallest table chunk the next table build uses (prepare_tables / prepare_shard_tables choose it)
   int32_t dbg_chain_deg = 0;      // SRW_DEBUG_CHAIN_DEG (read by run_shard_superstep)

@@ -322,7 +322,8 @@ __global__ void k_fo_from_slim(const Row *__restrict__ rows, const Ent *__restri
 struct PqCert {
   int emin; bool bad; double mass;
   int glsb;   // lowest set bit position over all nonzero variants: every variant (hence every sum) is a multiple of 2^glsb
-  __device__ PqCert() : emin(1 << 20), bad(false), mass(0.0), glsb(1 << 20) {}
+  float maxv; // largest variant of any candidate
+  __device__ PqCert() : emin(1 << 20), bad(false), mass(0.0), glsb(1 << 20), maxv(0.0f) {}
   __device__ inline void add(float x) {
     uint32_t b = __float_as_uint(x);
     int ex = (int)((b >> 23) & 0xFFu);
@@ -336,7 +337,9 @@ struct PqCert {
   __device__ inline void add_entry(float w, float p, float q) {
     const float a = div_exact(w, q), c = div_exact(w, p);
     add(w); add(a); add(c);
-    mass += (double)fmaxf(w, fmaxf(a, c));      // NaN-free once !bad
+    const float mx = fmaxf(w, fmaxf(a, c));
+    mass += (double)mx;      // NaN-free once !bad
+    maxv = fmaxf(maxv, mx);
   }
 };
 // every sum over the row is a multiple of 2^glsb and at most 2 * mass: below 2^(24 + glsb) it has at most 24 significant
@@ -344,6 +347,15 @@ struct PqCert {
 __device__ inline bool pq_row_f32(int glsb, double mass) {
   if (glsb > (1 << 19) || glsb < -1000) return false;
   return mass < ldexp(1.0, 22 + glsb);
+}
+// Row::flags bits of the 16-bit table deltas: the largest chunk (2^(c + 5) candidates, c = 1 .. 7) whose mass — at most chunk size x the
+// largest variant — stays below 65 536 units of 2^glsb, and the unit exponent itself
+__device__ inline uint32_t pq_row_u16_bits(int glsb, float maxv) {
+  if (glsb > 100 || glsb < -100 || !(maxv > 0.0f)) return 0u;
+  const double upc = ldexp((double)maxv, -glsb);                 // units per candidate at most (an integer: maxv is a multiple of 2^glsb)
+  uint32_t c = 0;
+  while (c < 7u && upc * (double)(1u << (c + 6u)) <= 65535.0) ++c;
+  return (c << ROW_U16_SHIFT) | (((uint32_t)(glsb + 128) & 0xFFu) << ROW_G_SHIFT);
 }
 __device__ inline bool pq_row_ok(int emin, bool bad, double mass) {
   if (bad) return false;
@@ -356,7 +368,7 @@ __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, 
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_slots; v += (int64_t)gridDim.x * blockDim.x) {
     Row r = rows[v];
     ok[v] = 0;
-    if (r.flags & (ROW_PQ_OK | ROW_PQ_F32)) { r.flags &= ~(ROW_PQ_OK | ROW_PQ_F32); rows[v].flags = r.flags; }   // the flag mirrors ok[v] (one load less per step)
+    if (r.flags & ROW_PQ_BITS) { r.flags &= ~ROW_PQ_BITS; rows[v].flags = r.flags; }   // the flag mirrors ok[v] (one load less per step)
     if (r.deg <= 0 || r.deg > SMALL_DEG) continue;
     PqCert c;
     for (int32_t k = 0; k < r.deg; ++k) c.add_entry(ent[r.off + k].w, p, q);
@@ -364,7 +376,7 @@ __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, 
     double acc = 0.0;
     for (int32_t k = 0; k < r.deg; ++k) { acc += (double)div_exact(ent[r.off + k].w, q); pq[r.off + k] = acc; }
     ok[v] = 1;
-    rows[v].flags = r.flags | ROW_PQ_OK | (pq_row_f32(c.glsb, c.mass) ? ROW_PQ_F32 : 0u);
+    rows[v].flags = r.flags | ROW_PQ_OK | (pq_row_f32(c.glsb, c.mass) ? ROW_PQ_F32 : 0u) | pq_row_u16_bits(c.glsb, c.maxv);
   }
 }
 
@@ -386,6 +398,7 @@ __global__ void k_pq_large(Row *__restrict__ rows, const Ent *__restrict__ ent, 
       const int emin = wave_min_i32(c.emin), glsb = wave_min_i32(c.glsb);
       const bool bad = __any(c.bad);
       const double mass = wave_sum_f64(bad ? 0.0 : c.mass);
+      const float maxv = __int_as_float(wave_max_i32(__float_as_int(bad ? 0.0f : c.maxv)));     // (non-negative floats order like their bit patterns)
       if (!pq_row_ok(emin, bad, mass)) { if (lane == 0) atomicAdd(next_slot + 1, 1ull); continue; }   // ok[v] stays 0 (set by k_pq_small)
       double carry = 0.0;                                            // exact sums: any order gives the same bits
       for (int32_t base = 0; base < r.deg; base += 64) {
@@ -395,7 +408,7 @@ __global__ void k_pq_large(Row *__restrict__ rows, const Ent *__restrict__ ent, 
         if (k < r.deg) pq[r.off + k] = carry + x;
         carry += readlane_f64(x, 63);
       }
-      if (lane == 0) { ok[v] = 1; rows[v].flags = r.flags | ROW_PQ_OK | (pq_row_f32(glsb, mass) ? ROW_PQ_F32 : 0u); }
+      if (lane == 0) { ok[v] = 1; rows[v].flags = r.flags | ROW_PQ_OK | (pq_row_f32(glsb, mass) ? ROW_PQ_F32 : 0u) | pq_row_u16_bits(glsb, maxv); }
     }
   }
 }

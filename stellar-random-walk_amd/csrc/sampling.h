@@ -946,7 +946,9 @@ __host__ __device__ inline BinGeom bin_geometry(int32_t deg, int min_sh, int cap
 __host__ __device__ inline PairGeom eb_pair_geometry(int32_t dv, int32_t du, const EbPolicy &P) {
   const BinGeom b = bin_geometry(dv, P.min_sh, P.cap);
   PairGeom g; g.csh = b.csh; g.n_bins = b.n_bins; g.cmask = false;
-  if (dv <= P.cm_max && du > P.cm_min_du && b.csh >= 6) g.cmask = true;
+  // (a shorter N(prev) is staged in LDS by the walk — deg(prev) / 16 lines per step — unless the row is short enough for the mask to be the
+  //  cheaper thing to keep: deg(curr) / 8 bytes of mask against deg(prev) x 4 bytes of staging traffic per visit, cm_ratio = deg(curr) / deg(prev))
+  if (dv <= P.cm_max && b.csh >= 6 && (du > P.cm_min_du || (du > 32 && (int64_t)dv <= (int64_t)P.cm_ratio * du))) g.cmask = true;
   else if (P.fine_cap > 0 && du > P.fine_min_du && P.fine_sh >= 6) {
     const BinGeom f = bin_geometry(dv, P.fine_sh, P.fine_cap);
     if (f.csh < b.csh) { g.csh = f.csh; g.n_bins = f.n_bins; }
@@ -955,15 +957,28 @@ __host__ __device__ inline PairGeom eb_pair_geometry(int32_t dv, int32_t du, con
 }
 __host__ __device__ inline uint32_t eb_prefix_units(bool f32, int32_t n_bins) { return f32 ? (uint32_t)((n_bins + 15) >> 4) : (uint32_t)((n_bins + 7) >> 3); }
 __host__ __device__ inline uint32_t eb_cmask_units(int32_t deg) { return (uint32_t)((((deg + 63) >> 6) + 7) >> 3); }
+// 16-bit level 0 (EbPolicy::u16): where the row's flags say that a chunk of this pair's size weighs less than 65 536 units of 2^G
+// (sampler_tables.hip:pq_row_u16_bits), level 0 holds the chunks' own masses as u16 multiples of 2^G instead of the absolute prefixes —
+// half (a quarter, for f64 rows) of the bytes of the level that IS the table; the search adds a block of 64 up with a wave scan on top
+// of the absolute prefix that the level above (or nothing, for the first block) provides.  Levels 1 and 2 stay absolute.
+__host__ __device__ inline bool eb_pair_u16(uint32_t row_flags, int csh, const EbPolicy &P) {
+  const int c = (int)((row_flags >> ROW_U16_SHIFT) & 7u);
+  return P.u16 && c > 0 && csh >= 6 && csh <= c + 5;
+}
+__host__ __device__ inline double eb_row_unit(uint32_t row_flags) {        // 2^G
+  const int G = (int)((row_flags >> ROW_G_SHIFT) & 0xFFu) - 128;
+  union { unsigned long long u; double d; } x; x.u = (unsigned long long)(1023 + G) << 52;     // (|G| <= 100: a normal double)
+  return x.d;
+}
 struct EbLayout { uint32_t l2_off, l1_off, l0_off, cm_off, units; int32_t n1, n2; };   // offsets in 64-byte units from the pair's block
-__host__ __device__ inline EbLayout eb_layout(bool f32, int32_t n_bins, bool cmask, int32_t dv) {
+__host__ __device__ inline EbLayout eb_layout(bool f32, int32_t n_bins, bool cmask, int32_t dv, bool u16 = false) {
   EbLayout L;
   L.n1 = n_bins > 64 ? (n_bins + 63) >> 6 : 0;
   L.n2 = L.n1 > 64 ? (L.n1 + 63) >> 6 : 0;          // (at most 64: tables have at most 2^18 chunks)
   L.l2_off = 0u;
   L.l1_off = L.n2 ? eb_prefix_units(f32, L.n2) : 0u;
   L.l0_off = L.l1_off + (L.n1 ? eb_prefix_units(f32, L.n1) : 0u);
-  L.cm_off = L.l0_off + eb_prefix_units(f32, n_bins);
+  L.cm_off = L.l0_off + (u16 ? (uint32_t)((n_bins + 31) >> 5) : eb_prefix_units(f32, n_bins));
   L.units = L.cm_off + (cmask ? eb_cmask_units(dv) : 0u);
   return L;
 }
@@ -1305,7 +1320,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   // first block instead of costing a dependent round trip once the chunk is known.  (Speculative: a chunk that turns out to hold
   // no special does not need it.)
   bool pre_staged = false;
-#ifndef SRW_NO_PRESTAGE
+#ifdef SRW_PRESTAGE            // measured and not kept (profiles/r04_table_kernel.md): the speculative copy costs requests when the chunk holds no special, -5 %
   if (ABS && !cmask && stage && !hubbits && m > 0 && m <= 1024) {
     int P2 = 1; while (P2 < m) P2 <<= 1;
     for (int32_t t0 = 0; t0 < m; t0 += 64)
@@ -1330,7 +1345,9 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   if constexpr (ABS) {
     // the pair's table in HBM: a 64-ary tree over the chunk prefixes (eb_layout), one block of <= 64 values per level;
     // S is the last element of the top level
-    const EbLayout lay = eb_layout(f32t, n_bins, false, 0);
+    const bool u16t = eb_pair_u16(rc.flags, csh, g.ebp);
+    const double unit = u16t ? eb_row_unit(rc.flags) : 0.0;
+    const EbLayout lay = eb_layout(f32t, n_bins, false, 0, u16t);
     const int nlev = lay.n2 ? 3 : lay.n1 ? 2 : 1;
     int32_t blk = 0;
     double prev_val = 0.0;                            // prefix just before the block being searched
@@ -1341,7 +1358,10 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       const int32_t i = blk * 64 + lane;
       const bool in_r = i < cnt;
       double v = 0.0;
-      if (in_r) v = f32t ? (double)reinterpret_cast<const float *>(bins + (size_t)off * 8)[i] : bins[(size_t)off * 8 + i];
+      if (L == 0 && u16t) {                           // the chunks' own masses, 16 bits each: prefix = what precedes the block + a wave scan
+        const double d = in_r ? (double)reinterpret_cast<const unsigned short *>(bins + (size_t)off * 8)[i] * unit : 0.0;
+        v = prev_val + wave_incl_scan_f64(d);         // (exact: every partial sum is an exact multiple of 2^G under the row certificate)
+      } else if (in_r) v = f32t ? (double)reinterpret_cast<const float *>(bins + (size_t)off * 8)[i] : bins[(size_t)off * 8 + i];
       if (L == nlev - 1) {
         S = readlane_f64(v, cnt - 1);               // (the top level has at most 64 elements)
         if (!(S > 0.0)) return -1;
@@ -1453,7 +1473,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
 #ifdef SRW_PHASE_TIMING
     tm.t_fin += 1;                                              // rounds of 64 * PL candidates
 #endif
-#ifdef SRW_NO_PREFETCH_ROUNDS
+#ifndef SRW_PREFETCH_ROUNDS
     if (base > k0) fetch_round(base);
 #endif
     Ent e[PL]; bool valid[PL], in[PL], want[PL]; uint32_t xs[PL]; unsigned long long mwc[PL];
@@ -1464,7 +1484,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
       valid[u] = k <= k1;
       e[u] = e_nx[u]; mwc[u] = mw_nx[u];
     }
-#ifndef SRW_NO_PREFETCH_ROUNDS
+#ifdef SRW_PREFETCH_ROUNDS      // measured and not kept (profiles/r04_table_kernel.md): a round requested ahead is wasted when the answer is in the current one, -9 %
     if (base + 64 * PL <= k1) fetch_round(base + 64 * PL);
 #endif
 #pragma unroll
@@ -1718,7 +1738,8 @@ __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc
   const PairGeom pg = eb_pair_geometry(rc.deg, b.prev_deg, g.ebp);
   BinGeom geo; geo.csh = pg.csh; geo.n_bins = pg.n_bins;
   const unsigned long long *cmask = nullptr;
-  if (pg.cmask) cmask = reinterpret_cast<const unsigned long long *>(table + (size_t)eb_layout(g.ebp.f32 && (rc.flags & ROW_PQ_F32), pg.n_bins, true, rc.deg).cm_off * 8);
+  if (pg.cmask) cmask = reinterpret_cast<const unsigned long long *>(table + (size_t)eb_layout(g.ebp.f32 && (rc.flags & ROW_PQ_F32), pg.n_bins, true, rc.deg,
+                                                                                              eb_pair_u16(rc.flags, pg.csh, g.ebp)).cm_off * 8);
   return binned_resolve<true, BF, CHAIN>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage, S_out, cmask);
 }
 

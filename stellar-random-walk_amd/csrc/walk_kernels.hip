@@ -14,6 +14,8 @@
 //                        owner(next) for the RCCL all-to-all.
 // No MFMA anywhere: integer/byte gather work bounded by HBM.
 #include <algorithm>
+#include <map>
+#include <tuple>
 #include <chrono>
 #include <cstring>
 
@@ -2244,12 +2246,89 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   // without the hash, the hash goes — the located chunks' probes of a long non-hub N(prev) fall back to the sorted row, and
   // every step still gains from chunks half as long (config 5's stand-in: 34 GB of hash; 32 chunks + hash 1.67e8 steps/s,
   // 32 chunks without 1.56e8, 64 chunks without 2.0e8 — s68, s69).
+  // ---- what HBM is spent on, in this order -------------------------------------------------------------------------
+  // A table step is bound by the memory requests it issues (profiles/r04_request_attribution.md), and what removes requests is table
+  // resolution: (1) a COMPLETE set (a cut set sends its uncovered steps to the on-the-fly samplers of the monolithic kernel) with as many
+  // chunks per table as fit (256 / 128 / 64 / 32), (2) the smallest chunk (64 / 128 / 256 candidates), (3) chunk masks for the rows up
+  // to 16 384 / 4 096 candidates whose N(prev) is too long for the LDS staging, (4) finer tables (up to 4 096 / 1 024 / 512 chunks) for
+  // the unmasked pairs with a long N(prev).  The edge hash (8 B x 2-3 per entry: one probe per candidate of a located chunk that has
+  // neither mask nor staged N(prev) nor hub bitmap) is kept only when dropping it would not buy a finer set — without it the long rows
+  // get their neighbor-set filters (4 B per entry) in front of the sorted rows (config 5's stand-in: 34 GB of hash; s68, s69, r04 s109).
+  // The hub bitmaps take what is left (at least 16 GB are set aside for them).
   bool drop_ehash = false;
-  if (want_eb && want_ehash && !(env_cap && *env_cap)) {
+  size_t hub_cap = want_eb ? (size_t)16 << 30 : (size_t)64 << 30;
+  size_t table_cap_used = 0;
+  int eb_cap = EB_BINS;
+  if (env_hub && *env_hub) hub_cap = (size_t)(atof(env_hub) * (double)((size_t)1 << 30));
+  if (env_cap && *env_cap) eb_cap = atoi(env_cap);
+  struct TabPlan { int cap = 0, min_sh = 8, cm = 0, fine = 0, ratio = 0; size_t need = 0; bool complete = false; };
+  auto finer = [](const TabPlan &a, const TabPlan &b) {      // a strictly finer than b
+    if (a.complete != b.complete) return a.complete;
+    if (a.cap != b.cap) return a.cap > b.cap;
+    if (a.min_sh != b.min_sh) return a.min_sh < b.min_sh;
+    if (a.cm != b.cm) return a.cm > b.cm;
+    if (a.fine != b.fine) return a.fine > b.fine;
+    return a.ratio > b.ratio;
+  };
+  size_t reserve = (size_t)24 << 30;
+  if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
+  std::map<std::tuple<int, int, int, int, int>, size_t> size_cache;
+  auto set_size = [&](int cap, int sh, int cm, int fine, int ratio = 0) {   // bytes of the complete set under this geometry (one pass over the entries; cached)
+    Graph &g = h->g;
+    const auto key = std::make_tuple(cap, sh, cm, fine, ratio);
+    auto it = size_cache.find(key);
+    if (it != size_cache.end()) return it->second;
+    g.eb_min_sh_sel = sh; g.eb_cm_sel = cm; g.eb_fine_cap_sel = fine; g.eb_cm_ratio_sel = ratio;
+    const size_t n = edge_tables_full_bytes(h, eb_mode, cap);
+    size_cache[key] = n;
+    return n;
+  };
+  auto plan_tables = [&](size_t free_b) {                    // the finest geometry whose complete set fits into free_b next to the reserve and the bitmaps' minimum
+    TabPlan t;
+    const size_t ceiling = (size_t)230 << 30;                 // (eb_off counts 64-byte units in 32 bits: 256 GiB)
+    auto fits = [&](size_t n, size_t margin) { return n > 0 && n < ceiling && free_b > n + reserve + margin; };
+    const bool fixed_cap = env_cap && *env_cap;
+    if (fixed_cap) { t.cap = eb_cap; t.need = set_size(t.cap, 8, 0, 0); t.complete = fits(t.need, (size_t)8 << 30); }
+    else
+      for (int c : {256, 128, 64, 32}) {
+        const size_t n = set_size(c, 8, 0, 0);
+        if (fits(n, (size_t)(c > 64 ? 40 : 8) << 30)) { t.cap = c; t.need = n; t.complete = true; break; }
+      }
+    if (!t.complete) { if (!t.cap) { t.cap = EB_BINS; t.need = set_size(t.cap, 8, 0, 0); } return t; }
+    if (eb_mode) return t;
+    if (!getenv("SRW_EB_MIN_SH"))
+      for (int sh : {6, 7}) {
+        const size_t n = set_size(t.cap, sh, 0, 0);
+        if (fits(n, (size_t)40 << 30)) { t.min_sh = sh; t.need = n; break; }
+      }
+    if (!getenv("SRW_EB_CM_MAX"))
+      for (int cm : {16384, 4096}) {
+        const size_t n = set_size(t.cap, t.min_sh, cm, 0);
+        if (fits(n, (size_t)24 << 30)) { t.cm = cm; t.need = n; break; }
+      }
+    if (!getenv("SRW_EB_FINE_CAP"))
+      for (int fc : {4096, 1024, 512}) {
+        if (fc <= t.cap) break;
+        const size_t n = set_size(t.cap, t.min_sh, t.cm, fc);
+        if (fits(n, (size_t)24 << 30)) { t.fine = fc; t.need = n; break; }
+      }
+    if (t.cm && !getenv("SRW_EB_CM_RATIO"))
+      for (int ratio : {16, 4}) {
+        const size_t n = set_size(t.cap, t.min_sh, t.cm, t.fine, ratio);
+        if (fits(n, (size_t)24 << 30)) { t.ratio = ratio; t.need = n; break; }
+      }
+    return t;
+  };
+  TabPlan plan;
+  bool standing = false;
+  if (want_eb) {
     Graph &g = h->g;
     uint32_t pb, qb; memcpy(&pb, &P.p, 4); memcpy(&qb, &P.q, 4);
-    if (g.has_eb && !g.eb_sharded && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode && (!want_hub || g.has_hub)) {
-      drop_ehash = g.eb_no_ehash;                                  // standing tables: as they were built
+    standing = g.has_eb && !g.eb_sharded && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode && (!want_hub || g.has_hub);
+    if (standing) {
+      drop_ehash = g.eb_no_ehash;                                  // standing tables: as they were built, with the bitmaps they were built with
+      eb_cap = g.eb_cap;
+      if (want_hub) hub_cap = g.hub_budget_cap;
     } else {
       uint64_t slots = 1024;
       while (slots < (uint64_t)g.n_entries + (uint64_t)g.n_entries / 2) slots <<= 1;      // build_edge_hash's sizing
@@ -2257,21 +2336,25 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
       size_t free_b = 0, total_b = 0;
       SRW_HIP(hipMemGetInfo(&free_b, &total_b));
       free_b += g.hub_bm.n * sizeof(uint32_t) + g.eb_bins.n * sizeof(double) + g.em_bits.n * sizeof(uint32_t) + g.eb_off.n * sizeof(uint32_t);
-      if (g.has_ehash) free_b += g.ehash.n * sizeof(uint64_t);     // free_b: with neither hash nor tables nor bitmaps
-      size_t reserve = (size_t)24 << 30;
-      if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
-      g.eb_min_sh_sel = 8;                                          // (sized with chunks of 256; refined below once the chunk count is known)
-      const size_t n64 = edge_tables_full_bytes(h, eb_mode, EB_BINS);
-      // what build_edge_tables will have: free - bitmaps (16 GB when the tables are tight) - reserve; 2 GB of margin
-      const size_t slack = reserve + (want_hub ? (size_t)16 << 30 : 0) + ((size_t)2 << 30);
-      const bool with_hash = n64 > 0 && n64 < ((size_t)160 << 30) && free_b > eh_bytes && free_b - eh_bytes > n64 + slack;
-      // (without the hash the long rows get their neighbor-set filters: at most 4 B per adjacency entry, graph_build.hip)
-      const bool without = n64 > 0 && n64 < ((size_t)200 << 30) && free_b > n64 + slack + (size_t)g.n_entries * 4;
-      drop_ehash = !with_hash && without;
+      if (g.has_ehash) free_b += g.ehash.n * sizeof(uint64_t);     // free_b: with neither hash nor tables nor bitmaps nor filters
+      if (g.has_bf) free_b += (g.bf_off.n + g.bf_bits.n) * sizeof(uint32_t);
+      const size_t filters = (size_t)g.n_entries * 4 + (size_t)g.n_slots * 4;
+      const TabPlan with = (want_ehash && free_b > eh_bytes) ? plan_tables(free_b - eh_bytes) : TabPlan();
+      const TabPlan without = plan_tables(free_b > filters ? free_b - filters : 0);
+      drop_ehash = want_ehash && finer(without, with);
+      plan = (want_ehash && !drop_ehash) ? with : without;
       if (getenv("SRW_TIMING"))
-        fprintf(stderr, "[timing] edge hash vs table resolution: %.1f GB free, hash %.1f GB, complete 64-chunk set %.1f GB, slack %.1f GB -> %s\n",
-                (double)free_b / 1e9, (double)eh_bytes / 1e9, (double)n64 / 1e9, (double)slack / 1e9,
-                with_hash ? "both fit" : without ? "the hash goes" : "neither: coarser tables");
+        fprintf(stderr, "[timing] table plan: %.1f GB free; with the edge hash (%.1f GB): %s %d chunks of >= %d, masks <= %d (ratio %d), fine %d (%.1f GB); without: %s %d chunks of >= %d, "
+                "masks <= %d (ratio %d), fine %d (%.1f GB) -> %s\n", (double)free_b / 1e9, (double)eh_bytes / 1e9, with.complete ? "complete" : "cut", with.cap, 1 << with.min_sh, with.cm, with.ratio, with.fine,
+                (double)with.need / 1e9, without.complete ? "complete" : "cut", without.cap, 1 << without.min_sh, without.cm, without.ratio, without.fine, (double)without.need / 1e9,
+                drop_ehash ? "the hash goes" : "the hash stays");
+      eb_cap = plan.cap ? plan.cap : eb_cap;
+      g.eb_min_sh_sel = plan.min_sh; g.eb_cm_sel = plan.cm; g.eb_fine_cap_sel = plan.fine; g.eb_cm_ratio_sel = plan.ratio;
+      if (plan.need > ((size_t)160 << 30)) table_cap_used = (size_t)230 << 30;
+      const size_t used = (drop_ehash || !want_ehash) ? filters : eh_bytes;
+      const size_t keep = plan.need + reserve + ((size_t)8 << 30) + used;
+      if (!(env_hub && *env_hub) && want_hub && plan.need > 0 && free_b > keep + ((size_t)16 << 30))
+        hub_cap = std::min<size_t>(free_b - keep, (size_t)96 << 30);
     }
   }
   if (want_eb && want_ehash && getenv("SRW_EB_DROP_EHASH")) drop_ehash = true;      // tests: the traded configuration on any graph
@@ -2285,93 +2368,6 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   // located chunks' probes from L2 (config 5's stand-in: 2.0e8 -> 2.73e8 steps/s, 3 GB).  With the hash they are not worth
   // their registers (config 3: -1 ... -4 %): k_walk_tables<false>.
   if (want_eb && !want_ehash && !getenv("SRW_NO_ROW_FILTERS")) build_row_filters(h);
-  // With per-edge tables the bitmaps serve the tables' own construction and the membership probes of a located chunk
-  // whose N(prev) is too long for LDS — one probe into a bitmap that the hub's many walkers keep in L2, against one
-  // HBM request into the edge hash (config 3: 16 / 40 / 80 GB of bitmaps -> 223 / 258 / 272 M steps/s, s44).  The tables
-  // come first: the bitmaps get what a COMPLETE set of tables leaves (16 GB when the tables will not fit anyway).
-  // Table resolution: a table has at most eb_cap chunks, so on a hub row a chunk is deg / eb_cap candidates long and the
-  // located chunk is what a table step streams (64 chunks: 628 candidates on average at config 3).  Finer tables cost HBM on
-  // the hub pairs only (config 3: 41.8 / 59.7 / 77.0 / 111.9 GB at 64 / 128 / 256 / 512 chunks -> 376 / 448 / 497 / 513 M steps/s,
-  // s45 / s47): the finest of 256 / 128 / 64 whose COMPLETE set fits next to 32 GB of bitmaps is taken.
-  size_t hub_cap = want_eb ? (size_t)16 << 30 : (size_t)64 << 30;
-  size_t table_cap_used = 0;
-  int eb_cap = EB_BINS;
-  if (env_hub && *env_hub) hub_cap = (size_t)(atof(env_hub) * (double)((size_t)1 << 30));
-  if (env_cap && *env_cap) eb_cap = atoi(env_cap);
-  if (want_eb) {
-    Graph &g = h->g;
-    uint32_t pb, qb; memcpy(&pb, &P.p, 4); memcpy(&qb, &P.q, 4);
-    if (g.has_eb && !g.eb_sharded && g.eb_pbits == pb && g.eb_qbits == qb && g.eb_mode == eb_mode && (!want_hub || g.has_hub)) {
-      eb_cap = g.eb_cap;                                           // standing tables: keep them and the bitmaps they were built with
-      if (want_hub) hub_cap = g.hub_budget_cap;
-    } else {
-      size_t free_b = 0, total_b = 0;
-      SRW_HIP(hipMemGetInfo(&free_b, &total_b));
-      free_b += g.hub_bm.n * sizeof(uint32_t) + g.eb_bins.n * sizeof(double) + g.em_bits.n * sizeof(uint32_t) + g.eb_off.n * sizeof(uint32_t);
-      size_t reserve = (size_t)24 << 30;
-      if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
-      const size_t table_cap = (size_t)(drop_ehash ? 200 : 160) << 30;   // build_edge_tables' own ceiling (Graph::eb_budget_gb)
-      size_t need = 0;
-      g.eb_min_sh_sel = 8;
-      if (!(env_cap && *env_cap)) {
-        for (int c : {256, 128}) {
-          const size_t n = edge_tables_full_bytes(h, eb_mode, c);
-          if (n > 0 && n < table_cap && free_b > n + reserve + ((size_t)40 << 30)) { eb_cap = c; need = n; break; }
-        }
-      }
-      if (need == 0) {
-        need = edge_tables_full_bytes(h, eb_mode, eb_cap);
-        // A set that is cut by the budget sends its uncovered steps to the on-the-fly samplers of the monolithic kernel
-        // (config 5's stand-in at 64 chunks: 125 of 142 GB fit, 10 % of the steps uncovered, 1.36e8 steps/s); a COMPLETE
-        // coarser set runs every step in the lean table kernel (32 chunks: 129 GB, 1.68e8; 16 chunks: 84 GB, 1.07e8 — s50).
-        if (!(env_cap && *env_cap) && need > 0 && (need >= table_cap || free_b < need + reserve + ((size_t)8 << 30))) {
-          const size_t n = edge_tables_full_bytes(h, eb_mode, 32);
-          if (n > 0 && n < table_cap && free_b > n + reserve + ((size_t)8 << 30)) { eb_cap = 32; need = n; }
-        }
-      }
-      // The smallest chunk: 256 candidates (one round of the located chunk's evaluation), or 128 / 64 when the complete set at the
-      // chosen number of chunks still fits next to 40 GB of bitmaps and margin — the rows of 256 .. 16 384 candidates, half of the
-      // steps at config 3, have fewer than 64 chunks of 256 (edge_tables.hip:eb_min_shift)
-      if (need > 0 && !eb_mode && !getenv("SRW_EB_MIN_SH")) {
-        for (int sh : {6, 7}) {
-          g.eb_min_sh_sel = sh;
-          const size_t n = edge_tables_full_bytes(h, eb_mode, eb_cap);
-          if (n > 0 && n < table_cap && free_b > n + reserve + ((size_t)40 << 30)) { need = n; break; }
-          g.eb_min_sh_sel = 8;
-        }
-      }
-      // Chunk masks (edge_tables.hip:eb_cm_select): the tables of the rows up to 16 384 (else 4 096) candidates also carry the pair's
-      // membership mask over the candidate positions, so that a located chunk is evaluated without a single membership probe — they
-      // come before the hub bitmaps, whose probes they replace (one HBM request per candidate of every located chunk whose N(prev)
-      // is too long for the LDS staging: 48 of the 62 requests of an average step at config 3, profiles/r04_request_attribution.md)
-      g.eb_cm_sel = 0;
-      if (need > 0 && !eb_mode && g.eb_min_sh_sel >= 6 && !getenv("SRW_EB_CM_MAX")) {
-        for (int cm : {16384, 4096}) {
-          g.eb_cm_sel = cm;
-          const size_t n = edge_tables_full_bytes(h, eb_mode, eb_cap);
-          if (n > 0 && n < ((size_t)230 << 30) && free_b > n + reserve + ((size_t)24 << 30)) { need = n; break; }
-          g.eb_cm_sel = 0;
-        }
-      }
-      // ... and finer tables for the pairs that keep probing: no mask (rows beyond 16 384 candidates) and an N(prev) too long for the LDS
-      // staging — a located chunk of deg / 256 candidates is one HBM request per candidate and one dependent round per 64 of them (the hub
-      // rows: 14 % of config 3's steps, half of its requests and a third of its time)
-      g.eb_fine_cap_sel = 0;
-      if (need > 0 && !eb_mode && !getenv("SRW_EB_FINE_CAP")) {
-        for (int fc : {4096, 1024, 512}) {
-          if (fc <= eb_cap) break;
-          g.eb_fine_cap_sel = fc;
-          const size_t n = edge_tables_full_bytes(h, eb_mode, eb_cap);
-          if (n > 0 && n < ((size_t)230 << 30) && free_b > n + reserve + ((size_t)24 << 30)) { need = n; break; }
-          g.eb_fine_cap_sel = 0;
-        }
-      }
-      if (need > table_cap) table_cap_used = (size_t)230 << 30;
-      const size_t keep = need + reserve + ((size_t)8 << 30);
-      if (!(env_hub && *env_hub) && want_hub && need > 0 && free_b > keep + ((size_t)16 << 30))
-        hub_cap = std::min<size_t>(free_b - keep, (size_t)96 << 30);
-    }
-  }
   if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, hub_cap);
   h->g.use_hub = want_hub;
   // ... and, last (they take what HBM is left), the per-edge bias tables: the most expensive (prev, curr) pairs get
@@ -2387,7 +2383,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
         (void)hipGetLastError();
         Graph &g = h->g;
         g.eb_bins.release(); g.em_bits.release(); g.has_eb = false; g.eb_complete = false; g.eb_tables = 0; g.eb_bytes = 0;
-        h->g.eb_budget_gb = 160; g.eb_min_sh_sel = 8; g.eb_cm_sel = 0; g.eb_fine_cap_sel = 0;
+        h->g.eb_budget_gb = 160; g.eb_min_sh_sel = 8; g.eb_cm_sel = 0; g.eb_fine_cap_sel = 0; g.eb_cm_ratio_sel = 0;
         if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] per-edge tables: %s — %s\n", e.what(), attempt == 0 && eb_cap > 32 ? "retrying with 32 chunks" : "walking without them");
         if (eb_cap <= 32) break;
       }

@@ -55,12 +55,12 @@ def test_weighted_rmat_biased_walks_equal_oracle(eng, oracle, scale, n_sample, L
         ss = st["strategy_steps"]
         if q != 1.0:
             assert st["edge_tables"] > 0 and ss["edge_table"] > 0 and ss["edge_mask"] > 0, st
-            if scale == 16:     # tables of binary32-exact rows are stored as floats: the f64 layout must give the same paths
-                os.environ["SRW_EB_NO_F32"] = "1"
+            if scale == 16:     # chunk prefixes as 16-bit chunk masses / floats where they are exact: the f64 layout must give the same paths
+                os.environ["SRW_EB_NO_F32"] = "1"; os.environ["SRW_EB_NO_U16"] = "1"
                 try:
                     p64, l64, st64 = eng.walk(p=p, q=q, walk_length=L, seed=1234)
                 finally:
-                    del os.environ["SRW_EB_NO_F32"]
+                    del os.environ["SRW_EB_NO_F32"]; del os.environ["SRW_EB_NO_U16"]
                 assert np.array_equal(p64, paths) and np.array_equal(l64, lens)
                 assert st64["edge_table_bytes"] > st["edge_table_bytes"], (st64["edge_table_bytes"], st["edge_table_bytes"])
                 eng.walk(p=p, q=q, walk_length=1, seed=1234)       # back to the default layout for what follows
@@ -131,3 +131,75 @@ def test_table_build_failure_degrades_instead_of_failing(oracle, monkeypatch, fa
         rp, rl, _ = g.walk(sources=src, p=0.25, q=4.0, walk_length=L, seed=77, threads=16)
         assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl)
         assert (st["edge_tables"] > 0) == expect_tables, st["edge_tables"]
+
+
+_GEOMETRIES = [
+    {"SRW_EB_NO_U16": "1"},                                                       # absolute prefixes at level 0
+    {"SRW_EB_CM_MAX": "0"},                                                       # no chunk masks: every located chunk probes
+    {"SRW_EB_CM_MIN_DU": "0"},                                                    # chunk masks on every pair into a row of up to 16 384 candidates
+    {"SRW_EB_CM_MAX": "0", "SRW_EB_FINE_CAP": "4096", "SRW_EB_FINE_MIN_DU": "0"},  # finer tables everywhere: two-level trees, HBM-scratch bins in the build
+    {"SRW_EB_CM_MAX": "4096", "SRW_EB_FINE_CAP": "1024", "SRW_EB_NO_U16": "1"},
+    {"SRW_EB_CHUNKS": "32", "SRW_EB_MIN_SH": "8"},                                # the coarse complete set of a graph that fills the GPU
+]
+
+
+def test_table_geometries_give_the_same_paths(monkeypatch):
+    """The per-edge tables' geometry (chunk size by (deg(curr), deg(prev)), chunk masks, finer tables, 16-bit level 0, tree depth) is a
+    memory / request trade: every choice must give the paths of the default selection — which the tests above pin to the oracle."""
+    scale = 18
+
+    def walk(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        try:
+            with pkg().Engine(device=0) as e:
+                e.generate_rmat(scale, 16 << scale, seed=5, weighted=True)
+                out = []
+                for p, q in ((0.25, 4.0), (4.0, 0.5)):
+                    paths, lens, st = e.walk(p=p, q=q, walk_length=30, seed=4321)
+                    assert st["strategy_steps"]["edge_table"] > 0, (env, st)
+                    out.append((paths, lens, st["edge_table_bytes"]))
+                return out
+        finally:
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+
+    ref = walk({})
+    sizes = {"default": [r[2] for r in ref]}
+    for env in _GEOMETRIES:
+        got = walk(env)
+        for (rp, rl, _), (gp, gl, gb) in zip(ref, got):
+            assert np.array_equal(gl, rl) and np.array_equal(gp, rp), env
+        sizes[str(env)] = [r[2] for r in got]
+    assert sizes[str(_GEOMETRIES[0])][0] > sizes["default"][0], sizes      # the 16-bit level 0 is what makes the default smaller
+    assert sizes[str(_GEOMETRIES[2])][0] > sizes["default"][0], sizes      # masks on every pair cost bytes
+
+
+def test_three_level_table_on_a_long_row(oracle, monkeypatch):
+    """A row of 300 000 candidates with chunks of 64: 4 688 chunks, a three-level tree (4 688 -> 74 -> 2), built through the HBM-scratch
+    bins; against the oracle."""
+    monkeypatch.setenv("SRW_EB_FINE_CAP", "32768")
+    monkeypatch.setenv("SRW_EB_FINE_MIN_DU", "0")
+    monkeypatch.setenv("SRW_EB_CM_MAX", "0")
+    rng = np.random.default_rng(12)
+    n_leaf = 300000
+    hub, hub2 = 0, 1
+    leaves = np.arange(2, 2 + n_leaf, dtype=np.int32)
+    s = [np.full(n_leaf, hub, np.int32), np.full(n_leaf // 3, hub2, np.int32)]
+    d = [leaves, rng.choice(leaves, n_leaf // 3, replace=False).astype(np.int32)]
+    a = rng.integers(2, 2 + n_leaf, 200000).astype(np.int32); b = rng.integers(2, 2 + n_leaf, 200000).astype(np.int32)
+    s.append(a); d.append(b)
+    s.append(np.array([hub], np.int32)); d.append(np.array([hub2], np.int32))
+    s = np.concatenate(s); d = np.concatenate(d)
+    w = (1 + (rng.integers(0, 8, len(s)))).astype(np.float32)
+    g = oracle.Graph.from_coo(s, d, w, directed=False)
+    with pkg().Engine(device=0) as e:
+        e.load_coo(s, d, w, directed=False)
+        verts = e.vertices()
+        src = np.unique(np.concatenate([[hub, hub2], rng.choice(verts, 3000, replace=False)])).astype(np.int32)
+        idx = np.searchsorted(verts, src)
+        for p, q in ((0.25, 4.0), (2.0, 0.5)):
+            rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=12, seed=31, threads=8)
+            paths, lens, st = e.walk(p=p, q=q, walk_length=12, seed=31)
+            assert np.array_equal(lens[idx], rl) and np.array_equal(paths[idx], rp), (p, q)
+            assert st["strategy_steps"]["edge_table"] > 0, st

@@ -533,7 +533,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));
   free_b += g.eb_off.n * sizeof(uint32_t);
-  const size_t fixed = (size_t)g.n_entries * 4 + (size_t)g.n_slots * 24 + env_gb("SRW_EB_RESERVE_GB", 24);
+  const size_t fixed = (size_t)g.n_entries * 4 + (size_t)g.n_slots * 24 + (getenv("SRW_EB_RESERVE_GB") ? env_gb("SRW_EB_RESERVE_GB", 24) : g.eb_reserve);
   if (free_b < fixed + ((size_t)64 << 20)) return;
   size_t budget = std::min(env_gb("SRW_EB_BUDGET_GB", g.eb_budget_gb), free_b - fixed);
   const int blocks = h->n_cus * 8;

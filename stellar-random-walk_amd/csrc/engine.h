@@ -101,6 +101,7 @@ struct Graph {
   int64_t pq_bad_rows = 0;        // rows the per-call certificate turned away (build_pq_tables)
   bool eb_complete = false;       // the HBM budget did not bind: every pair into a certified row has a table
   bool eb_no_ehash = false;       // the standing tables were built with the edge hash traded for their resolution (prepare_tables)
+  size_t eb_reserve = (size_t)24 << 30;   // what build_edge_tables leaves free for the walk's own buffers (prepare_tables: this call's paths + 8 GB)
   size_t eb_budget_gb = 160;      // build_edge_tables' ceiling for this call (SRW_EB_BUDGET_GB overrides)
   bool has_eb = false, use_eb = false; uint32_t eb_pbits = 0, eb_qbits = 0; int32_t eb_min_sh = 8, eb_mode = 0;
   int64_t eb_tables = 0, eb_bytes = 0; double eb_build_ms = 0.0;

@@ -2266,12 +2266,14 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
     if (a.complete != b.complete) return a.complete;
     if (a.cap != b.cap) return a.cap > b.cap;
     if (a.min_sh != b.min_sh) return a.min_sh < b.min_sh;
-    if (a.cm != b.cm) return a.cm > b.cm;
-    if (a.fine != b.fine) return a.fine > b.fine;
-    return a.ratio > b.ratio;
+    return a.cm > b.cm;          // (the finer tables of the unmasked pairs and the mask ratio are refinements: not worth the hash — config 3: ratio 16
+                                 //  without the hash 771 ms per iteration, ratio 4 with it 711 ms, r04 s112)
   };
-  size_t reserve = (size_t)24 << 30;
+  // what the walk itself allocates after the tables: one call's paths and lengths (+ hand-over lists, chain scratch, the build's HBM-scratch bins)
+  size_t reserve = (size_t)P.num_walks * (size_t)h->g.n_vertices * ((size_t)P.walk_length + 3) * 4 + ((size_t)8 << 30);
+  if (reserve > ((size_t)64 << 30)) reserve = (size_t)64 << 30;      // (srw_walk_to_host / _and_save stream one iteration at a time)
   if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
+  h->g.eb_reserve = reserve;
   std::map<std::tuple<int, int, int, int, int>, size_t> size_cache;
   auto set_size = [&](int cap, int sh, int cm, int fine, int ratio = 0) {   // bytes of the complete set under this geometry (one pass over the entries; cached)
     Graph &g = h->g;

@@ -244,6 +244,12 @@ int32_t srw_shard_capacity(const srw_handle *h, int64_t *n_local_vertices, int64
 int32_t srw_shard_vertex_ranks(const srw_handle *h, int32_t *out);
 /* Chunk capacities for `batch` walk iterations sharing their super-steps: slack * batch * nVertices / world^2 + 4096. */
 int32_t srw_shard_layout_for(const srw_handle *h, int32_t batch, double slack, srw_shard_layout *out);
+/* Two walker populations per handle: population 0 (the default) and 1 each have their own super-step context (scratch, cursors,
+ * counters, path staging) and their own stream; srw_shard_begin / _superstep / _flush / _finish act on the selected one.  A driver
+ * that interleaves the super-steps of two populations lets one's kernels run while the other's chunks are being exchanged — the
+ * overlap the reference's shuffle / count rhythm (RandomWalk.scala:91-162) does not have.  Select 0 again before any other call
+ * on the handle (srw_walk, loads, table builds use the selected stream). */
+int32_t srw_shard_select(srw_handle *h, int32_t population);
 /* Seeds this rank's batch * n_local walkers into its own receive buffer d_recv (world * chunk_bytes, device), writes
  * path slot 0 / lens into d_paths [batch * n_local][walk_length + 2] / d_lens (device), clears the counters. */
 int32_t srw_shard_begin(srw_handle *h, const srw_walk_params *params, int32_t batch, const srw_shard_layout *layout,

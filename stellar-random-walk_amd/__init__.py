@@ -79,7 +79,7 @@ EXPORTS = [
     "srw_shard_rows_commit", "srw_shard_rows_release", "srw_device_alloc", "srw_device_free", "srw_cluster_create", "srw_cluster_destroy", "srw_cluster_last_error",
     "srw_cluster_shard", "srw_cluster_load_edgelist", "srw_cluster_load_coo", "srw_cluster_generate_rmat",
     "srw_cluster_graph_stats", "srw_cluster_walk", "srw_cluster_fetch_paths", "srw_cluster_walk_and_save",
-    "srw_probe_request_rate", "srw_result_scan_sums", "srw_sample", "srw_second_order_weights",
+    "srw_shard_select", "srw_probe_request_rate", "srw_result_scan_sums", "srw_sample", "srw_second_order_weights",
     "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_version",
 ]
 
@@ -150,6 +150,7 @@ def lib():
     L.srw_cluster_walk.argtypes = [vp, C.POINTER(WalkParams), C.c_int32, C.POINTER(WalkStats)]
     L.srw_cluster_fetch_paths.argtypes = [vp, i32p, i32p]
     L.srw_cluster_walk_and_save.argtypes = [vp, C.POINTER(WalkParams), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(WalkStats)]
+    L.srw_shard_select.argtypes = [vp, C.c_int32]
     L.srw_probe_request_rate.argtypes = [vp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.srw_result_scan_sums.argtypes = [vp, i64p]
     L.srw_sample.argtypes = [vp, f32p, C.c_int64, C.c_float, i64p]

@@ -152,6 +152,12 @@ void srw_destroy(srw_handle *h) {
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   for (int i = 0; i < 2; ++i) { if (h->pin_paths[i]) (void)hipHostFree(h->pin_paths[i]); if (h->pin_lens[i]) (void)hipHostFree(h->pin_lens[i]); }
   for (int i = 0; i < 2; ++i) { if (h->pin_text[i]) (void)hipHostFree(h->pin_text[i]); if (h->pin_off[i]) (void)hipHostFree(h->pin_off[i]); }
+  if (h->shard_parked.stream) {
+    (void)hipStreamSynchronize(h->shard_parked.stream);
+    if (h->shard_parked.ev0) (void)hipEventDestroy(h->shard_parked.ev0);
+    if (h->shard_parked.ev1) (void)hipEventDestroy(h->shard_parked.ev1);
+    if (h->shard_parked.own_stream) (void)hipStreamDestroy(h->shard_parked.stream);
+  }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -412,6 +418,24 @@ int32_t srw_shard_layout_for(const srw_handle *h, int32_t batch, double slack, s
   return guarded(const_cast<srw_handle *>(h), [&] {
     need(h->g.loaded, "no graph loaded");
     shard_layout(h, batch, slack, out);
+  });
+}
+
+int32_t srw_shard_select(srw_handle *h, int32_t population) {
+  if (!h || population < 0 || population > 1) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    if (population == h->shard_population) return;
+    auto &k = h->shard_parked;
+    if (!k.stream) {                                   // first use of the second population: its own stream and events
+      SRW_HIP(hipSetDevice(h->cfg.device));
+      SRW_HIP(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking)); k.own_stream = true;
+      SRW_HIP(hipEventCreate(&k.ev0)); SRW_HIP(hipEventCreate(&k.ev1));
+    }
+    std::swap(h->counters, k.counters); std::swap(h->walk_cursor, k.walk_cursor); std::swap(h->walk_todo, k.walk_todo);
+    std::swap(h->shard_scratch, k.shard_scratch); std::swap(h->shard_blk, k.shard_blk); std::swap(h->shard_flag, k.shard_flag);
+    std::swap(h->shard_cur, k.shard_cur); std::swap(h->shard_pt, k.shard_pt); std::swap(h->chain_buf, k.chain_buf); std::swap(h->chain_d, k.chain_d);
+    std::swap(h->stream, k.stream); std::swap(h->own_stream, k.own_stream); std::swap(h->ev0, k.ev0); std::swap(h->ev1, k.ev1);
+    h->shard_population = population;
   });
 }
 

@@ -27,9 +27,9 @@ struct srw_cluster {
   std::vector<srw_handle *> sh;
   std::vector<int32_t> dev;
   std::string last_error;
-  std::vector<DevBuf<char>> recv[2];
+  std::vector<DevBuf<char>> recv[2][2];            // [population][super-step parity][shard]
   std::vector<DevBuf<int32_t>> paths, lens;
-  std::vector<hipEvent_t> ev[2];                   // per shard, alternating by super-step parity
+  std::vector<hipEvent_t> ev[2][2];                // [population][parity][shard]
   std::vector<std::vector<int32_t>> vrank;        // host copy: global rank of each local vertex
   struct Batch { int32_t it0, n; };
   std::vector<Batch> batches;                      // of the last walk
@@ -161,12 +161,12 @@ int32_t srw_cluster_create(const int32_t *devices, int32_t n_devices, int32_t fl
       for (int b = 0; b < n_devices; ++b) same += devices[a] == devices[b];
       c->sh[(size_t)a]->dev_share = same;
     }
-    c->recv[0].resize((size_t)n_devices); c->recv[1].resize((size_t)n_devices);
+    for (int pp = 0; pp < 2; ++pp) for (int b = 0; b < 2; ++b) c->recv[pp][b].resize((size_t)n_devices);
     c->paths.resize((size_t)n_devices); c->lens.resize((size_t)n_devices); c->vrank.resize((size_t)n_devices);
-    for (int b = 0; b < 2; ++b) c->ev[b].assign((size_t)n_devices, nullptr);
+    for (int pp = 0; pp < 2; ++pp) for (int b = 0; b < 2; ++b) c->ev[pp][b].assign((size_t)n_devices, nullptr);
     for (int r = 0; r < n_devices; ++r) {
       SRW_HIP(hipSetDevice(devices[r]));
-      for (int b = 0; b < 2; ++b) SRW_HIP(hipEventCreateWithFlags(&c->ev[b][(size_t)r], hipEventDisableTiming));
+      for (int pp = 0; pp < 2; ++pp) for (int b = 0; b < 2; ++b) SRW_HIP(hipEventCreateWithFlags(&c->ev[pp][b][(size_t)r], hipEventDisableTiming));
     }
   });
   if (rc != SRW_OK) {      // no cluster to ask: the message goes where srw_last_error(NULL) finds it
@@ -184,8 +184,8 @@ void srw_cluster_destroy(srw_cluster *c) {
   for (size_t r = 0; r < c->sh.size(); ++r) {
     (void)hipSetDevice(c->dev[r]);
     if (c->sh[r] && c->sh[r]->stream) (void)hipStreamSynchronize(c->sh[r]->stream);
-    for (int b = 0; b < 2; ++b) if (r < c->ev[b].size() && c->ev[b][r]) (void)hipEventDestroy(c->ev[b][r]);
-    for (int b = 0; b < 2; ++b) if (r < c->recv[b].size()) c->recv[b][r].release();
+    for (int pp = 0; pp < 2; ++pp) for (int b = 0; b < 2; ++b) if (r < c->ev[pp][b].size() && c->ev[pp][b][r]) (void)hipEventDestroy(c->ev[pp][b][r]);
+    for (int pp = 0; pp < 2; ++pp) for (int b = 0; b < 2; ++b) if (r < c->recv[pp][b].size()) c->recv[pp][b][r].release();
     if (r < c->paths.size()) { c->paths[r].release(); c->lens[r].release(); }
   }
   for (srw_handle *h : c->sh) srw_destroy(h);
@@ -246,27 +246,34 @@ int32_t srw_cluster_graph_stats(const srw_cluster *c, int64_t *n_vertices, int64
 }  // extern "C"
 
 namespace {
-// One batch (P.num_walks = B walk iterations starting at P.first_walk, one walker population) on every shard: begin,
-// walk_length + 1 super-steps, flush, finish.  pth / len: per shard, device buffers of B * n_local rows.  One host thread per
-// device; per super-step every thread enqueues its shard's kernels, records its event, meets the others at a barrier (so that
-// every event of this super-step IS recorded) and makes its stream wait for theirs — events alternate by super-step parity, so
-// one barrier per super-step is enough.  No host synchronisation with the devices inside the batch.  true: a chunk overflowed.
-bool run_batch(srw_cluster *c, const srw_walk_params &P, int32_t B, double slack, const std::vector<int32_t *> &pth,
-               const std::vector<int32_t *> &len, srw_walk_stats &bt) {
+// One or two walker populations (each: P.num_walks = B walk iterations starting at P.first_walk) on every shard: begin, walk_length + 1
+// super-steps, flush, finish.  pth / len: per shard, device buffers of B * n_local rows.  One host thread per device; per super-step
+// every thread enqueues its shard's kernels — population after population, each on its own stream (srw_shard_select) —, records
+// their events, meets the others at ONE barrier (so that every event of this super-step IS recorded) and makes each population's
+// stream wait for the other shards' events of that population; events and receive buffers alternate by super-step parity.  With two
+// populations a device runs B's kernels while A's chunks are still arriving from its peers (and, on one device, B fills the tails of
+// A's kernels): the shuffle / count rhythm of RandomWalk.scala:91-162 without its serialisation.  No host synchronisation with the
+// devices inside.  Pop::overflow: a chunk of that population was too small.
+struct Pop { srw_walk_params P; int32_t B; std::vector<int32_t *> pth, len; srw_walk_stats bt; bool overflow; };
+void run_populations(srw_cluster *c, std::vector<Pop> &pops, double slack) {
   const int32_t world = c->world();
-  srw_shard_layout lay;
-  ck(c, 0, srw_shard_layout_for(c->sh[0], B, slack, &lay));
-  const size_t buf_bytes = (size_t)world * (size_t)lay.chunk_bytes;
-  for (int r = 0; r < world; ++r) {
-    SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
-    for (int b = 0; b < 2; ++b) c->recv[b][(size_t)r].ensure(buf_bytes);
+  const int np = (int)pops.size();
+  const int32_t L = pops[0].P.walk_length;
+  std::vector<srw_shard_layout> lay((size_t)np);
+  for (int q = 0; q < np; ++q) {
+    ck(c, 0, srw_shard_layout_for(c->sh[0], pops[(size_t)q].B, slack, &lay[(size_t)q]));
+    const size_t buf_bytes = (size_t)world * (size_t)lay[(size_t)q].chunk_bytes;
+    for (int r = 0; r < world; ++r) {
+      SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
+      for (int b = 0; b < 2; ++b) c->recv[q][b][(size_t)r].ensure(buf_bytes);
+    }
   }
   SpinBarrier bar(world);
   std::atomic<bool> failed{false};
   std::vector<std::string> err((size_t)world);
   std::vector<int32_t> err_code((size_t)world, SRW_OK);
-  std::vector<srw_walk_stats> st((size_t)world);
-  std::vector<int32_t> of((size_t)world, 0);
+  std::vector<std::vector<srw_walk_stats>> st((size_t)np, std::vector<srw_walk_stats>((size_t)world));
+  std::vector<std::vector<int32_t>> of((size_t)np, std::vector<int32_t>((size_t)world, 0));
   auto body = [&](int r) {
     srw_handle *h = c->sh[(size_t)r];
     auto guard = [&](auto &&f) {                      // a failing shard keeps meeting the others at the barriers
@@ -275,28 +282,46 @@ bool run_batch(srw_cluster *c, const srw_walk_params &P, int32_t B, double slack
       catch (const Error &e) { err[(size_t)r] = e.what(); err_code[(size_t)r] = e.code; failed.store(true, std::memory_order_release); }
       catch (const std::exception &e) { err[(size_t)r] = e.what(); err_code[(size_t)r] = SRW_ERR_INVALID; failed.store(true, std::memory_order_release); }
     };
-    guard([&] { SRW_HIP(hipSetDevice(c->dev[(size_t)r])); ck(c, r, srw_shard_begin(h, &P, B, &lay, c->recv[0][(size_t)r].p, pth[(size_t)r], len[(size_t)r])); });
+    auto sel = [&](int q) { if (np > 1) ck(c, r, srw_shard_select(h, q)); };
+    guard([&] {
+      SRW_HIP(hipSetDevice(c->dev[(size_t)r]));
+      for (int q = 0; q < np; ++q) {
+        sel(q);
+        ck(c, r, srw_shard_begin(h, &pops[(size_t)q].P, pops[(size_t)q].B, &lay[(size_t)q], c->recv[q][0][(size_t)r].p, pops[(size_t)q].pth[(size_t)r], pops[(size_t)q].len[(size_t)r]));
+      }
+    });
     std::vector<void *> dst((size_t)world);
-    for (int32_t step = 1; step <= P.walk_length + 1; ++step) {
+    for (int32_t step = 1; step <= L + 1; ++step) {
       const int cur = (step - 1) & 1, nxt = cur ^ 1;
       guard([&] {
-        for (int d = 0; d < world; ++d) dst[(size_t)d] = c->recv[nxt][(size_t)d].p + (size_t)r * (size_t)lay.chunk_bytes;
-        ck(c, r, srw_shard_superstep(h, &P, B, step, &lay, c->recv[cur][(size_t)r].p, dst.data(), pth[(size_t)r], len[(size_t)r]));
-        SRW_HIP(hipEventRecord(c->ev[cur][(size_t)r], h->stream));
+        for (int q = 0; q < np; ++q) {
+          sel(q);
+          for (int d = 0; d < world; ++d) dst[(size_t)d] = c->recv[q][nxt][(size_t)d].p + (size_t)r * (size_t)lay[(size_t)q].chunk_bytes;
+          ck(c, r, srw_shard_superstep(h, &pops[(size_t)q].P, pops[(size_t)q].B, step, &lay[(size_t)q], c->recv[q][cur][(size_t)r].p, dst.data(),
+                                       pops[(size_t)q].pth[(size_t)r], pops[(size_t)q].len[(size_t)r]));
+          SRW_HIP(hipEventRecord(c->ev[q][cur][(size_t)r], h->stream));
+        }
       });
       if (world > 1) {
         bar.wait();
         guard([&] {
-          for (int o = 0; o < world; ++o)
-            if (o != r) SRW_HIP(hipStreamWaitEvent(h->stream, c->ev[cur][(size_t)o], 0));
+          for (int q = 0; q < np; ++q) {
+            sel(q);
+            for (int o = 0; o < world; ++o)
+              if (o != r) SRW_HIP(hipStreamWaitEvent(h->stream, c->ev[q][cur][(size_t)o], 0));
+          }
         });
       }
     }
-    const int fin = (P.walk_length + 1) & 1;
+    const int fin = (L + 1) & 1;
     guard([&] {
-      ck(c, r, srw_shard_flush(h, &P, B, &lay, c->recv[fin][(size_t)r].p, pth[(size_t)r], len[(size_t)r]));
-      ck(c, r, srw_shard_finish(h, &st[(size_t)r], &of[(size_t)r]));
+      for (int q = 0; q < np; ++q) {
+        sel(q);
+        ck(c, r, srw_shard_flush(h, &pops[(size_t)q].P, pops[(size_t)q].B, &lay[(size_t)q], c->recv[q][fin][(size_t)r].p, pops[(size_t)q].pth[(size_t)r], pops[(size_t)q].len[(size_t)r]));
+      }
+      for (int q = 0; q < np; ++q) { sel(q); ck(c, r, srw_shard_finish(h, &st[(size_t)q][(size_t)r], &of[(size_t)q][(size_t)r])); }
     });
+    if (np > 1) (void)srw_shard_select(h, 0);        // whatever happened: population 0's context is the handle's own again
   };
   if (world == 1) body(0);
   else {
@@ -306,17 +331,27 @@ bool run_batch(srw_cluster *c, const srw_walk_params &P, int32_t B, double slack
   }
   for (int r = 0; r < world; ++r)
     if (err_code[(size_t)r] != SRW_OK) throw Error(err_code[(size_t)r], err[(size_t)r]);
-  bool overflow = false;
-  memset(&bt, 0, sizeof bt);
-  for (int r = 0; r < world; ++r) {
-    const srw_walk_stats &x = st[(size_t)r];
-    overflow |= of[(size_t)r] != 0;
-    bt.n_steps += x.n_steps; bt.dead_ends += x.dead_ends; bt.sum_deg_curr += x.sum_deg_curr; bt.sum_deg_prev += x.sum_deg_prev;
-    bt.ent_reads += x.ent_reads; bt.fallbacks += x.fallbacks; bt.trials += x.trials;
-    for (int i = 0; i < 12; ++i) bt.strategy_steps[i] += x.strategy_steps[i];
-    bt.edge_tables += x.edge_tables; bt.edge_table_bytes += x.edge_table_bytes;      // per shard: summed = the whole graph's set
+  for (int q = 0; q < np; ++q) {
+    Pop &pp = pops[(size_t)q];
+    pp.overflow = false;
+    memset(&pp.bt, 0, sizeof pp.bt);
+    for (int r = 0; r < world; ++r) {
+      const srw_walk_stats &x = st[(size_t)q][(size_t)r];
+      pp.overflow |= of[(size_t)q][(size_t)r] != 0;
+      pp.bt.n_steps += x.n_steps; pp.bt.dead_ends += x.dead_ends; pp.bt.sum_deg_curr += x.sum_deg_curr; pp.bt.sum_deg_prev += x.sum_deg_prev;
+      pp.bt.ent_reads += x.ent_reads; pp.bt.fallbacks += x.fallbacks; pp.bt.trials += x.trials;
+      for (int i = 0; i < 12; ++i) pp.bt.strategy_steps[i] += x.strategy_steps[i];
+      pp.bt.edge_tables += x.edge_tables; pp.bt.edge_table_bytes += x.edge_table_bytes;      // per shard: summed = the whole graph's set
+    }
   }
-  return overflow;
+}
+bool run_batch(srw_cluster *c, const srw_walk_params &P, int32_t B, double slack, const std::vector<int32_t *> &pth,
+               const std::vector<int32_t *> &len, srw_walk_stats &bt) {
+  std::vector<Pop> pops(1);
+  pops[0].P = P; pops[0].B = B; pops[0].pth = pth; pops[0].len = len;
+  run_populations(c, pops, slack);
+  bt = pops[0].bt;
+  return pops[0].overflow;
 }
 
 struct WalkPlan { std::vector<int64_t> n_local; int64_t n_global = 0, stride = 0; int32_t batch = 1; int kind = 1; };
@@ -373,22 +408,34 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
     const auto t0 = std::chrono::steady_clock::now();
     double slack = 1.25;
     std::vector<int32_t *> pth((size_t)world), len((size_t)world);
+    // A batch of B >= 2 iterations runs as TWO populations of B / 2 and B - B / 2 on two streams per shard (run_populations):
+    // identical paths (a population is defined by its iterations), SRW_CLUSTER_POPULATIONS=1 for the single-population form.
+    const bool two = !(getenv("SRW_CLUSTER_POPULATIONS") && atoi(getenv("SRW_CLUSTER_POPULATIONS")) == 1);
     for (int32_t it0 = 0; it0 < P0.num_walks;) {
       const int32_t B = std::min(w.batch, P0.num_walks - it0);
-      srw_walk_params P = P0; P.first_walk = P0.first_walk + it0; P.num_walks = B;
-      for (int r = 0; r < world; ++r) {
-        pth[(size_t)r] = c->paths[(size_t)r].p + (int64_t)it0 * w.n_local[(size_t)r] * w.stride;
-        len[(size_t)r] = c->lens[(size_t)r].p + (int64_t)it0 * w.n_local[(size_t)r];
+      std::vector<Pop> pops((two && B >= 2) ? 2 : 1);
+      int32_t off = 0;
+      for (size_t q = 0; q < pops.size(); ++q) {
+        const int32_t Bq = pops.size() == 1 ? B : (q == 0 ? B / 2 : B - B / 2);
+        pops[q].P = P0; pops[q].P.first_walk = P0.first_walk + it0 + off; pops[q].P.num_walks = Bq; pops[q].B = Bq;
+        pops[q].pth.resize((size_t)world); pops[q].len.resize((size_t)world);
+        for (int r = 0; r < world; ++r) {
+          pops[q].pth[(size_t)r] = c->paths[(size_t)r].p + (int64_t)(it0 + off) * w.n_local[(size_t)r] * w.stride;
+          pops[q].len[(size_t)r] = c->lens[(size_t)r].p + (int64_t)(it0 + off) * w.n_local[(size_t)r];
+        }
+        off += Bq;
       }
-      srw_walk_stats bt;
-      if (run_batch(c, P, B, slack, pth, len, bt)) {      // a chunk was too small for this graph's skew: same batch again with more room
+      run_populations(c, pops, slack);
+      bool overflow = false;
+      for (const Pop &pp : pops) overflow |= pp.overflow;
+      if (overflow) {      // a chunk was too small for this graph's skew: same batch again with more room
         if (getenv("SRW_TIMING")) fprintf(stderr, "[cluster] chunk overflow at slack %.2f (batch %d, iteration %d): retrying\n", slack, B, it0);
         slack *= 2.0;
         if (slack > 64.0 * world) throw Error(SRW_ERR_NOMEM, "vertex-sharded walk: chunk overflow persists at 64 x world slack");
         continue;
       }
-      add_stats(tot, bt);
-      c->batches.push_back({it0, B});
+      off = 0;
+      for (const Pop &pp : pops) { add_stats(tot, pp.bt); c->batches.push_back({it0 + off, pp.B}); off += pp.B; }
       it0 += B;
     }
     tot.kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

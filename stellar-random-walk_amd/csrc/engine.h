@@ -186,6 +186,17 @@ struct srw_handle {
   srw::DevBuf<char> chain_buf;                   // sharded table steps whose draw sits on a CDF boundary: record list, meta, totals ...
   srw::DevBuf<double> chain_d;                   // ... and the quotients w'_k / S of their rows (k_chain_*)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // A second walker population on this handle (srw_shard_select): its own super-step context — scratch, cursors, counters, path
+  // staging, chain buffers — and its own stream, so that one population's kernels run while the other's chunks are on the wire
+  // (the serial shuffle / count rhythm of RandomWalk.scala:91-162 has no such overlap).  The parked context lives here; selecting
+  // swaps it with the members above.
+  struct ShardCtx {
+    srw::DevBuf<srw::DevCounters> counters; srw::DevBuf<unsigned long long> walk_cursor; srw::DevBuf<int32_t> walk_todo;
+    srw::DevBuf<char> shard_scratch; srw::DevBuf<uint32_t> shard_blk, shard_flag, shard_cur; srw::DevBuf<int32_t> shard_pt;
+    srw::DevBuf<char> chain_buf; srw::DevBuf<double> chain_d;
+    hipStream_t stream = nullptr; bool own_stream = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  } shard_parked;
+  int shard_population = 0;                      // which population's context is in the members above (0 / 1)
   // srw_walk_to_host: second stream + two staging buffers for compute/copy overlap
   hipStream_t copy_stream = nullptr;
   srw::DevBuf<int32_t> stage_paths[2], stage_lens[2];

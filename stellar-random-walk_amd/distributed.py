@@ -46,6 +46,17 @@ class HipShardEngine:
         self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.world = world
 
+    def select(self, population):
+        """srw_shard_select: population 0 / 1 of this handle, each with its own super-step context and its own torch stream
+        (returned: run the population's super-step and its collective under `with torch.cuda.stream(...)`)."""
+        if not hasattr(self, "_streams"):
+            self._streams = [torch.cuda.current_stream(self.device), None]
+        self.engine._ck(lib().srw_shard_select(self.engine.h, int(population)))
+        if population == 1 and self._streams[1] is None:
+            self._streams[1] = torch.cuda.Stream(device=self.device)
+            self.engine.set_stream(self._streams[1].cuda_stream)        # (the selected context's stream)
+        return self._streams[population]
+
     def capacity(self):
         return self.engine.shard_capacity()
 
@@ -219,21 +230,21 @@ class ShardedWalker:
             b -= 1
         return b
 
-    def _buffers(self, nbytes):
-        b = self._bufs.get("x")
+    def _buffers(self, nbytes, key=""):
+        b = self._bufs.get("x" + key)
         if b is None or b[0].numel() < nbytes:
             if self.engine is not None and self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
-                old = self._bufs.pop("mem", None)
+                old = self._bufs.pop("mem" + key, None)
                 if old:
                     for m in old:
                         m.free()
                 mem = (_DeviceBuffer(self.engine, nbytes, self.device), _DeviceBuffer(self.engine, nbytes, self.device))
-                self._bufs["mem"] = mem
+                self._bufs["mem" + key] = mem
                 b = (mem[0].tensor, mem[1].tensor)
             else:                           # the CPU protocol tests (gloo + the oracle as step engine)
                 b = (torch.empty(nbytes, dtype=torch.uint8, device=self.device), torch.empty(nbytes, dtype=torch.uint8, device=self.device))
-            self._bufs["x"] = b
+            self._bufs["x" + key] = b
         return b[0][:nbytes], b[1][:nbytes]
 
     # ---- walk_length + 1 super-steps over the walkers of `num_walks` consecutive walk iterations ----
@@ -277,6 +288,103 @@ class ShardedWalker:
         st["exchange_bytes_per_superstep"] = world * lay.chunk_bytes
         return paths[:B * n_local], lens[:B * n_local], st
 
+    def walk_populations(self, iteration=0, p=1.0, q=1.0, walk_length=80, num_walks=2, seed=42, rng="philox", const_r=0.0,
+                         slack=1.25, flags_kw=None):
+        """Iterations iteration .. iteration + num_walks - 1 as TWO walker populations (num_walks // 2 and the rest) whose super-steps
+        are interleaved, each on its own stream with its own exchange buffers: population B's kernels run while population A's chunks
+        are in the all-to-all — the overlap the reference's shuffle / count rhythm (RandomWalk.scala:91-162) does not have.  Identical
+        paths (a population is defined by its iterations).  Returns [(first iteration, n, paths, lens, stats)] per population.  Falls
+        back to ONE population when the step engine has no second context (the CPU protocol tests), num_walks < 2 or
+        SRW_SHARD_POPULATIONS=1."""
+        two = hasattr(self.se, "select") and num_walks >= 2 and os.environ.get("SRW_SHARD_POPULATIONS", "2") != "1"
+        kw = dict(p=p, q=q, walk_length=walk_length, seed=seed, rng=rng, const_r=const_r, slack=slack, flags_kw=flags_kw)
+        if not two:
+            pth, ln, st = self.walk_batch(iteration=iteration, num_walks=num_walks, **kw)
+            return [(iteration, num_walks, pth, ln, st)]
+        world = self.world
+        n_local, n_global = self.se.capacity()
+        stride = walk_length + 2
+        if self._linked is None and p == 1.0 and q == 1.0 and rng == "philox":
+            self._linked = bool(self.se.link_rows(self.group)) if hasattr(self.se, "link_rows") else False
+        dev = self.device
+        sizes = [num_walks // 2, num_walks - num_walks // 2]
+        firsts = [iteration, iteration + sizes[0]]
+        Ps = [Engine.params(p=p, q=q, walk_length=walk_length, num_walks=b, first_walk=f, rng=rng, const_r=const_r, seed=seed, **(flags_kw or {}))
+              for b, f in zip(sizes, firsts)]
+        paths = [torch.empty((max(b * n_local, 1), stride), dtype=torch.int32, device=dev) for b in sizes]
+        lens = [torch.empty(max(b * n_local, 1), dtype=torch.int32, device=dev) for b in sizes]
+        try:
+            while True:
+                lays = [self.se.layout(b, slack) for b in sizes]
+                for lay in lays:
+                    if lay.chunk_bytes > self.MAX_MESSAGE_BYTES:
+                        raise ValueError("vertex-sharded walk: a chunk of %d bytes per peer exceeds the %d-byte exchange message limit" % (lay.chunk_bytes, self.MAX_MESSAGE_BYTES))
+                bufs = [self._buffers(world * lay.chunk_bytes, key=str(k)) for k, lay in enumerate(lays)]
+                torch.cuda.synchronize(dev)
+                streams = [self.se.select(k) for k in (0, 1)]
+                for k in (0, 1):
+                    self.se.select(k)
+                    with torch.cuda.stream(streams[k]):
+                        self.se.begin(Ps[k], sizes[k], lays[k], bufs[k][0], paths[k], lens[k])
+                for step in range(1, walk_length + 2):
+                    for k in (0, 1):
+                        self.se.select(k)
+                        with torch.cuda.stream(streams[k]):
+                            self.se.superstep(Ps[k], sizes[k], step, lays[k], bufs[k][0], bufs[k][1], paths[k], lens[k])
+                            self._a2a(bufs[k][0], bufs[k][1])
+                sts, overflow = [], 0
+                for k in (0, 1):
+                    self.se.select(k)
+                    with torch.cuda.stream(streams[k]):
+                        self.se.flush(Ps[k], sizes[k], lays[k], bufs[k][0], paths[k], lens[k])
+                        st, of = self.se.finish()
+                    sts.append(st); overflow |= of
+                self.se.select(0)
+                torch.cuda.synchronize(dev)
+                t = torch.tensor([sts[0]["n_steps"] + sts[1]["n_steps"], sts[0]["dead_ends"] + sts[1]["dead_ends"], overflow], dtype=torch.int64, device=dev)
+                tot = t.clone()
+                self._ar(tot, dist.ReduceOp.SUM)
+                if int(tot[2]) == 0:
+                    break
+                slack *= 2.0
+                if slack > 64:
+                    raise RuntimeError("vertex-sharded walk: chunk overflow persists at 64x slack")
+        finally:
+            self.se.select(0)
+        out = []
+        for k in (0, 1):
+            sts[k]["n_steps_global"], sts[k]["dead_ends_global"] = (int(tot[0]), int(tot[1])) if k == 0 else (0, 0)
+            sts[k]["exchange_bytes_per_superstep"] = world * lays[k].chunk_bytes
+            out.append((firsts[k], sizes[k], paths[k][:sizes[k] * n_local], lens[k][:sizes[k] * n_local], sts[k]))
+        return out
+
+    def profile_batch(self, iteration=0, p=1.0, q=1.0, walk_length=80, num_walks=1, seed=42, slack=1.25):
+        """One single-population batch with device events around every super-step's kernels and around its all-to-all: what a
+        super-step costs in kernels and in exchange when nothing overlaps (bench.py prints it next to the overlapped rate, so that a
+        first multi-GPU run can be read).  Returns {"kernels_ms", "exchange_ms"} (means per super-step) or None on CPU engines."""
+        if self.device.type != "cuda":
+            return None
+        n_local, _ = self.se.capacity()
+        P = Engine.params(p=p, q=q, walk_length=walk_length, num_walks=num_walks, first_walk=iteration, seed=seed)
+        lay = self.se.layout(num_walks, slack)
+        recv, send = self._buffers(self.world * lay.chunk_bytes)
+        paths = torch.empty((max(num_walks * n_local, 1), walk_length + 2), dtype=torch.int32, device=self.device)
+        lens = torch.empty(max(num_walks * n_local, 1), dtype=torch.int32, device=self.device)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(walk_length + 1)]
+        self.se.begin(P, num_walks, lay, recv, paths, lens)
+        for i, step in enumerate(range(1, walk_length + 2)):
+            ev[i][0].record()
+            self.se.superstep(P, num_walks, step, lay, recv, send, paths, lens)
+            ev[i][1].record()
+            self._a2a(recv, send)
+            ev[i][2].record()
+        self.se.flush(P, num_walks, lay, recv, paths, lens)
+        self.se.finish()
+        torch.cuda.synchronize(self.device)
+        k = [e[0].elapsed_time(e[1]) for e in ev]
+        x = [e[1].elapsed_time(e[2]) for e in ev]
+        return {"kernels_ms": sum(k) / len(k), "exchange_ms": sum(x) / len(x), "super_steps": len(k), "exchange_bytes": self.world * lay.chunk_bytes}
+
     def walk(self, num_walks=1, first_walk=0, batch=None, **kw):
         """num_walks iterations; returns (paths [num_walks * nV, L + 2], lens, stats) in canonical order on every rank
         (all-gathered: tests and small graphs; production keeps the paths on their home ranks, see walk_batch)."""
@@ -288,14 +396,14 @@ class ShardedWalker:
         out_p = torch.full((num_walks * n_global, stride), -1, dtype=torch.int32, device=self.device)
         out_l = torch.zeros(num_walks * n_global, dtype=torch.int32, device=self.device)
         stats = []
-        for it in range(0, num_walks, batch):
-            b = min(batch, num_walks - it)
-            pth, ln, st = self.walk_batch(iteration=first_walk + it, num_walks=b, **kw)
-            lw = torch.arange(b * n_local, device=self.device, dtype=torch.int64)
-            canon = (it + lw % b) * n_global + vr[lw // b] if n_local else lw
-            out_p[canon] = pth
-            out_l[canon] = ln
-            stats.append(st)
+        for it0 in range(0, num_walks, batch):
+            for (f, b, pth, ln, st) in self.walk_populations(iteration=first_walk + it0, num_walks=min(batch, num_walks - it0), **kw):
+                it = f - first_walk
+                lw = torch.arange(b * n_local, device=self.device, dtype=torch.int64)
+                canon = (it + lw % b) * n_global + vr[lw // b] if n_local else lw
+                out_p[canon] = pth
+                out_l[canon] = ln
+                stats.append(st)
         # every canonical row is owned by exactly one rank; rows of other ranks are (-1.., 0) here
         self._ar(out_l, dist.ReduceOp.SUM)
         out_p += 1                                        # -1 filler -> 0, ids shifted by one: SUM assembles, no sentinel id
@@ -325,18 +433,23 @@ def bench_vertex_sharded(dist_mod, local_rank, rank, world, scale, n_edges, weig
     steps = 0
     st = None
     for it in range(W, W + K, B):
-        _, _, st = drv.walk_batch(iteration=it, num_walks=min(B, W + K - it), **kw)
-        steps += st["n_steps_global"]
+        for (_, _, _, _, st) in drv.walk_populations(iteration=it, num_walks=min(B, W + K - it), **kw):
+            steps += st["n_steps_global"]
     barrier_sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
     max_dt = float(t.item())
+    try:          # outside the timed region: one unoverlapped batch, kernels and exchange timed apart
+        prof = drv.profile_batch(iteration=W + K, num_walks=max(1, B // 2), **kw)
+    except Exception as ex:      # noqa: BLE001
+        prof = {"error": str(ex)[:200]}
     return {"value": steps / max_dt, "unit": "walk-steps/s", "ms_per_step": max_dt / max(K, 1) * 1e3, "scaling": "strong",
-            "steps": K, "warmup": W, "iterations_per_population": B,
+            "steps": K, "warmup": W, "iterations_per_batch": B, "populations_per_batch": 2 if (B >= 2 and os.environ.get("SRW_SHARD_POPULATIONS", "2") != "1") else 1,
             "workload": "RMAT scale-%d (%d edge lines, %d adjacency entries, %d vertices), p=%g q=%g walkLength=%d" % (
                 scale, n_edges, ne, nv, kw.get("p", 1.0), kw.get("q", 1.0), kw.get("walk_length", 80)),
             "parallelism": "graph sharded by source vertex x%d (owner = mix32(id) mod world), 1 RCCL all_to_all_single per super-step, "
                            "paths on the home GPU" % world,
             "local_vertices_rank0": n_local, "exchange_bytes_per_superstep_per_rank": st["exchange_bytes_per_superstep"] if st else 0,
+            "per_superstep_unoverlapped": prof,
             "setup_s": {"graph_generate_and_csr": t_graph}}

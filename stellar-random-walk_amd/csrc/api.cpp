@@ -152,11 +152,11 @@ void srw_destroy(srw_handle *h) {
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   for (int i = 0; i < 2; ++i) { if (h->pin_paths[i]) (void)hipHostFree(h->pin_paths[i]); if (h->pin_lens[i]) (void)hipHostFree(h->pin_lens[i]); }
   for (int i = 0; i < 2; ++i) { if (h->pin_text[i]) (void)hipHostFree(h->pin_text[i]); if (h->pin_off[i]) (void)hipHostFree(h->pin_off[i]); }
-  if (h->shard_parked.stream) {
-    (void)hipStreamSynchronize(h->shard_parked.stream);
+  if (h->shard_parked.init) {
+    if (h->shard_parked.stream) (void)hipStreamSynchronize(h->shard_parked.stream);
     if (h->shard_parked.ev0) (void)hipEventDestroy(h->shard_parked.ev0);
     if (h->shard_parked.ev1) (void)hipEventDestroy(h->shard_parked.ev1);
-    if (h->shard_parked.own_stream) (void)hipStreamDestroy(h->shard_parked.stream);
+    if (h->shard_parked.own_stream && h->shard_parked.stream) (void)hipStreamDestroy(h->shard_parked.stream);
   }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -426,7 +426,8 @@ int32_t srw_shard_select(srw_handle *h, int32_t population) {
   return guarded(h, [&] {
     if (population == h->shard_population) return;
     auto &k = h->shard_parked;
-    if (!k.stream) {                                   // first use of the second population: its own stream and events
+    if (!k.init) {                                     // first use of the second population: its own stream and events
+      k.init = true;                                   // (a flag, not "stream == null": a caller's stream may be the null stream — torch's default)
       SRW_HIP(hipSetDevice(h->cfg.device));
       SRW_HIP(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking)); k.own_stream = true;
       SRW_HIP(hipEventCreate(&k.ev0)); SRW_HIP(hipEventCreate(&k.ev1));

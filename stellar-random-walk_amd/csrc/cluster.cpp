@@ -410,7 +410,10 @@ int32_t srw_cluster_walk(srw_cluster *c, const srw_walk_params *params, int32_t 
     std::vector<int32_t *> pth((size_t)world), len((size_t)world);
     // A batch of B >= 2 iterations runs as TWO populations of B / 2 and B - B / 2 on two streams per shard (run_populations):
     // identical paths (a population is defined by its iterations), SRW_CLUSTER_POPULATIONS=1 for the single-population form.
-    const bool two = !(getenv("SRW_CLUSTER_POPULATIONS") && atoi(getenv("SRW_CLUSTER_POPULATIONS")) == 1);
+    // (world 1 has no exchange to hide: two half populations only double the launches there — 0.61 against 0.68 of the replicated
+    //  kernel at RMAT-24, r04 s114 — so one population unless SRW_CLUSTER_POPULATIONS=2 asks for two)
+    const int pops_env = getenv("SRW_CLUSTER_POPULATIONS") ? atoi(getenv("SRW_CLUSTER_POPULATIONS")) : 0;
+    const bool two = pops_env == 2 || (pops_env != 1 && world > 1);
     for (int32_t it0 = 0; it0 < P0.num_walks;) {
       const int32_t B = std::min(w.batch, P0.num_walks - it0);
       std::vector<Pop> pops((two && B >= 2) ? 2 : 1);

@@ -143,6 +143,9 @@ struct GraphView {
   const PairSlot *rh;
   uint32_t rh_buckets;
   EbPolicy ebp;            // geometry of the standing per-edge tables (chunk sizes, chunk masks, finer tables of the pairs with a long N(prev))
+  // Unit-weight graphs (every w == 1.0f: unweighted inputs, config 5): the ids alone, in input order — the table steps then read 4 bytes per
+  // candidate instead of the 8-byte (id, w) entry (graph_build.hip:build_unit_ids; null otherwise)
+  const int32_t *ids32;
   int32_t dbg_chain_deg;   // tests (SRW_DEBUG_CHAIN_DEG): sharded steps on rows at least this long are treated as draws on a CDF boundary (0: off)
 };
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;

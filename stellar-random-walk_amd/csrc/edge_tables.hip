@@ -758,6 +758,7 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
   // new (p, q) or first use: drop what stands, then size the new set against what is free
   g.has_eb = false; g.use_eb = false; g.eb_complete = false; g.eb_tables = 0; g.eb_bytes = 0;
   g.eb_bins.release(); g.em_bits.release(); g.ph.release(); g.ph_buckets = 0; g.eb_off.release();
+  build_unit_ids(h);                                         // unit-weight graphs: 4-byte ids for the table steps
   // 1. the finest complete set that fits
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));

@@ -121,6 +121,8 @@ struct Graph {
   int32_t eb_min_sh_sel = 8;      // log2 of the smallest table chunk the next table build uses (prepare_tables / prepare_shard_tables choose it)
   int32_t dbg_chain_deg = 0;      // SRW_DEBUG_CHAIN_DEG (read by run_shard_superstep)
   bool has_cfo_local = false;     // sharded: compact first-order records over the LOCAL rows (guide + ids; their links are not used)
+  DevBuf<int32_t> ids32;          // unit-weight graphs: the neighbor ids alone, input order (GraphView::ids32); unit_w: -1 not checked yet
+  bool has_ids32 = false; int unit_w = -1;
   DevBuf<uint32_t> bf_off, bf_bits; // neighbor-set filters of the rows beyond 1024 neighbors (GraphView::bf_off), built with the per-edge tables
   bool has_bf = false;
   // Compacted ids (sparse id spaces, SRW_CFG_COMPACT_IDS): slots are ranks among the sorted distinct input ids
@@ -136,7 +138,7 @@ struct Graph {
                      (has_eb && use_eb && !eb_sharded) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
                      has_rev ? rev.p : nullptr, eb_cap, compact ? orig_id.p : nullptr,
                      (has_bf && use_eb && !(has_ehash && use_ehash)) ? bf_off.p : nullptr, bf_bits.p,
-                     (has_eb && use_eb && eb_sharded) ? ph.p : nullptr, ph_buckets, has_rh ? rh.p : nullptr, rh_buckets, ebp, dbg_chain_deg}; }
+                     (has_eb && use_eb && eb_sharded) ? ph.p : nullptr, ph_buckets, has_rh ? rh.p : nullptr, rh_buckets, ebp, has_ids32 ? ids32.p : nullptr, dbg_chain_deg}; }
   // id <-> slot at the boundary (api.cpp): -1 if the id cannot be a vertex of this graph
   int64_t slot_of_id(int32_t v) const {
     if (!compact) { const int64_t s = (int64_t)v - vmin; return (s < 0 || s >= n_slots) ? -1 : s; }
@@ -194,7 +196,7 @@ struct srw_handle {
     srw::DevBuf<srw::DevCounters> counters; srw::DevBuf<unsigned long long> walk_cursor; srw::DevBuf<int32_t> walk_todo;
     srw::DevBuf<char> shard_scratch; srw::DevBuf<uint32_t> shard_blk, shard_flag, shard_cur; srw::DevBuf<int32_t> shard_pt;
     srw::DevBuf<char> chain_buf; srw::DevBuf<double> chain_d;
-    hipStream_t stream = nullptr; bool own_stream = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr; bool own_stream = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; bool init = false;
   } shard_parked;
   int shard_population = 0;                      // which population's context is in the members above (0 / 1)
   // srw_walk_to_host: second stream + two staging buffers for compute/copy overlap
@@ -297,6 +299,7 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,
                          DevBuf<int32_t> &d_src, DevBuf<int32_t> &d_dst, DevBuf<float> &d_w);
 void build_membership(srw_handle *h);
+void build_unit_ids(srw_handle *h);               // graph_build.hip: ids32 of a unit-weight graph (a no-op otherwise or when HBM is short)
 void build_row_filters(srw_handle *h);            // word-blocked Bloom filters of the long rows (GraphView::bf_off)
 void build_first_order_tables(srw_handle *h, bool want_exact);
 void build_pq_tables(srw_handle *h, float p, float q);

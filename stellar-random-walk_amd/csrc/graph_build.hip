@@ -384,6 +384,41 @@ void compact_ids(srw_handle *h, int32_t *d_src, int32_t *d_dst, int64_t n_lines,
 }
 
 // Optional accelerator of the table steps (binned_resolve): skipped when HBM is short or the offsets would not fit 32 bits.
+namespace {
+__global__ void k_unit_check(const Ent *__restrict__ ent, int64_t n, unsigned int *flag) {
+  bool bad = false;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) bad |= ent[e].w != 1.0f;
+  if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1u);
+}
+__global__ void k_unit_ids(const Ent *__restrict__ ent, int64_t n, int32_t *__restrict__ ids) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) ids[e] = ent[e].id;
+}
+}  // namespace
+// Unit-weight graphs: the table steps of the biased walk read ids32[e] (4 B) instead of ent[e] (8 B) — they are bound by memory requests
+// (config 5's stand-in: 0.9 of the request ceiling), and a located chunk's entries are a third of them.
+void build_unit_ids(srw_handle *h) {
+  Graph &g = h->g;
+  if (g.has_ids32 || g.unit_w == 0 || g.n_entries <= 0 || getenv("SRW_NO_UNIT_IDS")) return;
+  hipStream_t st = h->stream;
+  if (g.unit_w < 0) {
+    DevBuf<unsigned int> flag; flag.alloc(1);
+    SRW_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+    hipLaunchKernelGGL(k_unit_check, dim3(h->n_cus * 8), dim3(TPB), 0, st, g.ent.p, g.n_entries, flag.p);
+    unsigned int f = 0;
+    SRW_HIP(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    g.unit_w = f ? 0 : 1;
+  }
+  if (!g.unit_w) return;
+  size_t free_b = 0, total_b = 0;
+  SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+  if (free_b < (size_t)g.n_entries * 4 + ((size_t)32 << 30)) return;          // optional: not when HBM is short
+  g.ids32.alloc((size_t)g.n_entries);
+  hipLaunchKernelGGL(k_unit_ids, dim3(h->n_cus * 8), dim3(TPB), 0, st, g.ent.p, g.n_entries, g.ids32.p);
+  SRW_HIP(hipGetLastError());
+  g.has_ids32 = true;
+}
+
 void build_row_filters(srw_handle *h) {
   Graph &g = h->g;
   if (g.has_bf || g.n_entries_global <= 0) return;

@@ -46,6 +46,11 @@ __device__ inline float biased_weight(const Bias &b, int32_t id, float w) {
 
 // ---- exact pick, one lane, fully sequential (irregular rows and tiny degrees) ---------------------------
 // Literally RandomSample.sample on the (biased) row.
+// entry k of a row: the (id, w) pair, or — unit-weight graphs with GraphView::ids32 — the id alone (half the bytes per candidate)
+__device__ inline Ent load_ent(const GraphView &g, const Ent *row, int32_t k) {
+  if (g.ids32) { Ent e; e.id = g.ids32[(row - g.ent) + k]; e.w = 1.0f; return e; }
+  return row[k];
+}
 __device__ inline int32_t lane_pick_sequential(const Ent *row, int32_t deg, const Bias &b, float r) {
   double sum = 0.0;
   for (int32_t k = 0; k < deg; ++k) {
@@ -1420,7 +1425,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     for (int u = 0; u < PL; ++u) {
       const int32_t k = base + u * 64 + lane;
       e_nx[u].id = b.prev; e_nx[u].w = 0.0f; mw_nx[u] = 0ull;
-      if (k <= k1) e_nx[u] = row[k];
+      if (k <= k1) e_nx[u] = load_ent(g, row, k);
       if (cmask && base + u * 64 <= k1) mw_nx[u] = cmask[(base >> 6) + u];
     }
   };
@@ -1582,6 +1587,10 @@ __device__ inline int32_t wave_pick_first(const GraphView &g, const Row &rc, flo
   double part = 0.0;
   SumCert cert;
   bool neg = false;
+  if (g.ids32) {                                     // unit weights: S = deg, nothing to read
+    if (lane == 0) part = (double)deg;
+    cert.add(1.0f);
+  } else
   for (int32_t base = 0; base < deg; base += 256) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1607,7 +1616,7 @@ __device__ inline int32_t wave_pick_first(const GraphView &g, const Row &rc, flo
     const int32_t k = base + lane;
     const bool valid = k < deg;
     Ent e; e.id = 0; e.w = 0.0f;
-    if (valid) e = row[k];
+    if (valid) e = load_ent(g, row, k);
     const double incl = wave_incl_scan_f64((double)e.w);
     const double num = carry + incl;
     const double t = (double)(k + 8) * 0x1p-51;
@@ -1656,7 +1665,7 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
     const int32_t k = i * 64 + lane;
     wv[i] = 0.0f; idv[i] = 0;
     if (i < ni && k < deg) {
-      const Ent e = row[k];
+      const Ent e = load_ent(g, row, k);
       float w;
       if (e.id == b.prev) w = div_exact(e.w, b.p);
       else if ((mw[i] >> (lane & 31)) & 1u) w = e.w;

@@ -2241,6 +2241,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool want_eb = general && P.q != 1.0f && h->cfg.world == 1 && h->g.has_pq && !(P.flags & SRW_WALK_NO_EDGE_TABLES) &&
                        !(P.flags & SRW_WALK_NO_BINNED);
   const int eb_mode = (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0;
+  if (want_eb) build_unit_ids(h);                     // unit-weight graphs: 4-byte ids for the table steps (before the tables are sized)
   const char *env_hub = getenv("SRW_HUB_BUDGET_GB"), *env_cap = getenv("SRW_EB_CHUNKS");
   // The edge hash (8 B x 2-3 per entry) against table resolution: when a COMPLETE 64-chunk set of per-edge tables fits only
   // without the hash, the hash goes — the located chunks' probes of a long non-hub N(prev) fall back to the sorted row, and

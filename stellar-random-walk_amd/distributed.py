@@ -296,7 +296,9 @@ class ShardedWalker:
         paths (a population is defined by its iterations).  Returns [(first iteration, n, paths, lens, stats)] per population.  Falls
         back to ONE population when the step engine has no second context (the CPU protocol tests), num_walks < 2 or
         SRW_SHARD_POPULATIONS=1."""
-        two = hasattr(self.se, "select") and num_walks >= 2 and os.environ.get("SRW_SHARD_POPULATIONS", "2") != "1"
+        pops_env = os.environ.get("SRW_SHARD_POPULATIONS", "")
+        # (world 1 has no exchange to hide: one population there unless SRW_SHARD_POPULATIONS=2 asks for two)
+        two = hasattr(self.se, "select") and num_walks >= 2 and (pops_env == "2" or (pops_env != "1" and self.world > 1))
         kw = dict(p=p, q=q, walk_length=walk_length, seed=seed, rng=rng, const_r=const_r, slack=slack, flags_kw=flags_kw)
         if not two:
             pth, ln, st = self.walk_batch(iteration=iteration, num_walks=num_walks, **kw)
@@ -445,7 +447,7 @@ def bench_vertex_sharded(dist_mod, local_rank, rank, world, scale, n_edges, weig
     except Exception as ex:      # noqa: BLE001
         prof = {"error": str(ex)[:200]}
     return {"value": steps / max_dt, "unit": "walk-steps/s", "ms_per_step": max_dt / max(K, 1) * 1e3, "scaling": "strong",
-            "steps": K, "warmup": W, "iterations_per_batch": B, "populations_per_batch": 2 if (B >= 2 and os.environ.get("SRW_SHARD_POPULATIONS", "2") != "1") else 1,
+            "steps": K, "warmup": W, "iterations_per_batch": B, "populations_per_batch": 2 if (B >= 2 and (os.environ.get("SRW_SHARD_POPULATIONS", "") == "2" or (os.environ.get("SRW_SHARD_POPULATIONS", "") != "1" and world > 1))) else 1,
             "workload": "RMAT scale-%d (%d edge lines, %d adjacency entries, %d vertices), p=%g q=%g walkLength=%d" % (
                 scale, n_edges, ne, nv, kw.get("p", 1.0), kw.get("q", 1.0), kw.get("walk_length", 80)),
             "parallelism": "graph sharded by source vertex x%d (owner = mix32(id) mod world), 1 RCCL all_to_all_single per super-step, "

@@ -472,12 +472,15 @@ def test_sharded_walker_world1_nccl(oracle):
         paths, lens, stats = drv.walk(num_walks=2, p=0.5, walk_length=20, seed=3)
         rp, rl, rs = g.walk(num_walks=2, p=0.5, walk_length=20, seed=3)
         assert np.array_equal(paths, rp) and np.array_equal(lens, rl)
-        assert sum(s["n_steps_global"] for s in stats) == rs and len(stats) == 2     # one batch = two populations on two streams
-        os.environ["SRW_SHARD_POPULATIONS"] = "1"
+        assert sum(s["n_steps_global"] for s in stats) == rs and len(stats) == 1     # world 1: one batched population
+        os.environ["SRW_SHARD_POPULATIONS"] = "2"                                      # two populations on two streams: same paths, in any order of use
         try:
-            p1, l1, s1 = drv.walk(num_walks=2, p=0.5, walk_length=20, seed=3)            # the single-population form: same paths
+            for _ in range(2):
+                p2, l2, s2 = drv.walk(num_walks=2, p=0.5, walk_length=20, seed=3)
+                assert np.array_equal(p2, rp) and np.array_equal(l2, rl) and len(s2) == 2
         finally:
             del os.environ["SRW_SHARD_POPULATIONS"]
+        p1, l1, s1 = drv.walk(num_walks=2, p=0.5, walk_length=20, seed=3)
         assert np.array_equal(p1, rp) and np.array_equal(l1, rl) and len(s1) == 1
         for q, batch in ((4.0, 1), (0.5, 3)):                                       # q != 1, other batch sizes
             paths, lens, stats = drv.walk(num_walks=3, first_walk=2, batch=batch, p=0.25, q=q, walk_length=15, seed=8)

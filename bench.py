@@ -244,11 +244,8 @@ def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, 
                "steps": K, "warmup": W, "ms_per_step": dt / max(K, 1) * 1e3, "kernel_ms": avg_ms,
                "walk_steps_per_bench_step": int(steps / max(K, 1)),
                "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables},
-               # builder-side PMC traffic (profiles/pmc_latest.json) exists for config 3 (Mode R and Mode A) and config 5's stand-in (Mode R)
-               "roofline": roofline_of(st, steps / max(K, 1), avg_ms,
-                                       scale=scale if ((weighted and not directed and p == 0.25 and q == 4.0 and scale == 24) or
-                                                       (directed and not weighted and p == 4.0 and q == 0.5 and scale == 26 and ef == 27
-                                                        and sampler == "reference")) else None, n_entries=ne, ceiling=ceiling, scan=scan, q=q)}
+               "roofline": roofline_of(st, steps / max(K, 1), avg_ms, scale=scale,      # (profiles/pmc_latest.json is keyed by kernel and scale: the plan below has one configuration per key)
+                                       n_entries=ne, ceiling=ceiling, scan=scan, q=q)}
         if st["kernel_kind"] == 2:
             out["strategy_steps"] = {k: v for k, v in st["strategy_steps"].items() if v}
             out["edge_tables"] = {"count": st["edge_tables"], "bytes": st["edge_table_bytes"]}

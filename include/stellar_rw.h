@@ -310,6 +310,28 @@ int32_t srw_cluster_fetch_paths(srw_cluster *c, int32_t *paths, int32_t *lens);
 int32_t srw_cluster_walk_and_save(srw_cluster *c, const srw_walk_params *params, const char *output_dir, int32_t n_parts,
                                   int32_t write_crc, srw_walk_stats *stats);
 
+/* ---- the embedding stage (`--cmd node2vec` / `--cmd embedding`) ---------------------------------------
+ * Replaces Main.configureWord2Vec + Word2Vec.fit + the vector part of saveModelAndFeatures (M/Main.scala:36-44,77-97,113-124):
+ * skip-gram with hierarchical softmax over the paths, trained on the GPU (csrc/embedding.hip).  org.apache.spark.mllib.feature.
+ * Word2Vec is a dependency that is absent from the reference tree and seeds itself from the clock: PARITY UNPINNED — the build
+ * restates the published algorithm with a seed of its own and is checked against its CPU restatement (oracle: orc_w2v_fit). */
+typedef struct {
+  int32_t dim;            /* --dim     (setVectorSize)    */
+  int32_t window;         /* --window  (setWindowSize)    */
+  int32_t iterations;     /* --iter    (setNumIterations) */
+  float learning_rate;    /* --lr      (setLearningRate)  */
+  uint32_t seed;          /* the build's seed (MLlib: Utils.random.nextLong(), unseeded) */
+  int32_t threads;        /* 1: one wave, sentences in order (the sequential form); anything else: one wave per sentence, Hogwild */
+} srw_w2v_params;
+/* paths [n][stride] / lens on the HOST (what srw_fetch_paths returns, or a parsed paths file).  Outputs are malloc'ed (srw_free):
+ * vocab_ids[n_vocab] = the ids by descending count (ties: ascending id; minCount 0), vectors[n_vocab * dim]. */
+int32_t srw_w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, const srw_w2v_params *params,
+                    int32_t **vocab_ids, float **vectors, int64_t *n_vocab);
+/* "<id>\t<v0>\t...\t<v_dim-1>" lines (Main.scala:88-91; floats printed as java.lang.Float.toString prints them) into
+ * <output_dir>/vec/part-%05d + _SUCCESS, and a model directory <output_dir>/bin (metadata JSON + the same vectors as text: the
+ * reference writes Spark's parquet there, which this build does not).  Fails if <output_dir>/vec exists. */
+int32_t srw_w2v_save(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int32_t n_parts);
+
 /* ---- measurement hooks (bench.py's `roofline` object; not on the walk's path) ------------------------ */
 /* The ceiling the walk kernels are held against, measured on this handle's GPU in about a second: dependent, uniformly random
  * 16-byte reads (one chain per lane, 81 hops, the access pattern of a first-order step: one record per step) over a table of

@@ -83,6 +83,9 @@ def lib():
     L.orc_write_paths.argtypes = [i32p, i32p, C.c_int64, C.c_int64, C.c_char_p, C.c_int]
     L.orc_alias_row.argtypes = [f32p, C.c_int64, f32p, i32p]
     L.orc_graph_alias_row.argtypes = [C.c_void_p, C.c_int32, f32p, i32p]
+    L.orc_w2v_fit.argtypes = [i32p, i32p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint32,
+                              C.POINTER(i32p), C.POINTER(f32p), C.POINTER(C.c_int64)]
+    L.orc_free.argtypes = [C.c_void_p]
     L.orc_rmat_edges.argtypes = [C.c_int, C.c_uint32, C.c_int64, C.c_int64, i32p, i32p]
     L.orc_rmat_weight.restype = C.c_float
     L.orc_rmat_weight.argtypes = [C.c_int32, C.c_int32, C.c_uint32]
@@ -325,3 +328,16 @@ def rmat_edges(scale, n_edges, seed=42, first=0):
 
 def rmat_weight(u, v, seed=42):
     return float(lib().orc_rmat_weight(int(u), int(v), seed))
+
+
+def w2v_fit(paths, lens, dim=128, window=10, iterations=10, lr=0.025, seed=1):
+    """Sequential restatement of the embedding stage (PARITY UNPINNED, see srw_oracle.c): (vocab ids, vectors [vocab, dim])."""
+    paths = np.ascontiguousarray(paths, dtype=np.int32); lens = np.ascontiguousarray(lens, dtype=np.int32)
+    ids, vec, nv = C.POINTER(C.c_int32)(), C.POINTER(C.c_float)(), C.c_int64(0)
+    lib().orc_w2v_fit(_i32(paths), _i32(lens), paths.shape[0], paths.shape[1], dim, window, iterations, C.c_float(lr), seed,
+                      C.byref(ids), C.byref(vec), C.byref(nv))
+    n = nv.value
+    out_ids = np.ctypeslib.as_array(ids, shape=(max(n, 1),))[:n].copy()
+    out_vec = np.ctypeslib.as_array(vec, shape=(max(n * dim, 1),))[:n * dim].copy().reshape(n, dim)
+    lib().orc_free(ids); lib().orc_free(vec)
+    return out_ids, out_vec

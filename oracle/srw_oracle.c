@@ -867,3 +867,131 @@ float orc_rmat_weight(int32_t u, int32_t v, uint32_t seed) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return (float)(1u + (h & 15u));
 }
+
+/* ============================================================================================ */
+/* The embedding stage (`--cmd node2vec` / `--cmd embedding`) — PARITY UNPINNED                  */
+/* ============================================================================================ */
+/* M/Main.scala:36-44,113-124 hand the paths to org.apache.spark.mllib.feature.Word2Vec (Spark 2.2, pom.xml:125-135), which is NOT
+ * in /root/reference and seeds itself from the clock.  What is restated here is its published algorithm — skip-gram with
+ * hierarchical softmax as in word2vec.c, which MLlib ports: vocabulary by descending count, Huffman codes (<= 40 bits), the
+ * 1 000-entry sigmoid table over [-6, 6), a window shrunk by a random b per position, the learning rate decaying linearly to 1e-4 of
+ * its start, syn0 uniform in (-0.5, 0.5) / dim, syn1 zero — with the build's own seeded draws (w2v_hash) and ONE logical partition,
+ * sentence after sentence.  It checks the GPU trainer's sequential mode (threads == 1) within a float tolerance. */
+static uint32_t w2v_hash(uint32_t seed, uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t h = seed ^ 0x9E3779B9u;
+  h ^= a + 0x7F4A7C15u + (h << 6) + (h >> 2); h *= 0x85EBCA6Bu; h ^= h >> 13;
+  h ^= b + 0x165667B1u + (h << 6) + (h >> 2); h *= 0xC2B2AE35u; h ^= h >> 16;
+  h ^= c + 0x27D4EB2Fu + (h << 6) + (h >> 2); h *= 0x9E3779B1u; h ^= h >> 15;
+  return h;
+}
+typedef struct { int32_t id; int64_t cn; } w2v_word;
+static int w2v_cmp_id(const void *a, const void *b) { int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return (x > y) - (x < y); }
+static int w2v_cmp_word(const void *a, const void *b) {       /* count descending, id ascending */
+  const w2v_word *x = (const w2v_word *)a, *y = (const w2v_word *)b;
+  if (x->cn != y->cn) return x->cn > y->cn ? -1 : 1;
+  return (x->id > y->id) - (x->id < y->id);
+}
+/* paths [n][stride] / lens -> *n_vocab, vocab_ids (caller frees), vectors [n_vocab][dim] (caller frees). 0 on success. */
+int orc_w2v_fit(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, int32_t dim, int32_t window, int32_t iterations,
+                float lr, uint32_t seed, int32_t **vocab_ids_out, float **vectors_out, int64_t *n_vocab_out) {
+  int64_t total = 0;
+  for (int64_t w = 0; w < n; ++w) total += lens[w];
+  int32_t *all = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total ? total : 1));
+  { int64_t k = 0; for (int64_t w = 0; w < n; ++w) for (int32_t j = 0; j < lens[w]; ++j) all[k++] = paths[w * stride + j]; }
+  int32_t *sorted = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total ? total : 1));
+  memcpy(sorted, all, sizeof(int32_t) * (size_t)total);
+  qsort(sorted, (size_t)total, sizeof(int32_t), w2v_cmp_id);
+  int64_t V = 0;
+  w2v_word *voc = (w2v_word *)malloc(sizeof(w2v_word) * (size_t)(total ? total : 1));
+  for (int64_t i = 0; i < total; ++i) {
+    if (V && voc[V - 1].id == sorted[i]) voc[V - 1].cn++; else { voc[V].id = sorted[i]; voc[V].cn = 1; ++V; }
+  }
+  free(sorted);
+  qsort(voc, (size_t)V, sizeof(w2v_word), w2v_cmp_word);
+  /* id -> vocabulary index (binary search over a copy sorted by id) */
+  w2v_word *byid = (w2v_word *)malloc(sizeof(w2v_word) * (size_t)(V ? V : 1));
+  for (int64_t r = 0; r < V; ++r) { byid[r].id = voc[r].id; byid[r].cn = r; }
+  qsort(byid, (size_t)V, sizeof(w2v_word), w2v_cmp_id);    /* (id is the first field) */
+  int32_t *sent = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total ? total : 1));
+  for (int64_t i = 0; i < total; ++i) {
+    int64_t lo = 0, hi = V - 1;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (byid[mid].id < all[i]) lo = mid + 1; else hi = mid; }
+    sent[i] = (int32_t)byid[lo].cn;
+  }
+  free(byid); free(all);
+  float *syn0 = (float *)malloc(sizeof(float) * (size_t)(V ? V : 1) * (size_t)dim);
+  float *syn1 = (float *)calloc((size_t)(V ? V : 1) * (size_t)dim, sizeof(float));
+  for (int64_t r = 0; r < V; ++r)
+    for (int32_t j = 0; j < dim; ++j)
+      syn0[r * dim + j] = ((float)(w2v_hash(seed, 0xA11CEu, (uint32_t)r, (uint32_t)j) >> 8) * (1.0f / 16777216.0f) - 0.5f) / (float)dim;
+  int32_t *ids = (int32_t *)malloc(sizeof(int32_t) * (size_t)(V ? V : 1));
+  for (int64_t r = 0; r < V; ++r) ids[r] = voc[r].id;
+  if (V >= 2 && total > 0 && iterations > 0) {
+    /* CreateBinaryTree */
+    int64_t *count = (int64_t *)malloc(sizeof(int64_t) * (size_t)(2 * V + 1));
+    int32_t *parent = (int32_t *)calloc((size_t)(2 * V + 1), sizeof(int32_t));
+    uint8_t *binary = (uint8_t *)calloc((size_t)(2 * V + 1), 1);
+    for (int64_t a = 0; a < V; ++a) count[a] = voc[a].cn;
+    for (int64_t a = V; a < 2 * V + 1; ++a) count[a] = (int64_t)1e15;
+    int64_t pos1 = V - 1, pos2 = V;
+    for (int64_t a = 0; a < V - 1; ++a) {
+      int64_t min1, min2;
+      if (pos1 >= 0) { if (count[pos1] < count[pos2]) { min1 = pos1; pos1--; } else { min1 = pos2; pos2++; } } else { min1 = pos2; pos2++; }
+      if (pos1 >= 0) { if (count[pos1] < count[pos2]) { min2 = pos1; pos1--; } else { min2 = pos2; pos2++; } } else { min2 = pos2; pos2++; }
+      count[V + a] = count[min1] + count[min2];
+      parent[min1] = (int32_t)(V + a); parent[min2] = (int32_t)(V + a);
+      binary[min2] = 1;
+    }
+    int32_t *codelen = (int32_t *)malloc(sizeof(int32_t) * (size_t)V);
+    uint8_t *code = (uint8_t *)malloc((size_t)V * 40);
+    int32_t *point = (int32_t *)malloc(sizeof(int32_t) * (size_t)V * 41);
+    for (int64_t a = 0; a < V; ++a) {
+      uint8_t c[41]; int32_t p[41]; int i = 0; int64_t b = a;
+      for (;;) { c[i] = binary[b]; p[i] = (int32_t)b; i++; b = parent[b]; if (b == 2 * V - 2 || i >= 40) break; }
+      codelen[a] = i;
+      point[a * 41] = (int32_t)(V - 2);
+      for (int k = 0; k < i; ++k) { code[a * 40 + i - k - 1] = c[k]; point[a * 41 + i - k] = p[k] - (int32_t)V; }
+    }
+    float exp_table[1000];
+    for (int i = 0; i < 1000; ++i) { float e = (float)exp(((double)i / 1000 * 2.0 - 1.0) * 6.0); exp_table[i] = e / (e + 1.0f); }
+    float *neu = (float *)malloc(sizeof(float) * (size_t)dim);
+    for (int32_t k = 0; k < iterations; ++k) {
+      int64_t off = 0;
+      for (int64_t s = 0; s < n; ++s) {
+        const int32_t len = lens[s];
+        double a_ = (double)lr * (1.0 - ((double)k * (double)total + (double)off) / ((double)iterations * (double)total + 1.0));
+        if (a_ < (double)lr * 0.0001) a_ = (double)lr * 0.0001;
+        const float alpha = (float)a_;
+        for (int32_t pos = 0; pos < len; ++pos) {
+          const int32_t word = sent[off + pos];
+          const int32_t b = (int32_t)(w2v_hash(seed, (uint32_t)k, (uint32_t)s, (uint32_t)pos) % (uint32_t)window);
+          for (int32_t a = b; a < window * 2 + 1 - b; ++a) {
+            if (a == window) continue;
+            const int32_t c = pos - window + a;
+            if (c < 0 || c >= len) continue;
+            float *r0 = syn0 + (int64_t)sent[off + c] * dim;
+            for (int32_t j = 0; j < dim; ++j) neu[j] = 0.0f;
+            for (int32_t d = 0; d < codelen[word]; ++d) {
+              float *r1 = syn1 + (int64_t)point[word * 41 + d] * dim;
+              float f = 0.0f;
+              for (int32_t j = 0; j < dim; ++j) f += r0[j] * r1[j];
+              if (f > -6.0f && f < 6.0f) {
+                const int ind = (int)((f + 6.0f) * (1000.0f / 6.0f / 2.0f));
+                const float g = (1.0f - (float)code[word * 40 + d] - exp_table[ind]) * alpha;
+                for (int32_t j = 0; j < dim; ++j) neu[j] += g * r1[j];
+                for (int32_t j = 0; j < dim; ++j) r1[j] += g * r0[j];
+              }
+            }
+            for (int32_t j = 0; j < dim; ++j) r0[j] += neu[j];
+          }
+        }
+        off += len;
+      }
+    }
+    free(neu); free(codelen); free(code); free(point); free(count); free(parent); free(binary);
+  }
+  free(sent); free(syn1); free(voc);
+  *vocab_ids_out = ids; *vectors_out = syn0; *n_vocab_out = V;
+  return 0;
+}
+void orc_free(void *p) { free(p); }

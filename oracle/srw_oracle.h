@@ -117,6 +117,12 @@ int orc_graph_alias_row(const orc_graph *, int32_t v, float *prob, int32_t *alia
 int orc_write_paths(const int32_t *paths, const int32_t *lens, int64_t n_walkers, int64_t stride,
                     const char *output_dir, int n_parts);
 
+/* ---- the embedding stage (`--cmd node2vec`; MLlib Word2Vec is absent from the reference tree: PARITY UNPINNED) ------------------
+ * Sequential skip-gram + hierarchical softmax with the build's seeded draws; see srw_oracle.c.  Outputs malloc'ed: orc_free. */
+int orc_w2v_fit(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, int32_t dim, int32_t window, int32_t iterations,
+                float lr, uint32_t seed, int32_t **vocab_ids_out, float **vectors_out, int64_t *n_vocab_out);
+void orc_free(void *p);
+
 /* ---- synthetic input (build-defined, shared with the HIP generator) ---------- */
 void orc_rmat_edges(int scale, uint32_t seed, int64_t first, int64_t count, int32_t *src, int32_t *dst);
 float orc_rmat_weight(int32_t u, int32_t v, uint32_t seed);

@@ -33,6 +33,19 @@ WALK_NO_EDGE_TABLES = 262144
 WALK_EDGE_TABLES_ALL = 524288
 
 
+class W2vParams(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("window", C.c_int32), ("iterations", C.c_int32), ("learning_rate", C.c_float),
+                ("seed", C.c_uint32), ("threads", C.c_int32)]
+
+
+def w2v_save(vocab_ids, vectors, output_dir, n_parts=1):
+    """<output_dir>/vec/part-* ("id\\tv0\\t..." lines, Main.scala:88-91) + <output_dir>/bin."""
+    ids = np.ascontiguousarray(vocab_ids, dtype=np.int32); vec = np.ascontiguousarray(vectors, dtype=np.float32)
+    rc = lib().srw_w2v_save(_i32(ids), _f32(vec), len(ids), vec.shape[1] if vec.ndim == 2 else 1, os.fsencode(output_dir), n_parts)
+    if rc != 0:
+        raise SrwError(rc, "srw_w2v_save: %s" % lib().srw_last_error(None).decode())
+
+
 class SrwError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("srw error %d: %s" % (code, msg))
@@ -79,7 +92,7 @@ EXPORTS = [
     "srw_shard_rows_commit", "srw_shard_rows_release", "srw_device_alloc", "srw_device_free", "srw_cluster_create", "srw_cluster_destroy", "srw_cluster_last_error",
     "srw_cluster_shard", "srw_cluster_load_edgelist", "srw_cluster_load_coo", "srw_cluster_generate_rmat",
     "srw_cluster_graph_stats", "srw_cluster_walk", "srw_cluster_fetch_paths", "srw_cluster_walk_and_save",
-    "srw_shard_select", "srw_probe_request_rate", "srw_result_scan_sums", "srw_sample", "srw_second_order_weights",
+    "srw_shard_select", "srw_w2v_fit", "srw_w2v_save", "srw_probe_request_rate", "srw_result_scan_sums", "srw_sample", "srw_second_order_weights",
     "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_version",
 ]
 
@@ -151,6 +164,8 @@ def lib():
     L.srw_cluster_fetch_paths.argtypes = [vp, i32p, i32p]
     L.srw_cluster_walk_and_save.argtypes = [vp, C.POINTER(WalkParams), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(WalkStats)]
     L.srw_shard_select.argtypes = [vp, C.c_int32]
+    L.srw_w2v_fit.argtypes = [vp, i32p, i32p, C.c_int64, C.c_int64, C.POINTER(W2vParams), C.POINTER(i32p), C.POINTER(f32p), C.POINTER(C.c_int64)]
+    L.srw_w2v_save.argtypes = [i32p, f32p, C.c_int64, C.c_int32, C.c_char_p, C.c_int32]
     L.srw_probe_request_rate.argtypes = [vp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.srw_result_scan_sums.argtypes = [vp, i64p]
     L.srw_sample.argtypes = [vp, f32p, C.c_int64, C.c_float, i64p]
@@ -409,6 +424,20 @@ class Engine:
 
     def write_paths(self, output_dir, n_parts=1, write_crc=False):
         self._ck(lib().srw_write_paths(self.h, os.fsencode(output_dir), n_parts, int(write_crc)))
+
+    # ---- the embedding stage (--cmd node2vec / embedding; include/stellar_rw.h: parity unpinned) ----
+    def w2v_fit(self, paths, lens, dim=128, window=10, iterations=10, lr=0.025, seed=1, threads=0):
+        """Skip-gram + hierarchical softmax over host paths [n, stride] on the GPU: (vocab ids by descending count, vectors [vocab, dim])."""
+        paths = np.ascontiguousarray(paths, dtype=np.int32); lens = np.ascontiguousarray(lens, dtype=np.int32)
+        P = W2vParams(dim, window, iterations, lr, seed, threads)
+        ids, vec, nv = C.POINTER(C.c_int32)(), C.POINTER(C.c_float)(), C.c_int64(0)
+        n, stride = (paths.shape[0], paths.shape[1]) if paths.ndim == 2 else (0, 1)
+        self._ck(lib().srw_w2v_fit(self.h, _i32(paths), _i32(lens), n, stride, C.byref(P), C.byref(ids), C.byref(vec), C.byref(nv)))
+        k = nv.value
+        out_ids = np.ctypeslib.as_array(ids, shape=(max(k, 1),))[:k].copy()
+        out_vec = np.ctypeslib.as_array(vec, shape=(max(k * dim, 1),))[:k * dim].copy().reshape(k, dim)
+        lib().srw_free(ids); lib().srw_free(vec)
+        return out_ids, out_vec
 
     # ---- measurement hooks (bench.py's roofline object) ----
     def probe_request_rate(self, table_bytes=0):

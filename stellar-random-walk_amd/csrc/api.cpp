@@ -513,6 +513,28 @@ int32_t srw_shard_rows_release(srw_handle *h) {
   return guarded(h, [&] { shard_rows_release(h); });
 }
 
+int32_t srw_w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, const srw_w2v_params *params,
+                    int32_t **vocab_ids, float **vectors, int64_t *n_vocab) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(params && vocab_ids && vectors && n_vocab && (n == 0 || (paths && lens)) && stride >= 1 && n >= 0, "null or bad argument");
+    std::vector<int32_t> ids; std::vector<float> vec;
+    w2v_fit(h, paths, lens, n, stride, *params, ids, vec);
+    *n_vocab = (int64_t)ids.size();
+    *vocab_ids = (int32_t *)malloc(std::max<size_t>(ids.size() * 4, 1));
+    *vectors = (float *)malloc(std::max<size_t>(vec.size() * 4, 1));
+    if (!*vocab_ids || !*vectors) throw Error(SRW_ERR_NOMEM, "host allocation failed");
+    memcpy(*vocab_ids, ids.data(), ids.size() * 4); memcpy(*vectors, vec.data(), vec.size() * 4);
+  });
+}
+
+int32_t srw_w2v_save(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int32_t n_parts) {
+  if (!output_dir || n_vocab < 0 || dim < 1 || (n_vocab > 0 && (!vocab_ids || !vectors))) return SRW_ERR_INVALID;
+  try { write_vectors(vocab_ids, vectors, n_vocab, dim, output_dir, n_parts); return SRW_OK; }
+  catch (const Error &e) { set_create_error(e.what()); return e.code; }
+  catch (const std::exception &e) { set_create_error(e.what()); return SRW_ERR_INVALID; }
+}
+
 int32_t srw_probe_request_rate(srw_handle *h, int64_t table_bytes, double *reads_per_s, double *table_gib) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] { need(reads_per_s, "null argument"); probe_request_rate(h, table_bytes, reads_per_s, table_gib); });

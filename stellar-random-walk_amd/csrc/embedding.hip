@@ -1,0 +1,226 @@
+// embedding.hip — the stage behind `--cmd node2vec` / `--cmd embedding`: skip-gram with hierarchical softmax
+// over the walk paths, on the GPU (gfx950).
+//
+// Reference: M/Main.scala:36-44 (configureWord2Vec: learning rate, iterations, partitions, minCount 0, vector size, window),
+// :77-97 / :113-124 (fit on the paths as lists of id strings, then saveModelAndFeatures).  The model itself is
+// org.apache.spark.mllib.feature.Word2Vec (Spark 2.2, pom.xml:125-135) — a DEPENDENCY THAT IS NOT IN /root/reference: what follows
+// restates its published algorithm (skip-gram + hierarchical softmax, the word2vec.c scheme MLlib ports: vocabulary sorted by count,
+// Huffman codes of at most 40 bits, a 1 000-entry sigmoid table over [-6, 6), a window shrunk by a random b per position, the linear
+// decay of the learning rate down to 1e-4 of its start, syn0 uniform in (-0.5, 0.5) / dim, syn1 zero).  PARITY UNPINNED: MLlib seeds
+// itself from the clock, trains its partitions Hogwild-free but in an order Spark decides and sums their rows, so no output of the
+// reference can be reproduced bit for bit even by the reference; the build defines a seed (hash-based draws, below), trains one
+// logical partition, and is checked against its own CPU restatement (oracle/srw_oracle.c:orc_w2v_fit) — within a float tolerance in
+// the sequential mode (threads == 1), statistically in the Hogwild mode.
+//
+// Device side: sentences (the paths as vocabulary indices) in HBM, syn0 / syn1 as [vocab][dim] floats, one WAVE per sentence, the
+// positions of a sentence in order (as MLlib walks them), lanes across the vector: a (position, context word) pair reads syn0[context]
+// once, then per Huffman node of the centre word one dot product (wave reduction), one table look-up, two axpys — syn1[node] is
+// updated in place (Hogwild across waves, as word2vec.c across threads), syn0[context] after the pair's nodes.  The vectors of a
+// graph's embedding are small next to the walk's tables (vocab x dim x 8 bytes) and cache-resident for the upper Huffman nodes.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "engine.h"
+#include "wave_primitives.h"
+
+namespace srw {
+namespace {
+constexpr int TPB = 256;
+constexpr int EXP_TABLE_SIZE = 1000;
+constexpr float MAX_EXP = 6.0f;
+constexpr int MAX_CODE_LENGTH = 40;
+
+// the build's seeded draws (shared with oracle/srw_oracle.c:w2v_hash): a 32-bit mix of (seed, a, b, c)
+__host__ __device__ inline uint32_t w2v_hash(uint32_t seed, uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t h = seed ^ 0x9E3779B9u;
+  h ^= a + 0x7F4A7C15u + (h << 6) + (h >> 2); h *= 0x85EBCA6Bu; h ^= h >> 13;
+  h ^= b + 0x165667B1u + (h << 6) + (h >> 2); h *= 0xC2B2AE35u; h ^= h >> 16;
+  h ^= c + 0x27D4EB2Fu + (h << 6) + (h >> 2); h *= 0x9E3779B1u; h ^= h >> 15;
+  return h;
+}
+
+struct W2vDev {
+  const int64_t *sent_off; const int32_t *sent; int64_t n_sent;
+  const int64_t *words_before;          // words of the sentences before this one (the learning-rate schedule)
+  const int32_t *code_off; const int32_t *points; const uint8_t *codes;
+  float *syn0, *syn1; int32_t dim, window; uint32_t seed; int32_t iter, n_iter; int64_t total_words; float lr;
+};
+
+__device__ inline float wave_sum_f32(float v) {
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int ND>
+__global__ __launch_bounds__(TPB) void k_w2v_train(W2vDev d, int64_t n_waves) {
+  __shared__ float exp_table[EXP_TABLE_SIZE];
+  for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) {
+    const float e = (float)exp(((double)i / EXP_TABLE_SIZE * 2.0 - 1.0) * (double)MAX_EXP);
+    exp_table[i] = e / (e + 1.0f);
+  }
+  __syncthreads();
+  const int lane = lane_id();
+  const int64_t wave = blockIdx.x * (int64_t)(TPB / 64) + (threadIdx.x >> 6);
+  const int D = d.dim;
+  for (int64_t s = wave; s < d.n_sent; s += n_waves) {
+    const int64_t o0 = d.sent_off[s], o1 = d.sent_off[s + 1];
+    const int32_t len = (int32_t)(o1 - o0);
+    // learning rate of this sentence: linear decay over all iterations' words, floor at 1e-4 of the start
+    float alpha;
+    {
+      const double done = (double)d.iter * (double)d.total_words + (double)d.words_before[s];
+      double a = (double)d.lr * (1.0 - done / ((double)d.n_iter * (double)d.total_words + 1.0));
+      if (a < (double)d.lr * 0.0001) a = (double)d.lr * 0.0001;
+      alpha = (float)a;
+    }
+    for (int32_t pos = 0; pos < len; ++pos) {
+      const int32_t word = d.sent[o0 + pos];
+      const int32_t b = (int32_t)(w2v_hash(d.seed, (uint32_t)d.iter, (uint32_t)s, (uint32_t)pos) % (uint32_t)d.window);
+      const int32_t c0 = d.code_off[word], c1 = d.code_off[word + 1];
+      for (int32_t a = b; a < d.window * 2 + 1 - b; ++a) {
+        if (a == d.window) continue;
+        const int32_t c = pos - d.window + a;
+        if (c < 0 || c >= len) continue;
+        const int32_t last = d.sent[o0 + c];
+        float *r0 = d.syn0 + (int64_t)last * D;
+        float v0[ND], neu[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; v0[i] = j < D ? r0[j] : 0.0f; neu[i] = 0.0f; }
+        for (int32_t t = c0; t < c1; ++t) {
+          float *r1 = d.syn1 + (int64_t)d.points[t] * D;
+          float v1[ND];
+          float part = 0.0f;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; v1[i] = j < D ? r1[j] : 0.0f; part += v0[i] * v1[i]; }
+          const float f = wave_sum_f32(part);
+          if (f > -MAX_EXP && f < MAX_EXP) {
+            const int ind = (int)((f + MAX_EXP) * ((float)EXP_TABLE_SIZE / MAX_EXP / 2.0f));
+            const float g = (1.0f - (float)d.codes[t] - exp_table[ind]) * alpha;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+              const int j = lane + 64 * i;
+              neu[i] += g * v1[i];
+              if (j < D) r1[j] = v1[i] + g * v0[i];
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; if (j < D) r0[j] = v0[i] + neu[i]; }
+      }
+    }
+  }
+}
+
+// word2vec.c's CreateBinaryTree over counts sorted in DESCENDING order: codes and inner-node paths of every word
+void huffman(const std::vector<int64_t> &cn, std::vector<int32_t> &code_off, std::vector<int32_t> &points, std::vector<uint8_t> &codes) {
+  const int64_t V = (int64_t)cn.size();
+  code_off.assign((size_t)V + 1, 0);
+  points.clear(); codes.clear();
+  if (V == 0) return;
+  if (V == 1) { code_off[1] = 0; return; }
+  std::vector<int64_t> count((size_t)V * 2 + 1, (int64_t)1e15);
+  std::vector<int32_t> parent((size_t)V * 2 + 1, 0);
+  std::vector<uint8_t> binary((size_t)V * 2 + 1, 0);
+  for (int64_t a = 0; a < V; ++a) count[(size_t)a] = cn[(size_t)a];
+  int64_t pos1 = V - 1, pos2 = V, min1, min2;
+  for (int64_t a = 0; a < V - 1; ++a) {
+    if (pos1 >= 0 && count[(size_t)pos1] < count[(size_t)pos2]) { min1 = pos1; --pos1; } else { min1 = pos2; ++pos2; }
+    if (pos1 >= 0 && count[(size_t)pos1] < count[(size_t)pos2]) { min2 = pos1; --pos1; } else { min2 = pos2; ++pos2; }
+    count[(size_t)(V + a)] = count[(size_t)min1] + count[(size_t)min2];
+    parent[(size_t)min1] = (int32_t)(V + a); parent[(size_t)min2] = (int32_t)(V + a);
+    binary[(size_t)min2] = 1;
+  }
+  uint8_t code[MAX_CODE_LENGTH + 1]; int32_t point[MAX_CODE_LENGTH + 1];
+  for (int64_t a = 0; a < V; ++a) {
+    int64_t b = a; int i = 0;
+    while (true) {
+      if (i >= MAX_CODE_LENGTH) throw Error(SRW_ERR_INVALID, "word2vec: a Huffman code exceeds 40 bits");
+      code[i] = binary[(size_t)b]; point[i] = (int32_t)b; ++i;
+      b = parent[(size_t)b];
+      if (b == V * 2 - 2) break;
+    }
+    code_off[(size_t)a + 1] = code_off[(size_t)a] + i;
+    points.push_back((int32_t)(V - 2));                       // the root
+    for (int k = 0; k < i; ++k) {
+      codes.push_back(code[i - k - 1]);
+      if (k + 1 < i) points.push_back(point[i - k - 1] - (int32_t)V);
+    }
+  }
+}
+}  // namespace
+
+// paths [n][stride] (ids, lens) on the HOST -> vocabulary (ids by descending count, ties by ascending id) + vectors [vocab][dim]
+void w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, const srw_w2v_params &P,
+             std::vector<int32_t> &vocab_ids, std::vector<float> &vectors) {
+  if (P.dim < 1 || P.dim > 1024 || P.window < 1 || P.iterations < 0 || !(P.learning_rate > 0.0f))
+    throw Error(SRW_ERR_INVALID, "word2vec: dim in 1..1024, window >= 1, iterations >= 0, learning rate > 0");
+  hipStream_t st = h->stream;
+  // vocabulary: every id that occurs (minCount 0, Main.scala:41), most frequent first
+  std::vector<int32_t> all;
+  int64_t total = 0;
+  for (int64_t w = 0; w < n; ++w) total += lens[w];
+  all.reserve((size_t)total);
+  for (int64_t w = 0; w < n; ++w) for (int32_t k = 0; k < lens[w]; ++k) all.push_back(paths[w * stride + k]);
+  std::vector<int32_t> uniq(all);
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  const int64_t V = (int64_t)uniq.size();
+  std::vector<int64_t> cnt((size_t)V, 0);
+  std::vector<int32_t> idx((size_t)total);
+  for (int64_t i = 0; i < total; ++i) {
+    const int32_t u = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), all[(size_t)i]) - uniq.begin());
+    idx[(size_t)i] = u; cnt[(size_t)u]++;
+  }
+  std::vector<int32_t> order((size_t)V);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt[(size_t)a] > cnt[(size_t)b]; });   // ties: ascending id
+  std::vector<int32_t> rank((size_t)V);
+  std::vector<int64_t> cn((size_t)V);
+  vocab_ids.resize((size_t)V);
+  for (int64_t r = 0; r < V; ++r) { rank[(size_t)order[(size_t)r]] = (int32_t)r; cn[(size_t)r] = cnt[(size_t)order[(size_t)r]]; vocab_ids[(size_t)r] = uniq[(size_t)order[(size_t)r]]; }
+  for (int64_t i = 0; i < total; ++i) idx[(size_t)i] = rank[(size_t)idx[(size_t)i]];
+  vectors.assign((size_t)V * (size_t)P.dim, 0.0f);
+  for (int64_t r = 0; r < V; ++r)
+    for (int32_t j = 0; j < P.dim; ++j)
+      vectors[(size_t)r * P.dim + j] = ((float)(w2v_hash(P.seed, 0xA11CEu, (uint32_t)r, (uint32_t)j) >> 8) * (1.0f / 16777216.0f) - 0.5f) / (float)P.dim;
+  if (V < 2 || total == 0 || P.iterations == 0) return;
+  std::vector<int32_t> code_off, points; std::vector<uint8_t> codes;
+  huffman(cn, code_off, points, codes);
+  std::vector<int64_t> sent_off((size_t)n + 1, 0), before((size_t)n + 1, 0);
+  for (int64_t w = 0; w < n; ++w) { sent_off[(size_t)w + 1] = sent_off[(size_t)w] + lens[w]; before[(size_t)w + 1] = sent_off[(size_t)w + 1]; }
+  DevBuf<int64_t> d_off, d_before; DevBuf<int32_t> d_sent, d_coff, d_points; DevBuf<uint8_t> d_codes; DevBuf<float> d_syn0, d_syn1;
+  d_off.alloc((size_t)n + 1); d_before.alloc((size_t)n + 1); d_sent.alloc((size_t)std::max<int64_t>(total, 1));
+  d_coff.alloc((size_t)V + 1); d_points.alloc(std::max<size_t>(points.size(), 1)); d_codes.alloc(std::max<size_t>(codes.size(), 1));
+  d_syn0.alloc((size_t)V * P.dim); d_syn1.alloc((size_t)V * P.dim);
+  SRW_HIP(hipMemcpyAsync(d_off.p, sent_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemcpyAsync(d_before.p, before.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemcpyAsync(d_sent.p, idx.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemcpyAsync(d_coff.p, code_off.data(), ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemcpyAsync(d_points.p, points.data(), points.size() * 4, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemcpyAsync(d_codes.p, codes.data(), codes.size(), hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemcpyAsync(d_syn0.p, vectors.data(), vectors.size() * 4, hipMemcpyHostToDevice, st));
+  SRW_HIP(hipMemsetAsync(d_syn1.p, 0, (size_t)V * P.dim * 4, st));
+  W2vDev d;
+  d.sent_off = d_off.p; d.sent = d_sent.p; d.n_sent = n; d.words_before = d_before.p; d.code_off = d_coff.p; d.points = d_points.p; d.codes = d_codes.p;
+  d.syn0 = d_syn0.p; d.syn1 = d_syn1.p; d.dim = P.dim; d.window = P.window; d.seed = P.seed; d.n_iter = P.iterations; d.total_words = total; d.lr = P.learning_rate;
+  // threads == 1: ONE wave walks the sentences in order (the sequential form the oracle restates); else one wave per sentence, Hogwild
+  const int64_t n_waves = P.threads == 1 ? 1 : std::min<int64_t>(std::max<int64_t>(n, 1), (int64_t)h->n_cus * 32);
+  const int blocks = (int)((n_waves + TPB / 64 - 1) / (TPB / 64));
+  const int nd = (P.dim + 63) / 64;
+  for (int32_t k = 0; k < P.iterations; ++k) {
+    d.iter = k;
+    const dim3 grid(P.threads == 1 ? 1 : blocks), block(P.threads == 1 ? 64 : TPB);
+    if (nd <= 1) hipLaunchKernelGGL(k_w2v_train<1>, grid, block, 0, st, d, n_waves);
+    else if (nd <= 2) hipLaunchKernelGGL(k_w2v_train<2>, grid, block, 0, st, d, n_waves);
+    else if (nd <= 4) hipLaunchKernelGGL(k_w2v_train<4>, grid, block, 0, st, d, n_waves);
+    else if (nd <= 8) hipLaunchKernelGGL(k_w2v_train<8>, grid, block, 0, st, d, n_waves);
+    else hipLaunchKernelGGL(k_w2v_train<16>, grid, block, 0, st, d, n_waves);
+    SRW_HIP(hipGetLastError());
+  }
+  SRW_HIP(hipMemcpyAsync(vectors.data(), d_syn0.p, vectors.size() * 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+}
+}  // namespace srw

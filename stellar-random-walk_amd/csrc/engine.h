@@ -338,6 +338,12 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
 void run_shard_flush(srw_handle *h, const srw_walk_params &P, int32_t batch, const srw_shard_layout &lay, const void *d_recv,
                      int32_t *d_paths, int32_t *d_lens, int64_t stride);
 void run_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow);
+// embedding.hip: skip-gram + hierarchical softmax over host paths
+void w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, const srw_w2v_params &P,
+             std::vector<int32_t> &vocab_ids, std::vector<float> &vectors);
+// writer.cpp: <output>/vec part files + <output>/bin
+void write_vectors(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int n_parts);
+std::string java_float_to_string(float x);
 // probe.hip: measurement hooks of bench.py's roofline object
 void probe_request_rate(srw_handle *h, int64_t table_bytes, double *reads_per_s, double *table_gib);
 void result_scan_sums(srw_handle *h, int64_t *out3);

@@ -10,7 +10,10 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <algorithm>
 #include <cerrno>
+#include <cmath>
+#include <string>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -267,4 +270,89 @@ void write_path_files(const int32_t *paths, const int32_t *lens, int64_t n_walke
   w.close();
 }
 
+}  // namespace srw
+
+// ---- the embedding stage's output (Main.saveModelAndFeatures, M/Main.scala:77-97) -----------------------------------------------
+namespace srw {
+// java.lang.Float.toString: the shortest decimal that round-trips to the same float (the JDK's algorithm prints one digit more in
+// rare cases: not reproduced), as d.ddd for 1e-3 <= |x| < 1e7 and as d.dddE[-]n otherwise; "NaN", "Infinity", "-Infinity", "0.0", "-0.0".
+std::string java_float_to_string(float x) {
+  if (x != x) return "NaN";
+  if (x == 0.0f) return std::signbit(x) ? "-0.0" : "0.0";
+  if (std::isinf(x)) return x > 0 ? "Infinity" : "-Infinity";
+  char buf[64];
+  int prec = 1;
+  for (; prec <= 9; ++prec) {
+    snprintf(buf, sizeof(buf), "%.*e", prec - 1, (double)x);
+    if (strtof(buf, nullptr) == x) break;
+  }
+  // buf = [-]d[.ddd]e[+-]XX
+  std::string s(buf);
+  const bool neg = s[0] == '-';
+  if (neg) s.erase(0, 1);
+  const size_t epos = s.find('e');
+  std::string digits = s.substr(0, epos);
+  const int exp10 = atoi(s.c_str() + epos + 1);
+  digits.erase(std::remove(digits.begin(), digits.end(), '.'), digits.end());
+  while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+  std::string out;
+  const float ax = std::fabs(x);
+  if (ax >= 1e-3f && ax < 1e7f) {
+    if (exp10 >= 0) {
+      std::string ip = digits.substr(0, std::min<size_t>(digits.size(), (size_t)exp10 + 1));
+      while ((int)ip.size() < exp10 + 1) ip.push_back('0');
+      std::string fp = digits.size() > (size_t)exp10 + 1 ? digits.substr((size_t)exp10 + 1) : "0";
+      out = ip + "." + fp;
+    } else {
+      out = "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
+    }
+  } else {
+    out = digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E" + std::to_string(exp10);
+  }
+  return neg ? "-" + out : out;
+}
+
+void write_vectors(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int n_parts) {
+  if (n_parts < 1) n_parts = 1;
+  const std::string out(output_dir);
+  mkdir(out.c_str(), 0777);
+  const std::string vdir = out + "/vec", mdir = out + "/bin";
+  if (mkdir(vdir.c_str(), 0777) != 0)
+    throw Error(SRW_ERR_IO, errno == EEXIST ? "Output directory " + vdir + " already exists" : "cannot create " + vdir + ": " + strerror(errno));
+  auto put = [](const std::string &fn, const std::string &text) {
+    FILE *f = fopen(fn.c_str(), "wb");
+    if (!f) throw Error(SRW_ERR_IO, "cannot open " + fn + ": " + strerror(errno));
+    const bool ok = fwrite(text.data(), 1, text.size(), f) == text.size();
+    if (fclose(f) != 0 || !ok) throw Error(SRW_ERR_IO, "write error on " + fn);
+  };
+  // repartition(numPartitions): contiguous blocks of the vocabulary (the reference's order of lines is unspecified)
+  const int64_t per = (n_vocab + n_parts - 1) / n_parts;
+  for (int p = 0; p < n_parts; ++p) {
+    std::string text;
+    for (int64_t r = (int64_t)p * per; r < std::min<int64_t>(n_vocab, (int64_t)(p + 1) * per); ++r) {
+      text += std::to_string(vocab_ids[r]);
+      for (int32_t j = 0; j < dim; ++j) { text.push_back('\t'); text += java_float_to_string(vectors[r * dim + j]); }
+      text.push_back('\n');
+    }
+    char name[32]; snprintf(name, sizeof(name), "/part-%05d", p);
+    put(vdir + name, text);
+  }
+  put(vdir + "/_SUCCESS", "");
+  // the model directory: Spark's Word2VecModel.save layout in name (metadata + data), with the vectors as text instead of parquet
+  if (mkdir(mdir.c_str(), 0777) != 0 && errno != EEXIST) throw Error(SRW_ERR_IO, "cannot create " + mdir + ": " + strerror(errno));
+  mkdir((mdir + "/metadata").c_str(), 0777); mkdir((mdir + "/data").c_str(), 0777);
+  put(mdir + "/metadata/part-00000", "{\"class\":\"org.apache.spark.mllib.feature.Word2VecModel\",\"version\":\"1.0\",\"vectorSize\":" + std::to_string(dim) +
+                                         ",\"numWords\":" + std::to_string(n_vocab) + "}\n");
+  put(mdir + "/metadata/_SUCCESS", "");
+  {
+    std::string text;
+    for (int64_t r = 0; r < n_vocab; ++r) {
+      text += std::to_string(vocab_ids[r]);
+      for (int32_t j = 0; j < dim; ++j) { text.push_back('\t'); text += java_float_to_string(vectors[r * dim + j]); }
+      text.push_back('\n');
+    }
+    put(mdir + "/data/part-00000.tsv", text);
+    put(mdir + "/data/_SUCCESS", "");
+  }
+}
 }  // namespace srw

@@ -146,7 +146,7 @@ class HipShardEngine:
         if err is not None:
             raise err
         if not nobody_failed:
-            raise SrwError("srw_shard_rows_commit failed on another rank: the row links were released on every rank")
+            raise SrwError(3, "srw_shard_rows_commit failed on another rank: the row links were released on every rank")
         return all_linked
 
 

@@ -198,8 +198,8 @@ def test_cli_rejects_bad_values():
     assert _cli(*base, "--bogus", "1").returncode == 1
     r = _cli("--cmd", "pagerank", "--input", KARATE, "--output", "/tmp/unused_srw_out")
     assert r.returncode == 1 and "No value found for 'pagerank'" in r.stderr   # TaskName.withName throws
-    r = _cli("--cmd", "embedding", "--input", KARATE, "--output", "/tmp/unused_srw_out")
-    assert r.returncode == 2 and "Word2Vec" in r.stderr
+    r = _cli("--cmd", "embedding", "--input", "/nonexistent/paths", "--output", "/tmp/unused_srw_out")
+    assert r.returncode == 1 and "Input path does not exist" in r.stderr      # (the stage itself needs the GPU: tests/test_gpu_embedding.py)
     assert _cli("--help").returncode == 0
 
 
@@ -405,3 +405,44 @@ def test_tokenizer_inflates_gz_like_textfile(oracle, tmp_path):
     with pytest.raises(P.SrwError) as ei:
         P.parse_edgelist(str(trunc), weighted=False)
     assert ei.value.code in (P.ERR_IO, P.ERR_PARSE)
+
+
+def test_vector_files_and_java_float_strings(tmp_path):
+    """Main.saveModelAndFeatures (Main.scala:77-97): "<id>\\t<v0>\\t..." lines, floats as java.lang.Float.toString prints them —
+    known answers of the JDK (shortest digits that round-trip; plain decimal for 1e-3 <= |x| < 1e7, d.dddE[-]n otherwise)."""
+    P = pkg()
+    vals = np.array([[1.0, 0.001, 1.0e-4, 1.2345679e8, 3.4028235e38], [2.5e-5, 100.0, 1.0e7, 0.1, 1.0 / 3.0],
+                     [-2.5, 0.0, -0.0, 9999999.0, 123456.79]], dtype=np.float32)
+    out = str(tmp_path / "o")
+    P.w2v_save(np.array([7, -3, 12], dtype=np.int32), vals, out, n_parts=2)
+    lines = open(os.path.join(out, "vec", "part-00000")).read().splitlines() + open(os.path.join(out, "vec", "part-00001")).read().splitlines()
+    assert lines[0] == "7\t1.0\t0.001\t1.0E-4\t1.2345679E8\t3.4028235E38"      # (JDK >= 19 prints the shortest digits; JDK 8 printed 1.23456792E8 here: not reproduced)
+    assert lines[1] == "-3\t2.5E-5\t100.0\t1.0E7\t0.1\t0.33333334"
+    assert lines[2] == "12\t-2.5\t0.0\t-0.0\t9999999.0\t123456.79"
+    assert os.path.exists(os.path.join(out, "vec", "_SUCCESS"))
+    meta = open(os.path.join(out, "bin", "metadata", "part-00000")).read()
+    assert '"vectorSize":5' in meta and '"numWords":3' in meta and "Word2VecModel" in meta
+    with pytest.raises(P.SrwError):
+        P.w2v_save(np.array([1], dtype=np.int32), vals[:1], out)          # <output>/vec exists
+
+
+def test_oracle_embedding_separates_neighbours(oracle):
+    """The CPU restatement of the embedding stage (parity unpinned: MLlib's Word2Vec is not in the reference tree) on karate walks:
+    deterministic under its seed, vocabulary by descending count, neighbours closer than non-neighbours."""
+    g = oracle.Graph.load(KARATE)
+    p, l, _ = g.walk(p=1.0, q=1.0, walk_length=20, num_walks=5, seed=3)
+    ids, vec = oracle.w2v_fit(p, l, dim=16, window=5, iterations=5, lr=0.025, seed=7)
+    ids2, vec2 = oracle.w2v_fit(p, l, dim=16, window=5, iterations=5, lr=0.025, seed=7)
+    assert np.array_equal(ids, ids2) and np.array_equal(vec, vec2) and len(ids) == 34
+    flat = p[p >= 0]
+    cnt = np.array([(flat == v).sum() for v in ids])
+    assert (np.diff(cnt) <= 0).all()
+    vn = vec / np.linalg.norm(vec, axis=1, keepdims=True)
+    idx = {int(v): i for i, v in enumerate(ids)}
+    nb, nn = [], []
+    for a in ids.tolist():
+        na = set(g.neighbors(a)[0].tolist())
+        for b in ids.tolist():
+            if a < b:
+                (nb if b in na else nn).append(float(vn[idx[a]] @ vn[idx[b]]))
+    assert np.mean(nb) > np.mean(nn) + 0.2

@@ -161,7 +161,10 @@ void w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, int64_t n
   // vocabulary: every id that occurs (minCount 0, Main.scala:41), most frequent first
   std::vector<int32_t> all;
   int64_t total = 0;
-  for (int64_t w = 0; w < n; ++w) total += lens[w];
+  for (int64_t w = 0; w < n; ++w) {
+    if (lens[w] < 0 || lens[w] > stride) throw Error(SRW_ERR_INVALID, "word2vec: a path length outside [0, stride]");
+    total += lens[w];
+  }
   all.reserve((size_t)total);
   for (int64_t w = 0; w < n; ++w) for (int32_t k = 0; k < lens[w]; ++k) all.push_back(paths[w * stride + k]);
   std::vector<int32_t> uniq(all);

@@ -308,8 +308,10 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
 #ifndef SRW_LEAN_WAVES
 #define SRW_LEAN_WAVES 7
 #endif
+// Round 4 (tree tables, 16-bit level 0, 4-byte ids; s125, one box): the row-filter instantiation at 8 waves/SIMD (64 VGPRs, 200 B of scratch
+// per lane: 1.5 KB of spill writes per step reach the memory side at config 5's stand-in) 4 734 ms, 7 waves (72 VGPRs, 168 B) 4 637 ms, 6 waves 4 924 ms.
 #ifndef SRW_LEAN_WAVES_BF
-#define SRW_LEAN_WAVES_BF 8
+#define SRW_LEAN_WAVES_BF 7
 #endif
 __device__ inline Row uniform_row(Row r) {            // the row descriptor of a wave's walker is wave-uniform: keep it in SGPRs
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r.off), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)r.off >> 32));

@@ -70,7 +70,14 @@ enum {
    * shard needs to evaluate "x in N(prev)" for a prev it does not own, i.e. only when q != 1
    * (M/algorithm/RandomSample.scala:37); walks with q == 1 (config 4: p = q = 1) never read it.  A walk with q != 1 on
    * such a handle fails with SRW_ERR_INVALID.  With the flag a shard's memory is proportional to 1/world. */
-  SRW_CFG_NO_MEMBERSHIP = 4
+  SRW_CFG_NO_MEMBERSHIP = 4,
+  /* sharded handles (world > 1): owner(v) = nonNegativeMod(v, world) — org.apache.spark.HashPartitioner over as many partitions as
+   * there are GPUs, the partition map of the reference (RandomWalk.scala:16, UniformRandomWalk.scala:42: partitionBy(new
+   * HashPartitioner(rddPartitions)) on Int keys, whose hashCode is the value) — instead of the default mix32(v) mod world.
+   * Results are the same under any owner function (tests); the default mixes the ids first because the low bits of an unpermuted
+   * RMAT id correlate with the degree (one shard of eight gets 17 % of the walkers).  Ignored when the ids are compacted or a VCut
+   * partition table is in force. */
+  SRW_CFG_OWNER_HASH_PARTITIONER = 8
 };
 
 /* Replaces: SparkContext + GraphMap singleton lifetime (M/Main.scala:21-23, M/algorithm/GraphMap.scala:11). */

@@ -20,6 +20,7 @@ RNG_CONST, RNG_PHILOX = 0, 1
 CFG_OWNER_FROM_PARTITIONS = 1
 CFG_COMPACT_IDS = 2
 CFG_NO_MEMBERSHIP = 4
+CFG_OWNER_HASH_PARTITIONER = 8
 WALK_FORCE_GENERAL = 1
 WALK_NT_LOADS = 2
 WALK_CACHED_LOADS = 4
@@ -227,10 +228,11 @@ def save_paths(paths, lens, output_dir, n_parts=1, write_crc=False):
 class Engine:
     """One handle = one GPU.  Mirrors the life of the reference's SparkContext + GraphMap + RandomWalk object."""
 
-    def __init__(self, device=0, rank=0, world=1, owner_from_partitions=False, compact_ids=False, membership=True):
+    def __init__(self, device=0, rank=0, world=1, owner_from_partitions=False, compact_ids=False, membership=True, hash_partitioner=False):
         self.h = C.c_void_p()
         cfg = Config(device, rank, world, (CFG_OWNER_FROM_PARTITIONS if owner_from_partitions else 0) |
-                     (CFG_COMPACT_IDS if compact_ids else 0) | (0 if membership else CFG_NO_MEMBERSHIP))
+                     (CFG_COMPACT_IDS if compact_ids else 0) | (0 if membership else CFG_NO_MEMBERSHIP) |
+                     (CFG_OWNER_HASH_PARTITIONER if hash_partitioner else 0))
         rc = lib().srw_create(C.byref(cfg), C.byref(self.h))
         if rc != OK:
             self.h = None
@@ -491,12 +493,12 @@ class Cluster:
     """srw_cluster_*: the vertex-sharded walk inside one process over several devices (peer stores over xGMI, no
     collective).  `devices` may repeat an ordinal: several shards on one GPU (how single-GPU boxes test the protocol)."""
 
-    def __init__(self, devices, owner_from_partitions=False, membership=True):
+    def __init__(self, devices, owner_from_partitions=False, membership=True, hash_partitioner=False):
         """membership=False (SRW_CFG_NO_MEMBERSHIP): the shards skip the replicated neighbor-id structure; q == 1 walks only."""
         devs = np.ascontiguousarray(devices, dtype=np.int32)
         self.h = C.c_void_p()
         rc = lib().srw_cluster_create(_i32(devs), len(devs), (CFG_OWNER_FROM_PARTITIONS if owner_from_partitions else 0) |
-                                      (0 if membership else CFG_NO_MEMBERSHIP), C.byref(self.h))
+                                      (0 if membership else CFG_NO_MEMBERSHIP) | (CFG_OWNER_HASH_PARTITIONER if hash_partitioner else 0), C.byref(self.h))
         if rc != OK:
             raise SrwError(rc, lib().srw_last_error(None).decode())
         self.world = len(devs)

@@ -459,6 +459,16 @@ static void install_id_map(Graph &g, IdMap *m) {
   g.id_lo = m->id_lo; g.id_hi = m->id_hi;
 }
 
+namespace {
+// org.apache.spark.HashPartitioner on Int keys (Utils.nonNegativeMod(key.hashCode, numPartitions), RandomWalk.scala:16) as a partition table
+__global__ void k_owner_mod(int32_t *__restrict__ tab, int64_t n_slots, int32_t vmin, int32_t world) {
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots; s += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t id = s + (int64_t)vmin;
+    const int64_t r = id % (int64_t)world;
+    tab[s] = (int32_t)(r < 0 ? r + world : r);
+  }
+}
+}  // namespace
 void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const int32_t *d_dst, const float *d_w,
                                    int64_t n_lines, bool directed, int32_t vmin, int32_t vmax,
                                    const int32_t *host_owner_tab, IdMap *idmap) {
@@ -482,6 +492,9 @@ void build_graph_from_device_lines(srw_handle *h, const int32_t *d_src, const in
   if (sharded && host_owner_tab && (h->cfg.flags & SRW_CFG_OWNER_FROM_PARTITIONS)) {
     g.owner_tab.alloc((size_t)n_slots);
     SRW_HIP(hipMemcpyAsync(g.owner_tab.p, host_owner_tab, (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
+  } else if (sharded && (h->cfg.flags & SRW_CFG_OWNER_HASH_PARTITIONER) && !idmap) {
+    g.owner_tab.alloc((size_t)n_slots);         // HashPartitioner's map as a partition table: owner = nonNegativeMod(id, world)
+    hipLaunchKernelGGL(k_owner_mod, dim3(grid_for(n_slots)), dim3(TPB), 0, st, g.owner_tab.p, n_slots, vmin, h->cfg.world);
   }
 
   // SRW_CFG_NO_MEMBERSHIP: a shard that will only run q == 1 walks skips the replicated membership structure
@@ -551,6 +564,9 @@ void build_graph_blocked(srw_handle *h, const LineFetch &fetch, int64_t n_lines,
   if (host_owner_tab && (h->cfg.flags & SRW_CFG_OWNER_FROM_PARTITIONS)) {
     g.owner_tab.alloc((size_t)n_slots);
     SRW_HIP(hipMemcpyAsync(g.owner_tab.p, host_owner_tab, (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
+  } else if ((h->cfg.flags & SRW_CFG_OWNER_HASH_PARTITIONER) && !idmap) {
+    g.owner_tab.alloc((size_t)n_slots);         // HashPartitioner's map as a partition table: owner = nonNegativeMod(id, world)
+    hipLaunchKernelGGL(k_owner_mod, dim3(grid_for(n_slots)), dim3(TPB), 0, st, g.owner_tab.p, n_slots, vmin, h->cfg.world);
   }
   const bool want_membership = !(h->cfg.flags & SRW_CFG_NO_MEMBERSHIP);
   int64_t BL = (int64_t)32 << 20;

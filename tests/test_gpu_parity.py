@@ -416,6 +416,21 @@ def test_cluster_inprocess_shards(oracle, world, p, q, directed):
             assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs
 
 
+@pytest.mark.parametrize("world,p,q", [(3, 1.0, 1.0), (2, 0.25, 4.0), (3, 0.5, 1.0)])
+def test_cluster_hash_partitioner_owner(oracle, world, p, q):
+    """SRW_CFG_OWNER_HASH_PARTITIONER: owner(v) = nonNegativeMod(v, world), the reference's HashPartitioner map (RandomWalk.scala:16,
+    UniformRandomWalk.scala:42), negative ids included — the paths do not depend on the owner function."""
+    s, d, w = rmat_lines(oracle, 10, edge_factor=8, weighted=True)
+    s = s - 300; d = d - 300                                     # negative ids: nonNegativeMod, not %
+    g = oracle.Graph.from_coo(s, d, w, directed=False)
+    rp, rl, rs = g.walk(p=p, q=q, walk_length=12, num_walks=2, first_walk=1, seed=5, threads=8)
+    with pkg().Cluster([0] * world, hash_partitioner=True) as cl:
+        cl.load_coo(s, d, w, directed=False)
+        for batch in (1, 2):
+            paths, lens, st = cl.walk(p=p, q=q, walk_length=12, num_walks=2, first_walk=1, seed=5, batch=batch)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs, (world, batch)
+
+
 def test_cluster_without_replicated_membership(oracle):
     """SRW_CFG_NO_MEMBERSHIP: shards that skip the replicated neighbor-id structure (memory per shard ~ 1 / world) run every
     q == 1 walk — p = q = 1 through the linked records, p != 1 through the general step — and refuse q != 1."""

@@ -146,8 +146,18 @@ struct GraphView {
   // Unit-weight graphs (every w == 1.0f: unweighted inputs, config 5): the ids alone, in input order — the table steps then read 4 bytes per
   // candidate instead of the 8-byte (id, w) entry (graph_build.hip:build_unit_ids; null otherwise)
   const int32_t *ids32;
+  // ... and no prefix-sum array: the exact prefix of the base weights fl(1 / q) of a unit-weight row is (k + 1) * pq_unit (0: read pq)
+  double pq_unit;
   int32_t dbg_chain_deg;   // tests (SRW_DEBUG_CHAIN_DEG): sharded steps on rows at least this long are treated as draws on a CDF boundary (0: off)
 };
+// The exact prefix sums PQ[k] of a row's base weights fl(w / q): the per-call array (8 B per entry) — or, on a unit-weight graph, the
+// closed form (k + 1) * fl(1 / q): k + 1 < 2^24 and a 24-bit constant, the product is exact and equals the sum of k + 1 copies.
+struct PqRow {
+  const double *p; double unit;
+  __device__ PqRow(const GraphView &g, int64_t off) : p(g.pq ? g.pq + off : nullptr), unit(g.pq_unit) {}
+  __device__ inline double operator[](int64_t k) const { return p ? p[k] : (double)(k + 1) * unit; }
+};
+__device__ inline bool pq_ready(const GraphView &g) { return g.pq != nullptr || g.pq_unit != 0.0; }
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;
 constexpr int32_t BF_MIN_DEG = 1025;
 // words of the filter of a row of `deg` neighbors (a power of two, 16-32 bits per neighbor)

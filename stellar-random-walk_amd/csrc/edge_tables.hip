@@ -356,7 +356,7 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
       const double *bins = reinterpret_cast<const double *>(mine);
       double *out = eb_bins + (size_t)tab_word * 8;
       const int up = gc.csh - gf.csh;
-      const double *PQ = g.pq + rv.off;            // the table keeps the complete numerator A'_end(j) = PQ[end_j] + corrections
+      const PqRow PQ(g, rv.off);            // the table keeps the complete numerator A'_end(j) = PQ[end_j] + corrections
       const bool as_f32 = pol.f32 && (rv.flags & ROW_PQ_F32);      // every such sum is exactly representable in binary32
       const bool as_u16 = eb_pair_u16(rv.flags, gc.csh, pol);           // level 0 as the chunks' own masses, u16 multiples of the row's unit 2^G
       const double inv_unit = as_u16 ? 1.0 / eb_row_unit(rv.flags) : 0.0;

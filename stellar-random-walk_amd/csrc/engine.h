@@ -123,6 +123,7 @@ struct Graph {
   bool has_cfo_local = false;     // sharded: compact first-order records over the LOCAL rows (guide + ids; their links are not used)
   DevBuf<int32_t> ids32;          // unit-weight graphs: the neighbor ids alone, input order (GraphView::ids32); unit_w: -1 not checked yet
   bool has_ids32 = false; int unit_w = -1;
+  double pq_unit = 0.0;           // unit-weight graphs: fl(1 / q) of the call — the prefix sums are (k + 1) * pq_unit, no pq array (GraphView::pq_unit)
   DevBuf<uint32_t> bf_off, bf_bits; // neighbor-set filters of the rows beyond 1024 neighbors (GraphView::bf_off), built with the per-edge tables
   bool has_bf = false;
   // Compacted ids (sparse id spaces, SRW_CFG_COMPACT_IDS): slots are ranks among the sorted distinct input ids
@@ -132,13 +133,13 @@ struct Graph {
   int32_t id_lo = 0, id_hi = -1;  // smallest / largest id a path can print (text capacity of the formatter)
   std::vector<int32_t> part_of;   // VCut: last pId recorded per dst slot, -1 none (host side; empty if unused)
   GraphView view() const { return GraphView{rows.p, ent.p, sids.p, sperm.p, has_fo ? fo.p : nullptr, (has_cfo || cfo_linked || has_cfo_local) ? cfo.p : nullptr, has_al ? al.p : nullptr, has_al ? rsum.p : nullptr,
-                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, has_pq ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
+                     mrows.p ? mrows.p : rows.p, msids.p ? msids.p : sids.p, (has_pq && pq_unit == 0.0) ? pq.p : nullptr, has_pq ? pq_ok.p : nullptr, (has_ehash && use_ehash) ? ehash.p : nullptr, ehash_mask,
                      symmetric ? 1 : 0, owner_tab.p, vmin, n_slots, sw.p,
                      (has_hub && use_hub) ? hub_bm.p : nullptr, hub_words,
                      (has_eb && use_eb && !eb_sharded) ? eb_off.p : nullptr, eb_bins.p, eb_min_sh, em_bits.p, eb_mask_max, eb_f32,
                      has_rev ? rev.p : nullptr, eb_cap, compact ? orig_id.p : nullptr,
                      (has_bf && use_eb && !(has_ehash && use_ehash)) ? bf_off.p : nullptr, bf_bits.p,
-                     (has_eb && use_eb && eb_sharded) ? ph.p : nullptr, ph_buckets, has_rh ? rh.p : nullptr, rh_buckets, ebp, has_ids32 ? ids32.p : nullptr, dbg_chain_deg}; }
+                     (has_eb && use_eb && eb_sharded) ? ph.p : nullptr, ph_buckets, has_rh ? rh.p : nullptr, rh_buckets, ebp, has_ids32 ? ids32.p : nullptr, (has_pq && pq_unit != 0.0) ? pq_unit : 0.0, dbg_chain_deg}; }
   // id <-> slot at the boundary (api.cpp): -1 if the id cannot be a vertex of this graph
   int64_t slot_of_id(int32_t v) const {
     if (!compact) { const int64_t s = (int64_t)v - vmin; return (s < 0 || s >= n_slots) ? -1 : s; }
@@ -299,6 +300,7 @@ void build_graph_from_host_rows(srw_handle *h, const int32_t *vids, const int64_
 void generate_rmat_lines(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, bool weighted,
                          DevBuf<int32_t> &d_src, DevBuf<int32_t> &d_dst, DevBuf<float> &d_w);
 void build_membership(srw_handle *h);
+bool graph_has_unit_weights(srw_handle *h);     // graph_build.hip: every w == 1.0f (checked once per graph)
 void build_unit_ids(srw_handle *h);               // graph_build.hip: ids32 of a unit-weight graph (a no-op otherwise or when HBM is short)
 void build_row_filters(srw_handle *h);            // word-blocked Bloom filters of the long rows (GraphView::bf_off)
 void build_first_order_tables(srw_handle *h, bool want_exact);

@@ -396,11 +396,27 @@ __global__ void k_unit_ids(const Ent *__restrict__ ent, int64_t n, int32_t *__re
 }  // namespace
 // Unit-weight graphs: the table steps of the biased walk read ids32[e] (4 B) instead of ent[e] (8 B) — they are bound by memory requests
 // (config 5's stand-in: 0.9 of the request ceiling), and a located chunk's entries are a third of them.
+bool graph_has_unit_weights(srw_handle *h) {
+  Graph &g = h->g;
+  if (g.n_entries <= 0) return false;
+  hipStream_t st = h->stream;
+  if (g.unit_w < 0) {
+    DevBuf<unsigned int> flag; flag.alloc(1);
+    SRW_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+    hipLaunchKernelGGL(k_unit_check, dim3(h->n_cus * 8), dim3(TPB), 0, st, g.ent.p, g.n_entries, flag.p);
+    unsigned int f = 0;
+    SRW_HIP(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    g.unit_w = f ? 0 : 1;
+  }
+  return g.unit_w == 1;
+}
 void build_unit_ids(srw_handle *h) {
   Graph &g = h->g;
   if (g.has_ids32 || g.unit_w == 0 || g.n_entries <= 0 || getenv("SRW_NO_UNIT_IDS")) return;
   hipStream_t st = h->stream;
-  if (g.unit_w < 0) {
+  if (g.unit_w < 0) graph_has_unit_weights(h);
+  if (false) {
     DevBuf<unsigned int> flag; flag.alloc(1);
     SRW_HIP(hipMemsetAsync(flag.p, 0, 4, st));
     hipLaunchKernelGGL(k_unit_check, dim3(h->n_cus * 8), dim3(TPB), 0, st, g.ent.p, g.n_entries, flag.p);

@@ -374,7 +374,7 @@ __global__ void k_pq_small(Row *__restrict__ rows, const Ent *__restrict__ ent, 
     for (int32_t k = 0; k < r.deg; ++k) c.add_entry(ent[r.off + k].w, p, q);
     if (!pq_row_ok(c.emin, c.bad, c.mass)) { atomicAdd(bad_rows, 1ull); continue; }
     double acc = 0.0;
-    for (int32_t k = 0; k < r.deg; ++k) { acc += (double)div_exact(ent[r.off + k].w, q); pq[r.off + k] = acc; }
+    if (pq) for (int32_t k = 0; k < r.deg; ++k) { acc += (double)div_exact(ent[r.off + k].w, q); pq[r.off + k] = acc; }
     ok[v] = 1;
     rows[v].flags = r.flags | ROW_PQ_OK | (pq_row_f32(c.glsb, c.mass) ? ROW_PQ_F32 : 0u) | pq_row_u16_bits(c.glsb, c.maxv);
   }
@@ -405,7 +405,7 @@ __global__ void k_pq_large(Row *__restrict__ rows, const Ent *__restrict__ ent, 
         int32_t k = base + lane;
         double x = k < r.deg ? (double)div_exact(row[k].w, q) : 0.0;
         for (int o = 1; o < 64; o <<= 1) { double t = __shfl_up(x, o); if (lane >= o) x += t; }
-        if (k < r.deg) pq[r.off + k] = carry + x;
+        if (pq && k < r.deg) pq[r.off + k] = carry + x;
         carry += readlane_f64(x, 63);
       }
       if (lane == 0) { ok[v] = 1; rows[v].flags = r.flags | ROW_PQ_OK | (pq_row_f32(glsb, mass) ? ROW_PQ_F32 : 0u) | pq_row_u16_bits(glsb, maxv); }
@@ -423,9 +423,12 @@ void build_pq_tables(srw_handle *h, float p, float q) {
   g.has_pq = false;
   size_t free_b = 0, total_b = 0;
   SRW_HIP(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = (size_t)g.n_entries * sizeof(double) + (size_t)g.n_slots;
-  if (g.pq.n < (size_t)g.n_entries && free_b < need + ((size_t)8 << 30)) return;   // optional structure: skip when tight
-  g.pq.ensure((size_t)g.n_entries);
+  // unit-weight graphs: the prefix sums have a closed form (device_common.h:PqRow) — no array, only the rows' certificates and flags
+  const bool unit = !getenv("SRW_NO_UNIT_PQ") && graph_has_unit_weights(h);
+  g.pq_unit = unit ? (double)(1.0f / q) : 0.0;
+  const size_t need = (unit ? 0 : (size_t)g.n_entries * sizeof(double)) + (size_t)g.n_slots;
+  if (!unit && g.pq.n < (size_t)g.n_entries && free_b < need + ((size_t)8 << 30)) return;   // optional structure: skip when tight
+  if (unit) g.pq.release(); else g.pq.ensure((size_t)g.n_entries);
   g.pq_ok.ensure((size_t)g.n_slots);
   int gs = (int)std::min<int64_t>(std::max<int64_t>((g.n_slots + 255) / 256, 1), 256 * 32);
   DevBuf<unsigned long long> next_slot; next_slot.alloc(2);      // [0] cursor, [1] rows without the certificate

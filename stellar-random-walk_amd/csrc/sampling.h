@@ -686,7 +686,7 @@ constexpr int SP_CAP = 512;   // specials kept in the wave's LDS scratch: pos[51
 
 __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, int64_t curr_slot, const Bias &b,
                                            uint32_t *lds, float r, unsigned &fallback, unsigned &served) {
-  if (!g.pq || !b.second_order) return -1;
+  if (!pq_ready(g) || !b.second_order) return -1;
   const int32_t deg = rc.deg;
   if (deg < 128 || !(rc.flags & ROW_PQ_OK)) return -1;
   const int lc = 32 - __clz(deg | 1);
@@ -733,7 +733,7 @@ __device__ inline int32_t wave_pick_prefix(const GraphView &g, const Row &rc, in
   double csum = 0.0;
   for (uint32_t j = lane; j < n_sp; j += 64) csum += sp_corr[j];
   csum = wave_sum_f64(csum);                       // exact under the certificate
-  const double *PQ = g.pq + rc.off;
+  const PqRow PQ(g, rc.off);
   const double S = PQ[deg - 1] + csum;
   const double p = (double)r;
   auto not_miss = [&](int32_t k, bool &hit) {
@@ -787,9 +787,9 @@ template <bool CHAIN = true>
 __device__ inline int32_t wave_pick_returns(const GraphView &g, const Row &rc, const Bias &b, int64_t so, int32_t nr, float r,
                                             unsigned &fallback, double *S_out = nullptr) {
   const int32_t deg = rc.deg;
-  if (!g.pq || !(rc.flags & ROW_PQ_OK) || deg < 1) return -1;
+  if (!pq_ready(g) || !(rc.flags & ROW_PQ_OK) || deg < 1) return -1;
   const int lane = lane_id();
-  const double *PQ = g.pq + rc.off;
+  const PqRow PQ(g, rc.off);
   auto corr_of = [&](int64_t i) { const float w = g.sw[i]; return (double)div_exact(w, b.p) - (double)w; };
   double cs = 0.0;
   for (int32_t i = lane; i < nr; i += 64) cs += corr_of(so + i);
@@ -1316,7 +1316,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   const uint32_t xprev = (uint32_t)((int64_t)b.prev - b.vmin);
   const float p_ = b.p, q_ = b.q;
   const uint32_t *hubbits = (b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
-  const double *PQ = g.pq + rc.off;
+  const PqRow PQ(g, rc.off);
   auto chunk_end = [&](int32_t j) { const int64_t e = (((int64_t)j + 1) << csh) - 1; return (int32_t)(e < deg ? e : deg - 1); };
   // tables of rows whose every sum is binary32-exact are stored as floats (edge_tables.hip); LDS bins are always f64
   const bool f32t = ABS && g.ebp.f32 && (rc.flags & ROW_PQ_F32);
@@ -1725,7 +1725,7 @@ __device__ inline int32_t wave_pick_binned(const GraphView &g, const Row &rc, in
                                            bool force_small, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used,
                                            int32_t &id_out) {
   strat_used = 0;
-  if (!g.pq || !b.second_order || !b.need_member) return -1;
+  if (!pq_ready(g) || !b.second_order || !b.need_member) return -1;
   const int32_t deg = rc.deg;
   if ((!force_small && deg < 128) || !(rc.flags & ROW_PQ_OK)) return -1;
   const BinGeom geo = bin_geometry(deg, 6, BIN_CAP);

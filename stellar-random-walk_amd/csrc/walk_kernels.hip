@@ -447,7 +447,7 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
 template <bool NT>
 __device__ inline int q1_pick(const GraphView &g, const Row &r, const CfoEnt *crow, uint32_t rv, int32_t rv_pos0, float rv_w0, int32_t prev_id,
                               uint32_t m, float p, CfoEnt &e, int32_t &k, unsigned long long &reads, double *S_out = nullptr) {
-  const double *PQ = g.pq + r.off;
+  const PqRow PQ(g, r.off);
   int32_t rp[REV_MAX_RETURNS]; double rc[REV_MAX_RETURNS];      // return edges: input-order position, correction
   int nr = 0;
   double corr_all = 0.0;
@@ -2285,6 +2285,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
     if (it != size_cache.end()) return it->second;
     g.eb_min_sh_sel = sh; g.eb_cm_sel = cm; g.eb_fine_cap_sel = fine; g.eb_cm_ratio_sel = ratio;
     const size_t n = edge_tables_full_bytes(h, eb_mode, cap);
+    if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] table plan: %d chunks of >= %d, masks <= %d (ratio %d), fine %d: %.1f GB\n", cap, 1 << sh, cm, ratio, fine, (double)n / 1e9);
     size_cache[key] = n;
     return n;
   };
@@ -2346,7 +2347,10 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
       const size_t filters = (size_t)g.n_entries * 4 + (size_t)g.n_slots * 4;
       const TabPlan with = (want_ehash && free_b > eh_bytes) ? plan_tables(free_b - eh_bytes) : TabPlan();
       const TabPlan without = plan_tables(free_b > filters ? free_b - filters : 0);
-      drop_ehash = want_ehash && finer(without, with);
+      // equal plans: with chunk masks the few probes left are one request each in the hash (config 3: 711 ms with it, 771 ms without, r04 s112);
+      // without masks every located chunk probes all of its candidates, and the filters answer most of those from L2 (config 5's stand-in, the
+      // same 128 x 256 plan: 4 560 ms without the hash, 5 555 ms with it, r04 u2)
+      drop_ehash = want_ehash && (finer(without, with) || (!finer(with, without) && without.complete && without.cm == 0 && !eb_mode));
       plan = (want_ehash && !drop_ehash) ? with : without;
       if (getenv("SRW_TIMING"))
         fprintf(stderr, "[timing] table plan: %.1f GB free; with the edge hash (%.1f GB): %s %d chunks of >= %d, masks <= %d (ratio %d), fine %d (%.1f GB); without: %s %d chunks of >= %d, "

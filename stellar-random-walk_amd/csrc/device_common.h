@@ -215,6 +215,20 @@ __device__ inline float draw_uniform(const RngSpec &rng, uint32_t iter, uint32_t
   return (float)walk_bits24(rng.seed, iter, src, step) * (1.0f / 16777216.0f);
 }
 
+// One walker per wave: the draws of 64 consecutive steps at once — lane l computes step base + l (the same keyed Philox value the
+// per-step call gives), the step reads its lane.  10 Philox rounds are ~130 scalar instructions per step when every lane computes
+// the same one; here they are ~130 vector instructions per 64 steps (the table kernels are bound by instruction issue,
+// profiles/r04_valu_issue.md).
+struct WaveDraws {
+  float u = 0.0f;
+  // step = first, first + 1, ... in order (the walk loop): a new batch every 64 steps
+  __device__ inline float at(const RngSpec &rng, uint32_t iter, uint32_t src, int32_t step, int32_t first) {
+    const int32_t i = (step - first) & 63;            // (wave-uniform)
+    if (i == 0) u = draw_uniform(rng, iter, src, (uint32_t)(step + (int32_t)(threadIdx.x & 63u)));
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(u), i));
+  }
+};
+
 // Which shard owns vertex v.  The reference partitions by HashPartitioner = nonNegativeMod(id.hashCode, n) with
 // Int.hashCode = identity (RandomWalk.scala:16) — and inherits the skew of the ids: an RMAT graph without a vertex
 // permutation puts 44 % of its edge endpoints on ids whose three low bits are 000, so `v mod 8` hands one shard 44 % of

@@ -1307,19 +1307,23 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
                                          const unsigned long long *cmask = nullptr /* the pair's chunk masks (edge_tables.hip): bit k = candidate k is in N(prev) */) {
   constexpr int PL = SRW_RESOLVE_PER_LANE;
   const int lane = lane_id();
-  const int32_t deg = rc.deg;
-  const int csh = geo.csh;
-  const int32_t n_bins = geo.n_bins;
-  const Ent *row = g.ent + rc.off;
-  const uint32_t *B = b.prev_sids;
-  const int32_t m = b.prev_deg;
-  const uint32_t xprev = (uint32_t)((int64_t)b.prev - b.vmin);
+  // (one wave, one row, one pair: everything below that does not depend on the lane is scalar work — wave_primitives.h:uni)
+  const int32_t deg = uni(rc.deg);
+  const int csh = uni(geo.csh);
+  const int32_t n_bins = uni(geo.n_bins);
+  const uint32_t rflags = uni(rc.flags);
+  const int64_t roff = uni(rc.off);
+  const Ent *row = g.ent + roff;
+  const uint32_t *B = uni(b.prev_sids);
+  const int32_t m = uni(b.prev_deg);
+  const uint32_t xprev = uni((uint32_t)((int64_t)b.prev - b.vmin));
   const float p_ = b.p, q_ = b.q;
-  const uint32_t *hubbits = (b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
-  const PqRow PQ(g, rc.off);
+  const uint32_t prev_hub = uni(b.prev_hub);
+  const uint32_t *hubbits = (prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(prev_hub - 1) * g.hub_words : nullptr;
+  const PqRow PQ(g, roff);
   auto chunk_end = [&](int32_t j) { const int64_t e = (((int64_t)j + 1) << csh) - 1; return (int32_t)(e < deg ? e : deg - 1); };
   // tables of rows whose every sum is binary32-exact are stored as floats (edge_tables.hip); LDS bins are always f64
-  const bool f32t = ABS && g.ebp.f32 && (rc.flags & ROW_PQ_F32);
+  const bool f32t = ABS && g.ebp.f32 && (rflags & ROW_PQ_F32);
   // A short N(prev) is staged in LDS and searched there by the located chunk's candidates.  On a table step the copy is started
   // NOW, with direct-to-LDS loads (global_load_lds: no registers, no wait here), so that it travels together with the table's
   // first block instead of costing a dependent round trip once the chunk is known.  (Speculative: a chunk that turns out to hold
@@ -1350,8 +1354,8 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   if constexpr (ABS) {
     // the pair's table in HBM: a 64-ary tree over the chunk prefixes (eb_layout), one block of <= 64 values per level;
     // S is the last element of the top level
-    const bool u16t = eb_pair_u16(rc.flags, csh, g.ebp);
-    const double unit = u16t ? eb_row_unit(rc.flags) : 0.0;
+    const bool u16t = eb_pair_u16(rflags, csh, g.ebp);
+    const double unit = u16t ? eb_row_unit(rflags) : 0.0;
     const EbLayout lay = eb_layout(f32t, n_bins, false, 0, u16t);
     const int nlev = lay.n2 ? 3 : lay.n1 ? 2 : 1;
     int32_t blk = 0;
@@ -1744,11 +1748,14 @@ template <bool BF = false, bool CHAIN = true>
 __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc, const Bias &b, const double *table,
                                                float r, unsigned &fallback, unsigned &served, Member &tm, int32_t &id_out,
                                                uint32_t *stage /* 1024 words of the wave's LDS */, double *S_out = nullptr) {
-  const PairGeom pg = eb_pair_geometry(rc.deg, b.prev_deg, g.ebp);
+  const int32_t dv = uni(rc.deg);
+  const uint32_t rflags = uni(rc.flags);
+  table = uni(table);
+  const PairGeom pg = eb_pair_geometry(dv, uni(b.prev_deg), g.ebp);
   BinGeom geo; geo.csh = pg.csh; geo.n_bins = pg.n_bins;
   const unsigned long long *cmask = nullptr;
-  if (pg.cmask) cmask = reinterpret_cast<const unsigned long long *>(table + (size_t)eb_layout(g.ebp.f32 && (rc.flags & ROW_PQ_F32), pg.n_bins, true, rc.deg,
-                                                                                              eb_pair_u16(rc.flags, pg.csh, g.ebp)).cm_off * 8);
+  if (pg.cmask) cmask = reinterpret_cast<const unsigned long long *>(table + (size_t)eb_layout(g.ebp.f32 && (rflags & ROW_PQ_F32), pg.n_bins, true, dv,
+                                                                                              eb_pair_u16(rflags, pg.csh, g.ebp)).cm_off * 8);
   return binned_resolve<true, BF, CHAIN>(g, rc, b, table, geo, r, fallback, served, tm, id_out, stage, S_out, cmask);
 }
 

@@ -350,6 +350,7 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
     uint32_t w_fb = 0, w_dead = 0, w_fast = 0, w_srch = 0, w_tab = 0, w_mask = 0;    // (a handed-over walker is not counted here)
     bool handed_over = false;
     int32_t tie_rec = -1;
+    WaveDraws draws;
     for (int32_t s = 1; s <= L + 1; ++s) {
       const bool second = s > 1;
       const int64_t cslot = (int64_t)curr - g.vmin;
@@ -360,13 +361,13 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       r = uniform_row(r); eo = (uint32_t)__builtin_amdgcn_readfirstlane((int)eo);
       if (!in_range) { r.off = 0; r.deg = 0; r.flags = 0; }
       if (r.deg == 0) { w_dead += s > 1; break; }
-      const float u = draw_uniform(rng, iter, ksrc, (uint32_t)s);
+      const float u = draws.at(rng, iter, ksrc, s, 1);
       unsigned f = 0, sv = 0;
       int32_t k, next = 0;
       // (CHAIN = false: the exact chain is not in this kernel — a draw within rounding distance of a CDF boundary hands the
       //  walker over like a missing table; the chain's registers and scratch cost every step otherwise)
       if (!second) {
-        k = wave_pick_first<false>(g, r, u, f, next);
+        k = uni(wave_pick_first<false>(g, r, u, f, next));       // (uni: the pick is the wave's — a loop exit the compiler can see is uniform keeps the walker's state scalar)
         if (k < 0) { handed_over = true; break; }
       } else {
         Bias b;
@@ -374,12 +375,12 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
         b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT;
         SRW_T0(mem);
         if (r.deg <= g.eb_mask_max && (r.deg <= 32 || eo != EB_NONE)) {
-          k = wave_pick_masked<false>(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
+          k = uni(wave_pick_masked<false>(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next));
           w_mask += 1; w_srch += 8u * (uint32_t)r.deg + 4u * (uint32_t)((r.deg + 31) >> 5);
           SRW_T1(mem, t_a);
         } else if (r.deg > g.eb_mask_max && eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
           double S_tie = 0.0;
-          k = wave_pick_edge_table<BF, false>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie);
+          k = uni(wave_pick_edge_table<BF, false>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie));
           if (k >= 0) { w_tab += 1; w_srch += 8u * EB_BINS; w_fast += sv; }
           else if (k == CHAIN_NEEDED && tie.list) {      // a tie on a table step: its exact chain by the chain kernels (the whole GPU)
             if (lane == 0) {
@@ -397,9 +398,10 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
           if (rprev.deg > 1024) mem.t_p2 += wall_clock64() - mem.t_mark;      // ... of which steps with a long N(prev)
 #endif
         } else k = -1;
+        k = uni(k);                                        // (after the lane-0 region above: its join would make the pick look divergent)
         if (k < 0) { handed_over = true; break; }          // no table for this pair: the general kernel takes the walker
       }
-      k = __builtin_amdgcn_readfirstlane(k); next = __builtin_amdgcn_readfirstlane(next);
+      next = uni(next);
       w_fb += f;
       if (lane == 0) path[s] = next;
       prev = curr; curr = next; ++len; rprev = r; eprev = r.off + k;

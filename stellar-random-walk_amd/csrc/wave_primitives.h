@@ -22,29 +22,41 @@ __device__ inline double readlane_f64(double v, int lane) {
   return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
+// A value the whole wave holds (one walker per wave: rows, degrees, table geometry): back into SGPRs, so that the arithmetic that
+// follows is scalar — the table kernels are bound by VALU issue (profiles/r04_valu_issue.md), a wave-uniform integer op on the
+// vector unit costs a 64-lane instruction slot.
+__device__ inline int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline int64_t uni(int64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <typename T> __device__ inline const T *uni(const T *p) { return reinterpret_cast<const T *>((uintptr_t)uni((int64_t)(uintptr_t)p)); }
+
+// (the results are the wave's: handed back through SGPRs — uni — so that the compiler sees the branches they decide as uniform)
 __device__ inline double wave_sum_f64(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  return __longlong_as_double((long long)uni((int64_t)__double_as_longlong(v)));
 }
 __device__ inline int wave_min_i32(int v) {
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return v;
+  return uni((int32_t)v);
 }
 __device__ inline int wave_max_i32(int v) {
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
+  return uni((int32_t)v);
 }
 __device__ inline uint32_t wave_min_u32(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
-  return v;
+  return uni(v);
 }
 __device__ inline uint32_t wave_max_u32(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
-  return v;
+  return uni(v);
 }
 __device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  return (unsigned long long)uni((int64_t)v);
 }
 
 // Exactness certificate for a sum of f32 values widened to f64.

@@ -15,4 +15,4 @@ eng = pkg.Engine(0)
 eng.generate_rmat(sc, ef << sc, seed=42, weighted="w" in spec, directed="d" in spec)
 for it in range(iters):
     st = eng.walk(fetch=False, walk_length=80, num_walks=1, first_walk=it, seed=42, p=p, q=q, sampler=sampler, **extra)
-    print(f"iter {it}: {st['n_steps']/st['kernel_ms']/1e3:.1f} Msteps/s kernel {st['kernel_ms']:.1f} ms setup {st['setup_ms']:.0f} ms steps {st['n_steps']} trials {st['trials']} reads {st['ent_reads']} handed {st['strategy_steps'].get('handed_over_walkers')}", flush=True)
+    print(f"iter {it}: {st['n_steps']/st['kernel_ms']/1e3:.1f} Msteps/s kernel {st['kernel_ms']:.1f} ms setup {st['setup_ms']:.0f} ms steps {st['n_steps']} trials {st['trials']} reads {st['ent_reads']} handed {st['strategy_steps'].get('handed_over_walkers')} mix {st['strategy_steps']}", flush=True)

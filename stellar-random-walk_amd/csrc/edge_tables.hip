@@ -287,12 +287,13 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
 #ifdef SRW_PHASE_TIMING
       const unsigned long long t_it0 = wall_clock64();
 #endif
-      const uint2 it = items[i];
+      uint2 it = items[i];
+      it.x = uni(it.x); it.y = uni(it.y);                 // (one wave, one pair: the pair's state is scalar — wave_primitives.h:uni)
       // SH: it.y = position in u's SORTED row of the membership structure, eb_off = the work list's own offsets (item_off)
-      const Row ru = eb_urow<SH>(g, it.x);
+      const Row ru = uniform_row(eb_urow<SH>(g, it.x));
       const int64_t e = ru.off + it.y;
-      const Row rv = g.rows[SH ? (int64_t)g.msids[e] : (int64_t)g.ent[e].id - g.vmin];
-      const uint32_t tab_word = eb_off[SH ? i : e];
+      const Row rv = uniform_row(g.rows[SH ? (int64_t)g.msids[e] : (int64_t)g.ent[e].id - g.vmin]);
+      const uint32_t tab_word = uni(eb_off[SH ? i : e]);
       Bias b;
       b.p = p; b.q = q; b.prev = (int32_t)((int64_t)it.x + g.vmin); b.second_order = true; b.need_member = true;
       b.prev_sids = g.msids + ru.off; b.prev_deg = ru.deg; b.vmin = g.vmin; b.prev_hub = ru.flags >> ROW_HUB_SHIFT;

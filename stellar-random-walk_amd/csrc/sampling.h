@@ -17,6 +17,13 @@ struct Bias {
 };
 
 
+__device__ inline Row uniform_row(Row r) {            // the row descriptor of a wave's walker is wave-uniform: keep it in SGPRs
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r.off), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)r.off >> 32));
+  Row o; o.off = (int64_t)(((uint64_t)hi << 32) | lo); o.deg = __builtin_amdgcn_readfirstlane(r.deg);
+  o.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.flags);
+  return o;
+}
+
 // x / d, evaluated as x * 2^-k when d = 2^k: both are the correctly rounded value of the SAME real number (2^-k is exact
 // for |k| <= 126; FP32 denormals are on, .amdhsa_float_denorm_mode_32 3), so the bits are those of the reference's
 // `weight / q` (RandomSample.scala:33,35) — without the ~11-instruction correctly-rounded f32 divide per candidate.  d is
@@ -559,6 +566,10 @@ __device__ inline double wave_incl_scan_f64(double v) {
   return v;
 }
 
+// the wave's total by the same DPP steps (lane 63 of the scan) — for sums that are exact in any order (a row certificate holds) or
+// whose order is not observable; wave_sum_f64's butterflies stay where the order is part of a result
+__device__ inline double wave_total_f64(double v) { return readlane_f64(wave_incl_scan_f64(v), 63); }
+
 // Certified parallel evaluation of RandomSample.sample on the biased row.
 //   S: certified-exact parallel sum (else the sequential chain).
 //   acc: ANY summation order of the same quotients d_k = w'_k / S differs from the reference's left-to-right
@@ -1021,31 +1032,33 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
                                    const BinGeom geo, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used,
                                    uint32_t *mbits = nullptr /* edge_tables.hip: LDS bitmap over curr's positions, bit k = candidate k is in N(prev) */,
                                    double *gbins = nullptr) {
-  const int32_t deg = rc.deg;
+  const int32_t deg = uni(rc.deg);                    // (one wave, one pair: scalar state — wave_primitives.h:uni)
   const int lane = lane_id();
   double *bins = GB ? gbins : reinterpret_cast<double *>(lds);
   uint32_t *win = lds + 2 * BIN_CAP;
   SRW_T0(tm);
-  const int csh = geo.csh;
-  const int32_t n_bins = geo.n_bins;
+  const int csh = uni(geo.csh);
+  const int32_t n_bins = uni(geo.n_bins);
+  const int64_t roff = uni(rc.off);
   for (int t = lane; t < n_bins; t += 64) bins[t] = 0.0;
   if (mbits) for (int t = lane; t < ((deg + 31) >> 5); t += 64) mbits[t] = 0u;
   if (GB) __threadfence();                            // the zeros reach L2 before the first atomic does
   __builtin_amdgcn_wave_barrier();
-  const Ent *row = g.ent + rc.off;
-  const uint32_t *cs = g.sids + rc.off, *cp = g.sperm + rc.off;
-  const float *csw = g.sw + rc.off;
-  const uint32_t *B = b.prev_sids;
-  const int32_t m = b.prev_deg;
-  const uint32_t xprev = (uint32_t)((int64_t)b.prev - b.vmin);
+  const Ent *row = g.ent + roff;
+  const uint32_t *cs = g.sids + roff, *cp = g.sperm + roff;
+  const float *csw = g.sw + roff;
+  const uint32_t *B = uni(b.prev_sids);
+  const int32_t m = uni(b.prev_deg);
+  const uint32_t xprev = uni((uint32_t)((int64_t)b.prev - b.vmin));
   const float p_ = b.p, q_ = b.q;
   // strategy for (b) first, so that every wave-uniform lower bound this step needs is searched in one lockstep pass
   int strat = tune;
-  const uint32_t *hubbits = (b.prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(b.prev_hub - 1) * g.hub_words : nullptr;
+  const uint32_t prev_hub = uni(b.prev_hub);
+  const uint32_t *hubbits = (prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(prev_hub - 1) * g.hub_words : nullptr;
   if (strat == 4 && !hubbits) strat = 0;               // forced P3 without a bitmap: automatic choice
   uint32_t lo_id = 1u, hi_id = 0u;
   if (m > 0 && (strat == 0 || strat == 3)) {
-    lo_id = max(cs[0], B[0]); hi_id = min(cs[deg - 1], B[m - 1]);
+    lo_id = uni(max(cs[0], B[0])); hi_id = uni(min(cs[deg - 1], B[m - 1]));
     if (strat == 0) {
       BinnedCost bc = binned_cost(deg, m, hubbits != nullptr, g.ehash != nullptr);
       if (P1K > 2) bc.c1 = bc.c1 * 4 / P1K;                      // the searches with P1K (not two) in lockstep; measured flat between 2 / P1K and 4 / P1K
@@ -1604,7 +1617,7 @@ __device__ inline int32_t wave_pick_first(const GraphView &g, const Row &rc, flo
   }
   const int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
   const bool bad = __any(cert.bad) || __any(neg);
-  const double S = wave_sum_f64(part);
+  const double S = wave_total_f64(part);                   // (used only under the certificate below: exact in any order)
   if (bad || !sum_is_exact(emin, emax, false, deg) || !(S > 0.0)) {
     if (!CHAIN) return CHAIN_NEEDED;
     unsigned f = 0;
@@ -1680,7 +1693,7 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   }
   const int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
   const bool bad = __any(cert.bad) || __any(neg);
-  const double S_par = wave_sum_f64(part);
+  const double S_par = wave_total_f64(part);               // (used only under the certificate below: exact in any order)
   if (bad || !sum_is_exact(emin, emax, false, deg) || !(S_par > 0.0)) {     // (S = 0: the reference divides by zero -> chain)
     if (!CHAIN) return CHAIN_NEEDED;
     unsigned f = 0;

@@ -313,12 +313,6 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
 #ifndef SRW_LEAN_WAVES_BF
 #define SRW_LEAN_WAVES_BF 7
 #endif
-__device__ inline Row uniform_row(Row r) {            // the row descriptor of a wave's walker is wave-uniform: keep it in SGPRs
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r.off), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)r.off >> 32));
-  Row o; o.off = (int64_t)(((uint64_t)hi << 32) | lo); o.deg = __builtin_amdgcn_readfirstlane(r.deg);
-  o.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.flags);
-  return o;
-}
 template <bool BF>   // BF: the located chunk's probes of a long N(prev) go through the row filters (no edge hash; GraphView::bf_off)
 __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_walk_tables(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
                                                      int64_t n_walkers, int32_t L, int32_t first_walk, RngSpec rng, float p,

@@ -38,13 +38,19 @@ __device__ inline double wave_sum_f64(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return __longlong_as_double((long long)uni((int64_t)__double_as_longlong(v)));
 }
+// min / max over the wave by DPP (row shifts + row broadcasts, like sampling.h:wave_incl_scan_f64: lane 63 ends up with the whole
+// wave's) instead of six ds_bpermute butterflies; order does not matter for min / max, the value is the same
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_src_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }   // lanes without a source keep v
 __device__ inline int wave_min_i32(int v) {
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return uni((int32_t)v);
+  v = min(v, dpp_src_i32<0x111, 0xF>(v)); v = min(v, dpp_src_i32<0x112, 0xF>(v)); v = min(v, dpp_src_i32<0x114, 0xF>(v));
+  v = min(v, dpp_src_i32<0x118, 0xF>(v)); v = min(v, dpp_src_i32<0x142, 0xA>(v)); v = min(v, dpp_src_i32<0x143, 0xC>(v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ inline int wave_max_i32(int v) {
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return uni((int32_t)v);
+  v = max(v, dpp_src_i32<0x111, 0xF>(v)); v = max(v, dpp_src_i32<0x112, 0xF>(v)); v = max(v, dpp_src_i32<0x114, 0xF>(v));
+  v = max(v, dpp_src_i32<0x118, 0xF>(v)); v = max(v, dpp_src_i32<0x142, 0xA>(v)); v = max(v, dpp_src_i32<0x143, 0xC>(v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ inline uint32_t wave_min_u32(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
@@ -69,14 +75,14 @@ struct SumCert {
   int emax;  // max over nonzero addends of max(e, -126)
   bool bad;  // NaN / Inf seen
   __device__ SumCert() : emin(1 << 20), emax(-(1 << 20)), bad(false) {}
-  __device__ inline void add(float x) {
-    uint32_t b = __float_as_uint(x);
-    int ex = (int)((b >> 23) & 0xFFu);
-    if (ex == 255) { bad = true; return; }
-    if ((b & 0x7FFFFFFFu) == 0u) return;
-    int e = ex ? ex - 127 : -126;
-    emin = min(emin, e);
-    emax = max(emax, e);
+  __device__ inline void add(float x) {              // (branch-free: one candidate per lane, a branch here is an exec-mask round trip)
+    const uint32_t b = __float_as_uint(x);
+    const int ex = (int)((b >> 23) & 0xFFu);
+    const bool inf = ex == 255, skip = inf || (b & 0x7FFFFFFFu) == 0u;
+    bad |= inf;
+    const int e = ex ? ex - 127 : -126;
+    emin = skip ? emin : min(emin, e);
+    emax = skip ? emax : max(emax, e);
   }
 };
 

@@ -157,14 +157,29 @@ struct PqRow {
   __device__ PqRow(const GraphView &g, int64_t off) : p(g.pq ? g.pq + off : nullptr), unit(g.pq_unit) {}
   __device__ inline double operator[](int64_t k) const { return p ? p[k] : (double)(k + 1) * unit; }
 };
+// A kernel whose arguments are ONE struct A (the GraphView first in it) can read them again from the kernarg segment where it needs
+// them: ~130 dwords of arguments held in SGPRs for the whole kernel leave the compiler no SGPRs for the walker's state (it goes
+// through spill VGPRs: a v_readlane per use — profiles/r04_valu_issue.md).  fresh_args<A>() hands out a copy whose fields are
+// loaded (s_load, the scalar cache) at the point of the call, and only those the code that follows uses: the asm makes the pointer
+// opaque, so the loads are neither hoisted out of the walk loop nor kept live across it.
+template <typename A>
+__device__ inline A fresh_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uintptr_t ka = (uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  return *(const __attribute__((address_space(4))) A *)ka;
+#else
+  return A();                      // (the host pass of hipcc only parses device functions)
+#endif
+}
+__device__ inline GraphView fresh_graph() { return fresh_args<GraphView>(); }
 __device__ inline bool pq_ready(const GraphView &g) { return g.pq != nullptr || g.pq_unit != 0.0; }
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;
 constexpr int32_t BF_MIN_DEG = 1025;
 // words of the filter of a row of `deg` neighbors (a power of two, 16-32 bits per neighbor)
 __host__ __device__ inline uint32_t bf_words(int32_t deg) {
-  uint32_t half = (uint32_t)(deg - 1) >> 1, w = 1u;
-  while (w <= half) w <<= 1;
-  return w;
+  const uint32_t half = (uint32_t)(deg - 1) >> 1;       // the smallest power of two above half (closed form: the walk asks per table step)
+  return half ? 1u << (32 - __builtin_clz(half)) : 1u;
 }
 // word and 3-bit mask of id slot x in a filter of nw words
 __host__ __device__ inline void bf_hash(uint32_t x, uint32_t nw, uint32_t &word, uint32_t &mask) {

@@ -34,6 +34,22 @@ __device__ inline float div_exact(float x, float d) {
   return x / d;
 }
 
+// The biased weight of a candidate (RandomSample.scala:33-38) without a branch per class: the divisor (p for the return edge, 1 for a
+// common neighbor — x / 1.0f is x —, q otherwise) is selected per lane, then ONE divide; with p and q both powers of two (the test is
+// wave-uniform) one multiply by the selected 2^-k, as div_exact.  Same bits as the three-way if of biased_weight.
+struct BiasDiv {
+  float p, q, ip, iq; bool fast;
+  __device__ BiasDiv(float p_, float q_) : p(p_), q(q_), ip(0.0f), iq(0.0f) {
+    const uint32_t bp = __float_as_uint(p_), bq = __float_as_uint(q_), ep = bp >> 23, eq = bq >> 23;
+    fast = (bp & 0x007FFFFFu) == 0u && ep >= 1u && ep <= 253u && (bq & 0x007FFFFFu) == 0u && eq >= 1u && eq <= 253u;
+    if (fast) { ip = __uint_as_float((254u - ep) << 23); iq = __uint_as_float((254u - eq) << 23); }
+  }
+  __device__ inline float operator()(float w, bool is_prev, bool member) const {
+    if (fast) return w * (is_prev ? ip : member ? 1.0f : iq);
+    return w / (is_prev ? p : member ? 1.0f : q);
+  }
+};
+
 __device__ inline bool sorted_contains(const uint32_t *a, int32_t n, uint32_t x) {
   int32_t lo = 0, hi = n;
   while (lo < hi) {
@@ -1001,8 +1017,15 @@ __host__ __device__ inline EbLayout eb_layout(bool f32, int32_t n_bins, bool cma
 constexpr int32_t EB_FINE_CAP_LIMIT = 32768;     // chunks of a table at most (the build keeps one f64 per chunk and wave in an HBM scratch beyond BIN_CAP)
 constexpr int32_t EB_CM_LIMIT = 16384;         // the build keeps the mask of one pair in 2 KB of the wave's LDS
 __host__ __device__ inline BinGeom bin_geometry(int32_t deg, int min_sh, int cap) {
+  // smallest csh >= min_sh with ceil(deg / 2^csh) <= cap, i.e. cap * 2^csh >= deg, in closed form (the walk computes this per table step
+  // on the scalar unit: profiles/r04_valu_issue.md).  With c0 = bit_length(deg - 1) - bit_length(cap): no c < c0 can do
+  // (cap * 2^c < 2^(bit_length(deg - 1) - 1) <= deg - 1) and c0 + 1 always does (cap * 2^(c0 + 1) >= 2^bit_length(deg - 1) >= deg).
   BinGeom g; g.csh = min_sh;
-  while ((((int64_t)deg + ((int64_t)1 << g.csh) - 1) >> g.csh) > cap) ++g.csh;
+  if (deg > 1 && cap > 0) {
+    const int c0 = (32 - __builtin_clz((unsigned)(deg - 1))) - (32 - __builtin_clz((unsigned)cap));
+    if (c0 > g.csh) g.csh = c0;
+    if (((int64_t)cap << g.csh) < (int64_t)deg) ++g.csh;
+  }
   g.n_bins = (int32_t)(((int64_t)deg + ((int64_t)1 << g.csh) - 1) >> g.csh);
   return g;
 }
@@ -1462,12 +1485,14 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
   }
   // q > 1 and p <= q: every correction (w - w/q for a member, w/p - w/q for a return edge) is >= 0; q < 1 and p >= q:
   // every one is <= 0.  Then "the chunk's corrections sum to exactly 0" means "no special in the chunk".
+  const BiasDiv bdiv(p_, q_);
   const bool one_sign = (q_ > 1.0f && p_ <= q_) || (q_ < 1.0f && p_ >= q_);
   const bool no_specials = one_sign && !cmask && chunk_corr == 0.0;
   // a short N(prev): staged in LDS once (sorted, padded to a power of two), searched there
   int stage_levels = 0;
   if (!no_specials && !cmask && stage && !hubbits && m > 0 && m <= 1024) {
-    int P2 = 1; while (P2 < m) { P2 <<= 1; ++stage_levels; }
+    stage_levels = m > 1 ? 32 - __builtin_clz((unsigned)(m - 1)) : 0;       // ceil(log2 m): the padded length is a power of two
+    const int P2 = 1 << stage_levels;
     if (pre_staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the copy started before the table search has landed
     else for (int32_t t = lane; t < P2; t += 64) stage[t] = t < m ? B[t] : 0xFFFFFFFFu;
     if (stage_levels == 0) stage_levels = -1;               // m == 1: one compare, no search level
@@ -1560,14 +1585,8 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     for (int u = 0; u < PL; ++u) {
       const int32_t k = base + u * 64 + lane;
       if (base + u * 64 > k1) break;                 // wave-uniform
-      double term = 0.0;                                // the candidate's variant: base weight + correction (exact)
-      if (valid[u]) {
-        term = (double)div_exact(e[u].w, q_);
-        if (!no_specials) {
-          if (e[u].id == b.prev) term += (double)div_exact(e[u].w, p_) - (double)div_exact(e[u].w, q_);
-          else if (in[u]) term += (double)e[u].w - (double)div_exact(e[u].w, q_);
-        }
-      }
+      // the candidate's variant w' (= base weight fl(w / q) + the correction the tables hold, exact under the row certificate)
+      const double term = valid[u] ? (double)bdiv(e[u].w, !no_specials && e[u].id == b.prev, in[u]) : 0.0;
       const double incl = wave_incl_scan_f64(term);
       const double num = carry + incl;
       const bool nm = valid[u] && not_miss(k, num);
@@ -1677,16 +1696,14 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   double part = 0.0;
   SumCert cert;
   bool neg = false;
+  const BiasDiv bdiv(b.p, b.q);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int32_t k = i * 64 + lane;
     wv[i] = 0.0f; idv[i] = 0;
     if (i < ni && k < deg) {
       const Ent e = load_ent(g, row, k);
-      float w;
-      if (e.id == b.prev) w = div_exact(e.w, b.p);
-      else if ((mw[i] >> (lane & 31)) & 1u) w = e.w;
-      else w = div_exact(e.w, b.q);
+      const float w = bdiv(e.w, e.id == b.prev, ((mw[i] >> (lane & 31)) & 1u) != 0u);
       wv[i] = w; idv[i] = e.id;
       part += (double)w; cert.add(w); neg |= !(w >= 0.0f);
     }
@@ -1764,7 +1781,12 @@ __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc
   const int32_t dv = uni(rc.deg);
   const uint32_t rflags = uni(rc.flags);
   table = uni(table);
+#ifdef SRW_GEOM_ON_VALU
+  const PairGeom pgv = eb_pair_geometry(on_vector(dv), on_vector(uni(b.prev_deg)), g.ebp);
+  PairGeom pg; pg.csh = uni(pgv.csh); pg.n_bins = uni(pgv.n_bins); pg.cmask = uni((int32_t)pgv.cmask) != 0;
+#else
   const PairGeom pg = eb_pair_geometry(dv, uni(b.prev_deg), g.ebp);
+#endif
   BinGeom geo; geo.csh = pg.csh; geo.n_bins = pg.n_bins;
   const unsigned long long *cmask = nullptr;
   if (pg.cmask) cmask = reinterpret_cast<const unsigned long long *>(table + (size_t)eb_layout(g.ebp.f32 && (rflags & ROW_PQ_F32), pg.n_bins, true, dv,

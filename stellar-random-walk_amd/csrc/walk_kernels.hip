@@ -305,38 +305,57 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
 // 7 -> 433 M; config 5's stand-in (row filters, no hash: latency-bound) 5 -> 290 M, 6 -> 326 M, 7 -> 348 M.  With one candidate per
 // lane and round of the located chunk (SRW_RESOLVE_PER_LANE 1: fewer registers) and chunks of 64 (s59, A / B / C twice on one box):
 // config 3 6 -> 705-719 M, 7 -> 771 M, 8 -> 690 M; config 5's stand-in 7 -> 363 M, 8 -> 387 M.  So by instantiation:
+// Round 4, after the arguments left the SGPRs (TabArgs below: 65 VGPRs, no scratch at 7 waves; 64 VGPRs + 12 B at 8) and with SALU the
+// busier unit (448 scalar against 302 vector instructions per step, profiles/r04_valu_issue.md): 8 waves 624 ms against 644 at config 3,
+// 3 711 against 4 035 ms at config 5's stand-in (gpurun_out/ab2, A / B / C twice on one box).
 #ifndef SRW_LEAN_WAVES
-#define SRW_LEAN_WAVES 7
+#define SRW_LEAN_WAVES 8
 #endif
 // Round 4 (tree tables, 16-bit level 0, 4-byte ids; s125, one box): the row-filter instantiation at 8 waves/SIMD (64 VGPRs, 200 B of scratch
 // per lane: 1.5 KB of spill writes per step reach the memory side at config 5's stand-in) 4 734 ms, 7 waves (72 VGPRs, 168 B) 4 637 ms, 6 waves 4 924 ms.
 #ifndef SRW_LEAN_WAVES_BF
-#define SRW_LEAN_WAVES_BF 7
+#define SRW_LEAN_WAVES_BF 8
+#endif
+// The lean table kernel takes its arguments as ONE struct and reads them again from the kernarg segment where a walker / a step
+// needs them (device_common.h:fresh_args) instead of holding their ~130 dwords in SGPRs next to the walker's state.
+// -DSRW_TAB_FRESH=0: the arguments stay where the compiler puts them (one copy for the whole kernel).
+#ifndef SRW_TAB_FRESH
+#define SRW_TAB_FRESH 1
+#endif
+struct TabArgs {
+  GraphView g;                     // (first: fresh_graph() reads the same bytes)
+  const int32_t *verts; int64_t n_verts, n_walkers; int32_t L, first_walk; RngSpec rng; float p, q;
+  int32_t *paths, *lens; DevCounters *ctr; unsigned long long *cursor; int32_t *todo; unsigned long long *todo_n; TieSink tie;
+};
+#if SRW_TAB_FRESH
+#define TAB_ARGS() fresh_args<TabArgs>()
+#define GFRESH() fresh_graph()
+#else
+#define TAB_ARGS() a0
+#define GFRESH() a0.g
 #endif
 template <bool BF>   // BF: the located chunk's probes of a long N(prev) go through the row filters (no edge hash; GraphView::bf_off)
-__global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_walk_tables(GraphView g, const int32_t *__restrict__ verts, int64_t n_verts,
-                                                     int64_t n_walkers, int32_t L, int32_t first_walk, RngSpec rng, float p,
-                                                     float q, int32_t *__restrict__ paths, int32_t *__restrict__ lens,
-                                                     DevCounters *ctr, unsigned long long *cursor, int32_t *__restrict__ todo,
-                                                     unsigned long long *todo_n, TieSink tie) {
+__global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_walk_tables(TabArgs a0) {
   __shared__ __attribute__((aligned(16))) uint32_t stage_all[TPB / 64][1024];
   const int lane = lane_id();
   uint32_t *stage = stage_all[threadIdx.x >> 6];
   Member mem; mem.mode = 0; mem.bm = stage; mem.seg_base = 0;
+  const int32_t L = a0.L;
   const int64_t stride = (int64_t)L + 2;
   unsigned long long steps = 0, srch = 0;
   uint32_t fb = 0, dead = 0, fast = 0, n_tab = 0, n_mask = 0, n_first = 0;
   while (true) {
     unsigned long long grab = 0;
-    if (lane == 0) grab = atomicAdd(cursor, 1ull);
+    const TabArgs aw = TAB_ARGS();                    // (what a walker's start needs)
+    if (lane == 0) grab = atomicAdd(aw.cursor, 1ull);
     const int64_t wi = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab));
-    if (wi >= n_walkers) break;
-    const int64_t it = wi / n_verts, vi = wi - it * n_verts;
-    const uint32_t iter = (uint32_t)(first_walk + it);
-    const int32_t src = __builtin_amdgcn_readfirstlane(verts[vi]);
-    const uint32_t ksrc = (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, src));
-    int32_t *path = paths + wi * stride;
+    if (wi >= aw.n_walkers) break;
+    const int64_t it = wi / aw.n_verts, vi = wi - it * aw.n_verts;
+    const uint32_t iter = (uint32_t)(aw.first_walk + it);
+    const int32_t src = __builtin_amdgcn_readfirstlane(aw.verts[vi]);
+    const uint32_t ksrc = (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(aw.g, src));
+    int32_t *path = aw.paths + wi * stride;
     if (lane == 0) path[0] = src;
     int32_t prev = src, curr = src, len = 1;
     Row rprev; rprev.off = 0; rprev.deg = 0; rprev.flags = 0;
@@ -347,36 +366,39 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
     WaveDraws draws;
     for (int32_t s = 1; s <= L + 1; ++s) {
       const bool second = s > 1;
-      const int64_t cslot = (int64_t)curr - g.vmin;
-      const bool in_range = cslot >= 0 && cslot < g.n_slots;
-      Row r = g.rows[in_range ? cslot : 0];
+      const TabArgs as = TAB_ARGS();                  // (vmin, n_slots, rows, eb_off, the mask geometry, p, q, the seed: what the top of a step needs)
+      const GraphView &gs = as.g;
+      const int64_t cslot = (int64_t)curr - gs.vmin;
+      const bool in_range = cslot >= 0 && cslot < gs.n_slots;
+      Row r = gs.rows[in_range ? cslot : 0];
       uint32_t eo = EB_NONE;
-      if (second) eo = g.eb_off[eprev];
+      if (second) eo = gs.eb_off[eprev];
       r = uniform_row(r); eo = (uint32_t)__builtin_amdgcn_readfirstlane((int)eo);
       if (!in_range) { r.off = 0; r.deg = 0; r.flags = 0; }
       if (r.deg == 0) { w_dead += s > 1; break; }
-      const float u = draws.at(rng, iter, ksrc, s, 1);
+      const float u = draws.at(as.rng, iter, ksrc, s, 1);
       unsigned f = 0, sv = 0;
       int32_t k, next = 0;
       // (CHAIN = false: the exact chain is not in this kernel — a draw within rounding distance of a CDF boundary hands the
       //  walker over like a missing table; the chain's registers and scratch cost every step otherwise)
       if (!second) {
-        k = uni(wave_pick_first<false>(g, r, u, f, next));       // (uni: the pick is the wave's — a loop exit the compiler can see is uniform keeps the walker's state scalar)
+        k = uni(wave_pick_first<false>(GFRESH(), r, u, f, next));       // (uni: the pick is the wave's — a loop exit the compiler can see is uniform keeps the walker's state scalar)
         if (k < 0) { handed_over = true; break; }
       } else {
         Bias b;
-        b.p = p; b.q = q; b.prev = prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
-        b.prev_sids = g.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT;
+        b.p = as.p; b.q = as.q; b.prev = prev; b.second_order = true; b.need_member = true; b.vmin = gs.vmin;
+        b.prev_sids = gs.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT;
         SRW_T0(mem);
-        if (r.deg <= g.eb_mask_max && (r.deg <= 32 || eo != EB_NONE)) {
-          k = uni(wave_pick_masked<false>(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next));
+        if (r.deg <= gs.eb_mask_max && (r.deg <= 32 || eo != EB_NONE)) {
+          k = uni(wave_pick_masked<false>(GFRESH(), r, b, eo, r.deg > 32 ? gs.em_bits + (size_t)eo * 4 : nullptr, u, f, next));
           w_mask += 1; w_srch += 8u * (uint32_t)r.deg + 4u * (uint32_t)((r.deg + 31) >> 5);
           SRW_T1(mem, t_a);
-        } else if (r.deg > g.eb_mask_max && eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
+        } else if (r.deg > gs.eb_mask_max && eo != EB_NONE && (r.flags & ROW_PQ_OK)) {
           double S_tie = 0.0;
-          k = uni(wave_pick_edge_table<BF, false>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie));
+          k = uni(wave_pick_edge_table<BF, false>(GFRESH(), r, b, gs.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie));
           if (k >= 0) { w_tab += 1; w_srch += 8u * EB_BINS; w_fast += sv; }
-          else if (k == CHAIN_NEEDED && tie.list) {      // a tie on a table step: its exact chain by the chain kernels (the whole GPU)
+          else if (k == CHAIN_NEEDED && as.tie.list) {   // a tie on a table step: its exact chain by the chain kernels (the whole GPU)
+            const TieSink tie = TAB_ARGS().tie;
             if (lane == 0) {
               const unsigned long long c = atomicAdd(tie.cur, 1ull);
               if (c < (unsigned long long)CHAIN_CAP) {
@@ -401,20 +423,22 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       prev = curr; curr = next; ++len; rprev = r; eprev = r.off + k;
     }
     if (handed_over) {
+      const TabArgs ah = TAB_ARGS();
       if (lane == 0) {
-        const unsigned long long t = atomicAdd(todo_n, 1ull);
-        todo[t] = (int32_t)wi;
-        if (tie.todo_tie) tie.todo_tie[t] = tie_rec;
-        atomicAdd(&ctr->strat[SRW_STAT_HANDED_OVER], 1ull);
+        const unsigned long long t = atomicAdd(ah.todo_n, 1ull);
+        ah.todo[t] = (int32_t)wi;
+        if (ah.tie.todo_tie) ah.tie.todo_tie[t] = tie_rec;
+        atomicAdd(&ah.ctr->strat[SRW_STAT_HANDED_OVER], 1ull);
       }
       continue;
     }
     for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
-    if (lane == 0) lens[wi] = len;
+    if (lane == 0) TAB_ARGS().lens[wi] = len;
     steps += (unsigned long long)(len - 1); n_first += len > 1 ? 1u : 0u;
     fb += w_fb; dead += w_dead; fast += w_fast; srch += w_srch; n_tab += w_tab; n_mask += w_mask;
   }
   if (lane == 0) {
+    DevCounters *ctr = TAB_ARGS().ctr;
     srch += mem.res_bytes;
     if (steps) atomicAdd(&ctr->steps, steps);
     if (dead) atomicAdd(&ctr->dead_ends, (unsigned long long)dead);
@@ -1427,28 +1451,38 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
 constexpr int SH_GRAB = 16;         // records per cursor grab (a single counter word saturates at ~88 atomics/us)
 struct alignas(16) ChainMeta { long long d_off; int32_t deg; uint32_t u_off; };   // first quotient in the scratch array, row length, first work unit
 struct ChainUnits { double *usum; int32_t *ue; unsigned long long *utot; };       // per unit of 256 quotients: plain sum, guessed binade, integer increment
+// (arguments as one struct, read again from the kernarg segment where a record needs them: k_walk_tables, device_common.h:fresh_args)
+struct ShTabArgs {
+  GraphView g; ShardIO io; int32_t first_walk, step, last; RngSpec rng; float p, q; SWalker *scratch;
+  unsigned long long *cursor; uint32_t *todo; DevCounters *ctr; int32_t grab_n; ChainRec *chain;
+};
+#if SRW_TAB_FRESH
+#define SH_TAB_ARGS() fresh_args<ShTabArgs>()
+#else
+#define SH_TAB_ARGS() a0
+#endif
 template <bool BF>
-__global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_sh_step_tab(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last,
-                                                                     RngSpec rng, float p, float q, SWalker *__restrict__ scratch,
-                                                                     unsigned long long *cursor, uint32_t *__restrict__ todo, DevCounters *ctr, int32_t grab_n,
-                                                                     ChainRec *__restrict__ chain) {
+__global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_sh_step_tab(ShTabArgs a0) {
   __shared__ __attribute__((aligned(16))) uint32_t stage_all[TPB / 64][1024];
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
   const int lane = lane_id();
   uint32_t *stage = stage_all[threadIdx.x >> 6];
-  const uint32_t n_in = shard_in_prefix(io, pre);
+  const uint32_t n_in = shard_in_prefix(a0.io, pre);
   Member mem; mem.mode = 0; mem.bm = stage; mem.seg_base = 0;
+  const int32_t step = a0.step, grab_n = a0.grab_n;
   const bool second = step > 1;
   unsigned long long srch = 0;
   uint32_t steps = 0, fb = 0, dead = 0, fast = 0, n_tab = 0, n_mask = 0, n_first = 0, n_todo = 0;
   while (true) {
     unsigned long long grab = 0;
-    if (lane == 0) grab = atomicAdd(cursor, (unsigned long long)grab_n);
+    if (lane == 0) grab = atomicAdd(SH_TAB_ARGS().cursor, (unsigned long long)grab_n);
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(grab > 0xFFFFFFFFull ? 0xFFFFFFFFull : grab));
     if (r0 >= n_in) break;
     const uint32_t r1 = r0 + (uint32_t)grab_n < n_in ? r0 + (uint32_t)grab_n : n_in;
     for (uint32_t ri = r0; ri < r1; ++ri) {
-      SWalker wk = shard_in_record(io, pre, ri);
+      const ShTabArgs ar = SH_TAB_ARGS();             // (what the top of a record needs; the samplers read the graph again where they start)
+      const GraphView &g = ar.g;
+      SWalker wk = shard_in_record(ar.io, pre, ri);
       wk.lw = __builtin_amdgcn_readfirstlane(wk.lw); wk.src = __builtin_amdgcn_readfirstlane(wk.src);
       wk.prev = __builtin_amdgcn_readfirstlane(wk.prev); wk.curr = __builtin_amdgcn_readfirstlane(wk.curr);
       const int64_t cslot = (int64_t)wk.curr - g.vmin, pslot = (int64_t)wk.prev - g.vmin;
@@ -1464,12 +1498,12 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       r = uniform_row(r);
       if (!in_range) { r.off = 0; r.deg = 0; r.flags = 0; }
       if (r.deg == 0) {                                  // dead end (or a source without neighbors): tell the home rank the length
-        if (lane == 0) scratch[ri] = shard_dead(wk);
+        if (lane == 0) ar.scratch[ri] = shard_dead(wk);
         dead += second ? 1u : 0u;
         continue;
       }
-      const uint32_t iter = (uint32_t)(first_walk + wk.lw % io.batch);
-      const float u = draw_uniform(rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
+      const uint32_t iter = (uint32_t)(ar.first_walk + wk.lw % ar.io.batch);
+      const float u = draw_uniform(ar.rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
       unsigned f = 0, sv = 0;
       int32_t k, next = 0;
       // CHAIN = false: a draw within rounding distance of a CDF boundary is not decided here.  On a table step the record
@@ -1478,22 +1512,24 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       // other super-step; everywhere else (first steps, rows below 256 candidates) the general step takes the record.
       bool to_chain = false; double S_tie = 0.0;
       if (!second) {
-        k = wave_pick_first<false>(g, r, u, f, next);
+        k = wave_pick_first<false>(GFRESH(), r, u, f, next);
         n_first += k >= 0 ? 1u : 0u;
       } else {
         Bias b;
-        b.p = p; b.q = q; b.prev = wk.prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
+        b.p = ar.p; b.q = ar.q; b.prev = wk.prev; b.second_order = true; b.need_member = true; b.vmin = g.vmin;
         b.prev_sids = g.msids + mr.off; b.prev_deg = mr.deg; b.prev_hub = mr.flags >> ROW_HUB_SHIFT;
         if (r.deg <= g.eb_mask_max && found) {
-          k = wave_pick_masked<false>(g, r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
+          k = wave_pick_masked<false>(GFRESH(), r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
           if (k >= 0) { n_mask += 1; srch += 8ull * (unsigned long long)r.deg + 4ull * (unsigned long long)((r.deg + 31) >> 5); }
         } else if (r.deg > g.eb_mask_max && found && (r.flags & ROW_PQ_OK)) {
-          k = wave_pick_edge_table<BF, false>(g, r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie);
+          k = wave_pick_edge_table<BF, false>(GFRESH(), r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie);
           if (k >= 0) { n_tab += 1; srch += 8ull * EB_BINS; fast += sv; }
           to_chain = k == CHAIN_NEEDED;
         } else k = -1;
       }
       if (k < 0) {
+        const ShTabArgs at = SH_TAB_ARGS();
+        unsigned long long *cursor = at.cursor; ChainRec *chain = at.chain; uint32_t *todo = at.todo;
         if (lane == 0) {
           unsigned long long ci = to_chain ? atomicAdd(cursor + 2, 1ull) : (unsigned long long)CHAIN_CAP;
           if (ci < (unsigned long long)CHAIN_CAP) { ChainRec cr; cr.ri = ri; cr.pad = 0u; cr.S = S_tie; chain[ci] = cr; }
@@ -1504,10 +1540,11 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       }
       next = __builtin_amdgcn_readfirstlane(next);
       fb += f; steps += 1;
-      if (lane == 0) scratch[ri] = shard_advance(wk, step, next, last != 0);
+      if (lane == 0) { const ShTabArgs ao = SH_TAB_ARGS(); ao.scratch[ri] = shard_advance(wk, step, next, ao.last != 0); }
     }
   }
   if (lane == 0) {
+    DevCounters *ctr = SH_TAB_ARGS().ctr;
     srch += mem.res_bytes;
     if (steps) atomicAdd(&ctr->steps, (unsigned long long)steps);
     if (dead) atomicAdd(&ctr->dead_ends, (unsigned long long)dead);
@@ -2183,14 +2220,14 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
     }
     if (lean) {
       int64_t lb = std::min<int64_t>((n_walkers * 64 + TPB - 1) / TPB, (int64_t)h->n_cus * 16);
+      TabArgs ta;
+      ta.g = gv; ta.verts = g.verts.p; ta.n_verts = g.n_vertices; ta.n_walkers = n_walkers; ta.L = P.walk_length; ta.first_walk = first_walk;
+      ta.rng = rng; ta.p = P.p; ta.q = P.q; ta.paths = d_paths; ta.lens = d_lens; ta.ctr = h->counters.p; ta.cursor = h->walk_cursor.p;
+      ta.todo = h->walk_todo.p; ta.todo_n = h->walk_cursor.p + 1; ta.tie = tie;
       if (gv.bf_off) {
-        hipLaunchKernelGGL((k_walk_tables<true>), dim3((unsigned)lb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
-                         first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, h->walk_todo.p,
-                         h->walk_cursor.p + 1, tie);
+        hipLaunchKernelGGL((k_walk_tables<true>), dim3((unsigned)lb), dim3(TPB), 0, st, ta);
       } else {
-        hipLaunchKernelGGL((k_walk_tables<false>), dim3((unsigned)lb), dim3(TPB), 0, st, gv, g.verts.p, g.n_vertices, n_walkers, P.walk_length,
-                         first_walk, rng, P.p, P.q, d_paths, d_lens, h->counters.p, h->walk_cursor.p, h->walk_todo.p,
-                         h->walk_cursor.p + 1, tie);
+        hipLaunchKernelGGL((k_walk_tables<false>), dim3((unsigned)lb), dim3(TPB), 0, st, ta);
       }
       SRW_HIP(hipMemsetAsync(h->walk_cursor.p, 0, sizeof(unsigned long long), st));
       todo = h->walk_todo.p;
@@ -2818,12 +2855,11 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     static const int tb_mult = getenv("SRW_SH_BLOCKS") ? std::max(1, atoi(getenv("SRW_SH_BLOCKS"))) : 8;
     const int tb = h->n_cus * tb_mult;
     timed(1, [&] {
-      if (gv.bf_off)
-        hipLaunchKernelGGL((k_sh_step_tab<true>), dim3(tb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch,
-                           h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n, chain_list);
-      else
-        hipLaunchKernelGGL((k_sh_step_tab<false>), dim3(tb), dim3(TPB), 0, st, gv, io, P.first_walk, step, last, rng, P.p, P.q, scratch,
-                           h->walk_cursor.p, (uint32_t *)h->walk_todo.p, h->counters.p, grab_n, chain_list);
+      ShTabArgs ta;
+      ta.g = gv; ta.io = io; ta.first_walk = P.first_walk; ta.step = step; ta.last = last; ta.rng = rng; ta.p = P.p; ta.q = P.q; ta.scratch = scratch;
+      ta.cursor = h->walk_cursor.p; ta.todo = (uint32_t *)h->walk_todo.p; ta.ctr = h->counters.p; ta.grab_n = grab_n; ta.chain = chain_list;
+      if (gv.bf_off) hipLaunchKernelGGL((k_sh_step_tab<true>), dim3(tb), dim3(TPB), 0, st, ta);
+      else hipLaunchKernelGGL((k_sh_step_tab<false>), dim3(tb), dim3(TPB), 0, st, ta);
     });
     // draws on a CDF boundary of a table step
     timed(2, [&] { enqueue_chain(h, cb, gv, io, P, step, last, rng, scratch, (int)SRW_STRAT_EDGE_TABLE, h->walk_cursor.p, (uint32_t *)h->walk_todo.p); });

@@ -33,6 +33,11 @@ __device__ inline int64_t uni(int64_t v) {
 }
 template <typename T> __device__ inline const T *uni(const T *p) { return reinterpret_cast<const T *>((uintptr_t)uni((int64_t)(uintptr_t)p)); }
 
+// ... and the other way: once the scalar unit is the busier one (448 scalar against 302 vector instructions per table step,
+// profiles/r04_valu_issue.md) a self-contained piece of wave-uniform integer arithmetic is cheaper on the vector unit: on_vector() hides
+// the value's uniformity from the compiler, what is computed from it runs as vector instructions, uni() brings the results back.
+__device__ inline int32_t on_vector(int32_t v) { int32_t r; asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; }
+
 // (the results are the wave's: handed back through SGPRs — uni — so that the compiler sees the branches they decide as uniform)
 __device__ inline double wave_sum_f64(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -86,10 +91,8 @@ struct SumCert {
   }
 };
 
-__device__ inline int ceil_log2_i64(int64_t n) {
-  int b = 0;
-  while (((int64_t)1 << b) < n) ++b;
-  return b;
+__device__ inline int ceil_log2_i64(int64_t n) {     // smallest b with 2^b >= n (closed form: the mask step of the table kernels asks per step)
+  return n <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(n - 1));
 }
 
 // true when the sum of `n` addends described by the (wave-reduced) certificate is order-independent

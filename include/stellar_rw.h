@@ -376,6 +376,13 @@ void srw_free(void *p);
  * srw_write_paths, for callers that assembled several walk calls themselves. */
 int32_t srw_save_paths(const int32_t *paths, const int32_t *lens, int64_t n_walkers, int64_t stride,
                        const char *output_dir, int32_t n_parts, int32_t write_crc);
+/* The chunk geometry of the per-edge bias table of a pair (prev -> curr) — what the planner, the table builder and the walk kernels
+ * all compute from (deg(curr), deg(prev)) and the 10 policy words {min_shift, max_chunks, mask_max_deg, mask_min_prev_deg,
+ * fine_min_prev_deg, fine_shift, fine_max_chunks, f32, u16, mask_ratio} (csrc/sampling.h:eb_pair_geometry).  Chunks of
+ * 2^*chunk_shift candidates, *n_chunks of them, *masked = the pair carries chunk masks.  No reference counterpart (the reference
+ * recomputes the biased weights of N(curr) at every step, RandomSample.scala:27-44); exported for the CPU test of the closed form. */
+int32_t srw_table_geometry(int32_t deg_curr, int32_t deg_prev, const int32_t *policy, int32_t *chunk_shift, int32_t *n_chunks,
+                           int32_t *masked);
 /* Library / build identification ("stellar_rw gfx950 <git describe>"). */
 const char *srw_version(void);
 

@@ -94,7 +94,7 @@ EXPORTS = [
     "srw_cluster_shard", "srw_cluster_load_edgelist", "srw_cluster_load_coo", "srw_cluster_generate_rmat",
     "srw_cluster_graph_stats", "srw_cluster_walk", "srw_cluster_fetch_paths", "srw_cluster_walk_and_save",
     "srw_shard_select", "srw_w2v_fit", "srw_w2v_save", "srw_probe_request_rate", "srw_result_scan_sums", "srw_sample", "srw_second_order_weights",
-    "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_version",
+    "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_table_geometry", "srw_version",
 ]
 
 _lib = None
@@ -180,6 +180,7 @@ def lib():
     L.srw_free.argtypes = [vp]
     L.srw_free.restype = None
     L.srw_save_paths.argtypes = [i32p, i32p, C.c_int64, C.c_int64, C.c_char_p, C.c_int32, C.c_int32]
+    L.srw_table_geometry.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.srw_version.restype = C.c_char_p
     _lib = L
     return L

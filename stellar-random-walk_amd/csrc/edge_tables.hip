@@ -940,3 +940,16 @@ void build_rev_table(srw_handle *h) {
 }
 
 }  // namespace srw
+
+// Host-only hook (include/stellar_rw.h): the chunk geometry the planner, the builder and the walk kernels share (sampling.h:
+// eb_pair_geometry), for the CPU test that holds its closed form against the definition.
+extern "C" int32_t srw_table_geometry(int32_t deg_curr, int32_t deg_prev, const int32_t *policy, int32_t *chunk_shift, int32_t *n_chunks,
+                                      int32_t *masked) {
+  if (!policy || !chunk_shift || !n_chunks || !masked || deg_curr < 1 || deg_prev < 0 || policy[1] < 1 || policy[0] < 0 || policy[0] > 30) return SRW_ERR_INVALID;
+  srw::EbPolicy P;
+  P.min_sh = policy[0]; P.cap = policy[1]; P.cm_max = policy[2]; P.cm_min_du = policy[3]; P.fine_min_du = policy[4]; P.fine_sh = policy[5];
+  P.fine_cap = policy[6]; P.f32 = policy[7]; P.u16 = policy[8]; P.cm_ratio = policy[9];
+  const srw::PairGeom g = srw::eb_pair_geometry(deg_curr, deg_prev, P);
+  *chunk_shift = g.csh; *n_chunks = g.n_bins; *masked = g.cmask ? 1 : 0;
+  return SRW_OK;
+}

@@ -1392,12 +1392,25 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     // S is the last element of the top level
     const bool u16t = eb_pair_u16(rflags, csh, g.ebp);
     const double unit = u16t ? eb_row_unit(rflags) : 0.0;
+#ifndef SRW_LAYOUT_ON_SALU         // (the layout on the vector unit — the offsets only feed per-lane addresses: 577 against 591 ms at config 3, gpurun_out/ab4)
+    EbLayout lay = eb_layout(f32t, on_vector(n_bins), false, 0, u16t);
+    lay.n1 = uni(lay.n1); lay.n2 = uni(lay.n2);
+#else
     const EbLayout lay = eb_layout(f32t, n_bins, false, 0, u16t);
+#endif
     const int nlev = lay.n2 ? 3 : lay.n1 ? 2 : 1;
     int32_t blk = 0;
     double prev_val = 0.0;                            // prefix just before the block being searched
     jc = 0;
+    // (three copies with L a constant: what selects the level's offset / length / shift by L disappears — scalar instructions, the busier
+    //  unit: 591 against 604 ms at config 3, gpurun_out/ab4)
+#ifdef SRW_EB_ROLLED_LEVELS
     for (int L = nlev - 1; L >= 0; --L) {
+#else
+#pragma unroll
+    for (int L = 2; L >= 0; --L) {
+      if (L >= nlev) continue;
+#endif
       const uint32_t off = L == 2 ? lay.l2_off : L == 1 ? lay.l1_off : lay.l0_off;
       const int32_t cnt = L == 2 ? lay.n2 : L == 1 ? lay.n1 : n_bins;
       const int32_t i = blk * 64 + lane;
@@ -1781,7 +1794,7 @@ __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc
   const int32_t dv = uni(rc.deg);
   const uint32_t rflags = uni(rc.flags);
   table = uni(table);
-#ifdef SRW_GEOM_ON_VALU
+#ifndef SRW_GEOM_ON_SALU          // (the pair's geometry on the vector unit: 604-607 against 610-614 ms at config 3, gpurun_out/ab3; -DSRW_GEOM_ON_SALU: as before)
   const PairGeom pgv = eb_pair_geometry(on_vector(dv), on_vector(uni(b.prev_deg)), g.ebp);
   PairGeom pg; pg.csh = uni(pgv.csh); pg.n_bins = uni(pgv.n_bins); pg.cmask = uni((int32_t)pgv.cmask) != 0;
 #else

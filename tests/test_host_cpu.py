@@ -446,3 +446,52 @@ def test_oracle_embedding_separates_neighbours(oracle):
             if a < b:
                 (nb if b in na else nn).append(float(vn[idx[a]] @ vn[idx[b]]))
     assert np.mean(nb) > np.mean(nn) + 0.2
+
+
+# ---- chunk geometry of the per-edge tables: the closed form the kernels run per step == its definition -------------------------
+def _bin_geometry_def(deg, min_sh, cap):
+    """smallest csh >= min_sh with ceil(deg / 2^csh) <= cap, by search (the definition csrc/sampling.h:bin_geometry states)"""
+    c = min_sh
+    while ((deg + (1 << c) - 1) >> c) > cap:
+        c += 1
+    return c, (deg + (1 << c) - 1) >> c
+
+
+def _pair_geometry_def(dv, du, P):
+    min_sh, cap, cm_max, cm_min_du, fine_min_du, fine_sh, fine_cap, _f32, _u16, cm_ratio = P
+    csh, n = _bin_geometry_def(dv, min_sh, cap)
+    masked = False
+    if dv <= cm_max and csh >= 6 and (du > cm_min_du or (du > 32 and dv <= cm_ratio * du)):
+        masked = True
+    elif fine_cap > 0 and du > fine_min_du and fine_sh >= 6:
+        fc, fn = _bin_geometry_def(dv, fine_sh, fine_cap)
+        if fc < csh:
+            csh, n = fc, fn
+    return csh, n, int(masked)
+
+
+def test_table_geometry_closed_form_matches_its_definition():
+    import ctypes as C
+    L = pkg().lib()
+    rng = np.random.default_rng(5)
+    policies = [
+        (8, 64, 0, 0, 0, 0, 0, 0, 0, 0), (6, 256, 16384, 1024, 1024, 6, 4096, 1, 1, 16), (7, 128, 4096, 1024, 1024, 6, 1024, 0, 1, 4),
+        (2, 64, 0, 0, 0, 0, 0, 0, 0, 0), (6, 32, 16384, 64, 256, 7, 512, 1, 0, 0), (6, 100, 5000, 100, 300, 6, 1000, 0, 0, 3),
+        (8, 256, 0, 0, 1024, 6, 32768, 1, 1, 0),
+    ]
+    degs = list(range(1, 700)) + [(1 << k) + d for k in range(6, 31) for d in (-1, 0, 1)] + [int(x) for x in rng.integers(1, (1 << 31) - 1, 3000)]
+    dus = [0, 1, 31, 32, 33, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4096, 100000, (1 << 31) - 1]
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    n = 0
+    for P in policies:
+        pol = (C.c_int32 * 10)(*P)
+        for dv in degs:
+            for du in (dus if dv % 7 == 0 or dv < 300 else dus[::5]):
+                rc = L.srw_table_geometry(dv, du, pol, C.byref(a), C.byref(b), C.byref(c))
+                assert rc == 0
+                assert (a.value, b.value, c.value) == _pair_geometry_def(dv, du, P), (dv, du, P)
+                n += 1
+    assert n > 50000
+    # argument checks
+    assert L.srw_table_geometry(0, 1, (C.c_int32 * 10)(*policies[0]), C.byref(a), C.byref(b), C.byref(c)) != 0
+    assert L.srw_table_geometry(5, 1, None, C.byref(a), C.byref(b), C.byref(c)) != 0

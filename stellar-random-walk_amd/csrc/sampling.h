@@ -1392,7 +1392,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     // S is the last element of the top level
     const bool u16t = eb_pair_u16(rflags, csh, g.ebp);
     const double unit = u16t ? eb_row_unit(rflags) : 0.0;
-#ifndef SRW_LAYOUT_ON_SALU         // (the layout on the vector unit — the offsets only feed per-lane addresses: 577 against 591 ms at config 3, gpurun_out/ab4)
+#ifndef SRW_LAYOUT_ON_SALU         // (the layout on the vector unit — the offsets only feed per-lane addresses: 577 against 591 ms at config 3, profiles/r04_table_kernel_ab_runs.txt)
     EbLayout lay = eb_layout(f32t, on_vector(n_bins), false, 0, u16t);
     lay.n1 = uni(lay.n1); lay.n2 = uni(lay.n2);
 #else
@@ -1403,7 +1403,7 @@ __device__ inline int32_t binned_resolve(const GraphView &g, const Row &rc, cons
     double prev_val = 0.0;                            // prefix just before the block being searched
     jc = 0;
     // (three copies with L a constant: what selects the level's offset / length / shift by L disappears — scalar instructions, the busier
-    //  unit: 591 against 604 ms at config 3, gpurun_out/ab4)
+    //  unit: 591 against 604 ms at config 3, profiles/r04_table_kernel_ab_runs.txt)
 #ifdef SRW_EB_ROLLED_LEVELS
     for (int L = nlev - 1; L >= 0; --L) {
 #else
@@ -1693,16 +1693,17 @@ __device__ inline int32_t wave_pick_first(const GraphView &g, const Row &rc, flo
 // same certified evaluation as the table path (exact parallel S and prefix sums under the certificate, divide-free
 // certain-miss / certain-hit compares, the sequential chain otherwise) without a single membership lookup.
 constexpr int MASK_MAX_DEG = 256;       // rows up to 255 candidates: 4 per lane stay in registers
-template <bool CHAIN = true>
+// NS: slots of 64 candidates the instantiation handles (rows up to 64 * NS candidates); NS = 1 is the straight-line form for the short rows
+template <bool CHAIN = true, int NS = 4>
 __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, const Bias &b, uint32_t inline_mask,
                                            const uint32_t *words, float r, unsigned &fallback, int32_t &id_out) {
   const int lane = lane_id();
   const Ent *row = g.ent + rc.off;
   const int32_t deg = rc.deg;
-  const int ni = (deg + 63) >> 6;                  // <= 4
-  float wv[4]; int32_t idv[4]; uint32_t mw[4];
+  const int ni = NS == 1 ? 1 : (deg + 63) >> 6;     // <= NS
+  float wv[NS]; int32_t idv[NS]; uint32_t mw[NS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NS; ++i) {
     mw[i] = 0u;
     if (i < ni) mw[i] = words ? words[2 * i + (lane >> 5)] : ((i == 0 && lane < 32) ? inline_mask : 0u);
   }
@@ -1711,7 +1712,7 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   bool neg = false;
   const BiasDiv bdiv(b.p, b.q);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NS; ++i) {
     const int32_t k = i * 64 + lane;
     wv[i] = 0.0f; idv[i] = 0;
     if (i < ni && k < deg) {
@@ -1741,7 +1742,7 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   const double pS = p * S;
   double carry = 0.0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NS; ++i) {
     if (i >= ni) break;
     const int32_t k = i * 64 + lane;
     const bool valid = k < deg;
@@ -1794,7 +1795,7 @@ __device__ inline int32_t wave_pick_edge_table(const GraphView &g, const Row &rc
   const int32_t dv = uni(rc.deg);
   const uint32_t rflags = uni(rc.flags);
   table = uni(table);
-#ifndef SRW_GEOM_ON_SALU          // (the pair's geometry on the vector unit: 604-607 against 610-614 ms at config 3, gpurun_out/ab3; -DSRW_GEOM_ON_SALU: as before)
+#ifndef SRW_GEOM_ON_SALU          // (the pair's geometry on the vector unit: 604-607 against 610-614 ms at config 3, profiles/r04_table_kernel_ab_runs.txt; -DSRW_GEOM_ON_SALU: as before)
   const PairGeom pgv = eb_pair_geometry(on_vector(dv), on_vector(uni(b.prev_deg)), g.ebp);
   PairGeom pg; pg.csh = uni(pgv.csh); pg.n_bins = uni(pgv.n_bins); pg.cmask = uni((int32_t)pgv.cmask) != 0;
 #else

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
 // config 3 6 -> 705-719 M, 7 -> 771 M, 8 -> 690 M; config 5's stand-in 7 -> 363 M, 8 -> 387 M.  So by instantiation:
 // Round 4, after the arguments left the SGPRs (TabArgs below: 65 VGPRs, no scratch at 7 waves; 64 VGPRs + 12 B at 8) and with SALU the
 // busier unit (448 scalar against 302 vector instructions per step, profiles/r04_valu_issue.md): 8 waves 624 ms against 644 at config 3,
-// 3 711 against 4 035 ms at config 5's stand-in (gpurun_out/ab2, A / B / C twice on one box).
+// 3 711 against 4 035 ms at config 5's stand-in (profiles/r04_table_kernel_ab_runs.txt, A / B / C twice on one box).
 #ifndef SRW_LEAN_WAVES
 #define SRW_LEAN_WAVES 8
 #endif
@@ -356,7 +356,14 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
     const int32_t src = __builtin_amdgcn_readfirstlane(aw.verts[vi]);
     const uint32_t ksrc = (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(aw.g, src));
     int32_t *path = aw.paths + wi * stride;
+#ifdef SRW_PATH_BUF
+    // the path of the walker, 64 slots at a time, in ONE register (lane t = slot base + t, -1 = unused): a step writes its lane
+    // (v_writelane) instead of storing 4 bytes behind an exec mask, a block of 64 slots goes out with one coalesced store
+    int32_t pbuf = -1;
+    asm("v_writelane_b32 %0, %1, 0" : "+v"(pbuf) : "s"(src));
+#else
     if (lane == 0) path[0] = src;
+#endif
     int32_t prev = src, curr = src, len = 1;
     Row rprev; rprev.off = 0; rprev.deg = 0; rprev.flags = 0;
     int64_t eprev = 0;
@@ -390,6 +397,10 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
         b.prev_sids = gs.sids + rprev.off; b.prev_deg = rprev.deg; b.prev_hub = rprev.flags >> ROW_HUB_SHIFT;
         SRW_T0(mem);
         if (r.deg <= gs.eb_mask_max && (r.deg <= 32 || eo != EB_NONE)) {
+#ifdef SRW_MASK1
+          if (r.deg <= 64) k = uni(wave_pick_masked<false, 1>(GFRESH(), r, b, eo, r.deg > 32 ? gs.em_bits + (size_t)eo * 4 : nullptr, u, f, next));
+          else
+#endif
           k = uni(wave_pick_masked<false>(GFRESH(), r, b, eo, r.deg > 32 ? gs.em_bits + (size_t)eo * 4 : nullptr, u, f, next));
           w_mask += 1; w_srch += 8u * (uint32_t)r.deg + 4u * (uint32_t)((r.deg + 31) >> 5);
           SRW_T1(mem, t_a);
@@ -419,7 +430,12 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       }
       next = uni(next);
       w_fb += f;
+#ifdef SRW_PATH_BUF
+      asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pbuf) : "s"(next), "s"(s & 63) : "m0");      // (one SGPR operand per instruction: the lane index goes through m0)
+      if ((s & 63) == 63) { path[(s & ~63) + lane] = pbuf; pbuf = -1; }      // (a full block: s <= L + 1 < stride)
+#else
       if (lane == 0) path[s] = next;
+#endif
       prev = curr; curr = next; ++len; rprev = r; eprev = r.off + k;
     }
     if (handed_over) {
@@ -432,7 +448,15 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       }
       continue;
     }
+#ifdef SRW_PATH_BUF
+    {                                                 // the block the walk ended in (its unused lanes are the tail's -1), then the rest of the tail
+      const int64_t b0 = (int64_t)(len & ~63);
+      if (b0 + lane < stride) path[b0 + lane] = pbuf;
+      for (int64_t t = b0 + 64 + lane; t < stride; t += 64) path[t] = -1;
+    }
+#else
     for (int64_t t = len + lane; t < stride; t += 64) path[t] = -1;  // unused tail
+#endif
     if (lane == 0) TAB_ARGS().lens[wi] = len;
     steps += (unsigned long long)(len - 1); n_first += len > 1 ? 1u : 0u;
     fb += w_fb; dead += w_dead; fast += w_fast; srch += w_srch; n_tab += w_tab; n_mask += w_mask;

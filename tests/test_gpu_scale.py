@@ -203,3 +203,28 @@ def test_three_level_table_on_a_long_row(oracle, monkeypatch):
             paths, lens, st = e.walk(p=p, q=q, walk_length=12, seed=31)
             assert np.array_equal(lens[idx], rl) and np.array_equal(paths[idx], rp), (p, q)
             assert st["strategy_steps"]["edge_table"] > 0, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weighted", [False, True])
+def test_non_dyadic_pq_through_tables_and_masks(eng, oracle, weighted):
+    """p, q that are not powers of two: the biased weights are real f32 divides (RandomSample.scala:33,35), one per candidate with the
+    divisor selected per lane (sampling.h:BiasDiv) — on the table steps, the mask steps and the on-the-fly samplers alike."""
+    scale, L = 14, 30
+    n_edges = 16 << scale
+    s, d = oracle.rmat_edges(scale, n_edges, seed=9)
+    w = rmat_weights_np(s, d, 9) if weighted else None
+    g = oracle.Graph.from_coo(s, d, w, directed=False)
+    eng.generate_rmat(scale, n_edges, seed=9, weighted=weighted)
+    assert eng.stats() == (g.num_vertices, g.num_entries)
+    verts = eng.vertices()
+    src = _sources(g, verts, 1500, scale)
+    idx = np.searchsorted(verts, src)
+    for p, q in [(0.3, 0.7), (3.0, 7.0), (1.1, 0.9), (0.25, 3.0)]:
+        rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=L, seed=4321, threads=8)
+        paths, lens, st = eng.walk(p=p, q=q, walk_length=L, seed=4321)
+        assert np.array_equal(lens[idx], rl), (p, q)
+        bad = np.nonzero((paths[idx] != rp).any(axis=1))[0]
+        assert bad.size == 0, (p, q, int(src[bad[0]]), paths[idx][bad[0]], rp[bad[0]])
+        paths2, lens2, _ = eng.walk(p=p, q=q, walk_length=L, seed=4321, edge_tables=False)
+        assert np.array_equal(paths2, paths) and np.array_equal(lens2, lens), (p, q)

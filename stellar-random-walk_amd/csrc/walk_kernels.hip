@@ -1485,7 +1485,11 @@ struct ShTabArgs {
 #else
 #define SH_TAB_ARGS() a0
 #endif
-template <bool BF>
+// BATCH (round 4, SRW_SH_BATCH=0 for the A / B): what a record needs before its first table read — the record itself, its
+// Philox draw and the pair-hash probe — is fetched and computed for the WHOLE grab at once, lane l for record r0 + l (one Philox
+// evaluation and one probe chain per 16 records instead of 16 wave-wide ones; the record's step then starts at the row reads),
+// and every pick goes back through SGPRs (uni) so that the record loop is uniform in the compiler's eyes, as in k_walk_tables.
+template <bool BF, bool BATCH>
 __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_sh_step_tab(ShTabArgs a0) {
   __shared__ __attribute__((aligned(16))) uint32_t stage_all[TPB / 64][1024];
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
@@ -1503,12 +1507,36 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(grab > 0xFFFFFFFFull ? 0xFFFFFFFFull : grab));
     if (r0 >= n_in) break;
     const uint32_t r1 = r0 + (uint32_t)grab_n < n_in ? r0 + (uint32_t)grab_n : n_in;
+    // (BATCH) lane l: record r0 + l, its draw, the table word of its pair (b_eo: bit 0 of b_found = the pair has one)
+    SWalker bw; bw.lw = 0; bw.src = 0; bw.prev = 0; bw.curr = 0;
+    float bu = 0.0f; uint32_t b_eo = EB_NONE, b_found = 0u;
+    if constexpr (BATCH) {
+      const ShTabArgs ab = SH_TAB_ARGS();
+      const GraphView &g = ab.g;
+      const uint32_t rl = r0 + (uint32_t)lane < r1 ? r0 + (uint32_t)lane : r1 - 1u;      // (grab_n <= 64: run_shard_superstep)
+      bw = shard_in_record(ab.io, pre, rl);
+      const uint32_t iter = (uint32_t)(ab.first_walk + bw.lw % ab.io.batch);
+      bu = draw_uniform(ab.rng, iter, (uint32_t)rng_source(g, bw.src), (uint32_t)step);
+      const int64_t cslot = (int64_t)bw.curr - g.vmin, pslot = (int64_t)bw.prev - g.vmin;
+      if (second && cslot >= 0 && cslot < g.n_slots && pslot >= 0 && pslot < g.n_slots) {
+        uint32_t pad;
+        b_found = pair_lookup_lane(g.ph, g.ph_buckets, (uint32_t)pslot, (uint32_t)cslot, b_eo, pad) ? 1u : 0u;
+      }
+    }
     for (uint32_t ri = r0; ri < r1; ++ri) {
       const ShTabArgs ar = SH_TAB_ARGS();             // (what the top of a record needs; the samplers read the graph again where they start)
       const GraphView &g = ar.g;
-      SWalker wk = shard_in_record(ar.io, pre, ri);
-      wk.lw = __builtin_amdgcn_readfirstlane(wk.lw); wk.src = __builtin_amdgcn_readfirstlane(wk.src);
-      wk.prev = __builtin_amdgcn_readfirstlane(wk.prev); wk.curr = __builtin_amdgcn_readfirstlane(wk.curr);
+      SWalker wk;
+      if constexpr (BATCH) {
+        const int j = (int)(ri - r0);
+        wk.lw = __builtin_amdgcn_readlane(bw.lw, j); wk.src = __builtin_amdgcn_readlane(bw.src, j);
+        wk.prev = __builtin_amdgcn_readlane(bw.prev, j); wk.curr = __builtin_amdgcn_readlane(bw.curr, j);
+        wk.v = 0; wk.kind = 0; wk.pad0 = 0; wk.pad1 = 0;
+      } else {
+        wk = shard_in_record(ar.io, pre, ri);
+        wk.lw = __builtin_amdgcn_readfirstlane(wk.lw); wk.src = __builtin_amdgcn_readfirstlane(wk.src);
+        wk.prev = __builtin_amdgcn_readfirstlane(wk.prev); wk.curr = __builtin_amdgcn_readfirstlane(wk.curr);
+      }
       const int64_t cslot = (int64_t)wk.curr - g.vmin, pslot = (int64_t)wk.prev - g.vmin;
       const bool in_range = cslot >= 0 && cslot < g.n_slots;
       Row r = g.rows[in_range ? cslot : 0];
@@ -1516,7 +1544,10 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       uint32_t eo = EB_NONE; bool found = false;
       if (second && in_range && pslot >= 0 && pslot < g.n_slots) {
         mr = g.mrows[pslot];
-        found = pair_lookup_wave(g.ph, g.ph_buckets, (uint32_t)pslot, (uint32_t)cslot, eo);
+        if constexpr (BATCH) {
+          const int j = (int)(ri - r0);
+          eo = (uint32_t)__builtin_amdgcn_readlane((int)b_eo, j); found = __builtin_amdgcn_readlane((int)b_found, j) != 0;
+        } else found = pair_lookup_wave(g.ph, g.ph_buckets, (uint32_t)pslot, (uint32_t)cslot, eo);
         mr = uniform_row(mr);
       }
       r = uniform_row(r);
@@ -1526,8 +1557,12 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
         dead += second ? 1u : 0u;
         continue;
       }
-      const uint32_t iter = (uint32_t)(ar.first_walk + wk.lw % ar.io.batch);
-      const float u = draw_uniform(ar.rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
+      float u;
+      if constexpr (BATCH) u = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(bu), (int)(ri - r0)));
+      else {
+        const uint32_t iter = (uint32_t)(ar.first_walk + wk.lw % ar.io.batch);
+        u = draw_uniform(ar.rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
+      }
       unsigned f = 0, sv = 0;
       int32_t k, next = 0;
       // CHAIN = false: a draw within rounding distance of a CDF boundary is not decided here.  On a table step the record
@@ -1537,6 +1572,7 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       bool to_chain = false; double S_tie = 0.0;
       if (!second) {
         k = wave_pick_first<false>(GFRESH(), r, u, f, next);
+        if constexpr (BATCH) k = uni(k);
         n_first += k >= 0 ? 1u : 0u;
       } else {
         Bias b;
@@ -1544,9 +1580,11 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
         b.prev_sids = g.msids + mr.off; b.prev_deg = mr.deg; b.prev_hub = mr.flags >> ROW_HUB_SHIFT;
         if (r.deg <= g.eb_mask_max && found) {
           k = wave_pick_masked<false>(GFRESH(), r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
+          if constexpr (BATCH) k = uni(k);
           if (k >= 0) { n_mask += 1; srch += 8ull * (unsigned long long)r.deg + 4ull * (unsigned long long)((r.deg + 31) >> 5); }
         } else if (r.deg > g.eb_mask_max && found && (r.flags & ROW_PQ_OK)) {
           k = wave_pick_edge_table<BF, false>(GFRESH(), r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie);
+          if constexpr (BATCH) k = uni(k);
           if (k >= 0) { n_tab += 1; srch += 8ull * EB_BINS; fast += sv; }
           to_chain = k == CHAIN_NEEDED;
         } else k = -1;
@@ -2875,15 +2913,21 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     const ChainBufs cb = chain_bufs(h);
     ChainRec *chain_list = cb.list;
     const GraphView gv = g.view();
-    static const int grab_n = getenv("SRW_SH_GRAB") ? std::max(1, atoi(getenv("SRW_SH_GRAB"))) : SH_GRAB;
+    static const int grab_n = std::min(64, getenv("SRW_SH_GRAB") ? std::max(1, atoi(getenv("SRW_SH_GRAB"))) : SH_GRAB);   // (<= 64: one record per lane in the BATCH prologue)
+    static const bool sh_batch = !(getenv("SRW_SH_BATCH") && atoi(getenv("SRW_SH_BATCH")) == 0);
     static const int tb_mult = getenv("SRW_SH_BLOCKS") ? std::max(1, atoi(getenv("SRW_SH_BLOCKS"))) : 8;
     const int tb = h->n_cus * tb_mult;
     timed(1, [&] {
       ShTabArgs ta;
       ta.g = gv; ta.io = io; ta.first_walk = P.first_walk; ta.step = step; ta.last = last; ta.rng = rng; ta.p = P.p; ta.q = P.q; ta.scratch = scratch;
       ta.cursor = h->walk_cursor.p; ta.todo = (uint32_t *)h->walk_todo.p; ta.ctr = h->counters.p; ta.grab_n = grab_n; ta.chain = chain_list;
-      if (gv.bf_off) hipLaunchKernelGGL((k_sh_step_tab<true>), dim3(tb), dim3(TPB), 0, st, ta);
-      else hipLaunchKernelGGL((k_sh_step_tab<false>), dim3(tb), dim3(TPB), 0, st, ta);
+      if (sh_batch) {
+        if (gv.bf_off) hipLaunchKernelGGL((k_sh_step_tab<true, true>), dim3(tb), dim3(TPB), 0, st, ta);
+        else hipLaunchKernelGGL((k_sh_step_tab<false, true>), dim3(tb), dim3(TPB), 0, st, ta);
+      } else {
+        if (gv.bf_off) hipLaunchKernelGGL((k_sh_step_tab<true, false>), dim3(tb), dim3(TPB), 0, st, ta);
+        else hipLaunchKernelGGL((k_sh_step_tab<false, false>), dim3(tb), dim3(TPB), 0, st, ta);
+      }
     });
     // draws on a CDF boundary of a table step
     timed(2, [&] { enqueue_chain(h, cb, gv, io, P, step, last, rng, scratch, (int)SRW_STRAT_EDGE_TABLE, h->walk_cursor.p, (uint32_t *)h->walk_todo.p); });

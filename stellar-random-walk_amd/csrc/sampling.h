@@ -23,6 +23,13 @@ __device__ inline Row uniform_row(Row r) {            // the row descriptor of a
   o.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.flags);
   return o;
 }
+// ... and lane j's row descriptor (j wave-uniform): the per-lane rows of a grab of records (k_sh_step_tab)
+__device__ inline Row lane_row(const Row &r, int j) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.off, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)r.off >> 32), j);
+  Row o; o.off = (int64_t)(((uint64_t)hi << 32) | lo); o.deg = __builtin_amdgcn_readlane(r.deg, j);
+  o.flags = (uint32_t)__builtin_amdgcn_readlane((int)r.flags, j);
+  return o;
+}
 
 // x / d, evaluated as x * 2^-k when d = 2^k: both are the correctly rounded value of the SAME real number (2^-k is exact
 // for |k| <= 126; FP32 denormals are on, .amdhsa_float_denorm_mode_32 3), so the bits are those of the reference's

@@ -1489,7 +1489,9 @@ struct ShTabArgs {
 // Philox draw and the pair-hash probe — is fetched and computed for the WHOLE grab at once, lane l for record r0 + l (one Philox
 // evaluation and one probe chain per 16 records instead of 16 wave-wide ones; the record's step then starts at the row reads),
 // and every pick goes back through SGPRs (uni) so that the record loop is uniform in the compiler's eyes, as in k_walk_tables.
-template <bool BF, bool BATCH>
+// BATCH == 2: also the row of curr and the membership row of prev per lane, and the sampled records collected per lane
+// (v_writelane) and stored once per grab, coalesced.
+template <bool BF, int BATCH>
 __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_sh_step_tab(ShTabArgs a0) {
   __shared__ __attribute__((aligned(16))) uint32_t stage_all[TPB / 64][1024];
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
@@ -1510,7 +1512,9 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
     // (BATCH) lane l: record r0 + l, its draw, the table word of its pair (b_eo: bit 0 of b_found = the pair has one)
     SWalker bw; bw.lw = 0; bw.src = 0; bw.prev = 0; bw.curr = 0;
     float bu = 0.0f; uint32_t b_eo = EB_NONE, b_found = 0u;
-    if constexpr (BATCH) {
+    Row b_r, b_mr; b_r.off = 0; b_r.deg = 0; b_r.flags = 0; b_mr = b_r;
+    int32_t b_next = 0, b_stat = 0;                   // (BATCH == 2) per lane: the sampled vertex, 1 = advance / 2 = dead / 0 = not this kernel's
+    if constexpr (BATCH != 0) {
       const ShTabArgs ab = SH_TAB_ARGS();
       const GraphView &g = ab.g;
       const uint32_t rl = r0 + (uint32_t)lane < r1 ? r0 + (uint32_t)lane : r1 - 1u;      // (grab_n <= 64: run_shard_superstep)
@@ -1520,14 +1524,16 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       const int64_t cslot = (int64_t)bw.curr - g.vmin, pslot = (int64_t)bw.prev - g.vmin;
       if (second && cslot >= 0 && cslot < g.n_slots && pslot >= 0 && pslot < g.n_slots) {
         uint32_t pad;
+        if constexpr (BATCH == 2) b_mr = g.mrows[pslot];
         b_found = pair_lookup_lane(g.ph, g.ph_buckets, (uint32_t)pslot, (uint32_t)cslot, b_eo, pad) ? 1u : 0u;
       }
+      if constexpr (BATCH == 2) { if (cslot >= 0 && cslot < g.n_slots) b_r = g.rows[cslot]; }
     }
     for (uint32_t ri = r0; ri < r1; ++ri) {
       const ShTabArgs ar = SH_TAB_ARGS();             // (what the top of a record needs; the samplers read the graph again where they start)
       const GraphView &g = ar.g;
       SWalker wk;
-      if constexpr (BATCH) {
+      if constexpr (BATCH != 0) {
         const int j = (int)(ri - r0);
         wk.lw = __builtin_amdgcn_readlane(bw.lw, j); wk.src = __builtin_amdgcn_readlane(bw.src, j);
         wk.prev = __builtin_amdgcn_readlane(bw.prev, j); wk.curr = __builtin_amdgcn_readlane(bw.curr, j);
@@ -1539,26 +1545,34 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       }
       const int64_t cslot = (int64_t)wk.curr - g.vmin, pslot = (int64_t)wk.prev - g.vmin;
       const bool in_range = cslot >= 0 && cslot < g.n_slots;
-      Row r = g.rows[in_range ? cslot : 0];
-      Row mr; mr.off = 0; mr.deg = 0; mr.flags = 0;
+      Row r, mr;
       uint32_t eo = EB_NONE; bool found = false;
-      if (second && in_range && pslot >= 0 && pslot < g.n_slots) {
-        mr = g.mrows[pslot];
-        if constexpr (BATCH) {
-          const int j = (int)(ri - r0);
-          eo = (uint32_t)__builtin_amdgcn_readlane((int)b_eo, j); found = __builtin_amdgcn_readlane((int)b_found, j) != 0;
-        } else found = pair_lookup_wave(g.ph, g.ph_buckets, (uint32_t)pslot, (uint32_t)cslot, eo);
-        mr = uniform_row(mr);
+      if constexpr (BATCH == 2) {                        // (zero rows where a slot is out of range: the prologue left them so)
+        const int j = (int)(ri - r0);
+        r = lane_row(b_r, j); mr = lane_row(b_mr, j);
+        eo = (uint32_t)__builtin_amdgcn_readlane((int)b_eo, j); found = __builtin_amdgcn_readlane((int)b_found, j) != 0;
+      } else {
+        r = g.rows[in_range ? cslot : 0];
+        mr.off = 0; mr.deg = 0; mr.flags = 0;
+        if (second && in_range && pslot >= 0 && pslot < g.n_slots) {
+          mr = g.mrows[pslot];
+          if constexpr (BATCH != 0) {
+            const int j = (int)(ri - r0);
+            eo = (uint32_t)__builtin_amdgcn_readlane((int)b_eo, j); found = __builtin_amdgcn_readlane((int)b_found, j) != 0;
+          } else found = pair_lookup_wave(g.ph, g.ph_buckets, (uint32_t)pslot, (uint32_t)cslot, eo);
+          mr = uniform_row(mr);
+        }
+        r = uniform_row(r);
+        if (!in_range) { r.off = 0; r.deg = 0; r.flags = 0; }
       }
-      r = uniform_row(r);
-      if (!in_range) { r.off = 0; r.deg = 0; r.flags = 0; }
       if (r.deg == 0) {                                  // dead end (or a source without neighbors): tell the home rank the length
-        if (lane == 0) ar.scratch[ri] = shard_dead(wk);
+        if constexpr (BATCH == 2) write_lane(b_stat, 2, (int)(ri - r0));
+        else if (lane == 0) ar.scratch[ri] = shard_dead(wk);
         dead += second ? 1u : 0u;
         continue;
       }
       float u;
-      if constexpr (BATCH) u = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(bu), (int)(ri - r0)));
+      if constexpr (BATCH != 0) u = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(bu), (int)(ri - r0)));
       else {
         const uint32_t iter = (uint32_t)(ar.first_walk + wk.lw % ar.io.batch);
         u = draw_uniform(ar.rng, iter, (uint32_t)__builtin_amdgcn_readfirstlane(rng_source(g, wk.src)), (uint32_t)step);
@@ -1572,7 +1586,7 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       bool to_chain = false; double S_tie = 0.0;
       if (!second) {
         k = wave_pick_first<false>(GFRESH(), r, u, f, next);
-        if constexpr (BATCH) k = uni(k);
+        if constexpr (BATCH != 0) k = uni(k);
         n_first += k >= 0 ? 1u : 0u;
       } else {
         Bias b;
@@ -1580,11 +1594,11 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
         b.prev_sids = g.msids + mr.off; b.prev_deg = mr.deg; b.prev_hub = mr.flags >> ROW_HUB_SHIFT;
         if (r.deg <= g.eb_mask_max && found) {
           k = wave_pick_masked<false>(GFRESH(), r, b, eo, r.deg > 32 ? g.em_bits + (size_t)eo * 4 : nullptr, u, f, next);
-          if constexpr (BATCH) k = uni(k);
+          if constexpr (BATCH != 0) k = uni(k);
           if (k >= 0) { n_mask += 1; srch += 8ull * (unsigned long long)r.deg + 4ull * (unsigned long long)((r.deg + 31) >> 5); }
         } else if (r.deg > g.eb_mask_max && found && (r.flags & ROW_PQ_OK)) {
           k = wave_pick_edge_table<BF, false>(GFRESH(), r, b, g.eb_bins + (size_t)eo * 8, u, f, sv, mem, next, stage, &S_tie);
-          if constexpr (BATCH) k = uni(k);
+          if constexpr (BATCH != 0) k = uni(k);
           if (k >= 0) { n_tab += 1; srch += 8ull * EB_BINS; fast += sv; }
           to_chain = k == CHAIN_NEEDED;
         } else k = -1;
@@ -1602,7 +1616,14 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
       }
       next = __builtin_amdgcn_readfirstlane(next);
       fb += f; steps += 1;
-      if (lane == 0) { const ShTabArgs ao = SH_TAB_ARGS(); ao.scratch[ri] = shard_advance(wk, step, next, ao.last != 0); }
+      if constexpr (BATCH == 2) {
+        write_lane(b_next, next, (int)(ri - r0)); write_lane(b_stat, 1, (int)(ri - r0));
+      } else if (lane == 0) { const ShTabArgs ao = SH_TAB_ARGS(); ao.scratch[ri] = shard_advance(wk, step, next, ao.last != 0); }
+    }
+    if constexpr (BATCH == 2) {                          // the grab's sampled records, one per lane
+      const ShTabArgs ao = SH_TAB_ARGS();
+      if (r0 + (uint32_t)lane < r1 && b_stat != 0)
+        ao.scratch[r0 + (uint32_t)lane] = b_stat == 1 ? shard_advance(bw, step, b_next, ao.last != 0) : shard_dead(bw);
     }
   }
   if (lane == 0) {
@@ -2913,20 +2934,25 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     const ChainBufs cb = chain_bufs(h);
     ChainRec *chain_list = cb.list;
     const GraphView gv = g.view();
-    static const int grab_n = std::min(64, getenv("SRW_SH_GRAB") ? std::max(1, atoi(getenv("SRW_SH_GRAB"))) : SH_GRAB);   // (<= 64: one record per lane in the BATCH prologue)
-    static const bool sh_batch = !(getenv("SRW_SH_BATCH") && atoi(getenv("SRW_SH_BATCH")) == 0);
+    const char *sge = getenv("SRW_SH_GRAB");
+    const int grab_n = std::min(64, sge && *sge ? std::max(1, atoi(sge)) : SH_GRAB);   // (<= 64: one record per lane in the BATCH prologue)
+    const char *sbe = getenv("SRW_SH_BATCH");             // (read per super-step: tools/shard_tables_bench.py alternates the variants on one set of tables)
+    const int sh_batch = sbe && *sbe ? atoi(sbe) : 2;
     static const int tb_mult = getenv("SRW_SH_BLOCKS") ? std::max(1, atoi(getenv("SRW_SH_BLOCKS"))) : 8;
     const int tb = h->n_cus * tb_mult;
     timed(1, [&] {
       ShTabArgs ta;
       ta.g = gv; ta.io = io; ta.first_walk = P.first_walk; ta.step = step; ta.last = last; ta.rng = rng; ta.p = P.p; ta.q = P.q; ta.scratch = scratch;
       ta.cursor = h->walk_cursor.p; ta.todo = (uint32_t *)h->walk_todo.p; ta.ctr = h->counters.p; ta.grab_n = grab_n; ta.chain = chain_list;
-      if (sh_batch) {
-        if (gv.bf_off) hipLaunchKernelGGL((k_sh_step_tab<true, true>), dim3(tb), dim3(TPB), 0, st, ta);
-        else hipLaunchKernelGGL((k_sh_step_tab<false, true>), dim3(tb), dim3(TPB), 0, st, ta);
+      if (sh_batch == 2) {
+        if (gv.bf_off) hipLaunchKernelGGL((k_sh_step_tab<true, 2>), dim3(tb), dim3(TPB), 0, st, ta);
+        else hipLaunchKernelGGL((k_sh_step_tab<false, 2>), dim3(tb), dim3(TPB), 0, st, ta);
+      } else if (sh_batch == 1) {
+        if (gv.bf_off) hipLaunchKernelGGL((k_sh_step_tab<true, 1>), dim3(tb), dim3(TPB), 0, st, ta);
+        else hipLaunchKernelGGL((k_sh_step_tab<false, 1>), dim3(tb), dim3(TPB), 0, st, ta);
       } else {
-        if (gv.bf_off) hipLaunchKernelGGL((k_sh_step_tab<true, false>), dim3(tb), dim3(TPB), 0, st, ta);
-        else hipLaunchKernelGGL((k_sh_step_tab<false, false>), dim3(tb), dim3(TPB), 0, st, ta);
+        if (gv.bf_off) hipLaunchKernelGGL((k_sh_step_tab<true, 0>), dim3(tb), dim3(TPB), 0, st, ta);
+        else hipLaunchKernelGGL((k_sh_step_tab<false, 0>), dim3(tb), dim3(TPB), 0, st, ta);
       }
     });
     // draws on a CDF boundary of a table step

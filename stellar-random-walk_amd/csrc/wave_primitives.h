@@ -38,6 +38,10 @@ template <typename T> __device__ inline const T *uni(const T *p) { return reinte
 // the value's uniformity from the compiler, what is computed from it runs as vector instructions, uni() brings the results back.
 __device__ inline int32_t on_vector(int32_t v) { int32_t r; asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; }
 
+// v's lane j (wave-uniform) = val (wave-uniform).  (v_writelane takes one SGPR operand on gfx9: the lane index would go through m0,
+// which inline asm may not clobber — a compare and a select are two vector instructions.)
+__device__ inline void write_lane(int32_t &v, int32_t val, int j) { v = (int)(threadIdx.x & 63u) == j ? val : v; }
+
 // (the results are the wave's: handed back through SGPRs — uni — so that the compiler sees the branches they decide as uniform)
 __device__ inline double wave_sum_f64(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

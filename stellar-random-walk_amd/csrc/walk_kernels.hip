@@ -1472,7 +1472,11 @@ __global__ __launch_bounds__(TPB) void k_sh_bucket(GraphView g, ShardIO io, int3
 // hash probe that yields the table word eb_off[e] would hold on a whole-graph handle.  Steps without a table (uncertified
 // rows, test configurations) go to the todo list: k_sh_step redoes exactly those with the on-the-fly samplers.  The sampled
 // records land in `scratch` in input order; k_sh_scatter buckets them.
-constexpr int SH_GRAB = 16;         // records per cursor grab (a single counter word saturates at ~88 atomics/us)
+// records per cursor grab (a single counter word saturates at ~88 atomics/us).  With the BATCH prologue of k_sh_step_tab a grab is also
+// what one Philox evaluation / one round of record, row and pair-hash reads serves: 8 -> 1 221 ms, 16 -> 676, 32 -> 608, 64 -> 606 ms per
+// iteration at config 3's shape, 3 809 / 3 756 / 3 741 ms at config 5's (profiles/r04_sharded_batch.md); the kernel takes fewer per grab
+// when a super-step has fewer than 4 grabs per wave (small shards: the waves would not share the work evenly).
+constexpr int SH_GRAB = 32;
 struct alignas(16) ChainMeta { long long d_off; int32_t deg; uint32_t u_off; };   // first quotient in the scratch array, row length, first work unit
 struct ChainUnits { double *usum; int32_t *ue; unsigned long long *utot; };       // per unit of 256 quotients: plain sum, guessed binade, integer increment
 // (arguments as one struct, read again from the kernarg segment where a record needs them: k_walk_tables, device_common.h:fresh_args)
@@ -1499,7 +1503,9 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
   uint32_t *stage = stage_all[threadIdx.x >> 6];
   const uint32_t n_in = shard_in_prefix(a0.io, pre);
   Member mem; mem.mode = 0; mem.bm = stage; mem.seg_base = 0;
-  const int32_t step = a0.step, grab_n = a0.grab_n;
+  const int32_t step = a0.step;
+  const uint32_t n_waves4 = gridDim.x * (uint32_t)(TPB / 64) * 4u;
+  const int32_t grab_n = (int32_t)uni(n_in / n_waves4 >= (uint32_t)a0.grab_n ? (uint32_t)a0.grab_n : (n_in / n_waves4 ? n_in / n_waves4 : 1u));
   const bool second = step > 1;
   unsigned long long srch = 0;
   uint32_t steps = 0, fb = 0, dead = 0, fast = 0, n_tab = 0, n_mask = 0, n_first = 0, n_todo = 0;

@@ -25,7 +25,7 @@ for w in worlds:
         for v in [x for x in os.environ.get("SRW_AB", "").split(",") if x]:      # A / B of the table step's variants on one set of tables
             os.environ["SRW_SH_BATCH"], os.environ["SRW_SH_GRAB"] = (v.split("/") + ["16"])[:2]      # "variant" or "variant/records per grab"
             st = cl.walk(fetch=False, p=p, q=q, walk_length=L, num_walks=1, seed=2, batch=1)
-            print("world %d SRW_SH_BATCH=%s: %.3e steps/s (%.1f ms per iteration)" % (w, v, st["n_steps"] / st["kernel_ms"] * 1e3, st["kernel_ms"]), flush=True)
+            print("world %d SRW_SH_BATCH=%s: %.3e steps/s (%.1f ms per iteration) steps %d" % (w, v, st["n_steps"] / st["kernel_ms"] * 1e3, st["kernel_ms"], st["n_steps"]), flush=True)
         if os.environ.get("SRW_AB"):
             continue
         for B in (1, 2):

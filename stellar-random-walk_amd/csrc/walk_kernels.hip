@@ -1652,8 +1652,11 @@ __global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void 
 // return-edge record from the shard's hash (edge_tables.hip:build_shard_rev_hash) + q1_pick over the local compact records and
 // exact prefix sums.  An irregular row or a draw within rounding distance of a CDF boundary puts the record on the todo list
 // (k_sh_step redoes exactly those); k_sh_scatter buckets the scratch records.
+#ifndef SRW_SHQ1_WAVES
+#define SRW_SHQ1_WAVES 1          // (minimum waves per SIMD asked of the compiler: 1 = whatever the kernel needs — 86 VGPRs, 5 waves)
+#endif
 template <bool NT>
-__global__ __launch_bounds__(TPB) void k_sh_step_q1(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last, RngSpec rng, float p,
+__global__ __launch_bounds__(TPB, SRW_SHQ1_WAVES) void k_sh_step_q1(GraphView g, ShardIO io, int32_t first_walk, int32_t step, int32_t last, RngSpec rng, float p,
                                                     SWalker *__restrict__ scratch, unsigned long long *cursor, uint32_t *__restrict__ todo,
                                                     ChainRec *__restrict__ chain, DevCounters *ctr, uint32_t max_ret, uint32_t *__restrict__ many) {
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];

@@ -315,7 +315,7 @@ def exchange_model(world, steps_per_s=None):
     return m
 
 
-def run_sharded_biased_world1(pkg, device, name, scale, ef, weighted, directed, p, q, replicated_value, K=1, L=80):
+def run_sharded_biased_world1(pkg, device, name, scale, ef, weighted, directed, p, q, replicated_value, K=1, L=80, batch2=False):
     """A biased configuration through the vertex-sharded protocol at world = 1.  q != 1: the shard holds the per-edge tables
     of the pairs into its own rows behind the pair hash (edge_tables.hip:prepare_shard_tables), walkers arrive as 16-byte
     records, every super-step is the lean table step + the chain kernels + one fused bucketing pass.  q == 1 (p != 1): one record
@@ -336,6 +336,13 @@ def run_sharded_biased_world1(pkg, device, name, scale, ef, weighted, directed, 
         t_tables = time.perf_counter() - t0
         st = cl.walk(fetch=False, num_walks=K, first_walk=1, batch=K, **kw)
         val = st["n_steps"] / (st["kernel_ms"] * 1e-3)
+        two = None
+        if batch2:            # a numWalks >= 2 job walks several iterations per population: the per-super-step launches are shared
+            try:
+                st2 = cl.walk(fetch=False, num_walks=2, first_walk=1 + K, batch=2, **kw)
+                two = {"value": st2["n_steps"] / (st2["kernel_ms"] * 1e-3), "ms_per_iteration": st2["kernel_ms"] / 2.0}
+            except Exception as ex:
+                two = {"error": str(ex)[:200]}
     out = {"name": name,
            "workload": "RMAT scale-%d ef%d %s %s p=%g q=%g walkLength=%d, Mode R; %d walk iteration(s) as one population through "
                        "srw_cluster_walk at world 1" % (scale, ef, "directed" if directed else "undirected",
@@ -348,6 +355,10 @@ def run_sharded_biased_world1(pkg, device, name, scale, ef, weighted, directed, 
     if replicated_value:
         out["replicated_kernel_same_graph"] = replicated_value
         out["fraction_of_replicated"] = val / replicated_value
+    if two:
+        if replicated_value and "value" in two:
+            two["fraction_of_replicated"] = two["value"] / replicated_value
+        out["two_iterations_per_population"] = two
     return out
 
 
@@ -662,7 +673,7 @@ def main():
                          0.25, 1.0, "C3's graph with q = 1 (return-edge bias only), Mode R"),
                         ("C5 shape, vertex-sharded, world 1 (per-edge tables on the shard)", 26, 27, False, True, 4.0, 0.5, "C5 stand-in Mode R")]:
                     try:
-                        cfgs.append(run_sharded_biased_world1(pkg, local_rank, name, sc, ef, wt, dr, p, q, rep.get(of)))
+                        cfgs.append(run_sharded_biased_world1(pkg, local_rank, name, sc, ef, wt, dr, p, q, rep.get(of), batch2=(sc <= 24)))
                     except Exception as ex:
                         cfgs.append({"name": name, "error": str(ex)[:300]})
             out["configs"] = cfgs

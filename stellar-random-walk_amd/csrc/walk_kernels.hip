@@ -2947,7 +2947,8 @@ void run_shard_superstep(srw_handle *h, const srw_walk_params &P, int32_t batch,
     const int grab_n = std::min(64, sge && *sge ? std::max(1, atoi(sge)) : SH_GRAB);   // (<= 64: one record per lane in the BATCH prologue)
     const char *sbe = getenv("SRW_SH_BATCH");             // (read per super-step: tools/shard_tables_bench.py alternates the variants on one set of tables)
     const int sh_batch = sbe && *sbe ? atoi(sbe) : 2;
-    static const int tb_mult = getenv("SRW_SH_BLOCKS") ? std::max(1, atoi(getenv("SRW_SH_BLOCKS"))) : 8;
+    const char *sbl = getenv("SRW_SH_BLOCKS");            // (per super-step, like the two below: tests alternate the variants on one handle)
+    const int tb_mult = sbl && *sbl ? std::max(1, atoi(sbl)) : 8;
     const int tb = h->n_cus * tb_mult;
     timed(1, [&] {
       ShTabArgs ta;

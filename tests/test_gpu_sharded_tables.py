@@ -82,6 +82,37 @@ def test_shard_tables_at_scale_equal_replicated(world, scale, ef, weighted, dire
         assert ss["edge_table"] + ss["edge_mask"] + ss["scan"] >= 0.999 * cst["n_steps"], cst     # (scan: the first steps)
 
 
+@pytest.mark.parametrize("world,scale,ef,weighted,directed,p,q", [(1, 15, 16, True, False, 0.25, 4.0), (2, 15, 27, False, True, 4.0, 0.5)])
+def test_table_step_variants_give_the_same_paths(monkeypatch, world, scale, ef, weighted, directed, p, q):
+    """k_sh_step_tab serves a grab of records at once (lane l: record r0 + l, its Philox draw, its pair-hash probe, its rows; the
+    sampled records stored once per grab).  The variants behind SRW_SH_BATCH (0: one record at a time, 1, 2 = default) and every grab
+    size — the kernel takes fewer records per grab when a super-step has under 4 grabs per wave, so a small grid (SRW_SH_BLOCKS=1)
+    makes grabs of up to 64 real at this size — give the paths of the replicated kernel, ties through the chain kernels included."""
+    P = pkg()
+    kw = dict(p=p, q=q, walk_length=10, num_walks=4, seed=11)
+    with P.Engine(device=0) as eng:
+        eng.generate_rmat(scale, ef << scale, seed=3, weighted=weighted, directed=directed)
+        paths, lens, st = eng.walk(**kw)
+        cpaths, clens, cst = eng.walk(rng="const", const_r=0.5, **dict(kw, num_walks=1))
+    with P.Cluster([0] * world) as cl:
+        cl.generate_rmat(scale, ef << scale, seed=3, weighted=weighted, directed=directed)
+        for blocks, batch, grab in [("", "", ""), ("1", "0", "16"), ("1", "1", "16"), ("1", "2", "5"), ("1", "2", "32"), ("1", "2", "64"), ("2", "2", "33")]:
+            for k, v in (("SRW_SH_BLOCKS", blocks), ("SRW_SH_BATCH", batch), ("SRW_SH_GRAB", grab)):
+                if v:
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            sp, sl, sst = cl.walk(batch=4, **kw)               # one population of 4 iterations: 4 x 2^15 records per super-step
+            assert np.array_equal(sl, lens), (blocks, batch, grab)
+            bad = np.nonzero((sp != paths).any(axis=1))[0]
+            assert bad.size == 0, (blocks, batch, grab, bad[:5], sp[bad[0]], paths[bad[0]])
+            assert sst["n_steps"] == st["n_steps"]
+            ss = sst["strategy_steps"]
+            assert ss["edge_table"] > 0 and ss["edge_mask"] > 0, sst
+            sp, sl, sst = cl.walk(rng="const", const_r=0.5, **dict(kw, num_walks=1))      # CDF boundaries: ties
+            assert np.array_equal(sl, clens) and np.array_equal(sp, cpaths), (blocks, batch, grab)
+
+
 @pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.5, 2.0)])
 def test_all_vertices_in_one_partition(oracle, tmp_path, p, q):
     """SRW_CFG_OWNER_FROM_PARTITIONS with fewer partitions than shards: one shard owns every vertex, its seeds exceed a chunk

@@ -1495,8 +1495,14 @@ struct ShTabArgs {
 // and every pick goes back through SGPRs (uni) so that the record loop is uniform in the compiler's eyes, as in k_walk_tables.
 // BATCH == 2: also the row of curr and the membership row of prev per lane, and the sampled records collected per lane
 // (v_writelane) and stored once per grab, coalesced.
+#ifndef SRW_SH_LEAN_WAVES                 // (waves per SIMD of the sharded table step: the grab's per-lane state costs 36 B of scratch at 8)
+#define SRW_SH_LEAN_WAVES SRW_LEAN_WAVES
+#endif
+#ifndef SRW_SH_LEAN_WAVES_BF
+#define SRW_SH_LEAN_WAVES_BF SRW_LEAN_WAVES_BF
+#endif
 template <bool BF, int BATCH>
-__global__ __launch_bounds__(TPB, BF ? SRW_LEAN_WAVES_BF : SRW_LEAN_WAVES) void k_sh_step_tab(ShTabArgs a0) {
+__global__ __launch_bounds__(TPB, BF ? SRW_SH_LEAN_WAVES_BF : SRW_SH_LEAN_WAVES) void k_sh_step_tab(ShTabArgs a0) {
   __shared__ __attribute__((aligned(16))) uint32_t stage_all[TPB / 64][1024];
   __shared__ uint32_t pre[SHARD_MAX_WORLD + 1];
   const int lane = lane_id();

@@ -111,7 +111,7 @@ def cpu_baseline(args):
             "plan": plan}
 
 
-def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None, ceiling=None, scan=None, q=1.0):
+def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None, ceiling=None, scan=None, q=1.0, wl=None):
     """Algorithmic bytes per launch / average kernel time of the dominant kernel."""
     kind = stats["kernel_kind"]
     if kind == 1:
@@ -147,8 +147,11 @@ def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None, cei
         try:
             js = json.load(open(pmc))
             for j in (js if isinstance(js, list) else [js]):
-                if j.get("kernel") == name and j.get("scale") == scale:
+                # an entry stands for ONE workload: kernel, scale and (ef, p, q, weighted, directed) must all agree
+                if j.get("kernel") == name and j.get("scale") == scale and all(
+                        float(j.get(k, v)) == float(v) for k, v in (wl or {}).items()):
                     r["traffic"] = j.get("hbm_bytes_per_launch")
+                    r["traffic_commit"] = j.get("commit", "?")
                     r["traffic_source"] = ("profiles/pmc_latest.json <- %s (commit %s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ "
                                            "passes over the same command; the PMC counters cannot be read from inside bench.py" % (j.get("source", "profiles/"), j.get("commit", "?")))
                     if j.get("requests_per_launch"):
@@ -244,8 +247,8 @@ def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, 
                "steps": K, "warmup": W, "ms_per_step": dt / max(K, 1) * 1e3, "kernel_ms": avg_ms,
                "walk_steps_per_bench_step": int(steps / max(K, 1)),
                "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables},
-               "roofline": roofline_of(st, steps / max(K, 1), avg_ms, scale=scale,      # (profiles/pmc_latest.json is keyed by kernel and scale: the plan below has one configuration per key)
-                                       n_entries=ne, ceiling=ceiling, scan=scan, q=q)}
+               "roofline": roofline_of(st, steps / max(K, 1), avg_ms, scale=scale, n_entries=ne, ceiling=ceiling, scan=scan, q=q,
+                                       wl=dict(ef=ef, p=p, q=q, weighted=int(weighted), directed=int(directed)))}
         if st["kernel_kind"] == 2:
             out["strategy_steps"] = {k: v for k, v in st["strategy_steps"].items() if v}
             out["edge_tables"] = {"count": st["edge_tables"], "bytes": st["edge_table_bytes"]}
@@ -283,7 +286,7 @@ def run_sharded_world1(pkg, device, scale=24, K=4, L=80):
         cl.walk(fetch=False, num_walks=K, first_walk=1, batch=K, **kw)
         st = cl.walk(fetch=False, num_walks=K, first_walk=1 + K, batch=K, **kw)
         val = st["n_steps"] / (st["kernel_ms"] * 1e-3)
-    return {"name": "vertex-sharded protocol at world 1 (north_star's split on one GPU)",
+    return {"name": "sharded w1 p=q=1",
             "workload": "RMAT scale-%d ef16 undirected unweighted p=1 q=1 walkLength=%d, Mode R; %d walk iterations as one walker "
                         "population (srw_cluster_walk: %d super-steps, 2 kernels each)" % (scale, L, K, L + 1),
             "vertices": nv, "adjacency_entries": ne, "value": val, "unit": "walk-steps/s", "steps": K, "warmup": K,
@@ -396,8 +399,96 @@ def cluster_leg(pkg, torch, args, world, K):
         return {"error": str(ex)[:300]}
 
 
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg", "algorithmic_bytes_per_launch",
+                 "record_bytes", "physical_traffic_frac", "requests_per_step", "requests_per_s", "request_rate_ceiling",
+                 "request_rate_frac", "scan_equivalent_frac", "traffic_commit")
+SUMMARY_KEYS = ("name", "value", "ms_per_step", "kernel_ms", "job_numWalks10_steps_per_s", "fraction_of_replicated", "error")
+LINE_LIMIT = 4096               # the driver reads the LAST stdout line; round 4's 24 KB line was not parsed
+
+
+def _round(x, digits=6):
+    """Numbers of the compact line at 6 significant digits (the detail file keeps them whole)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _round(v, digits) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_round(v, digits) for v in x]
+    return x
+
+
+def compact_line(out):
+    """The ONE stdout line: the driver's keys, `config`, `roofline` (numbers only), `cpu_baseline` without its plan, a
+    `configs_summary` of the other configurations.  Everything else lives in the detail file."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data", "config") if k in out}
+    if "roofline" in out:
+        c["roofline"] = {k: out["roofline"][k] for k in ROOFLINE_KEYS if k in out["roofline"]}
+    if "setup_s" in out:
+        c["setup_s"] = {k: v for k, v in out["setup_s"].items() if not isinstance(v, str)}
+    if "end_to_end" in out:
+        c["end_to_end"] = {k: v for k, v in out["end_to_end"].items() if k in ("seconds", "walk_steps_per_s", "text_GB_per_s", "skipped", "error")}
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        c["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "value_fast_variant", "walk_steps", "seconds") if k in cb}
+    if "configs" in out:
+        rows = []
+        for cf in out["configs"]:
+            row = {k: cf[k] for k in SUMMARY_KEYS if k in cf}
+            rf = cf.get("roofline") or {}
+            for k in ("frac", "requests_per_step", "request_rate_frac"):
+                if k in rf:
+                    row[k] = rf[k]
+            if "setup_s" in cf:
+                row["setup_s"] = sum(v for v in cf["setup_s"].values() if isinstance(v, (int, float)))
+            rows.append(row)
+        c["configs_summary"] = rows
+    if "vertex_sharded" in out:
+        vs = {}
+        for leg, v in out["vertex_sharded"].items():
+            vs[leg] = {k: v[k] for k in ("value", "ms_per_step", "scaling", "steps", "leg_wall_s", "error") if k in v}
+            m = v.get("exchange_model") or {}
+            if "measured_fraction_of_exchange_ceiling" in m:
+                vs[leg]["fraction_of_exchange_ceiling"] = m["measured_fraction_of_exchange_ceiling"]
+        c["vertex_sharded"] = vs
+    if "detail_file" in out:
+        c["detail_file"] = out["detail_file"]
+    c = _round(c)
+    line = json.dumps(c, separators=(",", ":"))
+    # never hand the driver a line it cannot read: shed the optional objects, largest first
+    for k in ("configs_summary", "vertex_sharded", "end_to_end", "setup_s"):
+        if len(line) <= LINE_LIMIT:
+            break
+        if k == "configs_summary" and k in c:
+            for row in c[k]:
+                row["name"] = row["name"][:24]
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+        c.pop(k, None)
+        line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+def emit(out, args):
+    """Full detail -> bench_detail.json (next to gpurun_out/ when that exists, else the working directory) and stderr;
+    the compact object -> the last (and only) stdout line."""
+    full = json.dumps(out)
+    path = args.detail or os.path.join("gpurun_out" if os.path.isdir("gpurun_out") else ".", "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            f.write(full + "\n")
+        out["detail_file"] = path
+    except OSError as ex:
+        out["detail_file"] = "not written: %s" % ex
+    sys.stderr.write("BENCH_DETAIL " + full + "\n")
+    sys.stderr.flush()
+    print(compact_line(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--detail", default="", help="where the full (uncompacted) result goes; default gpurun_out/bench_detail.json or ./bench_detail.json")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -420,6 +511,7 @@ def main():
     ap.add_argument("--nt-loads", type=int, default=-1, help="-1 auto, 0 cached, 1 nontemporal record loads")
     ap.add_argument("--compact", type=int, default=1, help="0: do not use the 16-byte lattice records")
     ap.add_argument("--configs", type=int, default=1, help="1 GPU: also run BASELINE configs C2, C3 (Mode R / A), C5 stand-in")
+    ap.add_argument("--configs-scale-cap", type=int, default=0, help="tests: run the `configs` plan with every scale capped at this value")
     ap.add_argument("--end-to-end", type=int, default=1, help="1 GPU: also time one iteration through srw_walk_and_save")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-scale", type=int, default=20)
@@ -554,7 +646,7 @@ def main():
                 "metric": "walk-steps/sec", "value": total_steps / max_dt, "unit": "walk-steps/s", "n_gpus": world,
                 "steps": K, "warmup": W, "ms_per_step": max_dt / max(K, 1) * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None,
-                "dtype": "f64 CDF tables (u32 lattice compares in the walk), int32 ids", "data": "synthetic",
+                "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "RMAT scale-%d ef%d (%d edge lines, %d adjacency entries, %d vertices) %s "
                                        "%s p=%g q=%g walkLength=%d, 1 walk iteration per step, %s"
                                        % (args.scale, args.edge_factor, n_edges, ne, nv,
@@ -564,7 +656,8 @@ def main():
                            "walk_steps_per_bench_step": int(steps / max(K, 1)),
                            "parallelism": ("graph replicated, walk iterations sharded x%d, no collective" % world) if world > 1 else "1 GPU",
                            "rng": "Philox4x32-10 keyed (iteration, source, step)"},
-                "roofline": roofline_of(stats, steps / max(K, 1), avg_ms, scale=args.scale, n_entries=ne, ceiling=ceiling, scan=scan, q=args.q),
+                "roofline": roofline_of(stats, steps / max(K, 1), avg_ms, scale=args.scale, n_entries=ne, ceiling=ceiling, scan=scan, q=args.q,
+                                        wl=dict(ef=args.edge_factor, p=args.p, q=args.q, weighted=int(args.weighted), directed=int(args.directed))),
                 "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables,
                             "note": "outside the timed region; one-off per graph / per (p, q)"},
             }
@@ -643,7 +736,7 @@ def main():
             if out is None:
                 out = {"metric": "walk-steps/sec", "value": first.get("value"), "unit": "walk-steps/s", "n_gpus": world, "steps": K,
                        "warmup": W, "ms_per_step": first.get("ms_per_step"), "higher_is_better": True, "scaling": "strong",
-                       "vs_baseline": None, "dtype": "f64 CDF tables, int32 ids", "data": "synthetic",
+                       "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                        "config": {"workload": first.get("workload"), "parallelism": first.get("parallelism")}}
             out["vertex_sharded"] = vs
 
@@ -653,25 +746,27 @@ def main():
             plan = [("C2", 20, 16, False, False, 1.0, 1.0, "reference", 10, 1),
                     ("C3 Mode R", 24, 16, True, False, 0.25, 4.0, "reference", 2, 1),
                     ("C3 Mode A", 24, 16, True, False, 0.25, 4.0, "alias", 3, 1),
-                    ("C3's graph with q = 1 (return-edge bias only), Mode R", 24, 16, True, False, 0.25, 1.0, "reference", 3, 1),
+                    ("C3 graph q=1 Mode R", 24, 16, True, False, 0.25, 1.0, "reference", 3, 1),
                     ("C5 stand-in Mode R", 26, 27, False, True, 4.0, 0.5, "reference", 1, 1),
                     ("C5 stand-in Mode A", 26, 27, False, True, 4.0, 0.5, "alias", 2, 1)]
+            cap = args.configs_scale_cap or 99
             for (name, sc, ef, wt, dr, p, q, smp, k, w) in plan:
+                sc = min(sc, cap)
                 try:
                     cfgs.append(run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w, ceiling=ceiling))
                 except Exception as ex:
                     cfgs.append({"name": name, "error": str(ex)[:300]})
             if args.shard in ("both", "vertex"):
                 try:
-                    cfgs.append(run_sharded_world1(pkg, local_rank))
+                    cfgs.append(run_sharded_world1(pkg, local_rank, scale=min(24, cap)))
                 except Exception as ex:
-                    cfgs.append({"name": "vertex-sharded protocol at world 1", "error": str(ex)[:300]})
+                    cfgs.append({"name": "sharded w1 p=q=1", "error": str(ex)[:300]})
                 rep = {c.get("name"): c.get("value") for c in cfgs}
                 for (name, sc, ef, wt, dr, p, q, of) in [
-                        ("C3 shape, vertex-sharded, world 1 (per-edge tables on the shard)", 24, 16, True, False, 0.25, 4.0, "C3 Mode R"),
-                        ("C3's graph with q = 1, vertex-sharded, world 1 (one record per lane behind the return-edge hash)", 24, 16, True, False,
-                         0.25, 1.0, "C3's graph with q = 1 (return-edge bias only), Mode R"),
-                        ("C5 shape, vertex-sharded, world 1 (per-edge tables on the shard)", 26, 27, False, True, 4.0, 0.5, "C5 stand-in Mode R")]:
+                        ("sharded w1 C3", 24, 16, True, False, 0.25, 4.0, "C3 Mode R"),
+                        ("sharded w1 C3 graph q=1", 24, 16, True, False, 0.25, 1.0, "C3 graph q=1 Mode R"),
+                        ("sharded w1 C5 stand-in", 26, 27, False, True, 4.0, 0.5, "C5 stand-in Mode R")]:
+                    sc = min(sc, cap)
                     try:
                         cfgs.append(run_sharded_biased_world1(pkg, local_rank, name, sc, ef, wt, dr, p, q, rep.get(of), batch2=(sc <= 24)))
                     except Exception as ex:
@@ -679,7 +774,7 @@ def main():
             out["configs"] = cfgs
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

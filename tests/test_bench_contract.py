@@ -21,9 +21,10 @@ LINE_LIMIT = 4096        # round 4's 24 KB line was not parsed by the driver: th
 
 def last_json(out):
     lines = [l for l in out.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), out[-2000:]        # ONE stdout line, and it is the JSON object
-    assert len(lines[0]) <= LINE_LIMIT, len(lines[0])
-    return json.loads(lines[0])
+    # the LAST stdout line is the JSON object, and the only one (RCCL prints its version banner on stdout before it)
+    assert lines and lines[-1].startswith("{") and sum(l.startswith("{") for l in lines) == 1, out[-2000:]
+    assert len(lines[-1]) <= LINE_LIMIT, len(lines[-1])
+    return json.loads(lines[-1])
 
 
 def check_driver_keys(d):

@@ -88,6 +88,13 @@ const char *srw_last_error(const srw_handle *h);
 /* Launch all kernels on this hipStream_t (default: the handle's own stream). */
 int32_t srw_set_stream(srw_handle *h, void *hip_stream);
 
+/* The job's --numWalks (M/common/Params.scala:7-23, default 10): how many walk iterations will run over the sampling
+ * tables that the next srw_walk* call builds for its (p, q) — a caller that walks the job in several calls (one iteration
+ * per call, batches) announces the total here.  It only steers what is worth BUILDING (the finer per-edge tables of the
+ * biased walk cost ~8 s at config 3 and save ~0.1 s per iteration: they are built from 64 planned iterations on); results
+ * never depend on it.  0 = unknown: the reference's default (10), or the call's own num_walks if that is larger. */
+int32_t srw_plan_walks(srw_handle *h, int64_t num_walks);
+
 /* ---- graph load ---------------------------------------------------------------------------- */
 /* Replaces UniformRandomWalk.loadGraph (M/algorithm/UniformRandomWalk.scala:17-88) and, with
  * partitioned != 0, VCutRandomWalk.loadGraph (M/algorithm/VCutRandomWalk.scala:13-98): parses the

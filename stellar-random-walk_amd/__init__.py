@@ -85,7 +85,7 @@ STRATEGIES = ("edge_table", "p1", "p2", "w", "p3", "scan", "prefix", "chain", "e
 
 # every symbol include/stellar_rw.h declares
 EXPORTS = [
-    "srw_create", "srw_destroy", "srw_last_error", "srw_set_stream", "srw_load_edgelist", "srw_load_coo",
+    "srw_create", "srw_destroy", "srw_last_error", "srw_set_stream", "srw_plan_walks", "srw_load_edgelist", "srw_load_coo",
     "srw_load_adjacency", "srw_generate_rmat", "srw_graph_stats", "srw_graph_vertices", "srw_graph_neighbors",
     "srw_graph_partition", "srw_alias_row", "srw_walk", "srw_walk_to_host", "srw_walk_and_save", "srw_host_alloc", "srw_host_free", "srw_fetch_paths", "srw_device_paths", "srw_write_paths",
     "srw_shard_capacity", "srw_shard_vertex_ranks", "srw_shard_layout_for", "srw_shard_begin", "srw_shard_superstep",
@@ -117,6 +117,7 @@ def lib():
     L.srw_last_error.argtypes = [vp]
     L.srw_last_error.restype = C.c_char_p
     L.srw_set_stream.argtypes = [vp, vp]
+    L.srw_plan_walks.argtypes = [vp, C.c_int64]
     L.srw_load_edgelist.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.srw_load_coo.argtypes = [vp, i32p, i32p, f32p, i32p, C.c_int64, C.c_int32]
     L.srw_load_adjacency.argtypes = [vp, i32p, i64p, C.c_int64, i32p, f32p, i32p]
@@ -264,6 +265,11 @@ class Engine:
 
     def set_stream(self, stream_ptr):
         self._ck(lib().srw_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def plan_walks(self, num_walks):
+        """The job's --numWalks (total walk iterations over the tables the next walk builds): steers what is worth building."""
+        self._ck(lib().srw_plan_walks(self.h, int(num_walks)))
+        return self
 
     # ---- graph ----
     def load_edgelist(self, path, directed=False, weighted=True, partitioned=False, rdd_partitions=200):
@@ -518,6 +524,14 @@ class Cluster:
     def _ck(self, rc):
         if rc != OK:
             raise SrwError(rc, lib().srw_cluster_last_error(self.h).decode())
+
+    def plan_walks(self, num_walks):
+        """srw_plan_walks on every shard: the job's --numWalks."""
+        for r in range(self.world):
+            rc = lib().srw_plan_walks(C.c_void_p(lib().srw_cluster_shard(self.h, r)), int(num_walks))
+            if rc != OK:
+                raise SrwError(rc, "srw_plan_walks on shard %d" % r)
+        return self
 
     def load_edgelist(self, path, directed=False, weighted=True, partitioned=False, rdd_partitions=200):
         self._ck(lib().srw_cluster_load_edgelist(self.h, os.fsencode(path), int(directed), int(weighted), int(partitioned),

@@ -177,6 +177,14 @@ int32_t srw_set_stream(srw_handle *h, void *hip_stream) {
   });
 }
 
+int32_t srw_plan_walks(srw_handle *h, int64_t num_walks) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    if (num_walks < 0) throw srw::Error(SRW_ERR_INVALID, "srw_plan_walks: num_walks < 0");
+    h->planned_walks = num_walks;
+  });
+}
+
 int32_t srw_load_edgelist(srw_handle *h, const char *path, int32_t directed, int32_t weighted, int32_t partitioned,
                           int32_t rdd_partitions) {
   if (!h) return SRW_ERR_INVALID;

@@ -108,6 +108,20 @@ __device__ inline bool eb_pair(const GraphView &g, const Row &ru, int32_t k, con
   return ss.world == 1 || owner_of_tab((int32_t)((int64_t)xs + g.vmin), ss.world, g.owner_tab, g.vmin, g.n_slots) == ss.rank;
 }
 
+// The enumeration of the table passes (hist / rowsum / assign): position i of u's SORTED row.  A multi-edge (u -> x) x m — RMAT keeps
+// its duplicates, and between two hubs m runs into the hundreds — is m entries of u's row and ONE pair: its table depends on the
+// two rows only, so the first sorted occurrence (`rep`) gets the table and the work-list item, and the other m - 1 entries share
+// its word (k_eb_dups).  Cost-weighted, config 3 has ~1.3x more entries than pairs into table rows (profiles/r05_table_plan.md).
+//   k_item: what the work list records — the entry's input-order position (whole-graph handle) / the sorted position (shard).
+template <bool SH>
+__device__ inline bool eb_enum(const GraphView &g, const Row &ru, int32_t i, const ShardSel &ss, uint32_t &xs, int32_t &k_item, bool &rep) {
+  if (SH) { rep = true; k_item = i; return eb_pair<true>(g, ru, i, ss, xs); }
+  xs = g.sids[ru.off + i];
+  rep = !(i > 0 && g.sids[ru.off + i - 1] == xs);
+  k_item = (int32_t)g.sperm[ru.off + i];
+  return true;
+}
+
 // pass 1: table bytes per cost class (class = bit length of the cost), so that the host can fit a threshold to the budget
 // (hist[0][1]: pairs whose mask is inline — a shard's pair hash needs their count)
 template <bool SH>
@@ -123,8 +137,8 @@ __global__ __launch_bounds__(TPB) void k_eb_hist(GraphView g, ShardSel ss, EbSel
     for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < g.n_slots; ++u) {
       const Row ru = eb_urow<SH>(g, u);
       for (int32_t k = lane; k < ru.deg; k += 64) {
-        uint32_t xs;
-        if (!eb_pair<SH>(g, ru, k, ss, xs)) continue;
+        uint32_t xs; int32_t k_item; bool rep;
+        if (!eb_enum<SH>(g, ru, k, ss, xs, k_item, rep) || !rep) continue;
         const Row rv = g.rows[xs];
         int64_t cost; int kind;
         const uint32_t un = eb_units(ru, rv, sel, cost, kind);
@@ -158,8 +172,8 @@ __global__ __launch_bounds__(TPB) void k_eb_rowsum(GraphView g, ShardSel ss, EbS
       const Row ru = eb_urow<SH>(g, u);
       unsigned long long un = 0, mu = 0, np = 0;
       for (int32_t k = lane; k < ru.deg; k += 64) {
-        uint32_t xs;
-        if (!eb_pair<SH>(g, ru, k, ss, xs)) continue;
+        uint32_t xs; int32_t k_item; bool rep;
+        if (!eb_enum<SH>(g, ru, k, ss, xs, k_item, rep) || !rep) continue;
         const Row rv = g.rows[xs];
         int64_t cost; int kind;
         const uint32_t x = eb_units(ru, rv, sel, cost, kind);
@@ -189,33 +203,59 @@ __global__ __launch_bounds__(TPB) void k_eb_assign(GraphView g, ShardSel ss, EbS
       const Row ru = eb_urow<SH>(g, u);
       unsigned long long ubase = row_units[u], mbase = row_munits[u], pbase = row_pairs[u];
       for (int32_t base = 0; base < ru.deg; base += 64) {
-        const int32_t k = base + lane;
+        const int32_t k = base + lane;                 // position in u's SORTED row (eb_enum)
         uint32_t x = 0, xs = 0; int kind = 0;
+        int32_t k_item = 0; bool rep = false;
         bool mine = false;
-        if (k < ru.deg && eb_pair<SH>(g, ru, k, ss, xs)) {
+        if (k < ru.deg && eb_enum<SH>(g, ru, k, ss, xs, k_item, rep)) {
           mine = true;
           const Row rv = g.rows[xs];
           int64_t cost;
           x = eb_units(ru, rv, sel, cost, kind);
         }
-        uint32_t xb = kind == 1 ? x : 0u, xm = kind == 2 ? x : 0u, ib = xb, im = xm;
+        const bool tab = rep && (kind == 1 || kind == 2);          // a multi-edge's other entries take their word from k_eb_dups
+        uint32_t xb = (rep && kind == 1) ? x : 0u, xm = (rep && kind == 2) ? x : 0u, ib = xb, im = xm;
         for (int o = 1; o < 64; o <<= 1) {
           const uint32_t tb = (uint32_t)__shfl_up((int)ib, o), tm = (uint32_t)__shfl_up((int)im, o);
           if (lane >= o) { ib += tb; im += tm; }
         }
-        const bool listed = kind == 1 || kind == 2;
+        const bool listed = tab;
         const unsigned long long has = __ballot(listed);
-        const uint32_t word = kind == 1 ? (uint32_t)(ubase + ib - xb) : kind == 2 ? (uint32_t)(mbase + im - xm) : EB_NONE;
-        if (!SH) { if (k < ru.deg && kind != 3) eb_off[ru.off + k] = word; }
+        const uint32_t word = !tab ? EB_NONE : kind == 1 ? (uint32_t)(ubase + ib - xb) : (uint32_t)(mbase + im - xm);
+        if (!SH) { if (mine && (tab || kind == 0)) eb_off[ru.off + k_item] = word; }      // (kind 3: k_eb_inline writes the mask itself)
         else if (mine && listed) pair_insert(ph, ph_buckets, (uint32_t)u, xs, word);
         if (listed) {
           const unsigned long long idx = pbase + (unsigned long long)__popcll(has & ((1ull << lane) - 1ull));
-          items[idx] = make_uint2((uint32_t)u, (uint32_t)k);
+          items[idx] = make_uint2((uint32_t)u, (uint32_t)k_item);
           if (SH) item_off[idx] = word;
         }
         ubase += (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
         mbase += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         pbase += (unsigned long long)__popcll(has);
+      }
+    }
+  }
+}
+
+// pass 3b (whole-graph handles): the other entries of a multi-edge take the word of the pair's first sorted occurrence
+__global__ __launch_bounds__(TPB) void k_eb_dups(GraphView g, EbSel sel, unsigned long long *cursor, uint32_t *__restrict__ eb_off) {
+  const int lane = lane_id();
+  while (true) {
+    const int64_t v0 = grab_u64(cursor, GRAB_SLOTS);
+    if (v0 >= g.n_slots) break;
+    for (int64_t u = v0; u < v0 + GRAB_SLOTS && u < g.n_slots; ++u) {
+      const Row ru = g.rows[u];
+      const uint32_t *sr = g.sids + ru.off;
+      for (int32_t i = lane; i < ru.deg; i += 64) {
+        const uint32_t xs = sr[i];
+        if (i == 0 || sr[i - 1] != xs) continue;
+        const Row rv = g.rows[xs];
+        int64_t cost; int kind;
+        (void)eb_units(ru, rv, sel, cost, kind);
+        if (kind != 1 && kind != 2) continue;                  // no table (assign wrote EB_NONE) or an inline mask (k_eb_inline)
+        int32_t lo = 0, hi = i;                                // first occurrence of xs in the sorted row
+        while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (sr[mid] < xs) lo = mid + 1; else hi = mid; }
+        eb_off[ru.off + g.sperm[ru.off + i]] = eb_off[ru.off + g.sperm[ru.off + lo]];
       }
     }
   }
@@ -578,14 +618,23 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
     SRW_HIP(hipStreamSynchronize(st));
   }
   const unsigned long long all_pairs = pairs + mpairs;
+  const auto t_alloc0 = std::chrono::steady_clock::now();
   g.eb_off.ensure((size_t)g.n_entries);
   g.eb_bins.alloc((size_t)units * 8);
   g.em_bits.alloc((size_t)munits * 4);
   DevBuf<uint2> items; items.alloc((size_t)all_pairs);
+  if (getenv("SRW_TIMING"))
+    fprintf(stderr, "[edge tables] allocations (%.1f GB of tables, %.1f GB of masks, %.1f GB work list): %.0f ms; planning passes before them: %.0f ms\n",
+            (double)units * 64 / 1e9, (double)munits * 16 / 1e9, (double)all_pairs * 8 / 1e9,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc0).count(),
+            std::chrono::duration<double, std::milli>(t_alloc0 - t0).count());
   SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
   g.eb_sharded = false; g.ph.release(); g.ph_buckets = 0;
   hipLaunchKernelGGL((k_eb_assign<false>), dim3(blocks), dim3(TPB), 0, st, g.view(), ShardSel{0, 1}, sel, cursor.p,
                      row_units.p, row_munits.p, row_pairs.p, g.eb_off.p, items.p, (PairSlot *)nullptr, 0u, (uint32_t *)nullptr);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+  hipLaunchKernelGGL(k_eb_dups, dim3(blocks), dim3(TPB), 0, st, g.view(), sel, cursor.p, g.eb_off.p);
   SRW_HIP(hipGetLastError());
   g.has_eb = true; g.use_eb = true; g.eb_mask_max = sel.mask_max;
   GraphView gv = g.view();
@@ -819,7 +868,8 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
         if (fits(s2, p2)) { sel = s2; pl = p2; break; }
         g.eb_cm_ratio_sel = 0;
       }
-    if (!getenv("SRW_EB_FINE_CAP"))
+    // (finer tables only for a job long enough to pay for their build: walk_kernels.hip:prepare_tables, srw_plan_walks)
+    if (!getenv("SRW_EB_FINE_CAP") && std::max<int64_t>(h->planned_walks > 0 ? h->planned_walks : 10, P.num_walks) >= 64)
       for (int fc : {4096, 1024, 512}) {
         if (fc <= cap_sel) break;
         g.eb_fine_cap_sel = fc;

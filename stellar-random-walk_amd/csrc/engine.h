@@ -178,6 +178,7 @@ struct srw_handle {
   srw::DevBuf<unsigned long long> walk_cursor;   // [0] next walker of the persistent kernels, [1] walkers handed over by k_walk_tables
   srw::DevBuf<int32_t> walk_todo;                // their indices
   int n_cus = 256;
+  int64_t planned_walks = 0;                     // srw_plan_walks: the job's numWalks (0: unknown -> the reference's default 10)
   double shard_prof_acc[4] = {0, 0, 0, 0}, shard_prof_mx[4] = {0, 0, 0, 0};   // SRW_SHARD_PROFILE: per-kernel times of the super-steps (run_shard_superstep)
   int q1_occ[2] = {0, 0};           // resident blocks per CU of k_sh_step_q1<false / true> (queried once per handle)
   int dev_share = 1;                             // handles of one cluster on this device (virtual shards of a single-GPU box): optional structures take 1 / dev_share of what is free

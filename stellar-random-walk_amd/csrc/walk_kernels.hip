@@ -2408,6 +2408,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   if (reserve > ((size_t)64 << 30)) reserve = (size_t)64 << 30;      // (srw_walk_to_host / _and_save stream one iteration at a time)
   if (const char *r = getenv("SRW_EB_RESERVE_GB"); r && *r) reserve = (size_t)(atof(r) * (double)((size_t)1 << 30));
   h->g.eb_reserve = reserve;
+  const int64_t job_walks = std::max<int64_t>(h->planned_walks > 0 ? h->planned_walks : 10, P.num_walks);   // srw_plan_walks
   std::map<std::tuple<int, int, int, int, int>, size_t> size_cache;
   auto set_size = [&](int cap, int sh, int cm, int fine, int ratio = 0) {   // bytes of the complete set under this geometry (one pass over the entries; cached)
     Graph &g = h->g;
@@ -2443,7 +2444,9 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
         const size_t n = set_size(t.cap, t.min_sh, cm, 0);
         if (fits(n, (size_t)24 << 30)) { t.cm = cm; t.need = n; break; }
       }
-    if (!getenv("SRW_EB_FINE_CAP"))
+    // finer tables only for a job long enough to pay for them: config 3 builds them in +8.4 s (HBM-scratch bins, 40 GB more to
+    // allocate) and walks an iteration in 578 instead of 674 ms — break-even at ~85 iterations (profiles/r05_table_plan.md)
+    if (!getenv("SRW_EB_FINE_CAP") && job_walks >= 64)
       for (int fc : {4096, 1024, 512}) {
         if (fc <= t.cap) break;
         const size_t n = set_size(t.cap, t.min_sh, t.cm, fc);

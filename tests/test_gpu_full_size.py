@@ -2,8 +2,11 @@
 tests/big_c3_check.py (weighted RMAT-24, p = .25 q = 4, (4, .5), (.25, 1): ~1 500 sampled walkers incl. the 20 biggest hubs against
 the CPU oracle rebuilt from the same edge stream), tests/big_c5_check.py (config 5's stand-in, directed RMAT-26 ef 27, p = 4 q = .5,
 the same way: ~70 GB of host memory; the oracle's generator and row sorts run on all host cores) and tests/big_c4_check.py
-(config 4's shape on eight virtual shards against the single-launch kernel — the distributed == sequential property of
-T/UniformRandomWalkTest.scala:181-291 at size).  SRW_SKIP_FULL_SIZE=1 skips them (quick local runs)."""
+(config 4 at its own size, RMAT-27, on eight virtual shards against the single-launch kernel — the distributed == sequential
+property of T/UniformRandomWalkTest.scala:181-291 at size — and ~1 500 sampled walkers against the oracle over rows rebuilt on the
+host from the edge stream) and tests/big_shard_tables_check.py (the sharded per-edge tables at config 3's size, worlds 1 and 2,
+every walker against the replicated kernel).  A box that lacks the memory FAILS these tests; only SRW_SKIP_FULL_SIZE=1 skips
+them (quick local runs)."""
 import os
 import subprocess
 import sys
@@ -22,6 +25,14 @@ def _resources():
     return free, host
 
 
+def _need(free_gb, host_gb):
+    """A resource shortfall is a failure, not a skip: a silently skipped full-size test would leave the suite green."""
+    free, host = _resources()
+    if free < free_gb * 1e9 or host < host_gb * 1e9:
+        pytest.fail("needs ~%d GB of free HBM and ~%d GB of host memory (have %.0f / %.0f GB); SRW_SKIP_FULL_SIZE=1 skips the "
+                    "full-size tests on purpose" % (free_gb, host_gb, free / 1e9, host / 1e9))
+
+
 def _run(script, *args, timeout=3000):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script), *args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=timeout)
@@ -31,24 +42,24 @@ def _run(script, *args, timeout=3000):
 
 
 def test_config3_full_size_against_the_oracle():
-    free, host = _resources()
-    if free < 200e9 or host < 48e9:
-        pytest.skip("needs ~200 GB of free HBM and ~48 GB of host memory (have %.0f / %.0f GB)" % (free / 1e9, host / 1e9))
+    _need(200, 48)
     out = _run("big_c3_check.py")
     assert out.count("IDENTICAL") >= 3
 
 
 def test_config5_stand_in_full_size_against_the_oracle():
-    free, host = _resources()
-    if free < 260e9 or host < 80e9:
-        pytest.skip("needs ~260 GB of free HBM and ~80 GB of host memory (have %.0f / %.0f GB)" % (free / 1e9, host / 1e9))
+    _need(260, 80)
     out = _run("big_c5_check.py", timeout=3000)
     assert out.count("IDENTICAL") >= 1
 
 
-def test_config4_shape_eight_virtual_shards():
-    free, host = _resources()
-    if free < 200e9 or host < 24e9:
-        pytest.skip("needs ~200 GB of free HBM and ~24 GB of host memory (have %.0f / %.0f GB)" % (free / 1e9, host / 1e9))
-    out = _run("big_c4_check.py", "26", "8")
-    assert out.count("IDENTICAL") >= 1
+def test_config4_full_size_eight_virtual_shards_and_the_oracle():
+    _need(240, 64)
+    out = _run("big_c4_check.py", "27", "8")
+    assert out.count("IDENTICAL") >= 2 and "oracle:" in out
+
+
+def test_sharded_tables_at_config3_size():
+    _need(250, 24)
+    out = _run("big_shard_tables_check.py", "24", "16", "1", "0", "0.25", "4", "1", "2")
+    assert out.count("IDENTICAL") >= 4

@@ -854,7 +854,7 @@ def test_edge_tables_every_pair(eng, oracle, case):
 
 
 def test_edge_tables_hubs_and_leaves(eng, oracle):
-    """Default selection on two 100 000-entry hubs sharing half of their leaves, joined by a double edge: every pair that
+    """Default selection on two 100 000-entry hubs sharing half of their leaves, joined by a double edge (a multi-edge is one pair: its entries share one table): every pair that
     leads INTO a hub (leaf -> hub, hub -> hub) gets chunk prefixes (chunks of 2048 candidates), every pair that leads into
     a leaf (1 .. 2 candidates) an inline membership mask."""
     n = 100000
@@ -871,7 +871,7 @@ def test_edge_tables_hubs_and_leaves(eng, oracle):
         rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=8, seed=29, threads=8)
         paths, lens, st = eng.walk(p=p, q=q, walk_length=8, seed=29)
         assert np.array_equal(paths[idx], rp) and np.array_equal(lens[idx], rl), (p, q)
-        assert st["edge_tables"] == 2 * n + 4, st     # every leaf -> hub entry, 0 -> 1 twice, 1 -> 0 twice
+        assert st["edge_tables"] == 2 * n + 2, st     # every leaf -> hub entry; the double edge 0 -> 1 (and 1 -> 0) is ONE pair: one table, both entries point at it
         assert st["strategy_steps"]["edge_table"] > 0 and st["strategy_steps"]["edge_mask"] > 0, st
         served = sum(st["strategy_steps"][k] for k in ("p1", "p2", "w", "p3"))
         assert served == 0, st                         # nothing is left to the on-the-fly intersections
@@ -880,7 +880,7 @@ def test_edge_tables_hubs_and_leaves(eng, oracle):
     # a different (p, q) rebuilds them
     rp, rl, _ = g.walk(sources=src, p=0.5, q=2.0, walk_length=8, seed=31, threads=8)
     paths, lens, st = eng.walk(p=0.5, q=2.0, walk_length=8, seed=31)
-    assert np.array_equal(paths[idx], rp) and st["edge_tables"] == 2 * n + 4
+    assert np.array_equal(paths[idx], rp) and st["edge_tables"] == 2 * n + 2
 
 
 def test_giant_row_mass_certificate(eng, oracle):

@@ -175,6 +175,27 @@ def test_table_geometries_give_the_same_paths(monkeypatch):
     assert sizes[str(_GEOMETRIES[2])][0] > sizes["default"][0], sizes      # masks on every pair cost bytes
 
 
+def test_plan_walks_steers_the_tables_not_the_paths():
+    """srw_plan_walks (the job's --numWalks, Params.scala:7-23): the finer per-edge tables are built only for a job long enough to
+    pay for them (>= 64 planned iterations; default: the reference's 10).  The table set changes, the paths never do."""
+    scale = 18
+    res = []
+    for planned in (0, 10, 200):
+        with pkg().Engine(device=0) as e:
+            e.generate_rmat(scale, 16 << scale, seed=5, weighted=True)
+            if planned:
+                e.plan_walks(planned)
+            paths, lens, st = e.walk(p=0.25, q=4.0, walk_length=30, seed=4321)
+            assert st["strategy_steps"]["edge_table"] > 0, st
+            res.append((paths, lens, st["edge_table_bytes"]))
+    for paths, lens, _ in res[1:]:
+        assert np.array_equal(lens, res[0][1]) and np.array_equal(paths, res[0][0])
+    assert res[0][2] == res[1][2] and res[2][2] > res[1][2], [r[2] for r in res]      # 200 planned iterations: the finer tables are in
+    with pkg().Engine(device=0) as e:
+        with pytest.raises(pkg().SrwError):
+            e.plan_walks(-1)
+
+
 def test_three_level_table_on_a_long_row(oracle, monkeypatch):
     """A row of 300 000 candidates with chunks of 64: 4 688 chunks, a three-level tree (4 688 -> 74 -> 2), built through the HBM-scratch
     bins; against the oracle."""

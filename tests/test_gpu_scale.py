@@ -140,6 +140,8 @@ _GEOMETRIES = [
     {"SRW_EB_CM_MAX": "0", "SRW_EB_FINE_CAP": "4096", "SRW_EB_FINE_MIN_DU": "0"},  # finer tables everywhere: two-level trees, HBM-scratch bins in the build
     {"SRW_EB_CM_MAX": "4096", "SRW_EB_FINE_CAP": "1024", "SRW_EB_NO_U16": "1"},
     {"SRW_EB_CHUNKS": "32", "SRW_EB_MIN_SH": "8"},                                # the coarse complete set of a graph that fills the GPU
+    {"SRW_EB_NO_PAIRING": "1"},                                                   # every table from its own intersection (default: a pair and its reverse from one)
+    {"SRW_EB_NO_PAIRING": "1", "SRW_EB_CM_MAX": "0"},
 ]
 
 
@@ -173,6 +175,29 @@ def test_table_geometries_give_the_same_paths(monkeypatch):
         sizes[str(env)] = [r[2] for r in got]
     assert sizes[str(_GEOMETRIES[0])][0] > sizes["default"][0], sizes      # the 16-bit level 0 is what makes the default smaller
     assert sizes[str(_GEOMETRIES[2])][0] > sizes["default"][0], sizes      # masks on every pair cost bytes
+
+
+def test_paired_table_build_is_in_use():
+    """Undirected loads build (u -> v) and (v -> u) from one sorted-chunk intersection where both have a bins table (edge_tables.hip:
+    eb_fill_pair): the build's own count of such items must be positive on an RMAT graph, zero on a directed load and with
+    SRW_EB_NO_PAIRING=1 (the paths of all three forms are compared by the tests above and below)."""
+    import re, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); import _pkg; P = _pkg.load(); e = P.Engine(0); "
+            "e.generate_rmat(16, 16 << 16, seed=5, weighted=True, directed=bool(int(sys.argv[1]))); "
+            "e.walk(p=0.25, q=4.0, walk_length=4, seed=1, fetch=False)" % ROOT)
+
+    def paired(directed, env):
+        r = subprocess.run([sys.executable, "-c", code, str(directed)], env=dict(os.environ, SRW_TIMING="1", **env),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        m = re.search(r"W for a pair and its reverse at once (\d+)", r.stderr)
+        assert m, r.stderr[-2000:]
+        return int(m.group(1))
+
+    assert paired(0, {}) > 1000
+    assert paired(0, {"SRW_EB_NO_PAIRING": "1"}) == 0
+    assert paired(1, {}) == 0
 
 
 def test_plan_walks_steers_the_tables_not_the_paths():

@@ -44,7 +44,6 @@ struct EbSel {          // which pairs get a table
   int32_t min_deg;      // bins tables: shortest row of curr
   int64_t min_cost;     // bins tables: smallest priority (saved wave-cycles per 64 B of table, see eb_units) that still fits the budget
   int32_t has_ehash, has_hub;
-  int32_t pair;         // 1: a pair and its reverse are built by ONE intersection where both have a bins table (eb_pair_role)
   EbPolicy pol;         // bins tables: chunk sizes, chunk masks, finer tables of the pairs with a long N(prev) (sampling.h:eb_pair_geometry)
 };
 constexpr int INLINE_MAX_DEG = 32;   // masks of rows up to 32 candidates live in eb_off[e] itself
@@ -71,30 +70,6 @@ __device__ inline uint32_t eb_units(const Row &ru, const Row &rv, const EbSel &s
   if (cost_out < s.min_cost) return 0u;
   kind = 1;
   return units;
-}
-
-// Paired build (whole-graph handles of UNDIRECTED loads).  N(u) ∩ N(v) serves two tables: (u -> v) wants the members' positions and
-// weights in N(v), (v -> u) those in N(u) — and every x in N(v) has u... both rows hold the same ids.  Where both pairs get a bins table
-// that the wave's LDS bins can hold and the cost model sends the cheaper direction through the sorted-chunk intersection W (stream the
-// SHORTER row, stage the longer one), that one pass fills both: a match marks the staged element, and the marks of a staged chunk are
-// turned into the reverse table's corrections when the chunk is left (one coalesced read of the chunk's positions and weights) — instead
-// of a second intersection that streams the LONGER row.  70 % of config 3's build were W pairs between long rows (profiles/r03_eb_build.md).
-//   role of entry (u -> v): 0 = on its own, 1 = primary (its work item builds both tables), 2 = secondary (no work item).
-// A pure function of the two rows, the slots and the selection, so that both entries of a pair agree on it.
-__device__ inline int eb_pair_role(const Row &ru, const Row &rv, uint32_t us, uint32_t vs, const EbSel &s) {
-  if (!s.pair || us == vs) return 0;
-  int64_t c0, c1; int k0, k1;
-  (void)eb_units(ru, rv, s, c0, k0);
-  (void)eb_units(rv, ru, s, c1, k1);
-  if (k0 != 1 || k1 != 1) return 0;
-  const PairGeom g0 = eb_pair_geometry(rv.deg, ru.deg, s.pol), g1 = eb_pair_geometry(ru.deg, rv.deg, s.pol);
-  if (g0.n_bins > BIN_CAP || g1.n_bins > BIN_CAP) return 0;              // (the finer tables fill their bins in an HBM scratch)
-  // the primary direction streams the shorter row: curr = the shorter one (ties: the smaller slot)
-  const bool v_is_curr = rv.deg < ru.deg || (rv.deg == ru.deg && vs < us);
-  const Row &rc = v_is_curr ? rv : ru, &rp = v_is_curr ? ru : rv;
-  const BinnedCost bc = binned_cost(rc.deg, rp.deg, s.has_hub && (rp.flags >> ROW_HUB_SHIFT) != 0u, s.has_ehash != 0);
-  if (!(bc.cw < bc.c1 && bc.cw < bc.c2)) return 0;                          // binned_fill would not take W for it
-  return v_is_curr ? 1 : 2;
 }
 
 // Priority classes for the budget fit: 4 per octave from 2^11 up (class 1 .. 62; 0 unused, 63 = the masks).
@@ -203,8 +178,7 @@ __global__ __launch_bounds__(TPB) void k_eb_rowsum(GraphView g, ShardSel ss, EbS
         int64_t cost; int kind;
         const uint32_t x = eb_units(ru, rv, sel, cost, kind);
         if (kind == 1) un += x; else if (kind == 2) mu += x;
-        const bool second = !SH && kind == 1 && eb_pair_role(ru, rv, (uint32_t)u, xs, sel) == 2;      // built by its partner's work item
-        np += ((kind == 1 || kind == 2) && !second) ? 1u : 0u;
+        np += (kind == 1 || kind == 2) ? 1u : 0u;
       }
       un = wave_sum_u64(un); mu = wave_sum_u64(mu); np = wave_sum_u64(np);
       if (lane == 0) { row_units[u] = un; row_munits[u] = mu; row_pairs[u] = np; }
@@ -245,7 +219,7 @@ __global__ __launch_bounds__(TPB) void k_eb_assign(GraphView g, ShardSel ss, EbS
           const uint32_t tb = (uint32_t)__shfl_up((int)ib, o), tm = (uint32_t)__shfl_up((int)im, o);
           if (lane >= o) { ib += tb; im += tm; }
         }
-        const bool listed = tab && !(!SH && kind == 1 && eb_pair_role(ru, g.rows[xs], (uint32_t)u, xs, sel) == 2);
+        const bool listed = tab;
         const unsigned long long has = __ballot(listed);
         const uint32_t word = !tab ? EB_NONE : kind == 1 ? (uint32_t)(ubase + ib - xb) : (uint32_t)(mbase + im - xm);
         if (!SH) { if (mine && (tab || kind == 0)) eb_off[ru.off + k_item] = word; }      // (kind 3: k_eb_inline writes the mask itself)
@@ -320,231 +294,8 @@ __global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, ShardSel ss, EbS
   }
 }
 
-// The table of one pair from the wave's filled bins (bins[j] = corrections up to the end of fill chunk j, inclusive prefix): level 0 =
-// the chunk prefixes A'_end(j) = PQ[end_j] + corrections, level 1 / 2 = the last element of every block of 64 of the level below (the
-// walk's search tree), then the chunk masks.  rc = the row of curr, du = deg(prev).
-__device__ inline void eb_write_table(const GraphView &g, const Row &rc, const EbPolicy &pol, const PairGeom &pg, const BinGeom &gf, bool big,
-                                      const double *bins, const double *gbins, const uint32_t *mbits, double *out, unsigned long long *strat_count) {
-  const int lane = lane_id();
-  BinGeom gc; gc.csh = pg.csh; gc.n_bins = pg.n_bins;
-  const int up = gc.csh - gf.csh;
-  const PqRow PQ(g, rc.off);            // the table keeps the complete numerator A'_end(j) = PQ[end_j] + corrections
-  const bool as_f32 = pol.f32 && (rc.flags & ROW_PQ_F32);      // every such sum is exactly representable in binary32
-  const bool as_u16 = eb_pair_u16(rc.flags, gc.csh, pol);           // level 0 as the chunks' own masses, u16 multiples of the row's unit 2^G
-  const double inv_unit = as_u16 ? 1.0 / eb_row_unit(rc.flags) : 0.0;
-  const EbLayout lay = eb_layout(as_f32, gc.n_bins, pg.cmask, rc.deg, as_u16);
-  for (int L = 0; L < 3; ++L) {
-    const int32_t cnt = L == 0 ? gc.n_bins : L == 1 ? lay.n1 : lay.n2;
-    double *lo_ = out + (size_t)(L == 0 ? lay.l0_off : L == 1 ? lay.l1_off : lay.l2_off) * 8;
-    for (int32_t t = lane; t < cnt; t += 64) {
-      const int64_t je = (((int64_t)t + 1) << (6 * L)) - 1;
-      const int64_t j = je < gc.n_bins ? je : gc.n_bins - 1;          // the chunk this element is the prefix of
-      const int64_t fi = ((j + 1) << up) - 1;
-      const int64_t ke = ((j + 1) << gc.csh) - 1;
-      const int64_t fb = fi < gf.n_bins ? fi : gf.n_bins - 1;
-      const double corr = big ? __hip_atomic_load(gbins + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bins[fb];
-      const double a = PQ[ke < rc.deg ? ke : rc.deg - 1] + corr;
-      if (L == 0 && as_u16) {                  // the chunk's own mass = this prefix - the previous one (exact), in units of 2^G
-        double a0 = 0.0;
-        if (j > 0) {
-          const int64_t fp = (j << up) - 1, kp = (j << gc.csh) - 1;
-          a0 = PQ[kp] + (big ? __hip_atomic_load(gbins + fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bins[fp]);
-        }
-        const double du_ = (a - a0) * inv_unit;
-        const unsigned short q16 = (unsigned short)(du_ >= 0.0 && du_ <= 65535.0 ? du_ : 0.0);
-        if ((double)q16 != du_) atomicAdd(&strat_count[7], 1ull);         // must never happen (pq_row_u16_bits' bound)
-        reinterpret_cast<unsigned short *>(lo_)[t] = q16;
-      } else if (as_f32) {
-        reinterpret_cast<float *>(lo_)[t] = (float)a;
-        if ((double)(float)a != a) atomicAdd(&strat_count[7], 1ull);      // must never happen (pq_row_f32's bound)
-      } else lo_[t] = a;
-    }
-  }
-  if (mbits) {
-    unsigned long long *mo = reinterpret_cast<unsigned long long *>(out + (size_t)lay.cm_off * 8);
-    const int32_t n_mw = (rc.deg + 63) >> 6, n_w32 = (rc.deg + 31) >> 5;
-    for (int32_t t = lane; t < n_mw; t += 64)
-      mo[t] = (unsigned long long)mbits[2 * t] | ((2 * t + 1 < n_w32) ? ((unsigned long long)mbits[2 * t + 1] << 32) : 0ull);
-  }
-}
-
-// in-place inclusive prefix over a wave's LDS bins (exact additions), as binned_fill ends
-__device__ inline void eb_bins_prefix(double *bins, int32_t n_bins) {
-  const int lane = lane_id();
-  constexpr int PER = BIN_CAP / 64;
-  double loc[PER];
-  double run = 0.0;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) { const int j = lane * PER + i; run += (j < n_bins) ? bins[j] : 0.0; loc[i] = run; }
-  const double incl = wave_incl_scan_f64(run);
-  double excl = __shfl_up(incl, 1);
-  if (lane == 0) excl = 0.0;
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int i = 0; i < PER; ++i) { const int j = lane * PER + i; if (j < n_bins) bins[j] = excl + loc[i]; }
-  __builtin_amdgcn_wave_barrier();
-}
-
-// The paired fill (eb_pair_role == 1): ONE sorted-chunk intersection of N(u) and N(v) for the tables of (u -> v) [A: curr = v, the shorter
-// row, streamed 256 candidates at a time with their input-order positions and weights] and (v -> u) [B: curr = u, staged 1 024 sorted ids
-// at a time].  A match is a common neighbor x:
-//   A: candidate x of N(v) is in N(u)  -> its correction w - fl(w / q) goes to A's bin now (unless x == u: the return edge, handled apart);
-//   B: every occurrence of x in N(u) is a candidate of B that is in N(v) -> the staged elements of the run are MARKED (unless x == v: B's
-//      return edge), and when the staged chunk is left its marked elements' positions and weights are read (coalesced: the sorted
-//      permutation and weights of the chunk) and their corrections go to B's bins.  A run of equal ids that crosses the chunk boundary
-//      carries its mark over (the candidates equal to it have all been seen by then: the candidates advance in id order).
-// Same sums as two binned_fill calls (every partial sum is exact under the row certificate, so the order is free): tests compare the
-// paths, with SRW_EB_NO_PAIRING=1 as the unpaired build of the same tables.
-__device__ inline void eb_fill_pair(const GraphView &g, const Row &ru, const Row &rv, uint32_t xu, uint32_t xv, float p_, float q_,
-                                    double *binsA, const BinGeom gA, uint32_t *mbA, double *binsB, const BinGeom gB, uint32_t *mbB,
-                                    uint32_t *bch /* [HCHUNK] */, uint32_t *cbits /* [HCHUNK / 32] */, int32_t &ret_lo_out) {
-  const int lane = lane_id();
-  const int32_t dv = uni(rv.deg), du = uni(ru.deg);
-  const int cshA = uni(gA.csh), cshB = uni(gB.csh);
-  for (int t = lane; t < gA.n_bins; t += 64) binsA[t] = 0.0;
-  for (int t = lane; t < gB.n_bins; t += 64) binsB[t] = 0.0;
-  if (mbA) for (int t = lane; t < ((dv + 31) >> 5); t += 64) mbA[t] = 0u;
-  if (mbB) for (int t = lane; t < ((du + 31) >> 5); t += 64) mbB[t] = 0u;
-  if (lane < HCHUNK / 32) cbits[lane] = 0u;
-  __builtin_amdgcn_wave_barrier();
-  const uint32_t *cs = g.sids + rv.off, *cp = g.sperm + rv.off; const float *csw = g.sw + rv.off;      // v: streamed
-  const uint32_t *B = g.sids + ru.off, *Bp = g.sperm + ru.off; const float *Bw = g.sw + ru.off;        // u: staged
-  const uint32_t lo_id = uni(max(cs[0], B[0])), hi_id = uni(min(cs[dv - 1], B[du - 1]));
-  LowerBound lb[4] = {{cs, 0, dv, xu, false}, {B, 0, du, xv, false}, {cs, 0, dv, lo_id, false}, {B, 0, du, lo_id, false}};
-  wave_lower_bound_multi<4>(lb);
-  const int32_t ret_lo = lb[0].lo, retB_lo = lb[1].lo;
-  int32_t pa = lb[2].lo, pb = lb[3].lo;
-  ret_lo_out = ret_lo;
-  // the return edges: occurrences of u in N(v) (A) and of v in N(u) (B)
-  for (int32_t c = ret_lo + lane; c < dv && cs[c] == xu; c += 64)
-    atomicAdd(&binsA[cp[c] >> cshA], (double)div_exact(csw[c], p_) - (double)div_exact(csw[c], q_));
-  for (int32_t c = retB_lo + lane; c < du && B[c] == xv; c += 64)
-    atomicAdd(&binsB[Bp[c] >> cshB], (double)div_exact(Bw[c], p_) - (double)div_exact(Bw[c], q_));
-  if (lo_id <= hi_id) {
-    uint32_t AI[4], AC[4], NI[4], NC[4];
-    float AW[4], NW[4];
-    auto load_a = [&](int32_t pos, uint32_t v[4], uint32_t c[4], float w[4]) {   // lane holds 4 consecutive entries of v's sorted row
-      const int32_t i0 = pos + 4 * lane;
-      if (i0 + 3 < dv) {
-        const U32x4 q4 = *reinterpret_cast<const U32x4 *>(cs + i0);
-        const U32x4 r4 = *reinterpret_cast<const U32x4 *>(cp + i0);
-        const F32x4 w4 = *reinterpret_cast<const F32x4 *>(csw + i0);
-        v[0] = q4.a; v[1] = q4.b; v[2] = q4.c; v[3] = q4.d;
-        c[0] = r4.a; c[1] = r4.b; c[2] = r4.c; c[3] = r4.d;
-        w[0] = w4.a; w[1] = w4.b; w[2] = w4.c; w[3] = w4.d;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool ok = i0 + j < dv;
-          v[j] = ok ? cs[i0 + j] : HEMPTY; c[j] = ok ? cp[i0 + j] : 0u; w[j] = ok ? csw[i0 + j] : 0.0f;
-        }
-      }
-    };
-    auto stage_b = [&](int32_t pos) {                       // B[pos .. pos + 1024) -> LDS, sorted, padded
-#pragma unroll
-      for (int u4 = 0; u4 < 4; ++u4) {
-        const int32_t i0 = pos + 256 * u4 + 4 * lane;
-        uint4 q4;
-        if (i0 + 3 < du) { const U32x4 t = *reinterpret_cast<const U32x4 *>(B + i0); q4 = make_uint4(t.a, t.b, t.c, t.d); }
-        else q4 = make_uint4(i0 < du ? B[i0] : HEMPTY, i0 + 1 < du ? B[i0 + 1] : HEMPTY, i0 + 2 < du ? B[i0 + 2] : HEMPTY, HEMPTY);
-        reinterpret_cast<uint4 *>(bch)[64 * u4 + lane] = q4;
-      }
-    };
-    // the marked elements of the staged chunk [pb, pb + nb) -> B's corrections; clears the marks
-    auto flush_b = [&](int32_t nb) {
-      __builtin_amdgcn_wave_barrier();
-      for (int32_t w0 = 0; w0 < nb; w0 += 64 * 4) {
-        uint32_t word[4]; bool on[4]; uint32_t bp[4]; float bw[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int32_t i = w0 + 64 * t + lane;
-          word[t] = i < nb ? cbits[i >> 5] : 0u;
-          on[t] = (word[t] >> (i & 31)) & 1u;
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { const int32_t i = w0 + 64 * t + lane; bp[t] = 0u; bw[t] = 0.0f; if (on[t]) { bp[t] = Bp[pb + i]; bw[t] = Bw[pb + i]; } }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (on[t]) {
-            atomicAdd(&binsB[bp[t] >> cshB], (double)bw[t] - (double)div_exact(bw[t], q_));
-            if (mbB) atomicOr(&mbB[bp[t] >> 5], 1u << (bp[t] & 31));
-          }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < HCHUNK / 32) cbits[lane] = 0u;
-      __builtin_amdgcn_wave_barrier();
-    };
-    stage_b(pb);
-    load_a(pa, AI, AC, AW);
-    load_a(pa + 256, NI, NC, NW);
-    __builtin_amdgcn_wave_barrier();
-    uint32_t handled = 0; bool have_handled = false;     // candidates <= handled met every id of N(u) they could equal
-    while (true) {
-      const int32_t nb = (du - pb) < HCHUNK ? (du - pb) : HCHUNK;
-      const uint32_t bmax = bch[nb - 1];                   // uniform LDS read
-      bool want[4]; uint32_t pos[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { want[j] = AI[j] <= bmax && !(have_handled && AI[j] <= handled); pos[j] = 0u; }   // padding never <= bmax
-#pragma unroll
-      for (int step = HCHUNK / 2; step >= 1; step >>= 1) {
-        uint32_t probe[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) probe[j] = bch[pos[j] + step - 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (probe[j] < AI[j]) pos[j] += step;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (want[j] && bch[pos[j]] == AI[j]) {
-          if (AI[j] != xu) {
-            atomicAdd(&binsA[AC[j] >> cshA], (double)AW[j] - (double)div_exact(AW[j], q_));
-            if (mbA) atomicOr(&mbA[AC[j] >> 5], 1u << (AC[j] & 31));
-          }
-          if (AI[j] != xv) {
-            uint32_t t = pos[j];
-            do { atomicOr(&cbits[t >> 5], 1u << (t & 31)); ++t; } while (t < (uint32_t)nb && bch[t] == AI[j]);
-          }
-        }
-      // advance the list that ends first
-      const int32_t na = (dv - pa) < 256 ? (dv - pa) : 256;
-      const int jl = (na - 1) & 3;
-      const uint32_t alast = jl == 0 ? AI[0] : jl == 1 ? AI[1] : jl == 2 ? AI[2] : AI[3];
-      const uint32_t amax = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)alast, (na - 1) >> 2));
-      if (amax <= bmax) {
-        pa += 256;
-        if (pa >= dv) { flush_b(nb); break; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { AI[j] = NI[j]; AC[j] = NC[j]; AW[j] = NW[j]; }
-        load_a(pa + 256, NI, NC, NW);
-      } else {
-        __builtin_amdgcn_wave_barrier();
-        const bool carry = (cbits[(nb - 1) >> 5] >> ((nb - 1) & 31)) & 1u;      // the chunk's last element was matched: its run may go on
-        flush_b(nb);
-        handled = bmax; have_handled = true;
-        pb += HCHUNK;
-        if (pb >= du || bmax >= hi_id) break;
-        stage_b(pb);
-        __builtin_amdgcn_wave_barrier();
-        if (carry) {                                         // elements equal to the carried id are a prefix of the new chunk
-          const int32_t nb2 = (du - pb) < HCHUNK ? (du - pb) : HCHUNK;
-          for (int32_t i = lane; i < nb2; i += 64) {
-            const bool eq = bch[i] == bmax;
-            if (eq) atomicOr(&cbits[i >> 5], 1u << (i & 31));
-            if (!__any(eq)) break;
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  eb_bins_prefix(binsA, gA.n_bins);
-  eb_bins_prefix(binsB, gB.n_bins);
-}
-
 // pass 4: the tables.  One wave per pair: binned_fill exactly as a walk step over that pair would run it, then the
-// prefix at every table chunk end goes to HBM (eb_write_table).  Whole-graph handles of undirected loads build a pair and its
-// reverse from one intersection where they can (eb_pair_role, eb_fill_pair).
+// prefix at every table chunk end goes to HBM.
 // experiment switches (profiles/r03_eb_build.md: neither deeper prefetch nor wider lockstep searches move the build)
 #ifndef SRW_EB_PREFETCH
 #define SRW_EB_PREFETCH 1
@@ -555,17 +306,14 @@ __device__ inline void eb_fill_pair(const GraphView &g, const Row &ru, const Row
 #ifndef SRW_EB_WAVES
 #define SRW_EB_WAVES 4
 #endif
-constexpr int EB_LDS_WORDS = 2 * BIN_CAP + HCHUNK;      // binned_fill's bins + the staged ids of N(prev): 8 KB per wave
-constexpr int EB_LDS_WORDS_PAIR = EB_LDS_WORDS + 2 * BIN_CAP + HCHUNK / 32;     // + the reverse table's bins + the staged chunk's marks: 12.1 KB
+constexpr int EB_LDS_WORDS = 2 * BIN_CAP + HCHUNK;      // binned_fill's bins + the staged ids of N(prev): 6 KB per wave
 template <bool SH>
-__global__ __launch_bounds__(TPB, SH ? SRW_EB_WAVES : (SRW_EB_WAVES < 3 ? SRW_EB_WAVES : 3)) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
-                                                     float q, EbSel sel, const uint32_t *__restrict__ eb_off,
+__global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
+                                                     float q, int32_t mask_max, EbPolicy pol, const uint32_t *__restrict__ eb_off,
                                                      double *__restrict__ eb_bins, uint32_t *__restrict__ em_bits, unsigned long long *cursor,
                                                      unsigned long long *strat_count /* [8] */, int fill_tune, double *gscratch, int64_t gs_stride) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][SH ? EB_LDS_WORDS : EB_LDS_WORDS_PAIR];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TPB / 64][EB_LDS_WORDS];
   const int lane = lane_id();
-  const int32_t mask_max = sel.mask_max;
-  const EbPolicy pol = sel.pol;
   uint32_t *mine = lds[threadIdx.x >> 6];
   Member tm; tm.mode = 0; tm.bm = mine; tm.seg_base = 0; tm.ehash = g.ehash; tm.ehash_mask = g.ehash_mask;
   unsigned long long ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -584,8 +332,7 @@ __global__ __launch_bounds__(TPB, SH ? SRW_EB_WAVES : (SRW_EB_WAVES < 3 ? SRW_EB
       // SH: it.y = position in u's SORTED row of the membership structure, eb_off = the work list's own offsets (item_off)
       const Row ru = uniform_row(eb_urow<SH>(g, it.x));
       const int64_t e = ru.off + it.y;
-      const uint32_t vslot = uni(SH ? g.msids[e] : (uint32_t)((int64_t)g.ent[e].id - g.vmin));
-      const Row rv = uniform_row(g.rows[vslot]);
+      const Row rv = uniform_row(g.rows[SH ? (int64_t)g.msids[e] : (int64_t)g.ent[e].id - g.vmin]);
       const uint32_t tab_word = uni(eb_off[SH ? i : e]);
       Bias b;
       b.p = p; b.q = q; b.prev = (int32_t)((int64_t)it.x + g.vmin); b.second_order = true; b.need_member = true;
@@ -632,30 +379,6 @@ __global__ __launch_bounds__(TPB, SH ? SRW_EB_WAVES : (SRW_EB_WAVES < 3 ? SRW_EB
 #endif
       const PairGeom pg = eb_pair_geometry(rv.deg, ru.deg, pol);
       BinGeom gc; gc.csh = pg.csh; gc.n_bins = pg.n_bins;
-      if (!SH && fill_tune == 0 && eb_pair_role(ru, rv, it.x, vslot, sel) == 1) {
-        // this item builds (u -> v) and (v -> u) from one intersection
-        const PairGeom pgB = eb_pair_geometry(ru.deg, rv.deg, pol);
-        BinGeom gcB; gcB.csh = pgB.csh; gcB.n_bins = pgB.n_bins;
-        const BinGeom gfA = gc.csh < 6 ? gc : bin_geometry(rv.deg, 6, BIN_CAP), gfB = gcB.csh < 6 ? gcB : bin_geometry(ru.deg, 6, BIN_CAP);
-        double *binsA = reinterpret_cast<double *>(mine), *binsB = reinterpret_cast<double *>(mine + EB_LDS_WORDS);
-        uint32_t *mbA = pg.cmask ? mine + BIN_CAP : nullptr, *mbB = pgB.cmask ? mine + EB_LDS_WORDS + BIN_CAP : nullptr;
-        int32_t ret_lo = 0;
-        eb_fill_pair(g, ru, rv, it.x, vslot, p, q, binsA, gfA, mbA, binsB, gfB, mbB, mine + 2 * BIN_CAP, mine + EB_LDS_WORDS + 2 * BIN_CAP, ret_lo);
-        ns[5] += 1;
-#ifdef SRW_PHASE_TIMING
-        const unsigned long long t_fillp = wall_clock64();
-        tt[5] += t_fillp - t_hdr;
-#endif
-        // the reverse pair's table word: its entry is the first occurrence of u in v's sorted row (the pair's representative, eb_enum)
-        const uint32_t tab_word_B = uni(eb_off[rv.off + g.sperm[rv.off + ret_lo]]);
-        eb_write_table(g, rv, pol, pg, gfA, false, binsA, nullptr, mbA, eb_bins + (size_t)tab_word * 8, strat_count);
-        eb_write_table(g, ru, pol, pgB, gfB, false, binsB, nullptr, mbB, eb_bins + (size_t)tab_word_B * 8, strat_count);
-        __builtin_amdgcn_wave_barrier();          // the next fill clears the bins
-#ifdef SRW_PHASE_TIMING
-        tt[6] += wall_clock64() - t_fillp;
-#endif
-        continue;
-      }
       // more chunks than the wave's LDS holds bins for (the finer tables of the pairs with a long N(prev)): the bins live in this
       // wave's slice of an HBM scratch (exact f64 atomics: every partial sum is exact in any order) and are filled at the table's own granularity
       const bool big = gc.n_bins > BIN_CAP;
@@ -671,7 +394,48 @@ __global__ __launch_bounds__(TPB, SH ? SRW_EB_WAVES : (SRW_EB_WAVES < 3 ? SRW_EB
       const unsigned long long t_fill = wall_clock64();
       tt[2 + (su & 3)] += t_fill - t_hdr;              // su: 1 P1, 2 P2, 3 W, 4 P3 (-> slot 2)
 #endif
-      eb_write_table(g, rv, pol, pg, gf, big, reinterpret_cast<const double *>(mine), gbins, mbits, eb_bins + (size_t)tab_word * 8, strat_count);
+      const double *bins = reinterpret_cast<const double *>(mine);
+      double *out = eb_bins + (size_t)tab_word * 8;
+      const int up = gc.csh - gf.csh;
+      const PqRow PQ(g, rv.off);            // the table keeps the complete numerator A'_end(j) = PQ[end_j] + corrections
+      const bool as_f32 = pol.f32 && (rv.flags & ROW_PQ_F32);      // every such sum is exactly representable in binary32
+      const bool as_u16 = eb_pair_u16(rv.flags, gc.csh, pol);           // level 0 as the chunks' own masses, u16 multiples of the row's unit 2^G
+      const double inv_unit = as_u16 ? 1.0 / eb_row_unit(rv.flags) : 0.0;
+      const EbLayout lay = eb_layout(as_f32, gc.n_bins, pg.cmask, rv.deg, as_u16);
+      // level 0 = the chunk prefixes; level 1 / 2 = the last element of every block of 64 of the level below (the walk's search tree)
+      for (int L = 0; L < 3; ++L) {
+        const int32_t cnt = L == 0 ? gc.n_bins : L == 1 ? lay.n1 : lay.n2;
+        double *lo_ = out + (size_t)(L == 0 ? lay.l0_off : L == 1 ? lay.l1_off : lay.l2_off) * 8;
+        for (int32_t t = lane; t < cnt; t += 64) {
+          const int64_t je = (((int64_t)t + 1) << (6 * L)) - 1;
+          const int64_t j = je < gc.n_bins ? je : gc.n_bins - 1;          // the chunk this element is the prefix of
+          const int64_t fi = ((j + 1) << up) - 1;
+          const int64_t ke = ((j + 1) << gc.csh) - 1;
+          const int64_t fb = fi < gf.n_bins ? fi : gf.n_bins - 1;
+          const double corr = big ? __hip_atomic_load(gbins + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bins[fb];
+          const double a = PQ[ke < rv.deg ? ke : rv.deg - 1] + corr;
+          if (L == 0 && as_u16) {                  // the chunk's own mass = this prefix - the previous one (exact), in units of 2^G
+            double a0 = 0.0;
+            if (j > 0) {
+              const int64_t fp = (j << up) - 1, kp = (j << gc.csh) - 1;
+              a0 = PQ[kp] + (big ? __hip_atomic_load(gbins + fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bins[fp]);
+            }
+            const double du_ = (a - a0) * inv_unit;
+            const unsigned short q16 = (unsigned short)(du_ >= 0.0 && du_ <= 65535.0 ? du_ : 0.0);
+            if ((double)q16 != du_) atomicAdd(&strat_count[7], 1ull);         // must never happen (pq_row_u16_bits' bound)
+            reinterpret_cast<unsigned short *>(lo_)[t] = q16;
+          } else if (as_f32) {
+            reinterpret_cast<float *>(lo_)[t] = (float)a;
+            if ((double)(float)a != a) atomicAdd(&strat_count[7], 1ull);      // must never happen (pq_row_f32's bound)
+          } else lo_[t] = a;
+        }
+      }
+      if (mbits) {
+        unsigned long long *mo = reinterpret_cast<unsigned long long *>(out + (size_t)lay.cm_off * 8);
+        const int32_t n_mw = (rv.deg + 63) >> 6, n_w32 = (rv.deg + 31) >> 5;
+        for (int32_t t = lane; t < n_mw; t += 64)
+          mo[t] = (unsigned long long)mbits[2 * t] | ((2 * t + 1 < n_w32) ? ((unsigned long long)mbits[2 * t + 1] << 32) : 0ull);
+      }
       __builtin_amdgcn_wave_barrier();          // the next fill clears the bins
 #ifdef SRW_PHASE_TIMING
       tt[6] += wall_clock64() - t_fill;
@@ -766,7 +530,7 @@ size_t edge_tables_full_bytes(srw_handle *h, int mode, int bins_cap) {
   sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
   sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_cost = 0;
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
-  sel.has_ehash = 1; sel.has_hub = 1; sel.pair = 0;  // (they only move priorities, not sizes)
+  sel.has_ehash = 1; sel.has_hub = 1;               // (they only move priorities, not sizes)
   sel.pol = eb_policy(g, mode, bins_cap);
   DevBuf<unsigned long long> cursor, hist;
   cursor.alloc(1); hist.alloc(128);
@@ -805,8 +569,6 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   sel.pol = eb_policy(g, mode, bins_cap);
   g.ebp = sel.pol; g.eb_f32 = sel.pol.f32; g.eb_cap = bins_cap;
   sel.has_ehash = (g.has_ehash && g.use_ehash) ? 1 : 0; sel.has_hub = (g.has_hub && g.use_hub) ? 1 : 0;
-  // undirected loads: a pair and its reverse from one intersection (eb_fill_pair); SRW_EB_NO_PAIRING=1 builds every table on its own
-  { const char *e = getenv("SRW_EB_NO_PAIRING"); sel.pair = (g.symmetric && !(e && *e == '1') && !getenv("SRW_EB_FILL_TUNE")) ? 1 : 0; }
   g.eb_min_sh = sel.pol.min_sh;
   // budget: what is free now minus the offsets and a reserve for the walk's own buffers
   size_t free_b = 0, total_b = 0;
@@ -846,25 +608,21 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   hipLaunchKernelGGL((k_eb_rowsum<false>), dim3(blocks), dim3(TPB), 0, st, g.view(), ShardSel{0, 1}, sel, cursor.p,
                      row_units.p, row_munits.p, row_pairs.p);
   SRW_HIP(hipGetLastError());
-  unsigned long long n_listed = 0;          // work-list items: the pairs with a table minus those built by their reverse pair's item (eb_pair_role)
   {
-    SRW_HIP(hipMemsetAsync(row_pairs.p + g.n_slots, 0, 8, st));
     size_t tb = 0;
-    SRW_HIP(rocprim::exclusive_scan(nullptr, tb, row_pairs.p, row_pairs.p, 0ull, (size_t)g.n_slots + 1, rocprim::plus<unsigned long long>(), st));
+    SRW_HIP(rocprim::exclusive_scan(nullptr, tb, row_units.p, row_units.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
     DevBuf<char> temp; temp.alloc(tb);
     SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_units.p, row_units.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
     SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_munits.p, row_munits.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
-    SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_pairs.p, row_pairs.p, 0ull, (size_t)g.n_slots + 1, rocprim::plus<unsigned long long>(), st));
-    SRW_HIP(hipMemcpyAsync(&n_listed, row_pairs.p + g.n_slots, 8, hipMemcpyDeviceToHost, st));
+    SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, row_pairs.p, row_pairs.p, 0ull, (size_t)g.n_slots, rocprim::plus<unsigned long long>(), st));
     SRW_HIP(hipStreamSynchronize(st));
   }
   const unsigned long long all_pairs = pairs + mpairs;
-  if (n_listed > all_pairs) throw Error(SRW_ERR_INVALID, "per-edge tables: the work list is longer than the pairs with a table");
   const auto t_alloc0 = std::chrono::steady_clock::now();
   g.eb_off.ensure((size_t)g.n_entries);
   g.eb_bins.alloc((size_t)units * 8);
   g.em_bits.alloc((size_t)munits * 4);
-  DevBuf<uint2> items; items.alloc((size_t)std::max<unsigned long long>(n_listed, 1));
+  DevBuf<uint2> items; items.alloc((size_t)all_pairs);
   if (getenv("SRW_TIMING"))
     fprintf(stderr, "[edge tables] allocations (%.1f GB of tables, %.1f GB of masks, %.1f GB work list): %.0f ms; planning passes before them: %.0f ms\n",
             (double)units * 64 / 1e9, (double)munits * 16 / 1e9, (double)all_pairs * 8 / 1e9,
@@ -894,8 +652,8 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   if (all_pairs) {
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
     SRW_HIP(hipMemsetAsync(hist.p, 0, 16 * 8, st));
-    hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)n_listed, p, q, sel,
-                       g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0,
+    hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.mask_max,
+                       sel.pol, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0,
                        gscratch.p, gs_stride);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
@@ -920,9 +678,9 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
     fprintf(stderr, "[edge tables] chunks of >= %d candidates, chunk masks up to %d candidates (N(prev) > %d or deg(curr) <= %d deg(prev)), up to %d chunks for unmasked pairs with N(prev) > %d; ",
             1 << sel.pol.min_sh, sel.pol.cm_max, sel.pol.cm_min_du, sel.pol.cm_ratio, sel.pol.fine_cap ? sel.pol.fine_cap : sel.pol.cap, sel.pol.fine_min_du);
   if (getenv("SRW_TIMING"))
-    fprintf(stderr, "[edge tables] up to %d chunks per table; %llu bins tables (%.2f GB, min priority %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu, W for a pair and its reverse at once %llu) + %llu masks (%.2f GB) "
+    fprintf(stderr, "[edge tables] up to %d chunks per table; %llu bins tables (%.2f GB, min priority %lld; fill: P1 %llu, P2 %llu, W %llu, P3 %llu) + %llu masks (%.2f GB) "
             "+ inline masks (%.2f GB of offsets), built in %.0f ms\n", sel.pol.cap, pairs, (double)units * 64 / 1e9, (long long)sel.min_cost, sc[1], sc[2],
-            sc[3], sc[4], sc[5], mpairs, (double)munits * 16 / 1e9, (double)g.n_entries * 4 / 1e9, g.eb_build_ms);
+            sc[3], sc[4], mpairs, (double)munits * 16 / 1e9, (double)g.n_entries * 4 / 1e9, g.eb_build_ms);
 }
 
 // ---- the same tables on a vertex-sharded handle ------------------------------------------------------------------------
@@ -941,7 +699,7 @@ EbSel shard_sel(const Graph &g, int mode, int bins_cap) {
   sel.mask_max = mode ? 0 : MASK_MAX_DEG - 1;
   sel.min_deg = mode ? 1 : MASK_MAX_DEG; sel.min_cost = 0;
   { const char *e = getenv("SRW_EB_NO_MASKS"); if (e && *e == '1') sel.mask_max = 0; }
-  sel.has_ehash = 0; sel.has_hub = 1; sel.pair = 0; sel.pol = eb_policy(g, mode, bins_cap);
+  sel.has_ehash = 0; sel.has_hub = 1; sel.pol = eb_policy(g, mode, bins_cap);
   return sel;
 }
 
@@ -1016,8 +774,8 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
   if (all_pairs) {
     SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
     SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
-    hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel,
-                       item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0,
+    hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.mask_max,
+                       sel.pol, item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0,
                        gscratch.p, gs_stride);
     SRW_HIP(hipGetLastError());
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));

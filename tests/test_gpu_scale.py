@@ -140,8 +140,6 @@ _GEOMETRIES = [
     {"SRW_EB_CM_MAX": "0", "SRW_EB_FINE_CAP": "4096", "SRW_EB_FINE_MIN_DU": "0"},  # finer tables everywhere: two-level trees, HBM-scratch bins in the build
     {"SRW_EB_CM_MAX": "4096", "SRW_EB_FINE_CAP": "1024", "SRW_EB_NO_U16": "1"},
     {"SRW_EB_CHUNKS": "32", "SRW_EB_MIN_SH": "8"},                                # the coarse complete set of a graph that fills the GPU
-    {"SRW_EB_NO_PAIRING": "1"},                                                   # every table from its own intersection (default: a pair and its reverse from one)
-    {"SRW_EB_NO_PAIRING": "1", "SRW_EB_CM_MAX": "0"},
 ]
 
 
@@ -177,27 +175,39 @@ def test_table_geometries_give_the_same_paths(monkeypatch):
     assert sizes[str(_GEOMETRIES[2])][0] > sizes["default"][0], sizes      # masks on every pair cost bytes
 
 
-def test_paired_table_build_is_in_use():
-    """Undirected loads build (u -> v) and (v -> u) from one sorted-chunk intersection where both have a bins table (edge_tables.hip:
-    eb_fill_pair): the build's own count of such items must be positive on an RMAT graph, zero on a directed load and with
-    SRW_EB_NO_PAIRING=1 (the paths of all three forms are compared by the tests above and below)."""
-    import re, subprocess, sys
-    from conftest import ROOT
-    code = ("import sys; sys.path.insert(0, %r); import _pkg; P = _pkg.load(); e = P.Engine(0); "
-            "e.generate_rmat(16, 16 << 16, seed=5, weighted=True, directed=bool(int(sys.argv[1]))); "
-            "e.walk(p=0.25, q=4.0, walk_length=4, seed=1, fetch=False)" % ROOT)
-
-    def paired(directed, env):
-        r = subprocess.run([sys.executable, "-c", code, str(directed)], env=dict(os.environ, SRW_TIMING="1", **env),
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        m = re.search(r"W for a pair and its reverse at once (\d+)", r.stderr)
-        assert m, r.stderr[-2000:]
-        return int(m.group(1))
-
-    assert paired(0, {}) > 1000
-    assert paired(0, {"SRW_EB_NO_PAIRING": "1"}) == 0
-    assert paired(1, {}) == 0
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_tables_on_hubs_with_heavy_multi_edges(oracle, seed):
+    """Multi-edges through the per-edge tables against the oracle: eight hubs of ~6 000 entries over 3 000 shared leaves, every edge with a
+    random multiplicity 1 .. 5 (runs of equal ids in both sorted rows, some across the 1 024-id boundary of the staged chunks), hub <-> hub
+    multi-edges, self-loops on hubs and leaves, small integer weights.  A multi-edge is ONE pair: its entries share one table
+    (edge_tables.hip:eb_enum, k_eb_dups)."""
+    rng = np.random.default_rng(seed)
+    n_hub, n_leaf = 8, 3000
+    s, d = [], []
+    for h in range(n_hub):
+        leaves = n_hub + rng.choice(n_leaf, 2000, replace=False)
+        mult = rng.integers(1, 6, len(leaves))
+        s.append(np.full(int(mult.sum()), h)); d.append(np.repeat(leaves, mult))
+        for h2 in range(n_hub):                                # hub <-> hub, incl. self-loops (h2 == h)
+            m = int(rng.integers(0, 4))
+            s.append(np.full(m, h)); d.append(np.full(m, h2))
+    a = n_hub + rng.integers(0, n_leaf, 4000); b = n_hub + rng.integers(0, n_leaf, 4000)     # leaf - leaf, some self-loops
+    s.append(a); d.append(b)
+    s = np.concatenate(s).astype(np.int32); d = np.concatenate(d).astype(np.int32)
+    perm = rng.permutation(len(s)); s, d = s[perm], d[perm]                                  # input order is not sorted order
+    w = rng.integers(1, 9, len(s)).astype(np.float32)
+    g = oracle.Graph.from_coo(s, d, w, directed=False)
+    with pkg().Engine(device=0) as e:
+        e.load_coo(s, d, w, directed=False)
+        assert e.stats() == (g.num_vertices, g.num_entries)
+        verts = e.vertices()
+        for p, q in ((0.25, 4.0), (4.0, 0.5), (0.5, 2.0)):
+            rp, rl, _ = g.walk(p=p, q=q, walk_length=20, seed=77, threads=8)
+            paths, lens, st = e.walk(p=p, q=q, walk_length=20, seed=77)
+            assert np.array_equal(lens, rl), (p, q)
+            bad = np.nonzero((paths != rp).any(axis=1))[0]
+            assert bad.size == 0, (p, q, int(verts[bad[0]]), paths[bad[0]], rp[bad[0]])
+            assert st["strategy_steps"]["edge_table"] > 0, st
 
 
 def test_plan_walks_steers_the_tables_not_the_paths():

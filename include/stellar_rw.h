@@ -341,10 +341,24 @@ typedef struct {
  * vocab_ids[n_vocab] = the ids by descending count (ties: ascending id; minCount 0), vectors[n_vocab * dim]. */
 int32_t srw_w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, const srw_w2v_params *params,
                     int32_t **vocab_ids, float **vectors, int64_t *n_vocab);
+/* The same with the paths where srw_walk left them: in HBM (d_paths [n][stride], d_lens [n]: what srw_device_paths returns; both NULL =
+ * this handle's last walk result).  This is the reference's hand-over — `randomWalk(...)` feeds Word2Vec.fit without leaving the
+ * cluster (M/Main.scala:113-117): tokens are flattened, sorted, run-length encoded and ranked on the device; only the vocabulary's counts
+ * (for the Huffman tree) and the trained vectors cross PCIe. */
+int32_t srw_w2v_fit_device(srw_handle *h, const void *d_paths, const void *d_lens, int64_t n, int64_t stride, const srw_w2v_params *params,
+                           int32_t **vocab_ids, float **vectors, int64_t *n_vocab);
+/* Unit-test hook (host only, no GPU): word2vec.c's CreateBinaryTree as the trainer uses it.  counts[n_vocab] in descending order ->
+ * code_len[n_vocab], codes[n_vocab][40] (bits, root first), points[n_vocab][40] (rows of syn1 on the path, root = n_vocab - 2 first;
+ * -1 beyond the code).  Known answers: tests/test_w2v_known_answers.py. */
+int32_t srw_w2v_huffman(const int64_t *counts, int64_t n_vocab, int32_t *code_len, uint8_t *codes, int32_t *points);
 /* "<id>\t<v0>\t...\t<v_dim-1>" lines (Main.scala:88-91; floats printed as java.lang.Float.toString prints them) into
  * <output_dir>/vec/part-%05d + _SUCCESS, and a model directory <output_dir>/bin (metadata JSON + the same vectors as text: the
- * reference writes Spark's parquet there, which this build does not).  Fails if <output_dir>/vec exists. */
+ * reference writes Spark's parquet there, which this build does not).  As saveModelAndFeatures: the model first, then the vectors;
+ * fails before writing anything if <output_dir>/bin or <output_dir>/vec exists, and removes what it created if it fails midway. */
 int32_t srw_w2v_save(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int32_t n_parts);
+/* The same for a vocabulary of WORDS (`--cmd embedding` on a text whose tokens are not vertex ids: the reference's Word2Vec takes any
+ * token, M/Main.scala:119-124): words[r] is the NUL-terminated word of vocabulary row r. */
+int32_t srw_w2v_save_words(const char *const *words, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int32_t n_parts);
 
 /* ---- measurement hooks (bench.py's `roofline` object; not on the walk's path) ------------------------ */
 /* The ceiling the walk kernels are held against, measured on this handle's GPU in about a second: dependent, uniformly random

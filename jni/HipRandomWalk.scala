@@ -25,6 +25,11 @@ class HipRandomWalk(config: Params, seed: Int = 42, constR: Option[Float] = None
                                    partitioned: Boolean, rddPartitions: Int): Array[Long]
   @native private def walk(h: Long, p: Float, q: Float, walkLength: Int, iteration: Int,
                            constR: Float, useConst: Boolean, seed: Int): Long
+  @native private def walkAll(h: Long, p: Float, q: Float, walkLength: Int, numWalks: Int,
+                              constR: Float, useConst: Boolean, seed: Int): Long
+  @native private def planWalks(h: Long, numWalks: Long): Unit
+  @native private def w2vFitAndSave(h: Long, dim: Int, window: Int, iterations: Int, lr: Float, seed: Int, threads: Int,
+                                    output: String, parts: Int): Long
   @native private def writePaths(h: Long, output: String, parts: Int): Unit
   @native private def walkAndSave(h: Long, p: Float, q: Float, walkLength: Int, numWalks: Int,
                                   constR: Float, useConst: Boolean, seed: Int, output: String,
@@ -74,6 +79,30 @@ class HipRandomWalk(config: Params, seed: Int = 42, constR: Option[Float] = None
     println(s"vertices: $nVertices")
     for (_ <- 0 until config.numWalks) println("Unfinished Walkers: 0")
     if (dead > 0) println(s"Zero Neighbors: $dead")
+  }
+
+  /**
+    * `--cmd node2vec` (Main.scala:113-117): the walk, <output>/path, then Word2Vec on the paths — which stay in HBM between the two
+    * stages (the reference hands randomWalk's RDD to Word2Vec.fit without collecting it).  Vectors go to <output>/vec, the model
+    * directory to <output>/bin, as Main.saveModelAndFeatures (:36-44).  deterministic = one wave, sentence after sentence.
+    */
+  def node2vec(output: String, partitions: Int, deterministic: Boolean = false): Long = {
+    val h = create(device)
+    try {
+      val Array(v, e) = loadEdgeList(h, config.input, config.directed, config.weighted,
+        config.partitioned, config.rddPartitions)
+      nVertices = v
+      nEdges = e
+      println(s"edges: $nEdges")
+      println(s"vertices: $nVertices")
+      planWalks(h, config.numWalks)
+      walkAll(h, config.p.toFloat, config.q.toFloat, config.walkLength, config.numWalks,
+        constR.getOrElse(0f), constR.isDefined, seed)
+      for (_ <- 0 until config.numWalks) println("Unfinished Walkers: 0")
+      writePaths(h, output, partitions)
+      w2vFitAndSave(h, config.w2vDim, config.w2vWindow, config.w2vIter, config.w2vLr.toFloat, seed,
+        if (deterministic) 1 else 0, output, partitions)
+    } finally destroy(h)
   }
 
   /** randomWalk() with the paths returned to the JVM (e.g. to feed `--cmd node2vec`), one iteration at a time. */

@@ -89,6 +89,43 @@ JNIEXPORT jlong JNICALL FN(walk)(JNIEnv *env, jobject self, jlong hh, jfloat p, 
   return (jlong)st.n_steps;
 }
 
+/* all numWalks iterations in one call, paths kept in HBM (what `--cmd node2vec` hands to the embedding stage); returns the walk-steps */
+JNIEXPORT jlong JNICALL FN(walkAll)(JNIEnv *env, jobject self, jlong hh, jfloat p, jfloat q, jint walkLength,
+                                    jint numWalks, jfloat constR, jboolean useConst, jint seed) {
+  (void)self;
+  srw_walk_params P; fill_params(&P, p, q, walkLength, numWalks, 0, useConst, constR, seed, 0);
+  srw_walk_stats st;
+  const int32_t rc = srw_walk(H(hh), &P, &st);
+  if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return 0; }
+  return (jlong)st.n_steps;
+}
+
+/* the job's --numWalks for the table planners (srw_plan_walks): callers that walk one iteration per call announce the total */
+JNIEXPORT void JNICALL FN(planWalks)(JNIEnv *env, jobject self, jlong hh, jlong numWalks) {
+  (void)self;
+  const int32_t rc = srw_plan_walks(H(hh), (int64_t)numWalks);
+  if (rc != SRW_OK) throw_status(env, rc, H(hh));
+}
+
+/* Main.configureWord2Vec + Word2Vec.fit + saveModelAndFeatures (Main.scala:36-44,77-97) on the paths of the last walk WHERE THEY ARE
+ * (HBM: srw_w2v_fit_device), then <output>/bin and <output>/vec; returns the vocabulary size.  threads = 1: the deterministic form. */
+JNIEXPORT jlong JNICALL FN(w2vFitAndSave)(JNIEnv *env, jobject self, jlong hh, jint dim, jint window, jint iterations, jfloat lr,
+                                          jint seed, jint threads, jstring out, jint parts) {
+  (void)self;
+  srw_w2v_params wp; memset(&wp, 0, sizeof wp);
+  wp.dim = dim; wp.window = window; wp.iterations = iterations; wp.learning_rate = lr; wp.seed = (uint32_t)seed; wp.threads = threads;
+  int32_t *vocab = NULL; float *vec = NULL; int64_t nv = 0;
+  int32_t rc = srw_w2v_fit_device(H(hh), NULL, NULL, 0, 1, &wp, &vocab, &vec, &nv);
+  if (rc != SRW_OK) { throw_status(env, rc, H(hh)); return 0; }
+  const char *o = (*env)->GetStringUTFChars(env, out, NULL);
+  if (!o) { srw_free(vocab); srw_free(vec); return 0; }
+  rc = srw_w2v_save(vocab, vec, nv, dim, o, parts);
+  (*env)->ReleaseStringUTFChars(env, out, o);
+  srw_free(vocab); srw_free(vec);
+  if (rc != SRW_OK) { throw_status(env, rc == SRW_ERR_IO ? SRW_ERR_EXISTS : rc, NULL); return 0; }
+  return (jlong)nv;
+}
+
 /* RandomWalk.save of the last walk: <output>/path/part-* + _SUCCESS + Hadoop .crc side files */
 JNIEXPORT void JNICALL FN(writePaths)(JNIEnv *env, jobject self, jlong hh, jstring out, jint parts) {
   (void)self;

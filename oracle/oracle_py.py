@@ -86,6 +86,10 @@ def lib():
     L.orc_w2v_fit.argtypes = [i32p, i32p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint32,
                               C.POINTER(i32p), C.POINTER(f32p), C.POINTER(C.c_int64)]
     L.orc_free.argtypes = [C.c_void_p]
+    u8p = C.POINTER(C.c_uint8)
+    L.orc_w2v_huffman.argtypes = [C.POINTER(C.c_int64), C.c_int64, i32p, u8p, i32p]
+    L.orc_w2v_exp_table.argtypes = [f32p]
+    L.orc_w2v_pair_update.argtypes = [C.c_int32, f32p, f32p, u8p, C.c_int32, C.c_float]
     L.orc_rmat_edges.argtypes = [C.c_int, C.c_uint32, C.c_int64, C.c_int64, i32p, i32p]
     L.orc_rmat_weight.restype = C.c_float
     L.orc_rmat_weight.argtypes = [C.c_int32, C.c_int32, C.c_uint32]
@@ -341,3 +345,27 @@ def w2v_fit(paths, lens, dim=128, window=10, iterations=10, lr=0.025, seed=1):
     out_vec = np.ctypeslib.as_array(vec, shape=(max(n * dim, 1),))[:n * dim].copy().reshape(n, dim)
     lib().orc_free(ids); lib().orc_free(vec)
     return out_ids, out_vec
+
+
+def w2v_huffman(counts):
+    """word2vec.c CreateBinaryTree over counts in descending order -> list of (code bits, syn1 rows) per word, root first."""
+    cn = np.ascontiguousarray(counts, dtype=np.int64)
+    V = len(cn)
+    cl = np.zeros(V, np.int32); codes = np.zeros((V, 40), np.uint8); points = np.zeros((V, 40), np.int32)
+    lib().orc_w2v_huffman(cn.ctypes.data_as(C.POINTER(C.c_int64)), V, _i32(cl), codes.ctypes.data_as(C.POINTER(C.c_uint8)), _i32(points))
+    return [(codes[a, :cl[a]].tolist(), points[a, :cl[a]].tolist()) for a in range(V)]
+
+
+def w2v_exp_table():
+    t = np.zeros(1000, np.float32)
+    lib().orc_w2v_exp_table(_f32(t))
+    return t
+
+
+def w2v_pair_update(syn0_row, syn1_rows, code, alpha):
+    """One (centre, context) pair of skip-gram + hierarchical softmax: returns the updated (syn0 row, syn1 rows)."""
+    r0 = np.ascontiguousarray(syn0_row, dtype=np.float32).copy()
+    r1 = np.ascontiguousarray(syn1_rows, dtype=np.float32).copy()
+    cb = np.ascontiguousarray(code, dtype=np.uint8)
+    lib().orc_w2v_pair_update(r0.shape[0], _f32(r0), _f32(r1), cb.ctypes.data_as(C.POINTER(C.c_uint8)), r1.shape[0], C.c_float(alpha))
+    return r0, r1

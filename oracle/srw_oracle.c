@@ -891,6 +891,75 @@ static int w2v_cmp_word(const void *a, const void *b) {       /* count descendin
   if (x->cn != y->cn) return x->cn > y->cn ? -1 : 1;
   return (x->id > y->id) - (x->id < y->id);
 }
+/* --- the three pieces the known-answer tests pin (tests/test_w2v_known_answers.py), used by orc_w2v_fit below ------------------ */
+/* word2vec.c CreateBinaryTree: counts[V] in descending order -> codelen[V], code[V][40] (root first), point[V][41] (rows of syn1 on
+ * the path: point[.][0] = V - 2 = the root, then the inner nodes below it; entries beyond codelen are unused) */
+static void w2v_build_tree(const int64_t *cn, int64_t V, int32_t *codelen, uint8_t *code, int32_t *point) {
+  int64_t *count = (int64_t *)malloc(sizeof(int64_t) * (size_t)(2 * V + 1));
+  int32_t *parent = (int32_t *)calloc((size_t)(2 * V + 1), sizeof(int32_t));
+  uint8_t *binary = (uint8_t *)calloc((size_t)(2 * V + 1), 1);
+  for (int64_t a = 0; a < V; ++a) count[a] = cn[a];
+  for (int64_t a = V; a < 2 * V + 1; ++a) count[a] = (int64_t)1e15;
+  int64_t pos1 = V - 1, pos2 = V;
+  for (int64_t a = 0; a < V - 1; ++a) {
+    int64_t min1, min2;
+    if (pos1 >= 0) { if (count[pos1] < count[pos2]) { min1 = pos1; pos1--; } else { min1 = pos2; pos2++; } } else { min1 = pos2; pos2++; }
+    if (pos1 >= 0) { if (count[pos1] < count[pos2]) { min2 = pos1; pos1--; } else { min2 = pos2; pos2++; } } else { min2 = pos2; pos2++; }
+    count[V + a] = count[min1] + count[min2];
+    parent[min1] = (int32_t)(V + a); parent[min2] = (int32_t)(V + a);
+    binary[min2] = 1;
+  }
+  for (int64_t a = 0; a < V; ++a) {
+    uint8_t c[41]; int32_t p[41]; int i = 0; int64_t b = a;
+    for (;;) { c[i] = binary[b]; p[i] = (int32_t)b; i++; b = parent[b]; if (b == 2 * V - 2 || i >= 40) break; }
+    codelen[a] = i;
+    point[a * 41] = (int32_t)(V - 2);
+    for (int k = 0; k < i; ++k) { code[a * 40 + i - k - 1] = c[k]; point[a * 41 + i - k] = p[k] - (int32_t)V; }
+  }
+  free(count); free(parent); free(binary);
+}
+/* word2vec.c's expTable: sigmoid at 1 000 points of [-6, 6) */
+static void w2v_exp_table(float *t) {
+  for (int i = 0; i < 1000; ++i) { float e = (float)exp(((double)i / 1000 * 2.0 - 1.0) * 6.0); t[i] = e / (e + 1.0f); }
+}
+/* one (centre word, context word) pair of skip-gram + hierarchical softmax: r0 = syn0[context]; for every node d of the centre word's
+ * path (rows[d] = its row of syn1, code[d] its bit): f = r0 . r1; if |f| < 6: g = (1 - code - expTable[f]) * alpha; neu += g * r1 (the
+ * OLD r1); r1 += g * r0.  Then r0 += neu.  neu: dim floats of scratch. */
+static void w2v_pair(int32_t dim, float *r0, float *const *rows, const uint8_t *code, int32_t n_nodes, float alpha, const float *exp_table, float *neu) {
+  for (int32_t j = 0; j < dim; ++j) neu[j] = 0.0f;
+  for (int32_t d = 0; d < n_nodes; ++d) {
+    float *r1 = rows[d];
+    float f = 0.0f;
+    for (int32_t j = 0; j < dim; ++j) f += r0[j] * r1[j];
+    if (f > -6.0f && f < 6.0f) {
+      const int ind = (int)((f + 6.0f) * (1000.0f / 6.0f / 2.0f));
+      const float g = (1.0f - (float)code[d] - exp_table[ind]) * alpha;
+      for (int32_t j = 0; j < dim; ++j) neu[j] += g * r1[j];
+      for (int32_t j = 0; j < dim; ++j) r1[j] += g * r0[j];
+    }
+  }
+  for (int32_t j = 0; j < dim; ++j) r0[j] += neu[j];
+}
+/* the same three, exported for the known-answer tests */
+void orc_w2v_huffman(const int64_t *counts, int64_t V, int32_t *codelen, uint8_t *codes40, int32_t *points40) {
+  if (V < 2) { for (int64_t a = 0; a < V; ++a) codelen[a] = 0; return; }
+  int32_t *point = (int32_t *)malloc(sizeof(int32_t) * (size_t)V * 41);
+  w2v_build_tree(counts, V, codelen, codes40, point);
+  for (int64_t a = 0; a < V; ++a)
+    for (int k = 0; k < 40; ++k) points40[a * 40 + k] = k < codelen[a] ? point[a * 41 + k] : -1;
+  free(point);
+}
+void orc_w2v_exp_table(float *out1000) { w2v_exp_table(out1000); }
+void orc_w2v_pair_update(int32_t dim, float *syn0_row, float *syn1_rows /* [n_nodes][dim] */, const uint8_t *code, int32_t n_nodes, float alpha) {
+  float exp_table[1000];
+  w2v_exp_table(exp_table);
+  float **rows = (float **)malloc(sizeof(float *) * (size_t)(n_nodes ? n_nodes : 1));
+  for (int32_t d = 0; d < n_nodes; ++d) rows[d] = syn1_rows + (size_t)d * dim;
+  float *neu = (float *)malloc(sizeof(float) * (size_t)dim);
+  w2v_pair(dim, syn0_row, rows, code, n_nodes, alpha, exp_table, neu);
+  free(neu); free(rows);
+}
+
 /* paths [n][stride] / lens -> *n_vocab, vocab_ids (caller frees), vectors [n_vocab][dim] (caller frees). 0 on success. */
 int orc_w2v_fit(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, int32_t dim, int32_t window, int32_t iterations,
                 float lr, uint32_t seed, int32_t **vocab_ids_out, float **vectors_out, int64_t *n_vocab_out) {
@@ -927,34 +996,17 @@ int orc_w2v_fit(const int32_t *paths, const int32_t *lens, int64_t n, int64_t st
   int32_t *ids = (int32_t *)malloc(sizeof(int32_t) * (size_t)(V ? V : 1));
   for (int64_t r = 0; r < V; ++r) ids[r] = voc[r].id;
   if (V >= 2 && total > 0 && iterations > 0) {
-    /* CreateBinaryTree */
-    int64_t *count = (int64_t *)malloc(sizeof(int64_t) * (size_t)(2 * V + 1));
-    int32_t *parent = (int32_t *)calloc((size_t)(2 * V + 1), sizeof(int32_t));
-    uint8_t *binary = (uint8_t *)calloc((size_t)(2 * V + 1), 1);
-    for (int64_t a = 0; a < V; ++a) count[a] = voc[a].cn;
-    for (int64_t a = V; a < 2 * V + 1; ++a) count[a] = (int64_t)1e15;
-    int64_t pos1 = V - 1, pos2 = V;
-    for (int64_t a = 0; a < V - 1; ++a) {
-      int64_t min1, min2;
-      if (pos1 >= 0) { if (count[pos1] < count[pos2]) { min1 = pos1; pos1--; } else { min1 = pos2; pos2++; } } else { min1 = pos2; pos2++; }
-      if (pos1 >= 0) { if (count[pos1] < count[pos2]) { min2 = pos1; pos1--; } else { min2 = pos2; pos2++; } } else { min2 = pos2; pos2++; }
-      count[V + a] = count[min1] + count[min2];
-      parent[min1] = (int32_t)(V + a); parent[min2] = (int32_t)(V + a);
-      binary[min2] = 1;
-    }
+    int64_t *cn = (int64_t *)malloc(sizeof(int64_t) * (size_t)V);
+    for (int64_t a = 0; a < V; ++a) cn[a] = voc[a].cn;
     int32_t *codelen = (int32_t *)malloc(sizeof(int32_t) * (size_t)V);
     uint8_t *code = (uint8_t *)malloc((size_t)V * 40);
     int32_t *point = (int32_t *)malloc(sizeof(int32_t) * (size_t)V * 41);
-    for (int64_t a = 0; a < V; ++a) {
-      uint8_t c[41]; int32_t p[41]; int i = 0; int64_t b = a;
-      for (;;) { c[i] = binary[b]; p[i] = (int32_t)b; i++; b = parent[b]; if (b == 2 * V - 2 || i >= 40) break; }
-      codelen[a] = i;
-      point[a * 41] = (int32_t)(V - 2);
-      for (int k = 0; k < i; ++k) { code[a * 40 + i - k - 1] = c[k]; point[a * 41 + i - k] = p[k] - (int32_t)V; }
-    }
+    w2v_build_tree(cn, V, codelen, code, point);
+    free(cn);
     float exp_table[1000];
-    for (int i = 0; i < 1000; ++i) { float e = (float)exp(((double)i / 1000 * 2.0 - 1.0) * 6.0); exp_table[i] = e / (e + 1.0f); }
+    w2v_exp_table(exp_table);
     float *neu = (float *)malloc(sizeof(float) * (size_t)dim);
+    float *rows[40];
     for (int32_t k = 0; k < iterations; ++k) {
       int64_t off = 0;
       for (int64_t s = 0; s < n; ++s) {
@@ -965,30 +1017,18 @@ int orc_w2v_fit(const int32_t *paths, const int32_t *lens, int64_t n, int64_t st
         for (int32_t pos = 0; pos < len; ++pos) {
           const int32_t word = sent[off + pos];
           const int32_t b = (int32_t)(w2v_hash(seed, (uint32_t)k, (uint32_t)s, (uint32_t)pos) % (uint32_t)window);
+          for (int32_t d = 0; d < codelen[word]; ++d) rows[d] = syn1 + (int64_t)point[word * 41 + d] * dim;
           for (int32_t a = b; a < window * 2 + 1 - b; ++a) {
             if (a == window) continue;
             const int32_t c = pos - window + a;
             if (c < 0 || c >= len) continue;
-            float *r0 = syn0 + (int64_t)sent[off + c] * dim;
-            for (int32_t j = 0; j < dim; ++j) neu[j] = 0.0f;
-            for (int32_t d = 0; d < codelen[word]; ++d) {
-              float *r1 = syn1 + (int64_t)point[word * 41 + d] * dim;
-              float f = 0.0f;
-              for (int32_t j = 0; j < dim; ++j) f += r0[j] * r1[j];
-              if (f > -6.0f && f < 6.0f) {
-                const int ind = (int)((f + 6.0f) * (1000.0f / 6.0f / 2.0f));
-                const float g = (1.0f - (float)code[word * 40 + d] - exp_table[ind]) * alpha;
-                for (int32_t j = 0; j < dim; ++j) neu[j] += g * r1[j];
-                for (int32_t j = 0; j < dim; ++j) r1[j] += g * r0[j];
-              }
-            }
-            for (int32_t j = 0; j < dim; ++j) r0[j] += neu[j];
+            w2v_pair(dim, syn0 + (int64_t)sent[off + c] * dim, rows, code + (size_t)word * 40, codelen[word], alpha, exp_table, neu);
           }
         }
         off += len;
       }
     }
-    free(neu); free(codelen); free(code); free(point); free(count); free(parent); free(binary);
+    free(neu); free(codelen); free(code); free(point);
   }
   free(sent); free(syn1); free(voc);
   *vocab_ids_out = ids; *vectors_out = syn0; *n_vocab_out = V;

@@ -119,6 +119,9 @@ int orc_write_paths(const int32_t *paths, const int32_t *lens, int64_t n_walkers
 
 /* ---- the embedding stage (`--cmd node2vec`; MLlib Word2Vec is absent from the reference tree: PARITY UNPINNED) ------------------
  * Sequential skip-gram + hierarchical softmax with the build's seeded draws; see srw_oracle.c.  Outputs malloc'ed: orc_free. */
+void orc_w2v_huffman(const int64_t *counts, int64_t V, int32_t *codelen, uint8_t *codes40, int32_t *points40);
+void orc_w2v_exp_table(float *out1000);
+void orc_w2v_pair_update(int32_t dim, float *syn0_row, float *syn1_rows, const uint8_t *code, int32_t n_nodes, float alpha);
 int orc_w2v_fit(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, int32_t dim, int32_t window, int32_t iterations,
                 float lr, uint32_t seed, int32_t **vocab_ids_out, float **vectors_out, int64_t *n_vocab_out);
 void orc_free(void *p);

@@ -93,7 +93,7 @@ EXPORTS = [
     "srw_shard_rows_commit", "srw_shard_rows_release", "srw_device_alloc", "srw_device_free", "srw_cluster_create", "srw_cluster_destroy", "srw_cluster_last_error",
     "srw_cluster_shard", "srw_cluster_load_edgelist", "srw_cluster_load_coo", "srw_cluster_generate_rmat",
     "srw_cluster_graph_stats", "srw_cluster_walk", "srw_cluster_fetch_paths", "srw_cluster_walk_and_save",
-    "srw_shard_select", "srw_w2v_fit", "srw_w2v_save", "srw_probe_request_rate", "srw_result_scan_sums", "srw_sample", "srw_second_order_weights",
+    "srw_shard_select", "srw_w2v_fit", "srw_w2v_fit_device", "srw_w2v_huffman", "srw_w2v_save", "srw_w2v_save_words", "srw_probe_request_rate", "srw_result_scan_sums", "srw_sample", "srw_second_order_weights",
     "srw_second_order_sample", "srw_rng_uniform", "srw_parse_edgelist", "srw_free", "srw_save_paths", "srw_table_geometry", "srw_version",
 ]
 
@@ -167,6 +167,8 @@ def lib():
     L.srw_cluster_walk_and_save.argtypes = [vp, C.POINTER(WalkParams), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(WalkStats)]
     L.srw_shard_select.argtypes = [vp, C.c_int32]
     L.srw_w2v_fit.argtypes = [vp, i32p, i32p, C.c_int64, C.c_int64, C.POINTER(W2vParams), C.POINTER(i32p), C.POINTER(f32p), C.POINTER(C.c_int64)]
+    L.srw_w2v_fit_device.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.POINTER(W2vParams), C.POINTER(i32p), C.POINTER(f32p), C.POINTER(C.c_int64)]
+    L.srw_w2v_huffman.argtypes = [C.POINTER(C.c_int64), C.c_int64, i32p, C.POINTER(C.c_uint8), i32p]
     L.srw_w2v_save.argtypes = [i32p, f32p, C.c_int64, C.c_int32, C.c_char_p, C.c_int32]
     L.srw_probe_request_rate.argtypes = [vp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.srw_result_scan_sums.argtypes = [vp, i64p]
@@ -448,6 +450,17 @@ class Engine:
         lib().srw_free(ids); lib().srw_free(vec)
         return out_ids, out_vec
 
+    def w2v_fit_device(self, dim=128, window=10, iterations=10, lr=0.025, seed=1, threads=0):
+        """The same over the LAST WALK's paths where they are — in HBM (srw_w2v_fit_device with NULL pointers): no PCIe round trip."""
+        P = W2vParams(dim, window, iterations, lr, seed, threads)
+        ids, vec, nv = C.POINTER(C.c_int32)(), C.POINTER(C.c_float)(), C.c_int64(0)
+        self._ck(lib().srw_w2v_fit_device(self.h, None, None, 0, 1, C.byref(P), C.byref(ids), C.byref(vec), C.byref(nv)))
+        k = nv.value
+        out_ids = np.ctypeslib.as_array(ids, shape=(max(k, 1),))[:k].copy()
+        out_vec = np.ctypeslib.as_array(vec, shape=(max(k * dim, 1),))[:k * dim].copy().reshape(k, dim)
+        lib().srw_free(ids); lib().srw_free(vec)
+        return out_ids, out_vec
+
     # ---- measurement hooks (bench.py's roofline object) ----
     def probe_request_rate(self, table_bytes=0):
         """(dependent random 16-byte reads per second on this GPU, GiB of table used) — csrc/probe.hip."""
@@ -494,6 +507,17 @@ class Engine:
         self._ck(lib().srw_rng_uniform(self.h, seed, it.ctypes.data_as(u32p), src.ctypes.data_as(u32p),
                                        step.ctypes.data_as(u32p), len(it), _f32(out)))
         return out
+
+
+def w2v_huffman(counts):
+    """srw_w2v_huffman (host only): [(code bits, syn1 rows)] per word of a vocabulary given by its counts in descending order."""
+    cn = np.ascontiguousarray(counts, dtype=np.int64)
+    V = len(cn)
+    cl = np.zeros(max(V, 1), np.int32); codes = np.zeros((max(V, 1), 40), np.uint8); points = np.zeros((max(V, 1), 40), np.int32)
+    rc = lib().srw_w2v_huffman(cn.ctypes.data_as(C.POINTER(C.c_int64)), V, _i32(cl), codes.ctypes.data_as(C.POINTER(C.c_uint8)), _i32(points))
+    if rc != OK:
+        raise SrwError(rc, lib().srw_last_error(None).decode())
+    return [(codes[a, :cl[a]].tolist(), points[a, :cl[a]].tolist()) for a in range(V)]
 
 
 class Cluster:

@@ -536,9 +536,44 @@ int32_t srw_w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, in
   });
 }
 
+int32_t srw_w2v_fit_device(srw_handle *h, const void *d_paths, const void *d_lens, int64_t n, int64_t stride, const srw_w2v_params *params,
+                           int32_t **vocab_ids, float **vectors, int64_t *n_vocab) {
+  if (!h) return SRW_ERR_INVALID;
+  return guarded(h, [&] {
+    need(params && vocab_ids && vectors && n_vocab && stride >= 1 && n >= 0, "null or bad argument");
+    const int32_t *dp = (const int32_t *)d_paths, *dl = (const int32_t *)d_lens;
+    if (!dp && !dl) {                       // the handle's own last walk (srw_device_paths)
+      if (!h->res.valid) throw Error(SRW_ERR_INVALID, "srw_w2v_fit_device: no walk result on this handle");
+      dp = h->res.paths.p; dl = h->res.lens.p; n = h->res.n_walkers; stride = h->res.stride;
+    }
+    need(dp && dl, "null device pointer");
+    std::vector<int32_t> ids; std::vector<float> vec;
+    w2v_fit_device(h, dp, dl, n, stride, *params, ids, vec);
+    *n_vocab = (int64_t)ids.size();
+    *vocab_ids = (int32_t *)malloc(std::max<size_t>(ids.size() * 4, 1));
+    *vectors = (float *)malloc(std::max<size_t>(vec.size() * 4, 1));
+    if (!*vocab_ids || !*vectors) throw Error(SRW_ERR_NOMEM, "host allocation failed");
+    memcpy(*vocab_ids, ids.data(), ids.size() * 4); memcpy(*vectors, vec.data(), vec.size() * 4);
+  });
+}
+
+int32_t srw_w2v_huffman(const int64_t *counts, int64_t n_vocab, int32_t *code_len, uint8_t *codes, int32_t *points) {
+  if (!counts || !code_len || !codes || !points || n_vocab < 0) return SRW_ERR_INVALID;
+  try { w2v_huffman(counts, n_vocab, code_len, codes, points); return SRW_OK; }
+  catch (const Error &e) { set_create_error(e.what()); return e.code; }
+  catch (const std::exception &e) { set_create_error(e.what()); return SRW_ERR_INVALID; }
+}
+
 int32_t srw_w2v_save(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int32_t n_parts) {
   if (!output_dir || n_vocab < 0 || dim < 1 || (n_vocab > 0 && (!vocab_ids || !vectors))) return SRW_ERR_INVALID;
   try { write_vectors(vocab_ids, vectors, n_vocab, dim, output_dir, n_parts); return SRW_OK; }
+  catch (const Error &e) { set_create_error(e.what()); return e.code; }
+  catch (const std::exception &e) { set_create_error(e.what()); return SRW_ERR_INVALID; }
+}
+
+int32_t srw_w2v_save_words(const char *const *words, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int32_t n_parts) {
+  if (!output_dir || n_vocab < 0 || dim < 1 || (n_vocab > 0 && (!words || !vectors))) return SRW_ERR_INVALID;
+  try { write_vectors_words(words, vectors, n_vocab, dim, output_dir, n_parts); return SRW_OK; }
   catch (const Error &e) { set_create_error(e.what()); return e.code; }
   catch (const std::exception &e) { set_create_error(e.what()); return SRW_ERR_INVALID; }
 }

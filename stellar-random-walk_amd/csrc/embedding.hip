@@ -23,6 +23,8 @@
 #include <numeric>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "engine.h"
 #include "wave_primitives.h"
 
@@ -150,80 +152,181 @@ void huffman(const std::vector<int64_t> &cn, std::vector<int32_t> &code_off, std
     }
   }
 }
+// ---- vocabulary and sentences on the device ----------------------------------------------------------------------------------
+// The reference hands the walk's RDD straight to Word2Vec.fit (M/Main.scala:113-117); here the paths of srw_walk are in HBM already
+// (srw_device_paths) and stay there: lengths -> sentence offsets (scan), tokens flattened, sorted (radix) and run-length encoded into
+// (id, count), ordered by descending count (stable: ties by ascending id — minCount 0, Main.scala:41), every token replaced by its
+// vocabulary index by a search in the sorted ids.  Only the counts travel to the host (the Huffman tree is a sequential O(V) pass).
+__global__ void k_w2v_len64(const int32_t *__restrict__ lens, int64_t n, int64_t stride, long long *__restrict__ out, uint32_t *bad) {
+  const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (w > n) return;
+  int32_t l = w < n ? lens[w] : 0;
+  if (l < 0 || l > stride) { atomicOr(bad, 1u); l = 0; }
+  out[w] = l;
+}
+__global__ __launch_bounds__(TPB) void k_w2v_flatten(const int32_t *__restrict__ paths, const long long *__restrict__ off, int64_t n, int64_t stride,
+                                                     int32_t *__restrict__ flat) {
+  const int lane = lane_id();
+  const int64_t w = blockIdx.x * (int64_t)(TPB / 64) + (threadIdx.x >> 6);
+  if (w >= n) return;
+  const int64_t o0 = off[w], len = off[w + 1] - o0;
+  for (int64_t k = lane; k < len; k += 64) flat[o0 + k] = paths[w * stride + k];
+}
+__global__ void k_w2v_rank(const int32_t *__restrict__ order, const int32_t *__restrict__ uniq, int64_t V, int32_t *__restrict__ rank_of,
+                           int32_t *__restrict__ vocab) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= V) return;
+  const int32_t u = order[r];
+  rank_of[u] = (int32_t)r; vocab[r] = uniq[u];
+}
+__global__ void k_w2v_remap(int32_t *__restrict__ flat, int64_t total, const int32_t *__restrict__ uniq, int64_t V, const int32_t *__restrict__ rank_of) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int32_t x = flat[i];
+  int64_t lo = 0, hi = V - 1;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (uniq[mid] < x) lo = mid + 1; else hi = mid; }
+  flat[i] = rank_of[lo];
+}
+__global__ void k_w2v_init(float *__restrict__ syn0, int64_t V, int32_t dim, uint32_t seed) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= V * dim) return;
+  const uint32_t r = (uint32_t)(i / dim), j = (uint32_t)(i % dim);
+  syn0[i] = ((float)(w2v_hash(seed, 0xA11CEu, r, j) >> 8) * (1.0f / 16777216.0f) - 0.5f) / (float)dim;
+}
 }  // namespace
 
-// paths [n][stride] (ids, lens) on the HOST -> vocabulary (ids by descending count, ties by ascending id) + vectors [vocab][dim]
-void w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, const srw_w2v_params &P,
-             std::vector<int32_t> &vocab_ids, std::vector<float> &vectors) {
+// paths [n][stride] (ids, lens) in HBM -> vocabulary (ids by descending count, ties by ascending id) + vectors [vocab][dim]
+void w2v_fit_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens, int64_t n, int64_t stride, const srw_w2v_params &P,
+                    std::vector<int32_t> &vocab_ids, std::vector<float> &vectors) {
   if (P.dim < 1 || P.dim > 1024 || P.window < 1 || P.iterations < 0 || !(P.learning_rate > 0.0f))
     throw Error(SRW_ERR_INVALID, "word2vec: dim in 1..1024, window >= 1, iterations >= 0, learning rate > 0");
   hipStream_t st = h->stream;
-  // vocabulary: every id that occurs (minCount 0, Main.scala:41), most frequent first
-  std::vector<int32_t> all;
-  int64_t total = 0;
-  for (int64_t w = 0; w < n; ++w) {
-    if (lens[w] < 0 || lens[w] > stride) throw Error(SRW_ERR_INVALID, "word2vec: a path length outside [0, stride]");
-    total += lens[w];
+  vocab_ids.clear(); vectors.clear();
+  // sentence offsets
+  DevBuf<long long> d_off; d_off.alloc((size_t)n + 1);
+  DevBuf<uint32_t> d_bad; d_bad.alloc(1);
+  SRW_HIP(hipMemsetAsync(d_bad.p, 0, 4, st));
+  hipLaunchKernelGGL(k_w2v_len64, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, d_lens, n, stride, d_off.p, d_bad.p);
+  SRW_HIP(hipGetLastError());
+  DevBuf<char> temp; size_t tb = 0;
+  SRW_HIP(rocprim::exclusive_scan(nullptr, tb, d_off.p, d_off.p, 0ll, (size_t)n + 1, rocprim::plus<long long>(), st));
+  temp.alloc(tb);
+  SRW_HIP(rocprim::exclusive_scan((void *)temp.p, tb, d_off.p, d_off.p, 0ll, (size_t)n + 1, rocprim::plus<long long>(), st));
+  long long total = 0; uint32_t bad = 0;
+  SRW_HIP(hipMemcpyAsync(&total, d_off.p + n, 8, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  if (bad) throw Error(SRW_ERR_INVALID, "word2vec: a path length outside [0, stride]");
+  if (total >= (long long)0xFFFFFFF0ll) throw Error(SRW_ERR_INVALID, "word2vec: more than 2^32 tokens in one fit");
+  if (total == 0) return;
+  // tokens, sorted tokens, (id, count)
+  DevBuf<int32_t> d_sent, d_sorted, d_uniq; DevBuf<unsigned int> d_cnt, d_runs;
+  d_sent.alloc((size_t)total); d_sorted.alloc((size_t)total);
+  hipLaunchKernelGGL(k_w2v_flatten, dim3((unsigned)((n + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0, st, d_paths, d_off.p, n, stride, d_sent.p);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(rocprim::radix_sort_keys(nullptr, tb, d_sent.p, d_sorted.p, (size_t)total, 0, 32, st));
+  temp.alloc(tb);
+  SRW_HIP(rocprim::radix_sort_keys((void *)temp.p, tb, d_sent.p, d_sorted.p, (size_t)total, 0, 32, st));
+  // (the number of distinct ids is not known before the encode: room for one run per token, released below)
+  d_uniq.alloc((size_t)total); d_cnt.alloc((size_t)total); d_runs.alloc(1);
+  SRW_HIP(rocprim::run_length_encode(nullptr, tb, d_sorted.p, (unsigned int)total, d_uniq.p, d_cnt.p, d_runs.p, st));
+  temp.alloc(tb);
+  SRW_HIP(rocprim::run_length_encode((void *)temp.p, tb, d_sorted.p, (unsigned int)total, d_uniq.p, d_cnt.p, d_runs.p, st));
+  unsigned int runs = 0;
+  SRW_HIP(hipMemcpyAsync(&runs, d_runs.p, 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  d_sorted.release();
+  const int64_t V = (int64_t)runs;
+  // vocabulary order: count descending, ties by ascending id (a stable sort of the id-ordered runs)
+  DevBuf<unsigned int> d_cnt_s; DevBuf<int32_t> d_iota, d_order, d_rank, d_vocab;
+  d_cnt_s.alloc((size_t)V); d_iota.alloc((size_t)V); d_order.alloc((size_t)V); d_rank.alloc((size_t)V); d_vocab.alloc((size_t)V);
+  {
+    std::vector<int32_t> iota((size_t)V);
+    std::iota(iota.begin(), iota.end(), 0);
+    SRW_HIP(hipMemcpyAsync(d_iota.p, iota.data(), (size_t)V * 4, hipMemcpyHostToDevice, st));
+    SRW_HIP(rocprim::radix_sort_pairs_desc(nullptr, tb, d_cnt.p, d_cnt_s.p, d_iota.p, d_order.p, (size_t)V, 0, 32, st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::radix_sort_pairs_desc((void *)temp.p, tb, d_cnt.p, d_cnt_s.p, d_iota.p, d_order.p, (size_t)V, 0, 32, st));
+    SRW_HIP(hipStreamSynchronize(st));      // (iota is a host vector)
   }
-  all.reserve((size_t)total);
-  for (int64_t w = 0; w < n; ++w) for (int32_t k = 0; k < lens[w]; ++k) all.push_back(paths[w * stride + k]);
-  std::vector<int32_t> uniq(all);
-  std::sort(uniq.begin(), uniq.end());
-  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-  const int64_t V = (int64_t)uniq.size();
-  std::vector<int64_t> cnt((size_t)V, 0);
-  std::vector<int32_t> idx((size_t)total);
-  for (int64_t i = 0; i < total; ++i) {
-    const int32_t u = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), all[(size_t)i]) - uniq.begin());
-    idx[(size_t)i] = u; cnt[(size_t)u]++;
-  }
-  std::vector<int32_t> order((size_t)V);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt[(size_t)a] > cnt[(size_t)b]; });   // ties: ascending id
-  std::vector<int32_t> rank((size_t)V);
-  std::vector<int64_t> cn((size_t)V);
+  hipLaunchKernelGGL(k_w2v_rank, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d_order.p, d_uniq.p, V, d_rank.p, d_vocab.p);
+  SRW_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_w2v_remap, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_sent.p, (int64_t)total, d_uniq.p, V, d_rank.p);
+  SRW_HIP(hipGetLastError());
   vocab_ids.resize((size_t)V);
-  for (int64_t r = 0; r < V; ++r) { rank[(size_t)order[(size_t)r]] = (int32_t)r; cn[(size_t)r] = cnt[(size_t)order[(size_t)r]]; vocab_ids[(size_t)r] = uniq[(size_t)order[(size_t)r]]; }
-  for (int64_t i = 0; i < total; ++i) idx[(size_t)i] = rank[(size_t)idx[(size_t)i]];
-  vectors.assign((size_t)V * (size_t)P.dim, 0.0f);
-  for (int64_t r = 0; r < V; ++r)
-    for (int32_t j = 0; j < P.dim; ++j)
-      vectors[(size_t)r * P.dim + j] = ((float)(w2v_hash(P.seed, 0xA11CEu, (uint32_t)r, (uint32_t)j) >> 8) * (1.0f / 16777216.0f) - 0.5f) / (float)P.dim;
-  if (V < 2 || total == 0 || P.iterations == 0) return;
+  std::vector<unsigned int> cnt_h((size_t)V);
+  SRW_HIP(hipMemcpyAsync(vocab_ids.data(), d_vocab.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipMemcpyAsync(cnt_h.data(), d_cnt_s.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+  DevBuf<float> d_syn0, d_syn1;
+  d_syn0.alloc((size_t)V * P.dim); d_syn1.alloc((size_t)V * P.dim);
+  hipLaunchKernelGGL(k_w2v_init, dim3((unsigned)(((int64_t)V * P.dim + 255) / 256)), dim3(256), 0, st, d_syn0.p, V, P.dim, P.seed);
+  SRW_HIP(hipGetLastError());
+  SRW_HIP(hipMemsetAsync(d_syn1.p, 0, (size_t)V * P.dim * 4, st));
+  SRW_HIP(hipStreamSynchronize(st));
+  d_uniq.release(); d_cnt.release(); d_iota.release(); d_order.release(); d_rank.release(); d_vocab.release(); d_cnt_s.release();
+  vectors.resize((size_t)V * (size_t)P.dim);
+  if (V >= 2 && P.iterations > 0) {
+    std::vector<int64_t> cn((size_t)V);
+    for (int64_t r = 0; r < V; ++r) cn[(size_t)r] = (int64_t)cnt_h[(size_t)r];
+    std::vector<int32_t> code_off, points; std::vector<uint8_t> codes;
+    huffman(cn, code_off, points, codes);
+    DevBuf<int32_t> d_coff, d_points; DevBuf<uint8_t> d_codes;
+    d_coff.alloc((size_t)V + 1); d_points.alloc(std::max<size_t>(points.size(), 1)); d_codes.alloc(std::max<size_t>(codes.size(), 1));
+    SRW_HIP(hipMemcpyAsync(d_coff.p, code_off.data(), ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
+    SRW_HIP(hipMemcpyAsync(d_points.p, points.data(), points.size() * 4, hipMemcpyHostToDevice, st));
+    SRW_HIP(hipMemcpyAsync(d_codes.p, codes.data(), codes.size(), hipMemcpyHostToDevice, st));
+    W2vDev d;
+    d.sent_off = reinterpret_cast<const int64_t *>(d_off.p); d.sent = d_sent.p; d.n_sent = n; d.words_before = reinterpret_cast<const int64_t *>(d_off.p);
+    d.code_off = d_coff.p; d.points = d_points.p; d.codes = d_codes.p;
+    d.syn0 = d_syn0.p; d.syn1 = d_syn1.p; d.dim = P.dim; d.window = P.window; d.seed = P.seed; d.n_iter = P.iterations; d.total_words = total; d.lr = P.learning_rate;
+    // threads == 1: ONE wave walks the sentences in order (the sequential form the oracle restates); else one wave per sentence, Hogwild
+    const int64_t n_waves = P.threads == 1 ? 1 : std::min<int64_t>(std::max<int64_t>(n, 1), (int64_t)h->n_cus * 32);
+    const int blocks = (int)((n_waves + TPB / 64 - 1) / (TPB / 64));
+    const int nd = (P.dim + 63) / 64;
+    for (int32_t k = 0; k < P.iterations; ++k) {
+      d.iter = k;
+      const dim3 grid(P.threads == 1 ? 1 : blocks), block(P.threads == 1 ? 64 : TPB);
+      if (nd <= 1) hipLaunchKernelGGL(k_w2v_train<1>, grid, block, 0, st, d, n_waves);
+      else if (nd <= 2) hipLaunchKernelGGL(k_w2v_train<2>, grid, block, 0, st, d, n_waves);
+      else if (nd <= 4) hipLaunchKernelGGL(k_w2v_train<4>, grid, block, 0, st, d, n_waves);
+      else if (nd <= 8) hipLaunchKernelGGL(k_w2v_train<8>, grid, block, 0, st, d, n_waves);
+      else hipLaunchKernelGGL(k_w2v_train<16>, grid, block, 0, st, d, n_waves);
+      SRW_HIP(hipGetLastError());
+    }
+    SRW_HIP(hipMemcpyAsync(vectors.data(), d_syn0.p, vectors.size() * 4, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+  } else {
+    SRW_HIP(hipMemcpyAsync(vectors.data(), d_syn0.p, vectors.size() * 4, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+  }
+}
+
+// test hook: the codes (code_len[V], codes[V][40], points[V][40]: inner-node rows of syn1, root first) of a vocabulary by its counts
+void w2v_huffman(const int64_t *counts, int64_t n_vocab, int32_t *code_len, uint8_t *codes_out, int32_t *points_out) {
+  std::vector<int64_t> cn(counts, counts + n_vocab);
+  for (int64_t a = 1; a < n_vocab; ++a) if (cn[(size_t)a] > cn[(size_t)a - 1]) throw Error(SRW_ERR_INVALID, "word2vec: counts must be in descending order");
   std::vector<int32_t> code_off, points; std::vector<uint8_t> codes;
   huffman(cn, code_off, points, codes);
-  std::vector<int64_t> sent_off((size_t)n + 1, 0), before((size_t)n + 1, 0);
-  for (int64_t w = 0; w < n; ++w) { sent_off[(size_t)w + 1] = sent_off[(size_t)w] + lens[w]; before[(size_t)w + 1] = sent_off[(size_t)w + 1]; }
-  DevBuf<int64_t> d_off, d_before; DevBuf<int32_t> d_sent, d_coff, d_points; DevBuf<uint8_t> d_codes; DevBuf<float> d_syn0, d_syn1;
-  d_off.alloc((size_t)n + 1); d_before.alloc((size_t)n + 1); d_sent.alloc((size_t)std::max<int64_t>(total, 1));
-  d_coff.alloc((size_t)V + 1); d_points.alloc(std::max<size_t>(points.size(), 1)); d_codes.alloc(std::max<size_t>(codes.size(), 1));
-  d_syn0.alloc((size_t)V * P.dim); d_syn1.alloc((size_t)V * P.dim);
-  SRW_HIP(hipMemcpyAsync(d_off.p, sent_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
-  SRW_HIP(hipMemcpyAsync(d_before.p, before.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
-  SRW_HIP(hipMemcpyAsync(d_sent.p, idx.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
-  SRW_HIP(hipMemcpyAsync(d_coff.p, code_off.data(), ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
-  SRW_HIP(hipMemcpyAsync(d_points.p, points.data(), points.size() * 4, hipMemcpyHostToDevice, st));
-  SRW_HIP(hipMemcpyAsync(d_codes.p, codes.data(), codes.size(), hipMemcpyHostToDevice, st));
-  SRW_HIP(hipMemcpyAsync(d_syn0.p, vectors.data(), vectors.size() * 4, hipMemcpyHostToDevice, st));
-  SRW_HIP(hipMemsetAsync(d_syn1.p, 0, (size_t)V * P.dim * 4, st));
-  W2vDev d;
-  d.sent_off = d_off.p; d.sent = d_sent.p; d.n_sent = n; d.words_before = d_before.p; d.code_off = d_coff.p; d.points = d_points.p; d.codes = d_codes.p;
-  d.syn0 = d_syn0.p; d.syn1 = d_syn1.p; d.dim = P.dim; d.window = P.window; d.seed = P.seed; d.n_iter = P.iterations; d.total_words = total; d.lr = P.learning_rate;
-  // threads == 1: ONE wave walks the sentences in order (the sequential form the oracle restates); else one wave per sentence, Hogwild
-  const int64_t n_waves = P.threads == 1 ? 1 : std::min<int64_t>(std::max<int64_t>(n, 1), (int64_t)h->n_cus * 32);
-  const int blocks = (int)((n_waves + TPB / 64 - 1) / (TPB / 64));
-  const int nd = (P.dim + 63) / 64;
-  for (int32_t k = 0; k < P.iterations; ++k) {
-    d.iter = k;
-    const dim3 grid(P.threads == 1 ? 1 : blocks), block(P.threads == 1 ? 64 : TPB);
-    if (nd <= 1) hipLaunchKernelGGL(k_w2v_train<1>, grid, block, 0, st, d, n_waves);
-    else if (nd <= 2) hipLaunchKernelGGL(k_w2v_train<2>, grid, block, 0, st, d, n_waves);
-    else if (nd <= 4) hipLaunchKernelGGL(k_w2v_train<4>, grid, block, 0, st, d, n_waves);
-    else if (nd <= 8) hipLaunchKernelGGL(k_w2v_train<8>, grid, block, 0, st, d, n_waves);
-    else hipLaunchKernelGGL(k_w2v_train<16>, grid, block, 0, st, d, n_waves);
-    SRW_HIP(hipGetLastError());
+  for (int64_t a = 0; a < n_vocab; ++a) {
+    const int32_t c0 = code_off[(size_t)a], len = code_off[(size_t)a + 1] - c0;
+    code_len[a] = len;
+    for (int32_t k = 0; k < MAX_CODE_LENGTH; ++k) {
+      codes_out[a * MAX_CODE_LENGTH + k] = k < len ? codes[(size_t)(c0 + k)] : 0;
+      points_out[a * MAX_CODE_LENGTH + k] = k < len ? points[(size_t)(c0 + k)] : -1;
+    }
   }
-  SRW_HIP(hipMemcpyAsync(vectors.data(), d_syn0.p, vectors.size() * 4, hipMemcpyDeviceToHost, st));
-  SRW_HIP(hipStreamSynchronize(st));
+}
+
+// the same from HOST paths (a parsed paths file, `--cmd embedding`): one upload, then the device form
+void w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, const srw_w2v_params &P,
+             std::vector<int32_t> &vocab_ids, std::vector<float> &vectors) {
+  for (int64_t w = 0; w < n; ++w)
+    if (lens[w] < 0 || lens[w] > stride) throw Error(SRW_ERR_INVALID, "word2vec: a path length outside [0, stride]");
+  DevBuf<int32_t> d_paths, d_lens;
+  d_paths.alloc((size_t)std::max<int64_t>(n * stride, 1)); d_lens.alloc((size_t)std::max<int64_t>(n, 1));
+  SRW_HIP(hipMemcpyAsync(d_paths.p, paths, (size_t)(n * stride) * 4, hipMemcpyHostToDevice, h->stream));
+  SRW_HIP(hipMemcpyAsync(d_lens.p, lens, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  SRW_HIP(hipStreamSynchronize(h->stream));
+  w2v_fit_device(h, d_paths.p, d_lens.p, n, stride, P, vocab_ids, vectors);
 }
 }  // namespace srw

@@ -344,8 +344,12 @@ void run_shard_finish(srw_handle *h, srw_walk_stats *stats, int32_t *overflow);
 // embedding.hip: skip-gram + hierarchical softmax over host paths
 void w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride, const srw_w2v_params &P,
              std::vector<int32_t> &vocab_ids, std::vector<float> &vectors);
+void w2v_fit_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens, int64_t n, int64_t stride, const srw_w2v_params &P,
+                    std::vector<int32_t> &vocab_ids, std::vector<float> &vectors);
+void w2v_huffman(const int64_t *counts, int64_t n_vocab, int32_t *code_len, uint8_t *codes, int32_t *points);   // host only (test hook)
 // writer.cpp: <output>/vec part files + <output>/bin
 void write_vectors(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int n_parts);
+void write_vectors_words(const char *const *words, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int n_parts);
 std::string java_float_to_string(float x);
 // probe.hip: measurement hooks of bench.py's roofline object
 void probe_request_rate(srw_handle *h, int64_t table_bytes, double *reads_per_s, double *table_gib);

@@ -77,7 +77,9 @@ std::string CommandParser::usage() {
     << "  --gpus <value>           GPUs of this node to shard the graph over (by source vertex; 1 = whole graph on one GPU): 1\n"
     << "  --crc <value>            also write Hadoop .crc side files: false\n"
     << "  --sampler <value>        reference (bit-identical CDF inversion) | alias (alias tables + rejection): reference\n"
-    << "  --deviceFormat <value>   format the path text on the GPU (false: on host threads): true\n";
+    << "  --deviceFormat <value>   format the path text on the GPU (false: on host threads): true\n"
+    << "Environment: SRW_W2V_DETERMINISTIC=1 trains word2vec in one wave, sentence after sentence (reproducible vectors; the default "
+       "trains one wave per sentence, Hogwild, and two runs differ in their last bits even with the same --seed)\n";
   return o.str();
 }
 

@@ -3,7 +3,14 @@
 // <output>/path layout.  --cmd node2vec / embedding (M/Main.scala:113-124): the Word2Vec stage is the build's GPU skip-gram +
 // hierarchical softmax (csrc/embedding.hip; MLlib's Word2Vec is absent from the reference tree: parity unpinned), <output>/vec
 // holds "id\tv0\t..." lines as Main.saveModelAndFeatures writes them, <output>/bin the model directory (metadata + vectors as text).
+// `--cmd embedding --input X`: X is a file or a directory of part files (context.textFile), its tokens are words (any string).
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cerrno>
 #include <chrono>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -31,16 +38,19 @@ static void doRandomWalk(const Params &param) {  // Main.scala:53-62
   rw->executeAndSave(getNumOutputPartition(param), param.output);
 }
 
-// configureWord2Vec + fit + saveModelAndFeatures (Main.scala:36-44,77-97): setMinCount(0), --lr, --iter, --dim, --window;
-// --w2vPartitions only shapes MLlib's own parallelism (here: one logical partition, one wave per sentence)
-static void fitAndSave(srw_handle *h, const int32_t *ids, const int32_t *lens, int64_t n, int64_t stride, const Params &param) {
+// configureWord2Vec (Main.scala:77-97): setMinCount(0), --lr, --iter, --dim, --window; --w2vPartitions only shapes MLlib's own
+// parallelism (here: one logical partition, one wave per sentence, Hogwild across the waves as word2vec.c across its threads — so the
+// vectors of two runs differ in their last bits even with the same --seed; SRW_W2V_DETERMINISTIC=1 trains in ONE wave, sentence after
+// sentence: reproducible, and what the tests compare with the oracle's restatement)
+static srw_w2v_params w2vParams(const Params &param) {
   srw_w2v_params wp;
   wp.dim = param.w2vDim; wp.window = param.w2vWindow; wp.iterations = param.w2vIter; wp.learning_rate = (float)param.w2vLr;
-  wp.seed = (uint32_t)param.seed; wp.threads = 0;
-  int32_t *vocab = nullptr; float *vec = nullptr; int64_t nv = 0;
-  if (srw_w2v_fit(h, ids, lens, n, stride, &wp, &vocab, &vec, &nv) != SRW_OK) throw std::runtime_error(std::string("word2vec: ") + srw_last_error(h));
-  const int32_t rc = srw_w2v_save(vocab, vec, nv, wp.dim, param.output.c_str(), getNumOutputPartition(param));
-  srw_free(vocab); srw_free(vec);
+  wp.seed = (uint32_t)param.seed;
+  const char *det = getenv("SRW_W2V_DETERMINISTIC");
+  wp.threads = (det && *det == '1') ? 1 : 0;
+  return wp;
+}
+static void throwSave(int32_t rc) {
   if (rc != SRW_OK) throw std::runtime_error(std::string("org.apache.hadoop.mapred.FileAlreadyExistsException: ") + srw_last_error(nullptr));
 }
 
@@ -48,38 +58,116 @@ static void doNode2vec(const Params &param) {   // Main.scala:113-117: doRandomW
   std::unique_ptr<algorithm::RandomWalk> rw;
   if (param.partitioned) rw.reset(new algorithm::VCutRandomWalk(param, &std::cout));
   else rw.reset(new algorithm::UniformRandomWalk(param, &std::cout));
-  algorithm::Paths paths = rw->execute();
-  rw->save(paths, getNumOutputPartition(param), param.output);
-  fitAndSave(rw->handle(), paths.ids, paths.lens, paths.n, paths.stride, param);
+  // the reference feeds randomWalk's RDD to Word2Vec.fit without collecting it: the paths stay in HBM between the two stages
+  // (srw_walk -> srw_write_paths for <output>/path -> srw_w2v_fit_device), they cross PCIe once, as text
+  rw->executeOnDevice();
+  rw->saveFromDevice(getNumOutputPartition(param), param.output);
+  const srw_w2v_params wp = w2vParams(param);
+  int32_t *vocab = nullptr; float *vec = nullptr; int64_t nv = 0;
+  if (srw_w2v_fit_device(rw->handle(), nullptr, nullptr, 0, 1, &wp, &vocab, &vec, &nv) != SRW_OK)
+    throw std::runtime_error(std::string("word2vec: ") + srw_last_error(rw->handle()));
+  const int32_t rc = srw_w2v_save(vocab, vec, nv, wp.dim, param.output.c_str(), getNumOutputPartition(param));
+  srw_free(vocab); srw_free(vec);
+  throwSave(rc);
+}
+
+// String.split("\\s+") as Scala applies it to a line (Main.scala:121): runs of \s (space, \t, \n, \v, \f, \r) separate; a line that
+// STARTS with whitespace yields a leading empty token, trailing empty tokens are dropped, and an empty line is ONE empty token
+static void javaSplit(const std::string &line, std::vector<std::string> &out) {
+  out.clear();
+  auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+  size_t i = 0;
+  const size_t n = line.size();
+  if (n == 0) { out.emplace_back(); return; }
+  if (ws(line[0])) { out.emplace_back(); while (i < n && ws(line[i])) ++i; }
+  while (i < n) {
+    size_t j = i;
+    while (j < n && !ws(line[j])) ++j;
+    out.emplace_back(line, i, j - i);
+    i = j;
+    while (i < n && ws(line[i])) ++i;
+  }
+  if (out.size() == 1 && out[0].empty() && n > 0) out.clear();      // a line of whitespace only: "" then nothing -> Java drops the trailing empties: []
+}
+
+// the files behind context.textFile(path): the file itself, or — a directory, e.g. the randomwalk stage's own <output>/path — its
+// part files in name order (Hadoop skips names that start with '_' or '.': _SUCCESS, .part-00000.crc)
+static std::vector<std::string> inputFiles(const std::string &path) {
+  struct stat sb;
+  if (stat(path.c_str(), &sb) != 0) throw std::runtime_error("org.apache.hadoop.mapred.InvalidInputException: Input path does not exist: " + path);
+  std::vector<std::string> files;
+  if (!S_ISDIR(sb.st_mode)) { files.push_back(path); return files; }
+  DIR *d = opendir(path.c_str());
+  if (!d) throw std::runtime_error("Input path does not exist: " + path);
+  while (dirent *e = readdir(d)) {
+    const std::string name = e->d_name;
+    if (name.empty() || name[0] == '_' || name[0] == '.') continue;
+    struct stat fb;
+    if (stat((path + "/" + name).c_str(), &fb) == 0 && S_ISREG(fb.st_mode)) files.push_back(path + "/" + name);
+  }
+  closedir(d);
+  std::sort(files.begin(), files.end());
+  return files;
 }
 
 static void doEmbedding(const Params &param) {  // Main.scala:119-124: textFile(input).map(_.split("\\s+")) -> Word2Vec
-  std::ifstream in(param.input);
-  if (!in) throw std::runtime_error("Input path does not exist: " + param.input);
-  std::vector<std::vector<int32_t>> rows;
-  std::string line;
-  size_t stride = 1;
-  while (std::getline(in, line)) {
-    std::vector<int32_t> r;
-    std::istringstream ls(line);
-    std::string tok;
-    while (ls >> tok) {                        // (the reference keeps any token as a word; this build takes vertex ids)
+  std::vector<std::vector<std::string>> rows;
+  std::vector<std::string> toks;
+  for (const std::string &fn : inputFiles(param.input)) {
+    std::ifstream in(fn);
+    if (!in) throw std::runtime_error("Input path does not exist: " + fn);
+    std::string line;
+    while (std::getline(in, line)) { javaSplit(line, toks); rows.push_back(toks); }
+  }
+  size_t stride = 1, n_tok = 0;
+  for (const auto &r : rows) { stride = std::max(stride, r.size()); n_tok += r.size(); }
+  if (n_tok == 0) throw std::runtime_error("java.lang.IllegalArgumentException: requirement failed: The vocabulary size should be > 0 (no words under " + param.input + ")");
+  // Words are strings in the reference.  A text of canonical int32 tokens (what the randomwalk stage writes) keeps the ids as they are,
+  // so that `--cmd embedding` on <output>/path trains exactly what `--cmd node2vec` trains; any other text gets a dictionary (the
+  // distinct tokens in byte order) and its vectors are saved under the words themselves.
+  bool numeric = true;
+  for (const auto &r : rows) {
+    for (const auto &t : r) {
+      errno = 0;
       char *end = nullptr;
-      const long v = strtol(tok.c_str(), &end, 10);
-      if (*end != 0 || tok.empty()) throw std::runtime_error("embedding: token '" + tok + "' is not a vertex id");
-      r.push_back((int32_t)v);
+      const long long v = t.empty() ? 0 : strtoll(t.c_str(), &end, 10);
+      if (t.empty() || *end != 0 || errno == ERANGE || v > INT32_MAX || v < INT32_MIN || std::to_string(v) != t) { numeric = false; break; }
     }
-    stride = std::max(stride, r.size());
-    rows.push_back(std::move(r));
+    if (!numeric) break;
+  }
+  std::vector<std::string> dict;
+  if (!numeric) {
+    for (const auto &r : rows) dict.insert(dict.end(), r.begin(), r.end());
+    std::sort(dict.begin(), dict.end());
+    dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
   }
   std::vector<int32_t> ids(rows.size() * stride, -1), lens(rows.size());
-  for (size_t i = 0; i < rows.size(); ++i) { lens[i] = (int32_t)rows[i].size(); std::copy(rows[i].begin(), rows[i].end(), ids.begin() + i * stride); }
-  srw_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = 0; cfg.rank = 0; cfg.world = 1;
+  for (size_t i = 0; i < rows.size(); ++i) {
+    lens[i] = (int32_t)rows[i].size();
+    for (size_t k = 0; k < rows[i].size(); ++k)
+      ids[i * stride + k] = numeric ? (int32_t)strtoll(rows[i][k].c_str(), nullptr, 10)
+                                    : (int32_t)(std::lower_bound(dict.begin(), dict.end(), rows[i][k]) - dict.begin());
+  }
+  srw_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = param.device; cfg.rank = 0; cfg.world = 1;
   srw_handle *h = nullptr;
   if (srw_create(&cfg, &h) != SRW_OK) throw std::runtime_error(std::string("srw_create: ") + srw_last_error(nullptr));
-  try { fitAndSave(h, ids.data(), lens.data(), (int64_t)rows.size(), (int64_t)stride, param); }
-  catch (...) { srw_destroy(h); throw; }
+  int32_t *vocab = nullptr; float *vec = nullptr; int64_t nv = 0;
+  const srw_w2v_params wp = w2vParams(param);
+  if (srw_w2v_fit(h, ids.data(), lens.data(), (int64_t)rows.size(), (int64_t)stride, &wp, &vocab, &vec, &nv) != SRW_OK) {
+    const std::string msg = std::string("word2vec: ") + srw_last_error(h);
+    srw_destroy(h);
+    throw std::runtime_error(msg);
+  }
   srw_destroy(h);
+  int32_t rc;
+  if (numeric) rc = srw_w2v_save(vocab, vec, nv, wp.dim, param.output.c_str(), getNumOutputPartition(param));
+  else {
+    std::vector<const char *> words((size_t)nv);
+    for (int64_t r = 0; r < nv; ++r) words[(size_t)r] = dict[(size_t)vocab[r]].c_str();
+    rc = srw_w2v_save_words(words.data(), vec, nv, wp.dim, param.output.c_str(), getNumOutputPartition(param));
+  }
+  srw_free(vocab); srw_free(vec);
+  throwSave(rc);
 }
 
 int main(int argc, char **argv) {

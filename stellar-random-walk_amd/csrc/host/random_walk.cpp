@@ -106,6 +106,38 @@ void VCutRandomWalk::loadGraph() {
   printGraphStats();
 }
 
+void RandomWalk::executeOnDevice() {
+  loadGraph();
+  Phase ph("randomWalk (kernels; the paths stay in HBM)");
+  srw_walk_params P{};
+  P.p = (float)config_.p; P.q = (float)config_.q;               // .toFloat, :112
+  P.walk_length = config_.walkLength; P.num_walks = config_.numWalks; P.first_walk = 0;
+  P.rng_mode = SRW_RNG_PHILOX; P.const_r = 0.0f; P.seed = (uint32_t)config_.seed;
+  P.sampler = config_.alias ? SRW_SAMPLER_ALIAS : SRW_SAMPLER_REFERENCE;
+  srw_walk_stats st{};
+  check(h_, srw_walk(h_, &P, &st), "randomWalk");
+  if (log_) {
+    std::vector<int32_t> lens((size_t)config_.numWalks * (size_t)nVertices);
+    check(h_, srw_fetch_paths(h_, nullptr, lens.data()), "randomWalk");
+    const int32_t stride = config_.walkLength + 2;
+    for (int it = 0; it < config_.numWalks; ++it) {
+      int64_t dead = 0;
+      const int32_t *ln = lens.data() + (size_t)it * nVertices;
+      for (int64_t i = 0; i < nVertices; ++i) dead += (ln[i] >= 2 && ln[i] < stride);
+      *log_ << "Unfinished Walkers: 0\n";                       // :154
+      if (dead) *log_ << "Wrong Transports: 0\n" << "Zero Neighbors: " << dead << "\n";  // :155-160
+    }
+  }
+}
+void RandomWalk::saveFromDevice(int partitions, const std::string &output) const {
+  Phase ph("save (device formatter + part files)");
+  int32_t rc = srw_write_paths(h_, output.c_str(), partitions, config_.crc ? 1 : 0);
+  if (rc == SRW_ERR_EXISTS)
+    throw std::runtime_error("org.apache.hadoop.mapred.FileAlreadyExistsException: Output directory " + output + "/" +
+                             common::Property::pathSuffix + " already exists");
+  check(h_, rc, "save");
+}
+
 Paths RandomWalk::walkImpl(bool useConst, float constR) {
   Phase ph("randomWalk (kernels + path transfer, overlapped)");
   Paths out;

@@ -85,6 +85,10 @@ class RandomWalk {  // trait RandomWalk
   // materialising the paths on the host
   void executeAndSave(int partitions, const std::string &output);
   void executeAndSaveSharded(int partitions, const std::string &output);   // --gpus N > 1 (srw_cluster_*)
+  // loadGraph + randomWalk with the paths LEFT IN HBM (srw_walk) for a consumer on the device — the embedding stage of
+  // `--cmd node2vec` (M/Main.scala:113-117 feeds randomWalk's RDD to Word2Vec.fit) — and save() straight from there
+  void executeOnDevice();
+  void saveFromDevice(int partitions, const std::string &output) const;
   GraphMap graphMap() const { return GraphMap(h_); }
   srw_handle *handle() const { return h_; }
 

@@ -16,6 +16,7 @@
 #include <string>
 #include <cstdlib>
 #include <cstdio>
+#include <functional>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -312,47 +313,74 @@ std::string java_float_to_string(float x) {
   return neg ? "-" + out : out;
 }
 
-void write_vectors(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int n_parts) {
+// saveModelAndFeatures (M/Main.scala:36-44): model.save(<out>/bin) FIRST (Spark fails there if the directory exists), then the
+// "<word>\t<v0>\t..." lines under <out>/vec.  Nothing is overwritten: either directory existing is FileAlreadyExists before a byte
+// is written; part files go through a 1 MiB buffer (vocab x dim x ~12 B of text never sits in memory as one string); a failure
+// midway removes what this call created, so that a rerun does not trip over a half-written <out>/vec.
+void write_vectors_named(const std::function<void(std::string &, int64_t)> &put_name, const float *vectors, int64_t n_vocab, int32_t dim,
+                         const char *output_dir, int n_parts) {
   if (n_parts < 1) n_parts = 1;
   const std::string out(output_dir);
-  mkdir(out.c_str(), 0777);
   const std::string vdir = out + "/vec", mdir = out + "/bin";
-  if (mkdir(vdir.c_str(), 0777) != 0)
-    throw Error(SRW_ERR_IO, errno == EEXIST ? "Output directory " + vdir + " already exists" : "cannot create " + vdir + ": " + strerror(errno));
-  auto put = [](const std::string &fn, const std::string &text) {
-    FILE *f = fopen(fn.c_str(), "wb");
-    if (!f) throw Error(SRW_ERR_IO, "cannot open " + fn + ": " + strerror(errno));
-    const bool ok = fwrite(text.data(), 1, text.size(), f) == text.size();
-    if (fclose(f) != 0 || !ok) throw Error(SRW_ERR_IO, "write error on " + fn);
+  struct stat sb;
+  if (stat(mdir.c_str(), &sb) == 0) throw Error(SRW_ERR_IO, "Output directory " + mdir + " already exists");
+  if (stat(vdir.c_str(), &sb) == 0) throw Error(SRW_ERR_IO, "Output directory " + vdir + " already exists");
+  if (mkdir(out.c_str(), 0777) != 0 && errno != EEXIST) throw Error(SRW_ERR_IO, "cannot create " + out + ": " + strerror(errno));
+  std::vector<std::string> made_files, made_dirs;
+  auto mk = [&](const std::string &d) {
+    if (mkdir(d.c_str(), 0777) != 0) throw Error(SRW_ERR_IO, "cannot create " + d + ": " + strerror(errno));
+    made_dirs.push_back(d);
   };
-  // repartition(numPartitions): contiguous blocks of the vocabulary (the reference's order of lines is unspecified)
-  const int64_t per = (n_vocab + n_parts - 1) / n_parts;
-  for (int p = 0; p < n_parts; ++p) {
-    std::string text;
-    for (int64_t r = (int64_t)p * per; r < std::min<int64_t>(n_vocab, (int64_t)(p + 1) * per); ++r) {
-      text += std::to_string(vocab_ids[r]);
-      for (int32_t j = 0; j < dim; ++j) { text.push_back('\t'); text += java_float_to_string(vectors[r * dim + j]); }
-      text.push_back('\n');
+  struct Sink {                                   // buffered part-file writer
+    FILE *f = nullptr; std::string fn, buf;
+    void open(const std::string &name) {
+      fn = name; f = fopen(fn.c_str(), "wb");
+      if (!f) throw Error(SRW_ERR_IO, "cannot open " + fn + ": " + strerror(errno));
+      buf.clear(); buf.reserve((size_t)1 << 20);
     }
-    char name[32]; snprintf(name, sizeof(name), "/part-%05d", p);
-    put(vdir + name, text);
-  }
-  put(vdir + "/_SUCCESS", "");
-  // the model directory: Spark's Word2VecModel.save layout in name (metadata + data), with the vectors as text instead of parquet
-  if (mkdir(mdir.c_str(), 0777) != 0 && errno != EEXIST) throw Error(SRW_ERR_IO, "cannot create " + mdir + ": " + strerror(errno));
-  mkdir((mdir + "/metadata").c_str(), 0777); mkdir((mdir + "/data").c_str(), 0777);
-  put(mdir + "/metadata/part-00000", "{\"class\":\"org.apache.spark.mllib.feature.Word2VecModel\",\"version\":\"1.0\",\"vectorSize\":" + std::to_string(dim) +
-                                         ",\"numWords\":" + std::to_string(n_vocab) + "}\n");
-  put(mdir + "/metadata/_SUCCESS", "");
-  {
-    std::string text;
-    for (int64_t r = 0; r < n_vocab; ++r) {
-      text += std::to_string(vocab_ids[r]);
-      for (int32_t j = 0; j < dim; ++j) { text.push_back('\t'); text += java_float_to_string(vectors[r * dim + j]); }
-      text.push_back('\n');
+    void flush() { if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) throw Error(SRW_ERR_IO, "write error on " + fn); buf.clear(); }
+    void close() { flush(); FILE *g = f; f = nullptr; if (fclose(g) != 0) throw Error(SRW_ERR_IO, "write error on " + fn); }
+    ~Sink() { if (f) fclose(f); }
+  };
+  auto rows = [&](Sink &sk, int64_t r0, int64_t r1) {
+    for (int64_t r = r0; r < r1; ++r) {
+      put_name(sk.buf, r);
+      for (int32_t j = 0; j < dim; ++j) { sk.buf.push_back('\t'); sk.buf += java_float_to_string(vectors[r * dim + j]); }
+      sk.buf.push_back('\n');
+      if (sk.buf.size() >= ((size_t)1 << 20) - 4096) sk.flush();
     }
-    put(mdir + "/data/part-00000.tsv", text);
-    put(mdir + "/data/_SUCCESS", "");
+  };
+  auto file = [&](const std::string &fn, const std::string &text) {
+    Sink sk; sk.open(fn); made_files.push_back(fn); sk.buf = text; sk.close();
+  };
+  try {
+    // the model directory: Spark's Word2VecModel.save layout in name (metadata + data), with the vectors as text instead of parquet
+    mk(mdir); mk(mdir + "/metadata"); mk(mdir + "/data");
+    file(mdir + "/metadata/part-00000", "{\"class\":\"org.apache.spark.mllib.feature.Word2VecModel\",\"version\":\"1.0\",\"vectorSize\":" + std::to_string(dim) +
+                                            ",\"numWords\":" + std::to_string(n_vocab) + "}\n");
+    file(mdir + "/metadata/_SUCCESS", "");
+    { Sink sk; sk.open(mdir + "/data/part-00000.tsv"); made_files.push_back(sk.fn); rows(sk, 0, n_vocab); sk.close(); }
+    file(mdir + "/data/_SUCCESS", "");
+    // repartition(numPartitions): contiguous blocks of the vocabulary (the reference's order of lines is unspecified)
+    mk(vdir);
+    const int64_t per = (n_vocab + n_parts - 1) / n_parts;
+    for (int p = 0; p < n_parts; ++p) {
+      char name[32]; snprintf(name, sizeof(name), "/part-%05d", p);
+      Sink sk; sk.open(vdir + name); made_files.push_back(sk.fn);
+      rows(sk, (int64_t)p * per, std::min<int64_t>(n_vocab, (int64_t)(p + 1) * per));
+      sk.close();
+    }
+    file(vdir + "/_SUCCESS", "");
+  } catch (...) {
+    for (auto it = made_files.rbegin(); it != made_files.rend(); ++it) unlink(it->c_str());
+    for (auto it = made_dirs.rbegin(); it != made_dirs.rend(); ++it) rmdir(it->c_str());
+    throw;
   }
+}
+void write_vectors(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int n_parts) {
+  write_vectors_named([&](std::string &b, int64_t r) { b += std::to_string(vocab_ids[r]); }, vectors, n_vocab, dim, output_dir, n_parts);
+}
+void write_vectors_words(const char *const *words, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int n_parts) {
+  write_vectors_named([&](std::string &b, int64_t r) { b += words[r]; }, vectors, n_vocab, dim, output_dir, n_parts);
 }
 }  // namespace srw

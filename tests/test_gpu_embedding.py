@@ -88,3 +88,87 @@ def test_cli_node2vec_and_embedding(tmp_path):
     r = subprocess.run([cli, "--cmd", "embedding", "--input", os.path.join(out, "path", "part-00000"), "--output", out2, "--dim", "8"],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "already exists" in r.stderr
+
+
+def test_fit_from_the_device_resident_walk(eng, oracle):
+    """srw_w2v_fit_device on the handle's last walk (paths never leave HBM: M/Main.scala:113-117 hands randomWalk's RDD to Word2Vec.fit)
+    == srw_w2v_fit on the fetched paths (one upload, then the same device code) == the oracle's restatement; vocabulary built on the
+    device (radix sort + run-length encode + stable sort by count)."""
+    scale = 11
+    s, d = oracle.rmat_edges(scale, 8 << scale, seed=6)
+    eng.load_coo(s, d, None, directed=False)
+    paths, lens, _ = eng.walk(p=1.0, q=1.0, walk_length=12, num_walks=2, seed=4)
+    ids_d, vec_d = eng.w2v_fit_device(dim=32, window=4, iterations=2, lr=0.025, seed=5, threads=1)
+    ids_h, vec_h = eng.w2v_fit(paths, lens, dim=32, window=4, iterations=2, lr=0.025, seed=5, threads=1)
+    assert np.array_equal(ids_d, ids_h) and np.array_equal(vec_d, vec_h)            # the same kernels on the same sentences: bit for bit
+    oids, ovec = oracle.w2v_fit(paths, lens, dim=32, window=4, iterations=2, lr=0.025, seed=5)
+    assert np.array_equal(ids_d, oids)
+    assert np.allclose(vec_d, ovec, rtol=2e-3, atol=2e-4), float(np.abs(vec_d - ovec).max())
+    # vocabulary order: counts descending, ties by ascending id
+    flat = np.concatenate([paths[i, : lens[i]] for i in range(len(lens))])
+    u, c = np.unique(flat, return_counts=True)
+    order = np.lexsort((u, -c))
+    assert np.array_equal(ids_d, u[order])
+
+
+def test_fit_device_without_a_walk_fails_loudly():
+    with pkg().Engine(device=0) as e:
+        with pytest.raises(pkg().SrwError):
+            e.w2v_fit_device(dim=8)
+
+
+def _cli(*args, env=None):
+    cli = os.path.join(ROOT, "stellar-random-walk_amd", "stellar-rw")
+    return subprocess.run([cli, *args], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+
+
+def test_cli_embedding_reads_a_directory_of_part_files(tmp_path):
+    """context.textFile(input) takes the randomwalk stage's own <output>/path DIRECTORY (part files in name order, _SUCCESS and .crc
+    files skipped); round 4 opened it as one file and wrote an empty model with exit code 0."""
+    out = str(tmp_path / "rw")
+    r = _cli("--cmd", "randomwalk", "--input", KARATE, "--output", out, "--weighted", "false", "--walkLength", "8", "--numWalks", "4",
+             "--singleOutput", "false", "--rddPartitions", "3", "--crc", "true")
+    assert r.returncode == 0, r.stderr
+    names = sorted(os.listdir(os.path.join(out, "path")))
+    assert "part-00002" in names and "_SUCCESS" in names and any(n.endswith(".crc") for n in names)
+    det = {"SRW_W2V_DETERMINISTIC": "1"}
+    r = _cli("--cmd", "embedding", "--input", os.path.join(out, "path"), "--output", str(tmp_path / "e_dir"), "--dim", "8", "--iter", "2", env=det)
+    assert r.returncode == 0, r.stderr
+    vec_dir = open(os.path.join(str(tmp_path / "e_dir"), "vec", "part-00000")).read()
+    assert len(vec_dir.splitlines()) == 34
+    # the same text as ONE file gives the same model (deterministic mode), and a second deterministic run is byte-identical
+    cat = str(tmp_path / "all.txt")
+    with open(cat, "w") as f:
+        for n in names:
+            if n.startswith("part-"):
+                f.write(open(os.path.join(out, "path", n)).read())
+    for tag in ("e_file", "e_file2"):
+        r = _cli("--cmd", "embedding", "--input", cat, "--output", str(tmp_path / tag), "--dim", "8", "--iter", "2", env=det)
+        assert r.returncode == 0, r.stderr
+        assert open(os.path.join(str(tmp_path / tag), "vec", "part-00000")).read() == vec_dir
+    # nothing to read: an error, not an empty model
+    empty = tmp_path / "empty_dir"; empty.mkdir(); (empty / "_SUCCESS").write_text("")
+    r = _cli("--cmd", "embedding", "--input", str(empty), "--output", str(tmp_path / "e_none"), "--dim", "8")
+    assert r.returncode == 1 and "vocabulary size should be > 0" in r.stderr and not os.path.exists(str(tmp_path / "e_none" / "vec"))
+    r = _cli("--cmd", "embedding", "--input", str(tmp_path / "nope"), "--output", str(tmp_path / "e_none2"), "--dim", "8")
+    assert r.returncode == 1 and "Input path does not exist" in r.stderr
+
+
+def test_cli_embedding_takes_words(tmp_path):
+    """The reference's Word2Vec takes any token (Main.scala:119-124: textFile(input).map(_.split("\\\\s+"))): a text of words gets its
+    vectors under the words; ids out of the int32 range and non-canonical numbers ("007") are words too."""
+    txt = tmp_path / "corpus.txt"
+    lines = ["the quick brown fox", "the lazy dog 007 99999999999", "quick\tquick  fox the"] * 5
+    txt.write_text("\n".join(lines) + "\n")
+    out = str(tmp_path / "w")
+    r = _cli("--cmd", "embedding", "--input", str(txt), "--output", out, "--dim", "4", "--iter", "1", "--window", "2")
+    assert r.returncode == 0, r.stderr
+    rows = [l.split("\t") for l in open(os.path.join(out, "vec", "part-00000")).read().splitlines()]
+    words = [r_[0] for r_ in rows]
+    assert sorted(words) == sorted(["the", "quick", "brown", "fox", "lazy", "dog", "007", "99999999999"]) and all(len(r_) == 5 for r_ in rows)
+    assert words[:2] == ["quick", "the"]            # by descending count (quick 15, the 15: ties in dictionary order), then fox 10
+    assert words[2] == "fox"
+    # bin before vec, nothing overwritten: an existing <output>/bin alone fails the job before any vector is written
+    out2 = tmp_path / "w2"; (out2 / "bin").mkdir(parents=True)
+    r = _cli("--cmd", "embedding", "--input", str(txt), "--output", str(out2), "--dim", "4", "--iter", "1")
+    assert r.returncode == 1 and "already exists" in r.stderr and not (out2 / "vec").exists()

@@ -451,6 +451,8 @@ def compact_line(out):
             if "measured_fraction_of_exchange_ceiling" in m:
                 vs[leg]["fraction_of_exchange_ceiling"] = m["measured_fraction_of_exchange_ceiling"]
         c["vertex_sharded"] = vs
+    if out.get("switches_set"):
+        c["switches_set"] = out["switches_set"]
     if "detail_file" in out:
         c["detail_file"] = out["detail_file"]
     c = _round(c)
@@ -473,6 +475,8 @@ def compact_line(out):
 def emit(out, args):
     """Full detail -> bench_detail.json (next to gpurun_out/ when that exists, else the working directory) and stderr;
     the compact object -> the last (and only) stdout line."""
+    # tools/SWITCHES.md: the line describes the defaults unless it says otherwise
+    out["switches_set"] = sorted(k for k in os.environ if k.startswith("SRW_") and k not in ("SRW_TIMING",))
     full = json.dumps(out)
     path = args.detail or os.path.join("gpurun_out" if os.path.isdir("gpurun_out") else ".", "bench_detail.json")
     try:

@@ -262,7 +262,9 @@ int32_t srw_shard_layout_for(const srw_handle *h, int32_t batch, double slack, s
  * counters, path staging) and their own stream; srw_shard_begin / _superstep / _flush / _finish act on the selected one.  A driver
  * that interleaves the super-steps of two populations lets one's kernels run while the other's chunks are being exchanged — the
  * overlap the reference's shuffle / count rhythm (RandomWalk.scala:91-162) does not have.  Select 0 again before any other call
- * on the handle (srw_walk, loads, table builds use the selected stream). */
+ * on the handle: while population 1 is selected, srw_walk*, the loads, srw_w2v_fit* and srw_probe_request_rate fail with
+ * SRW_ERR_INVALID (they would run on the second population's stream with its cursors); srw_set_stream sets the SELECTED
+ * population's stream. */
 int32_t srw_shard_select(srw_handle *h, int32_t population);
 /* Seeds this rank's batch * n_local walkers into its own receive buffer d_recv (world * chunk_bytes, device), writes
  * path slot 0 / lens into d_paths [batch * n_local][walk_length + 2] / d_lens (device), clears the counters. */

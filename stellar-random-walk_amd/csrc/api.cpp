@@ -168,6 +168,13 @@ const char *srw_last_error(const srw_handle *h) {
   return g_create_error.c_str();
 }
 
+// srw_shard_select(h, 1) swaps the handle's stream, counters and cursors with the second population's: every entry point outside the
+// super-step family would run on that population's stream with its cursors.  They refuse instead.
+static void need_population0(const srw_handle *h, const char *what) {
+  if (h->shard_population != 0)
+    throw srw::Error(SRW_ERR_INVALID, std::string(what) + ": population 1 is selected on this handle (srw_shard_select(h, 0) first)");
+}
+
 int32_t srw_set_stream(srw_handle *h, void *hip_stream) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
@@ -189,6 +196,7 @@ int32_t srw_load_edgelist(srw_handle *h, const char *path, int32_t directed, int
                           int32_t rdd_partitions) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
+    need_population0(h, "srw_load_edgelist");
     need(path != nullptr, "path is null");
     const auto t0 = std::chrono::steady_clock::now();
     // two integer columns and nothing unusual: tokenized on the device (edgelist_device.hip); anything else: below
@@ -221,6 +229,7 @@ int32_t srw_load_coo(srw_handle *h, const int32_t *src, const int32_t *dst, cons
                      int64_t n_lines, int32_t directed) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
+    need_population0(h, "srw_load_coo");
     need(n_lines == 0 || (src && dst), "src/dst are null");
     load_lines(h, src, dst, w, pid, n_lines, directed != 0);
   });
@@ -230,6 +239,7 @@ int32_t srw_load_adjacency(srw_handle *h, const int32_t *vids, const int64_t *of
                            const float *w, const int32_t *pids) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
+    need_population0(h, "srw_load_adjacency");
     need(vids && offs && (ids || offs[n_rows] == 0), "null argument");
     build_graph_from_host_rows(h, vids, offs, n_rows, ids, w);
     h->g.part_of.clear();
@@ -249,6 +259,7 @@ int32_t srw_load_adjacency(srw_handle *h, const int32_t *vids, const int64_t *of
 int32_t srw_generate_rmat(srw_handle *h, int32_t scale, int64_t n_edges, uint32_t seed, int32_t weighted, int32_t directed) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
+    need_population0(h, "srw_generate_rmat");
     DevBuf<int32_t> d_src, d_dst; DevBuf<float> d_w;
     if (h->cfg.world > 1 && !getenv("SRW_BUILD_WHOLE")) {
       // a shard generates the stream block by block (edge i is a pure function of (seed, i)) and keeps what it owns
@@ -344,18 +355,19 @@ int32_t srw_alias_row(srw_handle *h, int32_t v, float *prob, int32_t *alias, int
 
 int32_t srw_walk(srw_handle *h, const srw_walk_params *params, srw_walk_stats *stats) {
   if (!h) return SRW_ERR_INVALID;
-  return guarded(h, [&] { need(params != nullptr, "params is null"); run_walk(h, *params, stats); });
+  return guarded(h, [&] { need_population0(h, "srw_walk"); need(params != nullptr, "params is null"); run_walk(h, *params, stats); });
 }
 
 int32_t srw_walk_to_host(srw_handle *h, const srw_walk_params *params, int32_t *paths, int32_t *lens, srw_walk_stats *stats) {
   if (!h) return SRW_ERR_INVALID;
-  return guarded(h, [&] { need(params && paths && lens, "null argument"); run_walk_to_host(h, *params, paths, lens, stats); });
+  return guarded(h, [&] { need_population0(h, "srw_walk_to_host"); need(params && paths && lens, "null argument"); run_walk_to_host(h, *params, paths, lens, stats); });
 }
 
 int32_t srw_walk_and_save(srw_handle *h, const srw_walk_params *params, const char *output_dir, int32_t n_parts,
                           int32_t write_crc, srw_walk_stats *stats, int64_t *dead_ends_per_iteration) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
+    need_population0(h, "srw_walk_and_save");
     need(params && output_dir, "null argument");
     run_walk_and_save(h, *params, output_dir, n_parts, write_crc != 0, stats, dead_ends_per_iteration);
   });
@@ -525,6 +537,7 @@ int32_t srw_w2v_fit(srw_handle *h, const int32_t *paths, const int32_t *lens, in
                     int32_t **vocab_ids, float **vectors, int64_t *n_vocab) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
+    need_population0(h, "srw_w2v_fit");
     need(params && vocab_ids && vectors && n_vocab && (n == 0 || (paths && lens)) && stride >= 1 && n >= 0, "null or bad argument");
     std::vector<int32_t> ids; std::vector<float> vec;
     w2v_fit(h, paths, lens, n, stride, *params, ids, vec);
@@ -540,6 +553,7 @@ int32_t srw_w2v_fit_device(srw_handle *h, const void *d_paths, const void *d_len
                            int32_t **vocab_ids, float **vectors, int64_t *n_vocab) {
   if (!h) return SRW_ERR_INVALID;
   return guarded(h, [&] {
+    need_population0(h, "srw_w2v_fit_device");
     need(params && vocab_ids && vectors && n_vocab && stride >= 1 && n >= 0, "null or bad argument");
     const int32_t *dp = (const int32_t *)d_paths, *dl = (const int32_t *)d_lens;
     if (!dp && !dl) {                       // the handle's own last walk (srw_device_paths)
@@ -580,7 +594,7 @@ int32_t srw_w2v_save_words(const char *const *words, const float *vectors, int64
 
 int32_t srw_probe_request_rate(srw_handle *h, int64_t table_bytes, double *reads_per_s, double *table_gib) {
   if (!h) return SRW_ERR_INVALID;
-  return guarded(h, [&] { need(reads_per_s, "null argument"); probe_request_rate(h, table_bytes, reads_per_s, table_gib); });
+  return guarded(h, [&] { need_population0(h, "srw_probe_request_rate"); need(reads_per_s, "null argument"); probe_request_rate(h, table_bytes, reads_per_s, table_gib); });
 }
 
 int32_t srw_result_scan_sums(srw_handle *h, int64_t *sums) {

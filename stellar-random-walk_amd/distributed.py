@@ -43,14 +43,15 @@ class HipShardEngine:
         torch.zeros(1, device=self.device)       # torch's device context first (it ships its own HIP runtime)
         self.engine = Engine(device=device, rank=rank, world=world, owner_from_partitions=owner_from_partitions,
                              membership=membership)     # False: SRW_CFG_NO_MEMBERSHIP (q == 1 walks only)
-        self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # population 0 runs on the stream that is current NOW — the object is kept: select() hands THIS stream back, whatever stream is
+        # current by the time of the first select (kernels and their all_to_all must share one stream)
+        self._streams = [torch.cuda.current_stream(self.device), None]
+        self.engine.set_stream(self._streams[0].cuda_stream)
         self.world = world
 
     def select(self, population):
         """srw_shard_select: population 0 / 1 of this handle, each with its own super-step context and its own torch stream
         (returned: run the population's super-step and its collective under `with torch.cuda.stream(...)`)."""
-        if not hasattr(self, "_streams"):
-            self._streams = [torch.cuda.current_stream(self.device), None]
         self.engine._ck(lib().srw_shard_select(self.engine.h, int(population)))
         if population == 1 and self._streams[1] is None:
             self._streams[1] = torch.cuda.Stream(device=self.device)

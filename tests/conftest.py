@@ -13,8 +13,25 @@ KARATE = os.path.join(GOLDEN, "karate.txt")
 TESTGRAPH = os.path.join(GOLDEN, "testgraph.txt")
 
 
+# environment variables that may be present without steering a kernel, a planner or a host path
+_NEUTRAL = {"SRW_SKIP_FULL_SIZE", "SRW_TIMING"}
+
+
+def steering_switches_set():
+    """SRW_* variables of tools/SWITCHES.md that are set in this process's environment (other than the neutral ones)."""
+    return sorted(k for k in os.environ if k.startswith("SRW_") and k not in _NEUTRAL)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """The suite describes the DEFAULTS: a session that starts with an experiment switch in its environment is refused (tests that
+    need one set it themselves, with monkeypatch, and take it away again)."""
+    bad = steering_switches_set()
+    if bad:
+        pytest.exit("steering switches are set in the environment: %s (tools/SWITCHES.md) — unset them" % ", ".join(bad), returncode=3)
 
 
 @pytest.fixture(scope="session")

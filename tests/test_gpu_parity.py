@@ -1169,3 +1169,20 @@ def test_device_tokenizer_fuzz(eng, tmp_path, monkeypatch):
         monkeypatch.setenv("SRW_HOST_TOKENIZER", "1")
         b = outcome()
         assert a == b, (k, text)
+
+
+def test_entry_points_refuse_while_population_1_is_selected():
+    """srw_shard_select(h, 1) swaps the handle's stream, counters and cursors with the second population's; every entry point outside
+    the super-step family refuses until population 0 is selected again, instead of running with the wrong context."""
+    P = pkg()
+    with P.Engine(device=0) as e:
+        e.load_edgelist(KARATE, directed=False)
+        ref = e.walk(walk_length=5, seed=1)
+        e._ck(P.lib().srw_shard_select(e.h, 1))
+        with pytest.raises(P.SrwError, match="population 1 is selected"):
+            e.walk(walk_length=5, seed=1)
+        with pytest.raises(P.SrwError, match="population 1 is selected"):
+            e.load_edgelist(KARATE, directed=False)
+        e._ck(P.lib().srw_shard_select(e.h, 0))
+        again = e.walk(walk_length=5, seed=1)
+        assert np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])

@@ -495,3 +495,28 @@ def test_table_geometry_closed_form_matches_its_definition():
     # argument checks
     assert L.srw_table_geometry(0, 1, (C.c_int32 * 10)(*policies[0]), C.byref(a), C.byref(b), C.byref(c)) != 0
     assert L.srw_table_geometry(5, 1, None, C.byref(a), C.byref(b), C.byref(c)) != 0
+
+
+def test_switches_are_listed_and_off_by_default():
+    """VERDICT r04 hygiene: ~50 SRW_* environment switches and ~20 compile switches steer the kernels.  Every one of them is listed in
+    tools/SWITCHES.md (the table there is regenerated from the sources and compared), the default build defines none of the compile
+    switches, and this very session runs with none of the environment switches set (tests/conftest.py enforces it)."""
+    import importlib.util
+    import re
+    import subprocess
+    spec = importlib.util.spec_from_file_location("list_switches", os.path.join(ROOT, "tools", "list_switches.py"))
+    ls = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ls)
+    env, comp = ls.scan()
+    assert len(env) >= 40 and len(comp) >= 15
+    doc = open(os.path.join(ROOT, "tools", "SWITCHES.md")).read()
+    assert ls.MARK in doc and doc.split(ls.MARK)[1].strip() == ls.table(env, comp).split(ls.MARK)[1].strip(), \
+        "tools/SWITCHES.md is stale: python tools/list_switches.py --write"
+    # the default build: no -DSRW_* on any compile line (EXTRA is empty unless a variant is asked for)
+    r = subprocess.run(["make", "-n", "-B", "-C", os.path.join(ROOT, "stellar-random-walk_amd", "csrc")], capture_output=True, text=True)
+    assert r.returncode == 0 and "hipcc" in r.stdout and not re.search(r"-DSRW_", r.stdout), r.stdout[-2000:]
+    mk = open(os.path.join(ROOT, "stellar-random-walk_amd", "csrc", "Makefile")).read()
+    assert re.search(r"^EXTRA\s*\?=\s*$", mk, re.M)
+    # and nothing steers this session
+    import conftest
+    assert conftest.steering_switches_set() == []

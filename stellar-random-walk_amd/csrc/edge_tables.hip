@@ -451,6 +451,23 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
     for (int i = 0; i < 8; ++i) if (ns[i]) atomicAdd(&strat_count[i], ns[i]);
 }
 
+// The build in segments (vm_buf.h): tables are laid out in row order and so is the work list, so the work list splits where the
+// tables cross a chunk boundary of the progressively mapped buffer.  Segment k = the rows that START in chunk k; seg_item[k] = its first
+// work-list item, seg_end[k] = where its last row's tables end (64-byte units) — what must be mapped before it runs.
+__global__ void k_eb_segments(const unsigned long long *__restrict__ row_units, const unsigned long long *__restrict__ row_pairs, int64_t n_slots,
+                              unsigned long long chunk_units, int n_seg, unsigned long long total_units, unsigned long long n_listed,
+                              unsigned long long *__restrict__ seg_item /* [n_seg + 1] */, unsigned long long *__restrict__ seg_end /* [n_seg] */) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k > n_seg) return;
+  if (k == 0) { seg_item[0] = 0ull; return; }
+  if (k == n_seg) { seg_item[k] = n_listed; seg_end[k - 1] = total_units; return; }
+  const unsigned long long B = (unsigned long long)k * chunk_units;
+  int64_t lo = 0, hi = n_slots;
+  while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (row_units[mid] < B) lo = mid + 1; else hi = mid; }
+  seg_item[k] = lo < n_slots ? row_pairs[lo] : n_listed;
+  seg_end[k - 1] = lo < n_slots ? row_units[lo] : total_units;
+}
+
 // rev[e] for every entry e = (u -> v): where the return edges sit in N(v) (k_walk_q1) — the index, in v's SORTED row, of
 // the first entry that leads back to u, and how many there are (multi-edges).  One lane per entry: lower bound of u in
 // v's sorted row, then the run of equal ids.
@@ -620,7 +637,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   const unsigned long long all_pairs = pairs + mpairs;
   const auto t_alloc0 = std::chrono::steady_clock::now();
   g.eb_off.ensure((size_t)g.n_entries);
-  g.eb_bins.alloc((size_t)units * 8);
+  g.eb_bins.alloc_progressive((size_t)units * 8, h->cfg.device);      // the pages arrive while the build fills them (vm_buf.h)
   g.em_bits.alloc((size_t)munits * 4);
   DevBuf<uint2> items; items.alloc((size_t)all_pairs);
   if (getenv("SRW_TIMING"))
@@ -649,16 +666,47 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   DevBuf<double> gscratch;
   const int64_t gs_stride = sel.pol.fine_cap > BIN_CAP ? (int64_t)sel.pol.fine_cap : 0;
   if (gs_stride) gscratch.alloc((size_t)blocks * (TPB / 64) * (size_t)gs_stride);
+  double waited_ms = 0.0; int n_launches = 0;
   if (all_pairs) {
-    SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+    const int fill_tune = getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0;
     SRW_HIP(hipMemsetAsync(hist.p, 0, 16 * 8, st));
-    hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.mask_max,
-                       sel.pol, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0,
-                       gscratch.p, gs_stride);
-    SRW_HIP(hipGetLastError());
+    auto launch = [&](unsigned long long i0, unsigned long long n_it) {
+      SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+      hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p + i0, (int64_t)n_it, p, q, sel.mask_max,
+                         sel.pol, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, fill_tune, gscratch.p, gs_stride);
+      SRW_HIP(hipGetLastError());
+      ++n_launches;
+    };
+    if (!g.eb_bins.progressive()) launch(0ull, all_pairs);
+    else {
+      // one launch per chunk of the table buffer, each as soon as its rows' tables are backed by pages
+      const unsigned long long chunk_units = (unsigned long long)(g.eb_bins.chunk_bytes() / 64);
+      const int n_seg = (int)((units + chunk_units - 1) / chunk_units);
+      DevBuf<unsigned long long> d_seg; d_seg.alloc((size_t)2 * n_seg + 2);
+      hipLaunchKernelGGL(k_eb_segments, dim3((unsigned)((n_seg + 1 + 255) / 256)), dim3(256), 0, st, row_units.p, row_pairs.p, (int64_t)g.n_slots, chunk_units,
+                         n_seg, units, all_pairs, d_seg.p, d_seg.p + n_seg + 1);
+      SRW_HIP(hipGetLastError());
+      std::vector<unsigned long long> seg((size_t)2 * n_seg + 2);
+      SRW_HIP(hipMemcpyAsync(seg.data(), d_seg.p, seg.size() * 8, hipMemcpyDeviceToHost, st));
+      SRW_HIP(hipStreamSynchronize(st));
+      for (int k = 0; k < n_seg; ++k) {
+        const unsigned long long i0 = seg[(size_t)k], i1 = seg[(size_t)k + 1];
+        if (i1 <= i0) continue;
+        const auto tw = std::chrono::steady_clock::now();
+        g.eb_bins.wait_mapped((size_t)seg[(size_t)n_seg + 1 + k] * 64);
+        waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+        launch(i0, i1 - i0);
+      }
+      const auto tw = std::chrono::steady_clock::now();
+      g.eb_bins.wait_all();
+      waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+    }
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
-  }
+  } else g.eb_bins.wait_all();
   SRW_HIP(hipStreamSynchronize(st));
+  if (getenv("SRW_TIMING") && g.eb_bins.progressive())
+    fprintf(stderr, "[edge tables] table buffer mapped in chunks of %.0f GiB while the build ran: %d launches, the host waited %.0f ms for pages\n",
+            (double)g.eb_bins.chunk_bytes() / (double)((size_t)1 << 30), n_launches, waited_ms);
 #ifdef SRW_PHASE_TIMING
   {
     unsigned long long tt[8];
@@ -750,7 +798,7 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
     SRW_HIP(hipStreamSynchronize(st));
   }
   const unsigned long long all_pairs = pl.pairs + pl.mpairs;
-  g.eb_bins.alloc((size_t)pl.units * 8);
+  g.eb_bins.alloc_progressive((size_t)pl.units * 8, h->cfg.device);      // (vm_buf.h: the pages arrive while the build fills them)
   g.em_bits.alloc((size_t)pl.munits * 4);
   g.ph.alloc((size_t)pl.buckets * 4); g.ph_buckets = pl.buckets;
   SRW_HIP(hipMemsetAsync(g.ph.p, 0xFF, (size_t)pl.buckets * 4 * sizeof(PairSlot), st));
@@ -772,14 +820,36 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
   const int64_t gs_stride = sel.pol.fine_cap > BIN_CAP ? (int64_t)sel.pol.fine_cap : 0;
   if (gs_stride) gscratch.alloc((size_t)blocks * (TPB / 64) * (size_t)gs_stride);
   if (all_pairs) {
-    SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+    const int fill_tune = getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0;
     SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
-    hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p, (int64_t)all_pairs, p, q, sel.mask_max,
-                       sel.pol, item_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0,
-                       gscratch.p, gs_stride);
-    SRW_HIP(hipGetLastError());
+    auto launch = [&](unsigned long long i0, unsigned long long n_it) {
+      SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
+      hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p + i0, (int64_t)n_it, p, q, sel.mask_max,
+                         sel.pol, item_off.p + i0, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, fill_tune, gscratch.p, gs_stride);
+      SRW_HIP(hipGetLastError());
+    };
+    if (!g.eb_bins.progressive()) launch(0ull, all_pairs);
+    else {                                           // one launch per chunk of the table buffer (build_edge_tables, k_eb_segments)
+      const unsigned long long chunk_units = (unsigned long long)(g.eb_bins.chunk_bytes() / 64);
+      const int n_seg = (int)((pl.units + chunk_units - 1) / chunk_units);
+      DevBuf<unsigned long long> d_seg; d_seg.alloc((size_t)2 * n_seg + 2);
+      SRW_HIP(hipMemsetAsync(row_pairs.p + g.n_slots, 0xFF, 8, st));          // (never read: the search stops below n_slots)
+      hipLaunchKernelGGL(k_eb_segments, dim3((unsigned)((n_seg + 1 + 255) / 256)), dim3(256), 0, st, row_units.p, row_pairs.p, (int64_t)g.n_slots, chunk_units,
+                         n_seg, pl.units, all_pairs, d_seg.p, d_seg.p + n_seg + 1);
+      SRW_HIP(hipGetLastError());
+      std::vector<unsigned long long> seg((size_t)2 * n_seg + 2);
+      SRW_HIP(hipMemcpyAsync(seg.data(), d_seg.p, seg.size() * 8, hipMemcpyDeviceToHost, st));
+      SRW_HIP(hipStreamSynchronize(st));
+      for (int k = 0; k < n_seg; ++k) {
+        const unsigned long long i0 = seg[(size_t)k], i1 = seg[(size_t)k + 1];
+        if (i1 <= i0) continue;
+        g.eb_bins.wait_mapped((size_t)seg[(size_t)n_seg + 1 + k] * 64);
+        launch(i0, i1 - i0);
+      }
+      g.eb_bins.wait_all();
+    }
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
-  }
+  } else g.eb_bins.wait_all();
   SRW_HIP(hipStreamSynchronize(st));
   if (sc[7]) throw Error(SRW_ERR_INVALID, "per-edge tables: a prefix sum of a ROW_PQ_F32 row was not exactly representable in binary32 (or a chunk mass not in 16 bits)");
   uint32_t pb, qb; memcpy(&pb, &p, 4); memcpy(&qb, &q, 4);
@@ -911,6 +981,7 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
     catch (const Error &e) {
       if (e.code != SRW_ERR_NOMEM) throw;
       (void)hipGetLastError();
+      (void)hipStreamSynchronize(h->stream);          // (segments of the build may be running over the chunks that did get mapped)
       g.eb_bins.release(); g.em_bits.release(); g.ph.release(); g.ph_buckets = 0; g.has_eb = false;
       if (attempt || cap_sel <= 32) break;
       cap_sel = 32; g.eb_min_sh_sel = 8; sel = shard_sel(g, mode, 32);

@@ -58,6 +58,10 @@ struct DevBuf {
   void ensure(size_t count) { if (count > n) alloc(count); }
 };
 
+}  // namespace srw
+#include "vm_buf.h"
+namespace srw {
+
 struct Graph {
   bool loaded = false;
   int32_t vmin = 0, vmax = -1;
@@ -93,7 +97,7 @@ struct Graph {
   DevBuf<uint64_t> ehash;         // Mode A: edge hash set (optional, built lazily when q != 1)
   uint64_t ehash_mask = 0; bool has_ehash = false; bool use_ehash = false;   // built / used by the current call
   DevBuf<uint32_t> eb_off;        // [n_entries] per-edge bias tables (edge_tables.hip): offset of entry e's table, 64-B units
-  DevBuf<double> eb_bins;         // the tables
+  VmBuf<double> eb_bins;          // the tables (their pages are mapped while the build fills them: vm_buf.h)
   DevBuf<uint32_t> em_bits;       // membership masks of the pairs whose curr row has 33 .. eb_mask_max candidates
   int32_t eb_mask_max = 0, eb_f32 = 0, eb_cap = 64;
   DevBuf<RevEnt> rev;             // [n_entries] the return edge(s) of every entry (k_walk_q1), built lazily

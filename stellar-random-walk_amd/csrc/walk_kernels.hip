@@ -2524,6 +2524,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
       catch (const Error &e) {
         if (e.code != SRW_ERR_NOMEM) throw;
         (void)hipGetLastError();
+        (void)hipStreamSynchronize(h->stream);          // (segments of the build may be running over the chunks that did get mapped)
         Graph &g = h->g;
         g.eb_bins.release(); g.em_bits.release(); g.has_eb = false; g.eb_complete = false; g.eb_tables = 0; g.eb_bytes = 0;
         h->g.eb_budget_gb = 160; g.eb_min_sh_sel = 8; g.eb_cm_sel = 0; g.eb_fine_cap_sel = 0; g.eb_cm_ratio_sel = 0;

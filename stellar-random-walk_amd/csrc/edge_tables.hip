@@ -306,9 +306,12 @@ __global__ __launch_bounds__(TPB) void k_eb_inline(GraphView g, ShardSel ss, EbS
 #ifndef SRW_EB_WAVES
 #define SRW_EB_WAVES 4
 #endif
-constexpr int EB_LDS_WORDS = 2 * BIN_CAP + HCHUNK;      // binned_fill's bins + the staged ids of N(prev): 6 KB per wave
+#ifndef SRW_EB_HC
+#define SRW_EB_HC 1024             // (2 048 ids per staged chunk halve the chunk advances but cost a wave per SIMD: 10.3 against 8.9 s at config 3, r05)
+#endif
+constexpr int EB_LDS_WORDS = 2 * BIN_CAP + SRW_EB_HC;      // binned_fill's bins + the staged ids of N(prev)
 template <bool SH>
-__global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
+__global__ __launch_bounds__(TPB, (SRW_EB_HC > 1024 && SRW_EB_WAVES > 3) ? 3 : SRW_EB_WAVES) void k_eb_build(GraphView g, const uint2 *__restrict__ items, int64_t n_items, float p,
                                                      float q, int32_t mask_max, EbPolicy pol, const uint32_t *__restrict__ eb_off,
                                                      double *__restrict__ eb_bins, uint32_t *__restrict__ em_bits, unsigned long long *cursor,
                                                      unsigned long long *strat_count /* [8] */, int fill_tune, double *gscratch, int64_t gs_stride) {
@@ -387,8 +390,8 @@ __global__ __launch_bounds__(TPB, SRW_EB_WAVES) void k_eb_build(GraphView g, con
       unsigned long long ab = 0; unsigned su = 0;
       // chunk masks (rows of at most EB_CM_LIMIT candidates: at most 256 fill bins, the upper half of the bins' LDS is free)
       uint32_t *mbits = pg.cmask ? mine + BIN_CAP : nullptr;
-      if (big) binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K, true>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits, gbins);
-      else binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K, false>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits);
+      if (big) binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K, true, SRW_EB_HC>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits, gbins);
+      else binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K, false, SRW_EB_HC>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits);
       ns[su & 7] += 1;
 #ifdef SRW_PHASE_TIMING
       const unsigned long long t_fill = wall_clock64();

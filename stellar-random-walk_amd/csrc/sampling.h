@@ -1057,7 +1057,8 @@ __host__ __device__ inline BinnedCost binned_cost(int32_t deg, int32_t m, bool h
 // PF: rounds of candidates the sorted-chunk intersection keeps in flight ahead of the one it works on (12 VGPRs each); P1K: binary
 // searches per lane in lockstep in P1.  Both are experiment parameters: 2 / 8 did not move the table build (profiles/r03_eb_build.md)
 // GB (edge_tables.hip, tables of more chunks than BIN_CAP): the bins are `gbins`, a slice of an HBM scratch owned by this wave
-template <int PF = 1, int P1K = 2, bool GB = false>
+// HC: ids of N(prev) staged per chunk (a power of two >= 1 024; the table build stages 2 048: half the chunk advances of a long N(prev))
+template <int PF = 1, int P1K = 2, bool GB = false, int HC = HCHUNK>
 __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias &b, uint32_t *lds, int tune,
                                    const BinGeom geo, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used,
                                    uint32_t *mbits = nullptr /* edge_tables.hip: LDS bitmap over curr's positions, bit k = candidate k is in N(prev) */,
@@ -1211,9 +1212,9 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
             }
           }
         };
-        auto stage_b = [&](int32_t pos) {                       // B[pos .. pos + 1024) -> LDS, sorted, padded
+        auto stage_b = [&](int32_t pos) {                       // B[pos .. pos + HC) -> LDS, sorted, padded
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < HC / 256; ++u) {
             const int32_t i0 = pos + 256 * u + 4 * lane;
             uint4 q;
             if (i0 + 3 < m) { const U32x4 t = *reinterpret_cast<const U32x4 *>(B + i0); q = make_uint4(t.a, t.b, t.c, t.d); }
@@ -1234,7 +1235,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
 #ifdef SRW_PHASE_TIMING
           tm.n_w_windows += 1;
 #endif
-          const int32_t nb = (m - pb) < HCHUNK ? (m - pb) : HCHUNK;
+          const int32_t nb = (m - pb) < HC ? (m - pb) : HC;
           const uint32_t bmax = bch[nb - 1];                   // uniform LDS read
           // my four candidates against the staged chunk
           bool want[4]; uint32_t pos[4];
@@ -1245,7 +1246,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
           }
           SRW_U0(tm);
 #pragma unroll
-          for (int step = HCHUNK / 2; step >= 1; step >>= 1) {
+          for (int step = HC / 2; step >= 1; step >>= 1) {
             uint32_t probe[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) probe[j] = bch[pos[j] + step - 1];
@@ -1277,7 +1278,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
             load_a(pa + 256 * PF, NI[PF - 1], NC[PF - 1], NW[PF - 1]);
           } else {
             handled = bmax; have_handled = true;
-            pb += HCHUNK;
+            pb += HC;
             if (pb >= m || bmax >= hi_id) break;
             __builtin_amdgcn_wave_barrier();
             stage_b(pb);

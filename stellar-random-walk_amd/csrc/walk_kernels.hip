@@ -2350,6 +2350,17 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
 }
 
 void prepare_tables(srw_handle *h, const srw_walk_params &P) {
+  // SRW_TIMING: where the cold start of a call goes, phase by phase (each phase synchronises the stream when timing is on)
+  const bool timing = getenv("SRW_TIMING") != nullptr;
+  auto t_phase = std::chrono::steady_clock::now();
+  auto phase = [&](const char *name) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(h->stream);
+    const auto t = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t - t_phase).count();
+    if (ms >= 20.0) fprintf(stderr, "[timing] prepare_tables: %s %.0f ms\n", name, ms);
+    t_phase = t;
+  };
   const bool alias = P.sampler == SRW_SAMPLER_ALIAS;
   const bool first_order = !alias && (P.p == 1.0f && P.q == 1.0f) && !(P.flags & SRW_WALK_FORCE_GENERAL);
   if (first_order) build_first_order_tables(h, P.rng_mode != SRW_RNG_PHILOX || (P.flags & SRW_WALK_NO_COMPACT));
@@ -2360,7 +2371,9 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
     build_first_order_tables(h, false);
     build_rev_table(h);
   }
+  phase("membership / first-order tables / return edges");
   if (alias) build_alias_tables(h);
+  phase("alias tables");
   const bool general = !alias && !first_order;
   // optional accelerators, most valuable first (each one skips itself when HBM is short):
   // exact base prefix sums for the search samplers ...
@@ -2374,7 +2387,9 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
   const bool want_eb = general && P.q != 1.0f && h->cfg.world == 1 && h->g.has_pq && !(P.flags & SRW_WALK_NO_EDGE_TABLES) &&
                        !(P.flags & SRW_WALK_NO_BINNED);
   const int eb_mode = (P.flags & SRW_WALK_EDGE_TABLES_ALL) ? 1 : 0;
+  phase("prefix sums of the (p, q) base weights");
   if (want_eb) build_unit_ids(h);                     // unit-weight graphs: 4-byte ids for the table steps (before the tables are sized)
+  phase("unit-weight ids");
   const char *env_hub = getenv("SRW_HUB_BUDGET_GB"), *env_cap = getenv("SRW_EB_CHUNKS");
   // The edge hash (8 B x 2-3 per entry) against table resolution: when a COMPLETE 64-chunk set of per-edge tables fits only
   // without the hash, the hash goes — the located chunks' probes of a long non-hub N(prev) fall back to the sorted row, and
@@ -2505,14 +2520,18 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
     want_ehash = false;
     if (h->g.has_ehash) { h->g.ehash.release(); h->g.has_ehash = false; }
   }
+  phase("table plan (sizing passes)");
   if (want_ehash) build_edge_hash(h);
   h->g.use_ehash = want_ehash;
+  phase("edge hash");
   // no edge hash for the table steps (traded above, or not wanted): the long rows' neighbor-set filters answer most of the
   // located chunks' probes from L2 (config 5's stand-in: 2.0e8 -> 2.73e8 steps/s, 3 GB).  With the hash they are not worth
   // their registers (config 3: -1 ... -4 %): k_walk_tables<false>.
   if (want_eb && !want_ehash && !getenv("SRW_NO_ROW_FILTERS")) build_row_filters(h);
+  phase("row filters");
   if (want_hub) build_hub_bitmaps(h, ((P.flags >> 15) & 1) ? 1 : 1024, hub_cap);
   h->g.use_hub = want_hub;
+  phase("hub bitmaps");
   // ... and, last (they take what HBM is left), the per-edge bias tables: the most expensive (prev, curr) pairs get
   // their N(prev) ∩ N(curr) corrections precomputed once per (p, q) instead of once per visit
   if (want_eb) {
@@ -2535,6 +2554,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
     h->g.eb_no_ehash = drop_ehash;
   }
   h->g.use_eb = want_eb;
+  phase("per-edge tables");
 }
 double timed_prepare_tables(srw_handle *h, const srw_walk_params &P) {   // builders synchronise the stream themselves
   const auto t0 = std::chrono::steady_clock::now();

@@ -117,7 +117,14 @@ static void doEmbedding(const Params &param) {  // Main.scala:119-124: textFile(
     std::ifstream in(fn);
     if (!in) throw std::runtime_error("Input path does not exist: " + fn);
     std::string line;
-    while (std::getline(in, line)) { javaSplit(line, toks); rows.push_back(toks); }
+    // MLlib's Word2Vec cuts a sentence after maxSentenceLength = 1000 words (its default; Main.configureWord2Vec does not change it): a
+    // longer line is several sentences, and no window crosses the cut
+    while (std::getline(in, line)) {
+      javaSplit(line, toks);
+      if (toks.size() <= 1000) { rows.push_back(toks); continue; }
+      for (size_t i = 0; i < toks.size(); i += 1000)
+        rows.emplace_back(toks.begin() + (long)i, toks.begin() + (long)std::min(toks.size(), i + 1000));
+    }
   }
   size_t stride = 1, n_tok = 0;
   for (const auto &r : rows) { stride = std::max(stride, r.size()); n_tok += r.size(); }

@@ -172,3 +172,19 @@ def test_cli_embedding_takes_words(tmp_path):
     out2 = tmp_path / "w2"; (out2 / "bin").mkdir(parents=True)
     r = _cli("--cmd", "embedding", "--input", str(txt), "--output", str(out2), "--dim", "4", "--iter", "1")
     assert r.returncode == 1 and "already exists" in r.stderr and not (out2 / "vec").exists()
+
+
+def test_cli_embedding_cuts_sentences_at_1000_words(tmp_path):
+    """MLlib's maxSentenceLength (1000, not changed by Main.configureWord2Vec): a line of 2 500 words trains as sentences of 1000, 1000
+    and 500 — the same model as the three lines written out."""
+    rng = np.random.default_rng(1)
+    words = [str(int(x)) for x in rng.integers(0, 50, 2500)]
+    one = tmp_path / "one.txt"; one.write_text(" ".join(words) + "\n")
+    three = tmp_path / "three.txt"; three.write_text("\n".join(" ".join(words[i:i + 1000]) for i in (0, 1000, 2000)) + "\n")
+    outs = []
+    for name, f in (("a", one), ("b", three)):
+        r = _cli("--cmd", "embedding", "--input", str(f), "--output", str(tmp_path / name), "--dim", "8", "--iter", "1", "--window", "3",
+                 env={"SRW_W2V_DETERMINISTIC": "1"})
+        assert r.returncode == 0, r.stderr
+        outs.append(open(os.path.join(str(tmp_path / name), "vec", "part-00000")).read())
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == 50

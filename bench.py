@@ -149,7 +149,7 @@ def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None, cei
             for j in (js if isinstance(js, list) else [js]):
                 # an entry stands for ONE workload: kernel, scale and (ef, p, q, weighted, directed) must all agree
                 if j.get("kernel") == name and j.get("scale") == scale and all(
-                        float(j.get(k, v)) == float(v) for k, v in (wl or {}).items()):
+                        float(j.get(k, -1)) == float(v) for k, v in (wl or {}).items()):
                     r["traffic"] = j.get("hbm_bytes_per_launch")
                     r["traffic_commit"] = j.get("commit", "?")
                     r["traffic_source"] = ("profiles/pmc_latest.json <- %s (commit %s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ "
@@ -219,7 +219,7 @@ def measure(eng, walk_kw, K, W, first_walk=0):
     return steps, dt, kernel_ms, stats, (setup_ms + inner_setup) * 1e-3
 
 
-def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L=80, ceiling=None):
+def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L=80, ceiling=None, plan_walks=0):
     """One BASELINE configuration on one GPU: graph generated on the device, W + K walk iterations."""
     import torch
     torch.cuda.synchronize()
@@ -228,6 +228,8 @@ def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, 
     try:
         eng.generate_rmat(scale, ef << scale, seed=42, weighted=weighted, directed=directed)
         nv, ne = eng.stats()
+        if plan_walks:                             # the job's --numWalks (srw_plan_walks): a long job gets the finer per-edge tables
+            eng.plan_walks(plan_walks)
         torch.cuda.synchronize()                   # device-wide: the build runs on the engine's own stream
         t_graph = time.perf_counter() - t0
         kw = dict(p=p, q=q, walk_length=L, num_walks=1, seed=42)
@@ -248,12 +250,15 @@ def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, 
                "walk_steps_per_bench_step": int(steps / max(K, 1)),
                "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables},
                "roofline": roofline_of(st, steps / max(K, 1), avg_ms, scale=scale, n_entries=ne, ceiling=ceiling, scan=scan, q=q,
-                                       wl=dict(ef=ef, p=p, q=q, weighted=int(weighted), directed=int(directed)))}
+                                       wl=dict(ef=ef, p=p, q=q, weighted=int(weighted), directed=int(directed), planned_walks=plan_walks))}
         if st["kernel_kind"] == 2:
             out["strategy_steps"] = {k: v for k, v in st["strategy_steps"].items() if v}
             out["edge_tables"] = {"count": st["edge_tables"], "bytes": st["edge_table_bytes"]}
             # the whole job of the config's numWalks = 10 from a cold start: tables once + 10 iterations
             out["job_numWalks10_steps_per_s"] = 10 * steps / max(K, 1) / (t_tables + 10 * dt / max(K, 1))
+            if plan_walks:
+                out["planned_walks"] = plan_walks
+                out["job_planned_steps_per_s"] = plan_walks * steps / max(K, 1) / (t_tables + plan_walks * dt / max(K, 1))
         if st["kernel_kind"] == 3:
             out["trials_per_step"] = st["trials"] / max(st["n_steps"], 1)
         return out
@@ -402,7 +407,7 @@ def cluster_leg(pkg, torch, args, world, K):
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg", "algorithmic_bytes_per_launch",
                  "record_bytes", "physical_traffic_frac", "requests_per_step", "requests_per_s", "request_rate_ceiling",
                  "request_rate_frac", "scan_equivalent_frac", "traffic_commit")
-SUMMARY_KEYS = ("name", "value", "ms_per_step", "kernel_ms", "job_numWalks10_steps_per_s", "fraction_of_replicated", "error")
+SUMMARY_KEYS = ("name", "value", "ms_per_step", "kernel_ms", "job_numWalks10_steps_per_s", "job_planned_steps_per_s", "fraction_of_replicated", "error")
 LINE_LIMIT = 4096               # the driver reads the LAST stdout line; round 4's 24 KB line was not parsed
 
 
@@ -661,7 +666,7 @@ def main():
                            "parallelism": ("graph replicated, walk iterations sharded x%d, no collective" % world) if world > 1 else "1 GPU",
                            "rng": "Philox4x32-10 keyed (iteration, source, step)"},
                 "roofline": roofline_of(stats, steps / max(K, 1), avg_ms, scale=args.scale, n_entries=ne, ceiling=ceiling, scan=scan, q=args.q,
-                                        wl=dict(ef=args.edge_factor, p=args.p, q=args.q, weighted=int(args.weighted), directed=int(args.directed))),
+                                        wl=dict(ef=args.edge_factor, p=args.p, q=args.q, weighted=int(args.weighted), directed=int(args.directed), planned_walks=0)),
                 "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables,
                             "note": "outside the timed region; one-off per graph / per (p, q)"},
             }
@@ -749,6 +754,7 @@ def main():
             cfgs = []
             plan = [("C2", 20, 16, False, False, 1.0, 1.0, "reference", 10, 1),
                     ("C3 Mode R", 24, 16, True, False, 0.25, 4.0, "reference", 2, 1),
+                    ("C3 Mode R numWalks=100", 24, 16, True, False, 0.25, 4.0, "reference", 2, 1),
                     ("C3 Mode A", 24, 16, True, False, 0.25, 4.0, "alias", 3, 1),
                     ("C3 graph q=1 Mode R", 24, 16, True, False, 0.25, 1.0, "reference", 3, 1),
                     ("C5 stand-in Mode R", 26, 27, False, True, 4.0, 0.5, "reference", 1, 1),
@@ -757,7 +763,8 @@ def main():
             for (name, sc, ef, wt, dr, p, q, smp, k, w) in plan:
                 sc = min(sc, cap)
                 try:
-                    cfgs.append(run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w, ceiling=ceiling))
+                    cfgs.append(run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w, ceiling=ceiling,
+                                           plan_walks=100 if "numWalks=100" in name else 0))
                 except Exception as ex:
                     cfgs.append({"name": name, "error": str(ex)[:300]})
             if args.shard in ("both", "vertex"):

@@ -82,7 +82,7 @@ def test_single_gpu_line_with_every_config_stays_small(tmp_path):
     check_driver_keys(d)
     rows = d["configs_summary"]
     full = json.load(open(detail))
-    assert [c["name"] for c in rows] == [c["name"] for c in full["configs"]] and len(rows) == 10
+    assert [c["name"] for c in rows] == [c["name"] for c in full["configs"]] and len(rows) == 11
     for c in rows:
         assert "error" not in c and c["value"] > 0 and c["ms_per_step"] > 0, c
     assert all("fraction_of_replicated" in c for c in rows if c["name"].startswith("sharded"))

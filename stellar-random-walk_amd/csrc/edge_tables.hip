@@ -708,8 +708,8 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   } else g.eb_bins.wait_all();
   SRW_HIP(hipStreamSynchronize(st));
   if (getenv("SRW_TIMING") && g.eb_bins.progressive())
-    fprintf(stderr, "[edge tables] table buffer mapped in chunks of %.0f GiB while the build ran: %d launches, the host waited %.0f ms for pages\n",
-            (double)g.eb_bins.chunk_bytes() / (double)((size_t)1 << 30), n_launches, waited_ms);
+    fprintf(stderr, "[edge tables] table buffer mapped in chunks of %.0f MiB while the build ran: %d launches, the host waited %.0f ms for pages\n",
+            (double)g.eb_bins.chunk_bytes() / (double)((size_t)1 << 20), n_launches, waited_ms);
 #ifdef SRW_PHASE_TIMING
   {
     unsigned long long tt[8];

@@ -23,7 +23,7 @@ template <typename T>
 struct VmBuf {
   T *p = nullptr;
   size_t n = 0;                                  // elements
-  static constexpr size_t CHUNK = (size_t)4 << 30;
+  size_t CHUNK = (size_t)4 << 30;                // bytes per mapped chunk (SRW_EB_VMM_CHUNK_MB: tests map small tables in many chunks)
   VmBuf() = default;
   VmBuf(const VmBuf &) = delete;
   VmBuf &operator=(const VmBuf &) = delete;
@@ -64,6 +64,7 @@ struct VmBuf {
     if (count == 0) count = 1;
     const size_t bytes = count * sizeof(T);
     const char *no = getenv("SRW_EB_NO_VMM");
+    if (const char *c = getenv("SRW_EB_VMM_CHUNK_MB"); c && atoi(c) >= 2) CHUNK = ((size_t)atoi(c) >> 1 << 1) << 20;     // (a multiple of 2 MiB)
     if (bytes < 2 * CHUNK || (no && *no == '1')) { alloc(count); return; }
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
@@ -116,7 +117,7 @@ struct VmBuf {
  private:
   void take(VmBuf &o) {                                      // (Graph is reset by move assignment: a buffer still being mapped is joined first)
     if (o.mapper_.joinable()) o.mapper_.join();
-    p = o.p; n = o.n; vmm_ = o.vmm_; oom_ = o.oom_; va_bytes_ = o.va_bytes_; handles_ = std::move(o.handles_); err_ = std::move(o.err_);
+    p = o.p; n = o.n; CHUNK = o.CHUNK; vmm_ = o.vmm_; oom_ = o.oom_; va_bytes_ = o.va_bytes_; handles_ = std::move(o.handles_); err_ = std::move(o.err_);
     mapped_.store(o.mapped_.load()); failed_.store(o.failed_.load()); stop_.store(false);
     o.p = nullptr; o.n = 0; o.vmm_ = false; o.va_bytes_ = 0; o.handles_.clear(); o.mapped_.store(0); o.failed_.store(false);
   }

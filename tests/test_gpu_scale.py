@@ -140,6 +140,8 @@ _GEOMETRIES = [
     {"SRW_EB_CM_MAX": "0", "SRW_EB_FINE_CAP": "4096", "SRW_EB_FINE_MIN_DU": "0"},  # finer tables everywhere: two-level trees, HBM-scratch bins in the build
     {"SRW_EB_CM_MAX": "4096", "SRW_EB_FINE_CAP": "1024", "SRW_EB_NO_U16": "1"},
     {"SRW_EB_CHUNKS": "32", "SRW_EB_MIN_SH": "8"},                                # the coarse complete set of a graph that fills the GPU
+    {"SRW_EB_VMM_CHUNK_MB": "64"},                                                # the table buffer mapped in 64 MiB chunks while the build fills it, one build segment per chunk (vm_buf.h; default: 4 GiB chunks, tables >= 8 GiB)
+    {"SRW_EB_VMM_CHUNK_MB": "16", "SRW_EB_FINE_CAP": "4096", "SRW_EB_FINE_MIN_DU": "0"},
 ]
 
 

@@ -260,3 +260,18 @@ def test_shard_chain_kernels_long_rows(oracle, monkeypatch, world, kind):
         assert ss["ties_resolved"] <= ss["handed_over_walkers"], ss
         if kind < 3 and not os.environ.get("SRW_NO_TIE_KERNELS"):   # (kind 3's hub row has no exact prefix sums, hence no table: its steps are the general kernel's own)
             assert ss["ties_resolved"] > 0, ss
+
+
+def test_shard_tables_built_over_a_progressively_mapped_buffer(oracle, monkeypatch):
+    """The shards' table buffer as a virtual range mapped chunk by chunk while the build runs one segment of its work list per chunk
+    (vm_buf.h, edge_tables.hip:k_eb_segments) — forced onto a small graph with 8 MiB chunks — against the oracle, worlds 1 and 3."""
+    monkeypatch.setenv("SRW_EB_VMM_CHUNK_MB", "8")
+    s, d, w = rmat_lines(oracle, 14, edge_factor=16, weighted=True)
+    g = oracle.Graph.from_coo(s, d, w, directed=False)
+    rp, rl, rs = g.walk(p=0.25, q=4.0, walk_length=10, seed=8, threads=8)
+    for world in (1, 3):
+        with pkg().Cluster([0] * world) as cl:
+            cl.load_coo(s, d, w, directed=False)
+            paths, lens, st = cl.walk(p=0.25, q=4.0, walk_length=10, seed=8)
+            assert np.array_equal(lens, rl) and np.array_equal(paths, rp) and st["n_steps"] == rs, world
+            assert st["edge_tables"] > 0 and st["edge_table_bytes"] > (32 << 20), st

@@ -458,6 +458,8 @@ def compact_line(out):
         c["vertex_sharded"] = vs
     if out.get("switches_set"):
         c["switches_set"] = out["switches_set"]
+    if out.get("library"):
+        c["library"] = out["library"]
     if "detail_file" in out:
         c["detail_file"] = out["detail_file"]
     c = _round(c)
@@ -481,6 +483,11 @@ def emit(out, args):
     """Full detail -> bench_detail.json (next to gpurun_out/ when that exists, else the working directory) and stderr;
     the compact object -> the last (and only) stdout line."""
     # tools/SWITCHES.md: the line describes the defaults unless it says otherwise
+    try:
+        import _pkg
+        out["library"] = _pkg.load().version()
+    except Exception:
+        pass
     out["switches_set"] = sorted(k for k in os.environ if k.startswith("SRW_") and k not in ("SRW_TIMING",))
     full = json.dumps(out)
     path = args.detail or os.path.join("gpurun_out" if os.path.isdir("gpurun_out") else ".", "bench_detail.json")

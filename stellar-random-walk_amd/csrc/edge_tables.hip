@@ -941,10 +941,11 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
         if (fits(s2, p2)) { sel = s2; pl = p2; break; }
         g.eb_cm_ratio_sel = 0;
       }
-    // (finer tables only for a job long enough to pay for their build: walk_kernels.hip:prepare_tables, srw_plan_walks)
-    if (!getenv("SRW_EB_FINE_CAP") && std::max<int64_t>(h->planned_walks > 0 ? h->planned_walks : 10, P.num_walks) >= 64)
+    // (finer tables beyond 512 chunks only for a job long enough to pay for their build: walk_kernels.hip:prepare_tables, srw_plan_walks)
+    if (!getenv("SRW_EB_FINE_CAP"))
       for (int fc : {4096, 1024, 512}) {
         if (fc <= cap_sel) break;
+        if (fc > BIN_CAP && std::max<int64_t>(h->planned_walks > 0 ? h->planned_walks : 10, P.num_walks) < 64) continue;   // (beyond the LDS bins: long jobs only)
         g.eb_fine_cap_sel = fc;
         EbSel s2; ShardTabPlan p2;
         if (fits(s2, p2)) { sel = s2; pl = p2; break; }

@@ -2459,11 +2459,14 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
         const size_t n = set_size(t.cap, t.min_sh, cm, 0);
         if (fits(n, (size_t)24 << 30)) { t.cm = cm; t.need = n; break; }
       }
-    // finer tables only for a job long enough to pay for them: config 3 builds them in +8.4 s (HBM-scratch bins, 40 GB more to
-    // allocate) and walks an iteration in 578 instead of 674 ms — break-even at ~85 iterations (profiles/r05_table_plan.md)
-    if (!getenv("SRW_EB_FINE_CAP") && job_walks >= 64)
+    // Finer tables for the unmasked pairs with a long N(prev).  Up to 512 chunks they fill the wave's LDS bins like every other table and
+    // cost nothing to build (config 3: +40 ms, +15 GB, 643 -> 602 ms per iteration); beyond that the bins live in an HBM scratch
+    // (+1.6 - 8 s by box and 40 GB more for 602 -> 573 ms): only for a job long enough to pay for them — srw_plan_walks,
+    // profiles/r05_table_build.md.
+    if (!getenv("SRW_EB_FINE_CAP"))
       for (int fc : {4096, 1024, 512}) {
         if (fc <= t.cap) break;
+        if (fc > BIN_CAP && job_walks < 64) continue;
         const size_t n = set_size(t.cap, t.min_sh, t.cm, fc);
         if (fits(n, (size_t)24 << 30)) { t.fine = fc; t.need = n; break; }
       }

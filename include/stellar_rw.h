@@ -354,8 +354,9 @@ int32_t srw_w2v_fit_device(srw_handle *h, const void *d_paths, const void *d_len
  * -1 beyond the code).  Known answers: tests/test_w2v_known_answers.py. */
 int32_t srw_w2v_huffman(const int64_t *counts, int64_t n_vocab, int32_t *code_len, uint8_t *codes, int32_t *points);
 /* "<id>\t<v0>\t...\t<v_dim-1>" lines (Main.scala:88-91; floats printed as java.lang.Float.toString prints them) into
- * <output_dir>/vec/part-%05d + _SUCCESS, and a model directory <output_dir>/bin (metadata JSON + the same vectors as text: the
- * reference writes Spark's parquet there, which this build does not).  As saveModelAndFeatures: the model first, then the vectors;
+ * <output_dir>/vec/part-%05d + _SUCCESS, and the model directory <output_dir>/bin as Word2VecModel.save lays it out: metadata/part-00000
+ * (one JSON line) + data/part-00000.parquet — Parquet with Spark's schema for (word: String, vector: Array[Float]), written by
+ * csrc/parquet_model.cpp (uncompressed; Spark writes snappy pages, any Parquet reader takes both).  As saveModelAndFeatures: the model first, then the vectors;
  * fails before writing anything if <output_dir>/bin or <output_dir>/vec exists, and removes what it created if it fails midway. */
 int32_t srw_w2v_save(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int32_t n_parts);
 /* The same for a vocabulary of WORDS (`--cmd embedding` on a text whose tokens are not vertex ids: the reference's Word2Vec takes any

@@ -168,6 +168,7 @@ def lib():
     L.srw_shard_select.argtypes = [vp, C.c_int32]
     L.srw_w2v_fit.argtypes = [vp, i32p, i32p, C.c_int64, C.c_int64, C.POINTER(W2vParams), C.POINTER(i32p), C.POINTER(f32p), C.POINTER(C.c_int64)]
     L.srw_w2v_fit_device.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.POINTER(W2vParams), C.POINTER(i32p), C.POINTER(f32p), C.POINTER(C.c_int64)]
+    L.srw_w2v_save_words.argtypes = [C.POINTER(C.c_char_p), f32p, C.c_int64, C.c_int32, C.c_char_p, C.c_int32]
     L.srw_w2v_huffman.argtypes = [C.POINTER(C.c_int64), C.c_int64, i32p, C.POINTER(C.c_uint8), i32p]
     L.srw_w2v_save.argtypes = [i32p, f32p, C.c_int64, C.c_int32, C.c_char_p, C.c_int32]
     L.srw_probe_request_rate.argtypes = [vp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -353,6 +353,8 @@ void w2v_fit_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens
 void w2v_huffman(const int64_t *counts, int64_t n_vocab, int32_t *code_len, uint8_t *codes, int32_t *points);   // host only (test hook)
 // writer.cpp: <output>/vec part files + <output>/bin
 void write_vectors(const int32_t *vocab_ids, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int n_parts);
+void write_word2vec_parquet(const std::string &path, const std::function<void(std::string &, int64_t)> &put_name, const float *vectors,
+                            int64_t n, int32_t dim);   // parquet_model.cpp: <output>/bin/data as Word2VecModel.save writes it
 void write_vectors_words(const char *const *words, const float *vectors, int64_t n_vocab, int32_t dim, const char *output_dir, int n_parts);
 std::string java_float_to_string(float x);
 // probe.hip: measurement hooks of bench.py's roofline object

@@ -2,7 +2,7 @@
 // (M/Main.scala:18-27,53-69,109-127) for the --cmd randomwalk path.  Same flags, same stdout lines, same
 // <output>/path layout.  --cmd node2vec / embedding (M/Main.scala:113-124): the Word2Vec stage is the build's GPU skip-gram +
 // hierarchical softmax (csrc/embedding.hip; MLlib's Word2Vec is absent from the reference tree: parity unpinned), <output>/vec
-// holds "id\tv0\t..." lines as Main.saveModelAndFeatures writes them, <output>/bin the model directory (metadata + vectors as text).
+// holds "id\tv0\t..." lines as Main.saveModelAndFeatures writes them, <output>/bin the model directory (metadata JSON + Parquet data, as Word2VecModel.save).
 // `--cmd embedding --input X`: X is a file or a directory of part files (context.textFile), its tokens are words (any string).
 #include <dirent.h>
 #include <sys/stat.h>

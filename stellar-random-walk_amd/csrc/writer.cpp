@@ -354,12 +354,13 @@ void write_vectors_named(const std::function<void(std::string &, int64_t)> &put_
     Sink sk; sk.open(fn); made_files.push_back(fn); sk.buf = text; sk.close();
   };
   try {
-    // the model directory: Spark's Word2VecModel.save layout in name (metadata + data), with the vectors as text instead of parquet
+    // the model directory as Word2VecModel.save lays it out: metadata/ (one JSON line) + data/ (Parquet: parquet_model.cpp)
     mk(mdir); mk(mdir + "/metadata"); mk(mdir + "/data");
     file(mdir + "/metadata/part-00000", "{\"class\":\"org.apache.spark.mllib.feature.Word2VecModel\",\"version\":\"1.0\",\"vectorSize\":" + std::to_string(dim) +
                                             ",\"numWords\":" + std::to_string(n_vocab) + "}\n");
     file(mdir + "/metadata/_SUCCESS", "");
-    { Sink sk; sk.open(mdir + "/data/part-00000.tsv"); made_files.push_back(sk.fn); rows(sk, 0, n_vocab); sk.close(); }
+    made_files.push_back(mdir + "/data/part-00000.parquet");
+    write_word2vec_parquet(made_files.back(), put_name, vectors, n_vocab, dim);       // (word: string, vector: array<float>), as Spark stores the model
     file(mdir + "/data/_SUCCESS", "");
     // repartition(numPartitions): contiguous blocks of the vocabulary (the reference's order of lines is unspecified)
     mk(vdir);

@@ -426,6 +426,50 @@ def test_vector_files_and_java_float_strings(tmp_path):
         P.w2v_save(np.array([1], dtype=np.int32), vals[:1], out)          # <output>/vec exists
 
 
+def test_model_directory_is_spark_parquet(tmp_path, monkeypatch):
+    """<output>/bin as Word2VecModel.save writes it (Main.saveModelAndFeatures -> model.save, Main.scala:36-44): metadata/ with one JSON line
+    and data/ as PARQUET with Spark's schema for `case class Data(word: String, vector: Array[Float])` — written by hand
+    (csrc/parquet_model.cpp: Thrift compact footer, RLE levels, PLAIN values), read back here with pyarrow: schema, Spark's row-metadata
+    key, every word, every float bit for bit; one page, many pages, several row groups, an empty model, words with UTF-8 bytes."""
+    pq = pytest.importorskip("pyarrow.parquet")
+    import ctypes as C
+    P = pkg()
+    rng = np.random.default_rng(4)
+    monkeypatch.setenv("SRW_PARQUET_GROUP_MB", "1")                                  # (default 64 MB per row group: a 1 MB limit makes a small model span several)
+    for n, dim in ((3, 5), (1, 1), (4000, 128), (0, 8)):                             # 4 000 x 128 floats = 2 MB: two row groups of four pages each
+        vec = rng.standard_normal((max(n, 1), dim)).astype(np.float32)[:n]
+        if n:
+            vec.flat[0] = np.float32(-0.0); vec.flat[-1] = np.float32(3.4028235e38)
+        ids = rng.permutation(np.arange(-5, n - 5, dtype=np.int32))
+        out = str(tmp_path / ("m%d_%d" % (n, dim)))
+        P.w2v_save(ids, vec, out, n_parts=1)
+        f = os.path.join(out, "bin", "data", "part-00000.parquet")
+        md = pq.read_metadata(f)
+        assert md.num_rows == n and md.num_columns == 2 and md.num_row_groups == (2 if n == 4000 else 1)
+        assert b"org.apache.spark.sql.parquet.row.metadata" in md.metadata
+        assert '"elementType":"float","containsNull":false' in md.metadata[b"org.apache.spark.sql.parquet.row.metadata"].decode()
+        schema = str(pq.ParquetFile(f).schema)
+        for piece in ("spark_schema", "optional binary field_id=-1 word (String)", "optional group field_id=-1 vector (List)",
+                      "repeated group field_id=-1 list", "required float field_id=-1 element"):
+            assert piece in schema, schema
+        t = pq.read_table(f)
+        assert t.column("word").to_pylist() == [str(int(x)) for x in ids]
+        col = t.column("vector").combine_chunks()
+        assert col.null_count == 0 and (n == 0 or set(np.diff(col.offsets.to_numpy()).tolist()) == {dim})        # every row: a list of exactly dim floats
+        got = col.flatten().to_numpy(zero_copy_only=False).astype(np.float32).reshape(n, dim) if n else np.zeros((0, dim), np.float32)
+        assert np.array_equal(got.view(np.uint32), vec.view(np.uint32))
+        assert os.path.exists(os.path.join(out, "bin", "data", "_SUCCESS")) and os.path.exists(os.path.join(out, "bin", "metadata", "_SUCCESS"))
+    # words (srw_w2v_save_words): any UTF-8 string
+    words = ["the", "", "naïve", "数据", "a\tb"]
+    arr = (C.c_char_p * len(words))(*[w.encode() for w in words])
+    vec = rng.standard_normal((len(words), 4)).astype(np.float32)
+    out = str(tmp_path / "words")
+    assert P.lib().srw_w2v_save_words(arr, vec.ctypes.data_as(C.POINTER(C.c_float)), len(words), 4, out.encode(), 1) == 0
+    t = pq.read_table(os.path.join(out, "bin", "data", "part-00000.parquet"))
+    assert t.column("word").to_pylist() == words
+    assert np.array_equal(np.array(t.column("vector").to_pylist(), dtype=np.float32), vec)
+
+
 def test_oracle_embedding_separates_neighbours(oracle):
     """The CPU restatement of the embedding stage (parity unpinned: MLlib's Word2Vec is not in the reference tree) on karate walks:
     deterministic under its seed, vocabulary by descending count, neighbours closer than non-neighbours."""

@@ -55,9 +55,11 @@ ok = same_or
 print("oracle: %d sampled walkers (longest start row %d), rows of %d path vertices rebuilt from the edge stream (%d of %d lines kept): %s (%.0f s)"
       % (len(src), int(degs.max()), int(on_path.sum()), len(fs), n_edges, "IDENTICAL" if same_or else "MISMATCH", time.time() - t), flush=True)
 del g, fs, fd, on_path, rp, rl
-st80 = eng.walk(fetch=False, walk_length=80, seed=2026)
-st80 = eng.walk(fetch=False, walk_length=80, seed=2026, first_walk=1)
-print("replicated walk L=80: %.2f G steps/s (kernel %.1f ms)" % (st80["n_steps"] / st80["kernel_ms"] / 1e6, st80["kernel_ms"]), flush=True)
+quick = bool(os.environ.get("SRW_CHECK_QUICK"))            # the driver's suite: parity only, no L = 80 timing walks
+if not quick:
+    st80 = eng.walk(fetch=False, walk_length=80, seed=2026)
+    st80 = eng.walk(fetch=False, walk_length=80, seed=2026, first_walk=1)
+    print("replicated walk L=80: %.2f G steps/s (kernel %.1f ms)" % (st80["n_steps"] / st80["kernel_ms"] / 1e6, st80["kernel_ms"]), flush=True)
 eng.close(); del eng
 t = time.time()
 with pkg.Cluster([0] * world, membership=False) as cl:      # config 4 is p = q = 1: SRW_CFG_NO_MEMBERSHIP
@@ -71,6 +73,8 @@ with pkg.Cluster([0] * world, membership=False) as cl:      # config 4 is p = q 
           % (L, world, "IDENTICAL" if same else "MISMATCH", len(clens), cst["n_steps"], cst["kernel_ms"], cst.get("overflow_retries")), flush=True)
     del cp, clens, paths, lens
     try:
+        if quick:
+            raise pkg.SrwError(0, "quick mode")
         c80 = cl.walk(fetch=False, walk_length=80, seed=2026, num_walks=2, batch=2)
         c80 = cl.walk(fetch=False, walk_length=80, seed=2026, num_walks=2, first_walk=2, batch=2)
         print("sharded walk L=80, 2 iterations as one population: %.2f G steps/s on ONE device (the %d shards' kernels run one after the other)"

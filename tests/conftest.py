@@ -14,7 +14,7 @@ TESTGRAPH = os.path.join(GOLDEN, "testgraph.txt")
 
 
 # environment variables that may be present without steering a kernel, a planner or a host path
-_NEUTRAL = {"SRW_SKIP_FULL_SIZE", "SRW_TIMING"}
+_NEUTRAL = {"SRW_SKIP_FULL_SIZE", "SRW_TIMING", "SRW_CHECK_QUICK"}
 
 
 def steering_switches_set():

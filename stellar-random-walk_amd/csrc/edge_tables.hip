@@ -983,10 +983,12 @@ void prepare_shard_tables(srw_handle *h, const srw_walk_params &P) {
   for (int attempt = 0; attempt < 2; ++attempt) {
     try { build_shard_edge_tables(h, P.p, P.q, mode, cap_sel, pl, sel); return; }
     catch (const Error &e) {
-      if (e.code != SRW_ERR_NOMEM) throw;
+      const bool remap = e.code == SRW_ERR_HIP && vm_buf_broken().load() && attempt == 0 && std::string(e.what()).find("mapping the table buffer") != std::string::npos;
+      if (e.code != SRW_ERR_NOMEM && !remap) throw;
       (void)hipGetLastError();
       (void)hipStreamSynchronize(h->stream);          // (segments of the build may be running over the chunks that did get mapped)
       g.eb_bins.release(); g.em_bits.release(); g.ph.release(); g.ph_buckets = 0; g.has_eb = false;
+      if (remap) { attempt = -1; continue; }          // (vm_buf.h: a mapping call refused for another reason than memory — once more with one hipMalloc)
       if (attempt || cap_sel <= 32) break;
       cap_sel = 32; g.eb_min_sh_sel = 8; sel = shard_sel(g, mode, 32);
       if (!shard_plan(h, sel, pl)) break;

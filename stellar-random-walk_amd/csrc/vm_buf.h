@@ -19,6 +19,9 @@
 
 namespace srw {
 
+// set when a mapping call failed for a reason other than memory: the process then allocates its table buffers in one piece
+inline std::atomic<bool> &vm_buf_broken() { static std::atomic<bool> b{false}; return b; }
+
 template <typename T>
 struct VmBuf {
   T *p = nullptr;
@@ -65,7 +68,7 @@ struct VmBuf {
     const size_t bytes = count * sizeof(T);
     const char *no = getenv("SRW_EB_NO_VMM");
     if (const char *c = getenv("SRW_EB_VMM_CHUNK_MB"); c && atoi(c) >= 2) CHUNK = ((size_t)atoi(c) >> 1 << 1) << 20;     // (a multiple of 2 MiB)
-    if (bytes < 2 * CHUNK || (no && *no == '1')) { alloc(count); return; }
+    if (bytes < 2 * CHUNK || (no && *no == '1') || vm_buf_broken().load()) { alloc(count); return; }
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
     size_t gran = 0;
@@ -88,6 +91,9 @@ struct VmBuf {
         hipMemGenericAllocationHandle_t h;
         const char *what = "hipMemCreate";
         hipError_t e = hipMemCreate(&h, sz, &prop, 0);
+        if (const char *fa = getenv("SRW_EB_VMM_FAIL_AT"); fa && e == hipSuccess && (size_t)atoll(fa) == off / CHUNK) {     // tests: the fallback path
+          (void)hipMemRelease(h); what = "hipMemCreate (simulated failure, SRW_EB_VMM_FAIL_AT)"; e = hipErrorInvalidValue;
+        }
         if (e == hipSuccess) {
           what = "hipMemMap";
           e = hipMemMap((char *)p + off, sz, 0, h, 0);
@@ -96,7 +102,9 @@ struct VmBuf {
         }
         if (e != hipSuccess) {
           err_ = std::string("mapping the table buffer: ") + what + " of " + std::to_string(sz) + " B at " + std::to_string(off) + " of " + std::to_string(total) + " B: " + hipGetErrorString(e);
-          oom_ = e == hipErrorOutOfMemory; failed_.store(true); return;
+          oom_ = e == hipErrorOutOfMemory;
+          if (!oom_) vm_buf_broken().store(true);          // (the caller retries: the next buffer is one hipMalloc)
+          failed_.store(true); return;
         }
         mapped_.store(off + sz);
       }

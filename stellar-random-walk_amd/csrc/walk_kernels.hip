@@ -2544,9 +2544,18 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
     for (int attempt = 0; attempt < 2; ++attempt) {
       try { build_edge_tables(h, P.p, P.q, eb_mode, attempt == 0 ? eb_cap : 32); break; }
       catch (const Error &e) {
-        if (e.code != SRW_ERR_NOMEM) throw;
+        // a mapping call of the progressively mapped table buffer refused for another reason than memory (vm_buf.h): once more, the
+        // buffer as one hipMalloc — an optional accelerator never fails a walk
+        const bool remap = e.code == SRW_ERR_HIP && vm_buf_broken().load() && attempt == 0 && std::string(e.what()).find("mapping the table buffer") != std::string::npos;
+        if (e.code != SRW_ERR_NOMEM && !remap) throw;
         (void)hipGetLastError();
         (void)hipStreamSynchronize(h->stream);          // (segments of the build may be running over the chunks that did get mapped)
+        if (remap) {
+          h->g.eb_bins.release(); h->g.em_bits.release(); h->g.has_eb = false;
+          if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] per-edge tables: %s — once more with one allocation\n", e.what());
+          attempt = -1;                                   // (the loop's ++ makes it attempt 0 again, now without the mapped range)
+          continue;
+        }
         Graph &g = h->g;
         g.eb_bins.release(); g.em_bits.release(); g.has_eb = false; g.eb_complete = false; g.eb_tables = 0; g.eb_bytes = 0;
         h->g.eb_budget_gb = 160; g.eb_min_sh_sel = 8; g.eb_cm_sel = 0; g.eb_fine_cap_sel = 0; g.eb_cm_ratio_sel = 0;

@@ -286,3 +286,28 @@ def test_non_dyadic_pq_through_tables_and_masks(eng, oracle, weighted):
         assert bad.size == 0, (p, q, int(src[bad[0]]), paths[idx][bad[0]], rp[bad[0]])
         paths2, lens2, _ = eng.walk(p=p, q=q, walk_length=L, seed=4321, edge_tables=False)
         assert np.array_equal(paths2, paths) and np.array_equal(lens2, lens), (p, q)
+
+
+def test_a_refused_mapping_call_falls_back_to_one_allocation(monkeypatch):
+    """vm_buf.h: the table buffer is mapped chunk by chunk while the build fills it; if a mapping call refuses for another reason than
+    memory (simulated at the third chunk, with segments of the build already running over the first two), the tables are built once
+    more over one hipMalloc and the walk goes on — same paths, same tables."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import _pkg; P = _pkg.load(); e = P.Engine(0); "
+            "e.generate_rmat(16, 16 << 16, seed=5, weighted=True); "
+            "p, l, st = e.walk(p=0.25, q=4.0, walk_length=12, seed=3); "
+            "print('RESULT', hashlib.sha256(p.tobytes() + l.tobytes()).hexdigest(), st['edge_tables'], st['strategy_steps']['edge_table'])" % ROOT)
+
+    def run(env):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRW_TIMING="1", **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0], r.stderr
+
+    ref, _ = run({"SRW_EB_NO_VMM": "1"})
+    mapped, err = run({"SRW_EB_VMM_CHUNK_MB": "8"})
+    assert mapped == ref and "mapped in chunks" in err
+    fell_back, err = run({"SRW_EB_VMM_CHUNK_MB": "8", "SRW_EB_VMM_FAIL_AT": "2"})
+    assert fell_back == ref and "once more with one allocation" in err and "simulated failure" in err
+    assert int(ref.split()[2]) > 0 and int(ref.split()[3]) > 0

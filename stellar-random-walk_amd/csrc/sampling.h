@@ -900,6 +900,9 @@ __device__ inline int32_t wave_pick_returns(const GraphView &g, const Row &rc, c
 //       LDS, four per lane in lockstep; whichever list ends first in id order advances.  At most
 //       |N(curr)| / 256 + |N(prev)| / 1024 rounds, independent of the id range.  (Tried before it: an id-window bitmap
 //       — 6 us per window, 300 windows per step at RMAT-24 — and an LDS hash set per chunk — 3x the LDS operations.)
+#ifndef SRW_W_MATCH_LOOP
+#define SRW_W_MATCH_LOOP 1                    // sorted-chunk intersection: the matches of a lane in a uniform loop (0: four exec-masked blocks, as before round 5)
+#endif
 constexpr int BIN_CAP = 512;                  // f64 bins: 4 KB of the wave's LDS
 constexpr int WIN_WORDS = 1280;               // scratch behind the bins: 5 KB (W stages 1024 sorted ids of N(prev) here)
 constexpr int HCHUNK = 1024;                // ids of N(prev) staged in LDS per round
@@ -1254,12 +1257,35 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
             for (int j = 0; j < 4; ++j) if (probe[j] < AI[j]) pos[j] += step;
           }
           SRW_U1(tm, t_pass1);
+#if SRW_W_MATCH_LOOP
+          // the matches of a lane's four candidates, one per pass of a wave-uniform loop: with ~10 % of the candidates matching, the
+          // fullest lane holds two of them, so two passes of the correction code run instead of four exec-masked copies of it
+          {
+            uint32_t hit[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hit[j] = bch[pos[j]];
+            uint32_t mm = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm |= (want[j] && hit[j] == AI[j]) ? (1u << j) : 0u;
+            while (__any(mm != 0u)) {
+              if (mm) {
+                const int j = __ffs((int)mm) - 1;
+                mm &= mm - 1u;
+                const uint32_t ac = j == 0 ? AC[0] : j == 1 ? AC[1] : j == 2 ? AC[2] : AC[3];
+                const float aw = j == 0 ? AW[0] : j == 1 ? AW[1] : j == 2 ? AW[2] : AW[3];
+                atomicAdd(&bins[ac >> csh], (double)aw - (double)div_exact(aw, q_));
+                if (mbits) atomicOr(&mbits[ac >> 5], 1u << (ac & 31));
+              }
+            }
+          }
+#else
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (want[j] && bch[pos[j]] == AI[j]) {
               atomicAdd(&bins[AC[j] >> csh], (double)AW[j] - (double)div_exact(AW[j], q_));
               if (mbits) atomicOr(&mbits[AC[j] >> 5], 1u << (AC[j] & 31));
             }
+#endif
           // advance the list that ends first
           const int32_t na = (deg - pa) < 256 ? (deg - pa) : 256;
           const int jl = (na - 1) & 3;

@@ -900,9 +900,6 @@ __device__ inline int32_t wave_pick_returns(const GraphView &g, const Row &rc, c
 //       LDS, four per lane in lockstep; whichever list ends first in id order advances.  At most
 //       |N(curr)| / 256 + |N(prev)| / 1024 rounds, independent of the id range.  (Tried before it: an id-window bitmap
 //       — 6 us per window, 300 windows per step at RMAT-24 — and an LDS hash set per chunk — 3x the LDS operations.)
-#ifndef SRW_W_SKIP_LEVELS
-#define SRW_W_SKIP_LEVELS 0                   // experiment: skip the search levels beyond a short staged chunk (uniform branches)
-#endif
 #ifndef SRW_W_MATCH_LOOP
 #define SRW_W_MATCH_LOOP 1                    // sorted-chunk intersection: the matches of a lane in a uniform loop (0: four exec-masked blocks, as before round 5)
 #endif
@@ -1251,14 +1248,8 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
             pos[j] = 0u;
           }
           SRW_U0(tm);
-#if SRW_W_SKIP_LEVELS
-          const int32_t nb_u = uni(nb);
-#endif
 #pragma unroll
           for (int step = HC / 2; step >= 1; step >>= 1) {
-#if SRW_W_SKIP_LEVELS
-            if (step > nb_u) continue;                        // (a short staged chunk: the levels that could only probe its padding)
-#endif
             uint32_t probe[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) probe[j] = bch[pos[j] + step - 1];

@@ -673,15 +673,30 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   if (all_pairs) {
     const int fill_tune = getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0;
     SRW_HIP(hipMemsetAsync(hist.p, 0, 16 * 8, st));
-    auto launch = [&](unsigned long long i0, unsigned long long n_it) {
-      SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
-      hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, st, gv, items.p + i0, (int64_t)n_it, p, q, sel.mask_max,
-                         sel.pol, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, fill_tune, gscratch.p, gs_stride);
+    // the segments of a progressively mapped buffer alternate between two streams (own cursor, own HBM-scratch bins): the tail of one
+    // segment — its last, slowest pairs — overlaps the start of the next (41 launches in a row cost 0.3 - 0.6 s of tails at config 3)
+    hipStream_t aux = nullptr; hipEvent_t ev = nullptr;
+    DevBuf<unsigned long long> cursor2; DevBuf<double> gscratch2;
+    struct AuxGuard { hipStream_t &s; hipEvent_t &e; ~AuxGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } if (e) (void)hipEventDestroy(e); } } aux_guard{aux, ev};
+    auto launch = [&](unsigned long long i0, unsigned long long n_it, int which = 0) {
+      hipStream_t ls = which ? aux : st;
+      unsigned long long *cur = which ? cursor2.p : cursor.p;
+      SRW_HIP(hipMemsetAsync(cur, 0, 8, ls));
+      hipLaunchKernelGGL((k_eb_build<false>), dim3(blocks), dim3(TPB), 0, ls, gv, items.p + i0, (int64_t)n_it, p, q, sel.mask_max,
+                         sel.pol, g.eb_off.p, g.eb_bins.p, g.em_bits.p, cur, hist.p, fill_tune, which ? gscratch2.p : gscratch.p, gs_stride);
       SRW_HIP(hipGetLastError());
       ++n_launches;
     };
     if (!g.eb_bins.progressive()) launch(0ull, all_pairs);
     else {
+      if (!getenv("SRW_EB_ONE_STREAM")) {
+        cursor2.alloc(1);
+        if (gs_stride) gscratch2.alloc((size_t)blocks * (TPB / 64) * (size_t)gs_stride);
+        SRW_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        SRW_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        SRW_HIP(hipEventRecord(ev, st));                       // (everything the build reads was written on the handle's stream)
+        SRW_HIP(hipStreamWaitEvent(aux, ev, 0));
+      }
       // one launch per chunk of the table buffer, each as soon as its rows' tables are backed by pages
       const unsigned long long chunk_units = (unsigned long long)(g.eb_bins.chunk_bytes() / 64);
       const int n_seg = (int)((units + chunk_units - 1) / chunk_units);
@@ -698,8 +713,9 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
         const auto tw = std::chrono::steady_clock::now();
         g.eb_bins.wait_mapped((size_t)seg[(size_t)n_seg + 1 + k] * 64);
         waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
-        launch(i0, i1 - i0);
+        launch(i0, i1 - i0, aux ? (n_launches & 1) : 0);
       }
+      if (aux) { SRW_HIP(hipEventRecord(ev, aux)); SRW_HIP(hipStreamWaitEvent(st, ev, 0)); }       // the handle's stream goes on after both
       const auto tw = std::chrono::steady_clock::now();
       g.eb_bins.wait_all();
       waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
@@ -825,14 +841,29 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
   if (all_pairs) {
     const int fill_tune = getenv("SRW_EB_FILL_TUNE") ? atoi(getenv("SRW_EB_FILL_TUNE")) : 0;
     SRW_HIP(hipMemsetAsync(hist.p, 0, 8 * 8, st));
-    auto launch = [&](unsigned long long i0, unsigned long long n_it) {
-      SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
-      hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, st, gv, items.p + i0, (int64_t)n_it, p, q, sel.mask_max,
-                         sel.pol, item_off.p + i0, g.eb_bins.p, g.em_bits.p, cursor.p, hist.p, fill_tune, gscratch.p, gs_stride);
+    hipStream_t aux = nullptr; hipEvent_t ev = nullptr;       // (two streams for the segments, as build_edge_tables)
+    DevBuf<unsigned long long> cursor2; DevBuf<double> gscratch2;
+    struct AuxGuard { hipStream_t &s; hipEvent_t &e; ~AuxGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } if (e) (void)hipEventDestroy(e); } } aux_guard{aux, ev};
+    int n_launches = 0;
+    auto launch = [&](unsigned long long i0, unsigned long long n_it, int which = 0) {
+      hipStream_t ls = which ? aux : st;
+      unsigned long long *cur = which ? cursor2.p : cursor.p;
+      SRW_HIP(hipMemsetAsync(cur, 0, 8, ls));
+      hipLaunchKernelGGL((k_eb_build<true>), dim3(blocks), dim3(TPB), 0, ls, gv, items.p + i0, (int64_t)n_it, p, q, sel.mask_max,
+                         sel.pol, item_off.p + i0, g.eb_bins.p, g.em_bits.p, cur, hist.p, fill_tune, which ? gscratch2.p : gscratch.p, gs_stride);
       SRW_HIP(hipGetLastError());
+      ++n_launches;
     };
     if (!g.eb_bins.progressive()) launch(0ull, all_pairs);
     else {                                           // one launch per chunk of the table buffer (build_edge_tables, k_eb_segments)
+      if (!getenv("SRW_EB_ONE_STREAM")) {
+        cursor2.alloc(1);
+        if (gs_stride) gscratch2.alloc((size_t)blocks * (TPB / 64) * (size_t)gs_stride);
+        SRW_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        SRW_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        SRW_HIP(hipEventRecord(ev, st));
+        SRW_HIP(hipStreamWaitEvent(aux, ev, 0));
+      }
       const unsigned long long chunk_units = (unsigned long long)(g.eb_bins.chunk_bytes() / 64);
       const int n_seg = (int)((pl.units + chunk_units - 1) / chunk_units);
       DevBuf<unsigned long long> d_seg; d_seg.alloc((size_t)2 * n_seg + 2);
@@ -847,8 +878,9 @@ void build_shard_edge_tables(srw_handle *h, float p, float q, int mode, int bins
         const unsigned long long i0 = seg[(size_t)k], i1 = seg[(size_t)k + 1];
         if (i1 <= i0) continue;
         g.eb_bins.wait_mapped((size_t)seg[(size_t)n_seg + 1 + k] * 64);
-        launch(i0, i1 - i0);
+        launch(i0, i1 - i0, aux ? (n_launches & 1) : 0);
       }
+      if (aux) { SRW_HIP(hipEventRecord(ev, aux)); SRW_HIP(hipStreamWaitEvent(st, ev, 0)); }
       g.eb_bins.wait_all();
     }
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));

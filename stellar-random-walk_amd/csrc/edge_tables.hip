@@ -653,17 +653,27 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
   hipLaunchKernelGGL((k_eb_assign<false>), dim3(blocks), dim3(TPB), 0, st, g.view(), ShardSel{0, 1}, sel, cursor.p,
                      row_units.p, row_munits.p, row_pairs.p, g.eb_off.p, items.p, (PairSlot *)nullptr, 0u, (uint32_t *)nullptr);
   SRW_HIP(hipGetLastError());
-  SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
-  hipLaunchKernelGGL(k_eb_dups, dim3(blocks), dim3(TPB), 0, st, g.view(), sel, cursor.p, g.eb_off.p);
+  // The multi-edge copies (k_eb_dups) and the inline masks (k_eb_inline) write eb_off words that the table build neither reads nor
+  // writes (it reads the representatives' words, written by k_eb_assign above): they run on a side stream NEXT TO the build (0.4 s at config 3).
+  DevBuf<unsigned long long> cursor3; cursor3.alloc(1);          // (declared before the guard: released after the side stream has drained)
+  hipStream_t side = nullptr; hipEvent_t side_ev = nullptr;
+  struct SideGuard { hipStream_t &s; hipEvent_t &e; ~SideGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } if (e) (void)hipEventDestroy(e); } } side_guard{side, side_ev};
+  SRW_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  SRW_HIP(hipEventCreateWithFlags(&side_ev, hipEventDisableTiming));
+  SRW_HIP(hipEventRecord(side_ev, st));
+  SRW_HIP(hipStreamWaitEvent(side, side_ev, 0));
+  SRW_HIP(hipMemsetAsync(cursor3.p, 0, 8, side));
+  hipLaunchKernelGGL(k_eb_dups, dim3(blocks), dim3(TPB), 0, side, g.view(), sel, cursor3.p, g.eb_off.p);
   SRW_HIP(hipGetLastError());
   g.has_eb = true; g.use_eb = true; g.eb_mask_max = sel.mask_max;
   GraphView gv = g.view();
   gv.eb_off = nullptr;                          // the builders never read the tables they are writing
   if (sel.mask_max > 0) {
-    SRW_HIP(hipMemsetAsync(cursor.p, 0, 8, st));
-    hipLaunchKernelGGL((k_eb_inline<false>), dim3(blocks), dim3(TPB), 0, st, gv, ShardSel{0, 1}, sel, cursor.p, g.eb_off.p, (PairSlot *)nullptr, 0u);
+    SRW_HIP(hipMemsetAsync(cursor3.p, 0, 8, side));
+    hipLaunchKernelGGL((k_eb_inline<false>), dim3(blocks), dim3(TPB), 0, side, gv, ShardSel{0, 1}, sel, cursor3.p, g.eb_off.p, (PairSlot *)nullptr, 0u);
     SRW_HIP(hipGetLastError());
   }
+  SRW_HIP(hipEventRecord(side_ev, side));       // (the handle's stream waits for it after the build: below)
   unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // tables of more chunks than the build's LDS holds bins for: one f64 per chunk and wave in an HBM scratch
   DevBuf<double> gscratch;
@@ -722,6 +732,7 @@ void build_edge_tables(srw_handle *h, float p, float q, int mode, int bins_cap) 
     }
     SRW_HIP(hipMemcpyAsync(sc, hist.p, sizeof(sc), hipMemcpyDeviceToHost, st));
   } else g.eb_bins.wait_all();
+  SRW_HIP(hipStreamWaitEvent(st, side_ev, 0));
   SRW_HIP(hipStreamSynchronize(st));
   if (getenv("SRW_TIMING") && g.eb_bins.progressive())
     fprintf(stderr, "[edge tables] table buffer mapped in chunks of %.0f MiB while the build ran: %d launches, the host waited %.0f ms for pages\n",

@@ -422,6 +422,23 @@ def _round(x, digits=6):
     return x
 
 
+def run_embedding_stage(pkg, device, scale):
+    """SURVEY §8 (f) rank 4 behind config 2's graph: one walk iteration, then ONE training iteration of skip-gram + hierarchical
+    softmax over the paths where they are (srw_w2v_fit_device; dim 128, window 10: Params.scala:7-23's defaults)."""
+    eng = pkg.Engine(device=device)
+    try:
+        eng.generate_rmat(scale, 16 << scale, seed=42)
+        st = eng.walk(fetch=False, walk_length=80, num_walks=1, seed=42, p=1.0, q=1.0)
+        t0 = time.perf_counter(); ids, _ = eng.w2v_fit_device(iterations=0, seed=7); t_vocab = time.perf_counter() - t0
+        t0 = time.perf_counter(); eng.w2v_fit_device(iterations=1, seed=7); t_fit = time.perf_counter() - t0
+        words = int(st["n_steps"]) + int(st.get("n_walkers", 0))
+        return {"what": "RMAT-%d, 1 walk per vertex (L = 80), Word2Vec dim 128 window 10, one training iteration, paths stay in HBM" % scale,
+                "words": words, "vocabulary": int(len(ids)), "vocabulary_and_init_s": t_vocab, "training_iteration_s": max(t_fit - t_vocab, 1e-9),
+                "words_per_s": words / max(t_fit - t_vocab, 1e-9)}
+    finally:
+        eng.close()
+
+
 def compact_line(out):
     """The ONE stdout line: the driver's keys, `config`, `roofline` (numbers only), `cpu_baseline` without its plan, a
     `configs_summary` of the other configurations.  Everything else lives in the detail file."""
@@ -456,6 +473,8 @@ def compact_line(out):
             if "measured_fraction_of_exchange_ceiling" in m:
                 vs[leg]["fraction_of_exchange_ceiling"] = m["measured_fraction_of_exchange_ceiling"]
         c["vertex_sharded"] = vs
+    if "embedding_stage" in out:
+        c["embedding_stage"] = {k: v for k, v in out["embedding_stage"].items() if k in ("words_per_s", "training_iteration_s", "error")}
     if out.get("switches_set"):
         c["switches_set"] = out["switches_set"]
     if out.get("library"):
@@ -465,7 +484,7 @@ def compact_line(out):
     c = _round(c)
     line = json.dumps(c, separators=(",", ":"))
     # never hand the driver a line it cannot read: shed the optional objects, largest first
-    for k in ("configs_summary", "vertex_sharded", "end_to_end", "setup_s"):
+    for k in ("configs_summary", "vertex_sharded", "end_to_end", "embedding_stage", "setup_s"):
         if len(line) <= LINE_LIMIT:
             break
         if k == "configs_summary" and k in c:
@@ -790,6 +809,10 @@ def main():
                     except Exception as ex:
                         cfgs.append({"name": name, "error": str(ex)[:300]})
             out["configs"] = cfgs
+            try:
+                out["embedding_stage"] = run_embedding_stage(pkg, local_rank, min(20, cap))
+            except Exception as ex:
+                out["embedding_stage"] = {"error": str(ex)[:200]}
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         emit(out, args)

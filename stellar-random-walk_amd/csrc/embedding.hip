@@ -116,6 +116,184 @@ __global__ __launch_bounds__(TPB) void k_w2v_train(W2vDev d, int64_t n_waves) {
   }
 }
 
+// Sum over the wave by DPP (row shifts, then the two row broadcasts: lane 63 ends up with the whole wave's) instead of six
+// ds_bpermute butterflies — the dot product of a node update is the head of its dependent chain.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_add_f32(float v) {      // lanes without a source (or outside the row mask) add 0
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ inline float wave_sum_f32_dpp(float v) {
+  v = dpp_add_f32<0x111, 0xF>(v); v = dpp_add_f32<0x112, 0xF>(v); v = dpp_add_f32<0x114, 0xF>(v); v = dpp_add_f32<0x118, 0xF>(v);
+  v = dpp_add_f32<0x142, 0xA>(v); v = dpp_add_f32<0x143, 0xC>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Four sums over the wave at the price of one and a half: two quad exchanges leave lane l with the quad's partial sum of value (l & 3),
+// two row shifts by multiples of four add the quads of a row (lanes 12..15 hold the row's), two butterflies add the rows.
+template <int CTRL>
+__device__ inline float dpp_mov_f32(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+__device__ inline float wave_sum4_f32(float a, float b, float c, float d, int lane) {
+  const bool odd = (lane & 1) != 0, hi = (lane & 2) != 0;
+  const float ab = (odd ? b : a) + dpp_mov_f32<0xB1>(odd ? a : b);        // quad_perm [1,0,3,2]: even lanes a-pairs, odd lanes b-pairs
+  const float cd = (odd ? d : c) + dpp_mov_f32<0xB1>(odd ? c : d);
+  float x = (hi ? cd : ab) + dpp_mov_f32<0x4E>(hi ? ab : cd);             // quad_perm [2,3,0,1]: lane & 3 -> a, b, c, d over the quad
+  x += dpp_mov_f32<0x114>(x);                                             // row_shr:4, row_shr:8 (lanes without a source add 0)
+  x += dpp_mov_f32<0x118>(x);
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+
+// The training kernel (round 5).  MLlib's loop (and word2vec.c's) visits, for ONE position, every context word of the window and for
+// each of them every Huffman node of the CENTRE word: the same <= 40 rows of syn1, read and written once per context — ~11 times at
+// window 10.  Here a position loads the centre word's rows ONCE into registers (R rows of ND floats per lane; the nodes of a longer
+// code go through memory as before), runs its contexts over them — same operations in the same order, so the sequential mode computes
+// what it did — and writes them back once; the next context's syn0 row is fetched while the current one's node chain runs (a context
+// word that repeats takes the row just written).  Everything that is the wave's (sentence, position, code, node index, f, g) stays in
+// scalar registers.  RMAT-20, one walk per vertex, dim 128, window 10: see profiles/r05_embedding.md.
+template <int ND, int R>
+__global__ __launch_bounds__(TPB) void k_w2v_train_rows(W2vDev d, int64_t n_waves) {
+  __shared__ float exp_table[EXP_TABLE_SIZE];
+  for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) {
+    const float e = (float)exp(((double)i / EXP_TABLE_SIZE * 2.0 - 1.0) * (double)MAX_EXP);
+    exp_table[i] = e / (e + 1.0f);
+  }
+  __syncthreads();
+  const int lane = lane_id();
+  const int64_t wave = blockIdx.x * (int64_t)(TPB / 64) + (int64_t)uni((int32_t)(threadIdx.x >> 6));
+  const int D = d.dim, W = d.window;
+  const bool vecwin = 2 * W + 1 <= 64;              // the window's tokens in one register (lane a = context slot a)
+  constexpr int G = 4;
+  static_assert(R % G == 0, "register rows come in groups");
+  for (int64_t s = wave; s < d.n_sent; s += n_waves) {
+    const int64_t o0 = uni(d.sent_off[s]), o1 = uni(d.sent_off[s + 1]);
+    const int32_t len = (int32_t)(o1 - o0);
+    float alpha;
+    {
+      const double done = (double)d.iter * (double)d.total_words + (double)uni(d.words_before[s]);
+      double a = (double)d.lr * (1.0 - done / ((double)d.n_iter * (double)d.total_words + 1.0));
+      if (a < (double)d.lr * 0.0001) a = (double)d.lr * 0.0001;
+      alpha = (float)a;
+    }
+    for (int32_t pos = 0; pos < len; ++pos) {
+      const int32_t word = uni(d.sent[o0 + pos]);
+      const int32_t b = (int32_t)(w2v_hash(d.seed, (uint32_t)d.iter, (uint32_t)s, (uint32_t)pos) % (uint32_t)W);
+      const int32_t c0 = uni(d.code_off[word]), n = uni(d.code_off[word + 1]) - c0;
+      const int32_t nr = n < R ? n : R;
+      int32_t pts = 0, cds = 0;                     // lane t: node t of the centre word's path (n <= 40 < 64)
+      if (lane < n) { pts = d.points[c0 + lane]; cds = d.codes[c0 + lane]; }
+      const unsigned long long code_bits = __ballot(cds != 0);
+      int32_t wtok = -1;
+      if (vecwin) { const int32_t c = pos - W + lane; if (lane <= 2 * W && c >= 0 && c < len) wtok = d.sent[o0 + c]; }
+      auto tok = [&](int32_t a) { return vecwin ? __builtin_amdgcn_readlane(wtok, a) : uni(d.sent[o0 + pos - W + a]); };
+      const int32_t a_end = 2 * W + 1 - b;
+      auto next_ctx = [&](int32_t a) {              // the next context slot after a that is a word of the sentence
+        for (++a; a < a_end; ++a) { const int32_t c = pos - W + a; if (a != W && c >= 0 && c < len) break; }
+        return a;
+      };
+      float v1[R][ND];
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) v1[t][i] = 0.0f;
+        if (t < nr) {
+          const float *r1 = d.syn1 + (int64_t)__builtin_amdgcn_readlane(pts, t) * D;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; if (j < D) v1[t][i] = r1[j]; }
+        }
+      }
+      int32_t a = next_ctx(b - 1), last = -1;
+      float v0[ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) v0[i] = 0.0f;
+      if (a < a_end) {
+        last = tok(a);
+        const float *r0 = d.syn0 + (int64_t)last * D;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; if (j < D) v0[i] = r0[j]; }
+      }
+      while (a < a_end) {
+        const int32_t an = next_ctx(a);
+        int32_t lastn = -1;
+        float v0n[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) v0n[i] = 0.0f;
+        if (an < a_end) {
+          lastn = tok(an);
+          if (lastn != last) {
+            const float *rn = d.syn0 + (int64_t)lastn * D;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; if (j < D) v0n[i] = rn[j]; }
+          }
+        }
+        float neu[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) neu[i] = 0.0f;
+        // the nodes of one context are independent of each other (v0 changes after the context, every node has its own row): four at
+        // a time without a branch between them, so that their reductions and table look-ups overlap; a slot past the code (its row is
+        // zero and never written back) and an |f| >= 6 get g = 0
+#pragma unroll
+        for (int t0 = 0; t0 < R; t0 += G) {
+          if (t0 < nr) {
+            float part[G], g[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+              part[u] = 0.0f;
+#pragma unroll
+              for (int i = 0; i < ND; ++i) part[u] += v0[i] * v1[t0 + u][i];
+            }
+            // the four dot products in ONE reduction (wave_sum4_f32: lanes 12..15 of every row end up with node t0 + (lane & 3)'s), then
+            // f -> g once, in those lanes, for all four
+            const float f = wave_sum4_f32(part[0], part[1], part[2], part[3], lane);
+            const int u_l = lane & 3;
+            const bool ok = f > -MAX_EXP && f < MAX_EXP && t0 + u_l < nr;
+            const int ind = ok ? (int)((f + MAX_EXP) * ((float)EXP_TABLE_SIZE / MAX_EXP / 2.0f)) : 0;
+            const float code = (float)(((uint32_t)(code_bits >> t0) >> u_l) & 1u);
+            const float gv = ok ? (1.0f - code - exp_table[ind]) * alpha : 0.0f;
+#pragma unroll
+            for (int u = 0; u < G; ++u) g[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), 12 + u));
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+#pragma unroll
+              for (int i = 0; i < ND; ++i) { neu[i] += g[u] * v1[t0 + u][i]; v1[t0 + u][i] = v1[t0 + u][i] + g[u] * v0[i]; }
+            }
+          }
+        }
+        for (int32_t t = R; t < n; ++t) {           // a code longer than the register rows (rare words): through memory
+          float *r1 = d.syn1 + (int64_t)__builtin_amdgcn_readlane(pts, t) * D;
+          float w1[ND];
+          float part = 0.0f;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; w1[i] = j < D ? r1[j] : 0.0f; part += v0[i] * w1[i]; }
+          const float f = wave_sum_f32_dpp(part);
+          if (f > -MAX_EXP && f < MAX_EXP) {
+            const int ind = (int)((f + MAX_EXP) * ((float)EXP_TABLE_SIZE / MAX_EXP / 2.0f));
+            const float g = (1.0f - (float)((code_bits >> t) & 1ull) - exp_table[ind]) * alpha;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; neu[i] += g * w1[i]; if (j < D) r1[j] = w1[i] + g * v0[i]; }
+          }
+        }
+        {
+          float *r0 = d.syn0 + (int64_t)last * D;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; v0[i] = v0[i] + neu[i]; if (j < D) r0[j] = v0[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) v0[i] = (an < a_end && lastn == last) ? v0[i] : v0n[i];
+        last = lastn; a = an;
+      }
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        if (t < nr) {
+          float *r1 = d.syn1 + (int64_t)__builtin_amdgcn_readlane(pts, t) * D;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) { const int j = lane + 64 * i; if (j < D) r1[j] = v1[t][i]; }
+        }
+      }
+    }
+  }
+}
+
 // word2vec.c's CreateBinaryTree over counts sorted in DESCENDING order: codes and inner-node paths of every word
 void huffman(const std::vector<int64_t> &cn, std::vector<int32_t> &code_off, std::vector<int32_t> &points, std::vector<uint8_t> &codes) {
   const int64_t V = (int64_t)cn.size();
@@ -279,18 +457,24 @@ void w2v_fit_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens
     d.sent_off = reinterpret_cast<const int64_t *>(d_off.p); d.sent = d_sent.p; d.n_sent = n; d.words_before = reinterpret_cast<const int64_t *>(d_off.p);
     d.code_off = d_coff.p; d.points = d_points.p; d.codes = d_codes.p;
     d.syn0 = d_syn0.p; d.syn1 = d_syn1.p; d.dim = P.dim; d.window = P.window; d.seed = P.seed; d.n_iter = P.iterations; d.total_words = total; d.lr = P.learning_rate;
-    // threads == 1: ONE wave walks the sentences in order (the sequential form the oracle restates); else one wave per sentence, Hogwild
-    const int64_t n_waves = P.threads == 1 ? 1 : std::min<int64_t>(std::max<int64_t>(n, 1), (int64_t)h->n_cus * 32);
-    const int blocks = (int)((n_waves + TPB / 64 - 1) / (TPB / 64));
     const int nd = (P.dim + 63) / 64;
+    static const bool rows_in_memory = getenv("SRW_W2V_ROWS_IN_MEMORY") && atoi(getenv("SRW_W2V_ROWS_IN_MEMORY")) != 0;   // (the round-4 kernel, for A / B)
+    void (*kern)(W2vDev, int64_t);
+    if (rows_in_memory) kern = nd <= 1 ? k_w2v_train<1> : nd <= 2 ? k_w2v_train<2> : nd <= 4 ? k_w2v_train<4> : nd <= 8 ? k_w2v_train<8> : k_w2v_train<16>;
+    else kern = nd <= 1 ? k_w2v_train_rows<1, 32> : nd <= 2 ? k_w2v_train_rows<2, 24> : nd <= 4 ? k_w2v_train_rows<4, 24>
+              : nd <= 8 ? k_w2v_train_rows<8, 8> : k_w2v_train_rows<16, 4>;
+    // threads == 1: ONE wave walks the sentences in order (the sequential form the oracle restates); else one wave per sentence at a
+    // time, Hogwild, as many waves as the GPU holds at once (sentences are of one length: a second, partial round of waves would idle
+    // a third of the chip)
+    int per_cu = 0;
+    SRW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), TPB, 0));
+    const int64_t resident = (int64_t)h->n_cus * std::max(per_cu, 1) * (TPB / 64);
+    const int64_t n_waves = P.threads == 1 ? 1 : std::min<int64_t>(std::max<int64_t>(n, 1), resident);
+    const int blocks = (int)((n_waves + TPB / 64 - 1) / (TPB / 64));
     for (int32_t k = 0; k < P.iterations; ++k) {
       d.iter = k;
       const dim3 grid(P.threads == 1 ? 1 : blocks), block(P.threads == 1 ? 64 : TPB);
-      if (nd <= 1) hipLaunchKernelGGL(k_w2v_train<1>, grid, block, 0, st, d, n_waves);
-      else if (nd <= 2) hipLaunchKernelGGL(k_w2v_train<2>, grid, block, 0, st, d, n_waves);
-      else if (nd <= 4) hipLaunchKernelGGL(k_w2v_train<4>, grid, block, 0, st, d, n_waves);
-      else if (nd <= 8) hipLaunchKernelGGL(k_w2v_train<8>, grid, block, 0, st, d, n_waves);
-      else hipLaunchKernelGGL(k_w2v_train<16>, grid, block, 0, st, d, n_waves);
+      hipLaunchKernelGGL(kern, grid, block, 0, st, d, n_waves);
       SRW_HIP(hipGetLastError());
     }
     SRW_HIP(hipMemcpyAsync(vectors.data(), d_syn0.p, vectors.size() * 4, hipMemcpyDeviceToHost, st));

@@ -34,7 +34,9 @@ def _cos_split(oracle_graph, ids, vec):
     return float(np.mean(nb)), float(np.mean(nn))
 
 
-@pytest.mark.parametrize("dim,window", [(16, 5), (128, 10), (70, 3)])
+# (16, 40): a window wider than a register holds (the tokens come from memory); 200 / 300 / 600: 4, 8, 16 floats per lane — with 16 the
+# kernel keeps 4 rows in registers and karate's 5-7 node codes run their tail through memory
+@pytest.mark.parametrize("dim,window", [(16, 5), (128, 10), (70, 3), (16, 40), (200, 4), (300, 3), (600, 2)])
 def test_sequential_mode_matches_the_cpu_restatement(eng, oracle, dim, window):
     g = oracle.Graph.load(KARATE)
     eng.load_edgelist(KARATE, directed=False)
@@ -49,6 +51,35 @@ def test_sequential_mode_matches_the_cpu_restatement(eng, oracle, dim, window):
     i0, v0 = eng.w2v_fit(paths, lens, dim=dim, window=window, iterations=0, seed=11)
     o0, ov0 = oracle.w2v_fit(paths, lens, dim=dim, window=window, iterations=0, seed=11)
     assert np.array_equal(i0, o0) and np.array_equal(v0, ov0)
+
+
+@pytest.mark.parametrize("dim,n_words", [(96, 27), (160, 26), (40, 20)])
+def test_deep_huffman_codes(eng, oracle, dim, n_words):
+    """Fibonacci counts give the deepest tree a vocabulary can have (code length n_words - 1): the rare words' codes are longer than the
+    rows the training kernel keeps in registers (24 at dim <= 128 and <= 256, 32 at dim <= 64), so their last nodes take the memory
+    path; the frequent words' codes are one or two nodes (groups with empty slots)."""
+    fib = [1, 1]
+    while len(fib) < n_words:
+        fib.append(fib[-1] + fib[-2])
+    rng = np.random.default_rng(n_words)
+    toks = np.repeat(np.arange(n_words, dtype=np.int32) + 100, fib)
+    rng.shuffle(toks)
+    stride = 50
+    n = (len(toks) + stride - 1) // stride
+    paths = np.full((n, stride), -1, np.int32)
+    paths.reshape(-1)[:len(toks)] = toks
+    lens = np.full(n, stride, np.int32); lens[-1] = len(toks) - (n - 1) * stride
+    ids, vec = eng.w2v_fit(paths, lens, dim=dim, window=2, iterations=1, lr=0.025, seed=5, threads=1)
+    oids, ovec = oracle.w2v_fit(paths, lens, dim=dim, window=2, iterations=1, lr=0.025, seed=5)
+    assert np.array_equal(ids, oids) and ids[0] == 100 + n_words - 1
+    codes = pkg().w2v_huffman(np.sort(np.array(fib, np.int64))[::-1])
+    assert max(len(c) for c, _ in codes) == n_words - 1
+    err = float(np.abs(vec - ovec).max())
+    assert np.allclose(vec, ovec, rtol=5e-3, atol=5e-4), err
+    # and the Hogwild launch over the same sentences trains (finite, moved away from the initial vectors)
+    _, hv = eng.w2v_fit(paths, lens, dim=dim, window=2, iterations=1, lr=0.025, seed=5)
+    _, v0 = eng.w2v_fit(paths, lens, dim=dim, window=2, iterations=0, seed=5)
+    assert np.isfinite(hv).all() and float(np.abs(hv - v0).max()) > 1e-3
 
 
 def test_hogwild_mode_embeds_the_graph(eng, oracle):

@@ -55,7 +55,8 @@ def cpu_baseline(args):
     karate, RMAT-14, RMAT-16 and an RMAT-20 sample, each at (p, q) = (1, 1) unweighted and (0.25, 4) weighted, the faithful
     variant (the reference's own O(deg(curr) * deg(prev)) linear `exists`, RandomSample.scala:27-44) and the fast one (sorted
     membership: same outputs).  The object's own value is the RMAT-20 (1, 1) faithful sample, as in rounds 1-2; `plan` lists
-    every measurement, so that the biased GPU lines have their CPU number beside them."""
+    every measurement, so that the biased GPU lines have their CPU number beside them.  The default run times the RMAT-20 samples only
+    (`--cpu-plan sample`: ~30 s of CPU work, as the bench contract asks); `--cpu-plan full` the whole plan."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_py
@@ -81,7 +82,12 @@ def cpu_baseline(args):
                 timed(gk, "karate.txt (34 vertices), walkLength 10", gk.vertices(), p, q, 10, faithful)
     head = None
     t_build = 0.0
-    for scale, n_faithful, n_fast in ((14, 2048, 0), (16, 1024, 4096), (args.cpu_scale, args.cpu_sources or max(256, 4 * cores), 16384)):
+    # --cpu-plan sample (default): the RMAT-20 samples only, ~30 s of CPU work in all (the object's own value, its fast variant, one biased
+    # sample beside the biased GPU rows); --cpu-plan full: BASELINE.md §3's whole plan, ~100 s (profiles/r05f_bench_n1.json has one)
+    full = args.cpu_plan == "full"
+    sizes = ((14, 2048, 0), (16, 1024, 4096), (args.cpu_scale, args.cpu_sources or max(256, 4 * cores), 16384)) if full else \
+            ((args.cpu_scale, args.cpu_sources or max(256, 4 * cores), 4096),)
+    for scale, n_faithful, n_fast in sizes:
         t0 = time.time()
         s, d = oracle_py.rmat_edges(scale, 16 << scale, seed=42)
         graphs = {(1.0, 1.0): oracle_py.Graph.from_coo(s, d, None, directed=False),
@@ -89,7 +95,9 @@ def cpu_baseline(args):
         t_build += time.time() - t0
         for (p, q), g in graphs.items():
             verts = g.vertices()
-            for faithful, n_src in ((True, n_faithful if (q == 1.0 or scale < args.cpu_scale) else max(64, n_faithful // 3)), (False, n_fast)):   # (the biased faithful walk is ~3x slower per step)
+            for faithful, n_src in ((True, n_faithful if (q == 1.0 or scale < args.cpu_scale) else max(64, n_faithful // (3 if full else 8))), (False, n_fast)):   # (the biased faithful walk is ~3x slower per step)
+                if not full and not faithful and q != 1.0:
+                    continue
                 src = verts if (n_src == 0 or n_src >= len(verts)) else verts[np.linspace(0, len(verts) - 1, n_src).astype(np.int64)]
                 e = timed(g, "RMAT scale-%d ef16 undirected %s, walkLength %d, %s" % (
                     scale, "unweighted" if q == 1.0 else "weighted", args.cpu_walk_length,
@@ -408,6 +416,7 @@ ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel
                  "record_bytes", "physical_traffic_frac", "requests_per_step", "requests_per_s", "request_rate_ceiling",
                  "request_rate_frac", "scan_equivalent_frac", "traffic_commit")
 SUMMARY_KEYS = ("name", "value", "ms_per_step", "kernel_ms", "job_numWalks10_steps_per_s", "job_planned_steps_per_s", "fraction_of_replicated", "error")
+T_START = time.perf_counter()
 LINE_LIMIT = 4096               # the driver reads the LAST stdout line; round 4's 24 KB line was not parsed
 
 
@@ -522,6 +531,8 @@ def emit(out, args):
 
 
 def main():
+    global T_START
+    T_START = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--detail", default="", help="where the full (uncompacted) result goes; default gpurun_out/bench_detail.json or ./bench_detail.json")
     ap.add_argument("--gpus", type=int, default=1)
@@ -547,8 +558,10 @@ def main():
     ap.add_argument("--compact", type=int, default=1, help="0: do not use the 16-byte lattice records")
     ap.add_argument("--configs", type=int, default=1, help="1 GPU: also run BASELINE configs C2, C3 (Mode R / A), C5 stand-in")
     ap.add_argument("--configs-scale-cap", type=int, default=0, help="tests: run the `configs` plan with every scale capped at this value")
+    ap.add_argument("--time-budget", type=float, default=420.0, help="seconds after which no further optional configuration starts")
     ap.add_argument("--end-to-end", type=int, default=1, help="1 GPU: also time one iteration through srw_walk_and_save")
     ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-plan", choices=["sample", "full"], default="sample", help="sample: ~30 s of CPU work; full: BASELINE.md's whole CPU plan (~100 s)")
     ap.add_argument("--cpu-scale", type=int, default=20)
     ap.add_argument("--cpu-sources", type=int, default=0, help="0 = max(64, 3 per host core)")
     ap.add_argument("--cpu-walk-length", type=int, default=80)
@@ -786,33 +799,40 @@ def main():
                     ("C5 stand-in Mode R", 26, 27, False, True, 4.0, 0.5, "reference", 1, 1),
                     ("C5 stand-in Mode A", 26, 27, False, True, 4.0, 0.5, "alias", 2, 1)]
             cap = args.configs_scale_cap or 99
+            # every optional leg is timed (`leg_wall_s`, detail file) and starts only while the run is inside --time-budget: on a box whose
+            # allocations stall (profiles/r05_table_build.md 5) the line loses its last rows instead of the run losing its line
+            def leg(name, fn):
+                if time.perf_counter() - T_START > args.time_budget:
+                    cfgs.append({"name": name, "error": "skipped: %.0f s time budget spent" % args.time_budget})
+                    return
+                t0 = time.perf_counter()
+                try:
+                    r = fn()
+                except Exception as ex:
+                    r = {"name": name, "error": str(ex)[:300]}
+                r["leg_wall_s"] = time.perf_counter() - t0
+                cfgs.append(r)
+
             for (name, sc, ef, wt, dr, p, q, smp, k, w) in plan:
                 sc = min(sc, cap)
-                try:
-                    cfgs.append(run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w, ceiling=ceiling,
-                                           plan_walks=100 if "numWalks=100" in name else 0))
-                except Exception as ex:
-                    cfgs.append({"name": name, "error": str(ex)[:300]})
+                leg(name, lambda: run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w, ceiling=ceiling,
+                                             plan_walks=100 if "numWalks=100" in name else 0))
             if args.shard in ("both", "vertex"):
-                try:
-                    cfgs.append(run_sharded_world1(pkg, local_rank, scale=min(24, cap)))
-                except Exception as ex:
-                    cfgs.append({"name": "sharded w1 p=q=1", "error": str(ex)[:300]})
+                leg("sharded w1 p=q=1", lambda: run_sharded_world1(pkg, local_rank, scale=min(24, cap)))
                 rep = {c.get("name"): c.get("value") for c in cfgs}
                 for (name, sc, ef, wt, dr, p, q, of) in [
                         ("sharded w1 C3", 24, 16, True, False, 0.25, 4.0, "C3 Mode R"),
                         ("sharded w1 C3 graph q=1", 24, 16, True, False, 0.25, 1.0, "C3 graph q=1 Mode R"),
                         ("sharded w1 C5 stand-in", 26, 27, False, True, 4.0, 0.5, "C5 stand-in Mode R")]:
                     sc = min(sc, cap)
-                    try:
-                        cfgs.append(run_sharded_biased_world1(pkg, local_rank, name, sc, ef, wt, dr, p, q, rep.get(of), batch2=(sc <= 24)))
-                    except Exception as ex:
-                        cfgs.append({"name": name, "error": str(ex)[:300]})
+                    leg(name, lambda: run_sharded_biased_world1(pkg, local_rank, name, sc, ef, wt, dr, p, q, rep.get(of), batch2=(sc <= 24)))
             out["configs"] = cfgs
-            try:
-                out["embedding_stage"] = run_embedding_stage(pkg, local_rank, min(20, cap))
-            except Exception as ex:
-                out["embedding_stage"] = {"error": str(ex)[:200]}
+            if time.perf_counter() - T_START <= args.time_budget:
+                try:
+                    out["embedding_stage"] = run_embedding_stage(pkg, local_rank, min(20, cap))
+                except Exception as ex:
+                    out["embedding_stage"] = {"error": str(ex)[:200]}
+            out["wall_s_before_cpu_baseline"] = time.perf_counter() - T_START
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         emit(out, args)

@@ -458,7 +458,11 @@ def compact_line(out):
     if "setup_s" in out:
         c["setup_s"] = {k: v for k, v in out["setup_s"].items() if not isinstance(v, str)}
     if "end_to_end" in out:
-        c["end_to_end"] = {k: v for k, v in out["end_to_end"].items() if k in ("seconds", "walk_steps_per_s", "text_GB_per_s", "skipped", "error")}
+        c["end_to_end"] = {k: v for k, v in out["end_to_end"].items() if k in ("seconds", "walk_steps_per_s", "text_GB_per_s", "part_files", "skipped", "error")}
+        if isinstance(out["end_to_end"].get("single_part"), dict):
+            c["end_to_end"]["single_part_walk_steps_per_s"] = out["end_to_end"]["single_part"].get("walk_steps_per_s")
+        if isinstance(out["end_to_end"].get("first_call"), dict):
+            c["end_to_end"]["first_call_seconds"] = out["end_to_end"]["first_call"].get("seconds")
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
         c["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "value_fast_variant", "walk_steps", "seconds") if k in cb}
@@ -711,7 +715,10 @@ def main():
             }
         # ---- end to end: the reference's contract is path FILES --------------------------------------------------------
         if rank == 0 and world == 1 and args.end_to_end:
-            e2e = {"what": "srw_walk_and_save, 1 walk iteration: walk kernel + device-side formatter + PCIe + part-00000 on local disk"}
+            e2e = {"what": "srw_walk_and_save, 1 walk iteration: walk kernel + device-side formatter + PCIe + <output>/path/part-00000 .. "
+                           "part-00199 on local disk (rddPartitions = 200, the reference's default: Params.scala:20; part files are "
+                           "written in parallel); `first_call`: the same with the text path's one-off allocations; `single_part`: into ONE file "
+                           "(bound by one inode's buffered writes)"}
             tmp_root = os.environ.get("TMPDIR", "/tmp")
             need = nv * (args.walk_length + 2) * 8          # generous bound on the text size
             try:
@@ -719,16 +726,22 @@ def main():
                 if free < need * 1.2:
                     e2e["skipped"] = "needs ~%.0f GB under %s, %.0f GB free" % (need / 1e9, tmp_root, free / 1e9)
                 else:
-                    d = tempfile.mkdtemp(prefix="srw_bench_", dir=tmp_root)
-                    try:
-                        t0 = time.perf_counter()
-                        st, _ = eng.walk_and_save(os.path.join(d, "out"), n_parts=1, first_walk=base + W + K, device_format=True, **walk_kw)
-                        dt_e = time.perf_counter() - t0
-                        nbytes = sum(os.path.getsize(os.path.join(d, "out", "path", f)) for f in os.listdir(os.path.join(d, "out", "path")))
-                        e2e.update({"seconds": dt_e, "walk_steps_per_s": st["n_steps"] / dt_e, "text_bytes": nbytes,
-                                    "text_GB_per_s": nbytes / dt_e / 1e9, "kernel_ms": st["kernel_ms"]})
-                    finally:
-                        shutil.rmtree(d, ignore_errors=True)
+                    # first call: with the one-off allocations of the text path (staging + text slots in HBM, pinned ring); second: without
+                    for key, parts in (("first_call", 200), ("", 200), ("single_part", 1)):
+                        d = tempfile.mkdtemp(prefix="srw_bench_", dir=tmp_root)
+                        try:
+                            t0 = time.perf_counter()
+                            st, _ = eng.walk_and_save(os.path.join(d, "out"), n_parts=parts, first_walk=base + W + K, device_format=True, **walk_kw)
+                            dt_e = time.perf_counter() - t0
+                            nbytes = sum(os.path.getsize(os.path.join(d, "out", "path", f)) for f in os.listdir(os.path.join(d, "out", "path")))
+                            r = {"seconds": dt_e, "walk_steps_per_s": st["n_steps"] / dt_e, "text_bytes": nbytes,
+                                 "text_GB_per_s": nbytes / dt_e / 1e9, "kernel_ms": st["kernel_ms"], "part_files": parts}
+                            if key:
+                                e2e[key] = r
+                            else:
+                                e2e.update(r)
+                        finally:
+                            shutil.rmtree(d, ignore_errors=True)
             except Exception as ex:  # the headline must survive a full disk
                 e2e["error"] = str(ex)[:200]
             out["end_to_end"] = e2e

@@ -151,7 +151,8 @@ void srw_destroy(srw_handle *h) {
   }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   for (int i = 0; i < 2; ++i) { if (h->pin_paths[i]) (void)hipHostFree(h->pin_paths[i]); if (h->pin_lens[i]) (void)hipHostFree(h->pin_lens[i]); }
-  for (int i = 0; i < 2; ++i) { if (h->pin_text[i]) (void)hipHostFree(h->pin_text[i]); if (h->pin_off[i]) (void)hipHostFree(h->pin_off[i]); }
+  for (int i = 0; i < srw_handle::PIN_RING; ++i) { if (h->pin_text[i]) (void)hipHostFree(h->pin_text[i]); if (h->pin_copied[i]) (void)hipEventDestroy(h->pin_copied[i]); }
+  for (int i = 0; i < 2; ++i) if (h->pin_off[i]) (void)hipHostFree(h->pin_off[i]);
   if (h->shard_parked.init) {
     if (h->shard_parked.stream) (void)hipStreamSynchronize(h->shard_parked.stream);
     if (h->shard_parked.ev0) (void)hipEventDestroy(h->shard_parked.ev0);

@@ -213,8 +213,10 @@ struct srw_handle {
   size_t pin_cap = 0, pin_lens_cap = 0;
   // device-side formatter (SRW_WALK_DEVICE_FORMAT): per staging slot the text + line offsets, one pinned text buffer
   srw::DevBuf<char> fmt_text[2]; srw::DevBuf<unsigned long long> fmt_len[2], fmt_off[2]; srw::DevBuf<char> fmt_temp;
-  char *pin_text[2] = {nullptr, nullptr}; unsigned long long *pin_off[2] = {nullptr, nullptr};
-  size_t pin_text_cap[2] = {0, 0}, pin_off_cap = 0;
+  static constexpr int PIN_RING = 6;             // pinned text slices in flight between the device and the writer's threads
+  char *pin_text[PIN_RING] = {nullptr}; unsigned long long *pin_off[2] = {nullptr, nullptr};
+  size_t pin_text_cap[PIN_RING] = {0}, pin_off_cap = 0;
+  hipEvent_t pin_copied[PIN_RING] = {nullptr};
 };
 
 namespace srw {
@@ -260,7 +262,11 @@ class PathWriter {
   ~PathWriter();
   void append(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride);
   // already formatted lines (device formatter): off[0..n] are byte offsets, text[0] is the byte at offset `base`
-  void append_text(const char *text, const unsigned long long *off, int64_t n, unsigned long long base = 0);
+  // token >= 0 (and no .crc files asked): the bytes are handed to a pool of writer threads — part files are written in parallel — and
+  // `text` must stay untouched until wait_token(token) returns (token: the caller's name for its buffer, < 16).  token < 0: written on return.
+  void append_text(const char *text, const unsigned long long *off, int64_t n, unsigned long long base = 0, int token = -1);
+  void wait_token(int token);      // token < 0: everything handed over so far
+  bool token_idle(int token);      // nothing handed over with this token is still being written
   void close();  // finishes the parts, writes _SUCCESS
  private:
   struct Impl;
@@ -274,6 +280,11 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool w
 // ---- path_format.hip ----
 size_t format_capacity(int64_t n, int64_t stride, int32_t vmin, int32_t vmax);
 void ensure_pinned_text(srw_handle *h, size_t slice_cap, size_t n_off);
+size_t text_slice_cap(int64_t stride, size_t text_bytes);
+// text [off[0], off[n]) of d_text (whole lines, offsets on the host) -> the writer, through the ring of pinned slices; all_copied():
+// every byte has left d_text (it may be overwritten)
+void drain_text(srw_handle *h, PathWriter &writer, const char *d_text, const unsigned long long *off, int64_t n, size_t slice_cap,
+                const std::function<void()> &all_copied);
 bool write_result_device(srw_handle *h, const char *output_dir, int n_parts, bool write_crc);
 void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens, int64_t n, int64_t stride,
                          unsigned long long *d_len_bytes, unsigned long long *d_off, char *d_text);

@@ -4,6 +4,7 @@
 //   k_fmt_len   : bytes of every line                      -> exclusive scan (rocPRIM) -> byte offset of every line
 //   k_fmt_write : every lane writes its own number (+ separator) at  line offset + wave-prefix of the lengths
 // The host then only copies the text out and pwrite()s it (run_walk_and_save with SRW_WALK_DEVICE_FORMAT).
+#include <chrono>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -88,15 +89,17 @@ void format_paths_device(srw_handle *h, const int32_t *d_paths, const int32_t *d
   SRW_HIP(hipGetLastError());
 }
 
-// Pinned staging of the device formatter's output: two text slices (+ the line offsets of one chunk).
+// Pinned staging of the device formatter's output: a ring of text slices (+ the line offsets of one chunk).
 void ensure_pinned_text(srw_handle *h, size_t slice_cap, size_t n_off) {
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < srw_handle::PIN_RING; ++i) {
     if (h->pin_text_cap[i] < slice_cap) {
       if (h->pin_text[i]) (void)hipHostFree(h->pin_text[i]);
       h->pin_text[i] = nullptr;
       SRW_HIP(hipHostMalloc((void **)&h->pin_text[i], slice_cap, hipHostMallocDefault));
       h->pin_text_cap[i] = slice_cap;
     }
+    if (!h->pin_copied[i]) SRW_HIP(hipEventCreateWithFlags(&h->pin_copied[i], hipEventDisableTiming));
+  }
   if (h->pin_off_cap < n_off) {
     for (int i = 0; i < 2; ++i) {
       if (h->pin_off[i]) (void)hipHostFree(h->pin_off[i]);
@@ -105,6 +108,66 @@ void ensure_pinned_text(srw_handle *h, size_t slice_cap, size_t n_off) {
     }
     h->pin_off_cap = n_off;
   }
+}
+// Pinned memory costs ~0.2 ms/MB to allocate and ~0.1 ms/MB to free on this stack, so the text leaves the device in slices of <= 64 MB
+// of whole lines — smaller ones for a small output (text_bytes: an upper bound of what one drain moves), so that a karate-sized job
+// does not pin 384 MB.  SRW_TEXT_SLICE_KB (tests): the slice size, so that a small graph takes the ring around several times.
+size_t text_slice_cap(int64_t stride, size_t text_bytes) {
+  size_t cap = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)1 << 20, text_bytes / (2 * srw_handle::PIN_RING)));
+  if (const char *e = getenv("SRW_TEXT_SLICE_KB"); e && atoi(e) > 0) cap = (size_t)atoi(e) << 10;
+  return std::max<size_t>(cap, (size_t)stride * 12 + 64);
+}
+
+// The text of [0, n) walkers leaves d_text through the ring: up to PIN_RING slices are between the copy stream and the writer's
+// threads at any time — slice j + 1 .. j + 5 are copied while slice j is written, and slices that fall into different part files are
+// written in parallel (writer.cpp).  A ring slot is reused when the writer has released it (wait_token).
+void drain_text(srw_handle *h, PathWriter &writer, const char *d_text, const unsigned long long *off, int64_t n, size_t slice_cap,
+                const std::function<void()> &all_copied) {
+  constexpr int K = srw_handle::PIN_RING;
+  auto slice_end = [&](int64_t w0) {                       // largest w1 > w0 with off[w1] - off[w0] <= slice_cap
+    int64_t lo = w0 + 1, hi = n;
+    while (lo < hi) { const int64_t mid = lo + (hi - lo + 1) / 2; if (off[mid] - off[w0] <= slice_cap) lo = mid; else hi = mid - 1; }
+    return lo;
+  };
+  struct Slice { int64_t w0, w1; };
+  Slice ring[K];
+  long long issued = 0, handed = 0;
+  int64_t w_next = 0;
+  const bool timing = getenv("SRW_TIMING") != nullptr;
+  double t_wait_writer = 0, t_wait_copy = 0, t_hand = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  // a slot goes free -> being copied into -> copied -> with the writer's threads -> free.  The host never blocks on a slot while a copied
+  // slice waits to be handed over (else the writes of the ring's slices would run one after the other)
+  for (;;) {
+    while (w_next < n && issued - handed < K && writer.token_idle((int)(issued % K))) {
+      const int buf = (int)(issued % K);
+      const int64_t w1 = slice_end(w_next);
+      SRW_HIP(hipMemcpyAsync(h->pin_text[buf], d_text + off[w_next], (size_t)(off[w1] - off[w_next]), hipMemcpyDeviceToHost, h->copy_stream));
+      SRW_HIP(hipEventRecord(h->pin_copied[buf], h->copy_stream));
+      ring[buf] = Slice{w_next, w1};
+      w_next = w1; ++issued;
+    }
+    if (handed < issued) {
+      const int buf = (int)(handed % K);
+      const auto t0 = now();
+      SRW_HIP(hipEventSynchronize(h->pin_copied[buf]));       // slice `handed` is in pin_text[buf]
+      const auto t1 = now();
+      ++handed;
+      if (handed == issued && w_next >= n && all_copied) all_copied();
+      writer.append_text(h->pin_text[buf], off + ring[buf].w0, ring[buf].w1 - ring[buf].w0, off[ring[buf].w0], buf);
+      t_wait_copy += ms(t0, t1); t_hand += ms(t1, now());
+      continue;
+    }
+    if (w_next >= n) break;
+    const auto t0 = now();
+    writer.wait_token((int)(issued % K));                     // every slot is with the writer: wait for the oldest
+    t_wait_writer += ms(t0, now());
+  }
+  if (timing)
+    fprintf(stderr, "[timing] text drain: %lld slices, %.1f GB; host waited %.0f ms for copies, %.0f ms for the writer's threads, %.0f ms handing over\n",
+            issued, n > 0 ? (double)(off[n] - off[0]) / 1e9 : 0.0, t_wait_copy, t_wait_writer, t_hand);
+  if (n <= 0 && all_copied) all_copied();
 }
 
 // srw_write_paths on a device-resident result: formatted on the GPU chunk by chunk, copied out in slices of whole lines
@@ -124,7 +187,7 @@ bool write_result_device(srw_handle *h, const char *output_dir, int n_parts, boo
   hipStream_t st = h->stream;
   if (!h->copy_stream) SRW_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   h->fmt_text[0].ensure(cap); h->fmt_len[0].ensure((size_t)chunk + 1); h->fmt_off[0].ensure((size_t)chunk + 1);
-  const size_t slice_cap = std::max<size_t>((size_t)64 << 20, (size_t)stride * 12 + 64);
+  const size_t slice_cap = text_slice_cap(stride, (size_t)n * per_walker);
   ensure_pinned_text(h, slice_cap, (size_t)chunk + 1);
   for (int64_t c0 = 0; c0 < n; c0 += chunk) {
     const int64_t m = std::min<int64_t>(chunk, n - c0);
@@ -132,26 +195,7 @@ bool write_result_device(srw_handle *h, const char *output_dir, int n_parts, boo
                         h->fmt_text[0].p);
     SRW_HIP(hipMemcpyAsync(h->pin_off[0], h->fmt_off[0].p, ((size_t)m + 1) * 8, hipMemcpyDeviceToHost, st));
     SRW_HIP(hipStreamSynchronize(st));
-    const unsigned long long *off = h->pin_off[0];
-    auto slice_end = [&](int64_t w0) {
-      int64_t lo = w0 + 1, hi = m;
-      while (lo < hi) { const int64_t mid = lo + (hi - lo + 1) / 2; if (off[mid] - off[w0] <= slice_cap) lo = mid; else hi = mid - 1; }
-      return lo;
-    };
-    auto copy_slice = [&](int64_t w0, int64_t w1, int buf) {
-      SRW_HIP(hipMemcpyAsync(h->pin_text[buf], h->fmt_text[0].p + off[w0], (size_t)(off[w1] - off[w0]), hipMemcpyDeviceToHost,
-                             h->copy_stream));
-    };
-    int64_t w0 = 0, w1 = slice_end(0);
-    int buf = 0;
-    copy_slice(w0, w1, buf);
-    while (w0 < m) {
-      SRW_HIP(hipStreamSynchronize(h->copy_stream));
-      const int64_t n0 = w1, n1 = n0 < m ? slice_end(n0) : n0;
-      if (n0 < m) copy_slice(n0, n1, buf ^ 1);
-      writer.append_text(h->pin_text[buf], off + w0, w1 - w0, off[w0]);
-      w0 = n0; w1 = n1; buf ^= 1;
-    }
+    drain_text(h, writer, h->fmt_text[0].p, h->pin_off[0], m, slice_cap, nullptr);
   }
   writer.close();
   return true;

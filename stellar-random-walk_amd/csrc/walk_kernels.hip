@@ -2681,11 +2681,12 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
     size_t free_b = 0, total_b = 0;
     SRW_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t have = h->fmt_text[0].n + h->fmt_text[1].n;
-    if (2 * cap > have && free_b < 2 * cap - have + need * 2 + ((size_t)4 << 30)) device_format = false;
+    const size_t slots = P.num_walks > 1 ? 2 : 1;
+    if (slots * cap > have && free_b < slots * cap - have + need * slots + ((size_t)4 << 30)) device_format = false;
   }
+  const int n_slots = P.num_walks > 1 ? 2 : 1;             // (a single iteration never touches the second staging / text slot: tens of GB at the headline's size)
   for (int i = 0; i < 2; ++i) {
-    h->stage_paths[i].ensure((size_t)nv * stride);
-    h->stage_lens[i].ensure((size_t)nv);
+    if (i < n_slots) { h->stage_paths[i].ensure((size_t)nv * stride); h->stage_lens[i].ensure((size_t)nv); }
     if (!h->stage_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming));
     if (!h->kernel_done[i]) SRW_HIP(hipEventCreateWithFlags(&h->kernel_done[i], hipEventDisableTiming));
     // pinned ring: the ids only travel to the host when the host formats them; the lengths always do (dead-end counts)
@@ -2711,7 +2712,7 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
   if (device_format) {
     // Device-side formatter (path_format.hip): the GPU turns iteration `it` into text while the host copies out and
     // writes the text of iteration `it - 1`; the host never touches the ids.
-    for (int i = 0; i < 2; ++i) { h->fmt_text[i].ensure(cap); h->fmt_len[i].ensure((size_t)nv + 1); h->fmt_off[i].ensure((size_t)nv + 1); }
+    for (int i = 0; i < n_slots; ++i) { h->fmt_text[i].ensure(cap); h->fmt_len[i].ensure((size_t)nv + 1); h->fmt_off[i].ensure((size_t)nv + 1); }
     const int32_t N = P.num_walks;
     auto launch = [&](int32_t it) {
       const int b = it & 1;
@@ -2720,39 +2721,23 @@ void run_walk_and_save(srw_handle *h, const srw_walk_params &P, const char *outp
                           h->fmt_text[b].p);
       SRW_HIP(hipEventRecord(h->kernel_done[b], st));
     };
-    // Pinned memory costs ~0.2 ms/MB to allocate and ~0.1 ms/MB to free on this stack, so the text leaves the device in
-    // slices of <= 64 MB of whole lines through two small pinned buffers: slice j + 1 is copied while slice j is written.
-    const size_t slice_cap = std::max<size_t>((size_t)64 << 20, (size_t)stride * 12 + 64);
+    // The text leaves the device in slices of whole lines through the ring of pinned buffers (path_format.hip:drain_text): the next
+    // slices are copied while the writer's threads put the earlier ones into their part files.
+    const size_t slice_cap = text_slice_cap(stride, cap);
     ensure_pinned_text(h, slice_cap, (size_t)nv + 1);
     launch(0);
     if (N > 1) launch(1);
     for (int32_t k = 0; k < N; ++k) {
       const int b = k & 1;
+      const auto tk0 = std::chrono::steady_clock::now();
       SRW_HIP(hipEventSynchronize(h->kernel_done[b]));                      // walk + format of iteration k done
-      SRW_HIP(hipMemcpyAsync(h->pin_off[0], h->fmt_off[b].p, ((size_t)nv + 1) * 8, hipMemcpyDeviceToHost, h->copy_stream));
+      if (getenv("SRW_TIMING")) fprintf(stderr, "[timing] walk_and_save: waited %.0f ms for walk + format of iteration %d\n",
+                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk0).count(), k);
+      unsigned long long *off = h->pin_off[b];
+      SRW_HIP(hipMemcpyAsync(off, h->fmt_off[b].p, ((size_t)nv + 1) * 8, hipMemcpyDeviceToHost, h->copy_stream));
       SRW_HIP(hipMemcpyAsync(h->pin_lens[b], h->stage_lens[b].p, (size_t)nv * 4, hipMemcpyDeviceToHost, h->copy_stream));
       SRW_HIP(hipStreamSynchronize(h->copy_stream));
-      const unsigned long long *off = h->pin_off[0];
-      auto slice_end = [&](int64_t w0) {                       // largest w1 > w0 with off[w1] - off[w0] <= slice_cap
-        int64_t lo = w0 + 1, hi = nv;
-        while (lo < hi) { const int64_t mid = lo + (hi - lo + 1) / 2; if (off[mid] - off[w0] <= slice_cap) lo = mid; else hi = mid - 1; }
-        return lo;
-      };
-      auto copy_slice = [&](int64_t w0, int64_t w1, int buf) {
-        SRW_HIP(hipMemcpyAsync(h->pin_text[buf], h->fmt_text[b].p + off[w0], (size_t)(off[w1] - off[w0]), hipMemcpyDeviceToHost,
-                               h->copy_stream));
-      };
-      int64_t w0 = 0, w1 = slice_end(0);
-      int buf = 0;
-      copy_slice(w0, w1, buf);
-      while (w0 < nv) {
-        SRW_HIP(hipStreamSynchronize(h->copy_stream));        // slice [w0, w1) is in pin_text[buf]
-        const int64_t n0 = w1, n1 = n0 < nv ? slice_end(n0) : n0;
-        if (n0 < nv) copy_slice(n0, n1, buf ^ 1);
-        else if (k + 2 < N) launch(k + 2);                    // every byte of device slot b is out: reuse it
-        writer.append_text(h->pin_text[buf], off + w0, w1 - w0, off[w0]);
-        w0 = n0; w1 = n1; buf ^= 1;
-      }
+      drain_text(h, writer, h->fmt_text[b].p, off, nv, slice_cap, [&] { if (k + 2 < N) launch(k + 2); });   // every byte of device slot b is out: reuse it
       if (dead_per_iter) {
         int64_t dead = 0;
         for (int64_t i = 0; i < nv; ++i) dead += (h->pin_lens[b][i] >= 2 && h->pin_lens[b][i] < stride);

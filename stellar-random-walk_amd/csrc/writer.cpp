@@ -19,7 +19,11 @@
 #include <functional>
 #include <cstring>
 #include <memory>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
+#include <vector>
 
 #include "engine.h"
 
@@ -105,7 +109,70 @@ struct PathWriter::Impl {
   int n_parts = 1;
   int64_t total = 0, per = 0, next = 0;     // walkers: total, per part, already written
   bool write_crc = false;
+  // the open part: jobs of the pool keep it alive (closed when the writer has moved on AND its last queued byte is written)
+  struct PartFd {
+    int fd = -1; std::mutex one_writer; off_t reserved = 0, final_size = -1;
+    ~PartFd() { if (fd >= 0) { if (reserved > 0 && final_size >= 0 && final_size < reserved) (void)!ftruncate(fd, final_size); ::close(fd); } }   // (gives back what the reservation overshot)
+  };   // (one inode: 12.4 GB/s with one writer, less with more)
+  std::shared_ptr<PartFd> part;
   int fd = -1; int cur_part = -1; off_t file_off = 0;
+  // ---- the pool behind append_text(..., token >= 0): part files are written in PARALLEL (one inode takes ~12 GB/s of buffered
+  // writes on the GPU box whatever the number of threads, 8 files 74 GB/s: tools/microbench_filewrite.cpp; the reference's default
+  // is 200 parts, Params.scala:20) while the caller copies the next slices out of the device
+  struct Job { std::shared_ptr<PartFd> f; const char *src; size_t bytes; off_t off; int token; std::string fn; };
+  static constexpr int MAX_TOKENS = 16;
+  std::vector<std::thread> pool;
+  std::deque<Job> jobs;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  int pending[MAX_TOKENS] = {0}; int pending_all = 0;
+  bool stop = false;
+  std::string pool_error;
+  double pool_job_ms = 0; size_t pool_bytes = 0; long long pool_jobs = 0;     // SRW_TIMING
+  void start_pool() {
+    if (!pool.empty()) return;
+    const int nt = (int)std::max(2u, std::min(16u, hw / 2));
+    for (int t = 0; t < nt; ++t)
+      pool.emplace_back([this] {
+        for (;;) {
+          Job j;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_job.wait(lk, [&] { return stop || !jobs.empty(); });
+            if (jobs.empty()) return;
+            j = std::move(jobs.front()); jobs.pop_front();
+          }
+          std::string err;
+          const auto tj0 = std::chrono::steady_clock::now();
+          try { std::lock_guard<std::mutex> one(j.f->one_writer); pwrite_all(j.f->fd, j.src, j.bytes, j.off, j.fn); } catch (const Error &er) { err = er.what(); }
+          j.f.reset();
+          const double tj = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count();
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err.empty() && pool_error.empty()) pool_error = err;
+            --pending[j.token]; --pending_all;
+            pool_job_ms += tj; pool_bytes += j.bytes; ++pool_jobs;
+          }
+          cv_done.notify_all();
+        }
+      });
+  }
+  void stop_pool() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_job.notify_all();
+    for (auto &t : pool) t.join();
+    pool.clear();
+  }
+  void enqueue(const char *src, size_t bytes, off_t off, int token, const std::string &fn) {
+    start_pool();
+    { std::lock_guard<std::mutex> lk(mu); jobs.push_back(Job{part, src, bytes, off, token, fn}); ++pending[token]; ++pending_all; }
+    cv_job.notify_one();
+  }
+  void wait_token(int token) {            // every byte handed over with this token is written (or failed: throws)
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return (token < 0 ? pending_all : pending[token]) == 0; });
+    if (!pool_error.empty()) throw Error(SRW_ERR_IO, pool_error);
+  }
   std::string crc_tail;                      // bytes of the current part not yet covered by a full 512-byte chunk
   std::vector<uint32_t> crcs;
   unsigned hw = 1;
@@ -115,6 +182,7 @@ struct PathWriter::Impl {
     std::string fn = dir + "/" + part_name(p);
     fd = ::open(fn.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) throw Error(SRW_ERR_IO, "cannot write " + fn);
+    part = std::make_shared<PartFd>(); part->fd = fd;
     cur_part = p; file_off = 0; crc_tail.clear(); crcs.clear();
   }
   void crc_feed(const char *p, size_t n) {
@@ -130,7 +198,8 @@ struct PathWriter::Impl {
   }
   void close_part() {
     if (fd < 0) return;
-    ::close(fd); fd = -1;
+    if (part) part->final_size = file_off;
+    part.reset(); fd = -1;                     // (closed now, or by the pool after the part's last queued write)
     if (write_crc) {
       if (!crc_tail.empty()) crcs.push_back(crc32_ieee((const unsigned char *)crc_tail.data(), crc_tail.size()));
       std::string fn = dir + "/." + part_name(cur_part) + ".crc";
@@ -198,7 +267,7 @@ PathWriter::PathWriter(const char *output_dir, int n_parts, int64_t total_walker
     throw Error(SRW_ERR_IO, "cannot create " + d + ": " + strerror(errno));
   }
 }
-PathWriter::~PathWriter() { if (p_) { if (p_->fd >= 0) ::close(p_->fd); delete p_; } }
+PathWriter::~PathWriter() { if (p_) { p_->stop_pool(); p_->part.reset(); delete p_; } }
 
 void PathWriter::append(const int32_t *paths, const int32_t *lens, int64_t n, int64_t stride) {
   int64_t done = 0;
@@ -214,7 +283,9 @@ void PathWriter::append(const int32_t *paths, const int32_t *lens, int64_t n, in
 }
 
 // Lines formatted on the device: split at the part boundaries (by walker count, as append does) and write the bytes.
-void PathWriter::append_text(const char *text, const unsigned long long *off, int64_t n, unsigned long long base) {
+void PathWriter::append_text(const char *text, const unsigned long long *off, int64_t n, unsigned long long base, int token) {
+  if (token >= Impl::MAX_TOKENS) throw Error(SRW_ERR_INVALID, "append_text: token out of range");
+  const bool async = token >= 0 && !p_->write_crc;          // (the .crc side files are computed in file order: synchronous)
   int64_t done = 0;
   while (done < n) {
     const int64_t g = p_->next;
@@ -227,7 +298,20 @@ void PathWriter::append_text(const char *text, const unsigned long long *off, in
     auto t0 = std::chrono::steady_clock::now();
     // measured on the GPU box (3.3 GB into the page cache): reserving the extent first and writing 64 MB per thread
     // (one or two threads per slice) takes ~295 ms; 2 MB per thread ~345 ms, 1 MB per thread ~585 ms (contention)
-    (void)posix_fallocate(p_->fd, p_->file_off, (off_t)bytes);
+    if (!async) (void)posix_fallocate(p_->fd, p_->file_off, (off_t)bytes);      // (async: the reservation would queue behind the part's writers on the inode)
+    if (async) {                                                  // one job per piece of a part
+      // the part's extent is reserved ONCE, before its first writer exists (a reservation per piece would queue behind the writers on
+      // the inode): what this piece's bytes per walker make of the walkers the part still gets, beyond the end of file, returned on close
+      if (p_->part && p_->part->reserved == 0 && take > 0) {
+        const off_t est = (off_t)((double)bytes / (double)take * (double)std::max<int64_t>(part_end - g, take) * 1.02) + 4096;
+        if (fallocate(p_->fd, FALLOC_FL_KEEP_SIZE, p_->file_off, est) == 0) p_->part->reserved = p_->file_off + est; else p_->part->reserved = -1;
+      }
+      p_->enqueue(src, bytes, p_->file_off, token, p_->dir + "/" + p_->part_name(p_->cur_part));
+      p_->file_off += (off_t)bytes;
+      p_->t_write += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      done += take; p_->next += take;
+      continue;
+    }
     const int nt = (int)std::max<size_t>(1, std::min<size_t>(p_->hw, bytes / ((size_t)64 << 20) + 1));
     std::vector<std::string> errs((size_t)nt);
     const std::string fn = p_->dir + "/" + p_->part_name(p_->cur_part);
@@ -250,10 +334,16 @@ void PathWriter::append_text(const char *text, const unsigned long long *off, in
   }
 }
 
+void PathWriter::wait_token(int token) { p_->wait_token(token); }
+bool PathWriter::token_idle(int token) { std::lock_guard<std::mutex> lk(p_->mu); return p_->pending[token] == 0; }
+
 void PathWriter::close() {
+  p_->wait_token(-1);                                          // everything queued is on its way to the disk; a failed write throws here
+  p_->stop_pool();
   if (p_->cur_part < 0 && p_->n_parts > 0) p_->open_part(0);   // zero paths: still an (empty) part-00000
   if (getenv("SRW_TIMING"))
-    fprintf(stderr, "[timing] writer: format %.1f ms, pwrite %.1f ms\n", p_->t_format, p_->t_write);
+    fprintf(stderr, "[timing] writer: format %.1f ms, pwrite %.1f ms; pool: %lld jobs, %.1f GB, %.0f thread-ms in pwrite (%.1f GB/s per thread)\n", p_->t_format,
+            p_->t_write, p_->pool_jobs, (double)p_->pool_bytes / 1e9, p_->pool_job_ms, p_->pool_job_ms > 0 ? (double)p_->pool_bytes / 1e6 / p_->pool_job_ms : 0.0);
   // parts that received no walker still exist as empty files, as with repartition(n)
   for (int part = p_->cur_part + 1; part < p_->n_parts; ++part) p_->open_part(part);
   p_->close_part();

@@ -666,6 +666,38 @@ def test_walk_and_save_streamed(eng, oracle, tmp_path, n_parts, num_walks):
             assert (tmp_path / "gpu_fmt" / "path" / name).read_bytes() == (tmp_path / "gpu" / "path" / name).read_bytes()
 
 
+@pytest.mark.parametrize("slice_kb,n_parts,crc", [(1, 5, False), (2, 1, False), (1, 37, False), (1, 4, True), (0, 200, False)])
+def test_text_leaves_the_device_through_the_ring(eng, oracle, tmp_path, monkeypatch, slice_kb, n_parts, crc):
+    """The formatted text goes device -> ring of pinned slices -> the writer's thread pool (part files written in parallel; with .crc
+    files synchronously).  Small slices (SRW_TEXT_SLICE_KB, tests only) take a small graph around the ring dozens of times, with part
+    boundaries inside slices and slices inside parts: the files are the oracle writer's, byte for byte — both entry points
+    (srw_walk_and_save's streamed form and srw_write_paths on a resident result)."""
+    if slice_kb:
+        monkeypatch.setenv("SRW_TEXT_SLICE_KB", str(slice_kb))
+    s, d = oracle.rmat_edges(10, 8 << 10, seed=3)
+    g = oracle.Graph.from_coo(s, d, None, directed=False)
+    eng.load_coo(s, d, None, directed=False)
+    kw = dict(walk_length=30, num_walks=3, seed=6, p=0.5, q=2.0)
+    rp, rl, _ = g.walk(threads=8, **kw)
+    assert oracle.write_paths(rp, rl, str(tmp_path / "ref"), n_parts) == 0
+    eng.walk_and_save(str(tmp_path / "a"), n_parts=n_parts, write_crc=crc, device_format=True, **kw)
+    eng.walk(fetch=False, **kw)
+    eng.write_paths(str(tmp_path / "b"), n_parts=n_parts, write_crc=crc)
+    total = 0
+    for k in range(n_parts):
+        name = "part-%05d" % k
+        want = (tmp_path / "ref" / "path" / name).read_bytes()
+        total += len(want)
+        for out in ("a", "b"):
+            assert (tmp_path / out / "path" / name).read_bytes() == want, (out, name)
+            if crc:
+                import zlib
+                c = (tmp_path / out / "path" / ("." + name + ".crc")).read_bytes()
+                assert c[8:] == b"".join(zlib.crc32(want[o:o + 512]).to_bytes(4, "big") for o in range(0, len(want), 512))
+    assert total > 200_000 and (tmp_path / "a" / "path" / "_SUCCESS").exists() and (tmp_path / "b" / "path" / "_SUCCESS").exists()
+    assert len(list((tmp_path / "a" / "path").glob("part-*"))) == n_parts
+
+
 def test_device_formatter_negative_ids_and_long_paths(eng, oracle, tmp_path):
     # negative ids (sign character), walkLength + 2 > 64 (two lane rounds per line), several iterations, odd part counts
     rng = np.random.default_rng(12)

@@ -155,8 +155,17 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool w
   int fd = open(path, O_RDONLY);
   if (fd < 0) return false;                                           // the host path reports the error
   struct stat sb;
-  if (fstat(fd, &sb) != 0 || sb.st_size <= 0 || (uint64_t)sb.st_size > ((uint64_t)8 << 30)) { close(fd); return false; }
+  if (fstat(fd, &sb) != 0 || sb.st_size <= 0) { close(fd); return false; }
   const int64_t size = (int64_t)sb.st_size;
+  {   // the text, the newline positions (8 B per line) and the parsed columns (8-12 B per line) are in HBM together: ~2.2x the file at
+      // 17 bytes per line — the 1 B-edge graph's 19 GB file fits many times over (rounds 1-4 stopped at 8 GB and sent it to the host
+      // tokenizer); a file that does not fit next to a reserve goes to the host tokenizer, which streams it.  SRW_DEVICE_TOKENIZER_MAX_MB: tests.
+    size_t free_b = 0, total_b = 0;
+    SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+    uint64_t cap = free_b > ((size_t)16 << 30) ? (uint64_t)((free_b - ((size_t)16 << 30)) / 3) : 0;
+    if (const char *e = getenv("SRW_DEVICE_TOKENIZER_MAX_MB"); e && *e) cap = (uint64_t)atoll(e) << 20;
+    if ((uint64_t)size > cap) { close(fd); return false; }
+  }
   const unsigned char *data = (const unsigned char *)mmap(nullptr, (size_t)size, PROT_READ, MAP_PRIVATE, fd, 0);
   close(fd);
   if (data == MAP_FAILED) return false;

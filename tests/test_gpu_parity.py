@@ -1119,6 +1119,12 @@ def test_device_tokenizer_equals_host_tokenizer(eng, oracle, tmp_path, monkeypat
         monkeypatch.delenv("SRW_HOST_TOKENIZER", raising=False)
         eng.load_edgelist(str(f), directed=False)
         assert eng.stats() == (g.num_vertices, g.num_entries), name
+        # a file larger than what the device tokenizer may take next to its reserve (a third of the free HBM; here: the test's cap of
+        # 0 MB) goes to the host tokenizer by itself
+        monkeypatch.setenv("SRW_DEVICE_TOKENIZER_MAX_MB", "0")
+        eng.load_edgelist(str(f), directed=False)
+        assert eng.stats() == (g.num_vertices, g.num_entries), name
+        monkeypatch.delenv("SRW_DEVICE_TOKENIZER_MAX_MB", raising=False)
     # weighted files with short decimal weights are tokenized on the device too: bitwise the same weights as strtof
     wrng = np.random.default_rng(21)
     def wtoken(i):

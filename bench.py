@@ -459,8 +459,8 @@ def compact_line(out):
         c["setup_s"] = {k: v for k, v in out["setup_s"].items() if not isinstance(v, str)}
     if "end_to_end" in out:
         c["end_to_end"] = {k: v for k, v in out["end_to_end"].items() if k in ("seconds", "walk_steps_per_s", "text_GB_per_s", "part_files", "skipped", "error")}
-        if isinstance(out["end_to_end"].get("single_part"), dict):
-            c["end_to_end"]["single_part_walk_steps_per_s"] = out["end_to_end"]["single_part"].get("walk_steps_per_s")
+        if isinstance(out["end_to_end"].get("parts_200"), dict):
+            c["end_to_end"]["parts_200_walk_steps_per_s"] = out["end_to_end"]["parts_200"].get("walk_steps_per_s")
         if isinstance(out["end_to_end"].get("first_call"), dict):
             c["end_to_end"]["first_call_seconds"] = out["end_to_end"]["first_call"].get("seconds")
     if "cpu_baseline" in out:
@@ -715,10 +715,10 @@ def main():
             }
         # ---- end to end: the reference's contract is path FILES --------------------------------------------------------
         if rank == 0 and world == 1 and args.end_to_end:
-            e2e = {"what": "srw_walk_and_save, 1 walk iteration: walk kernel + device-side formatter + PCIe + <output>/path/part-00000 .. "
-                           "part-00199 on local disk (rddPartitions = 200, the reference's default: Params.scala:20; part files are "
-                           "written in parallel); `first_call`: the same with the text path's one-off allocations; `single_part`: into ONE file "
-                           "(bound by one inode's buffered writes)"}
+            e2e = {"what": "srw_walk_and_save, 1 walk iteration: walk kernel + device-side formatter + PCIe + <output>/path/part-00000 on local "
+                           "disk — ONE part file, the reference's default (singleOutput = true: Params.scala:21, Main.scala:64-69; bound by one "
+                           "inode's buffered writes); `parts_200`: the same with --singleOutput false (rddPartitions = 200 part files, written in "
+                           "parallel); `first_call`: the single-file form with the text path's one-off allocations"}
             tmp_root = os.environ.get("TMPDIR", "/tmp")
             need = nv * (args.walk_length + 2) * 8          # generous bound on the text size
             try:
@@ -727,7 +727,7 @@ def main():
                     e2e["skipped"] = "needs ~%.0f GB under %s, %.0f GB free" % (need / 1e9, tmp_root, free / 1e9)
                 else:
                     # first call: with the one-off allocations of the text path (staging + text slots in HBM, pinned ring); second: without
-                    for key, parts in (("first_call", 200), ("", 200), ("single_part", 1)):
+                    for key, parts in (("first_call", 1), ("", 1), ("parts_200", 200)):
                         d = tempfile.mkdtemp(prefix="srw_bench_", dir=tmp_root)
                         try:
                             t0 = time.perf_counter()

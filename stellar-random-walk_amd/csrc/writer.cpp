@@ -117,8 +117,8 @@ struct PathWriter::Impl {
   std::shared_ptr<PartFd> part;
   int fd = -1; int cur_part = -1; off_t file_off = 0;
   // ---- the pool behind append_text(..., token >= 0): part files are written in PARALLEL (one inode takes ~12 GB/s of buffered
-  // writes on the GPU box whatever the number of threads, 8 files 74 GB/s: tools/microbench_filewrite.cpp; the reference's default
-  // is 200 parts, Params.scala:20) while the caller copies the next slices out of the device
+  // writes on the GPU box whatever the number of threads, 8 files 74 GB/s: tools/microbench_filewrite.cpp; --singleOutput false
+  // writes rddPartitions = 200 of them, Params.scala:20-21) while the caller copies the next slices out of the device
   struct Job { std::shared_ptr<PartFd> f; const char *src; size_t bytes; off_t off; int token; std::string fn; };
   static constexpr int MAX_TOKENS = 16;
   std::vector<std::thread> pool;

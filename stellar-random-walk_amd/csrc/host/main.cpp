@@ -64,9 +64,14 @@ static void doNode2vec(const Params &param) {   // Main.scala:113-117: doRandomW
   rw->saveFromDevice(getNumOutputPartition(param), param.output);
   const srw_w2v_params wp = w2vParams(param);
   int32_t *vocab = nullptr; float *vec = nullptr; int64_t nv = 0;
+  const auto t0 = std::chrono::steady_clock::now();
   if (srw_w2v_fit_device(rw->handle(), nullptr, nullptr, 0, 1, &wp, &vocab, &vec, &nv) != SRW_OK)
     throw std::runtime_error(std::string("word2vec: ") + srw_last_error(rw->handle()));
+  const auto t1 = std::chrono::steady_clock::now();
   const int32_t rc = srw_w2v_save(vocab, vec, nv, wp.dim, param.output.c_str(), getNumOutputPartition(param));
+  if (getenv("SRW_TIMING"))
+    std::cerr << "[timing] Word2Vec fit (vocabulary + " << wp.iterations << " iterations, paths in HBM): " << std::chrono::duration<double, std::milli>(t1 - t0).count()
+              << " ms; model + vectors saved: " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() << " ms\n";
   srw_free(vocab); srw_free(vec);
   throwSave(rc);
 }

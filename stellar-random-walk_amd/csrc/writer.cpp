@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <charconv>
 #include <chrono>
 #include <algorithm>
 #include <cerrno>
@@ -367,41 +368,40 @@ void write_path_files(const int32_t *paths, const int32_t *lens, int64_t n_walke
 namespace srw {
 // java.lang.Float.toString: the shortest decimal that round-trips to the same float (the JDK's algorithm prints one digit more in
 // rare cases: not reproduced), as d.ddd for 1e-3 <= |x| < 1e7 and as d.dddE[-]n otherwise; "NaN", "Infinity", "-Infinity", "0.0", "-0.0".
-std::string java_float_to_string(float x) {
-  if (x != x) return "NaN";
-  if (x == 0.0f) return std::signbit(x) ? "-0.0" : "0.0";
-  if (std::isinf(x)) return x > 0 ? "Infinity" : "-Infinity";
-  char buf[64];
-  int prec = 1;
-  for (; prec <= 9; ++prec) {
-    snprintf(buf, sizeof(buf), "%.*e", prec - 1, (double)x);
-    if (strtof(buf, nullptr) == x) break;
-  }
-  // buf = [-]d[.ddd]e[+-]XX
-  std::string s(buf);
-  const bool neg = s[0] == '-';
-  if (neg) s.erase(0, 1);
-  const size_t epos = s.find('e');
-  std::string digits = s.substr(0, epos);
-  const int exp10 = atoi(s.c_str() + epos + 1);
-  digits.erase(std::remove(digits.begin(), digits.end(), '.'), digits.end());
-  while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
-  std::string out;
+// (the digits: std::to_chars' shortest round-trip form — the same digits as the smallest %.{k}e that reads back as x, which is what this
+//  function searched for with snprintf + strtof until round 5, at ~1 us per float: 134 M floats of a config-2 model took minutes)
+void java_float_append(std::string &out, float x) {
+  if (x != x) { out += "NaN"; return; }
+  if (x == 0.0f) { out += std::signbit(x) ? "-0.0" : "0.0"; return; }
+  if (std::isinf(x)) { out += x > 0 ? "Infinity" : "-Infinity"; return; }
+  char buf[48];
+  const auto res = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::scientific);     // [-]d[.ddd]e[+-]XX
+  const char *p = buf, *end = res.ptr;
+  if (*p == '-') { out.push_back('-'); ++p; }
+  char digits[16]; int nd = 0;
+  while (p < end && *p != 'e') { if (*p != '.') digits[nd++] = *p; ++p; }
+  ++p;                                                                                           // 'e'
+  int exp10 = 0; { bool eneg = false; if (*p == '-') { eneg = true; ++p; } else if (*p == '+') ++p; while (p < end) exp10 = exp10 * 10 + (*p++ - '0'); if (eneg) exp10 = -exp10; }
+  while (nd > 1 && digits[nd - 1] == '0') --nd;
   const float ax = std::fabs(x);
   if (ax >= 1e-3f && ax < 1e7f) {
     if (exp10 >= 0) {
-      std::string ip = digits.substr(0, std::min<size_t>(digits.size(), (size_t)exp10 + 1));
-      while ((int)ip.size() < exp10 + 1) ip.push_back('0');
-      std::string fp = digits.size() > (size_t)exp10 + 1 ? digits.substr((size_t)exp10 + 1) : "0";
-      out = ip + "." + fp;
+      for (int i = 0; i <= exp10; ++i) out.push_back(i < nd ? digits[i] : '0');
+      out.push_back('.');
+      if (nd > exp10 + 1) out.append(digits + exp10 + 1, (size_t)(nd - exp10 - 1)); else out.push_back('0');
     } else {
-      out = "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
+      out += "0.";
+      out.append((size_t)(-exp10 - 1), '0');
+      out.append(digits, (size_t)nd);
     }
   } else {
-    out = digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E" + std::to_string(exp10);
+    out.push_back(digits[0]); out.push_back('.');
+    if (nd > 1) out.append(digits + 1, (size_t)(nd - 1)); else out.push_back('0');
+    out.push_back('E');
+    out += std::to_string(exp10);
   }
-  return neg ? "-" + out : out;
 }
+std::string java_float_to_string(float x) { std::string s; java_float_append(s, x); return s; }
 
 // saveModelAndFeatures (M/Main.scala:36-44): model.save(<out>/bin) FIRST (Spark fails there if the directory exists), then the
 // "<word>\t<v0>\t..." lines under <out>/vec.  Nothing is overwritten: either directory existing is FileAlreadyExists before a byte
@@ -432,12 +432,33 @@ void write_vectors_named(const std::function<void(std::string &, int64_t)> &put_
     void close() { flush(); FILE *g = f; f = nullptr; if (fclose(g) != 0) throw Error(SRW_ERR_IO, "write error on " + fn); }
     ~Sink() { if (f) fclose(f); }
   };
+  // the rows of a part, formatted by all host threads in batches (a batch's pieces are written in row order; at most a batch of text is
+  // in memory), then through the part's buffer
+  const int nt = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   auto rows = [&](Sink &sk, int64_t r0, int64_t r1) {
-    for (int64_t r = r0; r < r1; ++r) {
-      put_name(sk.buf, r);
-      for (int32_t j = 0; j < dim; ++j) { sk.buf.push_back('\t'); sk.buf += java_float_to_string(vectors[r * dim + j]); }
-      sk.buf.push_back('\n');
-      if (sk.buf.size() >= ((size_t)1 << 20) - 4096) sk.flush();
+    const int64_t per_thread = 1024;
+    std::vector<std::string> piece((size_t)nt);
+    for (int64_t b0 = r0; b0 < r1; b0 += per_thread * nt) {
+      const int64_t b1 = std::min<int64_t>(r1, b0 + per_thread * nt);
+      const int used = (int)((b1 - b0 + per_thread - 1) / per_thread);
+      auto work = [&](int t) {
+        std::string &o = piece[(size_t)t]; o.clear();
+        for (int64_t r = b0 + t * per_thread; r < std::min<int64_t>(b1, b0 + (t + 1) * per_thread); ++r) {
+          put_name(o, r);
+          for (int32_t j = 0; j < dim; ++j) { o.push_back('\t'); java_float_append(o, vectors[r * dim + j]); }
+          o.push_back('\n');
+        }
+      };
+      if (used == 1) work(0);
+      else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < used; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+      }
+      for (int t = 0; t < used; ++t) {
+        sk.flush();
+        if (fwrite(piece[(size_t)t].data(), 1, piece[(size_t)t].size(), sk.f) != piece[(size_t)t].size()) throw Error(SRW_ERR_IO, "write error on " + sk.fn);
+      }
     }
   };
   auto file = [&](const std::string &fn, const std::string &text) {

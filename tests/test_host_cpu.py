@@ -424,6 +424,32 @@ def test_vector_files_and_java_float_strings(tmp_path):
     assert '"vectorSize":5' in meta and '"numWords":3' in meta and "Word2VecModel" in meta
     with pytest.raises(P.SrwError):
         P.w2v_save(np.array([1], dtype=np.int32), vals[:1], out)          # <output>/vec exists
+    # every binade, both notations, subnormals: each string reads back as the same float and carries the SHORTEST digits that do
+    # (numpy's unique mode = the same criterion); 70 000 rows are several batches of the writer's threads, lines in row order
+    rng = np.random.default_rng(3)
+    n, dim = 70000, 3
+    bits = rng.integers(0, 2 ** 32, size=n * dim, dtype=np.uint64).astype(np.uint32)
+    big = bits.view(np.float32).copy()
+    big[~np.isfinite(big)] = np.float32(1.5)
+    big[:6] = np.array([1e-45, 1.17549435e-38, 9.999999e-4, 1e-3, 9999999.0, 1e7], dtype=np.float32)
+    big = big.reshape(n, dim)
+    out2 = str(tmp_path / "o2")
+    P.w2v_save(np.arange(n, dtype=np.int32), big, out2, n_parts=3)
+    rows = []
+    for k in range(3):
+        rows += open(os.path.join(out2, "vec", "part-%05d" % k)).read().splitlines()
+    assert len(rows) == n
+    for r in range(0, n, 7):
+        f = rows[r].split("\t")
+        assert f[0] == str(r)
+        for j in range(dim):
+            x = big[r, j]
+            assert np.float32(f[1 + j]) == x and (np.signbit(np.float32(f[1 + j])) == np.signbit(x)), (f[1 + j], x)
+            want = np.format_float_scientific(x, unique=True, trim="-").replace("-", "").replace("+", "").split("e")[0].replace(".", "").rstrip("0") or "0"
+            got = f[1 + j].replace("-", "").split("E")[0].replace(".", "").strip("0") or "0"
+            assert got == want.lstrip("0"), (f[1 + j], want, x)
+            ax = abs(float(x))
+            assert ("E" in f[1 + j]) == (not (1e-3 <= ax < 1e7) and ax != 0.0), (f[1 + j], x)
 
 
 def test_model_directory_is_spark_parquet(tmp_path, monkeypatch):

@@ -5,9 +5,13 @@
 // holds "id\tv0\t..." lines as Main.saveModelAndFeatures writes them, <output>/bin the model directory (metadata JSON + Parquet data, as Word2VecModel.save).
 // `--cmd embedding --input X`: X is a file or a directory of part files (context.textFile), its tokens are words (any string).
 #include <dirent.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <climits>
@@ -17,6 +21,9 @@
 #include <iostream>
 #include <memory>
 #include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "command_parser.h"
 #include "random_walk.h"
@@ -115,10 +122,137 @@ static std::vector<std::string> inputFiles(const std::string &path) {
   return files;
 }
 
+// Fast path of doEmbedding for what the randomwalk stage writes — lines of canonical int32 tokens: the files are mapped, cut into pieces
+// at line ends and parsed by all host threads straight into ids (the general path below keeps every token as a std::string: 849 M of
+// them for config 2's <output>/path).  Anything else — a token that is not a canonical int32 (as std::to_string prints it), a line that
+// starts with white space (split's empty first token), an empty line (one empty token) — returns false and the general path decides.
+static bool parseNumericFast(const std::vector<std::string> &files, std::vector<int32_t> &ids, std::vector<int32_t> &lens, size_t &stride) {
+  struct Map { const char *p = nullptr; size_t n = 0; };
+  std::vector<Map> maps(files.size());
+  struct Unmap { std::vector<Map> &m; ~Unmap() { for (auto &x : m) if (x.p && x.n) munmap((void *)x.p, x.n); } } unmap{maps};
+  struct Piece { size_t file; size_t b, e; std::vector<int32_t> toks, lens; bool ok = true; };
+  std::vector<Piece> pieces;
+  for (size_t f = 0; f < files.size(); ++f) {
+    const int fd = open(files[f].c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); return false; }
+    if (sb.st_size > 0) {
+      void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m == MAP_FAILED) { close(fd); return false; }
+      maps[f].p = (const char *)m; maps[f].n = (size_t)sb.st_size;
+    }
+    close(fd);
+    const size_t target = (size_t)32 << 20;
+    size_t b = 0;
+    while (b < maps[f].n) {
+      size_t e = std::min(maps[f].n, b + target);
+      while (e < maps[f].n && maps[f].p[e - 1] != '\n') ++e;           // (to the end of the line the cut falls into)
+      Piece pc; pc.file = f; pc.b = b; pc.e = e;
+      pieces.push_back(std::move(pc));
+      b = e;
+    }
+  }
+  auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\v' || c == '\f' || c == '\r'; };
+  std::atomic<size_t> next{0};
+  std::atomic<bool> bad{false};
+  auto work = [&] {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= pieces.size() || bad.load(std::memory_order_relaxed)) return;
+      Piece &pc = pieces[i];
+      const char *p = maps[pc.file].p + pc.b, *end = maps[pc.file].p + pc.e;
+      while (p < end) {
+        const char *le = (const char *)memchr(p, '\n', (size_t)(end - p));
+        if (!le) le = end;
+        if (p == le || ws(*p)) { pc.ok = false; bad = true; return; }      // an empty line / a leading blank: an empty token
+        int32_t n_in_row = 0;
+        const char *q = p;
+        while (q < le) {
+          bool neg = false;
+          if (*q == '-') { neg = true; ++q; }
+          const char *d0 = q;
+          long long v = 0;
+          while (q < le && *q >= '0' && *q <= '9' && q - d0 < 11) v = v * 10 + (*q++ - '0');
+          const long nd = (long)(q - d0);
+          if (nd == 0 || (q < le && !ws(*q)) || (nd > 1 && *d0 == '0') || (neg && v == 0) || (neg ? -v < (long long)INT32_MIN : v > (long long)INT32_MAX)) { pc.ok = false; bad = true; return; }
+          if (n_in_row == 1000) { pc.lens.push_back(n_in_row); n_in_row = 0; }       // MLlib's maxSentenceLength
+          pc.toks.push_back((int32_t)(neg ? -v : v)); ++n_in_row;
+          while (q < le && ws(*q)) ++q;
+        }
+        pc.lens.push_back(n_in_row);
+        p = le < end ? le + 1 : end;
+      }
+    }
+  };
+  {
+    const unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)std::max<size_t>(pieces.size(), 1)));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(work);
+    for (auto &x : th) x.join();
+  }
+  if (bad) return false;
+  size_t n_rows = 0;
+  stride = 1;
+  for (const auto &pc : pieces) { n_rows += pc.lens.size(); for (int32_t l : pc.lens) stride = std::max(stride, (size_t)l); }
+  ids.assign(n_rows * stride, -1); lens.resize(n_rows);
+  std::vector<size_t> row0(pieces.size() + 1, 0);
+  for (size_t i = 0; i < pieces.size(); ++i) row0[i + 1] = row0[i] + pieces[i].lens.size();
+  std::atomic<size_t> nx{0};
+  auto fill = [&] {
+    for (;;) {
+      const size_t i = nx.fetch_add(1);
+      if (i >= pieces.size()) return;
+      const Piece &pc = pieces[i];
+      size_t t = 0;
+      for (size_t r = 0; r < pc.lens.size(); ++r) {
+        lens[row0[i] + r] = pc.lens[r];
+        memcpy(ids.data() + (row0[i] + r) * stride, pc.toks.data() + t, (size_t)pc.lens[r] * 4);
+        t += (size_t)pc.lens[r];
+      }
+    }
+  };
+  {
+    const unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)std::max<size_t>(pieces.size(), 1)));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(fill);
+    for (auto &x : th) x.join();
+  }
+  return n_rows > 0;
+}
+
+static void fitAndSaveIds(const Params &param, const std::vector<int32_t> &ids, const std::vector<int32_t> &lens, size_t stride) {
+  srw_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = param.device; cfg.rank = 0; cfg.world = 1;
+  srw_handle *h = nullptr;
+  if (srw_create(&cfg, &h) != SRW_OK) throw std::runtime_error(std::string("srw_create: ") + srw_last_error(nullptr));
+  int32_t *vocab = nullptr; float *vec = nullptr; int64_t nv = 0;
+  const srw_w2v_params wp = w2vParams(param);
+  if (srw_w2v_fit(h, ids.data(), lens.data(), (int64_t)lens.size(), (int64_t)stride, &wp, &vocab, &vec, &nv) != SRW_OK) {
+    const std::string msg = std::string("word2vec: ") + srw_last_error(h);
+    srw_destroy(h);
+    throw std::runtime_error(msg);
+  }
+  srw_destroy(h);
+  const int32_t rc = srw_w2v_save(vocab, vec, nv, wp.dim, param.output.c_str(), getNumOutputPartition(param));
+  srw_free(vocab); srw_free(vec);
+  throwSave(rc);
+}
+
 static void doEmbedding(const Params &param) {  // Main.scala:119-124: textFile(input).map(_.split("\\s+")) -> Word2Vec
+  const std::vector<std::string> files = inputFiles(param.input);
+  {
+    std::vector<int32_t> fids, flens; size_t fstride = 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!getenv("SRW_EMBEDDING_GENERAL_PARSER") && parseNumericFast(files, fids, flens, fstride)) {      // (the switch: tests compare the two parsers)
+      if (getenv("SRW_TIMING")) std::cerr << "[timing] embedding input: " << flens.size() << " sentences of canonical ids parsed by the host threads in "
+                                          << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() << " ms\n";
+      fitAndSaveIds(param, fids, flens, fstride);
+      return;
+    }
+  }
   std::vector<std::vector<std::string>> rows;
   std::vector<std::string> toks;
-  for (const std::string &fn : inputFiles(param.input)) {
+  for (const std::string &fn : files) {
     std::ifstream in(fn);
     if (!in) throw std::runtime_error("Input path does not exist: " + fn);
     std::string line;

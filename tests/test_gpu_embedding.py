@@ -219,3 +219,30 @@ def test_cli_embedding_cuts_sentences_at_1000_words(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(open(os.path.join(str(tmp_path / name), "vec", "part-00000")).read())
     assert outs[0] == outs[1] and len(outs[0].splitlines()) == 50
+
+
+def test_cli_embedding_fast_id_parser_equals_the_general_one(tmp_path):
+    """`--cmd embedding` over canonical int32 tokens (what the randomwalk stage writes) is parsed by all host threads straight into ids;
+    anything else goes through the general string path.  Same sentences either way: CR LF line ends, TABs and runs of blanks, trailing
+    blanks, negative ids, a line of 2 300 ids (three sentences), several files, a last line without a newline — byte-identical models
+    in the deterministic mode; and a file with ONE non-canonical token ("+5") is words in both."""
+    rng = np.random.default_rng(5)
+    d = tmp_path / "in"; d.mkdir()
+    def line(n, sep):
+        return sep.join(str(int(x)) for x in rng.integers(-40, 60, n))
+    (d / "part-00000").write_text("\n".join(line(int(rng.integers(1, 30)), " ") for _ in range(300)) + "\n")
+    (d / "part-00001").write_text("\r\n".join(line(int(rng.integers(1, 30)), "\t") + "  " for _ in range(200)) + "\r\n")
+    (d / "part-00002").write_text(line(2300, "  \t") + "\n" + line(7, " "))
+    (d / "_SUCCESS").write_text("")
+    outs = []
+    for tag, env in (("fast", {}), ("general", {"SRW_EMBEDDING_GENERAL_PARSER": "1"})):
+        r = _cli("--cmd", "embedding", "--input", str(d), "--output", str(tmp_path / tag), "--dim", "8", "--iter", "2", "--window", "3",
+                 env=dict(env, SRW_W2V_DETERMINISTIC="1", SRW_TIMING="1"))
+        assert r.returncode == 0, r.stderr
+        assert ("parsed by the host threads" in r.stderr) == (tag == "fast")
+        outs.append(open(os.path.join(str(tmp_path / tag), "vec", "part-00000")).read())
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == 100
+    (d / "part-00003").write_text("1 2 +5\n")
+    r = _cli("--cmd", "embedding", "--input", str(d), "--output", str(tmp_path / "words"), "--dim", "8", "--iter", "1", env={"SRW_TIMING": "1"})
+    assert r.returncode == 0 and "parsed by the host threads" not in r.stderr
+    assert any(l.startswith("+5\t") for l in open(os.path.join(str(tmp_path / "words"), "vec", "part-00000")).read().splitlines())

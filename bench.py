@@ -769,6 +769,11 @@ def main():
                         "--p", repr(p), "--q", repr(q), "--weighted", str(int(weighted)), "--directed", str(int(directed))]
 
             def child(cmd, timeout):
+                # every leg lives inside --time-budget as well (an N > 1 run must not lose its line to a slow leg): its limit is what is left
+                left = args.time_budget - (time.perf_counter() - T_START)
+                if left < 45:
+                    return {"error": "skipped: %.0f s time budget spent" % args.time_budget}
+                timeout = min(timeout, left)
                 try:
                     t0 = time.perf_counter()
                     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)

@@ -161,7 +161,7 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool w
       // 17 bytes per line — the 1 B-edge graph's 19 GB file fits many times over (rounds 1-4 stopped at 8 GB and sent it to the host
       // tokenizer); a file that does not fit next to a reserve goes to the host tokenizer, which streams it.  SRW_DEVICE_TOKENIZER_MAX_MB: tests.
     size_t free_b = 0, total_b = 0;
-    SRW_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (const hipError_t me = hipMemGetInfo(&free_b, &total_b); me != hipSuccess) { close(fd); SRW_HIP(me); }
     uint64_t cap = free_b > ((size_t)16 << 30) ? (uint64_t)((free_b - ((size_t)16 << 30)) / 3) : 0;
     if (const char *e = getenv("SRW_DEVICE_TOKENIZER_MAX_MB"); e && *e) cap = (uint64_t)atoll(e) << 20;
     if ((uint64_t)size > cap) { close(fd); return false; }
@@ -190,6 +190,20 @@ bool load_edgelist_device(srw_handle *h, const char *path, bool directed, bool w
   SRW_HIP(hipMemsetAsync(flags.p, 0, 4, st));
   SRW_HIP(hipMemsetAsync(blk.p + n_blocks, 0, 4, st));
   hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_blocks), dim3(TTPB), 0, st, d_text.p, size, blk.p, flags.p);
+  if (size >= ((int64_t)1 << 32) || getenv("SRW_TOKENIZER_COUNT64")) {      // (the variable: tests take this branch on a small file)
+    // a file this long can hold 2^32 newlines or more: the 32-bit scan below would wrap, the 2^31-line guard would pass on the wrapped
+    // count and k_nl_pos would write past nlpos.  The total in 64 bits first; too many lines -> the host tokenizer (which streams).
+    DevBuf<unsigned long long> tot; tot.alloc(1);
+    auto wide = rocprim::make_transform_iterator(blk.p, [] __device__(uint32_t c) { return (unsigned long long)c; });
+    size_t rb = 0;
+    SRW_HIP(rocprim::reduce(nullptr, rb, wide, tot.p, 0ull, (size_t)n_blocks, rocprim::plus<unsigned long long>(), st));
+    DevBuf<char> rtemp; rtemp.alloc(rb);
+    SRW_HIP(rocprim::reduce((void *)rtemp.p, rb, wide, tot.p, 0ull, (size_t)n_blocks, rocprim::plus<unsigned long long>(), st));
+    unsigned long long n_nl64 = 0;
+    SRW_HIP(hipMemcpyAsync(&n_nl64, tot.p, 8, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    if (n_nl64 >= (1ull << 31) - 1ull) return false;
+  }
   size_t tb = 0;
   SRW_HIP(rocprim::exclusive_scan(nullptr, tb, blk.p, blkoff.p, 0u, (size_t)n_blocks + 1, rocprim::plus<uint32_t>(), st));
   temp.alloc(tb);

@@ -11,7 +11,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -40,11 +42,21 @@ struct VmBuf {
   void release() {
     if (mapper_.joinable()) { stop_.store(true); mapper_.join(); }
     if (vmm_) {
+      // chunk by chunk, as they were mapped: hipMemUnmap works per mapping — one call over a range of several mappings may undo
+      // only the first (up to ~170 GB of HBM and the address range would stay pinned behind a (p, q) change or the NOMEM retry)
       const size_t mapped = mapped_.load();
-      if (mapped) (void)hipMemUnmap((void *)p, mapped);
-      for (auto &h : handles_) (void)hipMemRelease(h);
+      auto complain = [](const char *what, size_t off, hipError_t e) {
+        fprintf(stderr, "[stellar_rw] VmBuf::release: %s at %zu: %s\n", what, off, hipGetErrorString(e));
+        (void)hipGetLastError();
+      };
+      for (size_t off = 0; off < mapped; off += CHUNK) {
+        const size_t sz = std::min(CHUNK, mapped - off);
+        if (hipError_t e = hipMemUnmap((char *)p + off, sz); e != hipSuccess) complain("hipMemUnmap", off, e);
+      }
+      for (size_t i = 0; i < handles_.size(); ++i)
+        if (hipError_t e = hipMemRelease(handles_[i]); e != hipSuccess) complain("hipMemRelease", i * CHUNK, e);
       handles_.clear();
-      if (p) (void)hipMemAddressFree((void *)p, va_bytes_);
+      if (p) { if (hipError_t e = hipMemAddressFree((void *)p, va_bytes_); e != hipSuccess) complain("hipMemAddressFree", 0, e); }
     } else if (p) (void)hipFree(p);
     p = nullptr; n = 0; vmm_ = false; va_bytes_ = 0; mapped_.store(0); failed_.store(false); stop_.store(false); err_.clear();
   }

@@ -21,27 +21,10 @@
 
 #include "engine.h"
 #include "sampling.h"
+#include "walk_records.h"
 
 namespace srw {
 namespace {
-// Records shared by the whole-graph kernels and the vertex-sharded ones (described with the k_sh_* kernels below).
-struct alignas(16) WWalker { int32_t lw, src, prev, curr; };      // on the wire: 16 bytes
-struct alignas(16) SWalker { int32_t lw, src, prev, curr, v, kind, pad0, pad1; };   // pad0: position of the chosen candidate (chain kernels)
-enum : int32_t { SK_WALKER_RET = 1, SK_RET = 2, SK_DEAD = 3 };   // walker + return; return only (last step); death notice only
-constexpr int CHAIN_CAP = 4096;     // draws on a CDF boundary per super-step / per launch that the chain kernels take (more: the general step)
-struct alignas(16) ChainRec { uint32_t ri, pad; double S; };      // record index, (whole-graph walks: the step), the reference's sum of the biased row
-// Whole-graph walks: where k_walk_tables leaves a table step whose draw sits on a CDF boundary — one wire record per tie (lw = the
-// iteration's offset) behind a chunk header, so that the chain kernels of the sharded walk read them like a super-step's input;
-// k_walk_general, which redoes the handed-over walkers, takes the resolved step from the chain kernels' output.
-struct TieSink {
-  uint32_t *hdr;                  // [0] records written (the chunk header the chain kernels read)
-  WWalker *recs;                  // [CHAIN_CAP]
-  ChainRec *list;                 // [CHAIN_CAP]
-  unsigned long long *cur;        // [2] ties met
-  int32_t *todo_tie;              // per todo entry: its record, or -1
-};
-
-constexpr int TPB = 256;
 constexpr int TILE = 16;  // path slots staged in LDS between flushes (64 B per walker per flush)
 
 __device__ inline const Row *row_of(const GraphView &g, int32_t v) {
@@ -322,11 +305,6 @@ __global__ __launch_bounds__(TPB, 4) void k_walk_general(GraphView g, const int3
 #ifndef SRW_TAB_FRESH
 #define SRW_TAB_FRESH 1
 #endif
-struct TabArgs {
-  GraphView g;                     // (first: fresh_graph() reads the same bytes)
-  const int32_t *verts; int64_t n_verts, n_walkers; int32_t L, first_walk; RngSpec rng; float p, q;
-  int32_t *paths, *lens; DevCounters *ctr; unsigned long long *cursor; int32_t *todo; unsigned long long *todo_n; TieSink tie;
-};
 #if SRW_TAB_FRESH
 #define TAB_ARGS() fresh_args<TabArgs>()
 #define GFRESH() fresh_graph()
@@ -2322,7 +2300,11 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
       ta.g = gv; ta.verts = g.verts.p; ta.n_verts = g.n_vertices; ta.n_walkers = n_walkers; ta.L = P.walk_length; ta.first_walk = first_walk;
       ta.rng = rng; ta.p = P.p; ta.q = P.q; ta.paths = d_paths; ta.lens = d_lens; ta.ctr = h->counters.p; ta.cursor = h->walk_cursor.p;
       ta.todo = h->walk_todo.p; ta.todo_n = h->walk_cursor.p + 1; ta.tie = tie;
-      if (gv.bf_off) {
+      // SRW_TABLE_GROUPS=1: one walker per 16 lanes (walk_groups.hip) — measured and not kept as the default, profiles/r06_group_kernel.md
+      const bool groups = getenv("SRW_TABLE_GROUPS") && atoi(getenv("SRW_TABLE_GROUPS")) != 0;
+      if (groups) {
+        launch_walk_tables_groups(ta, gv.bf_off != nullptr, h->n_cus, st);
+      } else if (gv.bf_off) {
         hipLaunchKernelGGL((k_walk_tables<true>), dim3((unsigned)lb), dim3(TPB), 0, st, ta);
       } else {
         hipLaunchKernelGGL((k_walk_tables<false>), dim3((unsigned)lb), dim3(TPB), 0, st, ta);

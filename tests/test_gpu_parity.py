@@ -1125,6 +1125,12 @@ def test_device_tokenizer_equals_host_tokenizer(eng, oracle, tmp_path, monkeypat
         eng.load_edgelist(str(f), directed=False)
         assert eng.stats() == (g.num_vertices, g.num_entries), name
         monkeypatch.delenv("SRW_DEVICE_TOKENIZER_MAX_MB", raising=False)
+        # files of 4 GiB and more count their newlines in 64 bits before the 32-bit scan (a wrapped count would pass the 2^31-line guard);
+        # the switch takes that branch on this small file
+        monkeypatch.setenv("SRW_TOKENIZER_COUNT64", "1")
+        eng.load_edgelist(str(f), directed=False)
+        assert eng.stats() == (g.num_vertices, g.num_entries), name
+        monkeypatch.delenv("SRW_TOKENIZER_COUNT64", raising=False)
     # weighted files with short decimal weights are tokenized on the device too: bitwise the same weights as strtof
     wrng = np.random.default_rng(21)
     def wtoken(i):

@@ -311,3 +311,26 @@ def test_a_refused_mapping_call_falls_back_to_one_allocation(monkeypatch):
     fell_back, err = run({"SRW_EB_VMM_CHUNK_MB": "8", "SRW_EB_VMM_FAIL_AT": "2"})
     assert fell_back == ref and "once more with one allocation" in err and "simulated failure" in err
     assert int(ref.split()[2]) > 0 and int(ref.split()[3]) > 0
+
+
+def test_mapped_table_buffer_gives_its_memory_back():
+    """vm_buf.h: a table buffer mapped in N chunks is unmapped chunk by chunk — after a second (p, q) rebuilt the tables in the
+    same process and after the engine is closed the device's free memory is back where it was, and no unmap / release call complained."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); import torch; torch.cuda.init(); import _pkg; P = _pkg.load(); "
+            "free = lambda: torch.cuda.mem_get_info(0)[0]; f0 = free(); e = P.Engine(0); "
+            "e.generate_rmat(16, 16 << 16, seed=5, weighted=True); f1 = free(); "
+            "st = e.walk(fetch=False, p=0.25, q=4.0, walk_length=12, seed=3); f2 = free(); "
+            "st2 = e.walk(fetch=False, p=4.0, q=0.5, walk_length=12, seed=3); f3 = free(); "
+            "st3 = e.walk(fetch=False, p=0.25, q=4.0, walk_length=12, seed=3); f4 = free(); e.close(); f5 = free(); "
+            "print('RESULT', f0, f1, f2, f3, f4, f5, st['edge_tables'], st2['edge_tables'])" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRW_TIMING="1", SRW_EB_VMM_CHUNK_MB="8"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mapped in chunks" in r.stderr and "VmBuf::release" not in r.stderr, r.stderr[-2000:]
+    f0, f1, f2, f3, f4, f5, t1, t2 = (int(x) for x in [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:])
+    assert t1 > 0 and t2 > 0
+    slack = 64 << 20
+    assert abs(f4 - f2) <= slack, (f2, f3, f4)          # the third build (the first (p, q) again) stands where the first stood: nothing of the second is left
+    assert f5 >= f0 - slack, (f0, f5)                   # everything is back once the engine is closed

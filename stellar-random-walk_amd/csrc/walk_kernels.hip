@@ -2302,7 +2302,11 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
       ta.todo = h->walk_todo.p; ta.todo_n = h->walk_cursor.p + 1; ta.tie = tie;
       // SRW_TABLE_GROUPS=1: one walker per 16 lanes (walk_groups.hip) — measured and not kept as the default, profiles/r06_group_kernel.md
       const bool groups = getenv("SRW_TABLE_GROUPS") && atoi(getenv("SRW_TABLE_GROUPS")) != 0;
-      if (groups) {
+      // SRW_TABLE_LANES=<mode>: one walker per lane (walk_lanes.hip); mode bit 0 mask rows per lane, bit 1 table steps per lane
+      const int lanes = getenv("SRW_TABLE_LANES") ? atoi(getenv("SRW_TABLE_LANES")) : -1;
+      if (lanes >= 0) {
+        launch_walk_tables_lanes(ta, gv.bf_off != nullptr, lanes, h->n_cus, st);
+      } else if (groups) {
         launch_walk_tables_groups(ta, gv.bf_off != nullptr, h->n_cus, st);
       } else if (gv.bf_off) {
         hipLaunchKernelGGL((k_walk_tables<true>), dim3((unsigned)lb), dim3(TPB), 0, st, ta);

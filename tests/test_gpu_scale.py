@@ -334,3 +334,42 @@ def test_mapped_table_buffer_gives_its_memory_back():
     slack = 64 << 20
     assert abs(f4 - f2) <= slack, (f2, f3, f4)          # the third build (the first (p, q) again) stands where the first stood: nothing of the second is left
     assert f5 >= f0 - slack, (f0, f5)                   # everything is back once the engine is closed
+
+
+@pytest.mark.parametrize("kernel", [{"SRW_TABLE_LANES": "3"}, {"SRW_TABLE_LANES": "2"}, {"SRW_TABLE_LANES": "0"}, {"SRW_TABLE_GROUPS": "1"}])
+def test_opt_in_table_kernels_walk_every_walker_like_the_default(oracle, monkeypatch, kernel):
+    """walk_lanes.hip (one walker per lane; modes: rows + tables per lane, tables only, every step served by the wave) and walk_groups.hip
+    (one walker per 16 lanes) are opt-in forms of the table walk (profiles/r06_lane_kernel.md, r06_group_kernel.md): EVERY walker as the
+    default kernel walks it — weighted and unit-weight, undirected and directed, three-level tables, chunk masks off, and with every
+    table step on a long row treated as a boundary draw (the tie list + the chain kernels) — and a sample against the oracle."""
+    rng = np.random.default_rng(77)
+    cases = [("w", False, 14, (0.25, 4.0), {}), ("", False, 14, (4.0, 0.5), {}), ("w", True, 13, (0.5, 2.0), {}),
+             ("w", False, 13, (0.25, 4.0), {"SRW_EB_CM_MAX": "0", "SRW_EB_FINE_CAP": "32768", "SRW_EB_FINE_MIN_DU": "0"}),
+             ("w", False, 13, (0.25, 4.0), {"SRW_DEBUG_CHAIN_DEG": "600"}), ("w", False, 12, (3.0, 0.7), {})]
+    for spec, directed, scale, (p, q), env in cases:
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        with pkg().Engine(device=0) as e:
+            e.generate_rmat(scale, 16 << scale, seed=9, weighted=bool(spec), directed=directed)
+            ref_p, ref_l, st0 = e.walk(p=p, q=q, walk_length=40, num_walks=2, seed=5)
+            assert st0["strategy_steps"]["edge_table"] > 0 and st0["strategy_steps"]["edge_mask"] > 0, st0
+            for k, v in kernel.items(): monkeypatch.setenv(k, v)
+            got_p, got_l, st = e.walk(p=p, q=q, walk_length=40, num_walks=2, seed=5)
+            for k in kernel: monkeypatch.delenv(k)
+            assert np.array_equal(got_l, ref_l) and np.array_equal(got_p, ref_p), (kernel, spec, directed, p, q, env)
+            for key in ("edge_table", "edge_mask", "scan", "handed_over_walkers"):
+                assert st["strategy_steps"][key] == st0["strategy_steps"][key], (kernel, key, st, st0)
+            assert st["trials"] == st0["trials"] and st["ent_reads"] == st0["ent_reads"] and st["n_steps"] == st0["n_steps"]
+            if env.get("SRW_DEBUG_CHAIN_DEG"): assert st["strategy_steps"]["handed_over_walkers"] > 0
+        for k in env: monkeypatch.delenv(k)
+    # ... and the default kernel's paths are the oracle's (the first case, sampled)
+    from helpers import rmat_weights_np as wts
+    s_, d_ = oracle.rmat_edges(14, 16 << 14, seed=9)
+    g = oracle.Graph.from_coo(s_, d_, wts(s_, d_, 9), directed=False)
+    with pkg().Engine(device=0) as e:
+        e.generate_rmat(14, 16 << 14, seed=9, weighted=True)
+        for k, v in kernel.items(): monkeypatch.setenv(k, v)
+        paths, lens, _ = e.walk(p=0.25, q=4.0, walk_length=40, seed=5)
+        verts = e.vertices()
+        pick = rng.choice(len(verts), 400, replace=False)
+        rp, rl, _ = g.walk(sources=verts[pick].astype(np.int32), p=0.25, q=4.0, walk_length=40, seed=5, threads=8)
+        assert np.array_equal(paths[pick], rp) and np.array_equal(lens[pick], rl), kernel

@@ -590,3 +590,20 @@ def test_switches_are_listed_and_off_by_default():
     # and nothing steers this session
     import conftest
     assert conftest.steering_switches_set() == []
+
+
+def test_package_directory_holds_no_extracted_code_objects():
+    """VERDICT r05 hygiene: `llvm-objdump --offloading` pointed at the library IN PLACE leaves libstellar_rw.so.N.hipv4-… / .host-… files
+    beside it (18 of them at the end of round 5).  tools/kernel_resources.py works on a copy in a temporary directory; nothing of the kind
+    may sit in the package directory, and the tool must leave none."""
+    import glob
+    import subprocess
+    pkg_dir = os.path.join(ROOT, "stellar-random-walk_amd")
+    strays = lambda: sorted(glob.glob(os.path.join(pkg_dir, "libstellar_rw.so.*")) + glob.glob(os.path.join(pkg_dir, "*.hipv4-*")) + glob.glob(os.path.join(pkg_dir, "*.host-x86_64*")))
+    assert strays() == [], strays()
+    lib = os.path.join(pkg_dir, "libstellar_rw.so")
+    if os.path.exists(lib) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        import sys as _sys
+        r = subprocess.run([_sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), lib, "k_walk_tables"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "vgpr" in r.stdout, r.stderr[-1000:]
+        assert strays() == [], strays()

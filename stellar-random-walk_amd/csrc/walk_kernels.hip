@@ -2302,10 +2302,14 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
       ta.todo = h->walk_todo.p; ta.todo_n = h->walk_cursor.p + 1; ta.tie = tie;
       // SRW_TABLE_GROUPS=1: one walker per 16 lanes (walk_groups.hip) — measured and not kept as the default, profiles/r06_group_kernel.md
       const bool groups = getenv("SRW_TABLE_GROUPS") && atoi(getenv("SRW_TABLE_GROUPS")) != 0;
-      // SRW_TABLE_LANES=<mode>: one walker per lane (walk_lanes.hip); mode bit 0 mask rows per lane, bit 1 table steps per lane
-      const int lanes = getenv("SRW_TABLE_LANES") ? atoi(getenv("SRW_TABLE_LANES")) : -1;
+      // One walker per LANE (walk_lanes.hip, mode 2: table steps per lane, the rest served by the wave) where the standing tables have
+      // chunks of 64 candidates — config 3: 585 against 602 ms per iteration, directed RMAT-23 ef 27 (p = 4, q = .5): 132 against 206 ms;
+      // one walker per WAVE (k_walk_tables) where a graph that fills the GPU left only chunks of >= 256: every table step would be served
+      // (config 5's stand-in: 4.13 against 3.34 s) — profiles/r06_lane_kernel.md.  SRW_TABLE_LANES=<mode> forces the lane kernel (bit 0: whole
+      // rows per lane, bit 1: table steps per lane), -1 the wave kernel.
+      const int lanes = getenv("SRW_TABLE_LANES") ? atoi(getenv("SRW_TABLE_LANES")) : (gv.ebp.min_sh <= 6 ? 2 : -1);
       if (lanes >= 0) {
-        launch_walk_tables_lanes(ta, gv.bf_off != nullptr, lanes, h->n_cus, st);
+        launch_walk_tables_lanes(ta, gv.bf_off != nullptr, lanes, getenv("SRW_LANE_CSH") ? atoi(getenv("SRW_LANE_CSH")) : 6, h->n_cus, st);
       } else if (groups) {
         launch_walk_tables_groups(ta, gv.bf_off != nullptr, h->n_cus, st);
       } else if (gv.bf_off) {

@@ -30,7 +30,7 @@ namespace {
 #define SRW_LANE_WAVES 6
 #endif
 #define LTAB_ARGS() fresh_args<LaneArgs>()
-struct LaneArgs { TabArgs t; int32_t mode; };         // mode: bit 0 mask rows per lane, bit 1 table steps per lane (0: every step served)
+struct LaneArgs { TabArgs t; int32_t mode, max_csh; }; // mode: bit 0 mask rows per lane, bit 1 table steps per lane (0: every step served); max_csh: located chunks of up to 2^max_csh candidates per lane
 
 enum : int32_t { K_NONE = 0, K_SERVE_FIRST = 1, K_SERVE_MASK = 2, K_SERVE_TABLE = 3, K_LANE_ROW = 4, K_LANE_TABLE = 5 };
 #ifndef SRW_LANE_NB
@@ -140,12 +140,12 @@ __device__ inline int32_t lane_pick_row(const GraphView &g, const Row &r, bool s
 // k >= 0; -1 (non-positive sum); CHAIN_NEEDED (S_out = the row's sum); LANE_SERVE: the wave takes the step.
 constexpr int32_t LANE_SERVE = -4;
 __device__ inline int32_t lane_pick_table(const GraphView &g, const Row &rc, int32_t prev, const Row &rprev, float p_, float q_, uint32_t eo,
-                                          float u, int32_t &id_out, double &S_out, uint32_t &res_bytes) {
+                                          float u, int max_csh, int32_t &id_out, double &S_out, uint32_t &res_bytes) {
   const int32_t deg = rc.deg, m = rprev.deg;
   const uint32_t rflags = rc.flags;
   const PairGeom pg = eb_pair_geometry(deg, m, g.ebp);
   const int csh = pg.csh;
-  if (csh > 6) return LANE_SERVE;                    // located chunks of more than 64 candidates: the wave's rounds
+  if (csh > max_csh) return LANE_SERVE;              // longer located chunks: the wave's rounds
   const uint32_t prev_hub = rprev.flags >> ROW_HUB_SHIFT;
   const uint32_t *hubbits = (prev_hub && g.hub_bm) ? g.hub_bm + (int64_t)(prev_hub - 1) * g.hub_words : nullptr;
   const bool one_sign = (q_ > 1.0f && p_ <= q_) || (q_ < 1.0f && p_ >= q_);
@@ -269,14 +269,16 @@ __device__ inline int32_t lane_pick_table(const GraphView &g, const Row &rc, int
     }
   }
   S_out = S;
-  // ---- the located chunk (at most 64 candidates)
+  // ---- the located chunk (at most 256 candidates: four mask words)
   const int32_t k0 = (int32_t)((int64_t)jc << csh), k1 = chunk_end(jc);
   const BiasDiv bdiv(p_, q_);
   unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};
   bool members = false, returns = true;
   const uint32_t *hub = nullptr;
   if (pg.cmask) {
-    mw[0] = reinterpret_cast<const unsigned long long *>(table + (size_t)lay.cm_off * 64)[k0 >> 6];
+    const unsigned long long *cm = reinterpret_cast<const unsigned long long *>(table + (size_t)lay.cm_off * 64) + (k0 >> 6);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (k0 + 64 * i <= k1) mw[i] = cm[i];
     members = true;
   } else {
     bool no_specials = false;
@@ -288,11 +290,14 @@ __device__ inline int32_t lane_pick_table(const GraphView &g, const Row &rc, int
     else if (hubbits) hub = hubbits;
     else return LANE_SERVE;                          // a short N(prev) (LDS staging), the row filters, the edge hash: the wave
   }
-  res_bytes += 8u * (uint32_t)(k1 - k0 + 1);
   double acc = b_prev;                               // A'_{k0-1}
   bool hit = false;
   const int32_t k = hub ? lane_scan<2>(g, rc.off, k0, k1, k0, mw, members, hub, returns, true, prev, bdiv, acc, pS, id_out, hit)
                         : lane_scan<LNB>(g, rc.off, k0, k1, k0, mw, members, hub, returns, true, prev, bdiv, acc, pS, id_out, hit);
+  {                                                  // (counted as the wave kernel counts it: the rounds of 64 up to the one that decided)
+    const int32_t rounds = (((k >= 0 ? k : k1) - k0) >> 6) + 1, all = k1 - k0 + 1;
+    res_bytes += 8u * (uint32_t)(all < 64 * rounds ? all : 64 * rounds);
+  }
   if (k < 0 || !hit) return CHAIN_NEEDED;
   return k;
 }
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(TPB, SRW_LANE_WAVES) void k_walk_tables_lanes(LaneA
     if (kind == K_LANE_TABLE) {
       const LaneArgs at = LTAB_ARGS();
       uint32_t rb = 0;
-      k = lane_pick_table(fresh_graph(), r, prev, rprev, at.t.p, at.t.q, eo, u, next, S_tie, rb);
+      k = lane_pick_table(fresh_graph(), r, prev, rprev, at.t.p, at.t.q, eo, u, at.max_csh, next, S_tie, rb);
       if (k == LANE_SERVE) { kind = K_SERVE_TABLE; k = -1; }
       else { if (rb) atomicAdd(&tot[T_SRCH], (unsigned long long)rb); if (k >= 0) { w_tab += 1; w_srch += 8u * (uint32_t)EB_BINS; } }
     }
@@ -499,11 +504,11 @@ __global__ __launch_bounds__(TPB, SRW_LANE_WAVES) void k_walk_tables_lanes(LaneA
 
 }  // namespace
 
-void launch_walk_tables_lanes(const TabArgs &ta, bool row_filters, int mode, int n_cus, hipStream_t st) {
+void launch_walk_tables_lanes(const TabArgs &ta, bool row_filters, int mode, int max_csh, int n_cus, hipStream_t st) {
   // persistent waves, 64 walkers each: enough blocks to fill every CU at the kernel's occupancy
   const int64_t waves = (ta.n_walkers + 63) / 64;
   const int64_t lb = std::max<int64_t>(1, std::min<int64_t>((waves * 64 + TPB - 1) / TPB, (int64_t)n_cus * SRW_LANE_WAVES * 2));
-  LaneArgs la; la.t = ta; la.mode = mode;
+  LaneArgs la; la.t = ta; la.mode = mode; la.max_csh = std::min(std::max(max_csh, 0), 8);
   if (row_filters) hipLaunchKernelGGL((k_walk_tables_lanes<true>), dim3((unsigned)lb), dim3(TPB), 0, st, la);
   else hipLaunchKernelGGL((k_walk_tables_lanes<false>), dim3((unsigned)lb), dim3(TPB), 0, st, la);
 }

@@ -35,6 +35,6 @@ struct TabArgs {
 // walk_groups.hip: the table walk with one walker per 16 lanes (four per wave)
 void launch_walk_tables_groups(const TabArgs &ta, bool row_filters, int n_cus, hipStream_t st);
 // walk_lanes.hip: ... with one walker per lane; mode bit 0: mask rows per lane, bit 1: table steps per lane (0: every step served by the wave)
-void launch_walk_tables_lanes(const TabArgs &ta, bool row_filters, int mode, int n_cus, hipStream_t st);
+void launch_walk_tables_lanes(const TabArgs &ta, bool row_filters, int mode, int max_csh, int n_cus, hipStream_t st);
 
 }  // namespace srw

@@ -336,11 +336,12 @@ def test_mapped_table_buffer_gives_its_memory_back():
     assert f5 >= f0 - slack, (f0, f5)                   # everything is back once the engine is closed
 
 
-@pytest.mark.parametrize("kernel", [{"SRW_TABLE_LANES": "3"}, {"SRW_TABLE_LANES": "2"}, {"SRW_TABLE_LANES": "0"}, {"SRW_TABLE_GROUPS": "1"}])
-def test_opt_in_table_kernels_walk_every_walker_like_the_default(oracle, monkeypatch, kernel):
-    """walk_lanes.hip (one walker per lane; modes: rows + tables per lane, tables only, every step served by the wave) and walk_groups.hip
-    (one walker per 16 lanes) are opt-in forms of the table walk (profiles/r06_lane_kernel.md, r06_group_kernel.md): EVERY walker as the
-    default kernel walks it — weighted and unit-weight, undirected and directed, three-level tables, chunk masks off, and with every
+@pytest.mark.parametrize("kernel", [{}, {"SRW_TABLE_LANES": "3"}, {"SRW_TABLE_LANES": "0"}, {"SRW_TABLE_LANES": "2", "SRW_LANE_CSH": "8"}, {"SRW_TABLE_GROUPS": "1", "SRW_TABLE_LANES": "-1"}])
+def test_table_kernels_walk_every_walker_alike(oracle, monkeypatch, kernel):
+    """The table walk has three kernels: one walker per wave (k_walk_tables, SRW_TABLE_LANES=-1: the reference here), one per lane
+    (walk_lanes.hip: the default — {} — where the tables' chunks are 64 candidates; modes: rows + tables per lane, every step served by the
+    wave, located chunks up to 256 candidates per lane) and one per 16 lanes (walk_groups.hip, opt-in) — profiles/r06_lane_kernel.md,
+    r06_group_kernel.md.  EVERY walker as the wave kernel walks it — weighted and unit-weight, undirected and directed, three-level tables, chunk masks off, and with every
     table step on a long row treated as a boundary draw (the tie list + the chain kernels) — and a sample against the oracle."""
     rng = np.random.default_rng(77)
     cases = [("w", False, 14, (0.25, 4.0), {}), ("", False, 14, (4.0, 0.5), {}), ("w", True, 13, (0.5, 2.0), {}),
@@ -350,7 +351,9 @@ def test_opt_in_table_kernels_walk_every_walker_like_the_default(oracle, monkeyp
         for k, v in env.items(): monkeypatch.setenv(k, v)
         with pkg().Engine(device=0) as e:
             e.generate_rmat(scale, 16 << scale, seed=9, weighted=bool(spec), directed=directed)
+            monkeypatch.setenv("SRW_TABLE_LANES", "-1")
             ref_p, ref_l, st0 = e.walk(p=p, q=q, walk_length=40, num_walks=2, seed=5)
+            monkeypatch.delenv("SRW_TABLE_LANES")
             assert st0["strategy_steps"]["edge_table"] > 0 and st0["strategy_steps"]["edge_mask"] > 0, st0
             for k, v in kernel.items(): monkeypatch.setenv(k, v)
             got_p, got_l, st = e.walk(p=p, q=q, walk_length=40, num_walks=2, seed=5)
@@ -361,7 +364,7 @@ def test_opt_in_table_kernels_walk_every_walker_like_the_default(oracle, monkeyp
             assert st["trials"] == st0["trials"] and st["ent_reads"] == st0["ent_reads"] and st["n_steps"] == st0["n_steps"]
             if env.get("SRW_DEBUG_CHAIN_DEG"): assert st["strategy_steps"]["handed_over_walkers"] > 0
         for k in env: monkeypatch.delenv(k)
-    # ... and the default kernel's paths are the oracle's (the first case, sampled)
+    # ... and the paths are the oracle's (the first case, sampled)
     from helpers import rmat_weights_np as wts
     s_, d_ = oracle.rmat_edges(14, 16 << 14, seed=9)
     g = oracle.Graph.from_coo(s_, d_, wts(s_, d_, 9), directed=False)

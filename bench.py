@@ -119,6 +119,114 @@ def cpu_baseline(args):
             "plan": plan}
 
 
+def _library_commit():
+    """The commit libstellar_rw.so was built from (srw_version(): 'stellar_rw gfx950 rN <commit>')."""
+    try:
+        import _pkg
+        return _pkg.load().version().split()[-1]
+    except Exception:
+        return "?"
+
+
+def pmc_child_pass(kernel_substr, one_walk_args, timeout_s=240):
+    """HBM-side counters of the dominant kernel, taken IN this run: child `rocprofv3 --kernel-trace --pmc` passes over
+    tools/one_walk.py with the same workload, in their own processes (the guide's rule: counters in a run of their own, --kernel-trace only;
+    FETCH_SIZE needs three of the four TCC counters, so WRITE_SIZE and the request count share a second pass).  Returns
+    {"hbm_bytes_per_launch", "requests_per_launch", ...} per launch of the kernel, or None when rocprofv3 is not on the box / a pass fails."""
+    import csv, glob, subprocess
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    tool = os.path.join(ROOT, "tools", "one_walk.py")
+    per_launch = {}
+    t0 = time.perf_counter()
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE", "TCC_EA0_RDREQ_sum"]):
+        d = tempfile.mkdtemp(prefix="srw_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", GRAFT_REPO_ROOT=ROOT)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable, tool]
+                               + [str(a) for a in one_walk_args], cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=timeout_s)
+            acc, seen = {}, {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr not in row["Kernel_Name"]:
+                        continue
+                    c = row["Counter_Name"]
+                    acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
+                    seen.setdefault(c, set()).add(row["Dispatch_Id"])
+            if r.returncode != 0 or not acc:
+                return None
+            for c, v in acc.items():
+                per_launch[c] = v / max(len(seen[c]), 1)
+                per_launch["launches_" + c] = len(seen[c])
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if "FETCH_SIZE" not in per_launch or "WRITE_SIZE" not in per_launch:
+        return None
+    # FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE = TCC_EA0_RDREQ x 64 B; a wide coalesced
+    # 16 B/lane stream is tallied at half its bytes — these kernels gather 16-byte records at random (one 64-byte request each), where
+    # request x 64 B IS what crossed the fabric: no doubling.  WRITE_SIZE is uncalibrated for partial-line stores (taken as reported).
+    return {"hbm_bytes_per_launch": (per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024.0,
+            "fetch_bytes_per_launch": per_launch["FETCH_SIZE"] * 1024.0, "write_bytes_per_launch": per_launch["WRITE_SIZE"] * 1024.0,
+            "requests_per_launch": per_launch.get("TCC_EA0_RDREQ_sum"), "launches": per_launch.get("launches_FETCH_SIZE"),
+            "seconds": time.perf_counter() - t0,
+            "source": "measured in this run: child rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE + TCC_EA0_RDREQ_sum) over tools/one_walk.py "
+                      + " ".join(str(a) for a in one_walk_args) + ", per launch of " + kernel_substr}
+
+
+def apply_pmc(roof, pm, avg_ms, steps_per_launch, ceiling=None):
+    """The counters of pmc_child_pass into a roofline object (traffic per launch, like `achieved`)."""
+    if not pm:
+        return roof
+    roof["traffic"] = pm["hbm_bytes_per_launch"]
+    roof["traffic_commit"] = _library_commit()
+    roof["traffic_source"] = pm["source"]
+    roof["physical_traffic_frac"] = pm["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    roof["traffic_over_algorithmic"] = pm["hbm_bytes_per_launch"] / max(roof.get("algorithmic_bytes_per_launch", 0), 1)
+    if pm.get("requests_per_launch"):
+        roof["requests_per_launch_pmc"] = pm["requests_per_launch"]
+        roof["requests_per_step_pmc"] = pm["requests_per_launch"] / max(steps_per_launch, 1)
+        if "requests_per_step" not in roof:
+            roof["requests_per_step"] = roof["requests_per_step_pmc"]
+            roof["requests_per_s"] = pm["requests_per_launch"] / (avg_ms * 1e-3)
+            if ceiling:
+                roof["request_rate_frac"] = roof["requests_per_s"] / ceiling["reads_per_s"]
+    roof["pmc_pass_seconds"] = pm["seconds"]
+    return roof
+
+
+def promote_vertex_sharded(out, vs, world):
+    """At N > 1 the line's `value` is north_star's split — the graph sharded by source vertex, one all_to_all per super-step (the RCCL driver's
+    leg; the one-process cluster driver if that leg failed) — on the headline graph; the replicated weak-scaling figure (no collective: it
+    says nothing about the shard / exchange design) moves to `replicated_weak_scaling`.  VERDICT r05 item 4; replaces the shuffle of
+    RandomWalk.scala:92-93,186-192."""
+    key = next((k for k in ("rccl", "cluster") if isinstance(vs.get(k), dict) and vs[k].get("value")), None)
+    if key is None:
+        out["vertex_sharded_note"] = "no vertex-sharded leg finished: `value` is the replicated weak-scaling figure"
+        return out
+    leg = vs[key]
+    top = {k: out[k] for k in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "data") if k in out}
+    top.update({"value": leg["value"], "n_gpus": world, "steps": leg.get("steps", out.get("steps")), "warmup": leg.get("warmup", out.get("warmup")),
+                "ms_per_step": leg["ms_per_step"], "scaling": "strong",
+                "config": {"workload": leg.get("workload", out["config"].get("workload")),
+                           "parallelism": "source-vertex shards x%d, one all_to_all per super-step (%s); paths on the home GPU"
+                                          % (world, "RCCL all_to_all_single over xGMI, one process per GPU" if key == "rccl"
+                                             else "one process driving all devices, chunks stored into the peers' buffers over xGMI"),
+                           "driver": key, "rng": out["config"].get("rng")},
+                "per_superstep_unoverlapped": leg.get("per_superstep_unoverlapped"), "exchange_model": leg.get("exchange_model"),
+                "roofline": out.get("roofline"),
+                "roofline_note": "the replicated single-GPU kernel's (k_walk_first_order on this rank's copy of the graph): the sharded step's kernels are timed apart in per_superstep_unoverlapped",
+                "replicated_weak_scaling": {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak", "steps": out.get("steps"),
+                                            "parallelism": out["config"].get("parallelism"), "walk_steps_per_bench_step": out["config"].get("walk_steps_per_bench_step")}})
+    for k in ("setup_s", "end_to_end"):
+        if k in out:
+            top[k] = out[k]
+    return top
+
+
 def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None, ceiling=None, scan=None, q=1.0, wl=None):
     """Algorithmic bytes per launch / average kernel time of the dominant kernel."""
     kind = stats["kernel_kind"]
@@ -154,8 +262,13 @@ def roofline_of(stats, steps_per_launch, avg_ms, scale=None, n_entries=None, cei
     if os.path.exists(pmc) and scale is not None:
         try:
             js = json.load(open(pmc))
+            lib_commit = _library_commit()
             for j in (js if isinstance(js, list) else [js]):
-                # an entry stands for ONE workload: kernel, scale and (ef, p, q, weighted, directed) must all agree
+                # an entry stands for ONE workload: kernel, scale and (ef, p, q, weighted, directed) must all agree — and for ONE library:
+                # counters of another commit are not this run's traffic: such an entry is skipped, the keys stay absent
+                # unless the run measures them itself (pmc_child_pass below)
+                if j.get("commit") != lib_commit:
+                    continue
                 if j.get("kernel") == name and j.get("scale") == scale and all(
                         float(j.get(k, -1)) == float(v) for k, v in (wl or {}).items()):
                     r["traffic"] = j.get("hbm_bytes_per_launch")
@@ -383,10 +496,10 @@ def cluster_leg(pkg, torch, args, world, K):
     super-steps ordered by events, paths on the home GPU.  Returns the `vertex_sharded` object of the bench line."""
     n_edges = args.edge_factor << args.scale
     try:
-        if torch.cuda.device_count() < world:
+        if not args.share_device and torch.cuda.device_count() < world:
             raise RuntimeError("the process sees %d devices, needs %d" % (torch.cuda.device_count(), world))
         t0 = time.perf_counter()
-        with pkg.Cluster(list(range(world)), membership=(args.q != 1.0)) as cl:       # q == 1: memory per shard ~ 1 / world
+        with pkg.Cluster([0] * world if args.share_device else list(range(world)), membership=(args.q != 1.0)) as cl:       # q == 1: memory per shard ~ 1 / world
             cl.generate_rmat(args.scale, n_edges, seed=42, weighted=bool(args.weighted), directed=bool(args.directed))
             cnv, cne = cl.stats()
             torch.cuda.synchronize()
@@ -486,6 +599,10 @@ def compact_line(out):
             if "measured_fraction_of_exchange_ceiling" in m:
                 vs[leg]["fraction_of_exchange_ceiling"] = m["measured_fraction_of_exchange_ceiling"]
         c["vertex_sharded"] = vs
+    if isinstance(out.get("replicated_weak_scaling"), dict):      # N > 1: `value` above is the vertex-sharded walk (promote_vertex_sharded)
+        c["replicated_weak_scaling"] = {k: v for k, v in out["replicated_weak_scaling"].items() if k in ("value", "ms_per_step", "scaling", "steps")}
+    if isinstance(out.get("per_superstep_unoverlapped"), dict):
+        c["per_superstep_unoverlapped"] = {k: v for k, v in out["per_superstep_unoverlapped"].items() if isinstance(v, (int, float))}
     if "embedding_stage" in out:
         c["embedding_stage"] = {k: v for k, v in out["embedding_stage"].items() if k in ("words_per_s", "training_iteration_s", "error")}
     if out.get("switches_set"):
@@ -551,7 +668,7 @@ def main():
     ap.add_argument("--directed", type=int, default=0)
     ap.add_argument("--sampler", choices=["reference", "alias"], default="reference")
     ap.add_argument("--shard", choices=["both", "replicate", "vertex"], default="both",
-                    help="N > 1: which multi-GPU mode(s) to run; `value` is always the replicated mode when it runs")
+                    help="N > 1: which multi-GPU mode(s) to run; `value` is the vertex-sharded walk when that leg runs (the replicated figure: replicated_weak_scaling)")
     ap.add_argument("--shard-driver", choices=["both", "cluster", "rccl"], default="both",
                     help="vertex-sharded legs of an N > 1 run: one process driving all devices (peer stores), one process per GPU "
                          "over RCCL (all_to_all_single per super-step), or both (default)")
@@ -564,12 +681,15 @@ def main():
     ap.add_argument("--configs-scale-cap", type=int, default=0, help="tests: run the `configs` plan with every scale capped at this value")
     ap.add_argument("--time-budget", type=float, default=420.0, help="seconds after which no further optional configuration starts")
     ap.add_argument("--end-to-end", type=int, default=1, help="1 GPU: also time one iteration through srw_walk_and_save")
+    ap.add_argument("--pmc", type=int, default=1, help="1 GPU: take roofline.traffic in this run (child rocprofv3 --pmc passes over the headline workload)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-plan", choices=["sample", "full"], default="sample", help="sample: ~30 s of CPU work; full: BASELINE.md's whole CPU plan (~100 s)")
     ap.add_argument("--cpu-scale", type=int, default=20)
     ap.add_argument("--cpu-sources", type=int, default=0, help="0 = max(64, 3 per host core)")
     ap.add_argument("--cpu-walk-length", type=int, default=80)
     ap.add_argument("--cluster-leg", type=int, default=0, help=argparse.SUPPRESS)   # child of an N > 1 run: see cluster_leg
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)     # tests: gloo (chunks staged through host memory)
+    ap.add_argument("--share-device", type=int, default=0, help=argparse.SUPPRESS)                     # tests: every rank on device 0 (a one-GPU box)
     args = ap.parse_args()
 
     import torch
@@ -589,10 +709,11 @@ def main():
         # one process per GPU, walkers exchanged by ONE RCCL all_to_all_single per super-step (stellar-random-walk_amd/distributed.py)
         import datetime
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        dev = 0 if args.share_device else local_rank
+        torch.cuda.set_device(dev)
         torch.zeros(1, device="cuda")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", timeout=datetime.timedelta(minutes=10))
+        dist.init_process_group(backend=args.backend, timeout=datetime.timedelta(minutes=10))
         from importlib import import_module
         sharded = import_module("stellar_random_walk_amd.distributed")
 
@@ -600,7 +721,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
         kw = dict(p=args.p, q=args.q, walk_length=args.walk_length, num_walks=1, seed=42)
-        vs = sharded.bench_vertex_sharded(dist, local_rank, rank, world, args.scale, args.edge_factor << args.scale, bool(args.weighted),
+        vs = sharded.bench_vertex_sharded(dist, dev, rank, world, args.scale, args.edge_factor << args.scale, bool(args.weighted),
                                           bool(args.directed), kw, args.steps, args.warmup, bs)
         if rank == 0:
             vs["exchange_model"] = exchange_model(world, vs.get("value"))
@@ -613,6 +734,8 @@ def main():
                          % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     torch.zeros(1, device="cuda")          # torch's device context first (it ships its own HIP runtime)
     dist = None
@@ -622,10 +745,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         import datetime
         tmo = datetime.timedelta(minutes=30)     # the other ranks wait at a barrier while rank 0 runs the cluster leg
-        try:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
-        except TypeError:  # older signature without device_id
-            dist.init_process_group(backend="nccl", timeout=tmo)
+        if args.backend != "nccl":
+            dist.init_process_group(backend=args.backend, timeout=tmo)
+        else:
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
+            except TypeError:  # older signature without device_id
+                dist.init_process_group(backend="nccl", timeout=tmo)
 
     def barrier_sync():
         if dist is not None:
@@ -635,7 +761,7 @@ def main():
     def allreduce(x, op):
         if dist is None:
             return x
-        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=op)
         return float(t.item())
 
@@ -713,6 +839,14 @@ def main():
                 "setup_s": {"graph_generate_and_csr": t_graph, "sampling_tables": t_tables,
                             "note": "outside the timed region; one-off per graph / per (p, q)"},
             }
+        # ---- the headline kernel's HBM-side counters, taken in this run (child processes; the engine above keeps its graph) -----------
+        if rank == 0 and world == 1 and args.pmc and out is not None:
+            spec = "%d%s%s" % (args.scale, "w" if args.weighted else "", "d" if args.directed else "")
+            pm = pmc_child_pass(out["roofline"]["kernel"].split(" ")[0], [spec, args.p, args.q, args.sampler, 3, args.edge_factor])
+            if pm is not None:
+                apply_pmc(out["roofline"], pm, avg_ms, steps / max(K, 1), ceiling)
+            else:
+                out["roofline"]["traffic_note"] = "rocprofv3 --pmc child pass unavailable on this box: traffic not measured in this run"
         # ---- end to end: the reference's contract is path FILES --------------------------------------------------------
         if rank == 0 and world == 1 and args.end_to_end:
             e2e = {"what": "srw_walk_and_save, 1 walk iteration: walk kernel + device-side formatter + PCIe + <output>/path/part-00000 on local "
@@ -785,7 +919,8 @@ def main():
                     return {"error": str(ex)[:300]}
 
             me = [sys.executable, os.path.abspath(__file__)]
-            head = workload(args.scale, args.edge_factor, args.weighted, args.directed, args.p, args.q, K)
+            test_sw = ["--backend", args.backend, "--share-device", str(args.share_device)]
+            head = test_sw + workload(args.scale, args.edge_factor, args.weighted, args.directed, args.p, args.q, K)
             if args.shard_driver in ("both", "cluster"):
                 vs["cluster"] = child(me + ["--cluster-leg", str(world)] + head, 360)
             if args.shard_driver in ("both", "rccl"):
@@ -795,8 +930,10 @@ def main():
                                     "--gpus", str(world), "--warmup", str(min(W, 1))] + head, 480)
             if args.biased_leg and args.shard_driver in ("both", "cluster"):
                 # north_star's named biased multi-GPU configuration (C5's stand-in): per-edge tables on the shards
-                vs["cluster_c5_shape"] = child(me + ["--cluster-leg", str(world)] + workload(26, 27, 0, 1, 4.0, 0.5, 1), 540)
+                vs["cluster_c5_shape"] = child(me + ["--cluster-leg", str(world)] + test_sw + workload(26, 27, 0, 1, 4.0, 0.5, 1), 540)
         dist.barrier()
+        if rank == 0 and world > 1 and out is not None:
+            out = promote_vertex_sharded(out, vs, world)
         if rank == 0:
             first = vs.get("cluster") or vs.get("rccl") or {}
             if out is None:

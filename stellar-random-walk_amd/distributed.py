@@ -440,7 +440,7 @@ def bench_vertex_sharded(dist_mod, local_rank, rank, world, scale, n_edges, weig
             steps += st["n_steps_global"]
     barrier_sync()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist_mod.get_backend() == "nccl" else "cpu")
     dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
     max_dt = float(t.item())
     try:          # outside the timed region: one unoverlapped batch, kernels and exchange timed apart

@@ -1,5 +1,5 @@
 """Verification of BASELINE config 5's stand-in at FULL size (directed unweighted RMAT-26 ef 27, p = 4 q = .5, Mode R, default sampler
-selection: per-edge tables + the lean kernel): ~1 500 sampled walkers (incl. the 20 highest-degree starts of a 2 000-vertex sample) are
+selection: per-edge tables + the lean kernel): 20 000 sampled walkers at walkLength 80 (incl. the 20 highest-degree starts of a 2 000-vertex sample) are
 compared bit for bit with the CPU ORACLE over the out-rows of every vertex on those walkers' DEVICE paths, rebuilt on the host from the
 same (seed, edge index) stream (256 M lines at a time, stream order kept) — as tests/big_c3_check.py; a deviation walks the oracle into
 a row that was not collected and shows as a mismatch.
@@ -14,7 +14,8 @@ import oracle_py as oracle
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 ef = int(sys.argv[2]) if len(sys.argv) > 2 else 27
 n_edges = ef << scale
-p, q, L = 4.0, 0.5, 20
+p, q, L = 4.0, 0.5, 80                   # the configuration's walkLength, 20 000 sampled walkers
+N_SAMPLE = int(os.environ.get("SRW_C5_SAMPLE", "20000"))
 pkg = _pkg.load()
 t = time.time()
 eng = pkg.Engine(0)
@@ -24,15 +25,14 @@ verts = eng.vertices()
 rng = np.random.default_rng(3)
 cand = np.arange(0, len(verts), max(1, len(verts) // 2000))
 degs = np.array([len(eng.neighbors(int(verts[i]))[0]) for i in cand])
-pick = np.unique(np.concatenate([cand[np.argsort(-degs)[:20]], rng.choice(len(verts), 1500, replace=False)]))
+pick = np.unique(np.concatenate([cand[np.argsort(-degs)[:20]], rng.choice(len(verts), N_SAMPLE, replace=False)]))
 src = verts[pick].astype(np.int32)
 print("device graph: %d vertices, %d entries, %.0f s" % (nv, ne, time.time() - t), flush=True)
 paths, lens, st = eng.walk(p=p, q=q, walk_length=L, seed=2026)
 sp, sl = paths[pick].copy(), lens[pick].copy()
 del paths, lens
 on_path = np.zeros(1 << scale, dtype=bool)
-for i in range(len(pick)):
-    on_path[sp[i, : sl[i]]] = True
+on_path[sp[sp >= 0]] = True
 t = time.time()
 fs, fd = [], []
 BLOCK = 1 << 28
@@ -45,7 +45,7 @@ fs = np.concatenate(fs); fd = np.concatenate(fd)
 g = oracle.Graph.from_coo(fs, fd, None, directed=True)
 print("oracle out-rows of %d path vertices rebuilt from the edge stream (%d of %d lines kept), %.0f s" % (int(on_path.sum()), len(fs), n_edges, time.time() - t), flush=True)
 t = time.time()
-rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=L, seed=2026, threads=min(64, os.cpu_count() or 8))
+rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=L, seed=2026, threads=min(128, os.cpu_count() or 8))
 ok = bool(np.array_equal(sp, rp) and np.array_equal(sl, rl))
 ss = {k: v for k, v in st["strategy_steps"].items() if v}
 print("p=%g q=%g L=%d: %d sampled walkers (longest start row %d) %s; oracle %.0f s; device kernel %.0f ms, setup %.0f ms, %s"

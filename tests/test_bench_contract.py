@@ -38,7 +38,10 @@ def check_driver_keys(d):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_walk_first_order"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 * rf["frac"] and rf["kernel_ms_avg"] > 0
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms_avg"] * 1e-3) / 1e9) < 1e-4 * rf["achieved"]
-    assert rf["traffic"] is None                      # no PMC entry for this workload: never a number that was not measured
+    # traffic: measured IN this run (child rocprofv3 --pmc passes over the same workload, stamped with the library's commit) or absent —
+    # never a counter replayed from another commit
+    if rf["traffic"] is not None:
+        assert rf["traffic"] > 0 and rf["traffic_commit"] == d["library"].split()[-1] and rf["physical_traffic_frac"] > 0, rf
 
 
 @pytest.mark.gpu
@@ -126,3 +129,55 @@ def test_torchrun_one_rank_adds_the_vertex_sharded_leg():
         assert vs["value"] > 0 and vs["scaling"] == "strong" and "sharded by source vertex" in vs["parallelism"], (leg, vs)
         assert d["vertex_sharded"][leg]["value"] > 0
     assert d["scaling"] == "weak" and d["n_gpus"] == 1
+
+
+def test_promote_vertex_sharded_makes_the_sharded_walk_the_value():
+    """N > 1: the line's value is the vertex-sharded RCCL leg; the replicated figure is an extra key; a run whose
+    sharded legs all failed keeps the replicated value and says so."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    rep = {"metric": "walk-steps/sec", "value": 8.0e10, "unit": "walk-steps/s", "n_gpus": 8, "steps": 10, "warmup": 2, "ms_per_step": 60.0,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "w", "parallelism": "graph replicated, walk iterations sharded x8, no collective", "rng": "philox"},
+           "roofline": {"bound": "hbm", "achieved": 800.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None, "kernel": "k_walk_first_order"}}
+    legs = {"cluster": {"value": 3.0e10, "ms_per_step": 160.0, "scaling": "strong", "steps": 10, "warmup": 10, "workload": "ws", "parallelism": "px"},
+            "rccl": {"value": 2.5e10, "ms_per_step": 190.0, "scaling": "strong", "steps": 10, "warmup": 2, "workload": "ws", "parallelism": "py",
+                     "per_superstep_unoverlapped": {"kernels_ms": 1.5, "exchange_ms": 0.4, "super_steps": 81}, "exchange_model": {"x": 1}}}
+    top = b.promote_vertex_sharded(dict(rep), legs, 8)
+    assert top["value"] == 2.5e10 and top["scaling"] == "strong" and top["n_gpus"] == 8 and top["ms_per_step"] == 190.0
+    assert "source-vertex shards x8, one all_to_all per super-step" in top["config"]["parallelism"] and top["config"]["driver"] == "rccl"
+    assert top["replicated_weak_scaling"]["value"] == 8.0e10 and top["replicated_weak_scaling"]["scaling"] == "weak"
+    assert top["per_superstep_unoverlapped"]["exchange_ms"] == 0.4 and top["roofline"]["kernel"] == "k_walk_first_order"
+    for k in KEYS:
+        assert k in top, k
+    line = json.loads(b.compact_line(dict(top, vertex_sharded=legs)))
+    assert line["value"] == 2.5e10 and line["replicated_weak_scaling"]["value"] == 8.0e10 and line["per_superstep_unoverlapped"]["super_steps"] == 81
+    # the RCCL leg failed: the cluster driver's leg is the value; both failed: the replicated value stays, with a note
+    top = b.promote_vertex_sharded(dict(rep), {"rccl": {"error": "x"}, "cluster": legs["cluster"]}, 8)
+    assert top["value"] == 3.0e10 and top["config"]["driver"] == "cluster"
+    top = b.promote_vertex_sharded(dict(rep), {"rccl": {"error": "x"}}, 8)
+    assert top["value"] == 8.0e10 and top["scaling"] == "weak" and "vertex_sharded_note" in top
+
+
+@pytest.mark.gpu
+def test_two_ranks_line_is_the_vertex_sharded_walk():
+    """The N > 1 form end to end on a one-GPU box: two ranks over gloo, both on device 0 (--backend gloo --share-device 1: the chunks are staged
+    through host memory, everything else is the path an 8-GPU run takes): the line's value is the RCCL driver's vertex-sharded leg."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "1",
+                        "--scale", "15", "--steps", "2", "--warmup", "1", "--configs", "0", "--end-to-end", "0", "--cpu-baseline", "0",
+                        "--biased-leg", "0", "--pmc", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "source-vertex shards x2, one all_to_all per super-step" in d["config"]["parallelism"]
+    assert d["config"]["driver"] == "rccl" and d["value"] == d["vertex_sharded"]["rccl"]["value"] > 0
+    assert d["replicated_weak_scaling"]["value"] > 0 and d["replicated_weak_scaling"]["scaling"] == "weak"
+    assert d["per_superstep_unoverlapped"]["super_steps"] > 0
+    full = json.loads([l for l in r.stderr.splitlines() if l.startswith("BENCH_DETAIL ")][-1][len("BENCH_DETAIL "):])
+    assert full["vertex_sharded"]["cluster"]["value"] > 0 and "exchange_model" in full

@@ -1,11 +1,12 @@
 """Full-size parity of the BASELINE configurations, driver-run, each behind a resource probe (HBM + host memory) and nothing else:
-tests/big_c3_check.py (weighted RMAT-24, p = .25 q = 4, (4, .5), (.25, 1): ~1 500 sampled walkers incl. the highest-degree starts against
+tests/big_c3_check.py (weighted RMAT-24, p = .25 q = 4 at walkLength 80 over 20 000 sampled walkers, (4, .5), (.25, 1) over ~1 500, incl. the highest-degree starts, against
 the CPU oracle over the rows of every vertex on their device paths, rebuilt on the host from the same edge stream), tests/big_c5_check.py
 (config 5's stand-in, directed RMAT-26 ef 27, p = 4 q = .5, the same way) and tests/big_c4_check.py
 (config 4 at its own size, RMAT-27, on eight virtual shards against the single-launch kernel — the distributed == sequential
 property of T/UniformRandomWalkTest.scala:181-291 at size — and ~1 500 sampled walkers against the oracle over rows rebuilt on the
 host from the edge stream) and tests/big_shard_tables_check.py (the sharded per-edge tables at config 3's size, worlds 1 and 2,
-every walker against the replicated kernel).  A box that lacks the memory FAILS these tests; only SRW_SKIP_FULL_SIZE=1 skips
+every walker against the replicated kernel), tests/big_every_walker_check.py (configs 3 and 5's stand-in: one
+iteration at walkLength 80 through the default table path, the other table kernel and the on-the-fly samplers — ALL walkers compared).  A box that lacks the memory FAILS these tests; only SRW_SKIP_FULL_SIZE=1 skips
 them (quick local runs)."""
 import os
 import subprocess
@@ -48,9 +49,23 @@ def test_config3_full_size_against_the_oracle():
 
 
 def test_config5_stand_in_full_size_against_the_oracle():
-    _need(260, 32)
+    _need(260, 64)
     out = _run("big_c5_check.py", timeout=3000)
     assert out.count("IDENTICAL") >= 1
+
+
+def test_config3_every_walker_through_independent_samplers():
+    """One iteration at walkLength 80: the default table path, the other table kernel and the on-the-fly samplers (tables off) agree on ALL
+    8.9 M walkers; boundary draws (the tie list, the chain kernels, hand-overs) are among them."""
+    _need(200, 24)
+    out = _run("big_every_walker_check.py", "c3")
+    assert out.count("IDENTICAL") >= 3
+
+
+def test_config5_stand_in_every_walker_through_independent_samplers():
+    _need(260, 64)
+    out = _run("big_every_walker_check.py", "c5", timeout=3000)
+    assert out.count("IDENTICAL") >= 3
 
 
 def test_config4_full_size_eight_virtual_shards_and_the_oracle():

@@ -198,6 +198,68 @@ class ShardedWalker:
         else:
             dist.all_to_all_single(recv.view(torch.int64), send.view(torch.int64), group=self.group)
 
+    # ---- variable-occupancy exchange ("counts first, then all-to-all-v of what is live") ------------------------------------------
+    # The chunk of a (sender, receiver) pair has room for the walkers a population STARTS with (x slack); on a directed graph walkers die
+    # (config 5: ~40 % alive on average), on any graph the last super-steps of a batch carry fewer — shipping `world x chunk_bytes` every
+    # super-step moves mostly empty slots then.  What is exchanged instead is the PREFIX of each section that holds records: the header +
+    # `tw` walker records + `tr` path returns per pair, packed into one contiguous equal-split message (two strided device copies either
+    # side of the one collective: no second collective, no per-step host synchronisation, any backend).  tw / tr follow the counts the
+    # chunk headers carry: every EXCHANGE_WINDOW super-steps the largest header count of the window goes through one small all-reduce
+    # (MAX) and the next window ships that x EXCHANGE_MARGIN (+ a pad); a chunk that outgrows its window's prefix sets a flag that joins
+    # the overflow vote at the end of the batch — every rank then redoes the batch with whole chunks, as for a capacity overflow.
+    EXCHANGE_WINDOW = int(os.environ.get("SRW_EXCHANGE_WINDOW", "8"))       # super-steps per count refresh; 0: always whole chunks
+    EXCHANGE_MARGIN = float(os.environ.get("SRW_EXCHANGE_MARGIN", "1.25"))
+    EXCHANGE_PAD = 256                                                      # records on top of margin x the window's largest count
+
+    class _Exchange:
+        """The per-batch state of the variable exchange over one (recv, send) buffer pair of layout `lay`."""
+
+        def __init__(self, walker, lay, recv, send, variable=True):
+            self.w, self.lay, self.recv, self.send = walker, lay, recv, send
+            self.cap_w, self.cap_r = int(lay.cap_walkers), int(lay.cap_rets)
+            self.tw, self.tr = self.cap_w, self.cap_r          # whole chunks until the first refresh
+            self.off_r = 16 + self.cap_w * 16
+            self.window = walker.EXCHANGE_WINDOW if variable else 0
+            self.seen = torch.zeros(2, dtype=torch.int32, device=recv.device)       # largest header counts of the window (this rank's sends)
+            self.trunc = torch.zeros(1, dtype=torch.int32, device=recv.device)      # a chunk outgrew the prefix that was shipped
+            self.bytes = 0
+            self.steps = 0
+
+        def run(self, step):
+            w, world, cb = self.w, self.w.world, int(self.lay.chunk_bytes)
+            S = self.send.view(world, cb)
+            if self.window > 0:
+                hdr = S[:, :8].view(torch.int32)                    # (world, 2): n_walkers, n_rets of the chunks this rank sends
+                mx = hdr.max(dim=0).values
+                self.seen = torch.maximum(self.seen, mx)
+                self.trunc |= ((mx[0] > self.tw) | (mx[1] > self.tr)).to(torch.int32)
+            if self.tw >= self.cap_w and self.tr >= self.cap_r:
+                w._a2a(self.recv, self.send)
+                self.bytes += world * cb
+            else:
+                nw, nr = 16 + self.tw * 16, self.tr * 8
+                pack = torch.cat([S[:, :nw], S[:, self.off_r:self.off_r + nr]], dim=1).contiguous()
+                ph = pack[:, :8].view(torch.int32)                  # (a chunk that outgrew the prefix: the receiver must not read past what was
+                ph[:, 0].clamp_(max=self.tw); ph[:, 1].clamp_(max=self.tr)      #  shipped — the batch is redone anyway, see truncated())
+                rpack = torch.empty_like(pack)
+                w._a2a(rpack.view(-1), pack.view(-1))
+                R = self.recv.view(world, cb)
+                R[:, :nw] = rpack[:, :nw]
+                R[:, self.off_r:self.off_r + nr] = rpack[:, nw:]
+                self.bytes += world * (nw + nr)
+            self.steps += 1
+            if self.window > 0 and step % self.window == 0:
+                m = self.seen.clone()
+                w._ar(m, dist.ReduceOp.MAX)                         # (one small collective + one read per window)
+                mw, mr = (int(x) for x in m.tolist())
+                # (the prefixes stay multiples of 8 records: the packed message stays 8-byte granular for the int64 view of the collective)
+                self.tw = min(self.cap_w, (int(mw * w.EXCHANGE_MARGIN) + w.EXCHANGE_PAD + 7) & ~7)
+                self.tr = min(self.cap_r, (int(mr * w.EXCHANGE_MARGIN) + w.EXCHANGE_PAD + 7) & ~7)
+                self.seen.zero_()
+
+        def truncated(self):
+            return int(self.trunc.item()) if self.window > 0 else 0
+
     def _ar(self, t, op):
         if hasattr(self.se, "all_reduce"):
             self.se.all_reduce(t, op, self.group)
@@ -264,6 +326,7 @@ class ShardedWalker:
         dev = self.device
         paths = torch.empty((max(B * n_local, 1), stride), dtype=torch.int32, device=dev)
         lens = torch.empty(max(B * n_local, 1), dtype=torch.int32, device=dev)
+        variable = True
         while True:
             lay = self.se.layout(B, slack)
             if lay.chunk_bytes > self.MAX_MESSAGE_BYTES:
@@ -271,22 +334,29 @@ class ShardedWalker:
                                  "(batch %d, slack %.2f): walk fewer iterations per population (max_batch())"
                                  % (lay.chunk_bytes, self.MAX_MESSAGE_BYTES, B, slack))
             recv, send = self._buffers(world * lay.chunk_bytes)
+            ex = self._Exchange(self, lay, recv, send, variable=variable)
             self.se.begin(P, B, lay, recv, paths, lens)
             for step in range(1, walk_length + 2):
                 self.se.superstep(P, B, step, lay, recv, send, paths, lens)
-                self._a2a(recv, send)                         # chunk (me -> d) -> rank d's slot `me`
+                ex.run(step)                                  # chunk (me -> d) -> rank d's slot `me` (the live prefix of it)
             self.se.flush(P, B, lay, recv, paths, lens)
             st, overflow = self.se.finish()
-            t = torch.tensor([st["n_steps"], st["dead_ends"], overflow], dtype=torch.int64, device=dev)
+            trunc = ex.truncated()
+            t = torch.tensor([st["n_steps"], st["dead_ends"], overflow, trunc], dtype=torch.int64, device=dev)
             tot = t.clone()
             self._ar(tot, dist.ReduceOp.SUM)
-            if int(tot[2]) == 0:
+            if int(tot[2]) == 0 and int(tot[3]) == 0:
                 break
-            slack *= 2.0                                  # a chunk was too small somewhere: every rank retries together
-            if slack > 64:
-                raise RuntimeError("vertex-sharded walk: chunk overflow persists at 64x slack")
+            if int(tot[3]):
+                variable = False                          # a chunk outgrew its window's prefix somewhere: every rank redoes the batch with whole chunks
+                self.exchange_retries = getattr(self, "exchange_retries", 0) + 1
+            if int(tot[2]):
+                slack *= 2.0                              # a chunk was too small somewhere: every rank retries together
+                if slack > 64:
+                    raise RuntimeError("vertex-sharded walk: chunk overflow persists at 64x slack")
         st["n_steps_global"], st["dead_ends_global"] = int(tot[0]), int(tot[1])
-        st["exchange_bytes_per_superstep"] = world * lay.chunk_bytes
+        st["exchange_bytes_per_superstep"] = ex.bytes // max(ex.steps, 1)        # what crossed the wire per super-step (mean)
+        st["exchange_bytes_capacity"] = world * lay.chunk_bytes                    # ... against whole chunks
         return paths[:B * n_local], lens[:B * n_local], st
 
     def walk_populations(self, iteration=0, p=1.0, q=1.0, walk_length=80, num_walks=2, seed=42, rng="philox", const_r=0.0,
@@ -310,6 +380,7 @@ class ShardedWalker:
         if self._linked is None and p == 1.0 and q == 1.0 and rng == "philox":
             self._linked = bool(self.se.link_rows(self.group)) if hasattr(self.se, "link_rows") else False
         dev = self.device
+        variable = True
         sizes = [num_walks // 2, num_walks - num_walks // 2]
         firsts = [iteration, iteration + sizes[0]]
         Ps = [Engine.params(p=p, q=q, walk_length=walk_length, num_walks=b, first_walk=f, rng=rng, const_r=const_r, seed=seed, **(flags_kw or {}))
@@ -323,6 +394,7 @@ class ShardedWalker:
                     if lay.chunk_bytes > self.MAX_MESSAGE_BYTES:
                         raise ValueError("vertex-sharded walk: a chunk of %d bytes per peer exceeds the %d-byte exchange message limit" % (lay.chunk_bytes, self.MAX_MESSAGE_BYTES))
                 bufs = [self._buffers(world * lay.chunk_bytes, key=str(k)) for k, lay in enumerate(lays)]
+                exs = [self._Exchange(self, lays[k], bufs[k][0], bufs[k][1], variable=variable) for k in (0, 1)]
                 torch.cuda.synchronize(dev)
                 streams = [self.se.select(k) for k in (0, 1)]
                 for k in (0, 1):
@@ -334,7 +406,7 @@ class ShardedWalker:
                         self.se.select(k)
                         with torch.cuda.stream(streams[k]):
                             self.se.superstep(Ps[k], sizes[k], step, lays[k], bufs[k][0], bufs[k][1], paths[k], lens[k])
-                            self._a2a(bufs[k][0], bufs[k][1])
+                            exs[k].run(step)
                 sts, overflow = [], 0
                 for k in (0, 1):
                     self.se.select(k)
@@ -344,20 +416,26 @@ class ShardedWalker:
                     sts.append(st); overflow |= of
                 self.se.select(0)
                 torch.cuda.synchronize(dev)
-                t = torch.tensor([sts[0]["n_steps"] + sts[1]["n_steps"], sts[0]["dead_ends"] + sts[1]["dead_ends"], overflow], dtype=torch.int64, device=dev)
+                trunc = exs[0].truncated() | exs[1].truncated()
+                t = torch.tensor([sts[0]["n_steps"] + sts[1]["n_steps"], sts[0]["dead_ends"] + sts[1]["dead_ends"], overflow, trunc], dtype=torch.int64, device=dev)
                 tot = t.clone()
                 self._ar(tot, dist.ReduceOp.SUM)
-                if int(tot[2]) == 0:
+                if int(tot[2]) == 0 and int(tot[3]) == 0:
                     break
-                slack *= 2.0
-                if slack > 64:
-                    raise RuntimeError("vertex-sharded walk: chunk overflow persists at 64x slack")
+                if int(tot[3]):
+                    variable = False
+                    self.exchange_retries = getattr(self, "exchange_retries", 0) + 1
+                if int(tot[2]):
+                    slack *= 2.0
+                    if slack > 64:
+                        raise RuntimeError("vertex-sharded walk: chunk overflow persists at 64x slack")
         finally:
             self.se.select(0)
         out = []
         for k in (0, 1):
             sts[k]["n_steps_global"], sts[k]["dead_ends_global"] = (int(tot[0]), int(tot[1])) if k == 0 else (0, 0)
-            sts[k]["exchange_bytes_per_superstep"] = world * lays[k].chunk_bytes
+            sts[k]["exchange_bytes_per_superstep"] = exs[k].bytes // max(exs[k].steps, 1)
+            sts[k]["exchange_bytes_capacity"] = world * lays[k].chunk_bytes
             out.append((firsts[k], sizes[k], paths[k][:sizes[k] * n_local], lens[k][:sizes[k] * n_local], sts[k]))
         return out
 

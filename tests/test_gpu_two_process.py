@@ -46,6 +46,7 @@ def _worker(rank, world, port, directed, out_dir):
     try:
         coo = np.load(os.path.join(out_dir, "coo.npz"))
         drv = sharded.ShardedWalker(device=0, rank=rank, world=world)
+        drv.EXCHANGE_WINDOW, drv.EXCHANGE_PAD = 4, 8      # the variable-occupancy exchange at this graph's size (defaults: 8 super-steps, 256 records)
         drv.load_coo(coo["s"], coo["d"], coo["w"], directed=directed)
         for ci, case in enumerate(CASES):
             kw = dict(case)
@@ -62,6 +63,8 @@ def _worker(rank, world, port, directed, out_dir):
                 np.savez(os.path.join(out_dir, "res_%d.npz" % ci), paths=paths, lens=lens,
                          steps=sum(s["n_steps_global"] for s in stats), linked=int(bool(drv._linked)),
                          tables=sum(s.get("edge_tables", 0) for s in stats),
+                         ex_bytes=sum(s["exchange_bytes_per_superstep"] for s in stats), ex_cap=sum(s["exchange_bytes_capacity"] for s in stats),
+                         ex_retries=getattr(drv, "exchange_retries", 0),
                          table_steps=sum(s["strategy_steps"]["edge_table"] + s["strategy_steps"]["edge_mask"] for s in stats))
     finally:
         dist.destroy_process_group()
@@ -80,5 +83,7 @@ def test_two_processes_hip_engines_equal_oracle(oracle, tmp_path, directed):
         assert int(r["steps"]) == rs, case
         if case["p"] == 1.0 and case["q"] == 1.0:
             assert int(r["linked"]) == (0 if case.get("no_links") else 1), case
+        # the exchange shipped the live prefix of the chunks, not whole chunks; on the directed graph walkers die and it shrinks further
+        assert 0 < int(r["ex_bytes"]) < int(r["ex_cap"]), (case, int(r["ex_bytes"]), int(r["ex_cap"]))
         if case["q"] != 1.0:        # the shards' own per-edge tables served the second-order steps (or were switched off)
             assert (int(r["table_steps"]) > 0) == case.get("edge_tables", True), case

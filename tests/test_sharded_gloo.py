@@ -52,6 +52,22 @@ def _worker(rank, world, port, directed, p, q, L, rng, out_dir):
         drv2 = sharded.ShardedWalker(rank=rank, world=world, step_engine=OracleShardEngine(g, rank, world, tiny_chunks=True))
         p2, l2, _ = drv2.walk(num_walks=2, first_walk=3, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
         assert np.array_equal(p2, paths) and np.array_equal(l2, lens)
+        # variable-occupancy exchange: after a window of super-steps only the live prefix of every chunk section is shipped —
+        # fewer bytes than whole chunks, the same paths; a window whose prefix a chunk outgrows (margin and pad forced to nothing)
+        # raises the vote and every rank redoes the batch with whole chunks
+        drv3 = sharded.ShardedWalker(rank=rank, world=world, step_engine=OracleShardEngine(g, rank, world))
+        drv3.EXCHANGE_WINDOW = 2
+        p3, l3, st3 = drv3.walk(num_walks=2, first_walk=3, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
+        assert np.array_equal(p3, paths) and np.array_equal(l3, lens)
+        assert all(s_["exchange_bytes_per_superstep"] < 0.5 * s_["exchange_bytes_capacity"] for s_ in st3), st3
+        drv3.EXCHANGE_WINDOW, drv3.EXCHANGE_MARGIN, drv3.EXCHANGE_PAD = 1, 0.0, 0
+        p4, l4, st4 = drv3.walk(num_walks=2, first_walk=3, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
+        assert np.array_equal(p4, paths) and np.array_equal(l4, lens) and getattr(drv3, "exchange_retries", 0) >= 1
+        assert all(s_["exchange_bytes_per_superstep"] == s_["exchange_bytes_capacity"] for s_ in st4), st4
+        drv0 = sharded.ShardedWalker(rank=rank, world=world, step_engine=OracleShardEngine(g, rank, world))
+        drv0.EXCHANGE_WINDOW = 0                                # whole chunks always
+        p5, l5, st5 = drv0.walk(num_walks=2, first_walk=3, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
+        assert np.array_equal(p5, paths) and all(s_["exchange_bytes_per_superstep"] == s_["exchange_bytes_capacity"] for s_ in st5)
         # memory: a rank holds the paths of ITS walkers only
         pl, ll, _ = drv.walk_batch(iteration=3, num_walks=2, p=p, q=q, walk_length=L, seed=11, rng=rng, const_r=0.4)
         assert pl.shape[0] == 2 * drv.se.capacity()[0]

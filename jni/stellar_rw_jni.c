@@ -122,7 +122,7 @@ JNIEXPORT jlong JNICALL FN(w2vFitAndSave)(JNIEnv *env, jobject self, jlong hh, j
   rc = srw_w2v_save(vocab, vec, nv, dim, o, parts);
   (*env)->ReleaseStringUTFChars(env, out, o);
   srw_free(vocab); srw_free(vec);
-  if (rc != SRW_OK) { throw_status(env, rc == SRW_ERR_IO ? SRW_ERR_EXISTS : rc, NULL); return 0; }
+  if (rc != SRW_OK) { throw_status(env, rc, NULL); return 0; }      /* (SRW_ERR_EXISTS only for an existing model / vector directory; a full disk stays an IOException) */
   return (jlong)nv;
 }
 

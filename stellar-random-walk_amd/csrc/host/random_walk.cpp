@@ -112,8 +112,9 @@ void RandomWalk::executeOnDevice() {
   srw_walk_params P{};
   P.p = (float)config_.p; P.q = (float)config_.q;               // .toFloat, :112
   P.walk_length = config_.walkLength; P.num_walks = config_.numWalks; P.first_walk = 0;
-  P.rng_mode = SRW_RNG_PHILOX; P.const_r = 0.0f; P.seed = (uint32_t)config_.seed;
-  P.sampler = config_.alias ? SRW_SAMPLER_ALIAS : SRW_SAMPLER_REFERENCE;
+  // (--constR is honoured here as in walkImpl / executeAndSave, and it switches the alias sampler off: a constant draw is a Mode R notion)
+  P.rng_mode = config_.hasConstR ? SRW_RNG_CONST : SRW_RNG_PHILOX; P.const_r = config_.hasConstR ? config_.constR : 0.0f; P.seed = (uint32_t)config_.seed;
+  P.sampler = (config_.alias && !config_.hasConstR) ? SRW_SAMPLER_ALIAS : SRW_SAMPLER_REFERENCE;
   srw_walk_stats st{};
   check(h_, srw_walk(h_, &P, &st), "randomWalk");
   if (log_) {

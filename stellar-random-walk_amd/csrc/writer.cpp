@@ -413,8 +413,8 @@ void write_vectors_named(const std::function<void(std::string &, int64_t)> &put_
   const std::string out(output_dir);
   const std::string vdir = out + "/vec", mdir = out + "/bin";
   struct stat sb;
-  if (stat(mdir.c_str(), &sb) == 0) throw Error(SRW_ERR_IO, "Output directory " + mdir + " already exists");
-  if (stat(vdir.c_str(), &sb) == 0) throw Error(SRW_ERR_IO, "Output directory " + vdir + " already exists");
+  if (stat(mdir.c_str(), &sb) == 0) throw Error(SRW_ERR_EXISTS, "Output directory " + mdir + " already exists");
+  if (stat(vdir.c_str(), &sb) == 0) throw Error(SRW_ERR_EXISTS, "Output directory " + vdir + " already exists");
   if (mkdir(out.c_str(), 0777) != 0 && errno != EEXIST) throw Error(SRW_ERR_IO, "cannot create " + out + ": " + strerror(errno));
   std::vector<std::string> made_files, made_dirs;
   auto mk = [&](const std::string &d) {

@@ -28,9 +28,13 @@ def test_library_exports_every_declared_symbol():
     assert "gfx950" in p.version()
 
 
-def test_library_contains_gfx950_code_object():
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", pkg().LIB_PATH],
-                         capture_output=True, text=True)
+def test_library_contains_gfx950_code_object(tmp_path):
+    # (on a COPY: `llvm-objdump --offloading` writes the code objects it extracts beside its input — pointed at the library in place it
+    #  left libstellar_rw.so.N.hipv4-… files in the package directory at every run of this suite: the strays VERDICT r04 / r05 found)
+    import shutil
+    lib = str(tmp_path / "libstellar_rw.so")
+    shutil.copy(pkg().LIB_PATH, lib)
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", lib], capture_output=True, text=True, cwd=str(tmp_path))
     if out.returncode != 0:
         pytest.skip("llvm-objdump unavailable")
     assert "gfx950" in out.stdout

@@ -350,6 +350,10 @@ __global__ __launch_bounds__(TPB) void k_w2v_flatten(const int32_t *__restrict__
   const int64_t o0 = off[w], len = off[w + 1] - o0;
   for (int64_t k = lane; k < len; k += 64) flat[o0 + k] = paths[w * stride + k];
 }
+__global__ void k_w2v_widen(const unsigned int *__restrict__ in, int64_t n, unsigned long long *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
 __global__ void k_w2v_rank(const int32_t *__restrict__ order, const int32_t *__restrict__ uniq, int64_t V, int32_t *__restrict__ rank_of,
                            int32_t *__restrict__ vocab) {
   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -395,36 +399,68 @@ void w2v_fit_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens
   SRW_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
   SRW_HIP(hipStreamSynchronize(st));
   if (bad) throw Error(SRW_ERR_INVALID, "word2vec: a path length outside [0, stride]");
-  if (total >= (long long)0xFFFFFFF0ll) throw Error(SRW_ERR_INVALID, "word2vec: more than 2^32 tokens in one fit");
   if (total == 0) return;
-  // tokens, sorted tokens, (id, count)
-  DevBuf<int32_t> d_sent, d_sorted, d_uniq; DevBuf<unsigned int> d_cnt, d_runs;
-  d_sent.alloc((size_t)total); d_sorted.alloc((size_t)total);
+  // tokens, then the vocabulary (id, count) — chunk by chunk (the reference's defaults numWalks = 10, walkLength = 80 exceed
+  // 2^32 tokens from ~5.3 M vertices on, and rocprim's run_length_encode takes a 32-bit size): every chunk of at most 2^30 tokens is
+  // sorted and run-length encoded on its own, its (id, count) runs are merged into the standing set (sort by id + reduce_by_key), the
+  // counts are 64-bit.  SRW_W2V_VOCAB_CHUNK (tokens): tests merge many small chunks.
+  DevBuf<int32_t> d_sent, d_sorted, d_uniq_c; DevBuf<unsigned int> d_cnt_c, d_runs;
+  d_sent.alloc((size_t)total);
   hipLaunchKernelGGL(k_w2v_flatten, dim3((unsigned)((n + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0, st, d_paths, d_off.p, n, stride, d_sent.p);
   SRW_HIP(hipGetLastError());
-  SRW_HIP(rocprim::radix_sort_keys(nullptr, tb, d_sent.p, d_sorted.p, (size_t)total, 0, 32, st));
-  temp.alloc(tb);
-  SRW_HIP(rocprim::radix_sort_keys((void *)temp.p, tb, d_sent.p, d_sorted.p, (size_t)total, 0, 32, st));
-  // (the number of distinct ids is not known before the encode: room for one run per token, released below)
-  d_uniq.alloc((size_t)total); d_cnt.alloc((size_t)total); d_runs.alloc(1);
-  SRW_HIP(rocprim::run_length_encode(nullptr, tb, d_sorted.p, (unsigned int)total, d_uniq.p, d_cnt.p, d_runs.p, st));
-  temp.alloc(tb);
-  SRW_HIP(rocprim::run_length_encode((void *)temp.p, tb, d_sorted.p, (unsigned int)total, d_uniq.p, d_cnt.p, d_runs.p, st));
-  unsigned int runs = 0;
-  SRW_HIP(hipMemcpyAsync(&runs, d_runs.p, 4, hipMemcpyDeviceToHost, st));
-  SRW_HIP(hipStreamSynchronize(st));
-  d_sorted.release();
-  const int64_t V = (int64_t)runs;
+  size_t CH = (size_t)1 << 30;
+  if (const char *e = getenv("SRW_W2V_VOCAB_CHUNK"); e && atoll(e) > 0) CH = (size_t)atoll(e);
+  const size_t ch_max = std::min<size_t>(CH, (size_t)total);
+  d_sorted.alloc(ch_max); d_uniq_c.alloc(ch_max); d_cnt_c.alloc(ch_max); d_runs.alloc(1);
+  DevBuf<int32_t> d_uniq; DevBuf<unsigned long long> d_cnt;       // the standing set: ids ascending, their counts
+  size_t R = 0;
+  for (size_t c0 = 0; c0 < (size_t)total; c0 += CH) {
+    const size_t nc = std::min(CH, (size_t)total - c0);
+    SRW_HIP(rocprim::radix_sort_keys(nullptr, tb, d_sent.p + c0, d_sorted.p, nc, 0, 32, st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::radix_sort_keys((void *)temp.p, tb, d_sent.p + c0, d_sorted.p, nc, 0, 32, st));
+    SRW_HIP(rocprim::run_length_encode(nullptr, tb, d_sorted.p, (unsigned int)nc, d_uniq_c.p, d_cnt_c.p, d_runs.p, st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::run_length_encode((void *)temp.p, tb, d_sorted.p, (unsigned int)nc, d_uniq_c.p, d_cnt_c.p, d_runs.p, st));
+    unsigned int runs = 0;
+    SRW_HIP(hipMemcpyAsync(&runs, d_runs.p, 4, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    // standing set + this chunk's runs -> sorted by id -> equal ids summed
+    const size_t m = R + runs;
+    DevBuf<int32_t> k_in, k_sorted, k_out; DevBuf<unsigned long long> v_in, v_sorted, v_out; DevBuf<unsigned long long> d_m;
+    k_in.alloc(m); v_in.alloc(m);
+    if (R) {
+      SRW_HIP(hipMemcpyAsync(k_in.p, d_uniq.p, R * 4, hipMemcpyDeviceToDevice, st));
+      SRW_HIP(hipMemcpyAsync(v_in.p, d_cnt.p, R * 8, hipMemcpyDeviceToDevice, st));
+    }
+    SRW_HIP(hipMemcpyAsync(k_in.p + R, d_uniq_c.p, (size_t)runs * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_w2v_widen, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, st, d_cnt_c.p, (int64_t)runs, v_in.p + R);
+    SRW_HIP(hipGetLastError());
+    if (R == 0) { d_uniq = std::move(k_in); d_cnt = std::move(v_in); R = m; continue; }      // (the first chunk's runs are sorted and distinct already)
+    k_sorted.alloc(m); v_sorted.alloc(m); k_out.alloc(m); v_out.alloc(m); d_m.alloc(1);
+    SRW_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_in.p, k_sorted.p, v_in.p, v_sorted.p, m, 0, 32, st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::radix_sort_pairs((void *)temp.p, tb, k_in.p, k_sorted.p, v_in.p, v_sorted.p, m, 0, 32, st));
+    SRW_HIP(rocprim::reduce_by_key(nullptr, tb, k_sorted.p, v_sorted.p, m, k_out.p, v_out.p, d_m.p, rocprim::plus<unsigned long long>(), rocprim::equal_to<int32_t>(), st));
+    temp.alloc(tb);
+    SRW_HIP(rocprim::reduce_by_key((void *)temp.p, tb, k_sorted.p, v_sorted.p, m, k_out.p, v_out.p, d_m.p, rocprim::plus<unsigned long long>(), rocprim::equal_to<int32_t>(), st));
+    unsigned long long merged = 0;
+    SRW_HIP(hipMemcpyAsync(&merged, d_m.p, 8, hipMemcpyDeviceToHost, st));
+    SRW_HIP(hipStreamSynchronize(st));
+    d_uniq = std::move(k_out); d_cnt = std::move(v_out); R = (size_t)merged;
+  }
+  d_sorted.release(); d_uniq_c.release(); d_cnt_c.release();
+  const int64_t V = (int64_t)R;
   // vocabulary order: count descending, ties by ascending id (a stable sort of the id-ordered runs)
-  DevBuf<unsigned int> d_cnt_s; DevBuf<int32_t> d_iota, d_order, d_rank, d_vocab;
+  DevBuf<unsigned long long> d_cnt_s; DevBuf<int32_t> d_iota, d_order, d_rank, d_vocab;
   d_cnt_s.alloc((size_t)V); d_iota.alloc((size_t)V); d_order.alloc((size_t)V); d_rank.alloc((size_t)V); d_vocab.alloc((size_t)V);
   {
     std::vector<int32_t> iota((size_t)V);
     std::iota(iota.begin(), iota.end(), 0);
     SRW_HIP(hipMemcpyAsync(d_iota.p, iota.data(), (size_t)V * 4, hipMemcpyHostToDevice, st));
-    SRW_HIP(rocprim::radix_sort_pairs_desc(nullptr, tb, d_cnt.p, d_cnt_s.p, d_iota.p, d_order.p, (size_t)V, 0, 32, st));
+    SRW_HIP(rocprim::radix_sort_pairs_desc(nullptr, tb, d_cnt.p, d_cnt_s.p, d_iota.p, d_order.p, (size_t)V, 0, 64, st));
     temp.alloc(tb);
-    SRW_HIP(rocprim::radix_sort_pairs_desc((void *)temp.p, tb, d_cnt.p, d_cnt_s.p, d_iota.p, d_order.p, (size_t)V, 0, 32, st));
+    SRW_HIP(rocprim::radix_sort_pairs_desc((void *)temp.p, tb, d_cnt.p, d_cnt_s.p, d_iota.p, d_order.p, (size_t)V, 0, 64, st));
     SRW_HIP(hipStreamSynchronize(st));      // (iota is a host vector)
   }
   hipLaunchKernelGGL(k_w2v_rank, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d_order.p, d_uniq.p, V, d_rank.p, d_vocab.p);
@@ -432,9 +468,9 @@ void w2v_fit_device(srw_handle *h, const int32_t *d_paths, const int32_t *d_lens
   hipLaunchKernelGGL(k_w2v_remap, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_sent.p, (int64_t)total, d_uniq.p, V, d_rank.p);
   SRW_HIP(hipGetLastError());
   vocab_ids.resize((size_t)V);
-  std::vector<unsigned int> cnt_h((size_t)V);
+  std::vector<unsigned long long> cnt_h((size_t)V);
   SRW_HIP(hipMemcpyAsync(vocab_ids.data(), d_vocab.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
-  SRW_HIP(hipMemcpyAsync(cnt_h.data(), d_cnt_s.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+  SRW_HIP(hipMemcpyAsync(cnt_h.data(), d_cnt_s.p, (size_t)V * 8, hipMemcpyDeviceToHost, st));
   DevBuf<float> d_syn0, d_syn1;
   d_syn0.alloc((size_t)V * P.dim); d_syn1.alloc((size_t)V * P.dim);
   hipLaunchKernelGGL(k_w2v_init, dim3((unsigned)(((int64_t)V * P.dim + 255) / 256)), dim3(256), 0, st, d_syn0.p, V, P.dim, P.seed);

@@ -53,6 +53,22 @@ def test_sequential_mode_matches_the_cpu_restatement(eng, oracle, dim, window):
     assert np.array_equal(i0, o0) and np.array_equal(v0, ov0)
 
 
+def test_vocabulary_built_in_chunks_is_the_same_vocabulary(eng, oracle, monkeypatch):
+    """more than 2^32 tokens in one fit (numWalks 10 x walkLength 80 from ~5.3 M vertices on) — the vocabulary is built chunk by
+    chunk (sort + run-length encode per chunk of 2^30 tokens, runs merged by id, 64-bit counts).  Here: chunks of 37 / 1 000 tokens."""
+    g = oracle.Graph.load(KARATE)
+    eng.load_edgelist(KARATE, directed=False)
+    paths, lens, _ = eng.walk(p=0.5, q=2.0, walk_length=30, num_walks=6, seed=5)
+    ref_ids, ref_vec = eng.w2v_fit(paths, lens, dim=32, window=5, iterations=2, lr=0.025, seed=11, threads=1)
+    oids, _ = oracle.w2v_fit(paths, lens, dim=32, window=5, iterations=0, seed=11)
+    assert np.array_equal(ref_ids, oids)
+    for chunk in ("37", "1000"):
+        monkeypatch.setenv("SRW_W2V_VOCAB_CHUNK", chunk)
+        ids, vec = eng.w2v_fit(paths, lens, dim=32, window=5, iterations=2, lr=0.025, seed=11, threads=1)
+        monkeypatch.delenv("SRW_W2V_VOCAB_CHUNK")
+        assert np.array_equal(ids, ref_ids) and np.array_equal(vec, ref_vec), chunk
+
+
 @pytest.mark.parametrize("dim,n_words", [(96, 27), (160, 26), (40, 20)])
 def test_deep_huffman_codes(eng, oracle, dim, n_words):
     """Fibonacci counts give the deepest tree a vocabulary can have (code length n_words - 1): the rare words' codes are longer than the

@@ -677,6 +677,6 @@ int32_t srw_save_paths(const int32_t *paths, const int32_t *lens, int64_t n_walk
 }
 
 #include "version.h"      // build/version.h: SRW_GIT_REV (Makefile)
-const char *srw_version(void) { return "stellar_rw gfx950 r5 " SRW_GIT_REV; }
+const char *srw_version(void) { return "stellar_rw gfx950 r6 " SRW_GIT_REV; }
 
 }  // extern "C"

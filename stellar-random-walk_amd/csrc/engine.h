@@ -181,6 +181,9 @@ struct srw_handle {
   srw::DevBuf<srw::DevCounters> counters;
   srw::DevBuf<unsigned long long> walk_cursor;   // [0] next walker of the persistent kernels, [1] walkers handed over by k_walk_tables
   srw::DevBuf<int32_t> walk_todo;                // their indices
+  srw::DevBuf<char> round_state;                 // the table walk in rounds (walk_rounds.hip): 80 B of parked state per walker ...
+  srw::DevBuf<int32_t> round_list;               // ... the two work lists (walkers a lane advances | walkers whose next step the wave serves) ...
+  srw::DevBuf<unsigned long long> round_ctr;     // ... their lengths and the kernels' cursors
   int n_cus = 256;
   int64_t planned_walks = 0;                     // srw_plan_walks: the job's numWalks (0: unknown -> the reference's default 10)
   double shard_prof_acc[4] = {0, 0, 0, 0}, shard_prof_mx[4] = {0, 0, 0, 0};   // SRW_SHARD_PROFILE: per-kernel times of the super-steps (run_shard_superstep)

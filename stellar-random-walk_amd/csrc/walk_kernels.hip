@@ -2308,7 +2308,9 @@ LaunchInfo launch_walk(srw_handle *h, const srw_walk_params &P, int32_t num_walk
       // (config 5's stand-in: 4.13 against 3.34 s) — profiles/r06_lane_kernel.md.  SRW_TABLE_LANES=<mode> forces the lane kernel (bit 0: whole
       // rows per lane, bit 1: table steps per lane), -1 the wave kernel.
       const int lanes = getenv("SRW_TABLE_LANES") ? atoi(getenv("SRW_TABLE_LANES")) : (gv.ebp.min_sh <= 6 ? 2 : -1);
-      if (lanes >= 0) {
+      if (getenv("SRW_TABLE_ROUNDS") && atoi(getenv("SRW_TABLE_ROUNDS")) != 0) {        // the table walk in rounds of two kernels (walk_rounds.hip)
+        launch_walk_tables_rounds(h, ta, gv.bf_off != nullptr, getenv("SRW_LANE_CSH") ? atoi(getenv("SRW_LANE_CSH")) : 6, st);
+      } else if (lanes >= 0) {
         launch_walk_tables_lanes(ta, gv.bf_off != nullptr, lanes, getenv("SRW_LANE_CSH") ? atoi(getenv("SRW_LANE_CSH")) : 6, h->n_cus, st);
       } else if (groups) {
         launch_walk_tables_groups(ta, gv.bf_off != nullptr, h->n_cus, st);

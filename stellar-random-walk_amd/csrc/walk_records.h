@@ -37,4 +37,7 @@ void launch_walk_tables_groups(const TabArgs &ta, bool row_filters, int n_cus, h
 // walk_lanes.hip: ... with one walker per lane; mode bit 0: mask rows per lane, bit 1: table steps per lane (0: every step served by the wave)
 void launch_walk_tables_lanes(const TabArgs &ta, bool row_filters, int mode, int max_csh, int n_cus, hipStream_t st);
 
+// walk_rounds.hip: ... in rounds of two kernels (lanes advance, the wave serves one parked step per walker)
+void launch_walk_tables_rounds(srw_handle *h, const TabArgs &ta, bool row_filters, int max_csh, hipStream_t st);
+
 }  // namespace srw

@@ -336,7 +336,8 @@ def test_mapped_table_buffer_gives_its_memory_back():
     assert f5 >= f0 - (1 << 30), (f0, f5)               # everything is back once the engine is closed (what stays: the runtime's own pools — kernel scratch, code objects)
 
 
-@pytest.mark.parametrize("kernel", [{}, {"SRW_TABLE_LANES": "3"}, {"SRW_TABLE_LANES": "0"}, {"SRW_TABLE_LANES": "2", "SRW_LANE_CSH": "8"}, {"SRW_TABLE_GROUPS": "1", "SRW_TABLE_LANES": "-1"}])
+@pytest.mark.parametrize("kernel", [{}, {"SRW_TABLE_LANES": "3"}, {"SRW_TABLE_LANES": "0"}, {"SRW_TABLE_LANES": "2", "SRW_LANE_CSH": "8"}, {"SRW_TABLE_GROUPS": "1", "SRW_TABLE_LANES": "-1"},
+                                    {"SRW_TABLE_ROUNDS": "1"}, {"SRW_TABLE_ROUNDS": "1", "SRW_LANE_CSH": "8"}])
 def test_table_kernels_walk_every_walker_alike(oracle, monkeypatch, kernel):
     """The table walk has three kernels: one walker per wave (k_walk_tables, SRW_TABLE_LANES=-1: the reference here), one per lane
     (walk_lanes.hip: the default — {} — where the tables' chunks are 64 candidates; modes: rows + tables per lane, every step served by the

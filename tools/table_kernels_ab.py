@@ -1,6 +1,6 @@
 """Scratch (round 6): the table-walk kernels against each other on one graph, in ONE process (the tables are built once): every walker of
 one iteration compared with the one-walker-per-wave kernel, then kernel times alternated.
-usage: table_kernels_ab.py SCALE[w][d] P Q [iters] [ef] [L] [variants, comma separated: waves,groups,lanes0,lanes1,lanes2,lanes3]"""
+usage: table_kernels_ab.py SCALE[w][d] P Q [iters] [ef] [L] [variants, comma separated: waves,groups,rounds,lanes0,lanes1,lanes2,lanes3]"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -15,12 +15,13 @@ sc = int(spec.rstrip("wd"))
 eng = pkg.Engine(0)
 eng.generate_rmat(sc, ef << sc, seed=42, weighted="w" in spec, directed="d" in spec)
 def run(v, fetch, it):
-    for k in ("SRW_TABLE_GROUPS", "SRW_TABLE_LANES"): os.environ.pop(k, None)
+    for k in ("SRW_TABLE_GROUPS", "SRW_TABLE_LANES", "SRW_TABLE_ROUNDS"): os.environ.pop(k, None)
     if v == "groups": os.environ["SRW_TABLE_GROUPS"] = "1"
+    elif v == "rounds": os.environ["SRW_TABLE_ROUNDS"] = "1"
     elif v.startswith("lanes"): os.environ["SRW_TABLE_LANES"] = v[5:]
     elif v == "waves": os.environ["SRW_TABLE_LANES"] = "-1"
     r = eng.walk(fetch=fetch, walk_length=L, num_walks=1, first_walk=it, seed=42, p=p, q=q)
-    for k in ("SRW_TABLE_GROUPS", "SRW_TABLE_LANES"): os.environ.pop(k, None)
+    for k in ("SRW_TABLE_GROUPS", "SRW_TABLE_LANES", "SRW_TABLE_ROUNDS"): os.environ.pop(k, None)
     return r
 ref = None; ok = True
 for v in ["waves"] + [x for x in variants if x != "waves"]:

@@ -115,8 +115,7 @@ __global__ __launch_bounds__(TPB, SRW_ROUND_LANE_WAVES) void k_round_lanes(Round
         if (!active && !exhausted) {
           const unsigned long long li = g0 + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
           if (li >= n_in) exhausted = true;
-          else {
-            wi = aw.list_in[li];
+          else if ((wi = aw.list_in[li]) >= 0) {       // (-1: a walker the wave finished or handed over — the slot is a hole)
             const uint4 *sp = reinterpret_cast<const uint4 *>(aw.state + wi);
             const uint4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
             eprev = (int64_t)(((uint64_t)q0.y << 32) | q0.x);
@@ -131,7 +130,8 @@ __global__ __launch_bounds__(TPB, SRW_ROUND_LANE_WAVES) void k_round_lanes(Round
         }
       }
     }
-    if (!__ballot(active)) break;
+    if (!__ballot(active || !exhausted)) break;
+    bool park = false;
     if (active) {
       const RoundArgs as = RARGS();
       const GraphView &gs = as.t.g;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(TPB, SRW_ROUND_LANE_WAVES) void k_round_lanes(Round
         q.x = (uint32_t)curr; q.y = w_tab; q.z = w_mask; q.w = w_srch; sp[2] = q;
         q.x = (uint32_t)r.off; q.y = (uint32_t)((uint64_t)r.off >> 32); q.z = (uint32_t)r.deg; q.w = r.flags; sp[3] = q;
         q.x = eo; q.y = __float_as_uint(u); q.z = 0u; q.w = 0u; sp[4] = q;
-        as.list_out[atomicAdd(as.n_out, 1ull)] = (int32_t)wi;
+        park = true;
         active = false;
       } else if (k < 0) {                              // no table / a boundary draw: the general kernel takes the walker
         int32_t tie_rec = -1;
@@ -195,6 +195,18 @@ __global__ __launch_bounds__(TPB, SRW_ROUND_LANE_WAVES) void k_round_lanes(Round
           finish_walker(as.t, wi, s, w_tab, w_mask, w_srch, tot);
           active = false;
         }
+      }
+    }
+    {   // the walkers parked in this trip join the wave's list: ONE atomic per wave (one per walker on one address serialises the GPU:
+        // the first version of this file spent 8.4 s per iteration of config 3 on it)
+      const unsigned long long pm = __ballot(park);
+      if (pm) {
+        const RoundArgs ap = RARGS();
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(ap.n_out, (unsigned long long)__popcll(pm));
+        const unsigned long long b0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        if (park) ap.list_out[b0 + (unsigned long long)__popcll(pm & ((1ull << lane) - 1ull))] = (int32_t)wi;
       }
     }
   }
@@ -217,13 +229,12 @@ __global__ __launch_bounds__(TPB, SRW_ROUND_SERVE_WAVES) void k_round_serve(Roun
   const int64_t stride = (int64_t)L + 2;
   const bool identity = a0.list_in == nullptr;         // the first launch of a walk: every walker, fresh
   const unsigned long long n_in = identity ? (unsigned long long)a0.t.n_walkers : *a0.n_in;
-  while (true) {
-    unsigned long long grab = 0;
+  // (no cursor, no append: wave w takes entries w, w + waves, ... — one step each, hundreds per wave — and answers in the SAME slot of the
+  //  lanes' list, -1 where the walker finished or was handed over)
+  const unsigned long long wave_id = (unsigned long long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), n_waves = (unsigned long long)gridDim.x * (TPB / 64);
+  if (wave_id == 0 && lane == 0) *a0.n_out = n_in;
+  for (unsigned long long li = wave_id; li < n_in; li += n_waves) {
     const RoundArgs aw = RARGS();
-    if (lane == 0) grab = atomicAdd(aw.cursor, 1ull);
-    const unsigned long long li = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(grab >> 32)) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)grab);
-    if (li >= n_in) break;
     const int64_t wi = identity ? (int64_t)li : (int64_t)__builtin_amdgcn_readfirstlane(aw.list_in[li]);
     // the parked step (scalar loads: the state was written by an EARLIER launch)
     Row r, rprev;
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(TPB, SRW_ROUND_SERVE_WAVES) void k_round_serve(Roun
     int32_t *path = aw.t.paths + wi * stride;
     if (r.deg == 0) {                                  // (only a fresh walker can stand on a row without candidates here)
       for (int64_t x = s + lane; x < stride; x += 64) path[x] = -1;
-      if (lane == 0) finish_walker(aw.t, wi, s, w_tab, w_mask, w_srch, tot);
+      if (lane == 0) { finish_walker(aw.t, wi, s, w_tab, w_mask, w_srch, tot); aw.list_out[li] = -1; }
       continue;
     }
     unsigned f = 0, sv = 0;
@@ -284,12 +295,12 @@ __global__ __launch_bounds__(TPB, SRW_ROUND_SERVE_WAVES) void k_round_serve(Roun
     next = uni(next);
     const RoundArgs ao = RARGS();
     if (k < 0) {
-      if (lane == 0) hand_over(ao.t, wi, tie_rec);
+      if (lane == 0) { hand_over(ao.t, wi, tie_rec); ao.list_out[li] = -1; }
       continue;
     }
     if (lane == 0) path[s] = next;
     if (s + 1 > L + 1) {                               // the path is complete
-      if (lane == 0) finish_walker(ao.t, wi, s + 1, w_tab, w_mask, w_srch, tot);
+      if (lane == 0) { finish_walker(ao.t, wi, s + 1, w_tab, w_mask, w_srch, tot); ao.list_out[li] = -1; }
       continue;
     }
     if (lane == 0) {                                   // back to the lanes
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(TPB, SRW_ROUND_SERVE_WAVES) void k_round_serve(Roun
       q.x = (uint32_t)eprev; q.y = (uint32_t)((uint64_t)eprev >> 32); q.z = (uint32_t)r.off; q.w = (uint32_t)((uint64_t)r.off >> 32); sp[0] = q;
       q.x = (uint32_t)r.deg; q.y = r.flags; q.z = (uint32_t)(s + 1); q.w = (uint32_t)curr; sp[1] = q;
       q.x = (uint32_t)next; q.y = w_tab; q.z = w_mask; q.w = w_srch; sp[2] = q;
-      ao.list_out[atomicAdd(ao.n_out, 1ull)] = (int32_t)wi;
+      ao.list_out[li] = (int32_t)wi;
     }
   }
   __builtin_amdgcn_wave_barrier();

@@ -340,8 +340,19 @@ def measure(eng, walk_kw, K, W, first_walk=0):
     return steps, dt, kernel_ms, stats, (setup_ms + inner_setup) * 1e-3
 
 
-def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L=80, ceiling=None, plan_walks=0):
-    """One BASELINE configuration on one GPU: graph generated on the device, W + K walk iterations."""
+def run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L=80, ceiling=None, plan_walks=0, pmc=False):
+    """One BASELINE configuration on one GPU: graph generated on the device, W + K walk iterations.  pmc: afterwards (the engine closed: its
+    tables fill most of the GPU) the child rocprofv3 --pmc passes over the same workload — the row's traffic and request count, in this run."""
+    out = _run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L, ceiling, plan_walks)
+    if pmc and "roofline" in out and time.perf_counter() - T_START < 330:
+        spec = "%d%s%s" % (scale, "w" if weighted else "", "d" if directed else "")
+        pm = pmc_child_pass("k_walk_tables", [spec, p, q, sampler, 2, ef], timeout_s=150)
+        if pm is not None:
+            apply_pmc(out["roofline"], pm, out["kernel_ms"], out["walk_steps_per_bench_step"], ceiling)
+    return out
+
+
+def _run_config(pkg, device, name, scale, ef, weighted, directed, p, q, sampler, K, W, L=80, ceiling=None, plan_walks=0):
     import torch
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -971,7 +982,7 @@ def main():
             for (name, sc, ef, wt, dr, p, q, smp, k, w) in plan:
                 sc = min(sc, cap)
                 leg(name, lambda: run_config(pkg, local_rank, name, sc, ef, wt, dr, p, q, smp, k, w, ceiling=ceiling,
-                                             plan_walks=100 if "numWalks=100" in name else 0))
+                                             plan_walks=100 if "numWalks=100" in name else 0, pmc=bool(args.pmc) and name == "C3 Mode R"))
             if args.shard in ("both", "vertex"):
                 leg("sharded w1 p=q=1", lambda: run_sharded_world1(pkg, local_rank, scale=min(24, cap)))
                 rep = {c.get("name"): c.get("value") for c in cfgs}

@@ -1745,6 +1745,10 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
   SumCert cert;
   bool neg = false;
   const BiasDiv bdiv(b.p, b.q);
+  // A row that holds the per-call certificate (ROW_PQ_OK, sampler_tables.hip:k_pq_*: every variant w, fl(w/p), fl(w/q) of every candidate
+  // finite and >= 0, every sum of variants exact in any order) needs no certificate of THIS step's weights: they are variants of that row.
+  // (Round 6: ~60 of the mask step's ~250 vector instructions — the per-candidate exponent bookkeeping and two wave reductions.)
+  const bool certified = uni((uint32_t)(rc.flags & ROW_PQ_OK)) != 0u;
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int32_t k = i * 64 + lane;
@@ -1753,13 +1757,17 @@ __device__ inline int32_t wave_pick_masked(const GraphView &g, const Row &rc, co
       const Ent e = load_ent(g, row, k);
       const float w = bdiv(e.w, e.id == b.prev, ((mw[i] >> (lane & 31)) & 1u) != 0u);
       wv[i] = w; idv[i] = e.id;
-      part += (double)w; cert.add(w); neg |= !(w >= 0.0f);
+      part += (double)w;
+      if (!certified) { cert.add(w); neg |= !(w >= 0.0f); }
     }
   }
-  const int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
-  const bool bad = __any(cert.bad) || __any(neg);
-  const double S_par = wave_total_f64(part);               // (used only under the certificate below: exact in any order)
-  if (bad || !sum_is_exact(emin, emax, false, deg) || !(S_par > 0.0)) {     // (S = 0: the reference divides by zero -> chain)
+  bool uncertain = false;
+  if (!certified) {
+    const int emin = wave_min_i32(cert.emin), emax = wave_max_i32(cert.emax);
+    uncertain = __any(cert.bad) || __any(neg) || !sum_is_exact(emin, emax, false, deg);
+  }
+  const double S_par = wave_total_f64(part);               // (used only under a certificate: exact in any order)
+  if (uncertain || !(S_par > 0.0)) {     // (S = 0: the reference divides by zero -> chain)
     if (!CHAIN) return CHAIN_NEEDED;
     unsigned f = 0;
     const double Sc = wave_sum_exact_or_chain(row, deg, b, f);

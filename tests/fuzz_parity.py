@@ -1,5 +1,5 @@
 """Randomized differential test: HIP path vs CPU oracle (test infrastructure; run on the GPU box).
-usage: python tests/fuzz_parity.py [seconds] [seed]; test_gpu_parity.py runs 8 s of it."""
+usage: python tests/fuzz_parity.py [seconds] [seed] [giant] [kernels]; test_gpu_parity.py runs 8 s of it.  kernels: every table-walk kernel form (waves / lanes modes / groups / rounds)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -7,7 +7,7 @@ import numpy as np
 import _pkg
 import oracle_py as oracle
 pkg = _pkg.load()
-def run(budget=60.0, seed=1, eng=None, giant=False):
+def run(budget=60.0, seed=1, eng=None, giant=False, kernels=False):
     rng = np.random.default_rng(seed)
     eng = eng or pkg.Engine(0)
     t0, n_graphs, n_walks = time.time(), 0, 0
@@ -66,8 +66,22 @@ def run(budget=60.0, seed=1, eng=None, giant=False):
             variants = [dict(), dict(force_general=True), dict(edge_tables_all=True), dict(edge_tables=False),
                         dict(binned_tune=8 | int(rng.integers(1, 5)), edge_tables=False), dict(hub_bitmaps=False, edge_tables=False),
                         dict(binned=False), dict(prefix=False), dict(compact=False)]
+            # the table walk's kernels (round 6): the default picks by the tables' geometry; the others are forced through their switches,
+            # with the default tables and with a table for every certified pair (chunks of 4 candidates)
+            if kernels:
+                for env in ({"SRW_TABLE_LANES": "-1"}, {"SRW_TABLE_LANES": "3"}, {"SRW_TABLE_LANES": "2", "SRW_LANE_CSH": "8"}, {"SRW_TABLE_LANES": "0"},
+                            {"SRW_TABLE_GROUPS": "1", "SRW_TABLE_LANES": "-1"}, {"SRW_TABLE_ROUNDS": "1"}):
+                    variants.append(dict(_env=env))
+                    variants.append(dict(_env=env, edge_tables_all=True))
             for v in variants:
-                got = eng.walk(**kw, **v)
+                v = dict(v)
+                env = v.pop("_env", None) or {}
+                for k_, x_ in env.items(): os.environ[k_] = x_
+                try:
+                    got = eng.walk(**kw, **v)
+                finally:
+                    for k_ in env: os.environ.pop(k_, None)
+                if env: v["_env"] = env
                 n_walks += 1
                 gp, gl = (got[0], got[1]) if sel is None else (got[0][sel], got[1][sel])
                 if not (np.array_equal(gp, ref[0]) and np.array_equal(gl, ref[1]) and (sel is not None or got[2]["n_steps"] == ref[2])):
@@ -88,5 +102,6 @@ def run(budget=60.0, seed=1, eng=None, giant=False):
 
 
 if __name__ == "__main__":
-    ok = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, giant=len(sys.argv) > 3)
+    ok = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, giant=len(sys.argv) > 3 and "giant" in sys.argv[3:],
+             kernels="kernels" in sys.argv[3:])
     sys.exit(0 if ok else 1)

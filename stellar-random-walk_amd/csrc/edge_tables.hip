@@ -388,10 +388,16 @@ __global__ __launch_bounds__(TPB, (SRW_EB_HC > 1024 && SRW_EB_WAVES > 3) ? 3 : S
       const BinGeom gf = (big || gc.csh < 6) ? gc : bin_geometry(rv.deg, 6, BIN_CAP);     // fill granularity: the walk's own
       double *gbins = big ? gscratch + ((int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) * gs_stride : nullptr;
       unsigned long long ab = 0; unsigned su = 0;
-      // chunk masks (rows of at most EB_CM_LIMIT candidates: at most 256 fill bins, the upper half of the bins' LDS is free)
-      uint32_t *mbits = pg.cmask ? mine + BIN_CAP : nullptr;
+      // chunk masks: rows of at most EB_CM_LIMIT candidates have at most 256 fill bins, the upper half of the bins' LDS is free for the pair's
+      // bits; a LONGER row's bits (round 6) are OR-ed straight into the pair's table block in HBM (binned_fill clears them first; the
+      // block is this wave's alone)
+      const double *out0 = eb_bins + (size_t)tab_word * 8;
+      const bool long_mask = pg.cmask && rv.deg > EB_CM_LIMIT;
+      uint32_t *mbits = !pg.cmask ? nullptr : !long_mask ? mine + BIN_CAP
+                        : reinterpret_cast<uint32_t *>(const_cast<double *>(out0) + (size_t)eb_layout(pol.f32 && (rv.flags & ROW_PQ_F32), gc.n_bins, true, rv.deg, eb_pair_u16(rv.flags, gc.csh, pol)).cm_off * 8);
+      if (long_mask && lane == 0 && (((rv.deg + 31) >> 5) & 1)) mbits[(rv.deg + 31) >> 5] = 0u;      // (the upper half of the last 64-bit word)
       if (big) binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K, true, SRW_EB_HC>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits, gbins);
-      else binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K, false, SRW_EB_HC>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits);
+      else binned_fill<SRW_EB_PREFETCH, SRW_EB_P1K, false, SRW_EB_HC>(g, rv, b, mine, fill_tune, gf, tm, ab, su, mbits, nullptr, long_mask);
       ns[su & 7] += 1;
 #ifdef SRW_PHASE_TIMING
       const unsigned long long t_fill = wall_clock64();
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(TPB, (SRW_EB_HC > 1024 && SRW_EB_WAVES > 3) ? 3 : S
           } else lo_[t] = a;
         }
       }
-      if (mbits) {
+      if (mbits && !long_mask) {
         unsigned long long *mo = reinterpret_cast<unsigned long long *>(out + (size_t)lay.cm_off * 8);
         const int32_t n_mw = (rv.deg + 63) >> 6, n_w32 = (rv.deg + 31) >> 5;
         for (int32_t t = lane; t < n_mw; t += 64)
@@ -521,7 +527,7 @@ static int32_t eb_cm_select(const Graph &g, int mode, int min_sh) {
   if (mode || min_sh < 6) return 0;
   const char *e = getenv("SRW_EB_CM_MAX");
   const int32_t v = e && *e ? atoi(e) : g.eb_cm_sel;
-  return v < MASK_MAX_DEG ? 0 : v > EB_CM_LIMIT ? EB_CM_LIMIT : v;
+  return v < MASK_MAX_DEG ? 0 : v;      // (beyond EB_CM_LIMIT: long masks, sampling.h:eb_pair_geometry)
 }
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
 // The geometry of the next set of tables: Graph::eb_min_sh_sel / eb_cm_sel / eb_fine_cap_sel are the planners' choices

@@ -984,13 +984,16 @@ struct BinGeom { int csh; int32_t n_bins; };
 // of floats) instead of striding over the whole table, and S = the last element of the top level.  Layout of a pair's block,
 // each part padded to 64 bytes: [level 2][level 1][level 0][chunk masks].
 struct PairGeom { int csh; int32_t n_bins; bool cmask; };
+constexpr int32_t EB_CM_LIMIT = 16384;         // the build keeps the mask of one pair in 2 KB of the wave's LDS; longer rows: straight into the table block
 __host__ __device__ inline BinGeom bin_geometry(int32_t deg, int min_sh, int cap);
 __host__ __device__ inline PairGeom eb_pair_geometry(int32_t dv, int32_t du, const EbPolicy &P) {
   const BinGeom b = bin_geometry(dv, P.min_sh, P.cap);
   PairGeom g; g.csh = b.csh; g.n_bins = b.n_bins; g.cmask = false;
   // (a shorter N(prev) is staged in LDS by the walk — deg(prev) / 16 lines per step — unless the row is short enough for the mask to be the
   //  cheaper thing to keep: deg(curr) / 8 bytes of mask against deg(prev) x 4 bytes of staging traffic per visit, cm_ratio = deg(curr) / deg(prev))
-  if (dv <= P.cm_max && b.csh >= 6 && (du > P.cm_min_du || (du > 32 && (int64_t)dv <= (int64_t)P.cm_ratio * du))) g.cmask = true;
+  // (round 6: cm_max may exceed EB_CM_LIMIT — LONG masks for the pairs whose N(prev) is too long for the LDS staging, the hub -> hub pairs whose
+  //  located chunks otherwise probe prev's bitmap once per candidate: half of config 3's memory requests; the ratio rule stays with the short rows)
+  if (dv <= P.cm_max && b.csh >= 6 && (du > P.cm_min_du || (dv <= EB_CM_LIMIT && du > 32 && (int64_t)dv <= (int64_t)P.cm_ratio * du))) g.cmask = true;
   else if (P.fine_cap > 0 && du > P.fine_min_du && P.fine_sh >= 6) {
     const BinGeom f = bin_geometry(dv, P.fine_sh, P.fine_cap);
     if (f.csh < b.csh) { g.csh = f.csh; g.n_bins = f.n_bins; }
@@ -1025,7 +1028,6 @@ __host__ __device__ inline EbLayout eb_layout(bool f32, int32_t n_bins, bool cma
   return L;
 }
 constexpr int32_t EB_FINE_CAP_LIMIT = 32768;     // chunks of a table at most (the build keeps one f64 per chunk and wave in an HBM scratch beyond BIN_CAP)
-constexpr int32_t EB_CM_LIMIT = 16384;         // the build keeps the mask of one pair in 2 KB of the wave's LDS
 __host__ __device__ inline BinGeom bin_geometry(int32_t deg, int min_sh, int cap) {
   // smallest csh >= min_sh with ceil(deg / 2^csh) <= cap, i.e. cap * 2^csh >= deg, in closed form (the walk computes this per table step
   // on the scalar unit: profiles/r04_valu_issue.md).  With c0 = bit_length(deg - 1) - bit_length(cap): no c < c0 can do
@@ -1065,7 +1067,7 @@ template <int PF = 1, int P1K = 2, bool GB = false, int HC = HCHUNK>
 __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias &b, uint32_t *lds, int tune,
                                    const BinGeom geo, Member &tm, unsigned long long &alg_bytes, unsigned &strat_used,
                                    uint32_t *mbits = nullptr /* edge_tables.hip: LDS bitmap over curr's positions, bit k = candidate k is in N(prev) */,
-                                   double *gbins = nullptr) {
+                                   double *gbins = nullptr, bool mbits_in_hbm = false /* long masks: mbits points into the pair's table block */) {
   const int32_t deg = uni(rc.deg);                    // (one wave, one pair: scalar state — wave_primitives.h:uni)
   const int lane = lane_id();
   double *bins = GB ? gbins : reinterpret_cast<double *>(lds);
@@ -1076,7 +1078,7 @@ __device__ inline void binned_fill(const GraphView &g, const Row &rc, const Bias
   const int64_t roff = uni(rc.off);
   for (int t = lane; t < n_bins; t += 64) bins[t] = 0.0;
   if (mbits) for (int t = lane; t < ((deg + 31) >> 5); t += 64) mbits[t] = 0u;
-  if (GB) __threadfence();                            // the zeros reach L2 before the first atomic does
+  if (GB || mbits_in_hbm) __threadfence();            // the zeros reach L2 before the first atomic does
   __builtin_amdgcn_wave_barrier();
   const Ent *row = g.ent + roff;
   const uint32_t *cs = g.sids + roff, *cp = g.sperm + roff;

@@ -2407,7 +2407,7 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
     if (a.complete != b.complete) return a.complete;
     if (a.cap != b.cap) return a.cap > b.cap;
     if (a.min_sh != b.min_sh) return a.min_sh < b.min_sh;
-    return a.cm > b.cm;          // (the finer tables of the unmasked pairs and the mask ratio are refinements: not worth the hash — config 3: ratio 16
+    return std::min(a.cm, 16384) > std::min(b.cm, 16384);          // (long masks, the finer tables of the unmasked pairs and the mask ratio are refinements: not worth the hash — config 3: ratio 16
                                  //  without the hash 771 ms per iteration, ratio 4 with it 711 ms, r04 s112)
   };
   // what the walk itself allocates after the tables: one call's paths and lengths (+ hand-over lists, chain scratch, the build's HBM-scratch bins)
@@ -2446,6 +2446,10 @@ void prepare_tables(srw_handle *h, const srw_walk_params &P) {
         const size_t n = set_size(t.cap, sh, 0, 0);
         if (fits(n, (size_t)40 << 30)) { t.min_sh = sh; t.need = n; break; }
       }
+    // chunk masks: every row up to 16 384 candidates (4 096 if memory is short).  LONG masks (round 6: rows beyond 16 384 candidates for the
+    // pairs with a long N(prev) — the hub -> hub pairs whose located chunks probe prev's bitmap once per candidate) are built when asked for
+    // (SRW_EB_CM_MAX > 16 384) but never planned: at config 3 they need +100 GB up to 32 768 candidates (no change in the iteration: 588 ms),
+    // +150 GB up to 131 072, +184 GB for every row — the probes come from the longest rows (profiles/r06_long_masks.md)
     if (!getenv("SRW_EB_CM_MAX"))
       for (int cm : {16384, 4096}) {
         const size_t n = set_size(t.cap, t.min_sh, cm, 0);

@@ -233,6 +233,44 @@ def test_plan_walks_steers_the_tables_not_the_paths():
             e.plan_walks(-1)
 
 
+def test_long_chunk_masks_on_hub_rows(oracle, monkeypatch):
+    """Round 6: pairs (prev -> curr) into rows of MORE than 16 384 candidates whose N(prev) is too long for the LDS staging get their membership
+    mask too — the builder ORs the bits straight into the pair's table block (sampling.h:eb_pair_geometry, edge_tables.hip:k_eb_build).  Three
+    hubs of 40 000 / 70 000 / 100 000 leaves sharing many of them, joined pairwise; against the oracle, with the long masks (SRW_EB_CM_MAX: the planner
+    never takes them by itself — they do not fit where they would matter, profiles/r06_long_masks.md) and without."""
+    rng = np.random.default_rng(5)
+    n_leaf = 120000
+    leaves = np.arange(8, 8 + n_leaf, dtype=np.int32)
+    s, d = [], []
+    for hub, k in ((0, 40000), (1, 70000), (2, 100000)):
+        s.append(np.full(k, hub, np.int32)); d.append(rng.choice(leaves, k, replace=False).astype(np.int32))
+    s.append(np.array([0, 1, 2, 0, 1], np.int32)); d.append(np.array([1, 2, 0, 2, 2], np.int32))      # hub <-> hub edges (one doubled)
+    a = rng.integers(8, 8 + n_leaf, 60000).astype(np.int32); b = rng.integers(8, 8 + n_leaf, 60000).astype(np.int32)
+    s.append(a); d.append(b)
+    s = np.concatenate(s); d = np.concatenate(d)
+    w = (1 + rng.integers(0, 8, len(s))).astype(np.float32)
+    g = oracle.Graph.from_coo(s, d, w, directed=False)
+    res = {}
+    for long_masks in (True, False):
+        if long_masks: monkeypatch.setenv("SRW_EB_CM_MAX", str(1 << 30))
+        with pkg().Engine(device=0) as e:
+            e.load_coo(s, d, w, directed=False)
+            verts = e.vertices()
+            src = np.unique(np.concatenate([[0, 1, 2], rng.choice(verts, 4000, replace=False)])).astype(np.int32)
+            idx = np.searchsorted(verts, src)
+            for p, q in ((0.25, 4.0), (2.0, 0.5)):
+                rp, rl, _ = g.walk(sources=src, p=p, q=q, walk_length=16, seed=41, threads=8)
+                for env in ({}, {"SRW_TABLE_LANES": "-1"}, {"SRW_TABLE_LANES": "2", "SRW_LANE_CSH": "8"}):
+                    for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+                    paths, lens, st = e.walk(p=p, q=q, walk_length=16, seed=41)
+                    for k_ in env: monkeypatch.delenv(k_)
+                    assert np.array_equal(lens[idx], rl) and np.array_equal(paths[idx], rp), (long_masks, p, q, env)
+                    assert st["strategy_steps"]["edge_table"] > 0, st
+                res[(long_masks, p)] = st["edge_table_bytes"]
+        if long_masks: monkeypatch.delenv("SRW_EB_CM_MAX")
+    assert res[(True, 0.25)] > res[(False, 0.25)]          # the hub -> hub pairs' masks are there
+
+
 def test_three_level_table_on_a_long_row(oracle, monkeypatch):
     """A row of 300 000 candidates with chunks of 64: 4 688 chunks, a three-level tree (4 688 -> 74 -> 2), built through the HBM-scratch
     bins; against the oracle."""

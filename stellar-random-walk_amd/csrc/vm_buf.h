@@ -90,6 +90,8 @@ struct VmBuf {
     // every chunk is a whole CHUNK, the last one included (up to 4 GiB of slack): hipMemSetAccess on a second mapping of ANOTHER size inside
     // one reservation fails with "invalid argument" on this stack, erratically (scratch probe, round 5: 6 MiB / 1 GiB / 3.6 GB behind a
     // 4 GiB chunk failed, 4 GiB behind 4 GiB never did)
+    // (the round-up is not in the planners' byte counts — their margins are: prepare_tables / prepare_shard_tables keep 8-40 GB
+    //  beyond the tables' own bytes free, CHUNK is 4 GiB)
     const size_t total = (bytes + CHUNK - 1) / CHUNK * CHUNK;
     void *va = nullptr;
     if (hipMemAddressReserve(&va, total, (size_t)2 << 20, nullptr, 0) != hipSuccess || !va) { (void)hipGetLastError(); alloc(count); return; }
